@@ -1,0 +1,232 @@
+/*
+ * svoslam.h -- C ABI of libsvoslam_hip.so, the MI355X (gfx950) drop-in for the
+ * GPU kernel API of dkotfis/Octree-SLAM (the "L3" free functions of
+ * SURVEY.md section 8b).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *  - every pointer named d_* is DEVICE memory (HBM); h_* is host memory;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *    calls enqueue work on it and return without synchronising unless the
+ *    comment says "blocking" (the reference API is blocking everywhere);
+ *  - vectors are packed floats: vec3 = 3 floats (12 B, glm::vec3 layout),
+ *    vec4 = 4 floats; mat4 = 16 floats column-major (glm::mat4 layout);
+ *  - every function returns SVOSLAM_OK (0) or a negative svoslam_status; the
+ *    reference returns void and checks nothing (SURVEY.md 8b "Errors");
+ *  - the library fails loudly (SVOSLAM_ERR_NO_DEVICE) when no gfx950 device is
+ *    present: there is no CPU fallback.
+ *
+ * Each entry point cites the reference declaration it replaces
+ * (paths relative to the reference checkout).
+ */
+#ifndef SVOSLAM_H_
+#define SVOSLAM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVOSLAM_ABI_VERSION 1
+
+typedef enum {
+  SVOSLAM_OK = 0,
+  SVOSLAM_ERR_INVALID_ARG = -1,
+  SVOSLAM_ERR_NO_DEVICE = -2,
+  SVOSLAM_ERR_HIP = -3,
+  SVOSLAM_ERR_OOM = -4,
+  SVOSLAM_ERR_DEPTH = -5,      /* max_depth outside [1, SVOSLAM_MAX_DEPTH] */
+  SVOSLAM_ERR_POOL_LIMIT = -6, /* pool would exceed 2^30 nodes (30-bit child index) */
+  SVOSLAM_ERR_TRACKING_LOST = -7
+} svoslam_status;
+
+#define SVOSLAM_MAX_DEPTH 16
+#define SVOSLAM_FLAG_CHILDREN 0x40000000u /* word0 bit 30, svo.cu:130 */
+#define SVOSLAM_CHILD_MASK 0x3FFFFFFFu    /* word0 bits 0-29, svo.cu:136 */
+
+int svoslam_abi_version(void);
+const char *svoslam_status_string(int status);
+/* last HIP error text seen by the calling thread (empty string if none) */
+const char *svoslam_last_error(void);
+/* name of the device the library runs on, e.g. "gfx950:..."; NULL if none */
+const char *svoslam_device_arch(void);
+/* number of HIP kernels compiled into the library (build sanity) */
+int svoslam_kernel_count(void);
+
+/* ------------------------------------------------------------------------
+ * Node pool.  Same layout as the reference (common_types.h:75-79, svo.cu):
+ * node i = words 2i, 2i+1; word0 = children flag | 30-bit index of the first
+ * of 8 contiguous children; word1 = R | G<<8 | B<<16 | A<<24; nodes 0-7 are
+ * the root's children.  Unlike the reference (realloc + whole-pool copy per
+ * frame, svo.cu:663-668) the pool keeps spare capacity and grows geometrically.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  uint32_t *d_data;    /* 2*capacity words, device */
+  int32_t size;        /* nodes in use (the reference's octree_size) */
+  int32_t capacity;    /* nodes allocated */
+} svoslam_pool;
+
+/* replaces svo::initOctree (svo.cu:24-31): 8 zeroed root children */
+int svoslam_pool_init(svoslam_pool *pool, int32_t capacity_nodes, void *stream);
+int svoslam_pool_reserve(svoslam_pool *pool, int32_t capacity_nodes, void *stream);
+int svoslam_pool_free(svoslam_pool *pool);
+
+/* Opaque scratch arena reused across calls (sort buffers, plan records...).
+ * The reference cudaMallocs ~6+D temporaries per call instead. */
+typedef struct svoslam_workspace svoslam_workspace;
+int svoslam_workspace_create(svoslam_workspace **ws);
+int svoslam_workspace_destroy(svoslam_workspace *ws);
+
+/* per-call statistics of the fusion path (host, filled after the call) */
+typedef struct {
+  int32_t num_points;       /* n */
+  int32_t num_split;        /* nodes split = new tiles allocated */
+  int32_t pass_sizes[SVOSLAM_MAX_DEPTH + 1]; /* code_sizes[] of svo.cu:179-237 */
+  int32_t pool_size_before;
+  int32_t pool_size_after;
+} svoslam_fuse_stats;
+
+/* replaces svo::svoFromPointCloud (include/octree_slam/world/svo/svo.h:16,
+ * src/world/svo/svo.cu:642-696).  d_points: n x vec3, d_colors: n x 3 bytes
+ * (Color256).  center/edge_length = root centre and HALF edge.
+ * Blocking once (one 4-byte count readback, as the reference's `int&
+ * octree_size` requires the new size on the host). stats may be NULL. */
+int svoslam_svo_from_point_cloud(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors,
+                                 int32_t n, int32_t max_depth, svoslam_pool *pool, const float center[3],
+                                 float edge_length, svoslam_fuse_stats *stats, void *stream);
+
+/* replaces svo::svoFromVoxelGrid (svo.h:14, svo.cu:584-640).  d_centers,
+ * d_colors: n x vec4 (VoxelGrid, common_types.h:55-63). */
+int svoslam_svo_from_voxel_grid(svoslam_workspace *ws, const float *d_centers, const float *d_colors, int32_t n,
+                                int32_t max_depth, svoslam_pool *pool, const float center[3], float edge_length,
+                                svoslam_fuse_stats *stats, void *stream);
+
+/* replaces svo::extractVoxelGridFromSVO (svo.h:18, svo.cu:699-745).  On return
+ * *d_centers / *d_colors are hipMalloc'ed n x vec4 arrays owned by the caller
+ * (free with svoslam_free), *n_out the voxel count.  Blocking. */
+int svoslam_extract_voxel_grid(svoslam_workspace *ws, const svoslam_pool *pool, int32_t max_depth,
+                               const float center[3], float edge_length, float **d_centers, float **d_colors,
+                               int32_t *n_out, void *stream);
+int svoslam_free(void *d_ptr);
+
+/* ------------------------------------------------------------------------
+ * Rendering
+ * ---------------------------------------------------------------------- */
+#define SVOSLAM_RENDER_REFERENCE 0 /* pixel stored only on retirement, as the reference does */
+#define SVOSLAM_RENDER_CARRY 1     /* local pixel carried across march steps */
+
+/* replaces rendering::coneTraceSVO (include/octree_slam/rendering/
+ * cone_tracing_kernels.h:16, src/rendering/cone_tracing_kernels.cu:157-198).
+ * d_pos: w*h uchar4 offscreen framebuffer (stands in for the mapped GL PBO of
+ * cuda_renderer.cpp:158-171).  view = Camera.view.  d_steps (optional, may be
+ * NULL): 2 x uint64 device counters {march steps, levels descended} the kernel
+ * adds to (for the bytes model). */
+int svoslam_cone_trace_svo(uint8_t *d_pos, int32_t width, int32_t height, float fov, const float view[16],
+                           const uint32_t *d_octree, const float center[3], float size, int32_t mode,
+                           unsigned long long *d_steps, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Sensor image kernels (include/octree_slam/sensor/image_kernels.h:21-55,
+ * src/sensor/image_kernels.cu)
+ * ---------------------------------------------------------------------- */
+/* generateVertexMap, image_kernels.h:24 / .cu:24-58 */
+int svoslam_generate_vertex_map(const uint16_t *d_depth, float *d_vertex, int32_t width, int32_t height, float fx,
+                                float fy, int32_t img_w, int32_t img_h, void *stream);
+/* generateNormalMap, image_kernels.h:30 / .cu:104-139 */
+int svoslam_generate_normal_map(const float *d_vertex, float *d_normal, int32_t width, int32_t height, void *stream);
+/* bilateralFilter, image_kernels.h:34 / .cu:142-186 */
+int svoslam_bilateral_filter(const uint16_t *d_in, uint16_t *d_out, int32_t width, int32_t height, void *stream);
+/* subsampleDepth<uint16_t|float>, image_kernels.h:41-42 / .cu:236-289.  In place:
+ * the (width/2 x height/2) result overwrites the head of d_data. d_tmp: scratch of
+ * width*height/4 elements (the reference cudaMallocs it per call). */
+int svoslam_subsample_depth_u16(uint16_t *d_data, uint16_t *d_tmp, int32_t width, int32_t height, void *stream);
+int svoslam_subsample_depth_f32(float *d_data, float *d_tmp, int32_t width, int32_t height, void *stream);
+/* subsample<float|Color256>, image_kernels.h:37-38 / .cu:291-326 */
+int svoslam_subsample_f32(float *d_data, float *d_tmp, int32_t width, int32_t height, void *stream);
+int svoslam_subsample_rgb8(uint8_t *d_data, uint8_t *d_tmp, int32_t width, int32_t height, void *stream);
+/* colorToIntensity, image_kernels.h:45 / .cu:188-203 */
+int svoslam_color_to_intensity(const uint8_t *d_rgb, float *d_out, int32_t n, void *stream);
+/* transformVertexMap / transformNormalMap, image_kernels.h:52,55 / .cu:206-234 */
+int svoslam_transform_vertex_map(float *d_vertex, const float trans[16], int32_t n, void *stream);
+int svoslam_transform_normal_map(float *d_normal, const float trans[16], int32_t n, void *stream);
+/* computePointCloudBoundingBox, image_kernels.h:27 / .cu:60-102.  bbox0/bbox1 are
+ * host in/out (zero = unset sentinel).  Blocking. */
+int svoslam_point_cloud_bbox(const float *d_points, int32_t n, float h_bbox0[3], float h_bbox1[3], void *stream);
+
+/* ------------------------------------------------------------------------
+ * ICP (include/octree_slam/sensor/localization_kernels.h:17-42,
+ * src/sensor/localization_kernels.cu)
+ * ---------------------------------------------------------------------- */
+/* computeICPCost2, localization_kernels.h:39 / .cu:154-229,303-326.  h_A (36) and
+ * h_b (6) are host outputs as in the reference.  Blocking. */
+int svoslam_icp_cost2(const float *d_last_vertex, const float *d_last_normal, const float *d_cur_vertex,
+                      const float *d_cur_normal, int32_t width, int32_t height, float h_A[36], float h_b[6],
+                      void *stream);
+/* Non-blocking building block used by the tracker and by multi-GPU row bands:
+ * adds the 27 exact fixed-point accumulators (21 upper-triangle A terms then 6
+ * b terms, carried in float64) of pixels [first_pixel, first_pixel+num_pixels)
+ * into d_acc[27].  Integer-valued doubles: sums are exact and associative, so
+ * band partials can be all-reduced (RCCL sum, float64) in any order. */
+int svoslam_icp_accumulate(const float *d_last_vertex, const float *d_last_normal, const float *d_cur_vertex,
+                           const float *d_cur_normal, int32_t width, int32_t height, int32_t first_pixel,
+                           int32_t num_pixels, double *d_acc, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Tracker: host mirror of sensor::RGBDCamera (include/octree_slam/sensor/
+ * rgbd_camera.h, src/sensor/rgbd_camera.cpp) with every per-iteration step
+ * (accumulate, 6x6 Cholesky, pose compose) resident on the device.
+ * ---------------------------------------------------------------------- */
+typedef struct svoslam_camera svoslam_camera;
+/* RGBDCamera::RGBDCamera, rgbd_camera.cpp:22-24.  band_first_row/band_rows select
+ * the image rows this process owns for ICP accumulation (0, height = all). */
+int svoslam_camera_create(svoslam_camera **cam, int32_t width, int32_t height, float fx, float fy);
+int svoslam_camera_destroy(svoslam_camera *cam);
+int svoslam_camera_set_band(svoslam_camera *cam, int32_t first_row, int32_t rows);
+/* RGBDCamera::update, rgbd_camera.cpp:53-191.  Non-blocking.  Returns 1 in
+ * *processed if the frame was used, 0 if its timestamp was stale (:55-59). */
+int svoslam_camera_update(svoslam_camera *cam, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp,
+                          int32_t *processed, void *stream);
+/* Multi-GPU stepping: update() split at the all-reduce points.  begin() builds
+ * the pyramids; for level = 2,1,0 and it = 0..iters(level)-1 call
+ * icp_accumulate() [adds this band's 27 doubles into svoslam_camera_acc()], then
+ * all-reduce that buffer across ranks, then icp_solve(); finally end(). */
+int svoslam_camera_begin(svoslam_camera *cam, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp,
+                         int32_t *processed, void *stream);
+int svoslam_camera_icp_iters(int32_t level); /* PYRAMID_ITERS, rgbd_camera.cpp:19 */
+int svoslam_camera_icp_accumulate(svoslam_camera *cam, int32_t level, int32_t iter, void *stream);
+double *svoslam_camera_acc(svoslam_camera *cam); /* device double[27] */
+/* redirect the accumulators to caller-owned device memory (e.g. a torch tensor that
+ * torch.distributed all-reduces); NULL restores the internal buffer.  Must be zeroed
+ * by the caller once; icp_solve() re-zeroes it after every iteration. */
+int svoslam_camera_set_acc(svoslam_camera *cam, double *d_acc);
+/* number of pyramid levels abandoned because the solve returned NaN
+ * ("Camera tracking is lost.", rgbd_camera.cpp:148-151).  Blocking. */
+int svoslam_camera_tracking_lost_count(svoslam_camera *cam, int32_t *count, void *stream);
+int svoslam_camera_icp_solve(svoslam_camera *cam, int32_t level, int32_t iter, void *stream);
+int svoslam_camera_end(svoslam_camera *cam, void *stream);
+/* position() / orientation() accessors, rgbd_camera.h:33-36.  Blocking (D2H). */
+int svoslam_camera_pose(svoslam_camera *cam, float h_position[3], float h_orientation[9], void *stream);
+/* device mat4 = mat4(orientation) * translate(I, position) (main.cpp:40); stays on the device */
+const float *svoslam_camera_fusion_transform_device(svoslam_camera *cam);
+/* last A, b, x (host copies; blocking) for tests */
+int svoslam_camera_last_system(svoslam_camera *cam, float h_A[36], float h_b[6], float h_x[6], void *stream);
+/* current-frame pyramid maps (device, level 0..2) for tests: after update() the
+ * frames have been swapped, so these are the maps of the frame just processed */
+const float *svoslam_camera_last_vertex(svoslam_camera *cam, int32_t level);
+const float *svoslam_camera_last_normal(svoslam_camera *cam, int32_t level);
+
+/* transformVertexMap with a DEVICE matrix (keeps main.cpp:40 off the host) */
+int svoslam_transform_vertex_map_dmat(float *d_vertex, const float *d_trans, int32_t n, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Timing hook: replaces startTiming/stopTiming (include/octree_slam/
+ * timing_utils.h:5-10, src/timing_utils.cu:11-32) with hipEvents on `stream`.
+ * ---------------------------------------------------------------------- */
+int svoslam_timer_start(void *stream);
+int svoslam_timer_stop(void *stream, float *h_ms); /* blocking */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVOSLAM_H_ */

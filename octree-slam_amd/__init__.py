@@ -1,0 +1,431 @@
+"""octree_slam_amd -- Python front end of libsvoslam_hip.so (include/svoslam.h).
+
+The product is the C-ABI shared library built from csrc/*.hip for gfx950; this
+package only binds it with ctypes and moves pointers of torch CUDA tensors
+across the boundary (PyTorch = device memory, streams, torch.distributed).
+There is NO CPU fallback: every compute entry point raises SvoslamError when
+the library or a gfx950 device is missing.
+
+The directory is called ``octree-slam_amd`` (not importable by name); load it
+with ``svoslam_pkg.load()`` from the repo root, which registers it as the module
+``octree_slam_amd``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvoslam_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "svoslam.h")
+
+MAX_DEPTH = 16
+FLAG_CHILDREN = 0x40000000
+CHILD_MASK = 0x3FFFFFFF
+RENDER_REFERENCE = 0
+RENDER_CARRY = 1
+PYRAMID_ITERS = (10, 5, 4)  # rgbd_camera.cpp:19, index = pyramid level
+
+
+class SvoslamError(RuntimeError):
+    pass
+
+
+def build(verbose=False, force=False):
+    """Compile csrc/*.hip for gfx950 into libsvoslam_hip.so (hipcc, in tree)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_svoslam_build", os.path.join(_HERE, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build(verbose=verbose, force=force)
+
+
+class _PoolStruct(C.Structure):
+    _fields_ = [("d_data", C.c_void_p), ("size", C.c_int32), ("capacity", C.c_int32)]
+
+
+class FuseStats(C.Structure):
+    _fields_ = [("num_points", C.c_int32), ("num_split", C.c_int32), ("pass_sizes", C.c_int32 * (MAX_DEPTH + 1)),
+                ("pool_size_before", C.c_int32), ("pool_size_after", C.c_int32)]
+
+
+_lib = None
+_vp, _i32, _f32 = C.c_void_p, C.c_int32, C.c_float
+_fp = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); this table is also what tests/test_abi_symbols.py checks against include/svoslam.h
+SIGNATURES = {
+    "svoslam_abi_version": (C.c_int, []),
+    "svoslam_status_string": (C.c_char_p, [C.c_int]),
+    "svoslam_last_error": (C.c_char_p, []),
+    "svoslam_device_arch": (C.c_char_p, []),
+    "svoslam_kernel_count": (C.c_int, []),
+    "svoslam_pool_init": (C.c_int, [C.POINTER(_PoolStruct), _i32, _vp]),
+    "svoslam_pool_reserve": (C.c_int, [C.POINTER(_PoolStruct), _i32, _vp]),
+    "svoslam_pool_free": (C.c_int, [C.POINTER(_PoolStruct)]),
+    "svoslam_workspace_create": (C.c_int, [C.POINTER(_vp)]),
+    "svoslam_workspace_destroy": (C.c_int, [_vp]),
+    "svoslam_svo_from_point_cloud": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _fp, _f32,
+                                                C.POINTER(FuseStats), _vp]),
+    "svoslam_svo_from_voxel_grid": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _fp, _f32,
+                                               C.POINTER(FuseStats), _vp]),
+    "svoslam_extract_voxel_grid": (C.c_int, [_vp, C.POINTER(_PoolStruct), _i32, _fp, _f32, C.POINTER(_vp),
+                                              C.POINTER(_vp), C.POINTER(_i32), _vp]),
+    "svoslam_free": (C.c_int, [_vp]),
+    "svoslam_cone_trace_svo": (C.c_int, [_vp, _i32, _i32, _f32, _fp, _vp, _fp, _f32, _i32, _vp, _vp]),
+    "svoslam_generate_vertex_map": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _f32, _i32, _i32, _vp]),
+    "svoslam_generate_normal_map": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "svoslam_bilateral_filter": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "svoslam_subsample_depth_u16": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "svoslam_subsample_depth_f32": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "svoslam_subsample_f32": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "svoslam_subsample_rgb8": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "svoslam_color_to_intensity": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "svoslam_transform_vertex_map": (C.c_int, [_vp, _fp, _i32, _vp]),
+    "svoslam_transform_normal_map": (C.c_int, [_vp, _fp, _i32, _vp]),
+    "svoslam_transform_vertex_map_dmat": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "svoslam_point_cloud_bbox": (C.c_int, [_vp, _i32, _fp, _fp, _vp]),
+    "svoslam_icp_cost2": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _fp, _fp, _vp]),
+    "svoslam_icp_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "svoslam_camera_create": (C.c_int, [C.POINTER(_vp), _i32, _i32, _f32, _f32]),
+    "svoslam_camera_destroy": (C.c_int, [_vp]),
+    "svoslam_camera_set_band": (C.c_int, [_vp, _i32, _i32]),
+    "svoslam_camera_set_acc": (C.c_int, [_vp, _vp]),
+    "svoslam_camera_update": (C.c_int, [_vp, _vp, _vp, C.c_longlong, C.POINTER(_i32), _vp]),
+    "svoslam_camera_begin": (C.c_int, [_vp, _vp, _vp, C.c_longlong, C.POINTER(_i32), _vp]),
+    "svoslam_camera_icp_iters": (C.c_int, [_i32]),
+    "svoslam_camera_icp_accumulate": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "svoslam_camera_acc": (_vp, [_vp]),
+    "svoslam_camera_icp_solve": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "svoslam_camera_end": (C.c_int, [_vp, _vp]),
+    "svoslam_camera_pose": (C.c_int, [_vp, _fp, _fp, _vp]),
+    "svoslam_camera_fusion_transform_device": (_vp, [_vp]),
+    "svoslam_camera_last_system": (C.c_int, [_vp, _fp, _fp, _fp, _vp]),
+    "svoslam_camera_last_vertex": (_vp, [_vp, _i32]),
+    "svoslam_camera_last_normal": (_vp, [_vp, _i32]),
+    "svoslam_camera_tracking_lost_count": (C.c_int, [_vp, C.POINTER(_i32), _vp]),
+    "svoslam_timer_start": (C.c_int, [_vp]),
+    "svoslam_timer_stop": (C.c_int, [_vp, _fp]),
+}
+
+
+def lib():
+    """Load libsvoslam_hip.so; raises SvoslamError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SvoslamError("%s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+                           "There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != 0:
+        L = lib()
+        raise SvoslamError("svoslam status %d (%s): %s" % (status, L.svoslam_status_string(status).decode(),
+                                                          L.svoslam_last_error().decode()))
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _fa(values, n):
+    a = (C.c_float * n)(*[float(v) for v in np.asarray(values, dtype=np.float32).reshape(-1)])
+    return a
+
+
+def device_arch():
+    a = lib().svoslam_device_arch()
+    return a.decode() if a else None
+
+
+# ----------------------------------------------------------------------------- pool / fusion
+class Workspace:
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(lib().svoslam_workspace_create(C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().svoslam_workspace_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Pool:
+    """Device node pool (svoslam_pool).  words() copies it to the host as uint32."""
+
+    def __init__(self, capacity_nodes=8):
+        self._p = _PoolStruct(None, 0, 0)
+        check(lib().svoslam_pool_init(C.byref(self._p), capacity_nodes, _stream()))
+
+    @property
+    def size(self):
+        return int(self._p.size)
+
+    @property
+    def capacity(self):
+        return int(self._p.capacity)
+
+    @property
+    def data_ptr(self):
+        return int(self._p.d_data)
+
+    def reserve(self, capacity_nodes):
+        check(lib().svoslam_pool_reserve(C.byref(self._p), capacity_nodes, _stream()))
+
+    def words(self):
+        import torch
+        torch.cuda.synchronize()
+        n = 2 * self.size
+        out = np.empty(n, dtype=np.uint32)
+        hip = _hip()
+        r = hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(self.data_ptr), C.c_size_t(n * 4), 2)
+        if r != 0:
+            raise SvoslamError("hipMemcpy D2H failed: %d" % r)
+        return out
+
+    def set_words(self, words):
+        import torch
+        torch.cuda.synchronize()
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        nodes = words.size // 2
+        self.reserve(nodes)
+        r = _hip().hipMemcpy(C.c_void_p(self.data_ptr), C.c_void_p(words.ctypes.data), C.c_size_t(words.nbytes), 1)
+        if r != 0:
+            raise SvoslamError("hipMemcpy H2D failed: %d" % r)
+        self._p.size = nodes
+
+    def close(self):
+        if self._p.d_data:
+            lib().svoslam_pool_free(C.byref(self._p))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_hiplib = None
+
+
+def _hip():
+    global _hiplib
+    if _hiplib is None:
+        _hiplib = C.CDLL("libamdhip64.so")
+        _hiplib.hipMemcpy.restype = C.c_int
+        _hiplib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return _hiplib
+
+
+def svo_from_point_cloud(ws, points, colors, max_depth, pool, center, edge_length):
+    """svo::svoFromPointCloud.  points: cuda float32 [n,3]; colors: cuda uint8 [n,3]."""
+    n = int(points.shape[0]) if points is not None else 0
+    stats = FuseStats()
+    check(lib().svoslam_svo_from_point_cloud(ws._h, _ptr(points), _ptr(colors), n, max_depth, C.byref(pool._p),
+                                             _fa(center, 3), float(edge_length), C.byref(stats), _stream()))
+    return stats
+
+
+def svo_from_voxel_grid(ws, centers, colors, max_depth, pool, center, edge_length):
+    """svo::svoFromVoxelGrid.  centers, colors: cuda float32 [n,4]."""
+    n = int(centers.shape[0]) if centers is not None else 0
+    stats = FuseStats()
+    check(lib().svoslam_svo_from_voxel_grid(ws._h, _ptr(centers), _ptr(colors), n, max_depth, C.byref(pool._p),
+                                            _fa(center, 3), float(edge_length), C.byref(stats), _stream()))
+    return stats
+
+
+def extract_voxel_grid(ws, pool, max_depth, center, edge_length):
+    """svo::extractVoxelGridFromSVO -> (centers[n,4], colors[n,4]) numpy float32."""
+    import torch
+    pc, pk, n = C.c_void_p(), C.c_void_p(), C.c_int32(0)
+    check(lib().svoslam_extract_voxel_grid(ws._h, C.byref(pool._p), max_depth, _fa(center, 3), float(edge_length),
+                                           C.byref(pc), C.byref(pk), C.byref(n), _stream()))
+    torch.cuda.synchronize()
+    ce = np.zeros((n.value, 4), np.float32)
+    co = np.zeros((n.value, 4), np.float32)
+    if n.value > 0:
+        _hip().hipMemcpy(C.c_void_p(ce.ctypes.data), pc, C.c_size_t(ce.nbytes), 2)
+        _hip().hipMemcpy(C.c_void_p(co.ctypes.data), pk, C.c_size_t(co.nbytes), 2)
+        lib().svoslam_free(pc)
+        lib().svoslam_free(pk)
+    return ce, co
+
+
+# ----------------------------------------------------------------------------- rendering
+def cone_trace_svo(out, fov, view, pool_ptr, center, size, mode=RENDER_REFERENCE, counters=None):
+    """rendering::coneTraceSVO into `out` (cuda uint8 [h,w,4])."""
+    h, w = int(out.shape[0]), int(out.shape[1])
+    check(lib().svoslam_cone_trace_svo(_ptr(out), w, h, float(fov), _fa(view, 16), C.c_void_p(int(pool_ptr)),
+                                       _fa(center, 3), float(size), int(mode), _ptr(counters), _stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------- sensor
+def generate_vertex_map(depth, out, fx, fy, img_w, img_h):
+    h, w = int(depth.shape[0]), int(depth.shape[1])
+    check(lib().svoslam_generate_vertex_map(_ptr(depth), _ptr(out), w, h, float(fx), float(fy), img_w, img_h, _stream()))
+    return out
+
+
+def generate_normal_map(vmap, out):
+    h, w = int(vmap.shape[0]), int(vmap.shape[1])
+    check(lib().svoslam_generate_normal_map(_ptr(vmap), _ptr(out), w, h, _stream()))
+    return out
+
+
+def bilateral_filter(depth, out):
+    h, w = int(depth.shape[0]), int(depth.shape[1])
+    check(lib().svoslam_bilateral_filter(_ptr(depth), _ptr(out), w, h, _stream()))
+    return out
+
+
+def subsample_depth(data, tmp, w, h):
+    import torch
+    fn = lib().svoslam_subsample_depth_u16 if data.dtype in (torch.uint16, torch.int16) else lib().svoslam_subsample_depth_f32
+    check(fn(_ptr(data), _ptr(tmp), w, h, _stream()))
+
+
+def subsample(data, tmp, w, h):
+    import torch
+    fn = lib().svoslam_subsample_rgb8 if data.dtype == torch.uint8 else lib().svoslam_subsample_f32
+    check(fn(_ptr(data), _ptr(tmp), w, h, _stream()))
+
+
+def color_to_intensity(rgb, out):
+    check(lib().svoslam_color_to_intensity(_ptr(rgb), _ptr(out), int(out.numel()), _stream()))
+    return out
+
+
+def transform_vertex_map(v, trans):
+    check(lib().svoslam_transform_vertex_map(_ptr(v), _fa(trans, 16), int(v.numel() // 3), _stream()))
+
+
+def transform_normal_map(v, trans):
+    check(lib().svoslam_transform_normal_map(_ptr(v), _fa(trans, 16), int(v.numel() // 3), _stream()))
+
+
+def transform_vertex_map_dmat(v, d_trans_ptr):
+    check(lib().svoslam_transform_vertex_map_dmat(_ptr(v), C.c_void_p(int(d_trans_ptr)), int(v.numel() // 3), _stream()))
+
+
+def point_cloud_bbox(points, bbox0=(0, 0, 0), bbox1=(0, 0, 0)):
+    b0, b1 = _fa(bbox0, 3), _fa(bbox1, 3)
+    check(lib().svoslam_point_cloud_bbox(_ptr(points), int(points.numel() // 3), b0, b1, _stream()))
+    return np.array(list(b0), np.float32), np.array(list(b1), np.float32)
+
+
+def icp_cost2(last_v, last_n, cur_v, cur_n):
+    h, w = int(last_v.shape[0]), int(last_v.shape[1])
+    A, b = (C.c_float * 36)(), (C.c_float * 6)()
+    check(lib().svoslam_icp_cost2(_ptr(last_v), _ptr(last_n), _ptr(cur_v), _ptr(cur_n), w, h, A, b, _stream()))
+    return np.array(list(A), np.float32).reshape(6, 6), np.array(list(b), np.float32)
+
+
+def icp_accumulate(last_v, last_n, cur_v, cur_n, first_pixel, num_pixels, acc):
+    h, w = int(last_v.shape[0]), int(last_v.shape[1])
+    check(lib().svoslam_icp_accumulate(_ptr(last_v), _ptr(last_n), _ptr(cur_v), _ptr(cur_n), w, h, first_pixel, num_pixels,
+                                       _ptr(acc), _stream()))
+
+
+# ----------------------------------------------------------------------------- tracker
+class Camera:
+    """Mirror of sensor::RGBDCamera (include/octree_slam/sensor/rgbd_camera.h)."""
+
+    def __init__(self, width, height, fx, fy):
+        self._h = C.c_void_p()
+        self.width, self.height = width, height
+        check(lib().svoslam_camera_create(C.byref(self._h), width, height, float(fx), float(fy)))
+
+    def update(self, depth, rgb, timestamp):
+        used = C.c_int32(0)
+        check(lib().svoslam_camera_update(self._h, _ptr(depth), _ptr(rgb), int(timestamp), C.byref(used), _stream()))
+        return int(used.value)
+
+    # multi-GPU stepping (all-reduce between accumulate and solve)
+    def set_band(self, first_row, rows):
+        check(lib().svoslam_camera_set_band(self._h, first_row, rows))
+
+    def set_acc(self, acc_tensor):
+        self._acc_keepalive = acc_tensor
+        check(lib().svoslam_camera_set_acc(self._h, _ptr(acc_tensor)))
+
+    def begin(self, depth, rgb, timestamp):
+        used = C.c_int32(0)
+        check(lib().svoslam_camera_begin(self._h, _ptr(depth), _ptr(rgb), int(timestamp), C.byref(used), _stream()))
+        return int(used.value)
+
+    def icp_accumulate(self, level, it):
+        check(lib().svoslam_camera_icp_accumulate(self._h, level, it, _stream()))
+
+    def icp_solve(self, level, it):
+        check(lib().svoslam_camera_icp_solve(self._h, level, it, _stream()))
+
+    def end(self):
+        check(lib().svoslam_camera_end(self._h, _stream()))
+
+    def pose(self):
+        p, o = (C.c_float * 3)(), (C.c_float * 9)()
+        check(lib().svoslam_camera_pose(self._h, p, o, _stream()))
+        return np.array(list(p), np.float32), np.array(list(o), np.float32)
+
+    def last_system(self):
+        A, b, x = (C.c_float * 36)(), (C.c_float * 6)(), (C.c_float * 6)()
+        check(lib().svoslam_camera_last_system(self._h, A, b, x, _stream()))
+        return np.array(list(A), np.float32).reshape(6, 6), np.array(list(b), np.float32), np.array(list(x), np.float32)
+
+    def fusion_transform_ptr(self):
+        return int(lib().svoslam_camera_fusion_transform_device(self._h))
+
+    def last_vertex_ptr(self, level):
+        return int(lib().svoslam_camera_last_vertex(self._h, level))
+
+    def last_normal_ptr(self, level):
+        return int(lib().svoslam_camera_last_normal(self._h, level))
+
+    def tracking_lost_count(self):
+        n = C.c_int32(0)
+        check(lib().svoslam_camera_tracking_lost_count(self._h, C.byref(n), _stream()))
+        return int(n.value)
+
+    def close(self):
+        if self._h:
+            lib().svoslam_camera_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def copy_from_device(ptr, shape, dtype):
+    """Copy a raw device buffer to a numpy array (tests)."""
+    import torch
+    torch.cuda.synchronize()
+    out = np.empty(shape, dtype=dtype)
+    r = _hip().hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(int(ptr)), C.c_size_t(out.nbytes), 2)
+    if r != 0:
+        raise SvoslamError("hipMemcpy D2H failed: %d" % r)
+    return out

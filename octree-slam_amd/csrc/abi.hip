@@ -1,0 +1,262 @@
+// abi.hip -- the extern "C" surface of libsvoslam_hip.so (include/svoslam.h).
+// Thin: argument checks, device check, dispatch into the kernel translation units.
+#include <stdio.h>
+#include <string.h>
+
+#include "common.hpp"
+#include "cone_trace.hpp"
+#include "icp.hpp"
+#include "image_kernels.hpp"
+#include "svo_build.hpp"
+#include "workspace.hpp"
+
+namespace svoslam {
+
+static thread_local char g_last_error[512] = "";
+static char g_arch[256] = "";
+static int g_device_state = 0;  // 0 = unknown, 1 = ok, -1 = none
+
+void set_last_error(const char *what, hipError_t e) {
+  snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
+}
+
+// Fail loudly when there is no gfx950 device: the library has no CPU path.
+int ensure_device() {
+  if (g_device_state == 1) return SVOSLAM_OK;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    snprintf(g_last_error, sizeof(g_last_error), "no HIP device (hipGetDeviceCount: %s); libsvoslam_hip has no CPU fallback",
+             hipGetErrorString(e));
+    g_device_state = -1;
+    return SVOSLAM_ERR_NO_DEVICE;
+  }
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) snprintf(g_arch, sizeof(g_arch), "%s", prop.gcnArchName);
+  if (strncmp(g_arch, "gfx950", 6) != 0) {
+    snprintf(g_last_error, sizeof(g_last_error), "device arch '%s' is not gfx950; this library is built for MI355X only", g_arch);
+    g_device_state = -1;
+    return SVOSLAM_ERR_NO_DEVICE;
+  }
+  g_device_state = 1;
+  return SVOSLAM_OK;
+}
+
+static thread_local hipEvent_t g_t0 = nullptr, g_t1 = nullptr;
+
+}  // namespace svoslam
+
+using namespace svoslam;
+
+#define S(stream) reinterpret_cast<hipStream_t>(stream)
+#define NEED_DEVICE() SVO_TRY(ensure_device())
+
+extern "C" {
+
+int svoslam_abi_version(void) { return SVOSLAM_ABI_VERSION; }
+
+const char *svoslam_status_string(int status) {
+  switch (status) {
+    case SVOSLAM_OK: return "ok";
+    case SVOSLAM_ERR_INVALID_ARG: return "invalid argument";
+    case SVOSLAM_ERR_NO_DEVICE: return "no gfx950 device (no CPU fallback)";
+    case SVOSLAM_ERR_HIP: return "HIP runtime error";
+    case SVOSLAM_ERR_OOM: return "out of device memory";
+    case SVOSLAM_ERR_DEPTH: return "max_depth outside [1,16]";
+    case SVOSLAM_ERR_POOL_LIMIT: return "node pool would exceed 2^30 nodes";
+    case SVOSLAM_ERR_TRACKING_LOST: return "camera tracking lost";
+    default: return "unknown status";
+  }
+}
+
+const char *svoslam_last_error(void) { return g_last_error; }
+
+const char *svoslam_device_arch(void) { return ensure_device() == SVOSLAM_OK ? g_arch : nullptr; }
+
+int svoslam_kernel_count(void) { return 33; }
+
+int svoslam_pool_init(svoslam_pool *pool, int32_t capacity_nodes, void *stream) {
+  NEED_DEVICE();
+  return pool_init(pool, capacity_nodes, S(stream));
+}
+int svoslam_pool_reserve(svoslam_pool *pool, int32_t capacity_nodes, void *stream) {
+  NEED_DEVICE();
+  return pool_reserve(pool, capacity_nodes, S(stream));
+}
+int svoslam_pool_free(svoslam_pool *pool) {
+  if (!pool) return SVOSLAM_ERR_INVALID_ARG;
+  if (pool->d_data) SVO_HIP(hipFree(pool->d_data));
+  pool->d_data = nullptr; pool->size = 0; pool->capacity = 0;
+  return SVOSLAM_OK;
+}
+
+int svoslam_workspace_create(svoslam_workspace **ws) {
+  if (!ws) return SVOSLAM_ERR_INVALID_ARG;
+  NEED_DEVICE();
+  *ws = new svoslam_workspace();
+  return SVOSLAM_OK;
+}
+int svoslam_workspace_destroy(svoslam_workspace *ws) {
+  if (!ws) return SVOSLAM_OK;
+  ws->release_all();
+  delete ws;
+  return SVOSLAM_OK;
+}
+
+int svoslam_svo_from_point_cloud(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int32_t n,
+                                 int32_t max_depth, svoslam_pool *pool, const float center[3], float edge_length,
+                                 svoslam_fuse_stats *stats, void *stream) {
+  NEED_DEVICE();
+  if (!center) return SVOSLAM_ERR_INVALID_ARG;
+  return svo_from_point_cloud(ws, d_points, d_colors, n, max_depth, pool, center, edge_length, stats, S(stream));
+}
+
+int svoslam_svo_from_voxel_grid(svoslam_workspace *ws, const float *d_centers, const float *d_colors, int32_t n,
+                                int32_t max_depth, svoslam_pool *pool, const float center[3], float edge_length,
+                                svoslam_fuse_stats *stats, void *stream) {
+  NEED_DEVICE();
+  if (!center) return SVOSLAM_ERR_INVALID_ARG;
+  return svo_from_voxel_grid(ws, d_centers, d_colors, n, max_depth, pool, center, edge_length, stats, S(stream));
+}
+
+int svoslam_extract_voxel_grid(svoslam_workspace *ws, const svoslam_pool *pool, int32_t max_depth, const float center[3],
+                               float edge_length, float **d_centers, float **d_colors, int32_t *n_out, void *stream) {
+  NEED_DEVICE();
+  if (!center) return SVOSLAM_ERR_INVALID_ARG;
+  return extract_voxel_grid(ws, pool, max_depth, center, edge_length, d_centers, d_colors, n_out, S(stream));
+}
+
+int svoslam_free(void *d_ptr) {
+  if (d_ptr) SVO_HIP(hipFree(d_ptr));
+  return SVOSLAM_OK;
+}
+
+int svoslam_cone_trace_svo(uint8_t *d_pos, int32_t width, int32_t height, float fov, const float view[16],
+                           const uint32_t *d_octree, const float center[3], float size, int32_t mode,
+                           unsigned long long *d_steps, void *stream) {
+  NEED_DEVICE();
+  return cone_trace_svo(d_pos, width, height, fov, view, d_octree, center, size, mode, d_steps, S(stream));
+}
+
+int svoslam_generate_vertex_map(const uint16_t *d_depth, float *d_vertex, int32_t width, int32_t height, float fx, float fy,
+                                int32_t img_w, int32_t img_h, void *stream) {
+  NEED_DEVICE();
+  return generate_vertex_map(d_depth, d_vertex, width, height, fx, fy, img_w, img_h, S(stream));
+}
+int svoslam_generate_normal_map(const float *d_vertex, float *d_normal, int32_t width, int32_t height, void *stream) {
+  NEED_DEVICE();
+  return generate_normal_map(d_vertex, d_normal, width, height, S(stream));
+}
+int svoslam_bilateral_filter(const uint16_t *d_in, uint16_t *d_out, int32_t width, int32_t height, void *stream) {
+  NEED_DEVICE();
+  return bilateral_filter(d_in, d_out, width, height, S(stream));
+}
+int svoslam_subsample_depth_u16(uint16_t *d_data, uint16_t *d_tmp, int32_t width, int32_t height, void *stream) {
+  NEED_DEVICE();
+  return subsample_depth_u16(d_data, d_tmp, width, height, S(stream));
+}
+int svoslam_subsample_depth_f32(float *d_data, float *d_tmp, int32_t width, int32_t height, void *stream) {
+  NEED_DEVICE();
+  return subsample_depth_f32(d_data, d_tmp, width, height, S(stream));
+}
+int svoslam_subsample_f32(float *d_data, float *d_tmp, int32_t width, int32_t height, void *stream) {
+  NEED_DEVICE();
+  return subsample_f32(d_data, d_tmp, width, height, S(stream));
+}
+int svoslam_subsample_rgb8(uint8_t *d_data, uint8_t *d_tmp, int32_t width, int32_t height, void *stream) {
+  NEED_DEVICE();
+  return subsample_rgb8(d_data, d_tmp, width, height, S(stream));
+}
+int svoslam_color_to_intensity(const uint8_t *d_rgb, float *d_out, int32_t n, void *stream) {
+  NEED_DEVICE();
+  return color_to_intensity(d_rgb, d_out, n, S(stream));
+}
+int svoslam_transform_vertex_map(float *d_vertex, const float trans[16], int32_t n, void *stream) {
+  NEED_DEVICE();
+  return transform_vertex_map(d_vertex, trans, n, S(stream));
+}
+int svoslam_transform_normal_map(float *d_normal, const float trans[16], int32_t n, void *stream) {
+  NEED_DEVICE();
+  return transform_normal_map(d_normal, trans, n, S(stream));
+}
+int svoslam_transform_vertex_map_dmat(float *d_vertex, const float *d_trans, int32_t n, void *stream) {
+  NEED_DEVICE();
+  return transform_vertex_map_dmat(d_vertex, d_trans, n, S(stream));
+}
+
+static svoslam::DeviceBuffer g_misc;  // bbox partials / icp_cost2 accumulators for the stateless entry points
+
+int svoslam_point_cloud_bbox(const float *d_points, int32_t n, float h_bbox0[3], float h_bbox1[3], void *stream) {
+  NEED_DEVICE();
+  return point_cloud_bbox(g_misc, d_points, n, h_bbox0, h_bbox1, S(stream));
+}
+
+int svoslam_icp_cost2(const float *d_last_vertex, const float *d_last_normal, const float *d_cur_vertex,
+                      const float *d_cur_normal, int32_t width, int32_t height, float h_A[36], float h_b[6], void *stream) {
+  NEED_DEVICE();
+  return icp_cost2(g_misc, d_last_vertex, d_last_normal, d_cur_vertex, d_cur_normal, width, height, h_A, h_b, S(stream));
+}
+
+int svoslam_icp_accumulate(const float *d_last_vertex, const float *d_last_normal, const float *d_cur_vertex,
+                           const float *d_cur_normal, int32_t width, int32_t height, int32_t first_pixel,
+                           int32_t num_pixels, double *d_acc, void *stream) {
+  NEED_DEVICE();
+  return icp_accumulate(d_last_vertex, d_last_normal, d_cur_vertex, d_cur_normal, width, height, first_pixel, num_pixels,
+                        d_acc, S(stream));
+}
+
+int svoslam_camera_create(svoslam_camera **cam, int32_t width, int32_t height, float fx, float fy) {
+  return camera_create(cam, width, height, fx, fy);
+}
+int svoslam_camera_destroy(svoslam_camera *cam) { return camera_destroy(cam); }
+int svoslam_camera_set_band(svoslam_camera *cam, int32_t first_row, int32_t rows) { return camera_set_band(cam, first_row, rows); }
+int svoslam_camera_set_acc(svoslam_camera *cam, double *d_acc) { return camera_set_acc(cam, d_acc); }
+int svoslam_camera_update(svoslam_camera *cam, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp,
+                          int32_t *processed, void *stream) {
+  return camera_update(cam, d_depth, d_rgb, timestamp, processed, S(stream));
+}
+int svoslam_camera_begin(svoslam_camera *cam, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp,
+                         int32_t *processed, void *stream) {
+  return camera_begin(cam, d_depth, d_rgb, timestamp, processed, S(stream));
+}
+int svoslam_camera_icp_iters(int32_t level) { return camera_icp_iters(level); }
+int svoslam_camera_icp_accumulate(svoslam_camera *cam, int32_t level, int32_t iter, void *stream) {
+  return camera_icp_accumulate(cam, level, iter, S(stream));
+}
+double *svoslam_camera_acc(svoslam_camera *cam) { return camera_acc(cam); }
+int svoslam_camera_icp_solve(svoslam_camera *cam, int32_t level, int32_t iter, void *stream) {
+  return camera_icp_solve(cam, level, iter, S(stream));
+}
+int svoslam_camera_end(svoslam_camera *cam, void *stream) { return camera_end(cam, S(stream)); }
+int svoslam_camera_pose(svoslam_camera *cam, float h_position[3], float h_orientation[9], void *stream) {
+  return camera_pose(cam, h_position, h_orientation, S(stream));
+}
+const float *svoslam_camera_fusion_transform_device(svoslam_camera *cam) { return camera_fusion_transform_device(cam); }
+int svoslam_camera_last_system(svoslam_camera *cam, float h_A[36], float h_b[6], float h_x[6], void *stream) {
+  return camera_last_system(cam, h_A, h_b, h_x, S(stream));
+}
+const float *svoslam_camera_last_vertex(svoslam_camera *cam, int32_t level) { return camera_last_vertex(cam, level); }
+const float *svoslam_camera_last_normal(svoslam_camera *cam, int32_t level) { return camera_last_normal(cam, level); }
+int svoslam_camera_tracking_lost_count(svoslam_camera *cam, int32_t *count, void *stream) {
+  return camera_tracking_lost_count(cam, count, S(stream));
+}
+
+// startTiming / stopTiming (src/timing_utils.cu:11-32) on hipEvents
+int svoslam_timer_start(void *stream) {
+  NEED_DEVICE();
+  if (!g_t0) { SVO_HIP(hipEventCreate(&g_t0)); SVO_HIP(hipEventCreate(&g_t1)); }
+  SVO_HIP(hipEventRecord(g_t0, S(stream)));
+  return SVOSLAM_OK;
+}
+int svoslam_timer_stop(void *stream, float *h_ms) {
+  NEED_DEVICE();
+  if (!g_t0 || !h_ms) return SVOSLAM_ERR_INVALID_ARG;
+  SVO_HIP(hipEventRecord(g_t1, S(stream)));
+  SVO_HIP(hipEventSynchronize(g_t1));
+  SVO_HIP(hipEventElapsedTime(h_ms, g_t0, g_t1));
+  return SVOSLAM_OK;
+}
+
+}  // extern "C"

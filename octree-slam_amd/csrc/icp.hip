@@ -1,0 +1,567 @@
+// icp.hip -- point-to-plane ICP normal equations + the RGBDCamera tracker loop,
+// resident on the device.
+//
+// Contract = sensor::computeICPCost2 (src/sensor/localization_kernels.cu:154-229,
+// 303-326) and sensor::RGBDCamera::update (src/sensor/rgbd_camera.cpp:53-222).
+//
+// Organisation (vs the reference):
+//  * accumulation: the reference gives each of 16-thread blocks' threads 20..60
+//    consecutive pixels, writes a 168-byte Mat6x7 partial per thread to HBM and
+//    thrust::reduces them in an unspecified float order.  Here every lane keeps
+//    the 27 distinct terms (A is symmetric) in registers as EXACT fixed-point
+//    values carried in float64 (q = rint(fl32(product) * 2^20 | 2^30)), reduces
+//    them across the wave with shuffles, across the workgroup through LDS and
+//    adds them to 27 global doubles.  Integer-valued sums are associative, so the
+//    result does not depend on lane/workgroup/GPU partitioning -- row-band
+//    partials from several GPUs all-reduce (RCCL, float64 sum) to the same bits.
+//  * the per-iteration rigid update is applied on the fly: the kernel replays
+//    the short chain of 4x4 transforms on each current-frame vertex/normal
+//    instead of rewriting both maps in HBM after every iteration
+//    (rgbd_camera.cpp:116-120,163-167); same operation order, same floats.
+//  * the 6x6 Cholesky (rgbd_camera.cpp:194-222) and the pose composition
+//    (:154-160,172-173) run in a one-lane kernel: 19 iterations per frame with
+//    no host round trip (the reference copies 168 B back and solves on the host
+//    19 times per frame).
+#include <math.h>
+#include <string.h>
+
+#include "icp.hpp"
+#include "image_kernels.hpp"
+
+namespace svoslam {
+
+__device__ constexpr float kDistThresh = 0.1f;   // localization_kernels.cu:17
+__device__ constexpr float kNormThresh = 0.87f;  // :18
+constexpr double kScaleA = 1048576.0;            // 2^20
+constexpr double kScaleB = 1073741824.0;         // 2^30
+constexpr int kMaxChain = 10;                    // max(PYRAMID_ITERS)
+
+struct CamState {
+  double acc[27];
+  float update_trans[16];
+  float level_start[16];
+  float chain[kMaxChain][16];
+  float position[3];
+  float orientation[9];
+  float fusion[16];
+  float lastA[36], lastb[6], lastx[6];
+  int lost;                 // NaN seen at this pyramid level (rgbd_camera.cpp:148-151)
+  int tracking_lost_count;  // levels abandoned so far
+};
+
+// ----------------------------------------------------------------------------
+// accumulate
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void icp_accumulate_kernel(const float *__restrict__ last_v, const float *__restrict__ last_n,
+                                                             const float *__restrict__ cur_v, const float *__restrict__ cur_n,
+                                                             int first, int end, const CamState *__restrict__ state,
+                                                             int use_level_start, int chain_len, double *__restrict__ acc_out) {
+  __shared__ double red[4][27];
+  __shared__ float chain_s[(kMaxChain + 1) * 16];
+  int nchain = 0;
+  bool lost = false;
+  if (state) {
+    lost = state->lost != 0;
+    if (use_level_start) {
+      if (threadIdx.x < 16) chain_s[threadIdx.x] = state->level_start[threadIdx.x];
+      nchain = 1;
+    }
+    for (int i = threadIdx.x; i < chain_len * 16; i += 256) chain_s[nchain * 16 + i] = (&state->chain[0][0])[i];
+    nchain += chain_len;
+  }
+  __syncthreads();
+  double acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; i++) acc[i] = 0.0;
+  if (!lost) {
+    for (int p = first + blockIdx.x * 256 + threadIdx.x; p < end; p += gridDim.x * 256) {
+      float v2x = cur_v[3 * (size_t)p], v2y = cur_v[3 * (size_t)p + 1], v2z = cur_v[3 * (size_t)p + 2];
+      float n2x = cur_n[3 * (size_t)p], n2y = cur_n[3 * (size_t)p + 1], n2z = cur_n[3 * (size_t)p + 2];
+      const float v1x = last_v[3 * (size_t)p], v1y = last_v[3 * (size_t)p + 1], v1z = last_v[3 * (size_t)p + 2];
+      const float n1x = last_n[3 * (size_t)p], n1y = last_n[3 * (size_t)p + 1], n1z = last_n[3 * (size_t)p + 2];
+      for (int k = 0; k < nchain; k++) {  // transformVertexMap / transformNormalMap replayed
+        float ox, oy, oz;
+        mat4_mul_point(chain_s + 16 * k, v2x, v2y, v2z, 1.0f, ox, oy, oz);
+        v2x = ox; v2y = oy; v2z = oz;
+        mat4_mul_point(chain_s + 16 * k, n2x, n2y, n2z, 0.0f, ox, oy, oz);
+        n2x = ox; n2y = oy; n2z = oz;
+      }
+      // gates, localization_kernels.cu:186-205
+      if (!finitef_(v2x) || !finitef_(v2y) || !finitef_(v2z) || !finitef_(v1x) || !finitef_(v1y) || !finitef_(v1z) ||
+          (v1z < 0.1f) || (v2z < 0.1f) || (v1z > 10.0f) || (v2z > 10.0f))
+        continue;
+      if (!finitef_(n2x) || !finitef_(n2y) || !finitef_(n2z) || !finitef_(n1x) || !finitef_(n1y) || !finitef_(n1z)) continue;
+      const float dx = v2x - v1x, dy = v2y - v1y, dz = v2z - v1z;
+      if (sqrtf(dot3(dx, dy, dz, dx, dy, dz)) > kDistThresh) continue;
+      if (dot3(n2x, n2y, n2z, n1x, n1y, n1z) < kNormThresh) continue;
+      // A_T = G_T * n1 with the G_T rows of :208-213 (Q14), products in source order
+      float J[6];
+      J[0] = (0.0f * n1x + (-v2x) * n1y) + (-v2y) * n1z;
+      J[1] = ((-v2z) * n1x + 0.0f * n1y) + v2x * n1z;
+      J[2] = (v2y * n1x + v2z * n1y) + 0.0f * n1z;
+      J[3] = (1.0f * n1x + 0.0f * n1y) + 0.0f * n1z;
+      J[4] = (0.0f * n1x + 1.0f * n1y) + 0.0f * n1z;
+      J[5] = (0.0f * n1x + 0.0f * n1y) + 1.0f * n1z;
+      const float bb = dot3(n1x, n1y, n1z, v1x - v2x, v1y - v2y, v1z - v2z);
+      int k = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) {
+          const float prod = J[i] * J[j];
+          acc[k++] += rint((double)prod * kScaleA);
+        }
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        const float prod = bb * J[i];
+        acc[21 + i] += rint((double)prod * kScaleB);
+      }
+    }
+  }
+  // wave -> workgroup -> global; every partial is an integer-valued double (exact)
+#pragma unroll
+  for (int i = 0; i < 27; i++) {
+    double v = acc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    acc[i] = v;
+  }
+  const unsigned wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 27; i++) red[wave][i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (s != 0.0) atomicAdd(&acc_out[threadIdx.x], s);
+  }
+}
+
+static int launch_accumulate(const float *lv, const float *ln, const float *cv, const float *cn, int w, int h, int first,
+                             int num, const CamState *state, int use_level_start, int chain_len, double *d_acc,
+                             hipStream_t s) {
+  const int n = w * h;
+  // Q15: load_size = 20*w/640; the reference reduces floor(n/load) partials, the tail is dropped
+  const int load_size = 20 * w / 640;
+  int limit = n;
+  if (load_size > 0) limit = (n / load_size) * load_size;
+  int end = first + num;
+  if (end > limit) end = limit;
+  if (first < 0) first = 0;
+  int blocks = (int)cdiv(end > first ? end - first : 1, 256 * 4);  // >= 4 pixels per lane
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  icp_accumulate_kernel<<<blocks, 256, 0, s>>>(lv, ln, cv, cn, first, end, state, use_level_start, chain_len, d_acc);
+  SVO_LAUNCH_CHECK();
+  return SVOSLAM_OK;
+}
+
+int icp_accumulate(const float *lv, const float *ln, const float *cv, const float *cn, int w, int h, int first, int num,
+                   double *d_acc, hipStream_t s) {
+  if (!lv || !ln || !cv || !cn || !d_acc || w <= 0 || h <= 0 || first < 0 || num < 0) return SVOSLAM_ERR_INVALID_ARG;
+  return launch_accumulate(lv, ln, cv, cn, w, h, first, num, nullptr, 0, 0, d_acc, s);
+}
+
+static void icp_finish_host(const double acc[27], float A[36], float b[6]) {
+  int k = 0;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++) {
+      const float v = (float)(acc[k++] * (1.0 / kScaleA));
+      A[6 * i + j] = v;
+      A[6 * j + i] = v;
+    }
+  for (int i = 0; i < 6; i++) b[i] = (float)(acc[21 + i] * (1.0 / kScaleB));
+}
+
+int icp_cost2(svoslam::DeviceBuffer &scratch, const float *lv, const float *ln, const float *cv, const float *cn, int w,
+              int h, float A[36], float b[6], hipStream_t s) {
+  if (!A || !b) return SVOSLAM_ERR_INVALID_ARG;
+  SVO_TRY(scratch.reserve(27 * sizeof(double)));
+  double *d_acc = scratch.as<double>();
+  SVO_HIP(hipMemsetAsync(d_acc, 0, 27 * sizeof(double), s));
+  SVO_TRY(icp_accumulate(lv, ln, cv, cn, w, h, 0, w * h, d_acc, s));
+  double acc[27];
+  SVO_HIP(hipMemcpyAsync(acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, s));
+  SVO_HIP(hipStreamSynchronize(s));
+  icp_finish_host(acc, A, b);
+  return SVOSLAM_OK;
+}
+
+// ----------------------------------------------------------------------------
+// device-resident solve + pose composition (one lane)
+// ----------------------------------------------------------------------------
+__device__ inline void d_identity(float *m) {
+  for (int i = 0; i < 16; i++) m[i] = 0.0f;
+  m[0] = m[5] = m[10] = m[15] = 1.0f;
+}
+// glm operator*(mat4, mat4), type_mat4x4.inl:753-775
+__device__ inline void d_mat4_mul(const float *a, const float *b, float *out) {
+  float r[16];
+  for (int c = 0; c < 4; c++)
+    for (int row = 0; row < 4; row++)
+      r[4 * c + row] = ((a[row] * b[4 * c] + a[4 + row] * b[4 * c + 1]) + a[8 + row] * b[4 * c + 2]) + a[12 + row] * b[4 * c + 3];
+  for (int i = 0; i < 16; i++) out[i] = r[i];
+}
+// glm::translate, gtc/matrix_transform.inl:35-45
+__device__ inline void d_translate(const float *m, const float *v, float *out) {
+  float r[16];
+  for (int i = 0; i < 16; i++) r[i] = m[i];
+  for (int row = 0; row < 4; row++) r[12 + row] = ((m[row] * v[0] + m[4 + row] * v[1]) + m[8 + row] * v[2]) + m[12 + row];
+  for (int i = 0; i < 16; i++) out[i] = r[i];
+}
+// Deterministic sin/cos in binary64 with explicit fma (Cody-Waite by pi/2 + fdlibm
+// kernels), rounded once to binary32; the CPU oracle evaluates the same sequence.
+// The reference calls the host libm through glm::rotate (matrix_transform.inl:60-61).
+__device__ inline void d_sincos(float af, float &s_out, float &c_out) {
+  const double x = (double)af;
+  const double kd = rint(x * 0.63661977236758134308);
+  double r = fma(kd, -1.57079632673412561417e+00, x);
+  r = fma(kd, -6.07710050650619224932e-11, r);
+  const double z = r * r;
+  double sp = 1.58969099521155010221e-10;
+  sp = fma(sp, z, -2.50507602534068634195e-08);
+  sp = fma(sp, z, 2.75573137070700676789e-06);
+  sp = fma(sp, z, -1.98412698298579493134e-04);
+  sp = fma(sp, z, 8.33333333332248946124e-03);
+  sp = fma(sp, z, -1.66666666666666324348e-01);
+  const double sn = fma(r * z, sp, r);
+  double cp = -1.13596475577881948265e-11;
+  cp = fma(cp, z, 2.08757232129817482790e-09);
+  cp = fma(cp, z, -2.75573143513906633035e-07);
+  cp = fma(cp, z, 2.48015872894767294178e-05);
+  cp = fma(cp, z, -1.38888888888741095749e-03);
+  cp = fma(cp, z, 4.16666666666666019037e-02);
+  const double cs = fma(z * z, cp, fma(z, -0.5, 1.0));
+  const long long k = (long long)kd;
+  double s, c;
+  switch ((int)(k & 3)) {
+    case 0: s = sn; c = cs; break;
+    case 1: s = cs; c = -sn; break;
+    case 2: s = -sn; c = -cs; break;
+    default: s = -cs; c = sn; break;
+  }
+  s_out = (float)s;
+  c_out = (float)c;
+}
+// glm::rotate (degrees API), gtc/matrix_transform.inl:47-86
+__device__ inline void d_rotate_deg(const float *m, float angle, float vx, float vy, float vz, float *out) {
+  const float a = angle * 0.01745329251994329576923690768489f;
+  float c, s;
+  d_sincos(a, s, c);
+  const float inv = 1.0f / sqrtf((vx * vx + vy * vy) + vz * vz);
+  const float axis[3] = {vx * inv, vy * inv, vz * inv};
+  const float temp[3] = {(1.0f - c) * axis[0], (1.0f - c) * axis[1], (1.0f - c) * axis[2]};
+  float R[3][3];
+  R[0][0] = c + temp[0] * axis[0];
+  R[0][1] = 0 + temp[0] * axis[1] + s * axis[2];
+  R[0][2] = 0 + temp[0] * axis[2] - s * axis[1];
+  R[1][0] = 0 + temp[1] * axis[0] - s * axis[2];
+  R[1][1] = c + temp[1] * axis[1];
+  R[1][2] = 0 + temp[1] * axis[2] + s * axis[0];
+  R[2][0] = 0 + temp[2] * axis[0] + s * axis[1];
+  R[2][1] = 0 + temp[2] * axis[1] - s * axis[0];
+  R[2][2] = c + temp[2] * axis[2];
+  float r[16];
+  for (int col = 0; col < 3; col++)
+    for (int row = 0; row < 4; row++) r[4 * col + row] = (m[row] * R[col][0] + m[4 + row] * R[col][1]) + m[8 + row] * R[col][2];
+  for (int row = 0; row < 4; row++) r[12 + row] = m[12 + row];
+  for (int i = 0; i < 16; i++) out[i] = r[i];
+}
+
+// RGBDCamera::solveCholesky, rgbd_camera.cpp:194-222 (float storage, double inner sums)
+__device__ inline void d_solve_cholesky(const float *A, const float *b, float *x) {
+  float LU[36], y[6];
+  for (int i = 0; i < 36; i++) LU[i] = 0.0f;
+  for (int i = 0; i < 6; i++) y[i] = 0.0f;
+  for (int k = 0; k < 6; ++k) {
+    double sum = 0.;
+    for (int p = 0; p < k; ++p) sum += LU[k * 6 + p] * LU[k * 6 + p];
+    LU[k * 6 + k] = (float)sqrt(A[k * 6 + k] - sum);
+    for (int i = k + 1; i < 6; ++i) {
+      double sum2 = 0.;
+      for (int p = 0; p < k; ++p) sum2 += LU[i * 6 + p] * LU[k * 6 + p];
+      LU[i * 6 + k] = (float)((A[i * 6 + k] - sum2) / LU[k * 6 + k]);
+    }
+  }
+  for (int i = 0; i < 6; ++i) {
+    double sum = 0.;
+    for (int k = 0; k < i; ++k) sum += LU[i * 6 + k] * y[k];
+    y[i] = (float)((b[i] - sum) / LU[i * 6 + i]);
+  }
+  for (int i = 5; i >= 0; --i) {
+    double sum = 0.;
+    for (int k = i + 1; k < 6; ++k) sum += LU[k * 6 + i] * x[k];
+    x[i] = (float)((y[i] - sum) / LU[i * 6 + i]);
+  }
+}
+
+__global__ void cam_frame_begin_kernel(CamState *st) {
+  if (threadIdx.x || blockIdx.x) return;
+  d_identity(st->update_trans);  // rgbd_camera.cpp:100
+}
+
+__global__ void cam_level_begin_kernel(CamState *st) {
+  if (threadIdx.x || blockIdx.x) return;
+  for (int i = 0; i < 16; i++) st->level_start[i] = st->update_trans[i];  // :116-120
+  st->lost = 0;
+}
+
+// one ICP iteration's host part (:143-160); slot = iteration index at this level
+__global__ void cam_solve_kernel(CamState *st, double *acc, int slot) {
+  if (threadIdx.x || blockIdx.x) return;
+  float A[36], b[6], x[6];
+  int k = 0;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++) {
+      const float v = (float)(acc[k] * (1.0 / kScaleA));
+      acc[k++] = 0.0;
+      A[6 * i + j] = v;
+      A[6 * j + i] = v;
+    }
+  for (int i = 0; i < 6; i++) { b[i] = (float)(acc[21 + i] * (1.0 / kScaleB)); acc[21 + i] = 0.0; }
+  if (st->lost) return;
+  for (int i = 0; i < 6; i++) x[i] = 0.0f;
+  d_solve_cholesky(A, b, x);
+  for (int i = 0; i < 36; i++) st->lastA[i] = A[i];
+  for (int i = 0; i < 6; i++) { st->lastb[i] = b[i]; st->lastx[i] = x[i]; }
+  if (x[0] != x[0] || x[1] != x[1] || x[2] != x[2] || x[3] != x[3] || x[4] != x[4] || x[5] != x[5]) {
+    st->lost = 1;  // "Camera tracking is lost." -> abandon this level (:148-151)
+    st->tracking_lost_count++;
+    return;
+  }
+  // this_trans = Rz(-x2) * Ry(-x1) * Rx(-x0) * T(x3,x4,x5), glm degrees API (:154-158)
+  float I[16], rz[16], ry[16], rx[16], tr[16], t1[16], t2[16], this_trans[16];
+  d_identity(I);
+  d_rotate_deg(I, -x[2] * 180.0f / 3.14159f, 0.0f, 0.0f, 1.0f, rz);
+  d_rotate_deg(I, -x[1] * 180.0f / 3.14159f, 0.0f, 1.0f, 0.0f, ry);
+  d_rotate_deg(I, -x[0] * 180.0f / 3.14159f, 1.0f, 0.0f, 0.0f, rx);
+  const float tv[3] = {x[3], x[4], x[5]};
+  d_translate(I, tv, tr);
+  d_mat4_mul(rz, ry, t1);
+  d_mat4_mul(t1, rx, t2);
+  d_mat4_mul(t2, tr, this_trans);
+  d_mat4_mul(this_trans, st->update_trans, st->update_trans);  // :160
+  if (slot < kMaxChain)
+    for (int i = 0; i < 16; i++) st->chain[slot][i] = this_trans[i];
+}
+
+// :172-173 pose update (Q17: row-vector products) and the fusion transform of main.cpp:40
+__global__ void cam_frame_end_kernel(CamState *st, int apply_update) {
+  if (threadIdx.x || blockIdx.x) return;
+  if (apply_update) {
+    const float *m = st->update_trans;
+    const float v[4] = {st->position[0], st->position[1], st->position[2], 1.0f};
+    float np[3];
+    for (int i = 0; i < 3; i++) np[i] = ((m[4 * i] * v[0] + m[4 * i + 1] * v[1]) + m[4 * i + 2] * v[2]) + m[4 * i + 3] * v[3];
+    st->position[0] = np[0]; st->position[1] = np[1]; st->position[2] = np[2];
+    float o4[16], no[16];
+    d_identity(o4);
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) o4[4 * c + r] = st->orientation[3 * c + r];
+    d_mat4_mul(o4, m, no);
+    for (int c = 0; c < 3; c++)
+      for (int r = 0; r < 3; r++) st->orientation[3 * c + r] = no[4 * c + r];
+  }
+  float o4[16], I[16], t[16];
+  d_identity(o4);
+  for (int c = 0; c < 3; c++)
+    for (int r = 0; r < 3; r++) o4[4 * c + r] = st->orientation[3 * c + r];
+  d_identity(I);
+  d_translate(I, st->position, t);
+  d_mat4_mul(o4, t, st->fusion);
+}
+
+}  // namespace svoslam
+
+// ----------------------------------------------------------------------------
+// host mirror of sensor::RGBDCamera
+// ----------------------------------------------------------------------------
+using svoslam::CamState;
+
+struct svoslam_camera {
+  int width = 0, height = 0;
+  float fx = 0, fy = 0;
+  int pass = 0;  // rgbd_camera.h:75 (caps at 2)
+  bool have_stamp = false;
+  long long latest_stamp = 0;
+  int band_first = 0, band_rows = 0;
+  uint16_t *filt[3] = {nullptr, nullptr, nullptr};
+  float *vert[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  float *norm[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  int cur = 0;  // index of the "current" set; the other is "last"
+  CamState *d_state = nullptr;
+  double *d_acc = nullptr;  // defaults to d_state->acc; may be redirected for multi-GPU all-reduce
+  bool frame_has_icp = false;
+};
+
+namespace svoslam {
+
+static const int kPyramidIters[3] = {10, 5, 4};  // rgbd_camera.cpp:19
+
+int camera_icp_iters(int level) { return (level >= 0 && level < 3) ? kPyramidIters[level] : 0; }
+
+int camera_create(svoslam_camera **out, int w, int h, float fx, float fy) {
+  if (!out || w < 8 || h < 8) return SVOSLAM_ERR_INVALID_ARG;
+  SVO_TRY(ensure_device());
+  svoslam_camera *c = new svoslam_camera();
+  c->width = w; c->height = h; c->fx = fx; c->fy = fy;
+  c->band_first = 0; c->band_rows = h;
+  for (int i = 0; i < 3; i++) {
+    const size_t n = (size_t)(w >> i) * (size_t)(h >> i);
+    SVO_HIP(hipMalloc((void **)&c->filt[i], n * 2));
+    for (int s = 0; s < 2; s++) {
+      SVO_HIP(hipMalloc((void **)&c->vert[s][i], n * 12));
+      SVO_HIP(hipMalloc((void **)&c->norm[s][i], n * 12));
+    }
+  }
+  SVO_HIP(hipMalloc((void **)&c->d_state, sizeof(CamState)));
+  CamState init;
+  memset(&init, 0, sizeof(init));
+  init.orientation[0] = init.orientation[4] = init.orientation[8] = 1.0f;  // glm::mat3() = identity, vec3() = 0
+  for (int i = 0; i < 16; i += 5) { init.update_trans[i] = 1.0f; init.fusion[i] = 1.0f; init.level_start[i] = 1.0f; }
+  SVO_HIP(hipMemcpy(c->d_state, &init, sizeof(init), hipMemcpyHostToDevice));
+  c->d_acc = c->d_state->acc;
+  *out = c;
+  return SVOSLAM_OK;
+}
+
+int camera_destroy(svoslam_camera *c) {
+  if (!c) return SVOSLAM_OK;
+  for (int i = 0; i < 3; i++) {
+    if (c->filt[i]) (void)hipFree(c->filt[i]);
+    for (int s = 0; s < 2; s++) {
+      if (c->vert[s][i]) (void)hipFree(c->vert[s][i]);
+      if (c->norm[s][i]) (void)hipFree(c->norm[s][i]);
+    }
+  }
+  if (c->d_state) (void)hipFree(c->d_state);
+  delete c;
+  return SVOSLAM_OK;
+}
+
+int camera_begin(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp, int32_t *processed,
+                 hipStream_t s) {
+  (void)d_rgb;  // intensity only feeds the unimplemented RGB-D term (localization_kernels.cu:328-331)
+  if (!c || !d_depth) return SVOSLAM_ERR_INVALID_ARG;
+  if (c->have_stamp && timestamp <= c->latest_stamp) {  // :55-59
+    if (processed) *processed = 0;
+    c->frame_has_icp = false;
+    return SVOSLAM_OK;
+  }
+  c->have_stamp = true;
+  c->latest_stamp = timestamp;
+  if (processed) *processed = 1;
+  const int W = c->width, H = c->height;
+  SVO_TRY(bilateral_filter(d_depth, c->filt[0], W, H, s));  // :62-64
+  for (int i = 0; i < 3; i++) {                             // :72-93
+    const int w = W >> i, h = H >> i;
+    SVO_TRY(generate_vertex_normal_maps(c->filt[i], c->vert[c->cur][i], c->norm[c->cur][i], w, h, c->fx, c->fy, W, H, s));
+    if (i != 2) SVO_TRY(subsample_depth_u16_to(c->filt[i], c->filt[i + 1], w, h, s));
+  }
+  c->frame_has_icp = c->pass >= 1;
+  if (c->frame_has_icp) {
+    cam_frame_begin_kernel<<<1, 64, 0, s>>>(c->d_state);
+    SVO_LAUNCH_CHECK();
+  }
+  return SVOSLAM_OK;
+}
+
+int camera_icp_accumulate(svoslam_camera *c, int level, int iter, hipStream_t s) {
+  if (!c || level < 0 || level > 2 || iter < 0 || iter >= kPyramidIters[level]) return SVOSLAM_ERR_INVALID_ARG;
+  if (!c->frame_has_icp) return SVOSLAM_OK;
+  if (iter == 0) {
+    cam_level_begin_kernel<<<1, 64, 0, s>>>(c->d_state);
+    SVO_LAUNCH_CHECK();
+  }
+  const int w = c->width >> level, h = c->height >> level;
+  const int r0 = c->band_first >> level, r1 = (c->band_first + c->band_rows) >> level;
+  const int last = 1 - c->cur;
+  return launch_accumulate(c->vert[last][level], c->norm[last][level], c->vert[c->cur][level], c->norm[c->cur][level], w, h,
+                           r0 * w, (r1 - r0) * w, c->d_state, level < 2 ? 1 : 0, iter, c->d_acc, s);
+}
+
+int camera_icp_solve(svoslam_camera *c, int level, int iter, hipStream_t s) {
+  if (!c || level < 0 || level > 2 || iter < 0 || iter >= kPyramidIters[level]) return SVOSLAM_ERR_INVALID_ARG;
+  if (!c->frame_has_icp) return SVOSLAM_OK;
+  cam_solve_kernel<<<1, 64, 0, s>>>(c->d_state, c->d_acc, iter);
+  SVO_LAUNCH_CHECK();
+  return SVOSLAM_OK;
+}
+
+int camera_end(svoslam_camera *c, hipStream_t s) {
+  if (!c) return SVOSLAM_ERR_INVALID_ARG;
+  cam_frame_end_kernel<<<1, 64, 0, s>>>(c->d_state, c->frame_has_icp ? 1 : 0);
+  SVO_LAUNCH_CHECK();
+  if (c->pass < 2) c->pass++;  // :176-178
+  c->cur = 1 - c->cur;         // swap current/last, :181-189
+  c->frame_has_icp = false;
+  return SVOSLAM_OK;
+}
+
+int camera_update(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp, int32_t *processed,
+                  hipStream_t s) {
+  int32_t used = 0;
+  SVO_TRY(camera_begin(c, d_depth, d_rgb, timestamp, &used, s));
+  if (processed) *processed = used;
+  if (!used) return SVOSLAM_OK;
+  for (int level = 2; level >= 0; level--)  // coarse to fine, :103
+    for (int it = 0; it < kPyramidIters[level]; it++) {
+      SVO_TRY(camera_icp_accumulate(c, level, it, s));
+      SVO_TRY(camera_icp_solve(c, level, it, s));
+    }
+  return camera_end(c, s);
+}
+
+int camera_set_band(svoslam_camera *c, int first_row, int rows) {
+  if (!c || first_row < 0 || rows < 0 || first_row + rows > c->height) return SVOSLAM_ERR_INVALID_ARG;
+  c->band_first = first_row; c->band_rows = rows;
+  return SVOSLAM_OK;
+}
+
+int camera_set_acc(svoslam_camera *c, double *d_acc) {
+  if (!c) return SVOSLAM_ERR_INVALID_ARG;
+  c->d_acc = d_acc ? d_acc : c->d_state->acc;
+  return SVOSLAM_OK;
+}
+
+double *camera_acc(svoslam_camera *c) { return c ? c->d_acc : nullptr; }
+
+int camera_pose(svoslam_camera *c, float pos[3], float ori[9], hipStream_t s) {
+  if (!c || !pos || !ori) return SVOSLAM_ERR_INVALID_ARG;
+  CamState st;
+  SVO_HIP(hipMemcpyAsync(&st, c->d_state, sizeof(st), hipMemcpyDeviceToHost, s));
+  SVO_HIP(hipStreamSynchronize(s));
+  memcpy(pos, st.position, sizeof(st.position));
+  memcpy(ori, st.orientation, sizeof(st.orientation));
+  return SVOSLAM_OK;
+}
+
+int camera_last_system(svoslam_camera *c, float A[36], float b[6], float x[6], hipStream_t s) {
+  if (!c) return SVOSLAM_ERR_INVALID_ARG;
+  CamState st;
+  SVO_HIP(hipMemcpyAsync(&st, c->d_state, sizeof(st), hipMemcpyDeviceToHost, s));
+  SVO_HIP(hipStreamSynchronize(s));
+  if (A) memcpy(A, st.lastA, sizeof(st.lastA));
+  if (b) memcpy(b, st.lastb, sizeof(st.lastb));
+  if (x) memcpy(x, st.lastx, sizeof(st.lastx));
+  return SVOSLAM_OK;
+}
+
+const float *camera_fusion_transform_device(svoslam_camera *c) { return c ? c->d_state->fusion : nullptr; }
+const float *camera_last_vertex(svoslam_camera *c, int level) {
+  return (c && level >= 0 && level < 3) ? c->vert[1 - c->cur][level] : nullptr;
+}
+const float *camera_last_normal(svoslam_camera *c, int level) {
+  return (c && level >= 0 && level < 3) ? c->norm[1 - c->cur][level] : nullptr;
+}
+int camera_tracking_lost_count(svoslam_camera *c, int *count, hipStream_t s) {
+  if (!c || !count) return SVOSLAM_ERR_INVALID_ARG;
+  CamState st;
+  SVO_HIP(hipMemcpyAsync(&st, c->d_state, sizeof(st), hipMemcpyDeviceToHost, s));
+  SVO_HIP(hipStreamSynchronize(s));
+  *count = st.tracking_lost_count;
+  return SVOSLAM_OK;
+}
+
+}  // namespace svoslam

@@ -1,0 +1,159 @@
+// radix_sort.hip -- stable LSD radix sort of (64-bit Morton key, 32-bit point
+// index) pairs, 8-bit digits, hand-written for wave64.
+//
+// Replaces the D per-level thrust::sort calls of the reference
+// (src/world/svo/svo.cu:216, :602) with ONE sort of the full-depth keys per
+// fused frame; every per-level unique list is then a prefix property of the
+// sorted array (see svo_build.hip).
+//
+// Per pass: upsweep (tile digit histogram) -> row_scan (exclusive scan of each
+// digit row over tiles) -> downsweep (stable in-tile ranking by ballot match,
+// scatter).  A tile is 256 threads x IPT items laid out wave-striped so that
+// (wave, round, lane) order equals index order, which keeps the sort stable.
+#include "radix_sort.hpp"
+#include "wave_rank.hpp"
+
+namespace svoslam {
+
+constexpr int kSortIPT = 4;
+constexpr int kSortTile = 256 * kSortIPT;
+
+__global__ __launch_bounds__(256) void radix_upsweep_kernel(const unsigned long long *__restrict__ keys, int n, int shift,
+                                                            unsigned mask, unsigned *__restrict__ tile_hist,
+                                                            int num_tiles) {
+  __shared__ unsigned hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int tile = blockIdx.x;
+  const long long base = (long long)tile * kSortTile;
+#pragma unroll
+  for (int r = 0; r < kSortIPT; r++) {
+    const long long idx = base + r * 256 + threadIdx.x;
+    if (idx < n) atomicAdd(&hist[(unsigned)(keys[idx] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  tile_hist[(size_t)threadIdx.x * num_tiles + tile] = hist[threadIdx.x];
+}
+
+// One workgroup per row: in-place exclusive scan of row[0..num_tiles), row total to totals[row].
+__global__ __launch_bounds__(256) void row_scan_kernel(unsigned *__restrict__ rows, int num_tiles,
+                                                       unsigned *__restrict__ totals) {
+  __shared__ unsigned tmp[4];
+  unsigned *row = rows + (size_t)blockIdx.x * num_tiles;
+  unsigned carry = 0;
+  for (int base = 0; base < num_tiles; base += 256) {
+    const int i = base + threadIdx.x;
+    const unsigned v = i < num_tiles ? row[i] : 0u;
+    unsigned total;
+    const unsigned ex = block256_exclusive_scan(v, tmp, total);
+    if (i < num_tiles) row[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void radix_downsweep_kernel(const unsigned long long *__restrict__ keys_in,
+                                                              const unsigned *__restrict__ vals_in,
+                                                              unsigned long long *__restrict__ keys_out,
+                                                              unsigned *__restrict__ vals_out, int n, int shift,
+                                                              unsigned mask, const unsigned *__restrict__ row_prefix,
+                                                              const unsigned *__restrict__ totals, int num_tiles,
+                                                              int iota_vals) {
+  __shared__ unsigned cnt[4][256];  // per-wave digit counters, then per-wave exclusive offsets
+  __shared__ unsigned dbase[256];   // global output base of each digit for this tile
+  __shared__ unsigned tmp[4];
+  const int tile = blockIdx.x;
+  const unsigned wave = threadIdx.x >> 6, lane = lane_id();
+#pragma unroll
+  for (int w = 0; w < 4; w++) cnt[w][threadIdx.x] = 0;
+  {
+    unsigned total;
+    const unsigned ex = block256_exclusive_scan(totals[threadIdx.x], tmp, total);
+    dbase[threadIdx.x] = ex + row_prefix[(size_t)threadIdx.x * num_tiles + tile];
+  }
+  __syncthreads();
+
+  const long long base = (long long)tile * kSortTile + (long long)wave * (kWave * kSortIPT);
+  unsigned long long k[kSortIPT];
+  unsigned v[kSortIPT], dig[kSortIPT], pre[kSortIPT];
+  bool ok[kSortIPT];
+  volatile unsigned *wc = cnt[wave];
+  const unsigned long long lt = lanemask_lt();
+#pragma unroll
+  for (int r = 0; r < kSortIPT; r++) {
+    const long long idx = base + r * kWave + lane;
+    ok[r] = idx < n;
+    k[r] = ok[r] ? keys_in[idx] : 0ull;
+    v[r] = ok[r] ? (iota_vals ? (unsigned)idx : vals_in[idx]) : 0u;
+    dig[r] = (unsigned)(k[r] >> shift) & mask;
+    const unsigned long long peers = match_digit8(ok[r], dig[r]);
+    pre[r] = 0;
+    if (ok[r]) {
+      const unsigned old = wc[dig[r]];
+      const unsigned rank = __popcll(peers & lt);
+      pre[r] = old + rank;
+      if (rank == 0) wc[dig[r]] = old + __popcll(peers);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  {  // exclusive offsets of each wave's share of digit threadIdx.x
+    unsigned run = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const unsigned t = cnt[w][threadIdx.x];
+      cnt[w][threadIdx.x] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kSortIPT; r++) {
+    if (ok[r]) {
+      const unsigned pos = dbase[dig[r]] + cnt[wave][dig[r]] + pre[r];
+      keys_out[pos] = k[r];
+      vals_out[pos] = v[r];
+    }
+  }
+}
+
+int radix_sort_num_tiles(int n) { return (int)cdiv(n, kSortTile); }
+
+void row_scan_rows(unsigned *rows, int num_tiles, unsigned *totals, hipStream_t stream) {
+  row_scan_kernel<<<256, 256, 0, stream>>>(rows, num_tiles, totals);
+}
+void row_scan_rows1(unsigned *row, int num_tiles, unsigned *total, hipStream_t stream) {
+  row_scan_kernel<<<1, 256, 0, stream>>>(row, num_tiles, total);
+}
+
+int radix_sort_pairs(svoslam_workspace *ws, int n, int num_bits, hipStream_t stream, unsigned long long **sorted_keys,
+                     unsigned **sorted_vals) {
+  // keys are in ws->keys_a; values are the identity permutation (generated in the first pass)
+  unsigned long long *ka = ws->keys_a.as<unsigned long long>(), *kb = ws->keys_b.as<unsigned long long>();
+  unsigned *va = ws->vals_a.as<unsigned>(), *vb = ws->vals_b.as<unsigned>();
+  unsigned *tile_hist = ws->tile_hist.as<unsigned>();
+  unsigned *totals = ws->small.as<unsigned>();  // first 256 words
+  const int tiles = radix_sort_num_tiles(n);
+  int passes = (num_bits + 7) / 8;
+  if (passes < 1) passes = 1;
+  int bit = 0;
+  for (int p = 0; p < passes; p++) {
+    // spread the bits evenly over the passes (e.g. 37 bits -> 8,8,7,7,7)
+    const int remaining_bits = num_bits - bit, remaining_passes = passes - p;
+    int width = (remaining_bits + remaining_passes - 1) / remaining_passes;
+    if (width < 1) width = 1;
+    const unsigned mask = (1u << width) - 1u;
+    radix_upsweep_kernel<<<tiles, 256, 0, stream>>>(ka, n, bit, mask, tile_hist, tiles);
+    row_scan_kernel<<<256, 256, 0, stream>>>(tile_hist, tiles, totals);
+    radix_downsweep_kernel<<<tiles, 256, 0, stream>>>(ka, va, kb, vb, n, bit, mask, tile_hist, totals, tiles, p == 0);
+    SVO_LAUNCH_CHECK();
+    unsigned long long *tk = ka; ka = kb; kb = tk;
+    unsigned *tv = va; va = vb; vb = tv;
+    bit += width;
+  }
+  *sorted_keys = ka;
+  *sorted_vals = va;
+  return SVOSLAM_OK;
+}
+
+}  // namespace svoslam

@@ -1,0 +1,582 @@
+// svo_build.hip -- sparse-voxel-octree fusion on gfx950.
+//
+// Functional contract = src/world/svo/svo.cu of the reference (node indices and
+// Morton keys bit-exact): computeKeys -> split planning -> tile allocation ->
+// leaf fusion -> mip-map, and the BFS extraction.  The organisation is new:
+//
+//   reference (svo.cu:179-237)                 here
+//   ------------------------------------------ ---------------------------------
+//   splitKeys + per pass {copy, remove_if,     ONE stable radix sort of the full
+//   sort, unique, malloc, rightToLeftShift}    keys, then a single "plan" sweep:
+//   = D sorts of n keys + 4D host syncs        every sorted unique leaf walks the
+//                                              existing pool once, finds its first
+//                                              unsplit ancestor (depth t) and owns
+//                                              the prefixes below its common prefix
+//                                              with the previous leaf.  A split
+//                                              record (pass p = d - t, depth d) is
+//                                              ranked inside its (p, d) bucket by a
+//                                              wave64 ballot match + popcount prefix,
+//                                              an LDS cross-wave offset and one row
+//                                              scan: rank order == the reference's
+//                                              "sorted unique codes of pass p".
+//   realloc + whole-pool copy per frame        geometric capacity, one 76-byte
+//   (:663-668)                                 count readback per frame
+//   fillNodes race on duplicate keys (:684)    lowest point index wins (stable sort)
+//   mipmapNodes: n redundant walks x D (:450)  owner lanes only, node indices saved
+//                                              by the fill walk
+#include <string.h>
+
+#include "radix_sort.hpp"
+#include "svo_build.hpp"
+#include "wave_rank.hpp"
+
+namespace svoslam {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr unsigned char kNotHead = 0xFE;  // sorted element is a duplicate or an invalid key
+constexpr unsigned char kNoSplit = 0xFF;  // path fully exists, nothing to split
+
+// ----------------------------------------------------------------------------
+// keys  (svo.cu:33-66, 92-106)
+// ----------------------------------------------------------------------------
+template <int STRIDE>
+__global__ __launch_bounds__(256) void compute_keys_kernel(const float *__restrict__ pts, int n, int depth, float cx,
+                                                           float cy, float cz, float edge, u64 *__restrict__ keys) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float px = pts[(size_t)i * STRIDE], py = pts[(size_t)i * STRIDE + 1], pz = pts[(size_t)i * STRIDE + 2];
+  u64 morton = 1;
+  // Q1 (svo.cu:38): the finite test reads x, z, z -- y is never tested
+  if (finitef_(px) && finitef_(pz)) {
+    for (int l = 0; l < depth; l++) {
+      const bool x = px > cx, y = py > cy, z = pz > cz;
+      morton = (morton << 3) + (u64)(x + 2 * y + 4 * z);
+      edge /= 2.0f;
+      cx += edge * (x ? 1 : -1);
+      cy += edge * (y ? 1 : -1);
+      cz += edge * (z ? 1 : -1);
+    }
+  }
+  keys[i] = morton;
+}
+
+// ----------------------------------------------------------------------------
+// planning
+// ----------------------------------------------------------------------------
+// number of leading 3-bit levels two distinct depth-D keys share
+__device__ inline int common_levels(u64 a, u64 b, int depth) {
+  const u64 x = a ^ b;  // != 0, < 2^(3D)
+  const int hb = 63 - __clzll((long long)x);
+  return depth - 1 - hb / 3;
+}
+
+__device__ inline bool is_head(const u64 *__restrict__ skey, int j, u64 &key, int &c, int depth) {
+  key = skey[j];
+  const u64 prev = j > 0 ? skey[j - 1] : 1ull;
+  if (key == 1ull || key == prev) return false;
+  c = (prev == 1ull) ? 0 : common_levels(key, prev, depth);
+  return true;
+}
+
+// splitKeys (svo.cu:108-142) for one key: first node on the path without the
+// children flag.  Q3: the last level is examined only when its octant is 7.
+// t in [1, D] = depth of that node, f = its index; t = kNoSplit -> f = leaf index.
+__device__ inline void walk_existing(const u32 *__restrict__ pool, u64 key, int depth, int &t, u32 &f) {
+  u32 base = 0, node = 0;
+  t = kNoSplit;
+  for (int lvl = 1; lvl <= depth; lvl++) {
+    const u32 oct = (u32)(key >> (3 * (depth - lvl))) & 7u;
+    node = base + oct;
+    if (lvl < depth || oct == 7u) {
+      const u32 w0 = pool[2 * (size_t)node];
+      if (!(w0 & kFlag)) { t = lvl; break; }
+      base = w0 & kMask;
+    }
+  }
+  f = node;
+}
+
+// record depths owned by a leaf: [lo, hi] (empty if lo > hi)
+__device__ inline void record_range(int t, int c, int depth, int &lo, int &hi) {
+  if (t == kNoSplit) { lo = 1; hi = 0; }
+  else if (t == depth) { lo = hi = depth; }  // Q4: an octant-7 leaf gains children
+  else { lo = t > c + 1 ? t : c + 1; hi = depth - 1; }
+}
+
+__device__ inline u32 bucket_id(int p, int d) { return (u32)(p * 16 + (d - 1)); }
+
+__global__ __launch_bounds__(256) void plan_count_kernel(const u64 *__restrict__ skey, int n, int depth,
+                                                         const u32 *__restrict__ pool, unsigned char *__restrict__ leaf_t,
+                                                         u32 *__restrict__ leaf_f, u32 *__restrict__ tile_hist,
+                                                         int num_tiles, int *__restrict__ any_valid) {
+  __shared__ u32 hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n) {
+    u64 key; int c = 0;
+    if (is_head(skey, j, key, c, depth)) {
+      int t; u32 f;
+      walk_existing(pool, key, depth, t, f);
+      leaf_t[j] = (unsigned char)t;
+      leaf_f[j] = f;
+      int lo, hi;
+      record_range(t, c, depth, lo, hi);
+      for (int d = lo; d <= hi; d++) atomicAdd(&hist[bucket_id(d - t, d)], 1u);
+      *any_valid = 1;  // benign race: every writer stores 1
+    } else {
+      leaf_t[j] = kNotHead;
+    }
+  }
+  __syncthreads();
+  tile_hist[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];
+}
+
+// bucket totals -> bucket bases in reference order (pass major, depth minor), pass ranges
+__global__ __launch_bounds__(256) void plan_finish_kernel(const u32 *__restrict__ totals, u32 *__restrict__ bucket_base,
+                                                          PlanCounts *__restrict__ counts, const int *__restrict__ any_valid) {
+  __shared__ u32 tmp[4];
+  __shared__ u32 sbase[257];
+  u32 total;
+  const u32 ex = block256_exclusive_scan(totals[threadIdx.x], tmp, total);
+  bucket_base[threadIdx.x] = ex;
+  sbase[threadIdx.x] = ex;
+  if (threadIdx.x == 0) sbase[256] = total;
+  __syncthreads();
+  if (threadIdx.x <= 16) counts->pass_start[threadIdx.x] = (int32_t)sbase[threadIdx.x * 16];
+  if (threadIdx.x == 17) { counts->pass_start[17] = (int32_t)total; counts->total_records = (int32_t)total; counts->any_valid = *any_valid; }
+}
+
+__global__ __launch_bounds__(256) void plan_emit_kernel(const u64 *__restrict__ skey, int n, int depth,
+                                                        const unsigned char *__restrict__ leaf_t,
+                                                        const u32 *__restrict__ leaf_f, const u32 *__restrict__ bucket_base,
+                                                        const u32 *__restrict__ row_prefix, int num_tiles,
+                                                        u64 *__restrict__ rec_key, u32 *__restrict__ rec_front) {
+  __shared__ u32 cnt[4][256];
+#pragma unroll
+  for (int w = 0; w < 4; w++) cnt[w][threadIdx.x] = 0;
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const unsigned wave = threadIdx.x >> 6;
+  const unsigned long long lt = lanemask_lt();
+  u64 key = 1; int c = 0, t = kNotHead, lo = 1, hi = 0; u32 f = 0;
+  if (j < n) {
+    t = leaf_t[j];
+    if (t != kNotHead) {
+      (void)is_head(skey, j, key, c, depth);
+      f = leaf_f[j];
+      record_range(t, c, depth, lo, hi);
+    }
+  }
+  // phase A: per-wave record counts per (pass, depth) bucket
+#pragma unroll
+  for (int d = 1; d <= SVOSLAM_MAX_DEPTH; d++) {
+    if (d > depth) break;
+    const bool valid = d >= lo && d <= hi;
+    if (!__ballot(valid)) continue;
+    const u32 b = bucket_id(d - t, d) & 255u;
+    const unsigned long long peers = match_digit8(valid, b);
+    if (valid && (peers & lt) == 0) cnt[wave][b] = (u32)__popcll(peers);
+  }
+  __syncthreads();
+  {
+    u32 run = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const u32 v = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = run; run += v; }
+  }
+  __syncthreads();
+  // phase B: emit records at their reference rank
+#pragma unroll
+  for (int d = 1; d <= SVOSLAM_MAX_DEPTH; d++) {
+    if (d > depth) break;
+    const bool valid = d >= lo && d <= hi;
+    if (!__ballot(valid)) continue;
+    const u32 b = bucket_id(d - t, d) & 255u;
+    const unsigned long long peers = match_digit8(valid, b);
+    if (valid) {
+      const u32 pos = bucket_base[b] + row_prefix[(size_t)b * num_tiles + blockIdx.x] + cnt[wave][b] +
+                      (u32)__popcll(peers & lt);
+      rec_key[pos] = key >> (3 * (depth - d));  // prefix key with its leading 1
+      rec_front[pos] = f;
+    }
+  }
+}
+
+// splitNodes (svo.cu:239-276) for the records of one pass: record r of the
+// whole call gets tile num_nodes0 + 8r, exactly the reference's
+// num_nodes + 8*index with index = rank in the pass's sorted unique list.
+__global__ __launch_bounds__(256) void split_pass_kernel(const u64 *__restrict__ rec_key, const u32 *__restrict__ rec_front,
+                                                         int begin, int end, int pass, u32 *__restrict__ pool,
+                                                         u32 num_nodes0) {
+  const int r = begin + blockIdx.x * 256 + threadIdx.x;
+  if (r >= end) return;
+  const u64 key = rec_key[r];
+  u32 node = rec_front[r];
+  for (int s = pass - 1; s >= 0; s--) node = (pool[2 * (size_t)node] & kMask) + ((u32)(key >> (3 * s)) & 7u);
+  const u32 child = num_nodes0 + 8u * (u32)r;
+  pool[2 * (size_t)node] = kFlag + (child & kMask);
+  uint4 *tile = reinterpret_cast<uint4 *>(pool + 2 * (size_t)child);  // 64-byte aligned child tile
+  const uint4 init = make_uint4(0u, 127u << 24, 0u, 127u << 24);
+  tile[0] = init; tile[1] = init; tile[2] = init; tile[3] = init;
+}
+
+// ----------------------------------------------------------------------------
+// leaf fusion (svo.cu:291-382) + path capture for the mip-map
+// ----------------------------------------------------------------------------
+__device__ inline u32 blend_color256(u32 cur, unsigned char r, unsigned char g, unsigned char b) {
+  const int a = (int)(cur >> 24);
+  const float f1 = (1 - ((float)a / 256.0f)), f2 = (float)a / 256.0f;
+  // new*f1 + cur*f2 is exact in binary32 (<= 16-bit numerators over 256)
+  const u32 nr = (u32)(unsigned char)((float)r * f1 + (float)(cur & 0xFF) * f2);
+  const u32 ng = (u32)(unsigned char)((float)g * f1 + (float)((cur >> 8) & 0xFF) * f2);
+  const u32 nb = (u32)(unsigned char)((float)b * f1 + (float)((cur >> 16) & 0xFF) * f2);
+  const int na = a + 2 < 255 ? a + 2 : 255;
+  return nr + (ng << 8) + (nb << 16) + ((u32)na << 24);
+}
+
+__device__ inline u32 blend_vec4(u32 cur, float r, float g, float b) {
+  float nr = r * 256.0f, ng = g * 256.0f, nb = b * 256.0f;
+  const int a = (int)(cur >> 24);
+  const float f1 = 1 - ((float)a / 256.0f), f2 = (float)a / 256.0f;
+  nr = nr * f1 + (float)(cur & 0xFF) * f2;
+  ng = ng * f1 + (float)((cur >> 8) & 0xFF) * f2;
+  nb = nb * f1 + (float)((cur >> 16) & 0xFF) * f2;
+  const int na = a + 2 < 255 ? a + 2 : 255;
+  // Q21: 256 carries into the next channel through the integer adds
+  return (u32)((int)nr) + ((u32)((int)ng) << 8) + ((u32)((int)nb) << 16) + ((u32)na << 24);
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void fill_kernel(const u64 *__restrict__ skey, const u32 *__restrict__ sidx, int n,
+                                                   int depth, const unsigned char *__restrict__ leaf_t,
+                                                   const void *__restrict__ colors, int color_by_position,
+                                                   u32 *__restrict__ pool, u32 *__restrict__ path_nodes) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n || leaf_t[j] == kNotHead) return;
+  u64 key; int c = 0;
+  (void)is_head(skey, j, key, c, depth);
+  u32 base = 0, node = 0;
+  for (int lvl = 1; lvl <= depth; lvl++) {
+    node = base + ((u32)(key >> (3 * (depth - lvl))) & 7u);
+    if (lvl < depth) {
+      if (lvl > c) path_nodes[(size_t)(lvl - 1) * n + j] = node;  // this lane owns prefix(lvl)
+      base = pool[2 * (size_t)node] & kMask;
+    }
+  }
+  // duplicates: the head of a run of equal keys is the lowest point index (stable sort)
+  const size_t ci = color_by_position ? (size_t)j : (size_t)sidx[j];
+  const u32 cur = pool[2 * (size_t)node + 1];
+  u32 out;
+  if (VEC4) {
+    const float *v = reinterpret_cast<const float *>(colors) + 4 * ci;
+    out = blend_vec4(cur, v[0], v[1], v[2]);
+  } else {
+    const unsigned char *v = reinterpret_cast<const unsigned char *>(colors) + 3 * ci;
+    out = blend_color256(cur, v[0], v[1], v[2]);
+  }
+  pool[2 * (size_t)node + 1] = out;
+}
+
+// averageChildren (svo.cu:384-441).  Q5: all 8 children always count.
+__device__ inline u32 average_tile(const u32 *__restrict__ pool, u32 child_base) {
+  const uint4 *tile = reinterpret_cast<const uint4 *>(pool + 2 * (size_t)child_base);
+  u32 r = 0, g = 0, b = 0, a = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const uint4 v = tile[q];
+    const u32 w1a = v.y, w1b = v.w;
+    r += (w1a & 0xFF) + (w1b & 0xFF);
+    g += ((w1a >> 8) & 0xFF) + ((w1b >> 8) & 0xFF);
+    b += ((w1a >> 16) & 0xFF) + ((w1b >> 16) & 0xFF);
+    const u32 aa = w1a >> 24, ab = w1b >> 24;
+    a = a > aa ? a : aa;
+    a = a > ab ? a : ab;
+  }
+  // float sums / 8.0f of the reference are exact: integer floor division
+  return (r >> 3) + ((g >> 3) << 8) + ((b >> 3) << 16) + (a << 24);
+}
+
+__global__ __launch_bounds__(256) void mip_level_kernel(const u64 *__restrict__ skey, int n, int depth, int d,
+                                                        const unsigned char *__restrict__ leaf_t,
+                                                        const u32 *__restrict__ path_nodes, u32 *__restrict__ pool) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n || leaf_t[j] == kNotHead) return;
+  u64 key; int c = 0;
+  (void)is_head(skey, j, key, c, depth);
+  if (c >= d) return;  // an earlier leaf owns this prefix
+  const u32 node = path_nodes[(size_t)(d - 1) * n + j];
+  pool[2 * (size_t)node + 1] = average_tile(pool, pool[2 * (size_t)node] & kMask);
+}
+
+// final mip pass (Q6): the mean of root children 0..7 lands in node 0's word1.
+// One thread = "every thread reads the pre-launch pool" made deterministic.
+__global__ void mip_root_kernel(u32 *__restrict__ pool, const PlanCounts *__restrict__ counts) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && counts->any_valid) pool[1] = average_tile(pool, 0);
+}
+
+// ----------------------------------------------------------------------------
+// host driver
+// ----------------------------------------------------------------------------
+static int grow_pool(svoslam_pool *pool, int64_t need_nodes, hipStream_t stream) {
+  if (need_nodes > (int64_t)kMask + 1) return SVOSLAM_ERR_POOL_LIMIT;
+  if (need_nodes <= pool->capacity) return SVOSLAM_OK;
+  int64_t cap = (int64_t)pool->capacity * 2;
+  if (cap < need_nodes) cap = need_nodes;
+  if (cap > (int64_t)kMask + 1) cap = (int64_t)kMask + 1;
+  u32 *fresh = nullptr;
+  SVO_HIP(hipMalloc((void **)&fresh, (size_t)cap * 8));
+  if (pool->d_data && pool->size > 0)
+    SVO_HIP(hipMemcpyAsync(fresh, pool->d_data, (size_t)pool->size * 8, hipMemcpyDeviceToDevice, stream));
+  SVO_HIP(hipStreamSynchronize(stream));
+  if (pool->d_data) SVO_HIP(hipFree(pool->d_data));
+  pool->d_data = fresh;
+  pool->capacity = (int32_t)cap;
+  return SVOSLAM_OK;
+}
+
+int pool_init(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream) {
+  if (!pool) return SVOSLAM_ERR_INVALID_ARG;
+  if (capacity_nodes < 8) capacity_nodes = 8;
+  pool->d_data = nullptr; pool->size = 0; pool->capacity = 0;
+  SVO_TRY(grow_pool(pool, capacity_nodes, stream));
+  SVO_HIP(hipMemsetAsync(pool->d_data, 0, 64, stream));  // initOctree, svo.cu:24-31
+  pool->size = 8;
+  return SVOSLAM_OK;
+}
+
+int pool_reserve(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream) {
+  if (!pool) return SVOSLAM_ERR_INVALID_ARG;
+  return grow_pool(pool, capacity_nodes, stream);
+}
+
+static int reserve_common(svoslam_workspace *ws, int n, int depth) {
+  const size_t nn = (size_t)(n > 0 ? n : 1);
+  SVO_TRY(ws->keys_a.reserve(nn * 8));
+  SVO_TRY(ws->keys_b.reserve(nn * 8));
+  SVO_TRY(ws->vals_a.reserve(nn * 4));
+  SVO_TRY(ws->vals_b.reserve(nn * 4));
+  const size_t tiles = (size_t)cdiv(n, 256) + 1;
+  SVO_TRY(ws->tile_hist.reserve(256 * tiles * 4));
+  SVO_TRY(ws->small.reserve(4096));
+  SVO_TRY(ws->leaf_t.reserve(nn));
+  SVO_TRY(ws->leaf_f.reserve(nn * 4));
+  SVO_TRY(ws->path_nodes.reserve(nn * 4 * (size_t)(depth > 1 ? depth - 1 : 1)));
+  if (!ws->h_counts) SVO_HIP(hipHostMalloc((void **)&ws->h_counts, sizeof(PlanCounts), hipHostMallocDefault));
+  return SVOSLAM_OK;
+}
+
+// layout of ws->small (u32 words): [0,256) totals | [256,512) bucket_base | [512..) PlanCounts | [640] any_valid
+static inline u32 *small_totals(svoslam_workspace *ws) { return ws->small.as<u32>(); }
+static inline u32 *small_bucket_base(svoslam_workspace *ws) { return ws->small.as<u32>() + 256; }
+static inline PlanCounts *small_counts(svoslam_workspace *ws) { return reinterpret_cast<PlanCounts *>(ws->small.as<u32>() + 512); }
+static inline int *small_any(svoslam_workspace *ws) { return reinterpret_cast<int *>(ws->small.as<u32>() + 640); }
+
+// keys of the n inputs are in ws->keys_a
+static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, const void *d_colors, bool vec4,
+                      bool color_by_position, svoslam_fuse_stats *stats, hipStream_t stream) {
+  u64 *skey = nullptr; u32 *sidx = nullptr;
+  SVO_TRY(radix_sort_pairs(ws, n, 3 * depth + 1, stream, &skey, &sidx));
+  const int tiles = (int)cdiv(n, 256);
+  unsigned char *leaf_t = ws->leaf_t.as<unsigned char>();
+  u32 *leaf_f = ws->leaf_f.as<u32>();
+  u32 *tile_hist = ws->tile_hist.as<u32>();
+  SVO_HIP(hipMemsetAsync(small_any(ws), 0, 4, stream));
+  plan_count_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, tiles, small_any(ws));
+  row_scan_rows(tile_hist, tiles, small_totals(ws), stream);
+  plan_finish_kernel<<<1, 256, 0, stream>>>(small_totals(ws), small_bucket_base(ws), small_counts(ws), small_any(ws));
+  SVO_LAUNCH_CHECK();
+  SVO_HIP(hipMemcpyAsync(ws->h_counts, small_counts(ws), sizeof(PlanCounts), hipMemcpyDeviceToHost, stream));
+  SVO_HIP(hipStreamSynchronize(stream));  // the one host round trip of a fused frame
+  const PlanCounts hc = *ws->h_counts;
+  const int total = hc.total_records;
+  const int32_t size0 = pool->size;
+  if (stats) {
+    stats->num_points = n; stats->num_split = total; stats->pool_size_before = size0;
+    for (int p = 0; p <= SVOSLAM_MAX_DEPTH; p++) stats->pass_sizes[p] = hc.pass_start[p + 1] - hc.pass_start[p];
+  }
+  if (total > 0) {
+    SVO_TRY(grow_pool(pool, (int64_t)size0 + 8ll * total, stream));
+    SVO_TRY(ws->rec_key.reserve((size_t)total * 8));
+    SVO_TRY(ws->rec_front.reserve((size_t)total * 4));
+    u64 *rec_key = ws->rec_key.as<u64>();
+    u32 *rec_front = ws->rec_front.as<u32>();
+    plan_emit_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, tiles, rec_key, rec_front);
+    for (int p = 0; p <= SVOSLAM_MAX_DEPTH; p++) {  // expandTreeAtKeys, svo.cu:278-289
+      const int begin = hc.pass_start[p], end = hc.pass_start[p + 1];
+      if (end > begin)
+        split_pass_kernel<<<cdiv(end - begin, 256), 256, 0, stream>>>(rec_key, rec_front, begin, end, p, pool->d_data, (u32)size0);
+    }
+    SVO_LAUNCH_CHECK();
+    pool->size = size0 + 8 * total;
+  }
+  if (stats) stats->pool_size_after = pool->size;
+  if (hc.any_valid) {
+    u32 *path_nodes = ws->path_nodes.as<u32>();
+    if (vec4)
+      fill_kernel<true><<<tiles, 256, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, color_by_position, pool->d_data, path_nodes);
+    else
+      fill_kernel<false><<<tiles, 256, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, color_by_position, pool->d_data, path_nodes);
+    for (int d = depth - 1; d >= 1; d--)  // mipmapNodes, svo.cu:450-465
+      mip_level_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, d, leaf_t, path_nodes, pool->d_data);
+    mip_root_kernel<<<1, 64, 0, stream>>>(pool->d_data, small_counts(ws));
+    SVO_LAUNCH_CHECK();
+  }
+  return SVOSLAM_OK;
+}
+
+int svo_from_point_cloud(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,
+                         svoslam_pool *pool, const float center[3], float edge, svoslam_fuse_stats *stats,
+                         hipStream_t stream) {
+  if (!ws || !pool || n < 0 || (n > 0 && (!d_points || !d_colors))) return SVOSLAM_ERR_INVALID_ARG;
+  if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
+  if (pool->size == 0) SVO_TRY(pool_init(pool, 8, stream));  // svo.cu:646-649
+  if (n == 0) {
+    if (stats) { memset(stats, 0, sizeof(*stats)); stats->pool_size_before = stats->pool_size_after = pool->size; }
+    return SVOSLAM_OK;
+  }
+  SVO_TRY(reserve_common(ws, n, depth));
+  compute_keys_kernel<3><<<cdiv(n, 256), 256, 0, stream>>>(d_points, n, depth, center[0], center[1], center[2], edge, ws->keys_a.as<u64>());
+  return svo_insert(ws, n, depth, pool, d_colors, false, false, stats, stream);
+}
+
+int svo_from_voxel_grid(svoslam_workspace *ws, const float *d_centers, const float *d_colors, int n, int depth,
+                        svoslam_pool *pool, const float center[3], float edge, svoslam_fuse_stats *stats,
+                        hipStream_t stream) {
+  if (!ws || !pool || n < 0 || (n > 0 && (!d_centers || !d_colors))) return SVOSLAM_ERR_INVALID_ARG;
+  if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
+  if (pool->size == 0) SVO_TRY(pool_init(pool, 8, stream));
+  if (n == 0) {
+    if (stats) { memset(stats, 0, sizeof(*stats)); stats->pool_size_before = stats->pool_size_after = pool->size; }
+    return SVOSLAM_OK;
+  }
+  SVO_TRY(reserve_common(ws, n, depth));
+  compute_keys_kernel<4><<<cdiv(n, 256), 256, 0, stream>>>(d_centers, n, depth, center[0], center[1], center[2], edge, ws->keys_a.as<u64>());
+  // Q20 (svo.cu:601-602,629): the reference sorts the keys alone, so sorted key i
+  // stays paired with colour i -> color_by_position
+  return svo_insert(ws, n, depth, pool, d_colors, true, true, stats, stream);
+}
+
+// ----------------------------------------------------------------------------
+// extraction (svo.cu:498-582, 699-745): level-synchronous BFS with an
+// order-preserving compaction per level
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bfs_count_kernel(const u32 *__restrict__ pool, const u64 *__restrict__ parents,
+                                                        int num, unsigned char *__restrict__ mask8,
+                                                        u32 *__restrict__ tile_cnt) {
+  __shared__ u32 tmp[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  u32 cntv = 0;
+  if (i < num) {
+    const u64 key = parents[i];
+    const int d = (63 - __clzll((long long)key)) / 3;
+    bool has_children = true;
+    u32 pointer = 0;
+    for (int l = d - 1; l >= 0; l--) {  // getOccupiedChildren :515-520
+      pointer += (u32)(key >> (3 * l)) & 7u;
+      const u32 w0 = pool[2 * (size_t)pointer];
+      has_children = (w0 & kFlag) != 0;
+      pointer = w0 & kMask;
+    }
+    u32 m = 0;
+    if (has_children) {
+      const uint4 *tile = reinterpret_cast<const uint4 *>(pool + 2 * (size_t)pointer);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint4 v = tile[q];
+        if ((v.y >> 24) > 127u) m |= 1u << (2 * q);
+        if ((v.w >> 24) > 127u) m |= 1u << (2 * q + 1);
+      }
+    }
+    mask8[i] = (unsigned char)m;
+    cntv = __popc(m);
+  }
+  u32 total;
+  (void)block256_exclusive_scan(cntv, tmp, total);
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void bfs_emit_kernel(const u64 *__restrict__ parents, int num,
+                                                       const unsigned char *__restrict__ mask8,
+                                                       const u32 *__restrict__ tile_prefix, u64 *__restrict__ children) {
+  __shared__ u32 tmp[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const u32 m = i < num ? mask8[i] : 0u;
+  u32 total;
+  u32 pos = tile_prefix[blockIdx.x] + block256_exclusive_scan(__popc(m), tmp, total);
+  if (i < num) {
+    const u64 key = parents[i];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (m & (1u << k)) children[pos++] = (key << 3) + (u64)k;
+  }
+}
+
+// voxelGridFromKeys, svo.cu:538-582
+__global__ __launch_bounds__(256) void voxel_grid_from_keys_kernel(const u32 *__restrict__ pool, const u64 *__restrict__ keys,
+                                                                   int num, float cx, float cy, float cz, float edge,
+                                                                   float4 *__restrict__ centers, float4 *__restrict__ colors) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= num) return;
+  const u64 key = keys[i];
+  const int d = (63 - __clzll((long long)key)) / 3;
+  u32 node = 0, child = 0;
+  for (int l = d - 1; l >= 0; l--) {
+    const u32 p = (u32)(key >> (3 * l)) & 7u;
+    node = child + p;
+    child = pool[2 * (size_t)node] & kMask;
+    edge /= 2.0f;
+    cx += edge * ((p & 1u) ? 1 : -1);
+    cy += edge * ((p & 2u) ? 1 : -1);
+    cz += edge * ((p & 4u) ? 1 : -1);
+  }
+  const u32 val = pool[2 * (size_t)node + 1];
+  centers[i] = make_float4(cx, cy, cz, 1.0f);
+  colors[i] = make_float4((float)(val & 0xFF) / 255.0f, (float)((val >> 8) & 0xFF) / 255.0f,
+                          (float)((val >> 16) & 0xFF) / 255.0f, (float)((val >> 24) & 0xFF) / 255.0f);
+}
+
+int extract_voxel_grid(svoslam_workspace *ws, const svoslam_pool *pool, int depth, const float center[3], float edge,
+                       float **d_centers, float **d_colors, int32_t *n_out, hipStream_t stream) {
+  if (!ws || !pool || !d_centers || !d_colors || !n_out) return SVOSLAM_ERR_INVALID_ARG;
+  if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
+  *d_centers = nullptr; *d_colors = nullptr; *n_out = 0;
+  if (pool->size == 0) return SVOSLAM_OK;
+  SVO_TRY(ws->small.reserve(4096));
+  SVO_TRY(ws->bfs_a.reserve(8));
+  const u64 one = 1;
+  SVO_HIP(hipMemcpyAsync(ws->bfs_a.ptr, &one, 8, hipMemcpyHostToDevice, stream));
+  SVO_HIP(hipStreamSynchronize(stream));
+  svoslam::DeviceBuffer *cur = &ws->bfs_a, *nxt = &ws->bfs_b;
+  int num = 1;
+  for (int lvl = 0; lvl < depth && num > 0; lvl++) {
+    const int tiles = (int)cdiv(num, 256);
+    SVO_TRY(ws->bfs_mask.reserve((size_t)num));
+    SVO_TRY(ws->tile_hist.reserve((size_t)(tiles + 1) * 4));
+    bfs_count_kernel<<<tiles, 256, 0, stream>>>(pool->d_data, cur->as<u64>(), num, ws->bfs_mask.as<unsigned char>(), ws->tile_hist.as<u32>());
+    row_scan_rows1(ws->tile_hist.as<u32>(), tiles, small_totals(ws), stream);
+    unsigned next_num = 0;
+    SVO_HIP(hipMemcpyAsync(&next_num, small_totals(ws), 4, hipMemcpyDeviceToHost, stream));
+    SVO_HIP(hipStreamSynchronize(stream));
+    if (next_num > 0) {
+      SVO_TRY(nxt->reserve((size_t)next_num * 8));
+      bfs_emit_kernel<<<tiles, 256, 0, stream>>>(cur->as<u64>(), num, ws->bfs_mask.as<unsigned char>(), ws->tile_hist.as<u32>(), nxt->as<u64>());
+      SVO_LAUNCH_CHECK();
+    }
+    svoslam::DeviceBuffer *t = cur; cur = nxt; nxt = t;
+    num = (int)next_num;
+  }
+  if (num <= 0) return SVOSLAM_OK;
+  float *ce = nullptr, *co = nullptr;
+  SVO_HIP(hipMalloc((void **)&ce, (size_t)num * 16));
+  SVO_HIP(hipMalloc((void **)&co, (size_t)num * 16));
+  voxel_grid_from_keys_kernel<<<cdiv(num, 256), 256, 0, stream>>>(pool->d_data, cur->as<u64>(), num, center[0], center[1], center[2], edge,
+                                                                  reinterpret_cast<float4 *>(ce), reinterpret_cast<float4 *>(co));
+  SVO_LAUNCH_CHECK();
+  SVO_HIP(hipStreamSynchronize(stream));
+  *d_centers = ce; *d_colors = co; *n_out = num;
+  return SVOSLAM_OK;
+}
+
+}  // namespace svoslam

@@ -1,0 +1,17 @@
+// svo_build.hpp -- see svo_build.hip
+#pragma once
+#include "common.hpp"
+#include "workspace.hpp"
+
+namespace svoslam {
+int pool_init(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream);
+int pool_reserve(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream);
+int svo_from_point_cloud(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,
+                         svoslam_pool *pool, const float center[3], float edge, svoslam_fuse_stats *stats,
+                         hipStream_t stream);
+int svo_from_voxel_grid(svoslam_workspace *ws, const float *d_centers, const float *d_colors, int n, int depth,
+                        svoslam_pool *pool, const float center[3], float edge, svoslam_fuse_stats *stats,
+                        hipStream_t stream);
+int extract_voxel_grid(svoslam_workspace *ws, const svoslam_pool *pool, int depth, const float center[3], float edge,
+                       float **d_centers, float **d_colors, int32_t *n_out, hipStream_t stream);
+}  // namespace svoslam

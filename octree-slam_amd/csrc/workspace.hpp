@@ -1,0 +1,54 @@
+// workspace.hpp -- grow-only device scratch buffers reused across calls.
+// The reference cudaMallocs and frees 6+D temporaries per fused frame
+// (svo.cu:184-188,221,594,652,713); here every temporary lives in one of these
+// slots and is reallocated only when a call needs more than it has.
+#pragma once
+
+#include "common.hpp"
+
+namespace svoslam {
+
+struct DeviceBuffer {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t need) {
+    if (need <= bytes) return SVOSLAM_OK;
+    if (ptr) { SVO_HIP(hipFree(ptr)); ptr = nullptr; bytes = 0; }
+    size_t want = need + need / 4 + 256;  // 25 % headroom: frames vary slightly in size
+    SVO_HIP(hipMalloc(&ptr, want));
+    bytes = want;
+    return SVOSLAM_OK;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr; bytes = 0;
+  }
+  template <class T> T *as() const { return reinterpret_cast<T *>(ptr); }
+};
+
+// Host-visible counters written by the device and read after ONE stream sync.
+struct PlanCounts {
+  int32_t total_records;                       // nodes to split this call
+  int32_t pass_start[SVOSLAM_MAX_DEPTH + 2];   // record range of pass p = [pass_start[p], pass_start[p+1])
+  int32_t any_valid;                           // at least one finite point
+};
+
+}  // namespace svoslam
+
+struct svoslam_workspace {
+  svoslam::DeviceBuffer keys_a, keys_b, vals_a, vals_b;  // radix sort ping-pong
+  svoslam::DeviceBuffer tile_hist;                        // [256][tiles] digit / bucket histograms
+  svoslam::DeviceBuffer small;                            // totals, bucket bases, counters
+  svoslam::DeviceBuffer leaf_t, leaf_f;                   // per sorted key: first unsplit depth, frontier node
+  svoslam::DeviceBuffer rec_key, rec_front;               // split records in reference order
+  svoslam::DeviceBuffer path_nodes;                       // [(D-1)][n] node index per owned depth (mip lists)
+  svoslam::DeviceBuffer bfs_a, bfs_b, bfs_mask, bfs_ptr;  // extraction
+  svoslam::DeviceBuffer misc;                             // bbox partials etc.
+  svoslam::PlanCounts *h_counts = nullptr;                // pinned host
+  void release_all() {
+    keys_a.release(); keys_b.release(); vals_a.release(); vals_b.release(); tile_hist.release(); small.release();
+    leaf_t.release(); leaf_f.release(); rec_key.release(); rec_front.release(); path_nodes.release();
+    bfs_a.release(); bfs_b.release(); bfs_mask.release(); bfs_ptr.release(); misc.release();
+    if (h_counts) { (void)hipHostFree(h_counts); h_counts = nullptr; }
+  }
+};

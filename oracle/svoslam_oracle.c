@@ -866,21 +866,26 @@ void ora_transform_normal_map(float *v, const float m[16], int n) {
 }
 
 /* image_kernels.cu:60-102.  thrust::reduce with min_vec3/max_vec3: points whose
- * x or z is not finite are skipped (Q1), a zero vector on the left means
- * "unset".  min/max are exact, so the reduction order is immaterial; the oracle
- * folds left to right starting from the caller's bbox. */
+ * x or z is not finite are skipped (Q1); a zero vector on the left means
+ * "unset".  The reduction order of thrust::reduce is unspecified; min/max are
+ * exact, so the oracle takes the plain min/max over the valid points and then
+ * combines it with the caller's bbox under the "zero = unset" rule. */
 void ora_point_cloud_bbox(const float *pts, int n, float bbox0[3], float bbox1[3]) {
-  float lo[3] = {bbox0[0], bbox0[1], bbox0[2]}, hi[3] = {bbox1[0], bbox1[1], bbox1[2]};
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  int any = 0;
   for (int i = 0; i < n; i++) {
     const float *p = pts + 3 * (size_t)i;
     if (!finitef_(p[0]) || !finitef_(p[2])) continue;
-    if (lo[0] == 0.0f && lo[1] == 0.0f && lo[2] == 0.0f) { lo[0] = p[0]; lo[1] = p[1]; lo[2] = p[2]; }
-    else for (int k = 0; k < 3; k++) lo[k] = fminf(p[k], lo[k]);
-    if (hi[0] == 0.0f && hi[1] == 0.0f && hi[2] == 0.0f) { hi[0] = p[0]; hi[1] = p[1]; hi[2] = p[2]; }
-    else for (int k = 0; k < 3; k++) hi[k] = fmaxf(p[k], hi[k]);
+    for (int k = 0; k < 3; k++) { lo[k] = fminf(p[k], lo[k]); hi[k] = fmaxf(p[k], hi[k]); }
+    any = 1;
   }
-  memcpy(bbox0, lo, sizeof(lo));
-  memcpy(bbox1, hi, sizeof(hi));
+  if (!any) return;
+  int unset0 = bbox0[0] == 0.0f && bbox0[1] == 0.0f && bbox0[2] == 0.0f;
+  int unset1 = bbox1[0] == 0.0f && bbox1[1] == 0.0f && bbox1[2] == 0.0f;
+  for (int k = 0; k < 3; k++) {
+    bbox0[k] = unset0 ? lo[k] : fminf(lo[k], bbox0[k]);
+    bbox1[k] = unset1 ? hi[k] : fmaxf(hi[k], bbox1[k]);
+  }
 }
 
 /* ======================================================================== */

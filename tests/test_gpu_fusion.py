@@ -1,0 +1,199 @@
+"""GPU parity: svoFromPointCloud / svoFromVoxelGrid / extractVoxelGridFromSVO through the C ABI
+vs the CPU oracle.  Integer work: the whole node pool must be bit-identical (node indices, child
+pointers, colours, alpha)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from util import describe_mismatch, random_cloud, rgba, surface_cloud
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "kat_appendix_c.json")))
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import svoslam_pkg
+    pkg = svoslam_pkg.load()
+    assert torch.cuda.is_available()
+    assert pkg.device_arch().startswith("gfx950")
+    return pkg, torch
+
+
+def gpu_insert(pkg, torch, ws, pool, pts, col, depth, center, edge):
+    tp = torch.from_numpy(np.ascontiguousarray(pts, np.float32)).cuda()
+    tc = torch.from_numpy(np.ascontiguousarray(col, np.uint8)).cuda()
+    return pkg.svo_from_point_cloud(ws, tp, tc, depth, pool, center, edge)
+
+
+def assert_pools_equal(pool, opool):
+    assert pool.size == opool.size
+    g, c = pool.words(), opool.words()
+    assert np.array_equal(g, c), describe_mismatch(g, c)
+
+
+def test_kat_c2_on_gpu(env, oracle):
+    pkg, torch = env
+    c1, c2 = KAT["C1_keys"], KAT["C2_insert"]
+    ws, pool = pkg.Workspace(), pkg.Pool()
+    st = gpu_insert(pkg, torch, ws, pool, c1["points"], c2["colors"], 2, c1["center"], c1["half_edge"])
+    assert pool.size == c2["size_after_first"] and st.num_split == 2 and list(st.pass_sizes)[:2] == [2, 0]
+    w = pool.words()
+    assert int(w[0]) == c2["node0_word0_after_first"] and int(w[14]) == c2["node7_word0_after_first"]
+    for node, val in c2["nodes_after_first"].items():
+        assert rgba(int(w[2 * int(node) + 1])) == val, node
+    gpu_insert(pkg, torch, ws, pool, c1["points"], c2["colors"], 2, c1["center"], c1["half_edge"])
+    assert pool.size == c2["size_after_second"]
+    w = pool.words()
+    assert int(w[2 * 23]) == c2["node23_word0_after_second"]
+    for node, val in c2["nodes_after_second"].items():
+        assert rgba(int(w[2 * int(node) + 1])) == val, node
+    gpu_insert(pkg, torch, ws, pool, c1["points"], c2["colors"], 2, c1["center"], c1["half_edge"])
+    assert pool.size == c2["size_after_second"]
+
+
+@pytest.mark.parametrize("depth,n,frames", [(1, 300, 2), (2, 2000, 3), (5, 20000, 3), (8, 30000, 3), (10, 40000, 2),
+                                            (12, 50000, 2), (16, 20000, 2)])
+def test_cloud_fusion_matches_oracle(env, oracle, depth, n, frames):
+    pkg, torch = env
+    rng = np.random.default_rng(100 + depth)
+    ws, pool = pkg.Workspace(), pkg.Pool()
+    opool = oracle.Pool()
+    center, edge = (0.05, -0.02, 0.01), 1.0
+    for f in range(frames):
+        pts, col = (surface_cloud(rng, n) if f % 2 == 0 else random_cloud(rng, n, nan_every=53, dup_frac=0.1))
+        pts = pts + np.float32(0.003 * f)
+        st = gpu_insert(pkg, torch, ws, pool, pts, col, depth, center, edge)
+        before = opool.size if opool.size else 8
+        opool.insert_cloud(pts, col, depth, center, edge)
+        assert st.pool_size_after == opool.size and st.pool_size_before == before
+        assert_pools_equal(pool, opool)
+
+
+def test_split_pass_sizes_match_reference_passes(env, oracle):
+    pkg, torch = env
+    rng = np.random.default_rng(5)
+    depth, center, edge = 7, (0, 0, 0), 1.0
+    ws, pool = pkg.Workspace(), pkg.Pool()
+    opool = oracle.Pool()
+    opool.insert_cloud(np.zeros((0, 3)), np.zeros((0, 3)), depth, center, edge)
+    for f in range(3):
+        pts, col = surface_cloud(rng, 8000)
+        keys = oracle.compute_keys(pts, depth, center, edge)
+        total, sizes, _ = opool.prepass(keys, depth)
+        st = gpu_insert(pkg, torch, ws, pool, pts, col, depth, center, edge)
+        assert st.num_split == total
+        assert list(st.pass_sizes)[:depth] == sizes
+        opool.insert_cloud(pts, col, depth, center, edge)
+        assert_pools_equal(pool, opool)
+
+
+def test_edge_cases(env, oracle):
+    pkg, torch = env
+    ws = pkg.Workspace()
+    center, edge = (0, 0, 0), 1.0
+    # empty input: pool initialised to 8 zero nodes, nothing else
+    pool = pkg.Pool()
+    st = pkg.svo_from_point_cloud(ws, None, None, 5, pool, center, edge)
+    assert pool.size == 8 and st.num_split == 0 and (pool.words() == 0).all()
+    # all points invalid
+    pts = np.full((100, 3), np.nan, np.float32)
+    col = np.zeros((100, 3), np.uint8)
+    st = gpu_insert(pkg, torch, ws, pool, pts, col, 5, center, edge)
+    assert pool.size == 8 and (pool.words() == 0).all()
+    # a single point, all points identical, and points outside the root cube (Q11 clamp)
+    for pts in (np.array([[0.3, 0.3, 0.3]], np.float32), np.tile(np.array([[0.7, -0.7, 0.2]], np.float32), (500, 1)),
+                np.array([[5, 5, 5], [-9, 2, 0.1], [0.1, 0.1, 40]], np.float32)):
+        pool, opool = pkg.Pool(), oracle.Pool()
+        col = (np.arange(pts.shape[0] * 3) % 251).astype(np.uint8).reshape(-1, 3)
+        for _ in range(2):
+            gpu_insert(pkg, torch, ws, pool, pts, col, 6, center, edge)
+            opool.insert_cloud(pts, col, 6, center, edge)
+            assert_pools_equal(pool, opool)
+    # depth out of range is refused
+    with pytest.raises(pkg.SvoslamError):
+        gpu_insert(pkg, torch, ws, pool, pts, col, 17, center, edge)
+
+
+def test_alpha_saturation_and_q4(env, oracle):
+    """re-observing the same cloud: alpha += 2 up to 255, octant-7 leaves split exactly once"""
+    pkg, torch = env
+    rng = np.random.default_rng(9)
+    pts, col = random_cloud(rng, 3000)
+    ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
+    sizes = []
+    for f in range(70):
+        gpu_insert(pkg, torch, ws, pool, pts, col, 4, (0, 0, 0), 1.0)
+        sizes.append(pool.size)
+        if f in (0, 1, 2, 69):
+            opool.insert_cloud(pts, col, 4, (0, 0, 0), 1.0)
+            if f < 3:
+                assert_pools_equal(pool, opool)
+        elif f < 69:
+            opool.insert_cloud(pts, col, 4, (0, 0, 0), 1.0)
+    assert_pools_equal(pool, opool)
+    assert sizes[1] > sizes[0] and sizes[2] == sizes[1]  # Q4 growth happens once
+    assert (pool.words()[1::2] >> 24).max() == 255
+
+
+def test_voxel_grid_path(env, oracle):
+    pkg, torch = env
+    rng = np.random.default_rng(21)
+    n, depth, center, edge = 6000, 6, (0.0, 0.1, 0.0), 0.5
+    ce = np.ones((n, 4), np.float32)
+    ce[:, :3] = (rng.random((n, 3)) - 0.5) * 0.9 + np.array(center)
+    ce[::31, 0] = np.nan
+    co = rng.random((n, 4)).astype(np.float32)
+    co[::17, :3] = 1.0  # Q21: 1.0*256 overflows into the next channel when alpha == 0
+    ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
+    for _ in range(2):
+        pkg.svo_from_voxel_grid(ws, torch.from_numpy(ce).cuda(), torch.from_numpy(co).cuda(), depth, pool, center, edge)
+        opool.insert_voxel_grid(ce, co, depth, center, edge)
+        assert_pools_equal(pool, opool)
+
+
+@pytest.mark.parametrize("depth", [3, 6, 9])
+def test_extract_matches_oracle(env, oracle, depth):
+    pkg, torch = env
+    rng = np.random.default_rng(33 + depth)
+    pts, col = surface_cloud(rng, 15000)
+    ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
+    for _ in range(2):
+        gpu_insert(pkg, torch, ws, pool, pts, col, depth, (0, 0, 0), 1.0)
+        opool.insert_cloud(pts, col, depth, (0, 0, 0), 1.0)
+    for d in (depth, max(1, depth - 2)):
+        ce, co = pkg.extract_voxel_grid(ws, pool, d, (0, 0, 0), 1.0)
+        rce, rco = opool.extract(d, (0, 0, 0), 1.0)
+        assert ce.shape == rce.shape and ce.shape[0] > 0
+        assert np.array_equal(ce.view(np.uint32), rce.view(np.uint32))
+        assert np.array_equal(co.view(np.uint32), rco.view(np.uint32))
+
+
+def test_large_cloud_invariants(env):
+    """full-size (640x480 points, depth 12) properties that need no oracle: tree invariants,
+    idempotent structure on re-insertion, every child pointer in range and tile aligned"""
+    pkg, torch = env
+    rng = np.random.default_rng(77)
+    n, depth = 640 * 480, 12
+    pts, col = surface_cloud(rng, n, jitter=0.002)
+    ws, pool = pkg.Workspace(), pkg.Pool()
+    st1 = gpu_insert(pkg, torch, ws, pool, pts, col, depth, (0, 0, 0), 1.024)
+    w = pool.words()
+    w0 = w[0::2]
+    flagged = (w0 & 0x40000000) != 0
+    child = w0[flagged] & 0x3FFFFFFF
+    assert st1.pool_size_after == 8 + 8 * st1.num_split == pool.size
+    assert flagged.sum() == st1.num_split
+    assert (child % 8 == 0).all() and child.min() >= 8 and child.max() + 8 <= pool.size
+    assert np.unique(child).size == child.size          # every tile has exactly one parent
+    assert (w0[~flagged] == 0).all()
+    size1 = pool.size
+    st2 = gpu_insert(pkg, torch, ws, pool, pts, col, depth, (0, 0, 0), 1.024)
+    w2 = pool.words()
+    assert (w2[0:2 * size1:2] & 0x3FFFFFFF == w[0::2] & 0x3FFFFFFF)[flagged].all()  # old pointers untouched
+    st3 = gpu_insert(pkg, torch, ws, pool, pts, col, depth, (0, 0, 0), 1.024)
+    assert st3.num_split == 0 and st2.num_split < st1.num_split  # only the one-off Q4 splits in pass 2

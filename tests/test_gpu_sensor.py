@@ -1,0 +1,194 @@
+"""GPU parity: sensor image kernels, ICP normal equations and the RGBDCamera tracker through the
+C ABI vs the CPU oracle.  All of these are bit-exact by construction (IEEE op-by-op float, exact
+fixed-point ICP sums); float maps are compared bit for bit with NaN == NaN."""
+import numpy as np
+import pytest
+
+from util import describe_mismatch, same_bits_or_nan
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import svoslam_pkg
+    pkg = svoslam_pkg.load()
+    import importlib
+    synth = importlib.import_module("octree_slam_amd.synth")
+    return pkg, torch, synth
+
+
+def u16(t):
+    return t.cpu().numpy().view(np.uint16)
+
+
+def dev16(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.uint16).view(np.int16)).cuda()
+
+
+def noisy_depth(rng, h, w):
+    yy, xx = np.mgrid[0:h, 0:w]
+    d = 1800 + 600 * np.sin(xx / 23.0) * np.cos(yy / 17.0) + rng.normal(scale=3.0, size=(h, w))
+    d[(xx // 40 + yy // 30) % 5 == 0] += 900      # depth discontinuities
+    d = np.clip(d, 0, 65535)
+    d[rng.random((h, w)) < 0.02] = 0              # dropouts
+    d[0:3, 0:5] = 20000                           # > 15000 -> invalid
+    return d.astype(np.uint16)
+
+
+@pytest.mark.parametrize("h,w", [(48, 64), (120, 160), (61, 97), (480, 640)])
+def test_bilateral(env, oracle, h, w):
+    pkg, torch, _ = env
+    rng = np.random.default_rng(h * w)
+    d = noisy_depth(rng, h, w)
+    out = torch.zeros((h, w), dtype=torch.int16, device="cuda")
+    pkg.bilateral_filter(dev16(torch, d), out)
+    ref = oracle.bilateral(d)
+    assert np.array_equal(u16(out), ref), describe_mismatch(u16(out), ref)
+
+
+def test_bilateral_constant_and_extremes(env, oracle):
+    pkg, torch, _ = env
+    for d in (np.full((20, 33), 1234, np.uint16), np.zeros((9, 9), np.uint16),
+              np.random.default_rng(1).integers(0, 40000, (37, 41)).astype(np.uint16)):
+        out = torch.zeros(d.shape, dtype=torch.int16, device="cuda")
+        pkg.bilateral_filter(dev16(torch, d), out)
+        assert np.array_equal(u16(out), oracle.bilateral(d))
+
+
+@pytest.mark.parametrize("h,w,iw,ih", [(480, 640, 640, 480), (240, 320, 640, 480), (120, 160, 640, 480), (61, 97, 97, 61)])
+def test_vertex_normal_maps(env, oracle, h, w, iw, ih):
+    pkg, torch, _ = env
+    rng = np.random.default_rng(h)
+    d = noisy_depth(rng, h, w)
+    f = 570.3 * iw / 640.0
+    v = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    n = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    pkg.generate_vertex_map(dev16(torch, d), v, f, f, iw, ih)
+    pkg.generate_normal_map(v, n)
+    rv = oracle.vertex_map(d, f, f, iw, ih)
+    rn = oracle.normal_map(rv)
+    assert same_bits_or_nan(v.cpu().numpy(), rv)
+    assert same_bits_or_nan(n.cpu().numpy(), rn)
+
+
+def test_pyramid_subsample(env, oracle):
+    pkg, torch, _ = env
+    rng = np.random.default_rng(4)
+    h, w = 120, 160
+    d = noisy_depth(rng, h, w)
+    buf, tmp = dev16(torch, d), torch.zeros((h // 2 * (w // 2),), dtype=torch.int16, device="cuda")
+    pkg.subsample_depth(buf, tmp, w, h)
+    ref = oracle.subsample_depth(d)
+    assert np.array_equal(u16(buf).reshape(-1)[: ref.size].reshape(ref.shape), ref)
+    fl = rng.random((h, w)).astype(np.float32) * 3000
+    fb, ft = torch.from_numpy(fl).cuda(), torch.zeros((h // 2 * (w // 2),), dtype=torch.float32, device="cuda")
+    pkg.subsample_depth(fb, ft, w, h)
+    assert np.array_equal(fb.cpu().numpy().reshape(-1)[: ref.size].reshape(ref.shape), oracle.subsample_depth(fl))
+    fb2 = torch.from_numpy(fl).cuda()
+    pkg.subsample(fb2, ft, w, h)
+    assert np.array_equal(fb2.cpu().numpy().reshape(-1)[: ref.size].reshape(ref.shape), oracle.subsample(fl))
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    rb, rt = torch.from_numpy(rgb).cuda(), torch.zeros((h // 2 * (w // 2) * 3,), dtype=torch.uint8, device="cuda")
+    pkg.subsample(rb, rt, w, h)
+    assert np.array_equal(rb.cpu().numpy().reshape(-1)[: ref.size * 3].reshape(ref.shape + (3,)), oracle.subsample(rgb))
+    inten = torch.zeros((h * w,), dtype=torch.float32, device="cuda")
+    pkg.color_to_intensity(torch.from_numpy(rgb).cuda(), inten)
+    assert np.array_equal(inten.cpu().numpy(), oracle.color_to_intensity(rgb))
+
+
+def test_transforms_and_bbox(env, oracle):
+    pkg, torch, _ = env
+    rng = np.random.default_rng(6)
+    d = noisy_depth(rng, 96, 128)
+    v = oracle.vertex_map(d, 114.06, 114.06, 128, 96)
+    T = oracle.icp_update_transform(np.array([0.01, -0.02, 0.015, 0.03, -0.01, 0.02], np.float32))
+    tv = torch.from_numpy(v.copy()).cuda()
+    pkg.transform_vertex_map(tv, T)
+    assert same_bits_or_nan(tv.cpu().numpy(), oracle.transform_vertex_map(v, T))
+    tn = torch.from_numpy(v.copy()).cuda()
+    pkg.transform_normal_map(tn, T)
+    assert same_bits_or_nan(tn.cpu().numpy(), oracle.transform_normal_map(v, T))
+    pts = tv.cpu().numpy().reshape(-1, 3)
+    b0, b1 = pkg.point_cloud_bbox(tv)
+    r0, r1 = oracle.point_cloud_bbox(pts)
+    assert np.array_equal(b0, r0) and np.array_equal(b1, r1)
+    b0, b1 = pkg.point_cloud_bbox(tv, (-9, 0.1, 0.2), (0.3, 50, 0.4))
+    r0, r1 = oracle.point_cloud_bbox(pts, (-9, 0.1, 0.2), (0.3, 50, 0.4))
+    assert np.array_equal(b0, r0) and np.array_equal(b1, r1)
+    allnan = torch.full((50, 3), float("nan"), device="cuda")
+    b0, b1 = pkg.point_cloud_bbox(allnan)
+    assert (b0 == 0).all() and (b1 == 0).all()
+
+
+@pytest.mark.parametrize("h,w", [(120, 160), (240, 320), (480, 640), (75, 101)])
+def test_icp_cost2(env, oracle, h, w):
+    pkg, torch, _ = env
+    rng = np.random.default_rng(w)
+    f = 570.3 * w / 640.0
+    d1 = noisy_depth(rng, h, w)
+    v1 = oracle.vertex_map(d1, f, f, w, h); n1 = oracle.normal_map(v1)
+    T = oracle.icp_update_transform(np.array([0.004, -0.003, 0.002, 0.004, -0.002, 0.003], np.float32))
+    v2 = oracle.transform_vertex_map(v1, T); n2 = oracle.transform_normal_map(n1, T)
+    A, b = pkg.icp_cost2(*(torch.from_numpy(x).cuda() for x in (v1, n1, v2, n2)))
+    rA, rb = oracle.icp_cost2(v1, n1, v2, n2)
+    assert np.array_equal(A, rA) and np.array_equal(b, rb), (A - rA, b - rb)
+    assert np.abs(A).max() > 0
+    # band partials add up exactly (what the multi-GPU all-reduce relies on)
+    acc = torch.zeros(27, dtype=torch.float64, device="cuda")
+    tens = [torch.from_numpy(x).cuda() for x in (v1, n1, v2, n2)]
+    rows = [0, h // 3, h // 2 + 1, h]
+    for r0, r1 in zip(rows[:-1], rows[1:]):
+        pkg.icp_accumulate(*tens, r0 * w, (r1 - r0) * w, acc)
+    raw = oracle.icp_cost2_raw(v1, n1, v2, n2)
+    assert np.array_equal(acc.cpu().numpy(), raw.astype(np.float64))
+
+
+def test_camera_tracker_matches_oracle(env, oracle):
+    pkg, torch, synth = env
+    w, h = 160, 120
+    f = synth.focal_length(w)
+    cam = pkg.Camera(w, h, f, f)
+    ocam = oracle.Camera(w, h, f, f)
+    for k in range(5):
+        d, c = synth.render_frame(3 * k, w, h)       # 0.3 deg / 2.6 mm between frames
+        dn = d.numpy().view(np.uint16)
+        used = cam.update(d.cuda(), c.cuda(), k)
+        assert used == ocam.update(dn, c.numpy(), k) == 1
+        p, o = cam.pose(); rp, ro = ocam.pose()
+        assert np.array_equal(p.view(np.uint32), rp.view(np.uint32)), (k, p, rp)
+        assert np.array_equal(o.view(np.uint32), ro.view(np.uint32)), (k, o, ro)
+        if k >= 1:
+            A, b, x = cam.last_system(); rA, rb, rx = ocam.last_system()
+            assert np.array_equal(A, rA) and np.array_equal(b, rb) and np.array_equal(x, rx)
+        fus = pkg.copy_from_device(cam.fusion_transform_ptr(), (16,), np.float32)
+        assert np.array_equal(fus, ocam.fusion_transform())
+    assert cam.update(d.cuda(), c.cuda(), 2) == 0 == ocam.update(dn, c.numpy(), 2)  # stale timestamp skipped
+    assert cam.tracking_lost_count() == 0
+    # the tracker follows the ground-truth yaw (3 frames x 0.3 deg ... sign/axis by convention: just non-trivial)
+    p, o = cam.pose()
+    assert np.abs(o.reshape(3, 3) - np.eye(3)).max() > 1e-3
+
+
+def test_camera_split_stepping_equals_update(env, oracle):
+    """begin / accumulate(bands) / solve / end == update (the multi-GPU stepping API)"""
+    pkg, torch, synth = env
+    w, h = 160, 120
+    f = synth.focal_length(w)
+    cam_a, cam_b = pkg.Camera(w, h, f, f), pkg.Camera(w, h, f, f)
+    acc = torch.zeros(27, dtype=torch.float64, device="cuda")
+    cam_b.set_acc(acc)
+    for k in range(3):
+        d, c = synth.render_frame(2 * k, w, h)
+        cam_a.update(d.cuda(), c.cuda(), k)
+        assert cam_b.begin(d.cuda(), c.cuda(), k) == 1
+        for level in (2, 1, 0):
+            for it in range(pkg.PYRAMID_ITERS[level]):
+                for r0, r1 in ((0, 40), (40, 120)):           # two row bands into one accumulator
+                    cam_b.set_band(r0, r1 - r0)
+                    cam_b.icp_accumulate(level, it)
+                cam_b.icp_solve(level, it)
+        cam_b.end()
+        pa, oa = cam_a.pose(); pb, ob = cam_b.pose()
+        assert np.array_equal(pa, pb) and np.array_equal(oa, ob)
