@@ -186,7 +186,8 @@ int svoslam_transform_vertex_map_dmat(float *d_vertex, const float *d_trans, int
   return transform_vertex_map_dmat(d_vertex, d_trans, n, S(stream));
 }
 
-static svoslam::DeviceBuffer g_misc;  // bbox partials / icp_cost2 accumulators for the stateless entry points
+static svoslam::DeviceBuffer g_misc;   // bbox partials / icp_cost2 accumulators for the stateless entry points
+static svoslam::DeviceBuffer g_misc2;  // per-workgroup rows of svoslam_icp_accumulate
 
 int svoslam_point_cloud_bbox(const float *d_points, int32_t n, float h_bbox0[3], float h_bbox1[3], void *stream) {
   NEED_DEVICE();
@@ -203,8 +204,8 @@ int svoslam_icp_accumulate(const float *d_last_vertex, const float *d_last_norma
                            const float *d_cur_normal, int32_t width, int32_t height, int32_t first_pixel,
                            int32_t num_pixels, double *d_acc, void *stream) {
   NEED_DEVICE();
-  return icp_accumulate(d_last_vertex, d_last_normal, d_cur_vertex, d_cur_normal, width, height, first_pixel, num_pixels,
-                        d_acc, S(stream));
+  return icp_accumulate(g_misc2, d_last_vertex, d_last_normal, d_cur_vertex, d_cur_normal, width, height, first_pixel,
+                        num_pixels, d_acc, S(stream));
 }
 
 int svoslam_camera_create(svoslam_camera **cam, int32_t width, int32_t height, float fx, float fy) {

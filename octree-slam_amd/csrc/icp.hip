@@ -55,7 +55,7 @@ struct CamState {
 __global__ __launch_bounds__(256) void icp_accumulate_kernel(const float *__restrict__ last_v, const float *__restrict__ last_n,
                                                              const float *__restrict__ cur_v, const float *__restrict__ cur_n,
                                                              int first, int end, const CamState *__restrict__ state,
-                                                             int use_level_start, int chain_len, double *__restrict__ acc_out) {
+                                                             int use_level_start, int chain_len, double *__restrict__ partial) {
   __shared__ double red[4][27];
   __shared__ float chain_s[(kMaxChain + 1) * 16];
   int nchain = 0;
@@ -118,7 +118,9 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const float *__rest
       }
     }
   }
-  // wave -> workgroup -> global; every partial is an integer-valued double (exact)
+  // wave -> workgroup -> one 27-double row per workgroup; every partial is an integer-valued
+  // double (exact).  Plain stores only: the rows are summed by icp_reduce_kernel in the next
+  // launch, so visibility rests on the kernel boundary alone (no cross-XCD atomics).
 #pragma unroll
   for (int i = 0; i < 27; i++) {
     double v = acc[i];
@@ -132,15 +134,35 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const float *__rest
     for (int i = 0; i < 27; i++) red[wave][i] = acc[i];
   }
   __syncthreads();
+  if (threadIdx.x < 27)
+    partial[(size_t)blockIdx.x * 27 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// acc[27] += column sums of partial[rows][27]  (one workgroup; exact integer-valued sums)
+__global__ __launch_bounds__(256) void icp_reduce_kernel(const double *__restrict__ partial, int rows,
+                                                         double *__restrict__ acc) {
+  __shared__ double red[8][27];
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  double s = 0.0;
+  if (col < 27)
+    for (int r = grp; r < rows; r += 8) s += partial[(size_t)r * 27 + col];
+  if (col < 27) red[grp][col] = s;
+  __syncthreads();
   if (threadIdx.x < 27) {
-    const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    if (s != 0.0) atomicAdd(&acc_out[threadIdx.x], s);
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; g++) t += red[g][threadIdx.x];
+    acc[threadIdx.x] += t;
   }
 }
 
+constexpr int kMaxIcpBlocks = 1024;
+
+// accumulate pixels [first, first+num) and ADD their 27 sums into d_acc (in-stream, no atomics)
 static int launch_accumulate(const float *lv, const float *ln, const float *cv, const float *cn, int w, int h, int first,
-                             int num, const CamState *state, int use_level_start, int chain_len, double *d_acc,
-                             hipStream_t s) {
+                             int num, const CamState *state, int use_level_start, int chain_len, double *d_partial,
+                             double *d_acc, hipStream_t s) {
   const int n = w * h;
   // Q15: load_size = 20*w/640; the reference reduces floor(n/load) partials, the tail is dropped
   const int load_size = 20 * w / 640;
@@ -150,17 +172,19 @@ static int launch_accumulate(const float *lv, const float *ln, const float *cv, 
   if (end > limit) end = limit;
   if (first < 0) first = 0;
   int blocks = (int)cdiv(end > first ? end - first : 1, 256 * 4);  // >= 4 pixels per lane
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > kMaxIcpBlocks) blocks = kMaxIcpBlocks;
   if (blocks < 1) blocks = 1;
-  icp_accumulate_kernel<<<blocks, 256, 0, s>>>(lv, ln, cv, cn, first, end, state, use_level_start, chain_len, d_acc);
+  icp_accumulate_kernel<<<blocks, 256, 0, s>>>(lv, ln, cv, cn, first, end, state, use_level_start, chain_len, d_partial);
+  icp_reduce_kernel<<<1, 256, 0, s>>>(d_partial, blocks, d_acc);
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
 }
 
-int icp_accumulate(const float *lv, const float *ln, const float *cv, const float *cn, int w, int h, int first, int num,
-                   double *d_acc, hipStream_t s) {
+int icp_accumulate(svoslam::DeviceBuffer &scratch, const float *lv, const float *ln, const float *cv, const float *cn,
+                   int w, int h, int first, int num, double *d_acc, hipStream_t s) {
   if (!lv || !ln || !cv || !cn || !d_acc || w <= 0 || h <= 0 || first < 0 || num < 0) return SVOSLAM_ERR_INVALID_ARG;
-  return launch_accumulate(lv, ln, cv, cn, w, h, first, num, nullptr, 0, 0, d_acc, s);
+  SVO_TRY(scratch.reserve((size_t)(kMaxIcpBlocks + 1) * 27 * sizeof(double)));
+  return launch_accumulate(lv, ln, cv, cn, w, h, first, num, nullptr, 0, 0, scratch.as<double>() + 27, d_acc, s);
 }
 
 static void icp_finish_host(const double acc[27], float A[36], float b[6]) {
@@ -177,10 +201,10 @@ static void icp_finish_host(const double acc[27], float A[36], float b[6]) {
 int icp_cost2(svoslam::DeviceBuffer &scratch, const float *lv, const float *ln, const float *cv, const float *cn, int w,
               int h, float A[36], float b[6], hipStream_t s) {
   if (!A || !b) return SVOSLAM_ERR_INVALID_ARG;
-  SVO_TRY(scratch.reserve(27 * sizeof(double)));
-  double *d_acc = scratch.as<double>();
+  SVO_TRY(scratch.reserve((size_t)(kMaxIcpBlocks + 1) * 27 * sizeof(double)));
+  double *d_acc = scratch.as<double>();  // [0,27) totals, then the per-workgroup rows
   SVO_HIP(hipMemsetAsync(d_acc, 0, 27 * sizeof(double), s));
-  SVO_TRY(icp_accumulate(lv, ln, cv, cn, w, h, 0, w * h, d_acc, s));
+  SVO_TRY(icp_accumulate(scratch, lv, ln, cv, cn, w, h, 0, w * h, d_acc, s));
   double acc[27];
   SVO_HIP(hipMemcpyAsync(acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, s));
   SVO_HIP(hipStreamSynchronize(s));
@@ -392,6 +416,7 @@ struct svoslam_camera {
   int cur = 0;  // index of the "current" set; the other is "last"
   CamState *d_state = nullptr;
   double *d_acc = nullptr;  // defaults to d_state->acc; may be redirected for multi-GPU all-reduce
+  double *d_partial = nullptr;  // per-workgroup rows of the accumulate kernel
   bool frame_has_icp = false;
 };
 
@@ -416,6 +441,7 @@ int camera_create(svoslam_camera **out, int w, int h, float fx, float fy) {
     }
   }
   SVO_HIP(hipMalloc((void **)&c->d_state, sizeof(CamState)));
+  SVO_HIP(hipMalloc((void **)&c->d_partial, (size_t)kMaxIcpBlocks * 27 * sizeof(double)));
   CamState init;
   memset(&init, 0, sizeof(init));
   init.orientation[0] = init.orientation[4] = init.orientation[8] = 1.0f;  // glm::mat3() = identity, vec3() = 0
@@ -436,6 +462,7 @@ int camera_destroy(svoslam_camera *c) {
     }
   }
   if (c->d_state) (void)hipFree(c->d_state);
+  if (c->d_partial) (void)hipFree(c->d_partial);
   delete c;
   return SVOSLAM_OK;
 }
@@ -478,7 +505,7 @@ int camera_icp_accumulate(svoslam_camera *c, int level, int iter, hipStream_t s)
   const int r0 = c->band_first >> level, r1 = (c->band_first + c->band_rows) >> level;
   const int last = 1 - c->cur;
   return launch_accumulate(c->vert[last][level], c->norm[last][level], c->vert[c->cur][level], c->norm[c->cur][level], w, h,
-                           r0 * w, (r1 - r0) * w, c->d_state, level < 2 ? 1 : 0, iter, c->d_acc, s);
+                           r0 * w, (r1 - r0) * w, c->d_state, level < 2 ? 1 : 0, iter, c->d_partial, c->d_acc, s);
 }
 
 int camera_icp_solve(svoslam_camera *c, int level, int iter, hipStream_t s) {

@@ -6,8 +6,8 @@
 struct svoslam_camera;
 
 namespace svoslam {
-int icp_accumulate(const float *lv, const float *ln, const float *cv, const float *cn, int w, int h, int first, int num,
-                   double *d_acc, hipStream_t s);
+int icp_accumulate(svoslam::DeviceBuffer &scratch, const float *lv, const float *ln, const float *cv, const float *cn,
+                   int w, int h, int first, int num, double *d_acc, hipStream_t s);
 int icp_cost2(svoslam::DeviceBuffer &scratch, const float *lv, const float *ln, const float *cv, const float *cn, int w,
               int h, float A[36], float b[6], hipStream_t s);
 int camera_icp_iters(int level);

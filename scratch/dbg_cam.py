@@ -1,0 +1,54 @@
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+import svoslam_pkg
+pkg = svoslam_pkg.load()
+import importlib
+synth = importlib.import_module("octree_slam_amd.synth")
+from oracle import oracle as ora
+w, h = 160, 120
+f = synth.focal_length(w)
+cam = pkg.Camera(w, h, f, f)
+frames = [synth.render_frame(3 * k, w, h) for k in range(2)]
+# oracle-side manual loop
+def pyr(d):
+    filt = ora.bilateral(d)
+    vs, ns = [], []
+    for i in range(3):
+        v = ora.vertex_map(filt, f, f, w, h); n = ora.normal_map(v)
+        vs.append(v); ns.append(n)
+        if i != 2: filt = ora.subsample_depth(filt)
+    return vs, ns
+d0 = frames[0][0].numpy().view(np.uint16); d1 = frames[1][0].numpy().view(np.uint16)
+lv, ln = pyr(d0); cv, cn = pyr(d1)
+cam.update(frames[0][0].cuda(), frames[0][1].cuda(), 0)
+# check last maps on GPU vs oracle pyramid of frame 0
+for lvl in range(3):
+    gv = pkg.copy_from_device(cam.last_vertex_ptr(lvl), (h >> lvl, w >> lvl, 3), np.float32)
+    gn = pkg.copy_from_device(cam.last_normal_ptr(lvl), (h >> lvl, w >> lvl, 3), np.float32)
+    print("level", lvl, "vertex equal", np.array_equal(np.nan_to_num(gv, nan=7, posinf=9), np.nan_to_num(lv[lvl], nan=7, posinf=9)),
+          "normal equal", np.array_equal(np.nan_to_num(gn, nan=7, posinf=9), np.nan_to_num(ln[lvl], nan=7, posinf=9)))
+assert cam.begin(frames[1][0].cuda(), frames[1][1].cuda(), 1) == 1
+upd = ora.mat4_identity()
+for level in (2, 1, 0):
+    fv, fn = cv[level].copy(), cn[level].copy()
+    if level < 2:
+        fv = ora.transform_vertex_map(fv, upd); fn = ora.transform_normal_map(fn, upd)
+    for it in range(pkg.PYRAMID_ITERS[level]):
+        A, b = ora.icp_cost2(lv[level], ln[level], fv, fn)
+        x = ora.solve_cholesky(A, b)
+        cam.icp_accumulate(level, it)
+        acc = pkg.copy_from_device(int(pkg.lib().svoslam_camera_acc(cam._h)), (27,), np.float64)
+        raw = ora.icp_cost2_raw(lv[level], ln[level], fv, fn)
+        cam.icp_solve(level, it)
+        gA, gb, gx = cam.last_system()
+        print(level, it, "acc equal", np.array_equal(acc, raw.astype(np.float64)), "A eq", np.array_equal(gA, A), "x eq", np.array_equal(gx, x), "lost", cam.tracking_lost_count())
+        if not np.array_equal(gx, x):
+            print("  gpu x", gx, "\n  ora x", x, "\n  acc", acc[:6], "\n  raw", raw[:6])
+        if np.isnan(x).any():
+            print("  oracle NaN -> break"); break
+        T = ora.icp_update_transform(x)
+        upd = ora.mat4_mul(T, upd)
+        if it < pkg.PYRAMID_ITERS[level] - 1:
+            fv = ora.transform_vertex_map(fv, T); fn = ora.transform_normal_map(fn, T)
+cam.end()
+print(cam.pose())
