@@ -126,6 +126,12 @@ int svoslam_cone_trace_svo(uint8_t *d_pos, int32_t width, int32_t height, float 
                            const uint32_t *d_octree, const float center[3], float size, int32_t mode,
                            unsigned long long *d_steps, void *stream);
 
+/* Row band of the same render: traces rows [row_first, row_first+rows) of the
+ * width x height frame into the full-frame buffer d_pos (multi-GPU image tiles). */
+int svoslam_cone_trace_svo_band(uint8_t *d_pos, int32_t width, int32_t height, int32_t row_first, int32_t rows,
+                                float fov, const float view[16], const uint32_t *d_octree, const float center[3],
+                                float size, int32_t mode, unsigned long long *d_steps, void *stream);
+
 /* ------------------------------------------------------------------------
  * Sensor image kernels (include/octree_slam/sensor/image_kernels.h:21-55,
  * src/sensor/image_kernels.cu)
@@ -133,6 +139,11 @@ int svoslam_cone_trace_svo(uint8_t *d_pos, int32_t width, int32_t height, float 
 /* generateVertexMap, image_kernels.h:24 / .cu:24-58 */
 int svoslam_generate_vertex_map(const uint16_t *d_depth, float *d_vertex, int32_t width, int32_t height, float fx,
                                 float fy, int32_t img_w, int32_t img_h, void *stream);
+/* same, restricted to image rows [first_row, first_row+rows) of the full-frame buffers
+ * (row band of a multi-GPU image split); pixel coordinates stay absolute */
+int svoslam_generate_vertex_map_rows(const uint16_t *d_depth, float *d_vertex, int32_t width, int32_t height,
+                                     int32_t first_row, int32_t rows, float fx, float fy, int32_t img_w, int32_t img_h,
+                                     void *stream);
 /* generateNormalMap, image_kernels.h:30 / .cu:104-139 */
 int svoslam_generate_normal_map(const float *d_vertex, float *d_normal, int32_t width, int32_t height, void *stream);
 /* bilateralFilter, image_kernels.h:34 / .cu:142-186 */
@@ -153,6 +164,10 @@ int svoslam_transform_normal_map(float *d_normal, const float trans[16], int32_t
 /* computePointCloudBoundingBox, image_kernels.h:27 / .cu:60-102.  bbox0/bbox1 are
  * host in/out (zero = unset sentinel).  Blocking. */
 int svoslam_point_cloud_bbox(const float *d_points, int32_t n, float h_bbox0[3], float h_bbox1[3], void *stream);
+/* non-blocking form for a device-resident frame loop: d_out7 = {min x,y,z, max x,y,z,
+ * any_valid} of the valid points (no "zero = unset" merge with a previous box) */
+int svoslam_point_cloud_bbox_device(svoslam_workspace *ws, const float *d_points, int32_t n, float *d_out7,
+                                    void *stream);
 
 /* ------------------------------------------------------------------------
  * ICP (include/octree_slam/sensor/localization_kernels.h:17-42,

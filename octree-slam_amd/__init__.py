@@ -73,7 +73,9 @@ SIGNATURES = {
                                               C.POINTER(_vp), C.POINTER(_i32), _vp]),
     "svoslam_free": (C.c_int, [_vp]),
     "svoslam_cone_trace_svo": (C.c_int, [_vp, _i32, _i32, _f32, _fp, _vp, _fp, _f32, _i32, _vp, _vp]),
+    "svoslam_cone_trace_svo_band": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _fp, _vp, _fp, _f32, _i32, _vp, _vp]),
     "svoslam_generate_vertex_map": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _f32, _i32, _i32, _vp]),
+    "svoslam_generate_vertex_map_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _vp]),
     "svoslam_generate_normal_map": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "svoslam_bilateral_filter": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "svoslam_subsample_depth_u16": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
@@ -85,6 +87,7 @@ SIGNATURES = {
     "svoslam_transform_normal_map": (C.c_int, [_vp, _fp, _i32, _vp]),
     "svoslam_transform_vertex_map_dmat": (C.c_int, [_vp, _vp, _i32, _vp]),
     "svoslam_point_cloud_bbox": (C.c_int, [_vp, _i32, _fp, _fp, _vp]),
+    "svoslam_point_cloud_bbox_device": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "svoslam_icp_cost2": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _fp, _fp, _vp]),
     "svoslam_icp_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "svoslam_camera_create": (C.c_int, [C.POINTER(_vp), _i32, _i32, _f32, _f32]),
@@ -281,10 +284,26 @@ def cone_trace_svo(out, fov, view, pool_ptr, center, size, mode=RENDER_REFERENCE
     return out
 
 
+def cone_trace_svo_band(out, row_first, rows, fov, view, pool_ptr, center, size, mode=RENDER_REFERENCE, counters=None):
+    """rows [row_first, row_first+rows) of the same render into the full-frame buffer `out`."""
+    h, w = int(out.shape[0]), int(out.shape[1])
+    check(lib().svoslam_cone_trace_svo_band(_ptr(out), w, h, int(row_first), int(rows), float(fov), _fa(view, 16),
+                                            C.c_void_p(int(pool_ptr)), _fa(center, 3), float(size), int(mode),
+                                            _ptr(counters), _stream()))
+    return out
+
+
 # ----------------------------------------------------------------------------- sensor
 def generate_vertex_map(depth, out, fx, fy, img_w, img_h):
     h, w = int(depth.shape[0]), int(depth.shape[1])
     check(lib().svoslam_generate_vertex_map(_ptr(depth), _ptr(out), w, h, float(fx), float(fy), img_w, img_h, _stream()))
+    return out
+
+
+def generate_vertex_map_rows(depth, out, first_row, rows, fx, fy, img_w, img_h):
+    h, w = int(depth.shape[0]), int(depth.shape[1])
+    check(lib().svoslam_generate_vertex_map_rows(_ptr(depth), _ptr(out), w, h, int(first_row), int(rows), float(fx), float(fy),
+                                                 img_w, img_h, _stream()))
     return out
 
 
@@ -333,6 +352,11 @@ def point_cloud_bbox(points, bbox0=(0, 0, 0), bbox1=(0, 0, 0)):
     b0, b1 = _fa(bbox0, 3), _fa(bbox1, 3)
     check(lib().svoslam_point_cloud_bbox(_ptr(points), int(points.numel() // 3), b0, b1, _stream()))
     return np.array(list(b0), np.float32), np.array(list(b1), np.float32)
+
+
+def point_cloud_bbox_device(ws, points, out7):
+    check(lib().svoslam_point_cloud_bbox_device(ws._h, _ptr(points), int(points.numel() // 3), _ptr(out7), _stream()))
+    return out7
 
 
 def icp_cost2(last_v, last_n, cur_v, cur_n):

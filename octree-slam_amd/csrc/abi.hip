@@ -137,13 +137,25 @@ int svoslam_cone_trace_svo(uint8_t *d_pos, int32_t width, int32_t height, float 
                            const uint32_t *d_octree, const float center[3], float size, int32_t mode,
                            unsigned long long *d_steps, void *stream) {
   NEED_DEVICE();
-  return cone_trace_svo(d_pos, width, height, fov, view, d_octree, center, size, mode, d_steps, S(stream));
+  return cone_trace_svo(d_pos, width, height, 0, height, fov, view, d_octree, center, size, mode, d_steps, S(stream));
+}
+
+int svoslam_cone_trace_svo_band(uint8_t *d_pos, int32_t width, int32_t height, int32_t row_first, int32_t rows, float fov,
+                                const float view[16], const uint32_t *d_octree, const float center[3], float size,
+                                int32_t mode, unsigned long long *d_steps, void *stream) {
+  NEED_DEVICE();
+  return cone_trace_svo(d_pos, width, height, row_first, rows, fov, view, d_octree, center, size, mode, d_steps, S(stream));
 }
 
 int svoslam_generate_vertex_map(const uint16_t *d_depth, float *d_vertex, int32_t width, int32_t height, float fx, float fy,
                                 int32_t img_w, int32_t img_h, void *stream) {
   NEED_DEVICE();
   return generate_vertex_map(d_depth, d_vertex, width, height, fx, fy, img_w, img_h, S(stream));
+}
+int svoslam_generate_vertex_map_rows(const uint16_t *d_depth, float *d_vertex, int32_t width, int32_t height, int32_t first_row,
+                                     int32_t rows, float fx, float fy, int32_t img_w, int32_t img_h, void *stream) {
+  NEED_DEVICE();
+  return generate_vertex_map_rows(d_depth, d_vertex, width, height, first_row, rows, fx, fy, img_w, img_h, S(stream));
 }
 int svoslam_generate_normal_map(const float *d_vertex, float *d_normal, int32_t width, int32_t height, void *stream) {
   NEED_DEVICE();
@@ -192,6 +204,12 @@ static svoslam::DeviceBuffer g_misc2;  // per-workgroup rows of svoslam_icp_accu
 int svoslam_point_cloud_bbox(const float *d_points, int32_t n, float h_bbox0[3], float h_bbox1[3], void *stream) {
   NEED_DEVICE();
   return point_cloud_bbox(g_misc, d_points, n, h_bbox0, h_bbox1, S(stream));
+}
+
+int svoslam_point_cloud_bbox_device(svoslam_workspace *ws, const float *d_points, int32_t n, float *d_out7, void *stream) {
+  NEED_DEVICE();
+  if (!ws) return SVOSLAM_ERR_INVALID_ARG;
+  return point_cloud_bbox_device(ws->misc, d_points, n, d_out7, S(stream));
 }
 
 int svoslam_icp_cost2(const float *d_last_vertex, const float *d_last_normal, const float *d_cur_vertex,

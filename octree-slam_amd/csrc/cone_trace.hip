@@ -48,6 +48,7 @@ struct TraceParams {
   float center[3];
   float size, pix_scale;
   int width, height, mode;
+  int row_first, row_end;  // rows [row_first, row_end) are traced (row band of a multi-GPU tile split)
 };
 
 __global__ __launch_bounds__(256) void cone_trace_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
@@ -55,9 +56,9 @@ __global__ __launch_bounds__(256) void cone_trace_kernel(uchar4 *__restrict__ po
   // 16x16 pixel workgroup, one 8x8 tile per wavefront
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const int px = blockIdx.x * 16 + (int)(wave & 1u) * 8 + (int)(lane & 7u);
-  const int py = blockIdx.y * 16 + (int)(wave >> 1) * 8 + (int)(lane >> 3);
+  const int py = P.row_first + blockIdx.y * 16 + (int)(wave >> 1) * 8 + (int)(lane >> 3);
   unsigned long long my_steps = 0, my_levels = 0;
-  if (px < P.width && py < P.height) {
+  if (px < P.width && py < P.row_end) {
     const int idx = py * P.width + px;
     // createRays :29-51 (hard-coded Kinect focal lengths; fov is unused there)
     const float res_x = (float)P.width, res_y = (float)P.height;
@@ -148,9 +149,12 @@ __global__ __launch_bounds__(256) void cone_trace_kernel(uchar4 *__restrict__ po
 // ---- host side: glm::inverse(view) products of :161-167, pix_scale of :171 ----
 static void mat4_inverse_host(const float *m, float *out);  // below
 
-int cone_trace_svo(uint8_t *d_pos, int width, int height, float fov, const float view[16], const uint32_t *d_octree,
-                   const float center[3], float size, int mode, unsigned long long *d_steps, hipStream_t stream) {
+int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int rows, float fov, const float view[16],
+                   const uint32_t *d_octree, const float center[3], float size, int mode, unsigned long long *d_steps,
+                   hipStream_t stream) {
   if (!d_pos || !view || !d_octree || !center || width <= 0 || height <= 0) return SVOSLAM_ERR_INVALID_ARG;
+  if (row_first < 0 || rows < 0 || row_first + rows > height) return SVOSLAM_ERR_INVALID_ARG;
+  if (rows == 0) return SVOSLAM_OK;
   if (mode != SVOSLAM_RENDER_REFERENCE && mode != SVOSLAM_RENDER_CARRY) return SVOSLAM_ERR_INVALID_ARG;
   float inv[16];
   mat4_inverse_host(view, inv);
@@ -162,7 +166,8 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, float fov, const float
   P.size = size;
   P.pix_scale = tanf(fov * 3.14159f / 180.0f) / (float)height;
   P.width = width; P.height = height; P.mode = mode;
-  dim3 grid(cdiv(width, 16), cdiv(height, 16));
+  P.row_first = row_first; P.row_end = row_first + rows;
+  dim3 grid(cdiv(width, 16), cdiv(rows, 16));
   cone_trace_kernel<<<grid, 256, 0, stream>>>(reinterpret_cast<uchar4 *>(d_pos), d_octree, P, d_steps);
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;

@@ -3,6 +3,8 @@
 #include "common.hpp"
 
 namespace svoslam {
-int cone_trace_svo(uint8_t *d_pos, int width, int height, float fov, const float view[16], const uint32_t *d_octree,
-                   const float center[3], float size, int mode, unsigned long long *d_steps, hipStream_t stream);
+// traces image rows [row_first, row_first + rows) of a width x height frame into d_pos (full-frame buffer)
+int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int rows, float fov, const float view[16],
+                   const uint32_t *d_octree, const float center[3], float size, int mode, unsigned long long *d_steps,
+                   hipStream_t stream);
 }  // namespace svoslam

@@ -21,9 +21,10 @@ __device__ inline void vertex_from_depth(int depth, int x, int y, int width, int
 }
 
 __global__ __launch_bounds__(256) void vertex_map_kernel(const uint16_t *__restrict__ depth, float *__restrict__ vmap,
-                                                         int width, int height, float fx, float fy, int img_w, int img_h) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= width * height) return;
+                                                         int width, int height, float fx, float fy, int img_w, int img_h,
+                                                         int first_idx, int end_idx) {
+  const int idx = first_idx + blockIdx.x * 256 + threadIdx.x;
+  if (idx >= end_idx) return;
   float vx, vy, vz;
   vertex_from_depth(depth[idx], idx % width, idx / width, width, height, fx, fy, img_w, img_h, vx, vy, vz);
   vmap[3 * (size_t)idx] = vx; vmap[3 * (size_t)idx + 1] = vy; vmap[3 * (size_t)idx + 2] = vz;
@@ -253,7 +254,18 @@ __global__ void bbox_final_kernel(const float *__restrict__ partial, int blocks,
 int generate_vertex_map(const uint16_t *d_depth, float *d_vertex, int w, int h, float fx, float fy, int img_w, int img_h, hipStream_t s) {
   CHECK_DIMS(w, h);
   if (!d_depth || !d_vertex) return SVOSLAM_ERR_INVALID_ARG;
-  vertex_map_kernel<<<cdiv((long long)w * h, 256), 256, 0, s>>>(d_depth, d_vertex, w, h, fx, fy, img_w, img_h);
+  vertex_map_kernel<<<cdiv((long long)w * h, 256), 256, 0, s>>>(d_depth, d_vertex, w, h, fx, fy, img_w, img_h, 0, w * h);
+  SVO_LAUNCH_CHECK();
+  return SVOSLAM_OK;
+}
+
+int generate_vertex_map_rows(const uint16_t *d_depth, float *d_vertex, int w, int h, int first_row, int rows, float fx,
+                             float fy, int img_w, int img_h, hipStream_t s) {
+  CHECK_DIMS(w, h);
+  if (!d_depth || !d_vertex || first_row < 0 || rows < 0 || first_row + rows > h) return SVOSLAM_ERR_INVALID_ARG;
+  if (rows == 0) return SVOSLAM_OK;
+  vertex_map_kernel<<<cdiv((long long)w * rows, 256), 256, 0, s>>>(d_depth, d_vertex, w, h, fx, fy, img_w, img_h, first_row * w,
+                                                                  (first_row + rows) * w);
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
 }
@@ -355,17 +367,24 @@ int transform_vertex_map_dmat(float *d_v, const float *d_trans, int n, hipStream
   return SVOSLAM_OK;
 }
 
+int point_cloud_bbox_device(svoslam::DeviceBuffer &scratch, const float *d_points, int n, float *d_out7, hipStream_t s) {
+  if (!d_points || !d_out7 || n <= 0) return SVOSLAM_ERR_INVALID_ARG;
+  int blocks = (int)cdiv(n, 256);
+  if (blocks > 1024) blocks = 1024;
+  SVO_TRY(scratch.reserve((size_t)(1024 + 1) * 7 * 4));
+  float *partial = scratch.as<float>() + 7;
+  bbox_partial_kernel<<<blocks, 256, 0, s>>>(d_points, n, partial);
+  bbox_final_kernel<<<1, 64, 0, s>>>(partial, blocks, d_out7);
+  SVO_LAUNCH_CHECK();
+  return SVOSLAM_OK;
+}
+
 int point_cloud_bbox(svoslam::DeviceBuffer &scratch, const float *d_points, int n, float h_bbox0[3], float h_bbox1[3], hipStream_t s) {
   if (!d_points || !h_bbox0 || !h_bbox1 || n < 0) return SVOSLAM_ERR_INVALID_ARG;
   if (n == 0) return SVOSLAM_OK;
-  int blocks = (int)cdiv(n, 256);
-  if (blocks > 1024) blocks = 1024;
-  SVO_TRY(scratch.reserve((size_t)(blocks + 1) * 7 * 4));
-  float *partial = scratch.as<float>();
-  float *result = partial + (size_t)blocks * 7;
-  bbox_partial_kernel<<<blocks, 256, 0, s>>>(d_points, n, partial);
-  bbox_final_kernel<<<1, 64, 0, s>>>(partial, blocks, result);
-  SVO_LAUNCH_CHECK();
+  SVO_TRY(scratch.reserve((size_t)(1024 + 1) * 7 * 4));
+  float *result = scratch.as<float>();
+  SVO_TRY(point_cloud_bbox_device(scratch, d_points, n, result, s));
   float r[7];
   SVO_HIP(hipMemcpyAsync(r, result, sizeof(r), hipMemcpyDeviceToHost, s));
   SVO_HIP(hipStreamSynchronize(s));

@@ -5,6 +5,8 @@
 
 namespace svoslam {
 int generate_vertex_map(const uint16_t *d_depth, float *d_vertex, int w, int h, float fx, float fy, int img_w, int img_h, hipStream_t s);
+int generate_vertex_map_rows(const uint16_t *d_depth, float *d_vertex, int w, int h, int first_row, int rows, float fx, float fy,
+                             int img_w, int img_h, hipStream_t s);
 int generate_normal_map(const float *d_vertex, float *d_normal, int w, int h, hipStream_t s);
 // fused vertex + normal map straight from the depth image (same values as the two calls above)
 int generate_vertex_normal_maps(const uint16_t *d_depth, float *d_vertex, float *d_normal, int w, int h, float fx, float fy,
@@ -20,5 +22,7 @@ int color_to_intensity(const uint8_t *d_rgb, float *d_out, int n, hipStream_t s)
 int transform_vertex_map(float *d_v, const float trans[16], int n, hipStream_t s);
 int transform_normal_map(float *d_v, const float trans[16], int n, hipStream_t s);
 int transform_vertex_map_dmat(float *d_v, const float *d_trans, int n, hipStream_t s);
+// non-blocking: d_out7 = {min x,y,z, max x,y,z, any_valid} on the device
+int point_cloud_bbox_device(svoslam::DeviceBuffer &scratch, const float *d_points, int n, float *d_out7, hipStream_t s);
 int point_cloud_bbox(svoslam::DeviceBuffer &scratch, const float *d_points, int n, float h_bbox0[3], float h_bbox1[3], hipStream_t s);
 }  // namespace svoslam

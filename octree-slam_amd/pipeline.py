@@ -1,0 +1,179 @@
+"""One SLAM frame = the body of mainLoop() (src/main.cpp:31-84) with the tracker
+call of main.cpp:35 enabled:
+
+    camera_estimation_->update(rawFrame)                      RGBDCamera::update      rgbd_camera.cpp:53
+    generateVertexMap(raw depth -> points_)                   main.cpp:39
+    transformVertexMap(points_, mat4(orientation)*T(position)) main.cpp:40
+    computePointCloudBoundingBox(points_)                     main.cpp:43
+    scene_->addPointCloudToOctree(...) -> svoFromPointCloud   main.cpp:44 / octree.cpp:290
+    cuda_renderer_->coneTraceSVO(svo, camera)                 main.cpp:56-58
+
+Single GPU: everything is enqueued on the current stream; the only host round
+trip of a frame is the 76-byte split-count readback inside the fusion call.
+
+Several GPUs (one process per GPU, torch.distributed over RCCL): the image is cut
+into row bands.  Each rank accumulates the ICP normal equations of its band and
+the 27 exact fixed-point sums are all-reduced (float64 sum: integer-valued, so
+every rank gets the same bits in any reduction order); each rank back-projects
+and transforms its band of points and the bands are all-gathered, after which
+every rank applies the same fusion to its full replica of the node pool (replicas
+stay byte-identical); each rank ray-marches its band of the output image.
+"""
+import numpy as np
+import torch
+
+import octree_slam_amd as pkg
+
+FOV = 45.0  # glfw_camera_controller.h:13 default
+
+
+def band_rows(height, rank, world):
+    """Contiguous row band [first, first+rows) of rank `rank`."""
+    base, rem = divmod(height, world)
+    first = rank * base + min(rank, rem)
+    rows = base + (1 if rank < rem else 0)
+    return first, rows
+
+
+class DistContext:
+    """Thin torch.distributed wrapper (backend nccl == RCCL on ROCm; gloo for the CPU tests)."""
+
+    def __init__(self, rank=0, world=1, group=None):
+        self.rank, self.world, self.group = rank, world, group
+
+    @property
+    def enabled(self):
+        return self.world > 1
+
+    def all_reduce_sum(self, t):
+        if self.enabled:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def all_gather_rows(self, full, height):
+        """`full` is [height, ...]; each rank has filled its own band; returns with all bands filled.
+        Bands may differ by one row, so gather into per-rank views of padded size."""
+        if not self.enabled:
+            return full
+        import torch.distributed as dist
+        base, rem = divmod(height, self.world)
+        maxrows = base + (1 if rem else 0)
+        first, rows = band_rows(height, self.rank, self.world)
+        row_shape = tuple(full.shape[1:])
+        send = torch.zeros((maxrows,) + row_shape, dtype=full.dtype, device=full.device)
+        send[:rows] = full[first:first + rows]
+        recv = torch.empty((self.world * maxrows,) + row_shape, dtype=full.dtype, device=full.device)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        for r in range(self.world):
+            f, n = band_rows(height, r, self.world)
+            full[f:f + n] = recv[r * maxrows:r * maxrows + n]
+        return full
+
+
+class SlamPipeline:
+    def __init__(self, width, height, max_depth, center, half_edge, render_mode=pkg.RENDER_REFERENCE, dist=None,
+                 pool_capacity_nodes=1 << 20, count_steps=False):
+        self.w, self.h, self.depth = width, height, max_depth
+        self.center, self.edge = tuple(float(c) for c in center), float(half_edge)
+        self.mode = render_mode
+        self.dist = dist or DistContext()
+        self.focal = 570.3 * width / 640.0
+        self.cam = pkg.Camera(width, height, self.focal, self.focal)
+        self.ws = pkg.Workspace()
+        self.pool = pkg.Pool(pool_capacity_nodes)
+        dev = "cuda"
+        self.points = torch.empty((height, width, 3), dtype=torch.float32, device=dev)
+        self.bbox = torch.zeros(7, dtype=torch.float32, device=dev)
+        self.image = torch.zeros((height, width, 4), dtype=torch.uint8, device=dev)
+        self.counters = torch.zeros(2, dtype=torch.int64, device=dev) if count_steps else None
+        self.first, self.rows = band_rows(height, self.dist.rank, self.dist.world)
+        if self.dist.enabled:
+            self.acc = torch.zeros(27, dtype=torch.float64, device=dev)
+            self.cam.set_acc(self.acc)
+            self.cam.set_band(self.first, self.rows)
+        self.last_stats = None
+
+    # -- stages (each enqueues on the current stream) -------------------------------------
+    def track(self, depth, rgb, timestamp):
+        if not self.dist.enabled:
+            return self.cam.update(depth, rgb, timestamp)
+        used = self.cam.begin(depth, rgb, timestamp)
+        if used:
+            for level in (2, 1, 0):
+                for it in range(pkg.PYRAMID_ITERS[level]):
+                    self.cam.icp_accumulate(level, it)      # this rank's row band
+                    self.dist.all_reduce_sum(self.acc)      # 27 x float64 over xGMI, exact
+                    self.cam.icp_solve(level, it)           # every rank: same 6x6 solve, same bits
+            self.cam.end()
+        return used
+
+    def backproject(self, depth):
+        if not self.dist.enabled:
+            pkg.generate_vertex_map(depth, self.points, self.focal, self.focal, self.w, self.h)
+            pkg.transform_vertex_map_dmat(self.points, self.cam.fusion_transform_ptr())
+        else:
+            # this rank's row band only (absolute pixel coordinates), then all-gather the bands
+            pkg.generate_vertex_map_rows(depth, self.points, self.first, self.rows, self.focal, self.focal, self.w, self.h)
+            pkg.transform_vertex_map_dmat(self.points[self.first:self.first + self.rows], self.cam.fusion_transform_ptr())
+            self.dist.all_gather_rows(self.points, self.h)
+        pkg.point_cloud_bbox_device(self.ws, self.points, self.bbox)
+
+    def fuse(self, rgb):
+        self.last_stats = pkg.svo_from_point_cloud(self.ws, self.points.view(-1, 3), rgb.view(-1, 3), self.depth, self.pool,
+                                                   self.center, self.edge)
+        return self.last_stats
+
+    def render(self, view):
+        if not self.dist.enabled:
+            pkg.cone_trace_svo(self.image, FOV, view, self.pool.data_ptr, self.center, self.edge, self.mode, self.counters)
+        else:
+            pkg.cone_trace_svo_band(self.image, self.first, self.rows, FOV, view, self.pool.data_ptr, self.center, self.edge,
+                                    self.mode, self.counters)
+        return self.image
+
+    def frame(self, depth, rgb, timestamp, view):
+        self.track(depth, rgb, timestamp)
+        self.backproject(depth)
+        self.fuse(rgb)
+        return self.render(view)
+
+
+def ground_truth_view(frame, synth):
+    """View matrix (glm lookAt convention) of the synthetic sensor pose of `frame`, expressed in the map
+    frame = camera frame of frame 0 (the tracker starts at identity)."""
+    (p0, yaw0), (pk, yawk) = synth.camera_pose(0), synth.camera_pose(frame)
+    c0, s0 = np.cos(yaw0), np.sin(yaw0)
+
+    def to_map(v):  # R0^T v with R0 = yaw about +y, camera forward +z
+        x, y, z = v
+        return np.array([c0 * x - s0 * z, y, s0 * x + c0 * z])
+
+    eye = to_map(np.array(pk) - np.array(p0))
+    fwd = to_map(np.array([np.sin(yawk), 0.0, np.cos(yawk)]))
+    return look_at(eye, eye + fwd, (0.0, 1.0, 0.0))
+
+
+def look_at(eye, center, up):
+    """glm::lookAt (gtc/matrix_transform.inl:416-441), float32, column-major flat[16]."""
+    f32 = np.float32
+    eye, center, up = (np.asarray(a, f32) for a in (eye, center, up))
+
+    def norm(v):
+        return (v * (f32(1.0) / np.sqrt(f32((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])))).astype(f32)
+
+    def cross(x, y):
+        return np.array([x[1] * y[2] - y[1] * x[2], x[2] * y[0] - y[2] * x[0], x[0] * y[1] - y[0] * x[1]], f32)
+
+    def dot(a, b):
+        return f32((a[0] * b[0] + a[1] * b[1]) + a[2] * b[2])
+
+    f = norm(center - eye)
+    s = norm(cross(f, up))
+    u = cross(s, f)
+    m = np.zeros((4, 4), f32)  # m[col][row]
+    m[0] = [s[0], u[0], -f[0], 0]
+    m[1] = [s[1], u[1], -f[1], 0]
+    m[2] = [s[2], u[2], -f[2], 0]
+    m[3] = [-dot(s, eye), -dot(u, eye), dot(f, eye), 1]
+    return m.reshape(16)

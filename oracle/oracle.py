@@ -206,12 +206,16 @@ class Pool:
 # ------------------------------------------------------------------ render
 def cone_trace(words, w, h, fov, view, center, size, mode=RENDER_REFERENCE, L=None):
     L = L or lib()
-    words = np.ascontiguousarray(words, dtype=np.uint32)
+    if isinstance(words, Pool):          # walk the oracle's own pool in place (no copy)
+        wptr = words._p.data
+    else:
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        wptr = _p(words, C.c_uint32)
     view = _f32(view).reshape(16)
     c = _f32(center)
     pos = np.zeros((h, w, 4), dtype=np.uint8)
     lv = C.c_int64(0)
-    steps = L.ora_cone_trace_svo(_p(pos, C.c_uint8), w, h, fov, _p(view, C.c_float), _p(words, C.c_uint32),
+    steps = L.ora_cone_trace_svo(_p(pos, C.c_uint8), w, h, fov, _p(view, C.c_float), wptr,
                                  _p(c, C.c_float), size, mode, C.byref(lv))
     return pos, int(steps), int(lv.value)
 
