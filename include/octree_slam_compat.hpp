@@ -1,0 +1,175 @@
+// octree_slam_compat.hpp -- header-only C++ shim that re-exposes the reference's GPU kernel
+// API (same names, argument order and meaning) on top of the C ABI of include/svoslam.h, so
+// callers written like the reference's octree.cpp / rgbd_camera.cpp / cuda_renderer.cpp compile
+// against libsvoslam_hip.so unchanged.  glm is not required: vec2/vec3/vec4/mat4 below are
+// layout-compatible PODs (glm::vec3 = 12 packed bytes, glm::mat4 = 16 floats column-major).
+//
+// Reference declarations mirrored:
+//   include/octree_slam/world/svo/svo.h:14-18
+//   include/octree_slam/rendering/cone_tracing_kernels.h:16
+//   include/octree_slam/sensor/image_kernels.h:21-55
+//   include/octree_slam/sensor/localization_kernels.h:17-42
+//   include/octree_slam/timing_utils.h:5-10
+#pragma once
+
+#include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+#include "svoslam.h"
+
+namespace octree_slam {
+
+struct vec2 { float x, y; };
+struct vec3 { float x, y, z; };
+struct vec4 { float x, y, z, w; };
+struct mat4 { float m[16]; };  // column-major, m[4*col + row]
+struct int2_t { int x, y; };
+struct uchar4_t { unsigned char x, y, z, w; };
+
+struct Color256 { uint8_t r, g, b; };                         // common_types.h:49-53
+struct BoundingBox { vec3 bbox0{0, 0, 0}, bbox1{0, 0, 0}; };  // common_types.h:8-18
+struct VoxelGrid {                                            // common_types.h:55-63
+  vec4 *centers = nullptr;
+  vec4 *colors = nullptr;
+  int size = 0;
+  float scale = 0.0f;
+  BoundingBox bbox;
+  ~VoxelGrid() { if (size > 0) { svoslam_free(centers); svoslam_free(colors); } }
+};
+struct SVO { unsigned int *data; vec3 center; float size; };  // common_types.h:75-79
+
+namespace detail {
+inline void check(int status, const char *what) {
+  if (status != SVOSLAM_OK)
+    throw std::runtime_error(std::string(what) + ": " + svoslam_status_string(status) + " (" + svoslam_last_error() + ")");
+}
+// The reference passes the pool as `unsigned int*& octree, int& octree_size`; capacity is kept here.
+struct Registry {
+  std::mutex mu;
+  std::map<unsigned int *, int> capacity;
+  svoslam_workspace *ws = nullptr;
+  static Registry &get() { static Registry r; return r; }
+  svoslam_workspace *workspace() {
+    if (!ws) check(svoslam_workspace_create(&ws), "svoslam_workspace_create");
+    return ws;
+  }
+  svoslam_pool open(unsigned int *data, int size) {
+    std::lock_guard<std::mutex> g(mu);
+    svoslam_pool p{data, size, size};
+    auto it = capacity.find(data);
+    if (it != capacity.end() && it->second >= size) p.capacity = it->second;
+    return p;
+  }
+  void close(unsigned int *old_data, const svoslam_pool &p) {
+    std::lock_guard<std::mutex> g(mu);
+    if (old_data != p.d_data) capacity.erase(old_data);
+    capacity[p.d_data] = p.capacity;
+  }
+};
+}  // namespace detail
+
+namespace svo {
+// svo.h:16 / svo.cu:642-696.  `octree` may be replaced by a larger allocation (the old one is freed),
+// `octree_size` is updated, exactly as the reference does; the caller frees with cudaFree/hipFree.
+inline void svoFromPointCloud(const vec3 *points, const Color256 *colors, const int size, const int max_depth,
+                              unsigned int *&octree, int &octree_size, vec3 octree_center, const float edge_length,
+                              void * /*cudaArray* d_bricks*/ = nullptr) {
+  auto &r = detail::Registry::get();
+  svoslam_pool p = r.open(octree, octree_size);
+  unsigned int *old = octree;
+  const float c[3] = {octree_center.x, octree_center.y, octree_center.z};
+  detail::check(svoslam_svo_from_point_cloud(r.workspace(), &points->x, &colors->r, size, max_depth, &p, c, edge_length,
+                                             nullptr, nullptr), "svoFromPointCloud");
+  r.close(old, p);
+  octree = p.d_data;
+  octree_size = p.size;
+}
+// svo.h:14 / svo.cu:584-640
+inline void svoFromVoxelGrid(const VoxelGrid &grid, const int max_depth, unsigned int *&octree, int &octree_size,
+                             vec3 octree_center, const float edge_length, void * = nullptr) {
+  auto &r = detail::Registry::get();
+  svoslam_pool p = r.open(octree, octree_size);
+  unsigned int *old = octree;
+  const float c[3] = {octree_center.x, octree_center.y, octree_center.z};
+  detail::check(svoslam_svo_from_voxel_grid(r.workspace(), &grid.centers->x, &grid.colors->x, grid.size, max_depth, &p, c,
+                                            edge_length, nullptr, nullptr), "svoFromVoxelGrid");
+  r.close(old, p);
+  octree = p.d_data;
+  octree_size = p.size;
+}
+// svo.h:18 / svo.cu:699-745
+inline void extractVoxelGridFromSVO(unsigned int *&octree, int &octree_size, const int max_depth, const vec3 center,
+                                    float edge_length, VoxelGrid &grid) {
+  auto &r = detail::Registry::get();
+  svoslam_pool p = r.open(octree, octree_size);
+  const float c[3] = {center.x, center.y, center.z};
+  float *ce = nullptr, *co = nullptr;
+  int32_t n = 0;
+  detail::check(svoslam_extract_voxel_grid(r.workspace(), &p, max_depth, c, edge_length, &ce, &co, &n, nullptr),
+                "extractVoxelGridFromSVO");
+  grid.centers = reinterpret_cast<vec4 *>(ce);
+  grid.colors = reinterpret_cast<vec4 *>(co);
+  grid.size = n;
+}
+}  // namespace svo
+
+namespace rendering {
+// cone_tracing_kernels.h:16 / cone_tracing_kernels.cu:157-198 (pos = mapped PBO in the reference,
+// any device uchar4 buffer here)
+inline void coneTraceSVO(uchar4_t *pos, vec2 resolution, float fov, mat4 cameraPose, SVO octree) {
+  const float c[3] = {octree.center.x, octree.center.y, octree.center.z};
+  detail::check(svoslam_cone_trace_svo(&pos->x, (int)resolution.x, (int)resolution.y, fov, cameraPose.m, octree.data, c,
+                                       octree.size, SVOSLAM_RENDER_REFERENCE, nullptr, nullptr), "coneTraceSVO");
+}
+}  // namespace rendering
+
+namespace sensor {
+struct ICPFrame {  // localization_kernels.h:17-24
+  ICPFrame(const int w, const int h) : width(w), height(h) {
+    detail::check(svoslam_malloc((void **)&vertex, sizeof(vec3) * (size_t)w * h), "ICPFrame");
+    detail::check(svoslam_malloc((void **)&normal, sizeof(vec3) * (size_t)w * h), "ICPFrame");
+  }
+  ~ICPFrame() { svoslam_free(vertex); svoslam_free(normal); }
+  vec3 *vertex; vec3 *normal; int width; int height;
+};
+// image_kernels.h:24-55
+inline void generateVertexMap(const uint16_t *depth_pixels, vec3 *vertex_map, const int width, const int height,
+                              const vec2 focal_length, const int2_t img_size) {
+  detail::check(svoslam_generate_vertex_map(depth_pixels, &vertex_map->x, width, height, focal_length.x, focal_length.y,
+                                            img_size.x, img_size.y, nullptr), "generateVertexMap");
+}
+inline void generateNormalMap(const vec3 *vertex_map, vec3 *normal_map, const int width, const int height) {
+  detail::check(svoslam_generate_normal_map(&vertex_map->x, &normal_map->x, width, height, nullptr), "generateNormalMap");
+}
+inline void bilateralFilter(const uint16_t *depth_in, uint16_t *filtered_out, const int width, const int height) {
+  detail::check(svoslam_bilateral_filter(depth_in, filtered_out, width, height, nullptr), "bilateralFilter");
+}
+inline void computePointCloudBoundingBox(vec3 *points, const int num_points, BoundingBox &bbox) {
+  detail::check(svoslam_point_cloud_bbox(&points->x, num_points, &bbox.bbox0.x, &bbox.bbox1.x, nullptr),
+                "computePointCloudBoundingBox");
+}
+inline void transformVertexMap(vec3 *vertex_map, const mat4 &trans, const int size) {
+  detail::check(svoslam_transform_vertex_map(&vertex_map->x, trans.m, size, nullptr), "transformVertexMap");
+}
+inline void transformNormalMap(vec3 *normal_map, const mat4 &trans, const int size) {
+  detail::check(svoslam_transform_normal_map(&normal_map->x, trans.m, size, nullptr), "transformNormalMap");
+}
+inline void colorToIntensity(const Color256 *color_in, float *intensity_out, const int size) {
+  detail::check(svoslam_color_to_intensity(&color_in->r, intensity_out, size, nullptr), "colorToIntensity");
+}
+// localization_kernels.h:39 : A (36) and b (6) are host arrays
+inline void computeICPCost2(const ICPFrame *last_frame, const ICPFrame &this_frame, float *A, float *b) {
+  detail::check(svoslam_icp_cost2(&last_frame->vertex->x, &last_frame->normal->x, &this_frame.vertex->x, &this_frame.normal->x,
+                                  this_frame.width, this_frame.height, A, b, nullptr), "computeICPCost2");
+}
+}  // namespace sensor
+
+// timing_utils.h:5-10
+inline void startTiming() { detail::check(svoslam_timer_start(nullptr), "startTiming"); }
+inline float stopTiming() { float ms = 0; detail::check(svoslam_timer_stop(nullptr, &ms), "stopTiming"); return ms; }
+
+}  // namespace octree_slam

@@ -109,6 +109,8 @@ int svoslam_extract_voxel_grid(svoslam_workspace *ws, const svoslam_pool *pool, 
                                const float center[3], float edge_length, float **d_centers, float **d_colors,
                                int32_t *n_out, void *stream);
 int svoslam_free(void *d_ptr);
+/* device allocation for callers that do not link the HIP runtime themselves */
+int svoslam_malloc(void **d_ptr, size_t bytes);
 
 /* ------------------------------------------------------------------------
  * Rendering

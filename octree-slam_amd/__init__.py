@@ -72,6 +72,7 @@ SIGNATURES = {
     "svoslam_extract_voxel_grid": (C.c_int, [_vp, C.POINTER(_PoolStruct), _i32, _fp, _f32, C.POINTER(_vp),
                                               C.POINTER(_vp), C.POINTER(_i32), _vp]),
     "svoslam_free": (C.c_int, [_vp]),
+    "svoslam_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "svoslam_cone_trace_svo": (C.c_int, [_vp, _i32, _i32, _f32, _fp, _vp, _fp, _f32, _i32, _vp, _vp]),
     "svoslam_cone_trace_svo_band": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _fp, _vp, _fp, _f32, _i32, _vp, _vp]),
     "svoslam_generate_vertex_map": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _f32, _i32, _i32, _vp]),

@@ -133,6 +133,13 @@ int svoslam_free(void *d_ptr) {
   return SVOSLAM_OK;
 }
 
+int svoslam_malloc(void **d_ptr, size_t bytes) {
+  NEED_DEVICE();
+  if (!d_ptr) return SVOSLAM_ERR_INVALID_ARG;
+  SVO_HIP(hipMalloc(d_ptr, bytes));
+  return SVOSLAM_OK;
+}
+
 int svoslam_cone_trace_svo(uint8_t *d_pos, int32_t width, int32_t height, float fov, const float view[16],
                            const uint32_t *d_octree, const float center[3], float size, int32_t mode,
                            unsigned long long *d_steps, void *stream) {

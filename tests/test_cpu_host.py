@@ -156,3 +156,32 @@ def test_synth_stream_is_deterministic_and_plausible():
     valid = d[d > 0]
     assert 400 < valid.min() and valid.max() < 6000       # inside the 6 x 3 x 6 m room
     assert c1.shape == (120, 160, 3)
+
+
+def test_compat_header_compiles(tmp_path):
+    """the reference-signature C++ shim compiles and links against the library with plain g++"""
+    import subprocess
+    pkg = load_pkg()
+    src = tmp_path / "host.cpp"
+    src.write_text('''
+#include "octree_slam_compat.hpp"
+using namespace octree_slam;
+void fuse_and_render(const vec3* d_points, const Color256* d_colors, int n, uchar4_t* d_image) {
+  static unsigned int* pool = nullptr; static int pool_size = 0;
+  svo::svoFromPointCloud(d_points, d_colors, n, 12, pool, pool_size, vec3{0, 1.5f, 0}, 4.096f);
+  mat4 view = {};
+  rendering::coneTraceSVO(d_image, vec2{640, 480}, 45.0f, view, SVO{pool, vec3{0, 1.5f, 0}, 4.096f});
+  VoxelGrid grid; svo::extractVoxelGridFromSVO(pool, pool_size, 12, vec3{0, 1.5f, 0}, 4.096f, grid);
+  sensor::ICPFrame a(8, 8), b(8, 8); float A[36], bb[6]; sensor::computeICPCost2(&a, b, A, bb);
+  startTiming(); (void)stopTiming();
+}
+int main() {
+  try { fuse_and_render(nullptr, nullptr, 0, nullptr); } catch (const std::exception& e) { return 0; }
+  return 0;
+}
+''')
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-L", libdir, "-lsvoslam_hip",
+                           "-Wl,-rpath," + libdir, "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0

@@ -1,0 +1,92 @@
+"""world_size-2 CPU test (gloo) of the N > 1 path: row-band partition, exact all-reduce of the
+ICP fixed-point sums, all-gather of point bands.  The band partials come from the CPU oracle (the
+GPU kernels cannot run here); what is under test is the sharding/communication logic that
+pipeline.SlamPipeline uses unchanged on RCCL."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, h, w, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import svoslam_pkg
+    svoslam_pkg.load()
+    pl = importlib.import_module("octree_slam_amd.pipeline")
+    from oracle import oracle as ora
+    ctx = pl.DistContext(rank, world)
+    first, rows = pl.band_rows(h, rank, world)
+    # identical inputs on every rank (same seed), as in bench.py
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:h, 0:w]
+    d = (1500 + 200 * np.sin(xx / 9.0) + 100 * np.cos(yy / 7.0) + rng.normal(scale=1.0, size=(h, w))).astype(np.uint16)
+    f = 570.3 * w / 640
+    v1 = ora.vertex_map(d, f, f, w, h); n1 = ora.normal_map(v1)
+    T = ora.icp_update_transform(np.array([0.003, -0.002, 0.001, 0.003, -0.002, 0.001], np.float32))
+    v2 = ora.transform_vertex_map(v1, T); n2 = ora.transform_normal_map(n1, T)
+    # 1) ICP: band partial -> all-reduce(sum, float64) == full-image sums, bit for bit
+    part = ora.icp_cost2_raw(v1, n1, v2, n2, first * w, rows * w).astype(np.float64)
+    acc = torch.from_numpy(part.copy())
+    ctx.all_reduce_sum(acc)
+    full = ora.icp_cost2_raw(v1, n1, v2, n2).astype(np.float64)
+    ok_icp = bool(np.array_equal(acc.numpy(), full)) and bool(np.abs(full).max() > 0)
+    A, b = ora.icp_finish(acc.numpy().astype(np.int64))
+    rA, rb = ora.icp_cost2(v1, n1, v2, n2)
+    ok_icp = ok_icp and np.array_equal(A, rA) and np.array_equal(b, rb)
+    # 2) point bands: each rank fills only its rows, all-gather restores the full map
+    pts = torch.full((h, w, 3), float("nan"), dtype=torch.float32)
+    pts[first:first + rows] = torch.from_numpy(v2[first:first + rows])
+    ctx.all_gather_rows(pts, h)
+    ok_gather = bool(np.array_equal(np.nan_to_num(pts.numpy(), nan=-7, posinf=9), np.nan_to_num(v2, nan=-7, posinf=9)))
+    # 3) every rank then holds identical fusion input -> identical pool (replicas byte-identical)
+    pool = ora.Pool()
+    col = (np.arange(h * w * 3) % 251).astype(np.uint8).reshape(-1, 3)
+    pool.insert_cloud(pts.numpy().reshape(-1, 3), col, 6, (0, 0, 1.5), 2.0)
+    digest = torch.tensor([int(pool.words().astype(np.uint64).sum() % (1 << 62)), pool.size], dtype=torch.int64)
+    gathered = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(gathered, digest)
+    ok_pool = all(bool((g == digest).all()) for g in gathered)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.array([ok_icp, ok_gather, ok_pool, first, rows]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("h,w", [(48, 64), (45, 64)])
+def test_two_rank_bands_gloo(tmp_path, h, w):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, h, w, str(tmp_path)), nprocs=world, join=True)
+    covered = 0
+    for r in range(world):
+        ok_icp, ok_gather, ok_pool, first, rows = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
+        assert ok_icp and ok_gather and ok_pool, (r, ok_icp, ok_gather, ok_pool)
+        assert first == covered
+        covered += rows
+    assert covered == h
+
+
+def test_band_rows_partition():
+    import sys
+    sys.path.insert(0, ROOT)
+    import svoslam_pkg
+    svoslam_pkg.load()
+    pl = importlib.import_module("octree_slam_amd.pipeline")
+    for h in (480, 1080, 2160, 7, 61):
+        for world in (1, 2, 3, 4, 8):
+            bands = [pl.band_rows(h, r, world) for r in range(world)]
+            assert bands[0][0] == 0 and sum(b[1] for b in bands) == h
+            for (f0, n0), (f1, _) in zip(bands[:-1], bands[1:]):
+                assert f0 + n0 == f1
+            assert max(b[1] for b in bands) - min(b[1] for b in bands) <= 1
