@@ -17,6 +17,7 @@ namespace svoslam {
 __device__ constexpr float kMaxRange = 10.0f;   // cone_tracing_kernels.cu:24
 __device__ constexpr float kStartDist = 0.002f; // :27
 constexpr int kMaxSteps = 1 << 20;              // guard only; the reference loops until retirement
+constexpr int kPathCache = 18;                  // levels kept in the per-ray path cache (depth 16 + Q4 level + 1)
 
 // ceil(log(q)/log(2)) of :69 from the binary32 exponent (exact; the reference's
 // float log() can be one level off within an ulp of a power of two)
@@ -76,6 +77,17 @@ __global__ __launch_bounds__(256) void cone_trace_kernel(uchar4 *__restrict__ po
     float rx = kStartDist * (dx * inv), ry = kStartDist * (dy * inv), rz = kStartDist * (dz * inv);
     uint32_t vx = 0, vy = 0, vz = 0, vw = 0;  // local uchar4 pixel
     uint32_t out = 0;
+    // Path cache: octant, word0 and word1 of the node visited at each level of the previous
+    // descent.  The pool is read-only while rendering, so when the new sample takes the same
+    // octant at level i (same comparisons against the same centres, recomputed in registers) the
+    // node is the same and its words are reused without a load; the first differing level
+    // invalidates the rest.  Consecutive samples of a ray share most of their ancestors, which
+    // removes most of the dependent loads of the walk; the comparisons and centre updates are
+    // executed exactly as in the reference, so the visited nodes are identical.
+    uint32_t c_w0[kPathCache], c_w1[kPathCache];
+    unsigned long long c_oct = 0;  // 3 bits per level
+    int c_len = 0;
+    const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
     for (int step = 0; step < kMaxSteps; step++) {
       my_steps++;
       // Q9: the reference re-reads pos[index], which stays 0 until retirement
@@ -85,20 +97,55 @@ __global__ __launch_bounds__(256) void cone_trace_kernel(uchar4 *__restrict__ po
       const float pix_size = ray_len * P.pix_scale;
       int depth = ceil_log2_pos(P.size / pix_size);
       uint32_t node_idx = 0, child_idx = 0;
+      uint32_t oct_val = 0;
+      bool have_val = false;
       float temp_size = P.size, cx = P.center[0], cy = P.center[1], cz = P.center[2];
-      for (int i = 0; i < depth; i++) {
-        const bool x = tx > cx, y = ty > cy, z = tz > cz;
-        node_idx = child_idx + (uint32_t)(x + 2 * y + 4 * z);
-        my_levels++;
-        const uint32_t w0 = octree[2 * (size_t)node_idx];
-        if (!(w0 & kFlag)) { depth = i + 1; break; }
-        child_idx = w0 & kMask;
-        temp_size /= 2.0f;
-        cx += temp_size * (x ? 1 : -1);
-        cy += temp_size * (y ? 1 : -1);
-        cz += temp_size * (z ? 1 : -1);
+      bool stopped = false;
+#pragma unroll
+      for (int i = 0; i < kPathCache; i++) {
+        if (!stopped && i < depth) {
+          const bool x = tx > cx, y = ty > cy, z = tz > cz;
+          const uint32_t oct = (uint32_t)(x + 2 * y + 4 * z);
+          node_idx = child_idx + oct;
+          my_levels++;
+          uint32_t w0, w1;
+          if (i < c_len && ((uint32_t)(c_oct >> (3 * i)) & 7u) == oct) {
+            w0 = c_w0[i]; w1 = c_w1[i];
+          } else {
+            const uint2 nd = nodes[node_idx];
+            w0 = nd.x; w1 = nd.y;
+            c_w0[i] = w0; c_w1[i] = w1;
+            c_oct = (c_oct & ~(7ull << (3 * i))) | ((unsigned long long)oct << (3 * i));
+            c_len = i + 1;
+          }
+          oct_val = w1; have_val = true;
+          if (!(w0 & kFlag)) { depth = i + 1; stopped = true; }
+          else {
+            child_idx = w0 & kMask;
+            temp_size /= 2.0f;
+            cx += temp_size * (x ? 1 : -1);
+            cy += temp_size * (y ? 1 : -1);
+            cz += temp_size * (z ? 1 : -1);
+          }
+        }
       }
-      const uint32_t oct_val = octree[2 * (size_t)node_idx + 1];
+      if (!stopped) {
+        // deeper than the cache (cannot happen for pools of depth <= 16 + the Q4 level): plain walk
+        for (int i = kPathCache; i < depth; i++) {
+          const bool x = tx > cx, y = ty > cy, z = tz > cz;
+          node_idx = child_idx + (uint32_t)(x + 2 * y + 4 * z);
+          my_levels++;
+          const uint2 nd = nodes[node_idx];
+          oct_val = nd.y; have_val = true;
+          if (!(nd.x & kFlag)) { depth = i + 1; break; }
+          child_idx = nd.x & kMask;
+          temp_size /= 2.0f;
+          cx += temp_size * (x ? 1 : -1);
+          cy += temp_size * (y ? 1 : -1);
+          cz += temp_size * (z ? 1 : -1);
+        }
+      }
+      if (!have_val) oct_val = octree[1];  // depth <= 0: the reference reads node 0 (:107 with node_idx = 0)
       // :108 max(0, unsigned) is the (int, unsigned) overload: no clamp, alpha = A - 127 signed
       const int alpha = (int)((oct_val >> 24) - 127u);
       const float af = (float)alpha / 127.0f;

@@ -52,21 +52,34 @@ struct CamState {
 // ----------------------------------------------------------------------------
 // accumulate
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void icp_accumulate_kernel(const float *__restrict__ last_v, const float *__restrict__ last_n,
-                                                             const float *__restrict__ cur_v, const float *__restrict__ cur_n,
-                                                             int first, int end, const CamState *__restrict__ state,
-                                                             int use_level_start, int chain_len, double *__restrict__ partial) {
-  __shared__ double red[4][27];
+constexpr int kIcpThreads = 1024;  // 16 wavefronts per workgroup, <= one workgroup per CU
+constexpr int kIcpWaves = kIcpThreads / kWave;
+constexpr int kMaxIcpBlocks = 256;
+
+// iteration flags (host-known)
+constexpr int kFlagLevelStart = 1;  // level < 2: the level's copy is first transformed by update_trans (:116-120)
+constexpr int kFlagFirstIter = 2;   // iteration 0 of its level
+constexpr int kFlagFirstOfFrame = 4;
+constexpr int kFlagLastOfFrame = 8;
+
+__global__ __launch_bounds__(kIcpThreads) void icp_accumulate_kernel(
+    const float *__restrict__ last_v, const float *__restrict__ last_n, const float *__restrict__ cur_v,
+    const float *__restrict__ cur_n, int first, int end, const CamState *__restrict__ state, int flags, int chain_len,
+    double *__restrict__ partial) {
+  __shared__ double red[kIcpWaves][27];
   __shared__ float chain_s[(kMaxChain + 1) * 16];
   int nchain = 0;
   bool lost = false;
   if (state) {
-    lost = state->lost != 0;
-    if (use_level_start) {
-      if (threadIdx.x < 16) chain_s[threadIdx.x] = state->level_start[threadIdx.x];
+    // iteration 0 of a level: the level-start transform is update_trans as the previous level left it
+    // and the "tracking lost" flag of the previous level no longer applies
+    lost = !(flags & kFlagFirstIter) && state->lost != 0;
+    if (flags & kFlagLevelStart) {
+      const float *src = (flags & kFlagFirstIter) ? state->update_trans : state->level_start;
+      if (threadIdx.x < 16) chain_s[threadIdx.x] = src[threadIdx.x];
       nchain = 1;
     }
-    for (int i = threadIdx.x; i < chain_len * 16; i += 256) chain_s[nchain * 16 + i] = (&state->chain[0][0])[i];
+    for (int i = threadIdx.x; i < chain_len * 16; i += kIcpThreads) chain_s[nchain * 16 + i] = (&state->chain[0][0])[i];
     nchain += chain_len;
   }
   __syncthreads();
@@ -74,7 +87,7 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const float *__rest
 #pragma unroll
   for (int i = 0; i < 27; i++) acc[i] = 0.0;
   if (!lost) {
-    for (int p = first + blockIdx.x * 256 + threadIdx.x; p < end; p += gridDim.x * 256) {
+    for (int p = first + blockIdx.x * kIcpThreads + threadIdx.x; p < end; p += gridDim.x * kIcpThreads) {
       float v2x = cur_v[3 * (size_t)p], v2y = cur_v[3 * (size_t)p + 1], v2z = cur_v[3 * (size_t)p + 2];
       float n2x = cur_n[3 * (size_t)p], n2y = cur_n[3 * (size_t)p + 1], n2z = cur_n[3 * (size_t)p + 2];
       const float v1x = last_v[3 * (size_t)p], v1y = last_v[3 * (size_t)p + 1], v1z = last_v[3 * (size_t)p + 2];
@@ -103,24 +116,26 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const float *__rest
       J[4] = (0.0f * n1x + 1.0f * n1y) + 0.0f * n1z;
       J[5] = (0.0f * n1x + 0.0f * n1y) + 1.0f * n1z;
       const float bb = dot3(n1x, n1y, n1z, v1x - v2x, v1y - v2y, v1z - v2z);
+      // fixed point: prod * 2^k is exact in binary32 (power-of-two scale), rintf gives the same
+      // integer as rint((double)prod * 2^k) of the specification
       int k = 0;
 #pragma unroll
       for (int i = 0; i < 6; i++)
 #pragma unroll
         for (int j = i; j < 6; j++) {
           const float prod = J[i] * J[j];
-          acc[k++] += rint((double)prod * kScaleA);
+          acc[k++] += (double)rintf(prod * 1048576.0f);
         }
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         const float prod = bb * J[i];
-        acc[21 + i] += rint((double)prod * kScaleB);
+        acc[21 + i] += (double)rintf(prod * 1073741824.0f);
       }
     }
   }
   // wave -> workgroup -> one 27-double row per workgroup; every partial is an integer-valued
-  // double (exact).  Plain stores only: the rows are summed by icp_reduce_kernel in the next
-  // launch, so visibility rests on the kernel boundary alone (no cross-XCD atomics).
+  // double (exact).  Plain stores only: the rows are summed in the NEXT launch, so visibility
+  // rests on the kernel boundary alone (no cross-XCD atomics on data).
 #pragma unroll
   for (int i = 0; i < 27; i++) {
     double v = acc[i];
@@ -134,16 +149,17 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const float *__rest
     for (int i = 0; i < 27; i++) red[wave][i] = acc[i];
   }
   __syncthreads();
-  if (threadIdx.x < 27)
-    partial[(size_t)blockIdx.x * 27 + threadIdx.x] =
-        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < 27) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kIcpWaves; w++) t += red[w][threadIdx.x];
+    partial[(size_t)blockIdx.x * 27 + threadIdx.x] = t;
+  }
 }
 
-// acc[27] += column sums of partial[rows][27]  (one workgroup; exact integer-valued sums)
-__global__ __launch_bounds__(256) void icp_reduce_kernel(const double *__restrict__ partial, int rows,
-                                                         double *__restrict__ acc) {
-  __shared__ double red[8][27];
-  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+// column sums of partial[rows][27] into LDS totals[27] (exact integer-valued sums); 256 threads
+__device__ inline void reduce_rows(const double *__restrict__ partial, int rows, double (*red)[27], double *totals) {
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;  // 8 row groups x 32 columns
   double s = 0.0;
   if (col < 27)
     for (int r = grp; r < rows; r += 8) s += partial[(size_t)r * 27 + col];
@@ -153,28 +169,42 @@ __global__ __launch_bounds__(256) void icp_reduce_kernel(const double *__restric
     double t = 0.0;
 #pragma unroll
     for (int g = 0; g < 8; g++) t += red[g][threadIdx.x];
-    acc[threadIdx.x] += t;
+    totals[threadIdx.x] = t;
   }
+  __syncthreads();
 }
 
-constexpr int kMaxIcpBlocks = 1024;
+// acc[27] += column sums (used by the stateless ABI call and the multi-GPU path)
+__global__ __launch_bounds__(256) void icp_reduce_kernel(const double *__restrict__ partial, int rows,
+                                                         double *__restrict__ acc) {
+  __shared__ double red[8][27];
+  __shared__ double totals[27];
+  reduce_rows(partial, rows, red, totals);
+  if (threadIdx.x < 27) acc[threadIdx.x] += totals[threadIdx.x];
+}
 
-// accumulate pixels [first, first+num) and ADD their 27 sums into d_acc (in-stream, no atomics)
-static int launch_accumulate(const float *lv, const float *ln, const float *cv, const float *cn, int w, int h, int first,
-                             int num, const CamState *state, int use_level_start, int chain_len, double *d_partial,
-                             double *d_acc, hipStream_t s) {
+static int accumulate_range(int w, int h, int &first, int num, int &end) {
   const int n = w * h;
   // Q15: load_size = 20*w/640; the reference reduces floor(n/load) partials, the tail is dropped
   const int load_size = 20 * w / 640;
   int limit = n;
   if (load_size > 0) limit = (n / load_size) * load_size;
-  int end = first + num;
+  end = first + num;
   if (end > limit) end = limit;
   if (first < 0) first = 0;
-  int blocks = (int)cdiv(end > first ? end - first : 1, 256 * 4);  // >= 4 pixels per lane
+  int blocks = (int)cdiv(end > first ? end - first : 1, kIcpThreads);
   if (blocks > kMaxIcpBlocks) blocks = kMaxIcpBlocks;
   if (blocks < 1) blocks = 1;
-  icp_accumulate_kernel<<<blocks, 256, 0, s>>>(lv, ln, cv, cn, first, end, state, use_level_start, chain_len, d_partial);
+  return blocks;
+}
+
+// accumulate pixels [first, first+num) and ADD their 27 sums into d_acc (in-stream, no atomics)
+static int launch_accumulate(const float *lv, const float *ln, const float *cv, const float *cn, int w, int h, int first,
+                             int num, const CamState *state, int flags, int chain_len, double *d_partial,
+                             double *d_acc, hipStream_t s) {
+  int end;
+  const int blocks = accumulate_range(w, h, first, num, end);
+  icp_accumulate_kernel<<<blocks, kIcpThreads, 0, s>>>(lv, ln, cv, cn, first, end, state, flags, chain_len, d_partial);
   icp_reduce_kernel<<<1, 256, 0, s>>>(d_partial, blocks, d_acc);
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
@@ -320,31 +350,17 @@ __device__ inline void d_solve_cholesky(const float *A, const float *b, float *x
   }
 }
 
-__global__ void cam_frame_begin_kernel(CamState *st) {
-  if (threadIdx.x || blockIdx.x) return;
-  d_identity(st->update_trans);  // rgbd_camera.cpp:100
-}
-
-__global__ void cam_level_begin_kernel(CamState *st) {
-  if (threadIdx.x || blockIdx.x) return;
-  for (int i = 0; i < 16; i++) st->level_start[i] = st->update_trans[i];  // :116-120
-  st->lost = 0;
-}
-
-// one ICP iteration's host part (:143-160); slot = iteration index at this level
-__global__ void cam_solve_kernel(CamState *st, double *acc, int slot) {
-  if (threadIdx.x || blockIdx.x) return;
+// one ICP iteration's host part (rgbd_camera.cpp:143-160) from the 27 fixed-point sums
+__device__ inline void solve_step(CamState *st, const double *sums, int slot) {
   float A[36], b[6], x[6];
   int k = 0;
   for (int i = 0; i < 6; i++)
     for (int j = i; j < 6; j++) {
-      const float v = (float)(acc[k] * (1.0 / kScaleA));
-      acc[k++] = 0.0;
+      const float v = (float)(sums[k++] * (1.0 / kScaleA));
       A[6 * i + j] = v;
       A[6 * j + i] = v;
     }
-  for (int i = 0; i < 6; i++) { b[i] = (float)(acc[21 + i] * (1.0 / kScaleB)); acc[21 + i] = 0.0; }
-  if (st->lost) return;
+  for (int i = 0; i < 6; i++) b[i] = (float)(sums[21 + i] * (1.0 / kScaleB));
   for (int i = 0; i < 6; i++) x[i] = 0.0f;
   d_solve_cholesky(A, b, x);
   for (int i = 0; i < 36; i++) st->lastA[i] = A[i];
@@ -371,8 +387,7 @@ __global__ void cam_solve_kernel(CamState *st, double *acc, int slot) {
 }
 
 // :172-173 pose update (Q17: row-vector products) and the fusion transform of main.cpp:40
-__global__ void cam_frame_end_kernel(CamState *st, int apply_update) {
-  if (threadIdx.x || blockIdx.x) return;
+__device__ inline void frame_end_step(CamState *st, int apply_update) {
   if (apply_update) {
     const float *m = st->update_trans;
     const float v[4] = {st->position[0], st->position[1], st->position[2], 1.0f};
@@ -394,6 +409,41 @@ __global__ void cam_frame_end_kernel(CamState *st, int apply_update) {
   d_identity(I);
   d_translate(I, st->position, t);
   d_mat4_mul(o4, t, st->fusion);
+}
+
+__device__ inline void level_begin_step(CamState *st, int flags) {
+  if (flags & kFlagFirstOfFrame) d_identity(st->update_trans);  // rgbd_camera.cpp:100
+  if (flags & kFlagFirstIter) {
+    for (int i = 0; i < 16; i++) st->level_start[i] = st->update_trans[i];  // :116-120
+    st->lost = 0;
+  }
+}
+
+// single-GPU iteration tail: sum the workgroup rows, solve, compose -- ONE launch
+__global__ __launch_bounds__(256) void cam_reduce_solve_kernel(CamState *st, const double *__restrict__ partial, int rows,
+                                                               int slot, int flags) {
+  __shared__ double red[8][27];
+  __shared__ double totals[27];
+  reduce_rows(partial, rows, red, totals);
+  if (threadIdx.x != 0) return;
+  level_begin_step(st, flags);
+  if (!st->lost) solve_step(st, totals, slot);
+  if (flags & kFlagLastOfFrame) frame_end_step(st, 1);
+}
+
+// multi-GPU iteration tail: acc[] holds the all-reduced sums
+__global__ void cam_solve_kernel(CamState *st, double *acc, int slot, int flags) {
+  if (threadIdx.x || blockIdx.x) return;
+  double sums[27];
+  for (int i = 0; i < 27; i++) { sums[i] = acc[i]; acc[i] = 0.0; }
+  level_begin_step(st, flags);
+  if (!st->lost) solve_step(st, sums, slot);
+  if (flags & kFlagLastOfFrame) frame_end_step(st, 1);
+}
+
+__global__ void cam_frame_end_kernel(CamState *st, int apply_update) {
+  if (threadIdx.x || blockIdx.x) return;
+  frame_end_step(st, apply_update);
 }
 
 }  // namespace svoslam
@@ -487,56 +537,80 @@ int camera_begin(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rg
     if (i != 2) SVO_TRY(subsample_depth_u16_to(c->filt[i], c->filt[i + 1], w, h, s));
   }
   c->frame_has_icp = c->pass >= 1;
-  if (c->frame_has_icp) {
-    cam_frame_begin_kernel<<<1, 64, 0, s>>>(c->d_state);
-    SVO_LAUNCH_CHECK();
-  }
   return SVOSLAM_OK;
 }
 
+static int iter_flags(int level, int iter) {
+  int f = 0;
+  if (level < 2) f |= kFlagLevelStart;
+  if (iter == 0) f |= kFlagFirstIter;
+  if (level == 2 && iter == 0) f |= kFlagFirstOfFrame;
+  if (level == 0 && iter == kPyramidIters[0] - 1) f |= kFlagLastOfFrame;
+  return f;
+}
+
+struct LevelArgs { const float *lv, *ln, *cv, *cn; int w, h, first, num; };
+static LevelArgs level_args(const svoslam_camera *c, int level) {
+  LevelArgs a;
+  a.w = c->width >> level; a.h = c->height >> level;
+  const int r0 = c->band_first >> level, r1 = (c->band_first + c->band_rows) >> level;
+  const int last = 1 - c->cur;
+  a.lv = c->vert[last][level]; a.ln = c->norm[last][level];
+  a.cv = c->vert[c->cur][level]; a.cn = c->norm[c->cur][level];
+  a.first = r0 * a.w; a.num = (r1 - r0) * a.w;
+  return a;
+}
+
+// stepping API (multi-GPU): this band's sums are ADDED to d_acc; the caller all-reduces d_acc
 int camera_icp_accumulate(svoslam_camera *c, int level, int iter, hipStream_t s) {
   if (!c || level < 0 || level > 2 || iter < 0 || iter >= kPyramidIters[level]) return SVOSLAM_ERR_INVALID_ARG;
   if (!c->frame_has_icp) return SVOSLAM_OK;
-  if (iter == 0) {
-    cam_level_begin_kernel<<<1, 64, 0, s>>>(c->d_state);
-    SVO_LAUNCH_CHECK();
-  }
-  const int w = c->width >> level, h = c->height >> level;
-  const int r0 = c->band_first >> level, r1 = (c->band_first + c->band_rows) >> level;
-  const int last = 1 - c->cur;
-  return launch_accumulate(c->vert[last][level], c->norm[last][level], c->vert[c->cur][level], c->norm[c->cur][level], w, h,
-                           r0 * w, (r1 - r0) * w, c->d_state, level < 2 ? 1 : 0, iter, c->d_partial, c->d_acc, s);
+  const LevelArgs a = level_args(c, level);
+  return launch_accumulate(a.lv, a.ln, a.cv, a.cn, a.w, a.h, a.first, a.num, c->d_state, iter_flags(level, iter), iter,
+                           c->d_partial, c->d_acc, s);
 }
 
 int camera_icp_solve(svoslam_camera *c, int level, int iter, hipStream_t s) {
   if (!c || level < 0 || level > 2 || iter < 0 || iter >= kPyramidIters[level]) return SVOSLAM_ERR_INVALID_ARG;
   if (!c->frame_has_icp) return SVOSLAM_OK;
-  cam_solve_kernel<<<1, 64, 0, s>>>(c->d_state, c->d_acc, iter);
+  cam_solve_kernel<<<1, 64, 0, s>>>(c->d_state, c->d_acc, iter, iter_flags(level, iter));
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
 }
 
 int camera_end(svoslam_camera *c, hipStream_t s) {
   if (!c) return SVOSLAM_ERR_INVALID_ARG;
-  cam_frame_end_kernel<<<1, 64, 0, s>>>(c->d_state, c->frame_has_icp ? 1 : 0);
-  SVO_LAUNCH_CHECK();
+  if (!c->frame_has_icp) {  // first frame: no ICP, only the fusion transform (the last solve did it otherwise)
+    cam_frame_end_kernel<<<1, 64, 0, s>>>(c->d_state, 0);
+    SVO_LAUNCH_CHECK();
+  }
   if (c->pass < 2) c->pass++;  // :176-178
   c->cur = 1 - c->cur;         // swap current/last, :181-189
   c->frame_has_icp = false;
   return SVOSLAM_OK;
 }
 
+// single-GPU frame: two launches per ICP iteration (accumulate, reduce+solve+compose)
 int camera_update(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp, int32_t *processed,
                   hipStream_t s) {
   int32_t used = 0;
   SVO_TRY(camera_begin(c, d_depth, d_rgb, timestamp, &used, s));
   if (processed) *processed = used;
   if (!used) return SVOSLAM_OK;
-  for (int level = 2; level >= 0; level--)  // coarse to fine, :103
-    for (int it = 0; it < kPyramidIters[level]; it++) {
-      SVO_TRY(camera_icp_accumulate(c, level, it, s));
-      SVO_TRY(camera_icp_solve(c, level, it, s));
+  if (c->frame_has_icp) {
+    for (int level = 2; level >= 0; level--) {  // coarse to fine, :103
+      LevelArgs a = level_args(c, level);
+      int end;
+      const int blocks = accumulate_range(a.w, a.h, a.first, a.num, end);
+      for (int it = 0; it < kPyramidIters[level]; it++) {
+        const int flags = iter_flags(level, it);
+        icp_accumulate_kernel<<<blocks, kIcpThreads, 0, s>>>(a.lv, a.ln, a.cv, a.cn, a.first, end, c->d_state, flags, it,
+                                                             c->d_partial);
+        cam_reduce_solve_kernel<<<1, 256, 0, s>>>(c->d_state, c->d_partial, blocks, it, flags);
+      }
     }
+    SVO_LAUNCH_CHECK();
+  }
   return camera_end(c, s);
 }
 

@@ -236,14 +236,22 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restri
   }
 }
 
-__global__ void bbox_final_kernel(const float *__restrict__ partial, int blocks, float *__restrict__ out) {
-  if (threadIdx.x != 0) return;
+// one wavefront: lane l folds rows l, l+64, ... then a shuffle tree (min/max are exact: any order)
+__global__ __launch_bounds__(64) void bbox_final_kernel(const float *__restrict__ partial, int blocks, float *__restrict__ out) {
   float r[7] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY, 0};
-  for (int b = 0; b < blocks; b++) {
+  for (int b = threadIdx.x; b < blocks; b += 64) {
+#pragma unroll
     for (int k = 0; k < 3; k++) { r[k] = fminf(r[k], partial[b * 7 + k]); r[3 + k] = fmaxf(r[3 + k], partial[b * 7 + 3 + k]); }
     r[6] = fmaxf(r[6], partial[b * 7 + 6]);
   }
-  for (int k = 0; k < 7; k++) out[k] = r[k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { r[k] = fminf(r[k], __shfl_down(r[k], o)); r[3 + k] = fmaxf(r[3 + k], __shfl_down(r[3 + k], o)); }
+    r[6] = fmaxf(r[6], __shfl_down(r[6], o));
+  }
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 7; k++) out[k] = r[k];
 }
 
 // ----------------------------------------------------------------------------

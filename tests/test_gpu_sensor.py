@@ -171,24 +171,52 @@ def test_camera_tracker_matches_oracle(env, oracle):
     assert np.abs(o.reshape(3, 3) - np.eye(3)).max() > 1e-3
 
 
-def test_camera_split_stepping_equals_update(env, oracle):
+@pytest.mark.parametrize("w,h,nframes", [(160, 120, 3), (640, 480, 10)])
+def test_camera_split_stepping_equals_update(env, oracle, w, h, nframes):
     """begin / accumulate(bands) / solve / end == update (the multi-GPU stepping API)"""
     pkg, torch, synth = env
-    w, h = 160, 120
     f = synth.focal_length(w)
     cam_a, cam_b = pkg.Camera(w, h, f, f), pkg.Camera(w, h, f, f)
     acc = torch.zeros(27, dtype=torch.float64, device="cuda")
     cam_b.set_acc(acc)
-    for k in range(3):
+    for k in range(nframes):
         d, c = synth.render_frame(2 * k, w, h)
         cam_a.update(d.cuda(), c.cuda(), k)
         assert cam_b.begin(d.cuda(), c.cuda(), k) == 1
         for level in (2, 1, 0):
             for it in range(pkg.PYRAMID_ITERS[level]):
-                for r0, r1 in ((0, 40), (40, 120)):           # two row bands into one accumulator
+                for r0, r1 in ((0, h // 3), (h // 3, h)):     # two row bands into one accumulator
                     cam_b.set_band(r0, r1 - r0)
                     cam_b.icp_accumulate(level, it)
                 cam_b.icp_solve(level, it)
         cam_b.end()
         pa, oa = cam_a.pose(); pb, ob = cam_b.pose()
         assert np.array_equal(pa, pb) and np.array_equal(oa, ob)
+
+
+def test_camera_tracker_full_size_matches_oracle_and_is_repeatable(env, oracle):
+    """640x480 (BASELINE config 3 size), 24 frames = 437 ICP iterations: pose, A, b, x bit-identical to the
+    oracle on every frame, and a second device run gives identical bits (no cross-workgroup visibility race)."""
+    pkg, torch, synth = env
+    w, h = 640, 480
+    f = synth.focal_length(w)
+    frames = [synth.render_frame(k, w, h, device="cuda") for k in range(24)]
+    ocam = oracle.Camera(w, h, f, f)
+    runs = []
+    for rep in range(2):
+        cam = pkg.Camera(w, h, f, f)
+        poses = []
+        for k, (d, c) in enumerate(frames):
+            cam.update(d, c, k)
+            p, o = cam.pose()
+            poses.append(o.copy())
+            if rep == 0:
+                ocam.update(d.cpu().numpy().view(np.uint16), c.cpu().numpy(), k)
+                rp, ro = ocam.pose()
+                assert np.array_equal(o.view(np.uint32), ro.view(np.uint32)), (k, o, ro)
+                if k >= 1:
+                    A, b, x = cam.last_system(); rA, rb, rx = ocam.last_system()
+                    assert np.array_equal(A, rA) and np.array_equal(b, rb) and np.array_equal(x.view(np.uint32), rx.view(np.uint32))
+        runs.append((np.stack(poses), cam.tracking_lost_count()))
+    assert np.array_equal(runs[0][0].view(np.uint32), runs[1][0].view(np.uint32))
+    assert runs[0][1] == runs[1][1]
