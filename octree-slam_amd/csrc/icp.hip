@@ -52,7 +52,7 @@ struct CamState {
 // ----------------------------------------------------------------------------
 // accumulate
 // ----------------------------------------------------------------------------
-constexpr int kIcpThreads = 1024;  // 16 wavefronts per workgroup, <= one workgroup per CU
+constexpr int kIcpThreads = 512;   // 8 wavefronts per workgroup, one workgroup per CU (108 KB of LDS)
 constexpr int kIcpWaves = kIcpThreads / kWave;
 constexpr int kMaxIcpBlocks = 256;
 
@@ -66,7 +66,10 @@ __global__ __launch_bounds__(kIcpThreads) void icp_accumulate_kernel(
     const float *__restrict__ last_v, const float *__restrict__ last_n, const float *__restrict__ cur_v,
     const float *__restrict__ cur_n, int first, int end, const CamState *__restrict__ state, int flags, int chain_len,
     double *__restrict__ partial) {
-  __shared__ double red[kIcpWaves][27];
+  // [27][threads] transpose buffer: the cross-lane reduction of 27 values per lane is done by
+  // re-reading columns lane-contiguously (conflict-free ds_read_b64) and shuffling ONE value per
+  // column per wavefront, instead of 27 x 6 ds_bpermute rounds per lane (LDS-issue bound).
+  __shared__ double sm[27][kIcpThreads];
   __shared__ float chain_s[(kMaxChain + 1) * 16];
   int nchain = 0;
   bool lost = false;
@@ -133,51 +136,45 @@ __global__ __launch_bounds__(kIcpThreads) void icp_accumulate_kernel(
       }
     }
   }
-  // wave -> workgroup -> one 27-double row per workgroup; every partial is an integer-valued
-  // double (exact).  Plain stores only: the rows are summed in the NEXT launch, so visibility
-  // rests on the kernel boundary alone (no cross-XCD atomics on data).
+  // workgroup -> one 27-double row; every partial is an integer-valued double (exact, order-free).
+  // Plain stores only: the rows are summed in the NEXT launch, so visibility rests on the kernel
+  // boundary alone (no cross-XCD atomics on data).
 #pragma unroll
-  for (int i = 0; i < 27; i++) {
-    double v = acc[i];
+  for (int i = 0; i < 27; i++) sm[i][threadIdx.x] = acc[i];
+  __syncthreads();
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  for (int c = (int)wave; c < 27; c += kIcpWaves) {
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < kIcpThreads / kWave; j++) v += sm[c][lane + kWave * j];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    acc[i] = v;
-  }
-  const unsigned wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int i = 0; i < 27; i++) red[wave][i] = acc[i];
-  }
-  __syncthreads();
-  if (threadIdx.x < 27) {
-    double t = 0.0;
-#pragma unroll
-    for (int w = 0; w < kIcpWaves; w++) t += red[w][threadIdx.x];
-    partial[(size_t)blockIdx.x * 27 + threadIdx.x] = t;
+    if (lane == 0) partial[(size_t)blockIdx.x * 27 + c] = v;
   }
 }
 
-// column sums of partial[rows][27] into LDS totals[27] (exact integer-valued sums); 256 threads
+// column sums of partial[rows][27] into LDS totals[27] (exact integer-valued sums);
+// blockDim.x / 32 row groups x 32 columns, all loads of a thread independent (<= 8 rows each)
+constexpr int kReduceThreads = 1024;
 __device__ inline void reduce_rows(const double *__restrict__ partial, int rows, double (*red)[27], double *totals) {
-  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;  // 8 row groups x 32 columns
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5, ngrp = blockDim.x >> 5;
   double s = 0.0;
   if (col < 27)
-    for (int r = grp; r < rows; r += 8) s += partial[(size_t)r * 27 + col];
+    for (int r = grp; r < rows; r += ngrp) s += partial[(size_t)r * 27 + col];
   if (col < 27) red[grp][col] = s;
   __syncthreads();
   if (threadIdx.x < 27) {
     double t = 0.0;
-#pragma unroll
-    for (int g = 0; g < 8; g++) t += red[g][threadIdx.x];
+    for (int g = 0; g < ngrp; g++) t += red[g][threadIdx.x];
     totals[threadIdx.x] = t;
   }
   __syncthreads();
 }
 
 // acc[27] += column sums (used by the stateless ABI call and the multi-GPU path)
-__global__ __launch_bounds__(256) void icp_reduce_kernel(const double *__restrict__ partial, int rows,
-                                                         double *__restrict__ acc) {
-  __shared__ double red[8][27];
+__global__ __launch_bounds__(kReduceThreads) void icp_reduce_kernel(const double *__restrict__ partial, int rows,
+                                                                    double *__restrict__ acc) {
+  __shared__ double red[kReduceThreads / 32][27];
   __shared__ double totals[27];
   reduce_rows(partial, rows, red, totals);
   if (threadIdx.x < 27) acc[threadIdx.x] += totals[threadIdx.x];
@@ -205,7 +202,7 @@ static int launch_accumulate(const float *lv, const float *ln, const float *cv, 
   int end;
   const int blocks = accumulate_range(w, h, first, num, end);
   icp_accumulate_kernel<<<blocks, kIcpThreads, 0, s>>>(lv, ln, cv, cn, first, end, state, flags, chain_len, d_partial);
-  icp_reduce_kernel<<<1, 256, 0, s>>>(d_partial, blocks, d_acc);
+  icp_reduce_kernel<<<1, kReduceThreads, 0, s>>>(d_partial, blocks, d_acc);
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
 }
@@ -420,9 +417,9 @@ __device__ inline void level_begin_step(CamState *st, int flags) {
 }
 
 // single-GPU iteration tail: sum the workgroup rows, solve, compose -- ONE launch
-__global__ __launch_bounds__(256) void cam_reduce_solve_kernel(CamState *st, const double *__restrict__ partial, int rows,
-                                                               int slot, int flags) {
-  __shared__ double red[8][27];
+__global__ __launch_bounds__(kReduceThreads) void cam_reduce_solve_kernel(CamState *st, const double *__restrict__ partial,
+                                                                          int rows, int slot, int flags) {
+  __shared__ double red[kReduceThreads / 32][27];
   __shared__ double totals[27];
   reduce_rows(partial, rows, red, totals);
   if (threadIdx.x != 0) return;
@@ -606,7 +603,7 @@ int camera_update(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_r
         const int flags = iter_flags(level, it);
         icp_accumulate_kernel<<<blocks, kIcpThreads, 0, s>>>(a.lv, a.ln, a.cv, a.cn, a.first, end, c->d_state, flags, it,
                                                              c->d_partial);
-        cam_reduce_solve_kernel<<<1, 256, 0, s>>>(c->d_state, c->d_partial, blocks, it, flags);
+        cam_reduce_solve_kernel<<<1, kReduceThreads, 0, s>>>(c->d_state, c->d_partial, blocks, it, flags);
       }
     }
     SVO_LAUNCH_CHECK();

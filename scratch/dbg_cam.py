@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import svoslam_pkg
 pkg = svoslam_pkg.load()
 import importlib
