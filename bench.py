@@ -106,11 +106,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libsvoslam_hip has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("SVOSLAM_FORCE_DIST") == "1"   # exercise the row-band/RCCL code path on one GPU
+    if world > 1 or force_dist:
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         tdist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        dist = pl.DistContext(rank, world)
+        dist = pl.DistContext(rank, world, force=force_dist)
     arch = pkg.device_arch()
     assert arch and arch.startswith("gfx950"), arch
 
@@ -125,7 +127,7 @@ def main():
                         pool_capacity_nodes=1 << 24)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             import torch.distributed as tdist
             tdist.barrier()
         torch.cuda.synchronize()
@@ -179,7 +181,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(depth, rgb, views, width, height, max_depth, center, edge)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as tdist
         tdist.barrier()
         tdist.destroy_process_group()

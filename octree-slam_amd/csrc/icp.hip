@@ -23,6 +23,7 @@
 //    no host round trip (the reference copies 168 B back and solves on the host
 //    19 times per frame).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "icp.hpp"
@@ -62,15 +63,14 @@ constexpr int kFlagFirstIter = 2;   // iteration 0 of its level
 constexpr int kFlagFirstOfFrame = 4;
 constexpr int kFlagLastOfFrame = 8;
 
-__global__ __launch_bounds__(kIcpThreads) void icp_accumulate_kernel(
-    const float *__restrict__ last_v, const float *__restrict__ last_n, const float *__restrict__ cur_v,
-    const float *__restrict__ cur_n, int first, int end, const CamState *__restrict__ state, int flags, int chain_len,
-    double *__restrict__ partial) {
-  // [27][threads] transpose buffer: the cross-lane reduction of 27 values per lane is done by
-  // re-reading columns lane-contiguously (conflict-free ds_read_b64) and shuffling ONE value per
-  // column per wavefront, instead of 27 x 6 ds_bpermute rounds per lane (LDS-issue bound).
-  __shared__ double sm[27][kIcpThreads];
-  __shared__ float chain_s[(kMaxChain + 1) * 16];
+// Body shared by the two accumulate kernels.  sm = [27][threads] transpose buffer: the cross-lane
+// reduction of 27 values per lane is done by re-reading columns lane-contiguously (conflict-free
+// ds_read_b64) and shuffling ONE value per column per wavefront, instead of 27 x 6 ds_bpermute
+// rounds per lane (LDS-issue bound).
+__device__ inline void accumulate_block(const float *__restrict__ last_v, const float *__restrict__ last_n,
+                                        const float *__restrict__ cur_v, const float *__restrict__ cur_n, int first, int end,
+                                        const CamState *state, int flags, int chain_len, double *__restrict__ partial,
+                                        double (*sm)[kIcpThreads], float *chain_s) {
   int nchain = 0;
   bool lost = false;
   if (state) {
@@ -151,6 +151,15 @@ __global__ __launch_bounds__(kIcpThreads) void icp_accumulate_kernel(
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     if (lane == 0) partial[(size_t)blockIdx.x * 27 + c] = v;
   }
+}
+
+__global__ __launch_bounds__(kIcpThreads) void icp_accumulate_kernel(
+    const float *__restrict__ last_v, const float *__restrict__ last_n, const float *__restrict__ cur_v,
+    const float *__restrict__ cur_n, int first, int end, const CamState *__restrict__ state, int flags, int chain_len,
+    double *__restrict__ partial) {
+  __shared__ double sm[27][kIcpThreads];
+  __shared__ float chain_s[(kMaxChain + 1) * 16];
+  accumulate_block(last_v, last_n, cur_v, cur_n, first, end, state, flags, chain_len, partial, sm, chain_s);
 }
 
 // column sums of partial[rows][27] into LDS totals[27] (exact integer-valued sums);
@@ -587,7 +596,10 @@ int camera_end(svoslam_camera *c, hipStream_t s) {
   return SVOSLAM_OK;
 }
 
-// single-GPU frame: two launches per ICP iteration (accumulate, reduce+solve+compose)
+// single-GPU frame: two launches per ICP iteration (accumulate; reduce + solve + compose).  A
+// single-launch variant (last-arriving workgroup reduces and solves behind an agent-scope
+// release/acquire) was measured 4 % slower end to end: the two fences cost what the kernel
+// boundary costs, so the simpler form stays.
 int camera_update(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp, int32_t *processed,
                   hipStream_t s) {
   int32_t used = 0;

@@ -38,12 +38,21 @@ def band_rows(height, rank, world):
 class DistContext:
     """Thin torch.distributed wrapper (backend nccl == RCCL on ROCm; gloo for the CPU tests)."""
 
-    def __init__(self, rank=0, world=1, group=None):
-        self.rank, self.world, self.group = rank, world, group
+    def __init__(self, rank=0, world=1, group=None, force=False):
+        self.rank, self.world, self.group, self.force = rank, world, group, force
+        if self.enabled:
+            # create the RCCL communicator and its streams NOW (first use is lazy and was observed to
+            # mis-order against kernels queued around it), then drain the device once
+            import torch.distributed as dist
+            t = torch.zeros(27, dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            g = torch.empty(self.world * 4, dtype=torch.float32, device="cuda")
+            dist.all_gather_into_tensor(g, torch.zeros(4, dtype=torch.float32, device="cuda"), group=self.group)
+            torch.cuda.synchronize()
 
     @property
     def enabled(self):
-        return self.world > 1
+        return self.world > 1 or self.force
 
     def all_reduce_sum(self, t):
         if self.enabled:
