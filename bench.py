@@ -162,6 +162,14 @@ def main():
     alg_bytes = (4.0 * (levels + steps) + 4.0 * width * rows * K) / K     # per launch (this rank's band)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
+    traffic = None
+    try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be sampled from inside the process)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        t = tj.get(args.workload, {}).get("cone_trace_kernel") if world == 1 else None
+        if t:
+            traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
+    except Exception:
+        traffic = None
     if rank == 0:
         out = {
             "metric": "SLAM frames/sec (fuse+ICP+raycast)", "value": K / elapsed, "unit": "frames/s",
@@ -174,7 +182,7 @@ def main():
                        "pool_nodes_end": P.pool.size, "mrays_per_s": width * rows / (kern_ms * 1e-3) / 1e6,
                        "tracking_lost_levels": P.cam.tracking_lost_count()},
             "roofline": {"bound": "hbm", "kernel": "cone_trace_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                          "steps_per_launch": steps / K, "levels_per_launch": levels / K},
         }
