@@ -113,6 +113,70 @@ int svoslam_free(void *d_ptr);
 int svoslam_malloc(void **d_ptr, size_t bytes);
 
 /* ------------------------------------------------------------------------
+ * Mesh path (configs 1, 2, 5): OBJ/BMP loading and mesh -> voxel grid
+ * ---------------------------------------------------------------------- */
+/* Mesh of include/octree_slam/common_types.h:20-32 as Scene::loadObjFile fills it
+ * (src/world/scene.cpp:26-33,115-133): HOST arrays, non-indexed (9 floats per triangle),
+ * recentred (x/z centred, y min = 0; obj.cpp:227-238). */
+typedef struct {
+  float *vbo;       /* 9 * n_tris floats */
+  float *tbo;       /* 6 * n_tris floats (uv per vertex) or NULL */
+  int32_t n_tris;
+  int32_t tbosize;  /* floats in tbo */
+  float bbox0[3], bbox1[3];
+} svoslam_mesh;
+/* bmp_texture of common_types.h:34-38: HOST width*height*3 floats, r,g,b in 0..1 */
+typedef struct {
+  float *data;
+  int32_t width, height;
+} svoslam_texture;
+/* Scene::loadObjFile (scene.cpp:26-33) = objLoader + obj::buildVBOs + objToMesh */
+int svoslam_mesh_load_obj(const char *path, svoslam_mesh *out);
+int svoslam_mesh_free(svoslam_mesh *mesh);
+/* Scene::loadBMP (scene.cpp:35-62) */
+int svoslam_texture_load_bmp(const char *path, svoslam_texture *out);
+int svoslam_texture_free(svoslam_texture *tex);
+/* replaces voxelization::meshToVoxelGrid (include/octree_slam/world/voxelization/voxelization.h:21,
+ * src/world/voxelization/voxelization.cu:381-405) with N = 2^log_N cells per axis over the mesh's own
+ * AABB (the reference fixes log_N = 8, log_T = 3: voxelization.cu:24-25).  tex may be NULL (voxels are
+ * green, voxelization.cu:101-103).  Outputs are hipMalloc'ed n x vec4 arrays in ascending framebuffer
+ * (tiled) index order, free with svoslam_free; d_indices (optional) receives those indices;
+ * *scale_out = computeScale (half a voxel edge along x).  Blocking. */
+int svoslam_mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const svoslam_texture *tex, int32_t log_N,
+                               int32_t log_T, float **d_centers, float **d_colors, unsigned long long **d_indices,
+                               int32_t *n_out, float *scale_out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Host objects: world::Scene + world::Octree (include/octree_slam/world/scene.h:20-81,
+ * octree.h:80-125; src/world/scene.cpp, octree.cpp:251-385) as an opaque handle.
+ * ---------------------------------------------------------------------- */
+typedef struct svoslam_scene svoslam_scene;
+int svoslam_scene_create(svoslam_scene **scene);                       /* Scene::Scene, scene.cpp:11-17 */
+int svoslam_scene_destroy(svoslam_scene *scene);
+int svoslam_scene_load_obj(svoslam_scene *scene, const char *path);    /* Scene::loadObjFile, scene.cpp:26-33 */
+int svoslam_scene_load_bmp(svoslam_scene *scene, const char *path);    /* Scene::loadBMP, scene.cpp:35-62 */
+/* optional: create the Octree explicitly (resolution, root centre, root half edge) before the first
+ * insertion and/or pin the tree depth (depth_override > 0) instead of deriving it from
+ * ceil(log2(edge/resolution)) (octree.cpp:284).  The reference derives everything from the first
+ * cloud / mesh bounding box (scene.cpp:77-79,101). */
+int svoslam_scene_set_octree(svoslam_scene *scene, float resolution, const float center[3], float size,
+                             int32_t depth_override);
+/* Scene::voxelizeMeshes(octree), scene.cpp:64-85.  log_N <= 0 selects the reference's 8. */
+int svoslam_scene_voxelize_meshes(svoslam_scene *scene, int32_t octree, int32_t log_N, void *stream);
+/* Scene::extractVoxelGridFromOctree, scene.cpp:87-96 (scale 0.01) */
+int svoslam_scene_extract_voxel_grid(svoslam_scene *scene, void *stream);
+/* Scene::addPointCloudToOctree, scene.cpp:98-113 (bbox = computePointCloudBoundingBox of the cloud) */
+int svoslam_scene_add_point_cloud(svoslam_scene *scene, const float origin[3], const float *d_points,
+                                  const uint8_t *d_colors, int32_t n, const float bbox0[3], const float bbox1[3],
+                                  void *stream);
+/* Scene::voxel_grid() accessor: device vec4 arrays owned by the scene */
+int svoslam_scene_voxel_grid(svoslam_scene *scene, const float **d_centers, const float **d_colors, int32_t *n,
+                             float *scale);
+/* Scene::svo(bbox) -> Octree::extractSVO (octree.cpp:339-360): non-owning view of the pool */
+int svoslam_scene_svo(svoslam_scene *scene, const uint32_t **d_data, float center[3], float *size, int32_t *num_nodes,
+                      int32_t *max_depth);
+
+/* ------------------------------------------------------------------------
  * Rendering
  * ---------------------------------------------------------------------- */
 #define SVOSLAM_RENDER_REFERENCE 0 /* pixel stored only on retirement, as the reference does */

@@ -44,6 +44,15 @@ class _PoolStruct(C.Structure):
     _fields_ = [("d_data", C.c_void_p), ("size", C.c_int32), ("capacity", C.c_int32)]
 
 
+class MeshStruct(C.Structure):
+    _fields_ = [("vbo", C.POINTER(C.c_float)), ("tbo", C.POINTER(C.c_float)), ("n_tris", C.c_int32), ("tbosize", C.c_int32),
+                ("bbox0", C.c_float * 3), ("bbox1", C.c_float * 3)]
+
+
+class TextureStruct(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_float)), ("width", C.c_int32), ("height", C.c_int32)]
+
+
 class FuseStats(C.Structure):
     _fields_ = [("num_points", C.c_int32), ("num_split", C.c_int32), ("pass_sizes", C.c_int32 * (MAX_DEPTH + 1)),
                 ("pool_size_before", C.c_int32), ("pool_size_after", C.c_int32)]
@@ -71,6 +80,22 @@ SIGNATURES = {
                                                C.POINTER(FuseStats), _vp]),
     "svoslam_extract_voxel_grid": (C.c_int, [_vp, C.POINTER(_PoolStruct), _i32, _fp, _f32, C.POINTER(_vp),
                                               C.POINTER(_vp), C.POINTER(_i32), _vp]),
+    "svoslam_mesh_load_obj": (C.c_int, [C.c_char_p, C.POINTER(MeshStruct)]),
+    "svoslam_mesh_free": (C.c_int, [C.POINTER(MeshStruct)]),
+    "svoslam_texture_load_bmp": (C.c_int, [C.c_char_p, C.POINTER(TextureStruct)]),
+    "svoslam_texture_free": (C.c_int, [C.POINTER(TextureStruct)]),
+    "svoslam_mesh_to_voxel_grid": (C.c_int, [_vp, C.POINTER(MeshStruct), C.POINTER(TextureStruct), _i32, _i32, C.POINTER(_vp),
+                                             C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _fp, _vp]),
+    "svoslam_scene_create": (C.c_int, [C.POINTER(_vp)]),
+    "svoslam_scene_destroy": (C.c_int, [_vp]),
+    "svoslam_scene_load_obj": (C.c_int, [_vp, C.c_char_p]),
+    "svoslam_scene_load_bmp": (C.c_int, [_vp, C.c_char_p]),
+    "svoslam_scene_set_octree": (C.c_int, [_vp, _f32, _fp, _f32, _i32]),
+    "svoslam_scene_voxelize_meshes": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "svoslam_scene_extract_voxel_grid": (C.c_int, [_vp, _vp]),
+    "svoslam_scene_add_point_cloud": (C.c_int, [_vp, _fp, _vp, _vp, _i32, _fp, _fp, _vp]),
+    "svoslam_scene_voxel_grid": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _fp]),
+    "svoslam_scene_svo": (C.c_int, [_vp, C.POINTER(_vp), _fp, _fp, C.POINTER(_i32), C.POINTER(_i32)]),
     "svoslam_free": (C.c_int, [_vp]),
     "svoslam_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "svoslam_cone_trace_svo": (C.c_int, [_vp, _i32, _i32, _f32, _fp, _vp, _fp, _f32, _i32, _vp, _vp]),
@@ -274,6 +299,132 @@ def extract_voxel_grid(ws, pool, max_depth, center, edge_length):
         lib().svoslam_free(pc)
         lib().svoslam_free(pk)
     return ce, co
+
+
+# ----------------------------------------------------------------------------- mesh path
+class Mesh:
+    """Host mesh as Scene::loadObjFile builds it (recentred, non-indexed)."""
+
+    def __init__(self, path=None):
+        self._m = MeshStruct()
+        if path is not None:
+            check(lib().svoslam_mesh_load_obj(str(path).encode(), C.byref(self._m)))
+
+    @property
+    def n_tris(self):
+        return int(self._m.n_tris)
+
+    def vbo(self):
+        return np.ctypeslib.as_array(self._m.vbo, shape=(self.n_tris, 3, 3)).copy() if self.n_tris else np.zeros((0, 3, 3), np.float32)
+
+    def tbo(self):
+        n = int(self._m.tbosize)
+        return np.ctypeslib.as_array(self._m.tbo, shape=(n // 6, 3, 2)).copy() if n else None
+
+    def bbox(self):
+        return np.array(list(self._m.bbox0), np.float32), np.array(list(self._m.bbox1), np.float32)
+
+    def __del__(self):
+        try:
+            lib().svoslam_mesh_free(C.byref(self._m))
+        except Exception:
+            pass
+
+
+class Texture:
+    def __init__(self, path=None):
+        self._t = TextureStruct()
+        if path is not None:
+            check(lib().svoslam_texture_load_bmp(str(path).encode(), C.byref(self._t)))
+
+    def data(self):
+        h, w = int(self._t.height), int(self._t.width)
+        return np.ctypeslib.as_array(self._t.data, shape=(h, w, 3)).copy()
+
+    def __del__(self):
+        try:
+            lib().svoslam_texture_free(C.byref(self._t))
+        except Exception:
+            pass
+
+
+def mesh_to_voxel_grid(ws, mesh, tex, log_n, log_t=3, want_indices=True):
+    """voxelization::meshToVoxelGrid -> (centers cuda [n,4], colors cuda [n,4], indices numpy or None, scale)."""
+    import torch
+    pc, pk, pi, n, scale = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int32(0), C.c_float(0)
+    check(lib().svoslam_mesh_to_voxel_grid(ws._h, C.byref(mesh._m), C.byref(tex._t) if tex is not None else None, log_n, log_t,
+                                           C.byref(pc), C.byref(pk), C.byref(pi) if want_indices else None, C.byref(n),
+                                           C.byref(scale), _stream()))
+    torch.cuda.synchronize()
+    cnt = n.value
+    ce = torch.empty((cnt, 4), dtype=torch.float32, device="cuda")
+    co = torch.empty((cnt, 4), dtype=torch.float32, device="cuda")
+    idx = None
+    if cnt > 0:
+        _hip().hipMemcpy(C.c_void_p(ce.data_ptr()), pc, C.c_size_t(cnt * 16), 3)
+        _hip().hipMemcpy(C.c_void_p(co.data_ptr()), pk, C.c_size_t(cnt * 16), 3)
+        lib().svoslam_free(pc); lib().svoslam_free(pk)
+        if want_indices:
+            idx = np.empty(cnt, np.uint64)
+            _hip().hipMemcpy(C.c_void_p(idx.ctypes.data), pi, C.c_size_t(cnt * 8), 2)
+            lib().svoslam_free(pi)
+    return ce, co, idx, float(scale.value)
+
+
+class Scene:
+    """Mirror of world::Scene (include/octree_slam/world/scene.h)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(lib().svoslam_scene_create(C.byref(self._h)))
+
+    def load_obj(self, path):
+        check(lib().svoslam_scene_load_obj(self._h, str(path).encode()))
+
+    def load_bmp(self, path):
+        check(lib().svoslam_scene_load_bmp(self._h, str(path).encode()))
+
+    def set_octree(self, resolution, center, size, depth_override=0):
+        check(lib().svoslam_scene_set_octree(self._h, float(resolution), _fa(center, 3), float(size), int(depth_override)))
+
+    def voxelize_meshes(self, octree=False, log_n=0):
+        check(lib().svoslam_scene_voxelize_meshes(self._h, 1 if octree else 0, int(log_n), _stream()))
+
+    def extract_voxel_grid_from_octree(self):
+        check(lib().svoslam_scene_extract_voxel_grid(self._h, _stream()))
+
+    def add_point_cloud_to_octree(self, origin, points, colors, bbox0, bbox1):
+        check(lib().svoslam_scene_add_point_cloud(self._h, _fa(origin, 3), _ptr(points), _ptr(colors), int(points.numel() // 3),
+                                                  _fa(bbox0, 3), _fa(bbox1, 3), _stream()))
+
+    def voxel_grid(self):
+        pc, pk, n, sc = C.c_void_p(), C.c_void_p(), C.c_int32(0), C.c_float(0)
+        check(lib().svoslam_scene_voxel_grid(self._h, C.byref(pc), C.byref(pk), C.byref(n), C.byref(sc)))
+        ce = copy_from_device(pc.value, (n.value, 4), np.float32) if n.value else np.zeros((0, 4), np.float32)
+        co = copy_from_device(pk.value, (n.value, 4), np.float32) if n.value else np.zeros((0, 4), np.float32)
+        return ce, co, float(sc.value)
+
+    def svo(self):
+        """-> dict(data_ptr, center, size, num_nodes, max_depth): the SVO view of Scene::svo()."""
+        pd, c, sz, nn, md = C.c_void_p(), (C.c_float * 3)(), C.c_float(0), C.c_int32(0), C.c_int32(0)
+        check(lib().svoslam_scene_svo(self._h, C.byref(pd), c, C.byref(sz), C.byref(nn), C.byref(md)))
+        return {"data_ptr": int(pd.value or 0), "center": np.array(list(c), np.float32), "size": float(sz.value),
+                "num_nodes": int(nn.value), "max_depth": int(md.value)}
+
+    def pool_words(self):
+        v = self.svo()
+        return copy_from_device(v["data_ptr"], (2 * v["num_nodes"],), np.uint32)
+
+    def close(self):
+        if self._h:
+            lib().svoslam_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ----------------------------------------------------------------------------- rendering

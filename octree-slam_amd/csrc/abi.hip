@@ -7,6 +7,7 @@
 #include "cone_trace.hpp"
 #include "icp.hpp"
 #include "image_kernels.hpp"
+#include "mesh.hpp"
 #include "svo_build.hpp"
 #include "workspace.hpp"
 
@@ -131,6 +132,17 @@ int svoslam_extract_voxel_grid(svoslam_workspace *ws, const svoslam_pool *pool, 
 int svoslam_free(void *d_ptr) {
   if (d_ptr) SVO_HIP(hipFree(d_ptr));
   return SVOSLAM_OK;
+}
+
+int svoslam_mesh_load_obj(const char *path, svoslam_mesh *out) { return mesh_load_obj(path, out); }
+int svoslam_mesh_free(svoslam_mesh *mesh) { return mesh_free(mesh); }
+int svoslam_texture_load_bmp(const char *path, svoslam_texture *out) { return texture_load_bmp(path, out); }
+int svoslam_texture_free(svoslam_texture *tex) { return texture_free(tex); }
+int svoslam_mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const svoslam_texture *tex, int32_t log_N,
+                               int32_t log_T, float **d_centers, float **d_colors, unsigned long long **d_indices,
+                               int32_t *n_out, float *scale_out, void *stream) {
+  NEED_DEVICE();
+  return mesh_to_voxel_grid(ws, mesh, tex, log_N, log_T, d_centers, d_colors, d_indices, n_out, scale_out, S(stream));
 }
 
 int svoslam_malloc(void **d_ptr, size_t bytes) {

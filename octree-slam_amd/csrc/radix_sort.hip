@@ -127,8 +127,8 @@ void row_scan_rows1(unsigned *row, int num_tiles, unsigned *total, hipStream_t s
 }
 
 int radix_sort_pairs(svoslam_workspace *ws, int n, int num_bits, hipStream_t stream, unsigned long long **sorted_keys,
-                     unsigned **sorted_vals) {
-  // keys are in ws->keys_a; values are the identity permutation (generated in the first pass)
+                     unsigned **sorted_vals, bool iota_vals) {
+  // keys are in ws->keys_a; values are the identity permutation (generated in the first pass) or ws->vals_a
   unsigned long long *ka = ws->keys_a.as<unsigned long long>(), *kb = ws->keys_b.as<unsigned long long>();
   unsigned *va = ws->vals_a.as<unsigned>(), *vb = ws->vals_b.as<unsigned>();
   unsigned *tile_hist = ws->tile_hist.as<unsigned>();
@@ -145,7 +145,7 @@ int radix_sort_pairs(svoslam_workspace *ws, int n, int num_bits, hipStream_t str
     const unsigned mask = (1u << width) - 1u;
     radix_upsweep_kernel<<<tiles, 256, 0, stream>>>(ka, n, bit, mask, tile_hist, tiles);
     row_scan_kernel<<<256, 256, 0, stream>>>(tile_hist, tiles, totals);
-    radix_downsweep_kernel<<<tiles, 256, 0, stream>>>(ka, va, kb, vb, n, bit, mask, tile_hist, totals, tiles, p == 0);
+    radix_downsweep_kernel<<<tiles, 256, 0, stream>>>(ka, va, kb, vb, n, bit, mask, tile_hist, totals, tiles, (p == 0 && iota_vals) ? 1 : 0);
     SVO_LAUNCH_CHECK();
     unsigned long long *tk = ka; ka = kb; kb = tk;
     unsigned *tv = va; va = vb; vb = tv;

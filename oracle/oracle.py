@@ -40,7 +40,8 @@ def lib(native=False):
         return _LIB
     path = os.path.join(_HERE, "libsvoslam_oracle_native.so" if native else "libsvoslam_oracle.so")
     src = os.path.join(_HERE, "svoslam_oracle.c")
-    if (not os.path.exists(path)) or os.path.getmtime(path) < os.path.getmtime(src):
+    src2 = os.path.join(_HERE, "svoslam_oracle_mesh.c")
+    if (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(src), os.path.getmtime(src2)):
         build(native)
     L = C.CDLL(path)
     f32p, u8p, u16p, u32p, i64p = (C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint16),
@@ -93,6 +94,13 @@ def lib(native=False):
     L.ora_camera_pose.argtypes = [C.c_void_p, f32p, f32p]
     L.ora_camera_fusion_transform.argtypes = [C.c_void_p, f32p]
     L.ora_camera_last_system.argtypes = [C.c_void_p, f32p, f32p, f32p]
+    L.ora_mesh_load_obj.restype = C.c_int
+    L.ora_mesh_load_obj.argtypes = [C.c_char_p, C.POINTER(f32p), C.POINTER(f32p), C.POINTER(C.c_int), f32p, f32p]
+    L.ora_load_bmp.restype = C.c_int
+    L.ora_load_bmp.argtypes = [C.c_char_p, C.POINTER(f32p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ora_mesh_to_voxel_grid.restype = C.c_int
+    L.ora_mesh_to_voxel_grid.argtypes = [f32p, C.c_int, f32p, C.c_int, f32p, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_int,
+                                         C.POINTER(f32p), C.POINTER(f32p), C.POINTER(i64p)]
     if not native:
         _LIB = L
     return L
@@ -402,3 +410,48 @@ class Camera:
             self._L.ora_camera_destroy(self._c)
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------ mesh path
+def _take(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
+    if n > 0:
+        out = np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype).reshape(shape).copy()
+    else:
+        out = np.zeros(shape, dtype)
+    libc.free(ptr)
+    return out
+
+
+def mesh_load_obj(path):
+    """-> dict(vbo [T,3,3], tbo [T,3,2] or None, bbox0, bbox1) as Scene::loadObjFile builds the Mesh"""
+    vb, tb = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+    tsz = C.c_int(0)
+    b0, b1 = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    n = lib().ora_mesh_load_obj(path.encode(), C.byref(vb), C.byref(tb), C.byref(tsz), _p(b0, C.c_float), _p(b1, C.c_float))
+    if n < 0:
+        raise IOError(path)
+    vbo = _take(vb, (n, 3, 3), np.float32)
+    tbo = _take(tb, (tsz.value // 6, 3, 2), np.float32) if tsz.value > 0 else None
+    return {"vbo": vbo, "tbo": tbo, "bbox0": b0, "bbox1": b1}
+
+
+def load_bmp(path):
+    d = C.POINTER(C.c_float)()
+    w, h = C.c_int(0), C.c_int(0)
+    if lib().ora_load_bmp(path.encode(), C.byref(d), C.byref(w), C.byref(h)) != 0:
+        raise IOError(path)
+    return _take(d, (h.value, w.value, 3), np.float32)
+
+
+def mesh_to_voxel_grid(mesh, tex, log_n, log_t=3):
+    vbo = _f32(mesh["vbo"]).reshape(-1)
+    tbo = _f32(mesh["tbo"]).reshape(-1) if mesh.get("tbo") is not None else np.zeros(0, np.float32)
+    texa = _f32(tex).reshape(-1) if tex is not None else np.zeros(0, np.float32)
+    tw, th = (tex.shape[1], tex.shape[0]) if tex is not None else (0, 0)
+    b0, b1 = _f32(mesh["bbox0"]), _f32(mesh["bbox1"])
+    pc, pk, pi = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.POINTER(C.c_int64)()
+    n = lib().ora_mesh_to_voxel_grid(_p(vbo, C.c_float), vbo.size // 9, _p(tbo, C.c_float), tbo.size, _p(texa, C.c_float), tw, th,
+                                     _p(b0, C.c_float), _p(b1, C.c_float), log_n, log_t, C.byref(pc), C.byref(pk), C.byref(pi))
+    return _take(pc, (n, 4), np.float32), _take(pk, (n, 4), np.float32), _take(pi, (n,), np.int64)

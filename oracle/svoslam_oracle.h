@@ -124,6 +124,16 @@ void ora_camera_fusion_transform(const ora_camera *c, float out[16]);
 /* last A,b,x of the last processed frame, for tests */
 void ora_camera_last_system(const ora_camera *c, float A[36], float b[6], float x[6]);
 
+/* ---------------------------------------------------------------- mesh path (svoslam_oracle_mesh.c) */
+/* objloader.cpp:14-122 + obj.cpp:33-135,227-238 + scene.cpp:115-133: returns #triangles, -1 on open failure */
+int ora_mesh_load_obj(const char *path, float **vbo, float **tbo, int *tbosize, float bbox0[3], float bbox1[3]);
+/* scene.cpp:35-62 */
+int ora_load_bmp(const char *path, float **data, int *width, int *height);
+/* voxelization.cu:381-405 with the VoxelPipe THIN / NO_BLENDING rule; N = 2^log_N cells per axis */
+int ora_mesh_to_voxel_grid(const float *vbo, int n_tris, const float *tbo, int tbosize, const float *tex, int tex_w,
+                           int tex_h, const float bbox0[3], const float bbox1[3], int log_N, int log_T,
+                           float **centers, float **colors, int64_t **indices);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,86 @@
+"""Procedural OBJ / BMP inputs for the mesh-path tests (the reference's objs/*.obj are not available on
+the GPU box; these files are generated, not copied)."""
+import struct
+
+import numpy as np
+
+
+def write_cube_obj(path, h=0.1):
+    """axis-aligned cube +-h in the 'v//vn' face format (the shape of the reference's objs/cube.obj: 8 v, 12 tris)"""
+    v = [(-h, -h, -h), (-h, -h, h), (-h, h, h), (-h, h, -h), (h, h, -h), (h, h, h), (h, -h, h), (h, -h, -h)]
+    n = [(1, 0, 0), (0, 1, 0), (0, 0, 1), (-1, 0, 0), (0, -1, 0), (0, 0, -1)]
+    f = [(1, 2, 4, 4), (4, 2, 3, 4), (8, 1, 5, 6), (5, 1, 4, 6), (5, 6, 8, 1), (8, 6, 7, 1), (6, 3, 7, 3), (7, 3, 2, 3),
+         (4, 3, 5, 2), (5, 3, 6, 2), (1, 8, 2, 5), (2, 8, 7, 5)]
+    with open(path, "w") as fp:
+        for p in v:
+            fp.write("v %g %g %g\n" % p)
+        fp.write("\n")
+        for q in n:
+            fp.write("vn %g %g %g\n" % q)
+        fp.write("\n")
+        for a, b, c, k in f:
+            fp.write("f %d//%d %d//%d %d//%d\n" % (a, k, b, k, c, k))
+    return path
+
+
+def write_sphere_obj(path, rings=24, segs=32, radius=(0.9, 1.3, 0.7), center=(0.3, 1.0, -0.2), quads=True):
+    """textured ellipsoid in the 'v/vt/vn' format; optionally quads (exercise the fan triangulation)"""
+    vs, vts, faces = [], [], []
+    for i in range(rings + 1):
+        th = np.pi * i / rings
+        for j in range(segs + 1):
+            ph = 2 * np.pi * j / segs
+            vs.append((center[0] + radius[0] * np.sin(th) * np.cos(ph), center[1] + radius[1] * np.cos(th),
+                       center[2] + radius[2] * np.sin(th) * np.sin(ph)))
+            vts.append((j / segs * 0.999, i / rings * 0.999))
+    idx = lambda i, j: i * (segs + 1) + j + 1
+    for i in range(rings):
+        for j in range(segs):
+            a, b, c, d = idx(i, j), idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)
+            if quads and 0 < i < rings - 1 and (i + j) % 3 == 0:
+                faces.append((a, b, c, d))
+            else:
+                if i > 0:
+                    faces.append((a, b, d))
+                if i < rings - 1:
+                    faces.append((b, c, d))
+    with open(path, "w") as fp:
+        fp.write("# generated\n")
+        for p in vs:
+            fp.write("v %.6f %.6f %.6f\n" % p)
+        for t in vts:
+            fp.write("vt %.6f %.6f\n" % t)
+        fp.write("vn 0 1 0\n")
+        for f in faces:
+            fp.write("f " + " ".join("%d/%d/1" % (k, k) for k in f) + "\n")
+    return path
+
+
+def write_soup_obj(path, n=300, seed=0):
+    """random triangles of assorted sizes/orientations (plain 'f a b c' format)"""
+    rng = np.random.default_rng(seed)
+    with open(path, "w") as fp:
+        for t in range(n):
+            c = rng.random(3) * 2 - 1
+            s = 10 ** rng.uniform(-2.0, -0.3)
+            for _ in range(3):
+                p = c + rng.normal(size=3) * s
+                fp.write("v %.6f %.6f %.6f\n" % tuple(p))
+        # a few exactly axis-aligned triangles (degenerate plane components)
+        fp.write("v 0.5 0.5 0.5\nv 0.5 0.9 0.5\nv 0.5 0.5 0.9\nv -0.5 0.2 0.1\nv 0.1 0.2 0.1\nv -0.5 0.2 0.7\n")
+        for t in range(n + 2):
+            fp.write("f %d %d %d\n" % (3 * t + 1, 3 * t + 2, 3 * t + 3))
+    return path
+
+
+def write_bmp(path, w=64, h=64, seed=0):
+    """24-bit BMP, rows as stored (Scene::loadBMP ignores row order/padding; w*3 is a multiple of 4 here)"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(xx * 255 // (w - 1)), (yy * 255 // (h - 1)), ((xx // 8 + yy // 8) % 2) * 200 + 30], -1).astype(np.uint8)
+    img[rng.random((h, w)) < 0.05] = 255
+    data = img[..., ::-1].tobytes()  # BGR
+    hdr = b"BM" + struct.pack("<IHHI", 54 + len(data), 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, len(data), 2835, 2835, 0, 0)
+    with open(path, "wb") as fp:
+        fp.write(hdr + data)
+    return path

@@ -1,0 +1,116 @@
+"""GPU parity of the mesh path: meshToVoxelGrid and Scene::voxelizeMeshes / the config-1 and config-2 style
+pipelines (mesh -> voxel grid -> SVO -> extract -> cone-traced render) through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+import meshgen
+from util import describe_mismatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import svoslam_pkg
+    return svoslam_pkg.load(), torch
+
+
+def f32(x):
+    return np.float32(x)
+
+
+@pytest.mark.parametrize("shape,log_n", [("cube", 5), ("cube", 8), ("sphere", 7), ("sphere", 10), ("soup", 8), ("soup", 9)])
+def test_mesh_to_voxel_grid_matches_oracle(env, oracle, tmp_path, shape, log_n):
+    pkg, torch = env
+    path = {"cube": meshgen.write_cube_obj, "sphere": meshgen.write_sphere_obj, "soup": meshgen.write_soup_obj}[shape](tmp_path / (shape + ".obj"))
+    tex_path = meshgen.write_bmp(tmp_path / "t.bmp") if shape == "sphere" else None
+    mesh, tex = pkg.Mesh(path), (pkg.Texture(tex_path) if tex_path else None)
+    omesh, otex = oracle.mesh_load_obj(str(path)), (oracle.load_bmp(str(tex_path)) if tex_path else None)
+    ws = pkg.Workspace()
+    ce, co, idx, scale = pkg.mesh_to_voxel_grid(ws, mesh, tex, log_n)
+    rce, rco, ridx = oracle.mesh_to_voxel_grid(omesh, otex, log_n)
+    assert len(ridx) > 100
+    assert np.array_equal(idx.astype(np.int64), ridx), describe_mismatch(idx.astype(np.int64), ridx)
+    assert np.array_equal(ce.cpu().numpy().view(np.uint32), rce.view(np.uint32))
+    assert np.array_equal(co.cpu().numpy().view(np.uint32), rco.view(np.uint32))
+    assert scale == float((omesh["bbox1"][0] - omesh["bbox0"][0]) / f32(1 << log_n) / f32(2.0))
+
+
+def oracle_scene(oracle, omesh, otex, log_n):
+    """Scene::voxelizeMeshes(true) composed from oracle calls (scene.cpp:64-85, octree.cpp:293-337)"""
+    ce, co, _ = oracle.mesh_to_voxel_grid(omesh, otex, log_n)
+    b0, b1 = omesh["bbox0"], omesh["bbox1"]
+    scale = b1[0] / f32(1 << log_n)
+    center = (b1 + b0) / f32(2.0)
+    size = b1[0]
+    pool = oracle.Pool()
+    pool.insert_voxel_grid(ce, co, log_n, center, float(size))   # depth = ceil(log2(size/scale)) = log_n exactly
+    ece, eco = pool.extract(log_n, center, float(size))
+    return pool, center, float(size), ece, eco, float(scale)
+
+
+@pytest.mark.parametrize("shape,log_n,res", [("cube", 5, (256, 256)), ("sphere", 8, (160, 120)), ("sphere", 10, (640, 480))])
+def test_scene_voxelize_and_render(env, oracle, tmp_path, shape, log_n, res):
+    """config 1 (cube, depth 5, one 256x256 raycast from lookAt((0,0.1,-0.6),(0,0.1,0),(0,1,0))) and a config-2
+    style textured mesh at depth 8 / 10, 640x480, 3 views"""
+    pkg, torch = env
+    path = (meshgen.write_cube_obj if shape == "cube" else meshgen.write_sphere_obj)(tmp_path / "m.obj")
+    tex_path = None if shape == "cube" else meshgen.write_bmp(tmp_path / "t.bmp")
+    scene = pkg.Scene()
+    scene.load_obj(path)
+    if tex_path:
+        scene.load_bmp(tex_path)
+    scene.voxelize_meshes(octree=True, log_n=log_n)
+    omesh, otex = oracle.mesh_load_obj(str(path)), (oracle.load_bmp(str(tex_path)) if tex_path else None)
+    opool, center, size, ece, eco, scale = oracle_scene(oracle, omesh, otex, log_n)
+    svo = scene.svo()
+    assert svo["max_depth"] == log_n and svo["num_nodes"] == opool.size
+    assert np.array_equal(svo["center"], center) and svo["size"] == size
+    gw, cw = scene.pool_words(), opool.words()
+    assert np.array_equal(gw, cw), describe_mismatch(gw, cw)
+    gce, gco, gscale = scene.voxel_grid()
+    assert gscale == scale and gce.shape == ece.shape and gce.shape[0] > 0
+    assert np.array_equal(gce.view(np.uint32), ece.view(np.uint32)) and np.array_equal(gco.view(np.uint32), eco.view(np.uint32))
+    w, h = res
+    if shape == "cube":
+        views = [oracle.look_at((0, 0.1, -0.6), (0, 0.1, 0), (0, 1, 0))]
+    else:
+        c = center.astype(np.float64)
+        views = [oracle.look_at(tuple(c + np.array(o)), tuple(c), (0, 1, 0)) for o in ((0.2, 0.4, -3.5), (3.0, 0.1, 0.5), (-1.5, 1.5, 2.0))]
+    for view in views:
+        for mode in (0, 1):
+            img = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+            pkg.cone_trace_svo(img, 45.0, view, svo["data_ptr"], center, size, mode)
+            ref, _, _ = oracle.cone_trace(opool, w, h, 45.0, view, center, size, mode)
+            got = img.cpu().numpy()
+            assert np.array_equal(got, ref), describe_mismatch(got, ref)
+    # a once-voxelized mesh never saturates (Q10): carry-mode image is non-trivial, reference-mode alpha is 255 everywhere
+    assert (ref[..., 3] == 255).all()
+
+
+def test_scene_point_cloud_path(env, oracle):
+    """Scene::addPointCloudToOctree: tree created from the first cloud's bbox (resolution 0.01, size = bbox1.x)"""
+    pkg, torch = env
+    rng = np.random.default_rng(2)
+    scene = pkg.Scene()
+    opool = None
+    for f in range(3):
+        pts = (rng.random((20000, 3)) * np.array([2.4, 1.6, 2.0]) + np.array([-1.2, -0.8, 0.4])).astype(np.float32) * f32(0.9 if f else 1.0)
+        col = rng.integers(0, 256, (20000, 3), dtype=np.uint8)
+        b0, b1 = oracle.point_cloud_bbox(pts)
+        if f == 0:
+            center, size = (b1 + b0) / f32(2.0), float(b1[0])
+            q = f32(size) / f32(0.01)
+            depth = int(np.ceil(np.log2(np.float64(q))))  # exact ceil-log2 of the rounded quotient (not a power of two here)
+            opool = oracle.Pool()
+        scene.add_point_cloud_to_octree((0, 0, 0), torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), b0, b1)
+        opool.insert_cloud(pts, col, depth, center, size)
+        svo = scene.svo()
+        assert svo["max_depth"] == depth and svo["num_nodes"] == opool.size
+        assert np.array_equal(scene.pool_words(), opool.words())
+    scene.extract_voxel_grid_from_octree()
+    gce, gco, gscale = scene.voxel_grid()
+    ed = int(np.ceil(np.log2(np.float64(f32(size) / f32(0.01)))))
+    rce, rco = opool.extract(ed, center, size)
+    assert np.array_equal(gce.view(np.uint32), rce.view(np.uint32)) and np.array_equal(gco.view(np.uint32), rco.view(np.uint32))
