@@ -44,11 +44,13 @@ class DistContext:
             # create the RCCL communicator and its streams NOW (first use is lazy and was observed to
             # mis-order against kernels queued around it), then drain the device once
             import torch.distributed as dist
-            t = torch.zeros(27, dtype=torch.float64, device="cuda")
+            dev = "cuda" if torch.cuda.is_available() else "cpu"   # cpu: the gloo tests
+            t = torch.zeros(27, dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-            g = torch.empty(self.world * 4, dtype=torch.float32, device="cuda")
-            dist.all_gather_into_tensor(g, torch.zeros(4, dtype=torch.float32, device="cuda"), group=self.group)
-            torch.cuda.synchronize()
+            g = torch.empty(self.world * 4, dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(g, torch.zeros(4, dtype=torch.float32, device=dev), group=self.group)
+            if dev == "cuda":
+                torch.cuda.synchronize()
 
     @property
     def enabled(self):
