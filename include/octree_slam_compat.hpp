@@ -59,7 +59,7 @@ struct Registry {
   }
   svoslam_pool open(unsigned int *data, int size) {
     std::lock_guard<std::mutex> g(mu);
-    svoslam_pool p{data, size, size};
+    svoslam_pool p{data, size, size, nullptr, 0, 0};
     auto it = capacity.find(data);
     if (it != capacity.end() && it->second >= size) p.capacity = it->second;
     return p;

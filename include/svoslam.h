@@ -63,14 +63,19 @@ int svoslam_kernel_count(void);
  * ---------------------------------------------------------------------- */
 typedef struct {
   uint32_t *d_data;    /* 2*capacity words, device */
-  int32_t size;        /* nodes in use (the reference's octree_size) */
+  int32_t size;        /* nodes in use (the reference's octree_size); exact unless `pending` > 0 */
   int32_t capacity;    /* nodes allocated */
+  int32_t *d_size;     /* device-resident copy of the size (kept by the library; NULL for foreign pools) */
+  int32_t pending;     /* asynchronous fusion calls enqueued since `size` was last exact */
+  int64_t pending_bound; /* upper bound on the nodes those calls can add */
 } svoslam_pool;
 
 /* replaces svo::initOctree (svo.cu:24-31): 8 zeroed root children */
 int svoslam_pool_init(svoslam_pool *pool, int32_t capacity_nodes, void *stream);
 int svoslam_pool_reserve(svoslam_pool *pool, int32_t capacity_nodes, void *stream);
 int svoslam_pool_free(svoslam_pool *pool);
+/* makes pool->size exact again after asynchronous fusion calls (one stream sync + 4-byte readback) */
+int svoslam_pool_sync(svoslam_pool *pool, void *stream);
 
 /* Opaque scratch arena reused across calls (sort buffers, plan records...).
  * The reference cudaMallocs ~6+D temporaries per call instead. */
@@ -95,6 +100,14 @@ typedef struct {
 int svoslam_svo_from_point_cloud(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors,
                                  int32_t n, int32_t max_depth, svoslam_pool *pool, const float center[3],
                                  float edge_length, svoslam_fuse_stats *stats, void *stream);
+
+/* Same fusion, fully asynchronous: nothing is read back, the new size stays on the device
+ * (pool->d_size) and pool->size becomes exact again at the next blocking call or svoslam_pool_sync.
+ * Capacity is reserved ahead for the worst case (sum over levels of min(8^d, n) splits per call);
+ * only when that reservation runs out does the call synchronise once to learn the true size. */
+int svoslam_svo_from_point_cloud_async(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors,
+                                       int32_t n, int32_t max_depth, svoslam_pool *pool, const float center[3],
+                                       float edge_length, void *stream);
 
 /* replaces svo::svoFromVoxelGrid (svo.h:14, svo.cu:584-640).  d_centers,
  * d_colors: n x vec4 (VoxelGrid, common_types.h:55-63). */

@@ -41,7 +41,8 @@ def build(verbose=False, force=False):
 
 
 class _PoolStruct(C.Structure):
-    _fields_ = [("d_data", C.c_void_p), ("size", C.c_int32), ("capacity", C.c_int32)]
+    _fields_ = [("d_data", C.c_void_p), ("size", C.c_int32), ("capacity", C.c_int32), ("d_size", C.c_void_p),
+                ("pending", C.c_int32), ("pending_bound", C.c_int64)]
 
 
 class MeshStruct(C.Structure):
@@ -72,6 +73,8 @@ SIGNATURES = {
     "svoslam_pool_init": (C.c_int, [C.POINTER(_PoolStruct), _i32, _vp]),
     "svoslam_pool_reserve": (C.c_int, [C.POINTER(_PoolStruct), _i32, _vp]),
     "svoslam_pool_free": (C.c_int, [C.POINTER(_PoolStruct)]),
+    "svoslam_pool_sync": (C.c_int, [C.POINTER(_PoolStruct), _vp]),
+    "svoslam_svo_from_point_cloud_async": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _fp, _f32, _vp]),
     "svoslam_workspace_create": (C.c_int, [C.POINTER(_vp)]),
     "svoslam_workspace_destroy": (C.c_int, [_vp]),
     "svoslam_svo_from_point_cloud": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _fp, _f32,
@@ -203,11 +206,13 @@ class Pool:
     """Device node pool (svoslam_pool).  words() copies it to the host as uint32."""
 
     def __init__(self, capacity_nodes=8):
-        self._p = _PoolStruct(None, 0, 0)
+        self._p = _PoolStruct(None, 0, 0, None, 0, 0)
         check(lib().svoslam_pool_init(C.byref(self._p), capacity_nodes, _stream()))
 
     @property
     def size(self):
+        if self._p.pending > 0:   # asynchronous fusion calls in flight: fetch the exact size (blocking)
+            check(lib().svoslam_pool_sync(C.byref(self._p), _stream()))
         return int(self._p.size)
 
     @property
@@ -273,6 +278,13 @@ def svo_from_point_cloud(ws, points, colors, max_depth, pool, center, edge_lengt
     check(lib().svoslam_svo_from_point_cloud(ws._h, _ptr(points), _ptr(colors), n, max_depth, C.byref(pool._p),
                                              _fa(center, 3), float(edge_length), C.byref(stats), _stream()))
     return stats
+
+
+def svo_from_point_cloud_async(ws, points, colors, max_depth, pool, center, edge_length):
+    """svoFromPointCloud without any host round trip (size stays on the device until pool.size is read)."""
+    n = int(points.shape[0]) if points is not None else 0
+    check(lib().svoslam_svo_from_point_cloud_async(ws._h, _ptr(points), _ptr(colors), n, max_depth, C.byref(pool._p),
+                                                   _fa(center, 3), float(edge_length), _stream()))
 
 
 def svo_from_voxel_grid(ws, centers, colors, max_depth, pool, center, edge_length):

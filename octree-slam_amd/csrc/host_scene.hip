@@ -39,10 +39,12 @@ static int ceil_log2_of(float q) {
 Octree::Octree(const float resolution, const float center[3], const float size) : size_(size), resolution_(resolution) {
   for (int k = 0; k < 3; k++) center_[k] = center[k];
   pool_.d_data = nullptr; pool_.size = 0; pool_.capacity = 0;
+  pool_.d_size = nullptr; pool_.pending = 0; pool_.pending_bound = 0;
 }
 
 Octree::~Octree() {
   if (pool_.d_data) (void)hipFree(pool_.d_data);
+  if (pool_.d_size) (void)hipFree(pool_.d_size);
 }
 
 int Octree::maxDepth(float edge_length, float resolution) const {

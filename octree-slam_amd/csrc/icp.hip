@@ -45,6 +45,8 @@ struct CamState {
   float position[3];
   float orientation[9];
   float fusion[16];
+  float fusion_ring[4][16];  // fusion transform of the last 4 frames (slot = frame sequence & 3): lets the
+                             // mapping stream read frame k's pose while the tracking stream is on frame k+1
   float lastA[36], lastb[6], lastx[6];
   int lost;                 // NaN seen at this pyramid level (rgbd_camera.cpp:148-151)
   int tracking_lost_count;  // levels abandoned so far
@@ -393,7 +395,7 @@ __device__ inline void solve_step(CamState *st, const double *sums, int slot) {
 }
 
 // :172-173 pose update (Q17: row-vector products) and the fusion transform of main.cpp:40
-__device__ inline void frame_end_step(CamState *st, int apply_update) {
+__device__ inline void frame_end_step(CamState *st, int apply_update, int slot) {
   if (apply_update) {
     const float *m = st->update_trans;
     const float v[4] = {st->position[0], st->position[1], st->position[2], 1.0f};
@@ -415,6 +417,7 @@ __device__ inline void frame_end_step(CamState *st, int apply_update) {
   d_identity(I);
   d_translate(I, st->position, t);
   d_mat4_mul(o4, t, st->fusion);
+  for (int i = 0; i < 16; i++) st->fusion_ring[slot & 3][i] = st->fusion[i];
 }
 
 __device__ inline void level_begin_step(CamState *st, int flags) {
@@ -427,29 +430,29 @@ __device__ inline void level_begin_step(CamState *st, int flags) {
 
 // single-GPU iteration tail: sum the workgroup rows, solve, compose -- ONE launch
 __global__ __launch_bounds__(kReduceThreads) void cam_reduce_solve_kernel(CamState *st, const double *__restrict__ partial,
-                                                                          int rows, int slot, int flags) {
+                                                                          int rows, int slot, int flags, int ring_slot) {
   __shared__ double red[kReduceThreads / 32][27];
   __shared__ double totals[27];
   reduce_rows(partial, rows, red, totals);
   if (threadIdx.x != 0) return;
   level_begin_step(st, flags);
   if (!st->lost) solve_step(st, totals, slot);
-  if (flags & kFlagLastOfFrame) frame_end_step(st, 1);
+  if (flags & kFlagLastOfFrame) frame_end_step(st, 1, ring_slot);
 }
 
 // multi-GPU iteration tail: acc[] holds the all-reduced sums
-__global__ void cam_solve_kernel(CamState *st, double *acc, int slot, int flags) {
+__global__ void cam_solve_kernel(CamState *st, double *acc, int slot, int flags, int ring_slot) {
   if (threadIdx.x || blockIdx.x) return;
   double sums[27];
   for (int i = 0; i < 27; i++) { sums[i] = acc[i]; acc[i] = 0.0; }
   level_begin_step(st, flags);
   if (!st->lost) solve_step(st, sums, slot);
-  if (flags & kFlagLastOfFrame) frame_end_step(st, 1);
+  if (flags & kFlagLastOfFrame) frame_end_step(st, 1, ring_slot);
 }
 
-__global__ void cam_frame_end_kernel(CamState *st, int apply_update) {
+__global__ void cam_frame_end_kernel(CamState *st, int apply_update, int ring_slot) {
   if (threadIdx.x || blockIdx.x) return;
-  frame_end_step(st, apply_update);
+  frame_end_step(st, apply_update, ring_slot);
 }
 
 }  // namespace svoslam
@@ -474,6 +477,8 @@ struct svoslam_camera {
   double *d_acc = nullptr;  // defaults to d_state->acc; may be redirected for multi-GPU all-reduce
   double *d_partial = nullptr;  // per-workgroup rows of the accumulate kernel
   bool frame_has_icp = false;
+  unsigned frame_seq = 0;  // processed frames so far
+  int ring_slot = 0;       // fusion_ring slot of the frame being / last processed
 };
 
 namespace svoslam {
@@ -501,7 +506,10 @@ int camera_create(svoslam_camera **out, int w, int h, float fx, float fy) {
   CamState init;
   memset(&init, 0, sizeof(init));
   init.orientation[0] = init.orientation[4] = init.orientation[8] = 1.0f;  // glm::mat3() = identity, vec3() = 0
-  for (int i = 0; i < 16; i += 5) { init.update_trans[i] = 1.0f; init.fusion[i] = 1.0f; init.level_start[i] = 1.0f; }
+  for (int i = 0; i < 16; i += 5) {
+    init.update_trans[i] = 1.0f; init.fusion[i] = 1.0f; init.level_start[i] = 1.0f;
+    for (int r = 0; r < 4; r++) init.fusion_ring[r][i] = 1.0f;
+  }
   SVO_HIP(hipMemcpy(c->d_state, &init, sizeof(init), hipMemcpyHostToDevice));
   c->d_acc = c->d_state->acc;
   *out = c;
@@ -543,6 +551,7 @@ int camera_begin(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rg
     if (i != 2) SVO_TRY(subsample_depth_u16_to(c->filt[i], c->filt[i + 1], w, h, s));
   }
   c->frame_has_icp = c->pass >= 1;
+  c->ring_slot = (int)(c->frame_seq++ & 3u);
   return SVOSLAM_OK;
 }
 
@@ -579,7 +588,7 @@ int camera_icp_accumulate(svoslam_camera *c, int level, int iter, hipStream_t s)
 int camera_icp_solve(svoslam_camera *c, int level, int iter, hipStream_t s) {
   if (!c || level < 0 || level > 2 || iter < 0 || iter >= kPyramidIters[level]) return SVOSLAM_ERR_INVALID_ARG;
   if (!c->frame_has_icp) return SVOSLAM_OK;
-  cam_solve_kernel<<<1, 64, 0, s>>>(c->d_state, c->d_acc, iter, iter_flags(level, iter));
+  cam_solve_kernel<<<1, 64, 0, s>>>(c->d_state, c->d_acc, iter, iter_flags(level, iter), c->ring_slot);
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
 }
@@ -587,7 +596,7 @@ int camera_icp_solve(svoslam_camera *c, int level, int iter, hipStream_t s) {
 int camera_end(svoslam_camera *c, hipStream_t s) {
   if (!c) return SVOSLAM_ERR_INVALID_ARG;
   if (!c->frame_has_icp) {  // first frame: no ICP, only the fusion transform (the last solve did it otherwise)
-    cam_frame_end_kernel<<<1, 64, 0, s>>>(c->d_state, 0);
+    cam_frame_end_kernel<<<1, 64, 0, s>>>(c->d_state, 0, c->ring_slot);
     SVO_LAUNCH_CHECK();
   }
   if (c->pass < 2) c->pass++;  // :176-178
@@ -615,7 +624,7 @@ int camera_update(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_r
         const int flags = iter_flags(level, it);
         icp_accumulate_kernel<<<blocks, kIcpThreads, 0, s>>>(a.lv, a.ln, a.cv, a.cn, a.first, end, c->d_state, flags, it,
                                                              c->d_partial);
-        cam_reduce_solve_kernel<<<1, kReduceThreads, 0, s>>>(c->d_state, c->d_partial, blocks, it, flags);
+        cam_reduce_solve_kernel<<<1, kReduceThreads, 0, s>>>(c->d_state, c->d_partial, blocks, it, flags, c->ring_slot);
       }
     }
     SVO_LAUNCH_CHECK();
@@ -658,7 +667,9 @@ int camera_last_system(svoslam_camera *c, float A[36], float b[6], float x[6], h
   return SVOSLAM_OK;
 }
 
-const float *camera_fusion_transform_device(svoslam_camera *c) { return c ? c->d_state->fusion : nullptr; }
+// pose of the frame most recently handed to update()/begin(); the slot stays untouched until three more
+// frames have been started, so another stream may read it while the tracker runs ahead
+const float *camera_fusion_transform_device(svoslam_camera *c) { return c ? c->d_state->fusion_ring[c->ring_slot] : nullptr; }
 const float *camera_last_vertex(svoslam_camera *c, int level) {
   return (c && level >= 0 && level < 3) ? c->vert[1 - c->cur][level] : nullptr;
 }

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void plan_finish_kernel(const u32 *__restrict_
   const u32 ex = block256_exclusive_scan(totals[threadIdx.x], tmp, total);
   bucket_base[threadIdx.x] = ex;
   sbase[threadIdx.x] = ex;
-  if (threadIdx.x == 0) sbase[256] = total;
+  if (threadIdx.x == 0) { sbase[256] = total; bucket_base[256] = total; }
   __syncthreads();
   if (threadIdx.x <= 16) counts->pass_start[threadIdx.x] = (int32_t)sbase[threadIdx.x * 16];
   if (threadIdx.x == 17) { counts->pass_start[17] = (int32_t)total; counts->total_records = (int32_t)total; counts->any_valid = *any_valid; }
@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void plan_emit_kernel(const u64 *__restrict__ 
                                                         const unsigned char *__restrict__ leaf_t,
                                                         const u32 *__restrict__ leaf_f, const u32 *__restrict__ bucket_base,
                                                         const u32 *__restrict__ row_prefix, int num_tiles,
-                                                        u64 *__restrict__ rec_key, u32 *__restrict__ rec_front) {
+                                                        u64 *__restrict__ rec_key, u32 *__restrict__ rec_front,
+                                                        unsigned char *__restrict__ rec_pass) {
   __shared__ u32 cnt[4][256];
 #pragma unroll
   for (int w = 0; w < 4; w++) cnt[w][threadIdx.x] = 0;
@@ -200,8 +201,61 @@ __global__ __launch_bounds__(256) void plan_emit_kernel(const u64 *__restrict__ 
                       (u32)__popcll(peers & lt);
       rec_key[pos] = key >> (3 * (depth - d));  // prefix key with its leading 1
       rec_front[pos] = f;
+      if (rec_pass) rec_pass[pos] = (unsigned char)(d - t);
     }
   }
+}
+
+// All splits of a call in ONE launch (the asynchronous path).  The reference runs one splitNodes
+// launch per pass because a pass walks the pool through the tiles the previous pass created
+// (svo.cu:278-289).  Here a record's tile index is its rank (num_nodes0 + 8r), known without
+// touching the pool, so every word is written exactly once by one lane, in any order:
+//  * a pass-0 record sets flag + tile index in its (existing) frontier node;
+//  * every record initialises its own 8-child tile, and gives child c the word0 the reference's
+//    NEXT pass would give it: flag + tile index of the record for key*8+c if that prefix is being
+//    split too (found by key in bucket (pass+1, depth+1), which is sorted), else 0.
+// Same pool contents as the pass loop, no pass ordering, no host-side counts.
+__global__ __launch_bounds__(256) void split_all_kernel(const u64 *__restrict__ rec_key, const u32 *__restrict__ rec_front,
+                                                        const unsigned char *__restrict__ rec_pass,
+                                                        const u32 *__restrict__ bucket_base, const PlanCounts *__restrict__ counts,
+                                                        u32 *__restrict__ pool, const int *__restrict__ d_size, int depth) {
+  const u32 total = (u32)counts->total_records;
+  const u32 n0 = (u32)*d_size;
+  for (u32 r = blockIdx.x * 256u + threadIdx.x; r < total; r += gridDim.x * 256u) {
+    const u64 key = rec_key[r];
+    const int pass = rec_pass[r];
+    const int d = (63 - __clzll((long long)key)) / 3;
+    const u32 child = n0 + 8u * r;
+    if (pass == 0) pool[2 * (size_t)rec_front[r]] = kFlag + (child & kMask);
+    u32 w0[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (d + 1 <= depth - 1) {  // children at depth d+1 can only be records while d+1 < D
+      const u32 b = bucket_id(pass + 1, d + 1);
+      u32 lo = bucket_base[b];
+      const u32 end = bucket_base[b + 1];
+      u32 hi = end;
+      const u64 first = key << 3;
+      while (lo < hi) {  // lower bound of key*8 in the sorted bucket
+        const u32 mid = (lo + hi) >> 1;
+        if (rec_key[mid] < first) lo = mid + 1; else hi = mid;
+      }
+      for (u32 q = lo; q < end && q < lo + 8u; q++) {
+        const u64 k = rec_key[q];
+        if ((k >> 3) != key) break;
+        w0[(u32)(k & 7ull)] = kFlag + ((n0 + 8u * q) & kMask);
+      }
+    }
+    uint4 *tile = reinterpret_cast<uint4 *>(pool + 2 * (size_t)child);  // 64-byte aligned child tile
+    const u32 a = 127u << 24;
+    tile[0] = make_uint4(w0[0], a, w0[1], a);
+    tile[1] = make_uint4(w0[2], a, w0[3], a);
+    tile[2] = make_uint4(w0[4], a, w0[5], a);
+    tile[3] = make_uint4(w0[6], a, w0[7], a);
+  }
+}
+
+// size bookkeeping of the asynchronous path: *d_size += 8 * records (the pool's device-side size)
+__global__ void pool_size_update_kernel(int *__restrict__ d_size, const PlanCounts *__restrict__ counts) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *d_size += 8 * counts->total_records;
 }
 
 // splitNodes (svo.cu:239-276) for the records of one pass: record r of the
@@ -319,9 +373,31 @@ __global__ void mip_root_kernel(u32 *__restrict__ pool, const PlanCounts *__rest
 // ----------------------------------------------------------------------------
 // host driver
 // ----------------------------------------------------------------------------
+int pool_sync(svoslam_pool *pool, hipStream_t stream) {
+  if (!pool) return SVOSLAM_ERR_INVALID_ARG;
+  if (pool->pending > 0 && pool->d_size) {
+    int32_t sz = 0;
+    SVO_HIP(hipMemcpyAsync(&sz, pool->d_size, 4, hipMemcpyDeviceToHost, stream));
+    SVO_HIP(hipStreamSynchronize(stream));
+    pool->size = sz;
+  }
+  pool->pending = 0;
+  pool->pending_bound = 0;
+  return SVOSLAM_OK;
+}
+
+static int ensure_device_size(svoslam_pool *pool, hipStream_t stream) {
+  if (pool->d_size) return SVOSLAM_OK;
+  SVO_HIP(hipMalloc((void **)&pool->d_size, 4));
+  SVO_HIP(hipMemcpyAsync(pool->d_size, &pool->size, 4, hipMemcpyHostToDevice, stream));
+  SVO_HIP(hipStreamSynchronize(stream));
+  return SVOSLAM_OK;
+}
+
 static int grow_pool(svoslam_pool *pool, int64_t need_nodes, hipStream_t stream) {
   if (need_nodes > (int64_t)kMask + 1) return SVOSLAM_ERR_POOL_LIMIT;
   if (need_nodes <= pool->capacity) return SVOSLAM_OK;
+  SVO_TRY(pool_sync(pool, stream));  // the copy below needs the exact size
   int64_t cap = (int64_t)pool->capacity * 2;
   if (cap < need_nodes) cap = need_nodes;
   if (cap > (int64_t)kMask + 1) cap = (int64_t)kMask + 1;
@@ -340,10 +416,11 @@ int pool_init(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream) {
   if (!pool) return SVOSLAM_ERR_INVALID_ARG;
   if (capacity_nodes < 8) capacity_nodes = 8;
   pool->d_data = nullptr; pool->size = 0; pool->capacity = 0;
+  pool->d_size = nullptr; pool->pending = 0; pool->pending_bound = 0;
   SVO_TRY(grow_pool(pool, capacity_nodes, stream));
   SVO_HIP(hipMemsetAsync(pool->d_data, 0, 64, stream));  // initOctree, svo.cu:24-31
   pool->size = 8;
-  return SVOSLAM_OK;
+  return ensure_device_size(pool, stream);
 }
 
 int pool_reserve(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream) {
@@ -367,15 +444,16 @@ static int reserve_common(svoslam_workspace *ws, int n, int depth) {
   return SVOSLAM_OK;
 }
 
-// layout of ws->small (u32 words): [0,256) totals | [256,512) bucket_base | [512..) PlanCounts | [640] any_valid
+// layout of ws->small (u32 words): [0,256) totals | [256,513) bucket_base | [520..) PlanCounts | [640] any_valid
 static inline u32 *small_totals(svoslam_workspace *ws) { return ws->small.as<u32>(); }
 static inline u32 *small_bucket_base(svoslam_workspace *ws) { return ws->small.as<u32>() + 256; }
-static inline PlanCounts *small_counts(svoslam_workspace *ws) { return reinterpret_cast<PlanCounts *>(ws->small.as<u32>() + 512); }
+static inline PlanCounts *small_counts(svoslam_workspace *ws) { return reinterpret_cast<PlanCounts *>(ws->small.as<u32>() + 520); }
 static inline int *small_any(svoslam_workspace *ws) { return reinterpret_cast<int *>(ws->small.as<u32>() + 640); }
 
 // keys of the n inputs are in ws->keys_a
 static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, const void *d_colors, bool vec4,
                       bool color_by_position, svoslam_fuse_stats *stats, hipStream_t stream) {
+  SVO_TRY(pool_sync(pool, stream));
   u64 *skey = nullptr; u32 *sidx = nullptr;
   SVO_TRY(radix_sort_pairs(ws, n, 3 * depth + 1, stream, &skey, &sidx));
   const int tiles = (int)cdiv(n, 256);
@@ -402,12 +480,13 @@ static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *poo
     SVO_TRY(ws->rec_front.reserve((size_t)total * 4));
     u64 *rec_key = ws->rec_key.as<u64>();
     u32 *rec_front = ws->rec_front.as<u32>();
-    plan_emit_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, tiles, rec_key, rec_front);
+    plan_emit_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, tiles, rec_key, rec_front, nullptr);
     for (int p = 0; p <= SVOSLAM_MAX_DEPTH; p++) {  // expandTreeAtKeys, svo.cu:278-289
       const int begin = hc.pass_start[p], end = hc.pass_start[p + 1];
       if (end > begin)
         split_pass_kernel<<<cdiv(end - begin, 256), 256, 0, stream>>>(rec_key, rec_front, begin, end, p, pool->d_data, (u32)size0);
     }
+    if (pool->d_size) pool_size_update_kernel<<<1, 64, 0, stream>>>(pool->d_size, small_counts(ws));
     SVO_LAUNCH_CHECK();
     pool->size = size0 + 8 * total;
   }
@@ -423,6 +502,73 @@ static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *poo
     mip_root_kernel<<<1, 64, 0, stream>>>(pool->d_data, small_counts(ws));
     SVO_LAUNCH_CHECK();
   }
+  return SVOSLAM_OK;
+}
+
+// worst-case number of split records of one call: at depth d at most min(8^d, n) distinct prefixes can be
+// split (d < D), plus at most n octant-7 leaves (Q4)
+static int64_t max_records(int n, int depth) {
+  int64_t r = n;
+  for (int d = 1; d < depth; d++) {
+    const int64_t cells = d >= 11 ? (int64_t)1 << 62 : (int64_t)1 << (3 * d);
+    r += cells < n ? cells : n;
+  }
+  return r;
+}
+
+// Asynchronous fusion: same kernels up to the plan, then every split in one launch (split_all_kernel), no
+// readback.  The host only knows an upper bound of the pool size; capacity is kept ahead of it.
+int svo_from_point_cloud_async(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,
+                               svoslam_pool *pool, const float center[3], float edge, hipStream_t stream) {
+  if (!ws || !pool || n < 0 || (n > 0 && (!d_points || !d_colors))) return SVOSLAM_ERR_INVALID_ARG;
+  if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
+  if (pool->size == 0) SVO_TRY(pool_init(pool, 8, stream));
+  if (n == 0) return SVOSLAM_OK;
+  SVO_TRY(ensure_device_size(pool, stream));
+  const int64_t rmax = max_records(n, depth);
+  if (rmax > 0x7FFFFFFFll / 8) return SVOSLAM_ERR_POOL_LIMIT;
+  int64_t bound = (int64_t)pool->size + pool->pending_bound + 8 * rmax;
+  if (bound > pool->capacity) {
+    SVO_TRY(pool_sync(pool, stream));  // learn the true size: the bound is very loose (surface data splits ~n, not ~6n)
+    bound = (int64_t)pool->size + 8 * rmax;
+    if (bound > pool->capacity) {
+      int64_t want = (int64_t)pool->size + 16 * 8 * rmax;  // room for ~16 worst-case calls before the next sync
+      if (want > (int64_t)kMask + 1) want = (int64_t)kMask + 1;
+      if (want < bound) return SVOSLAM_ERR_POOL_LIMIT;
+      SVO_TRY(grow_pool(pool, want, stream));
+    }
+  }
+  SVO_TRY(reserve_common(ws, n, depth));
+  SVO_TRY(ws->rec_key.reserve((size_t)rmax * 8));
+  SVO_TRY(ws->rec_front.reserve((size_t)rmax * 4));
+  SVO_TRY(ws->rec_pass.reserve((size_t)rmax));
+  compute_keys_kernel<3><<<cdiv(n, 256), 256, 0, stream>>>(d_points, n, depth, center[0], center[1], center[2], edge, ws->keys_a.as<u64>());
+  u64 *skey = nullptr; u32 *sidx = nullptr;
+  SVO_TRY(radix_sort_pairs(ws, n, 3 * depth + 1, stream, &skey, &sidx));
+  const int tiles = (int)cdiv(n, 256);
+  unsigned char *leaf_t = ws->leaf_t.as<unsigned char>();
+  u32 *leaf_f = ws->leaf_f.as<u32>();
+  u32 *tile_hist = ws->tile_hist.as<u32>();
+  SVO_HIP(hipMemsetAsync(small_any(ws), 0, 4, stream));
+  plan_count_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, tiles, small_any(ws));
+  row_scan_rows(tile_hist, tiles, small_totals(ws), stream);
+  plan_finish_kernel<<<1, 256, 0, stream>>>(small_totals(ws), small_bucket_base(ws), small_counts(ws), small_any(ws));
+  plan_emit_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, tiles,
+                                              ws->rec_key.as<u64>(), ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>());
+  int split_blocks = (int)cdiv(rmax, 256);
+  if (split_blocks > 2048) split_blocks = 2048;
+  split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
+                                                     ws->rec_pass.as<unsigned char>(), small_bucket_base(ws), small_counts(ws),
+                                                     pool->d_data, pool->d_size, depth);
+  pool_size_update_kernel<<<1, 64, 0, stream>>>(pool->d_size, small_counts(ws));
+  u32 *path_nodes = ws->path_nodes.as<u32>();
+  fill_kernel<false><<<tiles, 256, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, 0, pool->d_data, path_nodes);
+  for (int d = depth - 1; d >= 1; d--)
+    mip_level_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, d, leaf_t, path_nodes, pool->d_data);
+  mip_root_kernel<<<1, 64, 0, stream>>>(pool->d_data, small_counts(ws));
+  SVO_LAUNCH_CHECK();
+  pool->pending += 1;
+  pool->pending_bound += 8 * rmax;
   return SVOSLAM_OK;
 }
 
@@ -543,6 +689,7 @@ int extract_voxel_grid(svoslam_workspace *ws, const svoslam_pool *pool, int dept
   if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
   *d_centers = nullptr; *d_colors = nullptr; *n_out = 0;
   if (pool->size == 0) return SVOSLAM_OK;
+  if (pool->pending > 0) SVO_HIP(hipStreamSynchronize(stream));  // (size itself is not needed by the BFS)
   SVO_TRY(ws->small.reserve(4096));
   SVO_TRY(ws->bfs_a.reserve(8));
   const u64 one = 1;

@@ -41,6 +41,7 @@ struct svoslam_workspace {
   svoslam::DeviceBuffer small;                            // totals, bucket bases, counters
   svoslam::DeviceBuffer leaf_t, leaf_f;                   // per sorted key: first unsplit depth, frontier node
   svoslam::DeviceBuffer rec_key, rec_front;               // split records in reference order
+  svoslam::DeviceBuffer rec_pass;                         // async path: pass of each record
   svoslam::DeviceBuffer path_nodes;                       // [(D-1)][n] node index per owned depth (mip lists)
   svoslam::DeviceBuffer bfs_a, bfs_b, bfs_mask, bfs_ptr;  // extraction
   svoslam::DeviceBuffer misc;                             // bbox partials etc.
@@ -48,6 +49,7 @@ struct svoslam_workspace {
   void release_all() {
     keys_a.release(); keys_b.release(); vals_a.release(); vals_b.release(); tile_hist.release(); small.release();
     leaf_t.release(); leaf_f.release(); rec_key.release(); rec_front.release(); path_nodes.release();
+    rec_pass.release();
     bfs_a.release(); bfs_b.release(); bfs_mask.release(); bfs_ptr.release(); misc.release();
     if (h_counts) { (void)hipHostFree(h_counts); h_counts = nullptr; }
   }

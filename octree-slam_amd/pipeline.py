@@ -120,20 +120,20 @@ class SlamPipeline:
         return used
 
     def backproject(self, depth):
-        if not self.dist.enabled:
-            pkg.generate_vertex_map(depth, self.points, self.focal, self.focal, self.w, self.h)
-            pkg.transform_vertex_map_dmat(self.points, self.cam.fusion_transform_ptr())
-        else:
-            # this rank's row band only (absolute pixel coordinates), then all-gather the bands
-            pkg.generate_vertex_map_rows(depth, self.points, self.first, self.rows, self.focal, self.focal, self.w, self.h)
-            pkg.transform_vertex_map_dmat(self.points[self.first:self.first + self.rows], self.cam.fusion_transform_ptr())
-            self.dist.all_gather_rows(self.points, self.h)
-        pkg.point_cloud_bbox_device(self.ws, self.points, self.bbox)
+        # (multi-GPU: this rank's row band only, absolute pixel coordinates, then all-gather the bands)
+        self._backproject_with(depth, self.cam.fusion_transform_ptr())
 
-    def fuse(self, rgb):
-        self.last_stats = pkg.svo_from_point_cloud(self.ws, self.points.view(-1, 3), rgb.view(-1, 3), self.depth, self.pool,
-                                                   self.center, self.edge)
-        return self.last_stats
+    def fuse(self, rgb, blocking=False):
+        """svoFromPointCloud.  Default: the asynchronous entry point (no host round trip; pool.size is
+        fetched from the device when it is read).  blocking=True uses the reference-shaped call and
+        returns its statistics."""
+        if blocking:
+            self.last_stats = pkg.svo_from_point_cloud(self.ws, self.points.view(-1, 3), rgb.view(-1, 3), self.depth,
+                                                       self.pool, self.center, self.edge)
+            return self.last_stats
+        pkg.svo_from_point_cloud_async(self.ws, self.points.view(-1, 3), rgb.view(-1, 3), self.depth, self.pool,
+                                       self.center, self.edge)
+        return None
 
     def render(self, view):
         if not self.dist.enabled:
@@ -148,6 +148,58 @@ class SlamPipeline:
         self.backproject(depth)
         self.fuse(rgb)
         return self.render(view)
+
+    # -- software-pipelined stream of frames ------------------------------------------------
+    def run_stream(self, depths, rgbs, timestamps, views, on_render=None):
+        """Processes the frames in order with the tracker of frame k+1 overlapped with the mapping of
+        frame k: tracking (bilateral, pyramids, 19 ICP iterations) runs on one HIP stream; back-projection,
+        fusion and the raycast run on a second one and wait, per frame, for that frame's pose (an event).
+        The tracker state is only touched by the first stream and the node pool only by the second; the pose
+        crosses over through a 4-slot ring in the camera state.  Results are identical to frame(); only the
+        two latency-bound kernel chains overlap.  on_render(i, image) is called (stream-ordered on the
+        mapping stream, image valid until the next frame) after each frame's raycast has been enqueued."""
+        n = len(timestamps)
+        if n == 0:
+            return
+        if not hasattr(self, "_s_track"):
+            self._s_track, self._s_map = torch.cuda.Stream(), torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        self._s_track.wait_stream(cur)
+        self._s_map.wait_stream(cur)
+        ev = [torch.cuda.Event() for _ in range(n)]
+        fusion_ptr = [0] * n
+
+        def enqueue_track(i):
+            with torch.cuda.stream(self._s_track):
+                self.track(depths[i], rgbs[i], timestamps[i])
+                fusion_ptr[i] = self.cam.fusion_transform_ptr()   # ring slot of frame i
+                ev[i].record()
+
+        enqueue_track(0)
+        for i in range(n):
+            if i + 1 < n:
+                enqueue_track(i + 1)          # queued before this frame's mapping blocks the host
+            with torch.cuda.stream(self._s_map):
+                self._s_map.wait_event(ev[i])
+                self._backproject_with(depths[i], fusion_ptr[i])
+                self.fuse(rgbs[i])
+                if on_render is not None:
+                    on_render(i, None)        # "before render" hook (event timing)
+                self.render(views[i])
+                if on_render is not None:
+                    on_render(i, self.image)
+        cur.wait_stream(self._s_track)
+        cur.wait_stream(self._s_map)
+
+    def _backproject_with(self, depth, fusion_ptr):
+        if not self.dist.enabled:
+            pkg.generate_vertex_map(depth, self.points, self.focal, self.focal, self.w, self.h)
+            pkg.transform_vertex_map_dmat(self.points, fusion_ptr)
+        else:
+            pkg.generate_vertex_map_rows(depth, self.points, self.first, self.rows, self.focal, self.focal, self.w, self.h)
+            pkg.transform_vertex_map_dmat(self.points[self.first:self.first + self.rows], fusion_ptr)
+            self.dist.all_gather_rows(self.points, self.h)
+        pkg.point_cloud_bbox_device(self.ws, self.points, self.bbox)
 
 
 def ground_truth_view(frame, synth):

@@ -197,3 +197,38 @@ def test_large_cloud_invariants(env):
     assert (w2[0:2 * size1:2] & 0x3FFFFFFF == w[0::2] & 0x3FFFFFFF)[flagged].all()  # old pointers untouched
     st3 = gpu_insert(pkg, torch, ws, pool, pts, col, depth, (0, 0, 0), 1.024)
     assert st3.num_split == 0 and st2.num_split < st1.num_split  # only the one-off Q4 splits in pass 2
+
+
+@pytest.mark.parametrize("depth,n,frames", [(2, 500, 3), (6, 20000, 4), (10, 40000, 4), (12, 60000, 3), (16, 20000, 2)])
+def test_async_fusion_matches_oracle(env, oracle, depth, n, frames):
+    """the asynchronous entry point (no readback, all splits in one launch) builds the same pool"""
+    pkg, torch = env
+    rng = np.random.default_rng(700 + depth)
+    ws, pool = pkg.Workspace(), pkg.Pool()
+    opool = oracle.Pool()
+    center, edge = (0.05, -0.02, 0.01), 1.0
+    for f in range(frames):
+        pts, col = (surface_cloud(rng, n) if f % 2 == 0 else random_cloud(rng, n, nan_every=53, dup_frac=0.1))
+        pts = pts + np.float32(0.003 * f)
+        tp, tc = torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda()
+        pkg.svo_from_point_cloud_async(ws, tp, tc, depth, pool, center, edge)
+        opool.insert_cloud(pts, col, depth, center, edge)
+        if f % 2 == 1 or f == frames - 1:      # leave some calls un-synchronised in between
+            assert_pools_equal(pool, opool)
+    # mixing with the blocking entry point keeps working
+    pts, col = surface_cloud(rng, n)
+    st = gpu_insert(pkg, torch, ws, pool, pts, col, depth, center, edge)
+    opool.insert_cloud(pts, col, depth, center, edge)
+    assert st.pool_size_after == opool.size
+    assert_pools_equal(pool, opool)
+
+
+def test_async_fusion_many_frames_without_sync(env, oracle):
+    pkg, torch = env
+    rng = np.random.default_rng(808)
+    ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
+    for f in range(25):
+        pts, col = surface_cloud(rng, 15000, jitter=0.004)
+        pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), 9, pool, (0, 0, 0), 1.0)
+        opool.insert_cloud(pts, col, 9, (0, 0, 0), 1.0)
+    assert_pools_equal(pool, opool)
