@@ -125,7 +125,7 @@ def main():
     views = [pl.ground_truth_view(k, synth) for k in range(total)]
     mode = pkg.RENDER_REFERENCE if args.render_mode == "reference" else pkg.RENDER_CARRY
     P = pl.SlamPipeline(width, height, max_depth, center, edge, render_mode=mode, dist=dist, count_steps=True,
-                        pool_capacity_nodes=1 << 24)
+                        pool_capacity_nodes=1 << 28)
 
     def barrier():
         if world > 1 or force_dist:

@@ -68,6 +68,7 @@ typedef struct {
   int32_t *d_size;     /* device-resident copy of the size (kept by the library; NULL for foreign pools) */
   int32_t pending;     /* asynchronous fusion calls enqueued since `size` was last exact */
   int64_t pending_bound; /* upper bound on the nodes those calls can add */
+  void *tracker;       /* library-internal: non-blocking size readbacks of the asynchronous calls (NULL until first use) */
 } svoslam_pool;
 
 /* replaces svo::initOctree (svo.cu:24-31): 8 zeroed root children */
@@ -108,6 +109,19 @@ int svoslam_svo_from_point_cloud(svoslam_workspace *ws, const float *d_points, c
 int svoslam_svo_from_point_cloud_async(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors,
                                        int32_t n, int32_t max_depth, svoslam_pool *pool, const float center[3],
                                        float edge_length, void *stream);
+
+/* The asynchronous fusion in its three phases, for callers that overlap it with a render of the
+ * previous state (svoFromPointCloud then coneTraceSVO per frame, src/main.cpp:44,56):
+ *   sort   keys + sort of the points; touches only the workspace
+ *   plan   reads the pool's tree (must follow the previous commit; may run while the pool is ray-marched)
+ *   commit writes the pool (splits, leaf blend, mip levels)
+ * sort -> plan -> commit on one workspace == svoslam_svo_from_point_cloud_async.  Fusions in flight at
+ * the same time need a workspace each.  If plan has to grow the pool it first waits for the whole device. */
+int svoslam_svo_fuse_sort(svoslam_workspace *ws, const float *d_points, int32_t n, int32_t max_depth,
+                          const float center[3], float edge_length, void *stream);
+int svoslam_svo_fuse_plan(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream);
+int svoslam_svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int32_t n, int32_t max_depth,
+                            svoslam_pool *pool, void *stream);
 
 /* replaces svo::svoFromVoxelGrid (svo.h:14, svo.cu:584-640).  d_centers,
  * d_colors: n x vec4 (VoxelGrid, common_types.h:55-63). */

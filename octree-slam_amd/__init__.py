@@ -42,7 +42,7 @@ def build(verbose=False, force=False):
 
 class _PoolStruct(C.Structure):
     _fields_ = [("d_data", C.c_void_p), ("size", C.c_int32), ("capacity", C.c_int32), ("d_size", C.c_void_p),
-                ("pending", C.c_int32), ("pending_bound", C.c_int64)]
+                ("pending", C.c_int32), ("pending_bound", C.c_int64), ("tracker", C.c_void_p)]
 
 
 class MeshStruct(C.Structure):
@@ -75,6 +75,9 @@ SIGNATURES = {
     "svoslam_pool_free": (C.c_int, [C.POINTER(_PoolStruct)]),
     "svoslam_pool_sync": (C.c_int, [C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_from_point_cloud_async": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _fp, _f32, _vp]),
+    "svoslam_svo_fuse_sort": (C.c_int, [_vp, _vp, _i32, _i32, _fp, _f32, _vp]),
+    "svoslam_svo_fuse_plan": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
+    "svoslam_svo_fuse_commit": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_workspace_create": (C.c_int, [C.POINTER(_vp)]),
     "svoslam_workspace_destroy": (C.c_int, [_vp]),
     "svoslam_svo_from_point_cloud": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _fp, _f32,
@@ -285,6 +288,23 @@ def svo_from_point_cloud_async(ws, points, colors, max_depth, pool, center, edge
     n = int(points.shape[0]) if points is not None else 0
     check(lib().svoslam_svo_from_point_cloud_async(ws._h, _ptr(points), _ptr(colors), n, max_depth, C.byref(pool._p),
                                                    _fa(center, 3), float(edge_length), _stream()))
+
+
+def svo_fuse_sort(ws, points, max_depth, center, edge_length):
+    """phase 1 of the asynchronous fusion: keys + sort (workspace only)."""
+    n = int(points.shape[0]) if points is not None else 0
+    check(lib().svoslam_svo_fuse_sort(ws._h, _ptr(points), n, max_depth, _fa(center, 3), float(edge_length), _stream()))
+
+
+def svo_fuse_plan(ws, n, max_depth, pool):
+    """phase 2: split planning against the pool's current tree (reads the pool)."""
+    check(lib().svoslam_svo_fuse_plan(ws._h, int(n), max_depth, C.byref(pool._p), _stream()))
+
+
+def svo_fuse_commit(ws, colors, max_depth, pool):
+    """phase 3: splits, leaf blend, mip levels (writes the pool)."""
+    n = int(colors.shape[0]) if colors is not None else 0
+    check(lib().svoslam_svo_fuse_commit(ws._h, _ptr(colors), n, max_depth, C.byref(pool._p), _stream()))
 
 
 def svo_from_voxel_grid(ws, centers, colors, max_depth, pool, center, edge_length):

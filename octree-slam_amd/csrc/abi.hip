@@ -90,6 +90,7 @@ int svoslam_pool_free(svoslam_pool *pool) {
   if (!pool) return SVOSLAM_ERR_INVALID_ARG;
   if (pool->d_data) SVO_HIP(hipFree(pool->d_data));
   if (pool->d_size) SVO_HIP(hipFree(pool->d_size));
+  pool_tracker_destroy(pool);
   pool->d_data = nullptr; pool->size = 0; pool->capacity = 0;
   pool->d_size = nullptr; pool->pending = 0; pool->pending_bound = 0;
   return SVOSLAM_OK;
@@ -104,6 +105,22 @@ int svoslam_svo_from_point_cloud_async(svoslam_workspace *ws, const float *d_poi
   NEED_DEVICE();
   if (!center) return SVOSLAM_ERR_INVALID_ARG;
   return svo_from_point_cloud_async(ws, d_points, d_colors, n, max_depth, pool, center, edge_length, S(stream));
+}
+
+int svoslam_svo_fuse_sort(svoslam_workspace *ws, const float *d_points, int32_t n, int32_t max_depth, const float center[3],
+                          float edge_length, void *stream) {
+  NEED_DEVICE();
+  if (!center) return SVOSLAM_ERR_INVALID_ARG;
+  return svo_fuse_sort(ws, d_points, n, max_depth, center, edge_length, S(stream));
+}
+int svoslam_svo_fuse_plan(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream) {
+  NEED_DEVICE();
+  return svo_fuse_plan(ws, n, max_depth, pool, S(stream));
+}
+int svoslam_svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int32_t n, int32_t max_depth, svoslam_pool *pool,
+                            void *stream) {
+  NEED_DEVICE();
+  return svo_fuse_commit(ws, d_colors, n, max_depth, pool, S(stream));
 }
 
 int svoslam_workspace_create(svoslam_workspace **ws) {

@@ -9,13 +9,18 @@
 // (rays[], ind[], pos[]).  Here one launch marches every ray to retirement with
 // its state in registers; a wavefront is an 8x8 pixel tile.
 //
-// What bounds this kernel (measured, scratch/ray_steps.py): its run time equals the
-// critical path of its SLOWEST ray -- time tracks max(steps per ray), not the ray
-// count (half the rows: same time) -- i.e. steps x (dependent loads + dependent ALU)
-// per step.  Hence (1) the first kTop levels of every walk come from a dense "top
-// tree" whose addresses need no loads (one latency instead of kTop), (2) the
-// per-step arithmetic is reduced to one division and one square root without
-// changing a single result bit (see step_lod / the notes in the loop).
+// What bounds this kernel (measured, scratch/ray_steps.py + ISA): instruction issue while
+// the chip is full and, in the tail, the critical path of the SLOWEST ray (steps x
+// dependent latency per step); HBM traffic is ~4 % of the algorithmic bytes (the walk
+// hits in L2).  So each step is made short, without changing a result bit:
+//  (1) the octant decisions of ALL levels of a sample come from one lookup per axis into
+//      a sorted table of the reference's own split planes (see "split-plane table") instead
+//      of a 3-op-per-axis-per-level dependent chain;
+//  (2) levels 1..6 of the walk are ONE load from a dense 64^3 grid that stores, per cell,
+//      where the reference's walk stops and the colour word it ends on ("level-6 grid");
+//  (3) the per-step arithmetic is one division and one square root (see step_lod / loop notes).
+#include <cstring>
+
 #include "cone_trace.hpp"
 #include "workspace.hpp"
 
@@ -56,39 +61,39 @@ __device__ inline uint32_t f2u8(float f) { return __float2uint_rz(f) & 0xFFu; }
 
 __device__ inline float length3(float x, float y, float z) { return sqrtf(dot3(x, y, z, x, y, z)); }
 
-// ---- top tree --------------------------------------------------------------
-// Levels 1..kTop of the pool mirrored as a dense, heap-ordered array: entry
-// (d, path) = both words of the node reached by the octant path `path` of length d
-// (zeros if that node does not exist).  The octant bits of a sample depend only on
-// float comparisons against centres recomputed in registers, so the addresses of
-// its first kTop nodes are known WITHOUT loading anything: the kTop loads are
-// issued together (one memory latency) instead of kTop dependent round trips.
-// Rebuilt from the pool at the start of every render (the pool is const during it).
-constexpr int kTop = 6;
-__host__ __device__ constexpr int top_offset(int d) { return d <= 1 ? 0 : 8 * ((1 << (3 * (d - 1))) - 1) / 7; }  // entries before level d
-constexpr int kTopEntries = top_offset(kTop + 1);  // 8 + 64 + ... + 8^kTop = 299592
+// ---- split-plane table ----------------------------------------------------
+// The reference decides the octant at every level by comparing the sample with a centre
+// it builds on the way down: c_0 = centre, c_l = fl(c_{l-1} +/- size/2^l)
+// (cone_tracing_kernels.cu:84-100).  Per axis this is a binary search tree of float
+// thresholds: the node reached by the bit prefix b_1..b_{l-1} holds the plane tested at
+// level l.  Its in-order sequence S[0..2^T-2] is sorted (rounding errors are far below the
+// spacing; verified per lookup), so the T octant bits of a coordinate t are simply
+//     bits(t) = #{ j : S[j] < t }                         ("t > c" goes to the high side)
+// -- a position in a sorted array.  A float multiply guesses the cell g, the four
+// thresholds S[g-2..g+1] around it are loaded in one 16-byte access, counted, and the
+// bracket S[bits-1] < t <= S[bits] is CHECKED; a lane whose bracket is not confirmed
+// (extreme centre/size ratios, NaN) falls back to the reference's own chain.  The table
+// holds exactly the floats the chain produces, so the bits are the reference's bits.
+// Two tables: the first kLdsDepth levels live in LDS (48 KB per workgroup, copied at kernel start) and are
+// consulted every step; levels kLdsDepth+1..kTabDepth come from a global (L2-resident) table only
+// when a walk actually goes that deep.
+constexpr int kTabDepth = 16;                   // == SVOSLAM_MAX_DEPTH: every level a pool of this library can have
+constexpr int kTabCells = 1 << kTabDepth;
+constexpr int kTabStride = kTabCells + 3;       // [-inf, -inf, S[0..2^T-2], +inf, +inf]
+constexpr int kLdsDepth = 12;
+constexpr int kLdsCells = 1 << kLdsDepth;
+constexpr int kLdsStride = kLdsCells + 3;
+constexpr int kTraceThreads = 512;              // 3 workgroups x 8 waves per CU next to 3 x 49 KB of LDS
 
-__global__ __launch_bounds__(256) void build_top_tree_kernel(const uint32_t *__restrict__ octree, uint2 *__restrict__ top,
-                                                            float *__restrict__ alpha_lut) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  // (float)alpha / 127.0f of :110-112 for alpha = A - 127 in [-127, 128]: 256 IEEE quotients, computed once
-  if (e < 256) alpha_lut[e] = (float)(e - 127) / 127.0f;
-  if (e >= kTopEntries) return;
-  int d = 1;
-  while (d < kTop && e >= top_offset(d + 1)) d++;
-  const uint32_t path = (uint32_t)(e - top_offset(d));
-  const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
-  uint32_t base = 0;
-  uint2 nd = make_uint2(0u, 0u);
-  for (int l = 1; l <= d; l++) {
-    nd = nodes[base + ((path >> (3 * (d - l))) & 7u)];
-    if (l < d) {
-      if (!(nd.x & kFlag)) { nd = make_uint2(0u, 0u); break; }  // path does not exist below an unsplit node
-      base = nd.x & kMask;
-    }
-  }
-  top[e] = nd;
-}
+// ---- level-6 grid ----------------------------------------------------------
+// Dense 64^3 array indexed by the first six octant bits of each axis (z, y, x).  Entry =
+// outcome of the reference's walk over levels 1..6 on that path:
+//   all six nodes have children:  x = flag | tile index of the level-6 node's children, y = its colour word
+//   first childless node at level st (1..6): x = st, y = that node's colour word
+// so the six dependent loads of the reference become one.  Rebuilt from the pool at the
+// start of every render (the pool is const during it), 2 MB.
+constexpr int kGridLevel = 6;
+constexpr int kGridEntries = 1 << (3 * kGridLevel);
 
 struct TraceParams {
   float origin[3], x_dir[3], y_dir[3];
@@ -96,23 +101,160 @@ struct TraceParams {
   float size, pix_scale;
   int width, height, mode;
   int row_first, row_end;  // rows [row_first, row_end) are traced (row band of a multi-GPU tile split)
+  // lookup helpers (host-computed)
+  float lo[3], inv_cell, inv_cell_lds;   // guess of the table cell: (t - lo) * inv_cell
+  uint32_t lod_first, lod_span, size_man;  // fast LOD: valid when bits(pix_size) - lod_first <= lod_span
+  int size_exp;
 };
+
+__global__ __launch_bounds__(256) void build_accel_kernel(const uint32_t *__restrict__ octree, uint2 *__restrict__ grid,
+                                                         float *__restrict__ table, float *__restrict__ alpha_lut,
+                                                         TraceParams P) {
+  int e = blockIdx.x * 256 + threadIdx.x;
+  const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
+  if (e < kGridEntries) {
+    const uint32_t xi = (uint32_t)e & 63u, yi = ((uint32_t)e >> 6) & 63u, zi = (uint32_t)e >> 12;
+    uint32_t base = 0;
+    uint2 out = make_uint2(0u, 0u);
+    for (int l = 1; l <= kGridLevel; l++) {
+      const int sh = kGridLevel - l;
+      const uint32_t oct = ((xi >> sh) & 1u) | (((yi >> sh) & 1u) << 1) | (((zi >> sh) & 1u) << 2);
+      const uint2 nd = nodes[base + oct];
+      if (!(nd.x & kFlag)) { out = make_uint2((uint32_t)l, nd.y); break; }
+      base = nd.x & kMask;
+      out = make_uint2(kFlag | base, nd.y);
+    }
+    grid[e] = out;
+    return;
+  }
+  e -= kGridEntries;
+  if (e < 3 * (kTabStride + kLdsStride)) {
+    // fine table (kTabDepth levels) followed by the LDS image (kLdsDepth levels)
+    const bool fine = e < 3 * kTabStride;
+    const int T = fine ? kTabDepth : kLdsDepth, stride = fine ? kTabStride : kLdsStride;
+    const int r = fine ? e : e - 3 * kTabStride;
+    const int axis = r / stride, i = r - axis * stride;
+    float v;
+    if (i < 2) v = -__builtin_inff();
+    else if (i >= (1 << T) + 1) v = __builtin_inff();
+    else {
+      // in-order index j = i - 2 of the tree node at level l with bit prefix p: j + 1 = (2p + 1) * 2^(T - l)
+      const uint32_t q = (uint32_t)(i - 1);
+      const int tz = __ffs((int)q) - 1;
+      const int l = T - tz;
+      const uint32_t p = q >> (tz + 1);  // l - 1 bits, first decision in the top bit
+      float c = P.center[axis], ts = P.size;
+      for (int m = 1; m < l; m++) {
+        ts *= 0.5f;  // "/= 2.0f" (:97)
+        c += ts * (((p >> (l - 1 - m)) & 1u) ? 1.0f : -1.0f);
+      }
+      v = c;
+    }
+    table[e] = v;
+    return;
+  }
+  e -= 3 * (kTabStride + kLdsStride);
+  // (float)alpha / 127.0f of :110-112 for alpha = A - 127 in [-127, 128]: 256 IEEE quotients, computed once
+  if (e < 256) alpha_lut[e] = (float)(e - 127) / 127.0f;
+}
+
+struct __attribute__((packed, aligned(4))) Float4U { float a, b, c, d; };
+
+// kLdsDepth octant bits of one coordinate from the LDS table
+__device__ inline uint32_t axis_bits_lds(float t, float lo, float inv_cell, const float *tab, bool &ok) {
+  int g = (int)((t - lo) * inv_cell);
+  g = g < 0 ? 0 : (g > kLdsCells - 1 ? kLdsCells - 1 : g);
+  const float a = tab[g], b = tab[g + 1], c = tab[g + 2], d = tab[g + 3];  // S[g-2..g+1]
+  const bool c0 = a < t, c1 = b < t, c2 = c < t, c3 = d < t;
+  ok = ok && c0 && !c3;
+  return (uint32_t)(g - 2) + (uint32_t)c0 + (uint32_t)c1 + (uint32_t)c2 + (uint32_t)c3;
+}
+
+// kTabDepth octant bits of one coordinate (first level in the top bit); ok = bracket confirmed
+__device__ inline uint32_t axis_bits(float t, float lo, float inv_cell, const float *__restrict__ tab, bool &ok) {
+  int g = (int)((t - lo) * inv_cell);  // v_cvt_i32_f32: truncating, saturating, NaN -> 0
+  g = g < 0 ? 0 : (g > kTabCells - 1 ? kTabCells - 1 : g);
+  const Float4U th = *reinterpret_cast<const Float4U *>(reinterpret_cast<const char *>(tab) + ((uint32_t)g << 2));  // S[g-2..g+1]
+  const bool c0 = th.a < t, c1 = th.b < t, c2 = th.c < t, c3 = th.d < t;
+  ok = ok && c0 && !c3;
+  return (uint32_t)(g - 2) + (uint32_t)c0 + (uint32_t)c1 + (uint32_t)c2 + (uint32_t)c3;
+}
+
+// the reference's chain for `levels` levels (fallback of axis_bits and levels beyond the table)
+__device__ __forceinline__ uint32_t axis_bits_chain(float t, float center, float size, int levels) {
+  uint32_t bits = 0;
+  float c = center, ts = size;
+  for (int l = 0; l < levels; l++) {
+    const bool hi = t > c;
+    bits = (bits << 1) | (uint32_t)hi;
+    ts *= 0.5f;
+    c += ts * (hi ? 1.0f : -1.0f);
+  }
+  return bits;
+}
+
+// walk below the LDS table's levels: octant bits from the fine (global) table, one lookup per step
+__device__ __forceinline__ void walk_deep(const uint2 *__restrict__ nodes, const float *__restrict__ table, const TraceParams &P,
+                                       float tx, float ty, float tz, int level, uint32_t child_idx, int &depth, uint32_t &w1) {
+  bool fok = true;
+  uint32_t fxb = axis_bits(tx, P.lo[0], P.inv_cell, table, fok);
+  uint32_t fyb = axis_bits(ty, P.lo[1], P.inv_cell, table + kTabStride, fok);
+  uint32_t fzb = axis_bits(tz, P.lo[2], P.inv_cell, table + 2 * kTabStride, fok);
+  if (!fok) {
+    fxb = axis_bits_chain(tx, P.center[0], P.size, kTabDepth);
+    fyb = axis_bits_chain(ty, P.center[1], P.size, kTabDepth);
+    fzb = axis_bits_chain(tz, P.center[2], P.size, kTabDepth);
+  }
+  for (int i = level; i <= depth; i++) {
+    uint32_t oct;
+    if (i <= kTabDepth) {
+      const int sh = kTabDepth - i;
+      oct = ((fxb >> sh) & 1u) | (((fyb >> sh) & 1u) << 1) | (((fzb >> sh) & 1u) << 2);
+    } else {  // deeper than any pool this library builds
+      oct = (axis_bits_chain(tx, P.center[0], P.size, i) & 1u) | ((axis_bits_chain(ty, P.center[1], P.size, i) & 1u) << 1) |
+            ((axis_bits_chain(tz, P.center[2], P.size, i) & 1u) << 2);
+    }
+    const uint2 nd = nodes[child_idx + oct];
+    w1 = nd.y;
+    if (!(nd.x & kFlag)) { depth = i; break; }
+    child_idx = nd.x & kMask;
+  }
+}
+
+// walk from the root for an LOD depth above the grid level (1 <= depth < kGridLevel)
+__device__ __forceinline__ void walk_shallow(const uint2 *__restrict__ nodes, uint32_t xb, uint32_t yb, uint32_t zb, int &depth, uint32_t &w1) {
+  uint32_t child_idx = 0;
+  for (int i = 1; i <= depth; i++) {
+    const int sh = kLdsDepth - i;
+    const uint32_t oct = ((xb >> sh) & 1u) | (((yb >> sh) & 1u) << 1) | (((zb >> sh) & 1u) << 2);
+    const uint2 nd = nodes[child_idx + oct];
+    w1 = nd.y;
+    if (!(nd.x & kFlag)) { depth = i; break; }
+    child_idx = nd.x & kMask;
+  }
+}
 
 // CARRY = false: SVOSLAM_RENDER_REFERENCE.  The reference re-reads pos[index] every step and that
 // pixel stays 0 until the ray retires (Q9), so a sample's colour matters only on the step that
 // retires the ray: the march needs alpha alone and the colour is formed once, after the loop.
 // CARRY = true: the local pixel is carried across steps.
 template <bool CARRY>
-__global__ __launch_bounds__(256) void cone_trace_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
-                                                         const uint2 *__restrict__ top, const float *__restrict__ alpha_lut_g,
-                                                         TraceParams P, unsigned long long *__restrict__ counters) {
+__global__ __launch_bounds__(kTraceThreads) void cone_trace_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
+                                                         const uint2 *__restrict__ grid, const float *__restrict__ table,
+                                                         const float *__restrict__ alpha_lut_g, TraceParams P,
+                                                         unsigned long long *__restrict__ counters) {
   __shared__ float alpha_lut[256];
-  alpha_lut[threadIdx.x] = alpha_lut_g[threadIdx.x];
+  __shared__ float lds_tab[3 * kLdsStride];
+  if (threadIdx.x < 256) alpha_lut[threadIdx.x] = alpha_lut_g[threadIdx.x];
+  {
+    const float *src = table + 3 * kTabStride;  // LDS image follows the fine table
+    for (int i = threadIdx.x; i < 3 * kLdsStride; i += kTraceThreads) lds_tab[i] = src[i];
+  }
   __syncthreads();
-  // 16x16 pixel workgroup, one 8x8 tile per wavefront
+  // 32x16 pixel workgroup, one 8x8 tile per wavefront
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  const int px = blockIdx.x * 16 + (int)(wave & 1u) * 8 + (int)(lane & 7u);
-  const int py = P.row_first + blockIdx.y * 16 + (int)(wave >> 1) * 8 + (int)(lane >> 3);
+  const int px = blockIdx.x * 32 + (int)(wave & 3u) * 8 + (int)(lane & 7u);
+  const int py = P.row_first + blockIdx.y * 16 + (int)(wave >> 2) * 8 + (int)(lane >> 3);
   uint32_t my_steps = 0, my_levels = 0;
   if (px < P.width && py < P.row_end) {
     const int idx = py * P.width + px;
@@ -138,61 +280,115 @@ __global__ __launch_bounds__(256) void cone_trace_kernel(uchar4 *__restrict__ po
     uint32_t oct_val = 0;
     int alpha = 0;
     bool range_exit = false;
+    // path cache (see the walk)
+    uint32_t pxb = 0xFFFFFFFFu, pyb = 0xFFFFFFFFu, pzb = 0xFFFFFFFFu;
+    uint32_t ctile[kLdsDepth - kGridLevel + 1];  // ctile[k]: tile holding the level (kGridLevel + 1 + k) nodes of the cached path
+#pragma unroll
+    for (int k = 0; k <= kLdsDepth - kGridLevel; k++) ctile[k] = 0;
+    int cvalid = 0;        // deepest level whose tile is cached (0: none)
+    uint2 gprev = make_uint2(0u, 0u);
+    bool gvalid = false;
+#ifdef SVO_PROF
+    long long pc[5] = {0, 0, 0, 0, 0};
+#define PROF_T(k) { const long long now_ = clock64(); pc[k] += now_ - t_prev; t_prev = now_; }
+#else
+#define PROF_T(k)
+#endif
     for (int step = 0; step < kMaxSteps; step++) {
+#ifdef SVO_PROF
+      long long t_prev = clock64();
+#endif
       my_steps++;
       const float tx = P.origin[0] + rx, ty = P.origin[1] + ry, tz = P.origin[2] + rz;
       const float pix_size = ray_len * P.pix_scale;
-      int depth = step_lod(P.size, pix_size);
-      float temp_size = P.size, cx = P.center[0], cy = P.center[1], cz = P.center[2];
-      // levels 1..kTop: octant bits by comparisons only (no loads), then kTop independent loads from the
-      // top tree, all issued unconditionally (levels beyond the LOD depth read valid, unused entries)
-      uint2 e[kTop];
+      // LOD depth (:69); fast form of step_lod when both operands are ordinary positive floats
+      int depth;
       {
-        uint32_t path = 0;
-#pragma unroll
-        for (int i = 0; i < kTop; i++) {
-          const bool x = tx > cx, y = ty > cy, z = tz > cz;
-          path = path * 8u + (uint32_t)(x + 2 * y + 4 * z);
-          e[i] = top[top_offset(i + 1) + path];
-          temp_size *= 0.5f;  // "/= 2.0f" (:97): exact either way
-          cx += temp_size * (x ? 1 : -1);
-          cy += temp_size * (y ? 1 : -1);
-          cz += temp_size * (z ? 1 : -1);
-        }
+        const uint32_t ub = f2bits(pix_size);
+        if (ub - P.lod_first <= P.lod_span) depth = (P.size_exp - (int)(ub >> 23)) + ((ub & 0x7FFFFFu) < P.size_man ? 1 : 0);
+        else depth = step_lod(P.size, pix_size);
       }
-      // first level (in walk order) whose node has no children, among the nb = min(depth, kTop) levels
-      // the reference would visit; branch-free select chain
-      const int nb = depth < kTop ? depth : kTop;
-      int stop = kTop;
-#pragma unroll
-      for (int i = kTop - 1; i >= 0; i--) stop = (!(e[i].x & kFlag)) ? i : stop;
-      const bool stopped = stop < nb;
-      const int last = stopped ? stop : nb - 1;  // index of the last visited level (-1 if nb <= 0)
-      my_levels += (uint32_t)(last + 1 > 0 ? last + 1 : 0);
+      // octant bits of every level, per axis
+      bool ok = true;
+      uint32_t xb = axis_bits_lds(tx, P.lo[0], P.inv_cell_lds, lds_tab, ok);
+      uint32_t yb = axis_bits_lds(ty, P.lo[1], P.inv_cell_lds, lds_tab + kLdsStride, ok);
+      uint32_t zb = axis_bits_lds(tz, P.lo[2], P.inv_cell_lds, lds_tab + 2 * kLdsStride, ok);
+      if (!ok) {
+        xb = axis_bits_chain(tx, P.center[0], P.size, kLdsDepth);
+        yb = axis_bits_chain(ty, P.center[1], P.size, kLdsDepth);
+        zb = axis_bits_chain(tz, P.center[2], P.size, kLdsDepth);
+      }
+      asm volatile("" :: "v"(xb), "v"(yb), "v"(zb));
+      PROF_T(0)
+      // ---- the walk (:76-105), shortened by what this lane already knows ----
+      // Path cache: consecutive samples of a ray near a surface are a few millimetres apart and share
+      // most of their ancestors.  The lane keeps the octant bits of its previous sample, the level-6
+      // grid entry and the child-tile indices of levels 7..13 it walked through; a new sample whose first
+      // L levels coincide with the previous one resumes at level min(L + 1, deepest cached level, depth)
+      // instead of level 1.  (The kernel is bound by the L1's miss throughput on these per-lane
+      // gathers, so loads not issued are what count.)  The pool is const during a render, so cached
+      // tiles are exactly what the loads would return.
+      const uint32_t diff = (xb ^ pxb) | (yb ^ pyb) | (zb ^ pzb);
+#ifdef SVO_NOCACHE
+      const int same = -1;
+#else
+      const int same = (diff == 0u ? 32 : __clz((int)diff)) - (32 - kLdsDepth);  // leading levels shared with the previous sample (< 0: none)
+#endif
+      pxb = xb; pyb = yb; pzb = zb;
+      gvalid = gvalid && same >= kGridLevel;
+      cvalid = cvalid < same + 1 ? cvalid : same + 1;
       uint32_t w1 = 0;
-#pragma unroll
-      for (int i = 0; i < kTop; i++) w1 = (i == last) ? e[i].y : w1;
-      bool have_val = last >= 0;
-      if (stopped) depth = stop + 1;
-      // deeper levels: the dependent walk of the reference, continued from level kTop; word0 and
-      // word1 of a node are fetched together so the colour needs no further dependent load
-      if (!stopped && depth > kTop) {
-        uint32_t child_idx = e[kTop - 1].x & kMask;
-        for (int i = kTop; i < depth; i++) {
-          const bool x = tx > cx, y = ty > cy, z = tz > cz;
-          my_levels++;
-          const uint2 nd = nodes[child_idx + (uint32_t)(x + 2 * y + 4 * z)];
-          w1 = nd.y;
-          if (!(nd.x & kFlag)) { depth = i + 1; break; }
-          child_idx = nd.x & kMask;
-          temp_size *= 0.5f;
-          cx += temp_size * (x ? 1 : -1);
-          cy += temp_size * (y ? 1 : -1);
-          cz += temp_size * (z ? 1 : -1);
+      bool walking = false;  // levels kGridLevel+1.. still to visit
+      int first = kGridLevel + 1;
+      if (depth > kGridLevel && cvalid > kGridLevel) {
+        walking = true;
+        first = cvalid < depth ? cvalid : depth;
+      } else if (depth >= kGridLevel) {
+        if (!gvalid) {
+          const uint32_t cell = ((zb >> (kLdsDepth - kGridLevel)) << (2 * kGridLevel)) | ((yb >> (kLdsDepth - kGridLevel)) << kGridLevel) |
+                                (xb >> (kLdsDepth - kGridLevel));
+          gprev = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(grid) + (cell << 3));
+          gvalid = true;
+        }
+        w1 = gprev.y;
+        if (gprev.x & kFlag) {
+          ctile[0] = gprev.x & kMask;
+          cvalid = cvalid > kGridLevel + 1 ? cvalid : kGridLevel + 1;
+          walking = depth > kGridLevel;
+        } else {
+          depth = (int)gprev.x;  // stopped at the first childless node
+          cvalid = 0;
         }
       }
-      if (!have_val) w1 = octree[1];  // depth <= 0: the reference reads node 0 (:107 with node_idx = 0)
+      asm volatile("" :: "v"(w1));
+      PROF_T(1)
+      if (walking) {
+        // levels 7..kLdsDepth: both words of a node are fetched together; tiles go to the path cache
+#pragma unroll
+        for (int l = kGridLevel + 1; l <= kLdsDepth; l++) {
+          if (walking && l >= first && l <= depth) {
+            const int sh = kLdsDepth - l;
+            const uint32_t oct = ((xb >> sh) & 1u) | (((yb >> sh) & 1u) << 1) | (((zb >> sh) & 1u) << 2);
+            uint2 nd = nodes[ctile[l - kGridLevel - 1] + oct];
+            asm volatile("" : "+v"(nd.y));  // keep the colour word in the same 8-byte load (not a second, dependent one)
+            w1 = nd.y;
+            if (!(nd.x & kFlag)) { depth = l; walking = false; cvalid = l; }
+            else { ctile[l - kGridLevel] = nd.x & kMask; cvalid = cvalid > l + 1 ? cvalid : l + 1; }
+          }
+        }
+        if (walking && depth > kLdsDepth)  // below the LDS table (uncached)
+          walk_deep(nodes, table, P, tx, ty, tz, kLdsDepth + 1, ctile[kLdsDepth - kGridLevel], depth, w1);
+      } else if (depth >= 1 && depth < kGridLevel) {
+        // LOD coarser than the grid (sample farther than ~size/(32 pix_scale)): the reference's walk from the root
+        walk_shallow(nodes, xb, yb, zb, depth, w1);
+      } else if (depth < 1) {
+        w1 = octree[1];  // depth <= 0: the reference reads node 0 (:107 with node_idx = 0)
+      }
+      my_levels += (uint32_t)(depth > 0 ? depth : 0);  // levels the reference visits == the depth it ends on
       oct_val = w1;
+      asm volatile("" :: "v"(w1));
+      PROF_T(2)
+
       // :108 max(0, unsigned) is the (int, unsigned) overload: no clamp, alpha = A - 127 signed
       alpha = (int)((oct_val >> 24) - 127u);
       bool retired;
@@ -212,8 +408,16 @@ __global__ __launch_bounds__(256) void cone_trace_kernel(uchar4 *__restrict__ po
       const float s = (ray_len + new_dist) / ray_len;
       rx *= s; ry *= s; rz *= s;
       ray_len = length3(rx, ry, rz);
+      asm volatile("" :: "v"(ray_len));
+      PROF_T(3)
       if (ray_len > kMaxRange) { range_exit = true; break; }
     }
+#ifdef SVO_PROF
+    if (counters && lane == 0) {
+      for (int k = 0; k < 4; k++) atomicAdd(&counters[2 + k], (unsigned long long)pc[k]);
+      atomicAdd(&counters[6], (unsigned long long)my_steps);
+    }
+#endif
     if (!CARRY) {  // the pixel of the retiring step, formed from an all-zero pos[index]
       const float af = alpha_lut[alpha + 127];
       vx = f2u8(af * (float)(oct_val & 0xFF));
@@ -273,15 +477,37 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   P.pix_scale = tanf(fov * 3.14159f / 180.0f) / (float)height;
   P.width = width; P.height = height; P.mode = mode;
   P.row_first = row_first; P.row_end = row_first + rows;
-  dim3 grid(cdiv(width, 16), cdiv(rows, 16));
-  static DeviceBuffer top_tree;  // 2.4 MB, library-owned (calls from several host threads must be serialised)
-  SVO_TRY(top_tree.reserve((size_t)kTopEntries * sizeof(uint2) + 256 * sizeof(float)));
-  float *alpha_lut = reinterpret_cast<float *>(top_tree.as<uint2>() + kTopEntries);
-  build_top_tree_kernel<<<cdiv(kTopEntries, 256), 256, 0, stream>>>(d_octree, top_tree.as<uint2>(), alpha_lut);
+  // lookup helpers: the table-cell guess and the operand range of the fast LOD form
+  for (int k = 0; k < 3; k++) P.lo[k] = center[k] - size;
+  P.inv_cell = (float)kTabCells / (2.0f * size);
+  P.inv_cell_lds = (float)kLdsCells / (2.0f * size);
+  {
+    uint32_t us;
+    memcpy(&us, &size, 4);
+    const int ea = (int)((us >> 23) & 0xFF);
+    P.size_exp = ea;
+    P.size_man = us & 0x7FFFFFu;
+    if ((int32_t)us > 0 && ea >= 1 && ea <= 254) {
+      const int eb_min = ea - 99 < 1 ? 1 : ea - 99, eb_max = ea + 99 > 254 ? 254 : ea + 99;
+      P.lod_first = (uint32_t)eb_min << 23;
+      P.lod_span = (((uint32_t)eb_max + 1u) << 23) - 1u - P.lod_first;
+    } else {  // size is not an ordinary positive float: always the general form (1 - 2 wraps; never <= 0)
+      P.lod_first = 0xFFFFFFFFu;
+      P.lod_span = 0u;
+    }
+  }
+  dim3 grid(cdiv(width, 32), cdiv(rows, 16));
+  static DeviceBuffer accel;  // grid 2 MB + tables 0.8 MB, library-owned (calls from several host threads must be serialised)
+  const size_t accel_bytes = (size_t)kGridEntries * sizeof(uint2) + (size_t)(3 * (kTabStride + kLdsStride) + 256) * sizeof(float) + 64;
+  SVO_TRY(accel.reserve(accel_bytes));
+  uint2 *d_grid = accel.as<uint2>();
+  float *d_table = reinterpret_cast<float *>(d_grid + kGridEntries);
+  float *alpha_lut = d_table + 3 * (kTabStride + kLdsStride);
+  build_accel_kernel<<<cdiv(kGridEntries + 3 * (kTabStride + kLdsStride) + 256, 256), 256, 0, stream>>>(d_octree, d_grid, d_table, alpha_lut, P);
   if ((mode & 0xFF) == SVOSLAM_RENDER_CARRY)
-    cone_trace_kernel<true><<<grid, 256, 0, stream>>>(reinterpret_cast<uchar4 *>(d_pos), d_octree, top_tree.as<uint2>(), alpha_lut, P, d_steps);
+    cone_trace_kernel<true><<<grid, kTraceThreads, 0, stream>>>(reinterpret_cast<uchar4 *>(d_pos), d_octree, d_grid, d_table, alpha_lut, P, d_steps);
   else
-    cone_trace_kernel<false><<<grid, 256, 0, stream>>>(reinterpret_cast<uchar4 *>(d_pos), d_octree, top_tree.as<uint2>(), alpha_lut, P, d_steps);
+    cone_trace_kernel<false><<<grid, kTraceThreads, 0, stream>>>(reinterpret_cast<uchar4 *>(d_pos), d_octree, d_grid, d_table, alpha_lut, P, d_steps);
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
 }

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "graph_cache.hpp"
 #include "icp.hpp"
 #include "image_kernels.hpp"
 
@@ -442,9 +443,18 @@ __global__ __launch_bounds__(kReduceThreads) void cam_reduce_solve_kernel(CamSta
 
 // multi-GPU iteration tail: acc[] holds the all-reduced sums
 __global__ void cam_solve_kernel(CamState *st, double *acc, int slot, int flags, int ring_slot) {
-  if (threadIdx.x || blockIdx.x) return;
-  double sums[27];
-  for (int i = 0; i < 27; i++) { sums[i] = acc[i]; acc[i] = 0.0; }
+  // Read-and-reset, one element per LANE.  (A single thread doing "sums[i] = acc[i]; acc[i] = 0" gets
+  // uniform-address SCALAR loads followed by vector stores of a constant: nothing orders the two memory
+  // paths, and the zero was observed to overtake the load -- six of the 27 sums read back as 0 once in a
+  // few hundred frames.  A lane's vector load and store of one address stay in order.)
+  __shared__ double sums[27];
+  if (blockIdx.x) return;
+  if (threadIdx.x < 27) {
+    sums[threadIdx.x] = acc[threadIdx.x];
+    acc[threadIdx.x] = 0.0;
+  }
+  __syncthreads();
+  if (threadIdx.x) return;
   level_begin_step(st, flags);
   if (!st->lost) solve_step(st, sums, slot);
   if (flags & kFlagLastOfFrame) frame_end_step(st, 1, ring_slot);
@@ -479,6 +489,7 @@ struct svoslam_camera {
   bool frame_has_icp = false;
   unsigned frame_seq = 0;  // processed frames so far
   int ring_slot = 0;       // fusion_ring slot of the frame being / last processed
+  svoslam::GraphCache graphs;  // recorded launch sequences of camera_update (graph_cache.hpp)
 };
 
 namespace svoslam {
@@ -531,6 +542,18 @@ int camera_destroy(svoslam_camera *c) {
   return SVOSLAM_OK;
 }
 
+// bilateral filter + the three pyramid levels of the incoming frame (rgbd_camera.cpp:62-93)
+static int enqueue_preprocess(const svoslam_camera *c, const uint16_t *d_depth, hipStream_t s) {
+  const int W = c->width, H = c->height;
+  SVO_TRY(bilateral_filter(d_depth, c->filt[0], W, H, s));  // :62-64
+  for (int i = 0; i < 3; i++) {                             // :72-93
+    const int w = W >> i, h = H >> i;
+    SVO_TRY(generate_vertex_normal_maps(c->filt[i], c->vert[c->cur][i], c->norm[c->cur][i], w, h, c->fx, c->fy, W, H, s));
+    if (i != 2) SVO_TRY(subsample_depth_u16_to(c->filt[i], c->filt[i + 1], w, h, s));
+  }
+  return SVOSLAM_OK;
+}
+
 int camera_begin(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp, int32_t *processed,
                  hipStream_t s) {
   (void)d_rgb;  // intensity only feeds the unimplemented RGB-D term (localization_kernels.cu:328-331)
@@ -543,13 +566,7 @@ int camera_begin(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rg
   c->have_stamp = true;
   c->latest_stamp = timestamp;
   if (processed) *processed = 1;
-  const int W = c->width, H = c->height;
-  SVO_TRY(bilateral_filter(d_depth, c->filt[0], W, H, s));  // :62-64
-  for (int i = 0; i < 3; i++) {                             // :72-93
-    const int w = W >> i, h = H >> i;
-    SVO_TRY(generate_vertex_normal_maps(c->filt[i], c->vert[c->cur][i], c->norm[c->cur][i], w, h, c->fx, c->fy, W, H, s));
-    if (i != 2) SVO_TRY(subsample_depth_u16_to(c->filt[i], c->filt[i + 1], w, h, s));
-  }
+  SVO_TRY(enqueue_preprocess(c, d_depth, s));
   c->frame_has_icp = c->pass >= 1;
   c->ring_slot = (int)(c->frame_seq++ & 3u);
   return SVOSLAM_OK;
@@ -611,25 +628,49 @@ int camera_end(svoslam_camera *c, hipStream_t s) {
 // boundary costs, so the simpler form stays.
 int camera_update(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp, int32_t *processed,
                   hipStream_t s) {
-  int32_t used = 0;
-  SVO_TRY(camera_begin(c, d_depth, d_rgb, timestamp, &used, s));
-  if (processed) *processed = used;
-  if (!used) return SVOSLAM_OK;
-  if (c->frame_has_icp) {
-    for (int level = 2; level >= 0; level--) {  // coarse to fine, :103
-      LevelArgs a = level_args(c, level);
-      int end;
-      const int blocks = accumulate_range(a.w, a.h, a.first, a.num, end);
-      for (int it = 0; it < kPyramidIters[level]; it++) {
-        const int flags = iter_flags(level, it);
-        icp_accumulate_kernel<<<blocks, kIcpThreads, 0, s>>>(a.lv, a.ln, a.cv, a.cn, a.first, end, c->d_state, flags, it,
-                                                             c->d_partial);
-        cam_reduce_solve_kernel<<<1, kReduceThreads, 0, s>>>(c->d_state, c->d_partial, blocks, it, flags, c->ring_slot);
+  (void)d_rgb;
+  if (!c || !d_depth) return SVOSLAM_ERR_INVALID_ARG;
+  if (c->have_stamp && timestamp <= c->latest_stamp) {  // :55-59
+    if (processed) *processed = 0;
+    c->frame_has_icp = false;
+    return SVOSLAM_OK;
+  }
+  c->have_stamp = true;
+  c->latest_stamp = timestamp;
+  if (processed) *processed = 1;
+  const bool has_icp = c->pass >= 1;
+  const int ring_slot = (int)(c->frame_seq & 3u);
+  // the ~50 launches of a frame depend only on these: recorded once per key, then replayed as one graph
+  GraphKey key;
+  key.add(d_depth).add((unsigned long long)c->cur).add((unsigned long long)ring_slot).add((unsigned long long)has_icp)
+     .add((unsigned long long)c->band_first).add((unsigned long long)c->band_rows);
+  auto enqueue = [&]() -> int {
+    SVO_TRY(enqueue_preprocess(c, d_depth, s));
+    if (has_icp) {
+      for (int level = 2; level >= 0; level--) {  // coarse to fine, :103
+        LevelArgs a = level_args(c, level);
+        int end;
+        const int blocks = accumulate_range(a.w, a.h, a.first, a.num, end);
+        for (int it = 0; it < kPyramidIters[level]; it++) {
+          const int flags = iter_flags(level, it);
+          icp_accumulate_kernel<<<blocks, kIcpThreads, 0, s>>>(a.lv, a.ln, a.cv, a.cn, a.first, end, c->d_state, flags, it,
+                                                               c->d_partial);
+          cam_reduce_solve_kernel<<<1, kReduceThreads, 0, s>>>(c->d_state, c->d_partial, blocks, it, flags, ring_slot);
+        }
       }
+    } else {  // first frame: no ICP, only the fusion transform (the last solve does it otherwise)
+      cam_frame_end_kernel<<<1, 64, 0, s>>>(c->d_state, 0, ring_slot);
     }
     SVO_LAUNCH_CHECK();
-  }
-  return camera_end(c, s);
+    return SVOSLAM_OK;
+  };
+  SVO_TRY(c->graphs.run(key, s, enqueue));
+  c->frame_seq++;
+  c->ring_slot = ring_slot;
+  if (c->pass < 2) c->pass++;  // :176-178
+  c->cur = 1 - c->cur;         // swap current/last, :181-189
+  c->frame_has_icp = false;
+  return SVOSLAM_OK;
 }
 
 int camera_set_band(svoslam_camera *c, int first_row, int rows) {

@@ -156,4 +156,15 @@ int radix_sort_pairs(svoslam_workspace *ws, int n, int num_bits, hipStream_t str
   return SVOSLAM_OK;
 }
 
+// which ping-pong buffers a radix_sort_pairs of num_bits leaves its result in (for replayed graphs)
+int radix_sort_output(svoslam_workspace *ws, int n, int num_bits, unsigned long long **sorted_keys, unsigned **sorted_vals) {
+  (void)n;
+  int passes = (num_bits + 7) / 8;
+  if (passes < 1) passes = 1;
+  const bool in_b = (passes & 1) != 0;
+  *sorted_keys = in_b ? ws->keys_b.as<unsigned long long>() : ws->keys_a.as<unsigned long long>();
+  *sorted_vals = in_b ? ws->vals_b.as<unsigned>() : ws->vals_a.as<unsigned>();
+  return SVOSLAM_OK;
+}
+
 }  // namespace svoslam

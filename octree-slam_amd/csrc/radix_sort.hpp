@@ -11,6 +11,8 @@ int radix_sort_num_tiles(int n);
 // iota_vals = false: the values to carry are in ws->vals_a.
 int radix_sort_pairs(svoslam_workspace *ws, int n, int num_bits, hipStream_t stream,
                      unsigned long long **sorted_keys, unsigned **sorted_vals, bool iota_vals = true);
+// Where that sort leaves its result (depends only on the pass count).
+int radix_sort_output(svoslam_workspace *ws, int n, int num_bits, unsigned long long **sorted_keys, unsigned **sorted_vals);
 // In-place exclusive scan of each of 256 rows of num_tiles counters; row totals to totals[256].
 void row_scan_rows(unsigned *rows, int num_tiles, unsigned *totals, hipStream_t stream);
 // Same for a single row.

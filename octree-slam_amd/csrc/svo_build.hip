@@ -373,9 +373,86 @@ __global__ void mip_root_kernel(u32 *__restrict__ pool, const PlanCounts *__rest
 // ----------------------------------------------------------------------------
 // host driver
 // ----------------------------------------------------------------------------
+// ---- non-blocking size tracking of the asynchronous fusion ----------------------------------------
+// Every commit copies the new size (4 bytes) to a pinned host slot behind an event.  The next plan polls
+// the events: each completed one makes pool->size current up to that commit and releases its worst-case
+// reservation, so the host learns the true size a frame or two late WITHOUT ever waiting for the device.
+struct PoolTracker {
+  static constexpr int kSlots = 8;
+  int32_t *h_size = nullptr;  // pinned [kSlots]
+  hipEvent_t ev[kSlots];
+  struct InFlight { int slot; int64_t bound; };
+  InFlight q[kSlots];  // oldest first
+  int count = 0, next = 0;
+};
+
+static PoolTracker *tracker_of(svoslam_pool *pool) { return reinterpret_cast<PoolTracker *>(pool->tracker); }
+
+static int tracker_create(svoslam_pool *pool) {
+  if (pool->tracker) return SVOSLAM_OK;
+  PoolTracker *t = new PoolTracker();
+  if (hipHostMalloc((void **)&t->h_size, PoolTracker::kSlots * 4, hipHostMallocDefault) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
+  for (int i = 0; i < PoolTracker::kSlots; i++) {
+    if (hipEventCreateWithFlags(&t->ev[i], hipEventDisableTiming) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
+  }
+  pool->tracker = t;
+  return SVOSLAM_OK;
+}
+
+void pool_tracker_destroy(svoslam_pool *pool) {
+  PoolTracker *t = pool ? tracker_of(pool) : nullptr;
+  if (!t) return;
+  for (int i = 0; i < PoolTracker::kSlots; i++) (void)hipEventDestroy(t->ev[i]);
+  if (t->h_size) (void)hipHostFree(t->h_size);
+  delete t;
+  pool->tracker = nullptr;
+}
+
+// retire the completed readbacks (wait_all: block until every one has completed)
+static int tracker_poll(svoslam_pool *pool, bool wait_all) {
+  PoolTracker *t = tracker_of(pool);
+  if (!t) return SVOSLAM_OK;
+  while (t->count > 0) {
+    const PoolTracker::InFlight f = t->q[0];
+    if (wait_all) SVO_HIP(hipEventSynchronize(t->ev[f.slot]));
+    else {
+      const hipError_t e = hipEventQuery(t->ev[f.slot]);
+      if (e == hipErrorNotReady) { (void)hipGetLastError(); break; }
+      SVO_HIP(e);
+    }
+    pool->size = t->h_size[f.slot];
+    pool->pending_bound -= f.bound;
+    if (pool->pending_bound < 0) pool->pending_bound = 0;
+    if (pool->pending > 0) pool->pending -= 1;
+    for (int i = 1; i < t->count; i++) t->q[i - 1] = t->q[i];
+    t->count--;
+  }
+  return SVOSLAM_OK;
+}
+
+// after a commit has been enqueued on `stream`
+static int tracker_push(svoslam_pool *pool, int64_t bound, hipStream_t stream) {
+  PoolTracker *t = tracker_of(pool);
+  if (!t) return SVOSLAM_OK;
+  if (t->count == PoolTracker::kSlots) {  // ring full: the oldest readback is long done in practice
+    SVO_HIP(hipEventSynchronize(t->ev[t->q[0].slot]));
+    SVO_TRY(tracker_poll(pool, false));
+  }
+  const int slot = t->next;
+  t->next = (t->next + 1) % PoolTracker::kSlots;
+  SVO_HIP(hipMemcpyAsync(&t->h_size[slot], pool->d_size, 4, hipMemcpyDeviceToHost, stream));
+  SVO_HIP(hipEventRecord(t->ev[slot], stream));
+  t->q[t->count].slot = slot;
+  t->q[t->count].bound = bound;
+  t->count++;
+  return SVOSLAM_OK;
+}
+
 int pool_sync(svoslam_pool *pool, hipStream_t stream) {
   if (!pool) return SVOSLAM_ERR_INVALID_ARG;
-  if (pool->pending > 0 && pool->d_size) {
+  if (tracker_of(pool) && tracker_of(pool)->count > 0) {  // the last commit's readback is the exact size
+    SVO_TRY(tracker_poll(pool, true));
+  } else if (pool->pending > 0 && pool->d_size) {
     int32_t sz = 0;
     SVO_HIP(hipMemcpyAsync(&sz, pool->d_size, 4, hipMemcpyDeviceToHost, stream));
     SVO_HIP(hipStreamSynchronize(stream));
@@ -391,7 +468,7 @@ static int ensure_device_size(svoslam_pool *pool, hipStream_t stream) {
   SVO_HIP(hipMalloc((void **)&pool->d_size, 4));
   SVO_HIP(hipMemcpyAsync(pool->d_size, &pool->size, 4, hipMemcpyHostToDevice, stream));
   SVO_HIP(hipStreamSynchronize(stream));
-  return SVOSLAM_OK;
+  return tracker_create(pool);
 }
 
 static int grow_pool(svoslam_pool *pool, int64_t need_nodes, hipStream_t stream) {
@@ -416,7 +493,7 @@ int pool_init(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream) {
   if (!pool) return SVOSLAM_ERR_INVALID_ARG;
   if (capacity_nodes < 8) capacity_nodes = 8;
   pool->d_data = nullptr; pool->size = 0; pool->capacity = 0;
-  pool->d_size = nullptr; pool->pending = 0; pool->pending_bound = 0;
+  pool->d_size = nullptr; pool->pending = 0; pool->pending_bound = 0; pool->tracker = nullptr;
   SVO_TRY(grow_pool(pool, capacity_nodes, stream));
   SVO_HIP(hipMemsetAsync(pool->d_data, 0, 64, stream));  // initOctree, svo.cu:24-31
   pool->size = 8;
@@ -518,18 +595,62 @@ static int64_t max_records(int n, int depth) {
 
 // Asynchronous fusion: same kernels up to the plan, then every split in one launch (split_all_kernel), no
 // readback.  The host only knows an upper bound of the pool size; capacity is kept ahead of it.
-int svo_from_point_cloud_async(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,
-                               svoslam_pool *pool, const float center[3], float edge, hipStream_t stream) {
-  if (!ws || !pool || n < 0 || (n > 0 && (!d_points || !d_colors))) return SVOSLAM_ERR_INVALID_ARG;
+// ---- asynchronous fusion in three phases --------------------------------------------------------
+// sort:   keys + radix sort of the new points.  Touches only the workspace.
+// plan:   per sorted leaf, where the pool's current tree ends and which nodes must be split (records in
+//         reference order).  READS the pool's structure words; must follow the previous call's commit.
+// commit: all splits in one launch, leaf blend, mip levels.  WRITES the pool.
+// A caller that renders between fusions can run sort + plan of frame k+1 on another stream while frame
+// k is ray-marched (the pool is only read), and commit when the render is done; results are those of
+// the one-call form.  Phases of one fusion share one workspace; concurrent fusions need their own.
+int svo_fuse_sort(svoslam_workspace *ws, const float *d_points, int n, int depth, const float center[3], float edge,
+                  hipStream_t stream) {
+  if (!ws || n < 0 || (n > 0 && !d_points)) return SVOSLAM_ERR_INVALID_ARG;
   if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
-  if (pool->size == 0) SVO_TRY(pool_init(pool, 8, stream));
+  ws->sorted_keys = nullptr; ws->sorted_idx = nullptr; ws->planned_n = -1;
   if (n == 0) return SVOSLAM_OK;
-  SVO_TRY(ensure_device_size(pool, stream));
   const int64_t rmax = max_records(n, depth);
   if (rmax > 0x7FFFFFFFll / 8) return SVOSLAM_ERR_POOL_LIMIT;
+  SVO_TRY(reserve_common(ws, n, depth));
+  SVO_TRY(ws->rec_key.reserve((size_t)rmax * 8));
+  SVO_TRY(ws->rec_front.reserve((size_t)rmax * 4));
+  SVO_TRY(ws->rec_pass.reserve((size_t)rmax));
+  u64 *skey = nullptr; u32 *sidx = nullptr;
+  auto enqueue = [&]() -> int {
+    compute_keys_kernel<3><<<cdiv(n, 256), 256, 0, stream>>>(d_points, n, depth, center[0], center[1], center[2], edge, ws->keys_a.as<u64>());
+    SVO_TRY(radix_sort_pairs(ws, n, 3 * depth + 1, stream, &skey, &sidx));
+    SVO_LAUNCH_CHECK();
+    return SVOSLAM_OK;
+  };
+  GraphKey key;
+  key.add(d_points).add((unsigned long long)n).add((unsigned long long)depth).addf(center[0]).addf(center[1]).addf(center[2])
+     .addf(edge).add(ws->layout_hash());
+  SVO_TRY(ws->g_sort.run(key, stream, enqueue));
+  if (!skey) SVO_TRY(radix_sort_output(ws, n, 3 * depth + 1, &skey, &sidx));  // replayed: where the recorded sort leaves its result
+  ws->sorted_keys = skey; ws->sorted_idx = sidx;
+  return SVOSLAM_OK;
+}
+
+int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream) {
+  if (!ws || !pool || n < 0) return SVOSLAM_ERR_INVALID_ARG;
+  if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
+  if (pool->size == 0) SVO_TRY(pool_init(pool, 8, stream));
+  ws->planned_n = -1;
+  if (n == 0) { ws->planned_n = 0; return SVOSLAM_OK; }
+  if (!ws->sorted_keys) return SVOSLAM_ERR_INVALID_ARG;  // svo_fuse_sort has not run on this workspace
+  SVO_TRY(ensure_device_size(pool, stream));
+  SVO_TRY(tracker_poll(pool, false));  // sizes the device has reported since the last call
+  const int64_t rmax = max_records(n, depth);
   int64_t bound = (int64_t)pool->size + pool->pending_bound + 8 * rmax;
   if (bound > pool->capacity) {
-    SVO_TRY(pool_sync(pool, stream));  // learn the true size: the bound is very loose (surface data splits ~n, not ~6n)
+    // the bound is very loose (surface data splits ~n, not ~6n): first let the commits in flight report their sizes
+    SVO_TRY(tracker_poll(pool, true));
+    bound = (int64_t)pool->size + pool->pending_bound + 8 * rmax;
+  }
+  if (bound > pool->capacity) {
+    // growing moves the pool: nothing on ANY stream may still be using it (a render of the previous frame)
+    SVO_HIP(hipDeviceSynchronize());
+    SVO_TRY(pool_sync(pool, stream));
     bound = (int64_t)pool->size + 8 * rmax;
     if (bound > pool->capacity) {
       int64_t want = (int64_t)pool->size + 16 * 8 * rmax;  // room for ~16 worst-case calls before the next sync
@@ -538,38 +659,69 @@ int svo_from_point_cloud_async(svoslam_workspace *ws, const float *d_points, con
       SVO_TRY(grow_pool(pool, want, stream));
     }
   }
-  SVO_TRY(reserve_common(ws, n, depth));
-  SVO_TRY(ws->rec_key.reserve((size_t)rmax * 8));
-  SVO_TRY(ws->rec_front.reserve((size_t)rmax * 4));
-  SVO_TRY(ws->rec_pass.reserve((size_t)rmax));
-  compute_keys_kernel<3><<<cdiv(n, 256), 256, 0, stream>>>(d_points, n, depth, center[0], center[1], center[2], edge, ws->keys_a.as<u64>());
-  u64 *skey = nullptr; u32 *sidx = nullptr;
-  SVO_TRY(radix_sort_pairs(ws, n, 3 * depth + 1, stream, &skey, &sidx));
+  const u64 *skey = ws->sorted_keys;
   const int tiles = (int)cdiv(n, 256);
   unsigned char *leaf_t = ws->leaf_t.as<unsigned char>();
   u32 *leaf_f = ws->leaf_f.as<u32>();
   u32 *tile_hist = ws->tile_hist.as<u32>();
-  SVO_HIP(hipMemsetAsync(small_any(ws), 0, 4, stream));
-  plan_count_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, tiles, small_any(ws));
-  row_scan_rows(tile_hist, tiles, small_totals(ws), stream);
-  plan_finish_kernel<<<1, 256, 0, stream>>>(small_totals(ws), small_bucket_base(ws), small_counts(ws), small_any(ws));
-  plan_emit_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, tiles,
-                                              ws->rec_key.as<u64>(), ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>());
+  auto enqueue = [&]() -> int {
+    SVO_HIP(hipMemsetAsync(small_any(ws), 0, 4, stream));
+    plan_count_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, tiles, small_any(ws));
+    row_scan_rows(tile_hist, tiles, small_totals(ws), stream);
+    plan_finish_kernel<<<1, 256, 0, stream>>>(small_totals(ws), small_bucket_base(ws), small_counts(ws), small_any(ws));
+    plan_emit_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, tiles,
+                                                ws->rec_key.as<u64>(), ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>());
+    SVO_LAUNCH_CHECK();
+    return SVOSLAM_OK;
+  };
+  GraphKey key;
+  key.add(skey).add((unsigned long long)n).add((unsigned long long)depth).add(pool->d_data).add(ws->layout_hash());
+  SVO_TRY(ws->g_plan.run(key, stream, enqueue));
+  ws->planned_n = n;
+  pool->pending_bound += 8 * rmax;  // reserved from now on
+  return SVOSLAM_OK;
+}
+
+int svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, hipStream_t stream) {
+  if (!ws || !pool || n < 0 || (n > 0 && !d_colors)) return SVOSLAM_ERR_INVALID_ARG;
+  if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
+  if (ws->planned_n != n) return SVOSLAM_ERR_INVALID_ARG;  // svo_fuse_plan has not run for this batch
+  ws->planned_n = -1;
+  if (n == 0) return SVOSLAM_OK;
+  const int64_t rmax = max_records(n, depth);
+  const u64 *skey = ws->sorted_keys;
+  const u32 *sidx = ws->sorted_idx;
+  const int tiles = (int)cdiv(n, 256);
+  const unsigned char *leaf_t = ws->leaf_t.as<unsigned char>();
   int split_blocks = (int)cdiv(rmax, 256);
   if (split_blocks > 2048) split_blocks = 2048;
-  split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
-                                                     ws->rec_pass.as<unsigned char>(), small_bucket_base(ws), small_counts(ws),
-                                                     pool->d_data, pool->d_size, depth);
-  pool_size_update_kernel<<<1, 64, 0, stream>>>(pool->d_size, small_counts(ws));
   u32 *path_nodes = ws->path_nodes.as<u32>();
-  fill_kernel<false><<<tiles, 256, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, 0, pool->d_data, path_nodes);
-  for (int d = depth - 1; d >= 1; d--)
-    mip_level_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, d, leaf_t, path_nodes, pool->d_data);
-  mip_root_kernel<<<1, 64, 0, stream>>>(pool->d_data, small_counts(ws));
-  SVO_LAUNCH_CHECK();
+  auto enqueue = [&]() -> int {
+    split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
+                                                       ws->rec_pass.as<unsigned char>(), small_bucket_base(ws), small_counts(ws),
+                                                       pool->d_data, pool->d_size, depth);
+    pool_size_update_kernel<<<1, 64, 0, stream>>>(pool->d_size, small_counts(ws));
+    fill_kernel<false><<<tiles, 256, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, 0, pool->d_data, path_nodes);
+    for (int d = depth - 1; d >= 1; d--)
+      mip_level_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, d, leaf_t, path_nodes, pool->d_data);
+    mip_root_kernel<<<1, 64, 0, stream>>>(pool->d_data, small_counts(ws));
+    SVO_LAUNCH_CHECK();
+    return SVOSLAM_OK;
+  };
+  GraphKey key;
+  key.add(skey).add(d_colors).add((unsigned long long)n).add((unsigned long long)depth).add(pool->d_data).add(pool->d_size)
+     .add(ws->layout_hash());
+  SVO_TRY(ws->g_commit.run(key, stream, enqueue));
   pool->pending += 1;
-  pool->pending_bound += 8 * rmax;
-  return SVOSLAM_OK;
+  return tracker_push(pool, 8 * rmax, stream);
+}
+
+int svo_from_point_cloud_async(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,
+                               svoslam_pool *pool, const float center[3], float edge, hipStream_t stream) {
+  if (!ws || !pool || n < 0 || (n > 0 && (!d_points || !d_colors))) return SVOSLAM_ERR_INVALID_ARG;
+  SVO_TRY(svo_fuse_sort(ws, d_points, n, depth, center, edge, stream));
+  SVO_TRY(svo_fuse_plan(ws, n, depth, pool, stream));
+  return svo_fuse_commit(ws, d_colors, n, depth, pool, stream);
 }
 
 int svo_from_point_cloud(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,

@@ -7,8 +7,13 @@ namespace svoslam {
 int pool_init(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream);
 int pool_reserve(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream);
 int pool_sync(svoslam_pool *pool, hipStream_t stream);
+void pool_tracker_destroy(svoslam_pool *pool);
 int svo_from_point_cloud_async(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,
                                svoslam_pool *pool, const float center[3], float edge, hipStream_t stream);
+int svo_fuse_sort(svoslam_workspace *ws, const float *d_points, int n, int depth, const float center[3], float edge,
+                  hipStream_t stream);
+int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream);
+int svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, hipStream_t stream);
 int svo_from_point_cloud(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,
                          svoslam_pool *pool, const float center[3], float edge, svoslam_fuse_stats *stats,
                          hipStream_t stream);

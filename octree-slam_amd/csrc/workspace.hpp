@@ -5,6 +5,7 @@
 #pragma once
 
 #include "common.hpp"
+#include "graph_cache.hpp"
 
 namespace svoslam {
 
@@ -46,11 +47,25 @@ struct svoslam_workspace {
   svoslam::DeviceBuffer bfs_a, bfs_b, bfs_mask, bfs_ptr;  // extraction
   svoslam::DeviceBuffer misc;                             // bbox partials etc.
   svoslam::PlanCounts *h_counts = nullptr;                // pinned host
+  // phased fusion (svo_fuse_sort -> plan -> commit): where the sort left its output, what has been planned
+  const unsigned long long *sorted_keys = nullptr;
+  const unsigned int *sorted_idx = nullptr;
+  int planned_n = -1;
+  svoslam::GraphCache g_sort, g_plan, g_commit;            // recorded launch sequences of the three phases
+  // every buffer address the recorded phases bake in (a reallocation makes a new key)
+  unsigned long long layout_hash() const {
+    const void *p[] = {keys_a.ptr, keys_b.ptr, vals_a.ptr, vals_b.ptr, tile_hist.ptr, small.ptr, leaf_t.ptr, leaf_f.ptr,
+                       rec_key.ptr, rec_front.ptr, rec_pass.ptr, path_nodes.ptr};
+    unsigned long long h = 1469598103934665603ull;
+    for (const void *q : p) h = (h ^ (unsigned long long)(uintptr_t)q) * 1099511628211ull;
+    return h;
+  }
   void release_all() {
     keys_a.release(); keys_b.release(); vals_a.release(); vals_b.release(); tile_hist.release(); small.release();
     leaf_t.release(); leaf_f.release(); rec_key.release(); rec_front.release(); path_nodes.release();
     rec_pass.release();
     bfs_a.release(); bfs_b.release(); bfs_mask.release(); bfs_ptr.release(); misc.release();
     if (h_counts) { (void)hipHostFree(h_counts); h_counts = nullptr; }
+    g_sort.clear(); g_plan.clear(); g_commit.clear();
   }
 };

@@ -151,45 +151,84 @@ class SlamPipeline:
 
     # -- software-pipelined stream of frames ------------------------------------------------
     def run_stream(self, depths, rgbs, timestamps, views, on_render=None):
-        """Processes the frames in order with the tracker of frame k+1 overlapped with the mapping of
-        frame k: tracking (bilateral, pyramids, 19 ICP iterations) runs on one HIP stream; back-projection,
-        fusion and the raycast run on a second one and wait, per frame, for that frame's pose (an event).
-        The tracker state is only touched by the first stream and the node pool only by the second; the pose
-        crosses over through a 4-slot ring in the camera state.  Results are identical to frame(); only the
-        two latency-bound kernel chains overlap.  on_render(i, image) is called (stream-ordered on the
-        mapping stream, image valid until the next frame) after each frame's raycast has been enqueued."""
+        """Processes the frames in order on three HIP streams, every frame still going through
+        track -> back-project -> fuse -> render with the results of frame():
+
+          T  tracker of frame k+1 (bilateral, pyramids, 19 ICP iterations); touches only the camera state
+          S  back-projection, keys + sort and split planning of frame k+1 (reads the pool's tree)
+          M  commit of frame k (splits, leaf blend, mip levels -- the only writer of the pool), raycast of frame k
+
+        While frame k is ray-marched on M, S prepares frame k+1 and T tracks it; M then only has to commit.
+        Cross-stream order (events): S waits for the pose of its frame (from T) and, before planning, for
+        the commit of the previous frame (from M); M waits for the plan of its frame; T waits, before it
+        overwrites a slot of the 4-deep pose ring, for the back-projection that reads that slot.
+        on_render(i, None) / on_render(i, image) are called around each raycast (stream-ordered on M; the
+        image is valid until the next frame)."""
         n = len(timestamps)
         if n == 0:
             return
         if not hasattr(self, "_s_track"):
-            self._s_track, self._s_map = torch.cuda.Stream(), torch.cuda.Stream()
+            self._s_track, self._s_prep, self._s_map = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+            self._ws2 = [self.ws, pkg.Workspace()]
+            self._points2 = [self.points, torch.empty_like(self.points)]
+            # fixed input addresses per stream: the library replays its launch sequences as HIP graphs keyed
+            # on the pointers it is given (csrc/graph_cache.hpp), so each frame is copied into a staging buffer
+            self._in_track = torch.empty_like(depths[0])
+            self._in_prep = torch.empty_like(depths[0])
+            self._in_rgb = torch.empty_like(rgbs[0])
         cur = torch.cuda.current_stream()
-        self._s_track.wait_stream(cur)
-        self._s_map.wait_stream(cur)
-        ev = [torch.cuda.Event() for _ in range(n)]
+        for st in (self._s_track, self._s_prep, self._s_map):
+            st.wait_stream(cur)
+        ev_pose = [torch.cuda.Event() for _ in range(n)]
+        ev_bp = [torch.cuda.Event() for _ in range(n)]
+        ev_plan = [torch.cuda.Event() for _ in range(n)]
+        ev_commit = [torch.cuda.Event() for _ in range(n)]
         fusion_ptr = [0] * n
+        npts = self.w * self.h
 
         def enqueue_track(i):
             with torch.cuda.stream(self._s_track):
-                self.track(depths[i], rgbs[i], timestamps[i])
+                if i >= 4:
+                    self._s_track.wait_event(ev_bp[i - 4])       # ring slot i % 4 has been consumed
+                self._in_track.copy_(depths[i])
+                self.track(self._in_track, rgbs[i], timestamps[i])
                 fusion_ptr[i] = self.cam.fusion_transform_ptr()   # ring slot of frame i
-                ev[i].record()
+                ev_pose[i].record()
+
+        def enqueue_prepare(i):
+            ws, pts = self._ws2[i & 1], self._points2[i & 1]
+            with torch.cuda.stream(self._s_prep):
+                self._s_prep.wait_event(ev_pose[i])
+                self.points = pts
+                self._in_prep.copy_(depths[i])
+                self._backproject_with(self._in_prep, fusion_ptr[i])
+                ev_bp[i].record()
+                pkg.svo_fuse_sort(ws, pts.view(-1, 3), self.depth, self.center, self.edge)
+                if i > 0:
+                    self._s_prep.wait_event(ev_commit[i - 1])    # the tree the plan reads
+                pkg.svo_fuse_plan(ws, npts, self.depth, self.pool)
+                ev_plan[i].record()
 
         enqueue_track(0)
+        enqueue_prepare(0)
         for i in range(n):
             if i + 1 < n:
-                enqueue_track(i + 1)          # queued before this frame's mapping blocks the host
+                enqueue_track(i + 1)
             with torch.cuda.stream(self._s_map):
-                self._s_map.wait_event(ev[i])
-                self._backproject_with(depths[i], fusion_ptr[i])
-                self.fuse(rgbs[i])
+                self._s_map.wait_event(ev_plan[i])
+                self._in_rgb.copy_(rgbs[i])
+                pkg.svo_fuse_commit(self._ws2[i & 1], self._in_rgb.view(-1, 3), self.depth, self.pool)
+                ev_commit[i].record()
+            if i + 1 < n:
+                enqueue_prepare(i + 1)      # host order: after ev_commit[i] has been recorded
+            with torch.cuda.stream(self._s_map):
                 if on_render is not None:
                     on_render(i, None)        # "before render" hook (event timing)
                 self.render(views[i])
                 if on_render is not None:
                     on_render(i, self.image)
-        cur.wait_stream(self._s_track)
-        cur.wait_stream(self._s_map)
+        for st in (self._s_track, self._s_prep, self._s_map):
+            cur.wait_stream(st)
 
     def _backproject_with(self, depth, fusion_ptr):
         if not self.dist.enabled:

@@ -99,18 +99,20 @@ def test_band_render_tiles_assemble_full_image(env, oracle):
         assert np.array_equal(img.cpu().numpy(), full)
 
 
-def test_two_stream_overlap_equals_sequential(env):
-    """run_stream (tracker of frame k+1 on one HIP stream, mapping + raycast of frame k on another) must give
-    exactly the images, pool and poses of the strictly sequential frame() loop"""
+@pytest.mark.parametrize("capacity", [1 << 20, 1 << 12])
+def test_stream_overlap_equals_sequential(env, capacity):
+    """run_stream (tracker of frame k+1, preparation of frame k+1 and commit + raycast of frame k on three HIP
+    streams) must give exactly the images, pool and poses of the strictly sequential frame() loop -- also when
+    the pool has to grow in the middle of the stream (capacity 4096 nodes)"""
     pkg, torch, synth, pl = env
     w, h, depth, center, edge = 320, 240, 10, (0.0, 1.5, 0.0), 4.096
-    n = 12
+    n = 20
     frames = [synth.render_frame(k, w, h, device="cuda") for k in range(n)]
     views = [pl.ground_truth_view(k, synth) for k in range(n)]
     A = pl.SlamPipeline(w, h, depth, center, edge, render_mode=1)
     seq_imgs = [A.frame(frames[k][0], frames[k][1], k, views[k]).cpu().numpy().copy() for k in range(n)]
     for rep in range(3):
-        B = pl.SlamPipeline(w, h, depth, center, edge, render_mode=1)
+        B = pl.SlamPipeline(w, h, depth, center, edge, render_mode=1, pool_capacity_nodes=capacity)
         imgs = []
         B.run_stream([f[0] for f in frames], [f[1] for f in frames], list(range(n)), views,
                      on_render=lambda i, im: imgs.append(im.clone()) if im is not None else None)
