@@ -280,14 +280,6 @@ __global__ __launch_bounds__(kTraceThreads) void cone_trace_kernel(uchar4 *__res
     uint32_t oct_val = 0;
     int alpha = 0;
     bool range_exit = false;
-    // path cache (see the walk)
-    uint32_t pxb = 0xFFFFFFFFu, pyb = 0xFFFFFFFFu, pzb = 0xFFFFFFFFu;
-    uint32_t ctile[kLdsDepth - kGridLevel + 1];  // ctile[k]: tile holding the level (kGridLevel + 1 + k) nodes of the cached path
-#pragma unroll
-    for (int k = 0; k <= kLdsDepth - kGridLevel; k++) ctile[k] = 0;
-    int cvalid = 0;        // deepest level whose tile is cached (0: none)
-    uint2 gprev = make_uint2(0u, 0u);
-    bool gvalid = false;
 #ifdef SVO_PROF
     long long pc[5] = {0, 0, 0, 0, 0};
 #define PROF_T(k) { const long long now_ = clock64(); pc[k] += now_ - t_prev; t_prev = now_; }
@@ -320,68 +312,41 @@ __global__ __launch_bounds__(kTraceThreads) void cone_trace_kernel(uchar4 *__res
       }
       asm volatile("" :: "v"(xb), "v"(yb), "v"(zb));
       PROF_T(0)
-      // ---- the walk (:76-105), shortened by what this lane already knows ----
-      // Path cache: consecutive samples of a ray near a surface are a few millimetres apart and share
-      // most of their ancestors.  The lane keeps the octant bits of its previous sample, the level-6
-      // grid entry and the child-tile indices of levels 7..13 it walked through; a new sample whose first
-      // L levels coincide with the previous one resumes at level min(L + 1, deepest cached level, depth)
-      // instead of level 1.  (The kernel is bound by the L1's miss throughput on these per-lane
-      // gathers, so loads not issued are what count.)  The pool is const during a render, so cached
-      // tiles are exactly what the loads would return.
-      const uint32_t diff = (xb ^ pxb) | (yb ^ pyb) | (zb ^ pzb);
-#ifdef SVO_NOCACHE
-      const int same = -1;
-#else
-      const int same = (diff == 0u ? 32 : __clz((int)diff)) - (32 - kLdsDepth);  // leading levels shared with the previous sample (< 0: none)
-#endif
-      pxb = xb; pyb = yb; pzb = zb;
-      gvalid = gvalid && same >= kGridLevel;
-      cvalid = cvalid < same + 1 ? cvalid : same + 1;
+      // ---- the walk (:76-105) ----
+      // (A per-lane cache of the previous sample's path -- resume at the first level that differs -- was
+      // measured: it removes most loads of a lane but not the wavefront's latency, which is set by the one
+      // lane per step that crosses a coarse boundary; 0.277 ms against 0.261 ms without it.)
       uint32_t w1 = 0;
-      bool walking = false;  // levels kGridLevel+1.. still to visit
-      int first = kGridLevel + 1;
-      if (depth > kGridLevel && cvalid > kGridLevel) {
-        walking = true;
-        first = cvalid < depth ? cvalid : depth;
-      } else if (depth >= kGridLevel) {
-        if (!gvalid) {
-          const uint32_t cell = ((zb >> (kLdsDepth - kGridLevel)) << (2 * kGridLevel)) | ((yb >> (kLdsDepth - kGridLevel)) << kGridLevel) |
-                                (xb >> (kLdsDepth - kGridLevel));
-          gprev = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(grid) + (cell << 3));
-          gvalid = true;
-        }
-        w1 = gprev.y;
-        if (gprev.x & kFlag) {
-          ctile[0] = gprev.x & kMask;
-          cvalid = cvalid > kGridLevel + 1 ? cvalid : kGridLevel + 1;
-          walking = depth > kGridLevel;
-        } else {
-          depth = (int)gprev.x;  // stopped at the first childless node
-          cvalid = 0;
-        }
-      }
-      asm volatile("" :: "v"(w1));
-      PROF_T(1)
-      if (walking) {
-        // levels 7..kLdsDepth: both words of a node are fetched together; tiles go to the path cache
-#pragma unroll
-        for (int l = kGridLevel + 1; l <= kLdsDepth; l++) {
-          if (walking && l >= first && l <= depth) {
+      if (depth >= kGridLevel) {
+        const uint32_t cell = ((zb >> (kLdsDepth - kGridLevel)) << (2 * kGridLevel)) | ((yb >> (kLdsDepth - kGridLevel)) << kGridLevel) |
+                              (xb >> (kLdsDepth - kGridLevel));
+        const uint2 g = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(grid) + (cell << 3));
+        w1 = g.y;
+        asm volatile("" :: "v"(w1));
+        PROF_T(1)
+        if (!(g.x & kFlag)) {
+          depth = (int)g.x;  // stopped at the first childless node
+        } else if (depth > kGridLevel) {
+          // levels 7..: the dependent walk of the reference; both words of a node are fetched together
+          uint32_t child_idx = g.x & kMask;
+          const int lds_end = depth < kLdsDepth ? depth : kLdsDepth;
+          bool stopped = false;
+          for (int l = kGridLevel + 1; l <= lds_end; l++) {
             const int sh = kLdsDepth - l;
             const uint32_t oct = ((xb >> sh) & 1u) | (((yb >> sh) & 1u) << 1) | (((zb >> sh) & 1u) << 2);
-            uint2 nd = nodes[ctile[l - kGridLevel - 1] + oct];
+            uint2 nd = nodes[child_idx + oct];
             asm volatile("" : "+v"(nd.y));  // keep the colour word in the same 8-byte load (not a second, dependent one)
             w1 = nd.y;
-            if (!(nd.x & kFlag)) { depth = l; walking = false; cvalid = l; }
-            else { ctile[l - kGridLevel] = nd.x & kMask; cvalid = cvalid > l + 1 ? cvalid : l + 1; }
+            if (!(nd.x & kFlag)) { depth = l; stopped = true; break; }
+            child_idx = nd.x & kMask;
           }
+          if (!stopped && depth > kLdsDepth)  // below the LDS table's levels
+            walk_deep(nodes, table, P, tx, ty, tz, kLdsDepth + 1, child_idx, depth, w1);
         }
-        if (walking && depth > kLdsDepth)  // below the LDS table (uncached)
-          walk_deep(nodes, table, P, tx, ty, tz, kLdsDepth + 1, ctile[kLdsDepth - kGridLevel], depth, w1);
-      } else if (depth >= 1 && depth < kGridLevel) {
+      } else if (depth >= 1) {
         // LOD coarser than the grid (sample farther than ~size/(32 pix_scale)): the reference's walk from the root
         walk_shallow(nodes, xb, yb, zb, depth, w1);
-      } else if (depth < 1) {
+      } else {
         w1 = octree[1];  // depth <= 0: the reference reads node 0 (:107 with node_idx = 0)
       }
       my_levels += (uint32_t)(depth > 0 ? depth : 0);  // levels the reference visits == the depth it ends on
@@ -442,7 +407,11 @@ __global__ __launch_bounds__(kTraceThreads) void cone_trace_kernel(uchar4 *__res
     pos[idx] = o;
   }
   if (counters) {
-    // wave-level sums, one atomic pair per wavefront
+    // wave sums -> workgroup sums in LDS -> one atomic pair per workgroup (9600 same-address atomics,
+    // one pair per wavefront, cost 60 us of L2 serialisation per frame)
+    __shared__ unsigned long long wg_sum[2];
+    if (threadIdx.x == 0) { wg_sum[0] = 0ull; wg_sum[1] = 0ull; }
+    __syncthreads();
     unsigned long long s64 = my_steps, l64 = my_levels;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -450,8 +419,13 @@ __global__ __launch_bounds__(kTraceThreads) void cone_trace_kernel(uchar4 *__res
       l64 += __shfl_down(l64, o);
     }
     if (lane == 0) {
-      atomicAdd(&counters[0], s64);
-      atomicAdd(&counters[1], l64);
+      atomicAdd(&wg_sum[0], s64);
+      atomicAdd(&wg_sum[1], l64);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(&counters[0], wg_sum[0]);
+      atomicAdd(&counters[1], wg_sum[1]);
     }
   }
 }
