@@ -29,6 +29,10 @@ import os
 import sys
 import time
 
+# The frame pipeline uses four HIP streams next to the default one; the HIP runtime multiplexes streams
+# onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams sharing a queue run in order.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -295,6 +295,14 @@ int svoslam_camera_set_band(svoslam_camera *cam, int32_t first_row, int32_t rows
  * *processed if the frame was used, 0 if its timestamp was stale (:55-59). */
 int svoslam_camera_update(svoslam_camera *cam, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp,
                           int32_t *processed, void *stream);
+/* update() in its two halves, for callers that overlap them: prepare() filters the depth image and builds
+ * the vertex/normal pyramids of the next frame (independent of earlier poses; up to two frames may be
+ * prepared ahead), track() estimates the pose of the oldest prepared frame.  update() == prepare() then
+ * track() on one stream.  With several streams the caller orders prepare(f) after track(f-2) and
+ * track(f) after prepare(f) (the maps live in three rotating sets). */
+int svoslam_camera_prepare(svoslam_camera *cam, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp,
+                           int32_t *processed, void *stream);
+int svoslam_camera_track(svoslam_camera *cam, void *stream);
 /* Multi-GPU stepping: update() split at the all-reduce points.  begin() builds
  * the pyramids; for level = 2,1,0 and it = 0..iters(level)-1 call
  * icp_accumulate() [adds this band's 27 doubles into svoslam_camera_acc()], then

@@ -128,6 +128,8 @@ SIGNATURES = {
     "svoslam_camera_set_acc": (C.c_int, [_vp, _vp]),
     "svoslam_camera_update": (C.c_int, [_vp, _vp, _vp, C.c_longlong, C.POINTER(_i32), _vp]),
     "svoslam_camera_begin": (C.c_int, [_vp, _vp, _vp, C.c_longlong, C.POINTER(_i32), _vp]),
+    "svoslam_camera_prepare": (C.c_int, [_vp, _vp, _vp, C.c_longlong, C.POINTER(_i32), _vp]),
+    "svoslam_camera_track": (C.c_int, [_vp, _vp]),
     "svoslam_camera_icp_iters": (C.c_int, [_i32]),
     "svoslam_camera_icp_accumulate": (C.c_int, [_vp, _i32, _i32, _vp]),
     "svoslam_camera_acc": (_vp, [_vp]),
@@ -168,8 +170,17 @@ def check(status):
                                                           L.svoslam_last_error().decode()))
 
 
+_raw_stream = None
+
+
 def _stream():
+    """torch's current HIP stream as a raw handle (the C call, not the Stream object: this runs ~20x per frame)"""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or False
+    if _raw_stream:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -569,6 +580,16 @@ class Camera:
         used = C.c_int32(0)
         check(lib().svoslam_camera_update(self._h, _ptr(depth), _ptr(rgb), int(timestamp), C.byref(used), _stream()))
         return int(used.value)
+
+    def prepare(self, depth, rgb, timestamp):
+        """first half of update(): bilateral filter + pyramids of the next frame (may run ahead on another stream)"""
+        used = C.c_int32(0)
+        check(lib().svoslam_camera_prepare(self._h, _ptr(depth), _ptr(rgb), int(timestamp), C.byref(used), _stream()))
+        return int(used.value)
+
+    def track_prepared(self):
+        """second half of update(): pose of the oldest prepared frame"""
+        check(lib().svoslam_camera_track(self._h, _stream()))
 
     # multi-GPU stepping (all-reduce between accumulate and solve)
     def set_band(self, first_row, rows):

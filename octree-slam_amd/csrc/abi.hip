@@ -285,6 +285,11 @@ int svoslam_camera_update(svoslam_camera *cam, const uint16_t *d_depth, const ui
                           int32_t *processed, void *stream) {
   return camera_update(cam, d_depth, d_rgb, timestamp, processed, S(stream));
 }
+int svoslam_camera_prepare(svoslam_camera *cam, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp,
+                           int32_t *processed, void *stream) {
+  return camera_prepare(cam, d_depth, d_rgb, timestamp, processed, S(stream));
+}
+int svoslam_camera_track(svoslam_camera *cam, void *stream) { return camera_track(cam, S(stream)); }
 int svoslam_camera_begin(svoslam_camera *cam, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp,
                          int32_t *processed, void *stream) {
   return camera_begin(cam, d_depth, d_rgb, timestamp, processed, S(stream));

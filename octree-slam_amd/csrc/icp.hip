@@ -49,6 +49,7 @@ struct CamState {
   float fusion_ring[4][16];  // fusion transform of the last 4 frames (slot = frame sequence & 3): lets the
                              // mapping stream read frame k's pose while the tracking stream is on frame k+1
   float lastA[36], lastb[6], lastx[6];
+  int frames_done;          // frames whose pose is final; the next frame's pose goes to fusion_ring[frames_done & 3]
   int lost;                 // NaN seen at this pyramid level (rgbd_camera.cpp:148-151)
   int tracking_lost_count;  // levels abandoned so far
 };
@@ -56,7 +57,7 @@ struct CamState {
 // ----------------------------------------------------------------------------
 // accumulate
 // ----------------------------------------------------------------------------
-constexpr int kIcpThreads = 512;   // 8 wavefronts per workgroup, one workgroup per CU (108 KB of LDS)
+constexpr int kIcpThreads = 512;   // 8 wavefronts per workgroup
 constexpr int kIcpWaves = kIcpThreads / kWave;
 constexpr int kMaxIcpBlocks = 256;
 
@@ -66,14 +67,35 @@ constexpr int kFlagFirstIter = 2;   // iteration 0 of its level
 constexpr int kFlagFirstOfFrame = 4;
 constexpr int kFlagLastOfFrame = 8;
 
-// Body shared by the two accumulate kernels.  sm = [27][threads] transpose buffer: the cross-lane
-// reduction of 27 values per lane is done by re-reading columns lane-contiguously (conflict-free
-// ds_read_b64) and shuffling ONE value per column per wavefront, instead of 27 x 6 ds_bpermute
-// rounds per lane (LDS-issue bound).
+// Sum of a double over the 64 lanes of a wavefront with DPP moves only (VALU; no LDS traffic):
+// row_shr 1,2,4,8 leave each 16-lane row's sum in its last lane, row_bcast15 / row_bcast31 carry
+// them on; the total ends up in lane 63.  Every addend is an integer-valued double, so the order
+// of the additions does not matter (exact).
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_add(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int slo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, true);
+  const int shi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, true);
+  return v + __hiloint2double(shi, slo);
+}
+__device__ inline double wave_sum_to_lane63(double v) {
+  v = dpp_add<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xF>(v);  // row_shr:8
+  v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+// Body of the accumulate kernel.  The 27 sums of a lane are reduced across the wavefront in registers
+// (DPP) and across the 8 wavefronts through a 1.7 KB LDS array.  (Earlier forms: 27 x 6 ds_bpermute
+// shuffles per lane were LDS-issue bound; a [27][512] LDS transpose was fast but its 108 KB kept the
+// kernel off every CU that still held raycast workgroups with their 48 KB tables.)
 __device__ inline void accumulate_block(const float *__restrict__ last_v, const float *__restrict__ last_n,
                                         const float *__restrict__ cur_v, const float *__restrict__ cur_n, int first, int end,
                                         const CamState *state, int flags, int chain_len, double *__restrict__ partial,
-                                        double (*sm)[kIcpThreads], float *chain_s) {
+                                        double (*wsum)[27], float *chain_s) {
   int nchain = 0;
   bool lost = false;
   if (state) {
@@ -142,17 +164,18 @@ __device__ inline void accumulate_block(const float *__restrict__ last_v, const 
   // workgroup -> one 27-double row; every partial is an integer-valued double (exact, order-free).
   // Plain stores only: the rows are summed in the NEXT launch, so visibility rests on the kernel
   // boundary alone (no cross-XCD atomics on data).
-#pragma unroll
-  for (int i = 0; i < 27; i++) sm[i][threadIdx.x] = acc[i];
-  __syncthreads();
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  for (int c = (int)wave; c < 27; c += kIcpWaves) {
+#pragma unroll
+  for (int i = 0; i < 27; i++) {
+    const double t = wave_sum_to_lane63(acc[i]);
+    if (lane == 63u) wsum[wave][i] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
     double v = 0.0;
 #pragma unroll
-    for (int j = 0; j < kIcpThreads / kWave; j++) v += sm[c][lane + kWave * j];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    if (lane == 0) partial[(size_t)blockIdx.x * 27 + c] = v;
+    for (int w = 0; w < kIcpWaves; w++) v += wsum[w][threadIdx.x];
+    partial[(size_t)blockIdx.x * 27 + threadIdx.x] = v;
   }
 }
 
@@ -160,9 +183,9 @@ __global__ __launch_bounds__(kIcpThreads) void icp_accumulate_kernel(
     const float *__restrict__ last_v, const float *__restrict__ last_n, const float *__restrict__ cur_v,
     const float *__restrict__ cur_n, int first, int end, const CamState *__restrict__ state, int flags, int chain_len,
     double *__restrict__ partial) {
-  __shared__ double sm[27][kIcpThreads];
+  __shared__ double wsum[kIcpWaves][27];
   __shared__ float chain_s[(kMaxChain + 1) * 16];
-  accumulate_block(last_v, last_n, cur_v, cur_n, first, end, state, flags, chain_len, partial, sm, chain_s);
+  accumulate_block(last_v, last_n, cur_v, cur_n, first, end, state, flags, chain_len, partial, wsum, chain_s);
 }
 
 // column sums of partial[rows][27] into LDS totals[27] (exact integer-valued sums);
@@ -396,7 +419,8 @@ __device__ inline void solve_step(CamState *st, const double *sums, int slot) {
 }
 
 // :172-173 pose update (Q17: row-vector products) and the fusion transform of main.cpp:40
-__device__ inline void frame_end_step(CamState *st, int apply_update, int slot) {
+__device__ inline void frame_end_step(CamState *st, int apply_update) {
+  const int slot = st->frames_done;  // kept on the device so that the recorded launch sequence is the same for every frame
   if (apply_update) {
     const float *m = st->update_trans;
     const float v[4] = {st->position[0], st->position[1], st->position[2], 1.0f};
@@ -419,6 +443,7 @@ __device__ inline void frame_end_step(CamState *st, int apply_update, int slot) 
   d_translate(I, st->position, t);
   d_mat4_mul(o4, t, st->fusion);
   for (int i = 0; i < 16; i++) st->fusion_ring[slot & 3][i] = st->fusion[i];
+  st->frames_done = slot + 1;
 }
 
 __device__ inline void level_begin_step(CamState *st, int flags) {
@@ -431,18 +456,18 @@ __device__ inline void level_begin_step(CamState *st, int flags) {
 
 // single-GPU iteration tail: sum the workgroup rows, solve, compose -- ONE launch
 __global__ __launch_bounds__(kReduceThreads) void cam_reduce_solve_kernel(CamState *st, const double *__restrict__ partial,
-                                                                          int rows, int slot, int flags, int ring_slot) {
+                                                                          int rows, int slot, int flags) {
   __shared__ double red[kReduceThreads / 32][27];
   __shared__ double totals[27];
   reduce_rows(partial, rows, red, totals);
   if (threadIdx.x != 0) return;
   level_begin_step(st, flags);
   if (!st->lost) solve_step(st, totals, slot);
-  if (flags & kFlagLastOfFrame) frame_end_step(st, 1, ring_slot);
+  if (flags & kFlagLastOfFrame) frame_end_step(st, 1);
 }
 
 // multi-GPU iteration tail: acc[] holds the all-reduced sums
-__global__ void cam_solve_kernel(CamState *st, double *acc, int slot, int flags, int ring_slot) {
+__global__ void cam_solve_kernel(CamState *st, double *acc, int slot, int flags) {
   // Read-and-reset, one element per LANE.  (A single thread doing "sums[i] = acc[i]; acc[i] = 0" gets
   // uniform-address SCALAR loads followed by vector stores of a constant: nothing orders the two memory
   // paths, and the zero was observed to overtake the load -- six of the 27 sums read back as 0 once in a
@@ -457,12 +482,12 @@ __global__ void cam_solve_kernel(CamState *st, double *acc, int slot, int flags,
   if (threadIdx.x) return;
   level_begin_step(st, flags);
   if (!st->lost) solve_step(st, sums, slot);
-  if (flags & kFlagLastOfFrame) frame_end_step(st, 1, ring_slot);
+  if (flags & kFlagLastOfFrame) frame_end_step(st, 1);
 }
 
-__global__ void cam_frame_end_kernel(CamState *st, int apply_update, int ring_slot) {
+__global__ void cam_frame_end_kernel(CamState *st, int apply_update) {
   if (threadIdx.x || blockIdx.x) return;
-  frame_end_step(st, apply_update, ring_slot);
+  frame_end_step(st, apply_update);
 }
 
 }  // namespace svoslam
@@ -475,21 +500,22 @@ using svoslam::CamState;
 struct svoslam_camera {
   int width = 0, height = 0;
   float fx = 0, fy = 0;
-  int pass = 0;  // rgbd_camera.h:75 (caps at 2)
   bool have_stamp = false;
   long long latest_stamp = 0;
   int band_first = 0, band_rows = 0;
   uint16_t *filt[3] = {nullptr, nullptr, nullptr};
-  float *vert[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-  float *norm[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-  int cur = 0;  // index of the "current" set; the other is "last"
+  // pyramid maps of frame f live in set f % 3: the tracker reads sets f and f-1 while the maps of frame f+1
+  // can already be generated on another stream (rgbd_camera.cpp:181-189 swaps two sets)
+  float *vert[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  float *norm[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  unsigned prepared = 0;  // frames whose maps have been generated
+  unsigned tracked = 0;   // frames whose pose has been estimated (rgbd_camera.h:75 `pass` saturates this at 2)
   CamState *d_state = nullptr;
   double *d_acc = nullptr;  // defaults to d_state->acc; may be redirected for multi-GPU all-reduce
   double *d_partial = nullptr;  // per-workgroup rows of the accumulate kernel
   bool frame_has_icp = false;
-  unsigned frame_seq = 0;  // processed frames so far
-  int ring_slot = 0;       // fusion_ring slot of the frame being / last processed
-  svoslam::GraphCache graphs;  // recorded launch sequences of camera_update (graph_cache.hpp)
+  int ring_slot = 0;       // fusion_ring slot of the frame being / last tracked
+  svoslam::GraphCache g_prep, g_track;  // recorded launch sequences (graph_cache.hpp)
 };
 
 namespace svoslam {
@@ -507,7 +533,7 @@ int camera_create(svoslam_camera **out, int w, int h, float fx, float fy) {
   for (int i = 0; i < 3; i++) {
     const size_t n = (size_t)(w >> i) * (size_t)(h >> i);
     SVO_HIP(hipMalloc((void **)&c->filt[i], n * 2));
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < 3; s++) {
       SVO_HIP(hipMalloc((void **)&c->vert[s][i], n * 12));
       SVO_HIP(hipMalloc((void **)&c->norm[s][i], n * 12));
     }
@@ -531,7 +557,7 @@ int camera_destroy(svoslam_camera *c) {
   if (!c) return SVOSLAM_OK;
   for (int i = 0; i < 3; i++) {
     if (c->filt[i]) (void)hipFree(c->filt[i]);
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < 3; s++) {
       if (c->vert[s][i]) (void)hipFree(c->vert[s][i]);
       if (c->norm[s][i]) (void)hipFree(c->norm[s][i]);
     }
@@ -542,33 +568,50 @@ int camera_destroy(svoslam_camera *c) {
   return SVOSLAM_OK;
 }
 
-// bilateral filter + the three pyramid levels of the incoming frame (rgbd_camera.cpp:62-93)
-static int enqueue_preprocess(const svoslam_camera *c, const uint16_t *d_depth, hipStream_t s) {
+// bilateral filter + the three pyramid levels of the incoming frame (rgbd_camera.cpp:62-93) into map set `set`
+static int enqueue_preprocess(const svoslam_camera *c, const uint16_t *d_depth, int set, hipStream_t s) {
   const int W = c->width, H = c->height;
   SVO_TRY(bilateral_filter(d_depth, c->filt[0], W, H, s));  // :62-64
   for (int i = 0; i < 3; i++) {                             // :72-93
     const int w = W >> i, h = H >> i;
-    SVO_TRY(generate_vertex_normal_maps(c->filt[i], c->vert[c->cur][i], c->norm[c->cur][i], w, h, c->fx, c->fy, W, H, s));
+    SVO_TRY(generate_vertex_normal_maps(c->filt[i], c->vert[set][i], c->norm[set][i], w, h, c->fx, c->fy, W, H, s));
     if (i != 2) SVO_TRY(subsample_depth_u16_to(c->filt[i], c->filt[i + 1], w, h, s));
   }
   return SVOSLAM_OK;
 }
 
-int camera_begin(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp, int32_t *processed,
-                 hipStream_t s) {
+// Maps of the next frame.  Independent of the pose estimation of earlier frames, so it may run on
+// another stream while they are tracked -- the caller orders it after the camera_track of the frame
+// three before it (whose "last" set it overwrites) and before the camera_track of its own frame.
+int camera_prepare(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp, int32_t *processed,
+                   hipStream_t s) {
   (void)d_rgb;  // intensity only feeds the unimplemented RGB-D term (localization_kernels.cu:328-331)
   if (!c || !d_depth) return SVOSLAM_ERR_INVALID_ARG;
   if (c->have_stamp && timestamp <= c->latest_stamp) {  // :55-59
     if (processed) *processed = 0;
-    c->frame_has_icp = false;
     return SVOSLAM_OK;
   }
+  if (c->prepared - c->tracked >= 2) return SVOSLAM_ERR_INVALID_ARG;  // the third set still holds a frame to be tracked against
   c->have_stamp = true;
   c->latest_stamp = timestamp;
   if (processed) *processed = 1;
-  SVO_TRY(enqueue_preprocess(c, d_depth, s));
-  c->frame_has_icp = c->pass >= 1;
-  c->ring_slot = (int)(c->frame_seq++ & 3u);
+  const int set = (int)(c->prepared % 3u);
+  GraphKey key;
+  key.add(d_depth).add((unsigned long long)set);
+  SVO_TRY(c->g_prep.run(key, s, [&]() -> int { return enqueue_preprocess(c, d_depth, set, s); }));
+  c->prepared++;
+  return SVOSLAM_OK;
+}
+
+int camera_begin(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp, int32_t *processed,
+                 hipStream_t s) {
+  if (!c) return SVOSLAM_ERR_INVALID_ARG;
+  int32_t used = 0;
+  if (c->prepared != c->tracked) return SVOSLAM_ERR_INVALID_ARG;  // a prepared frame is waiting for camera_track
+  SVO_TRY(camera_prepare(c, d_depth, d_rgb, timestamp, &used, s));
+  if (processed) *processed = used;
+  c->frame_has_icp = used && c->tracked >= 1;
+  if (used) c->ring_slot = (int)(c->tracked & 3u);
   return SVOSLAM_OK;
 }
 
@@ -586,9 +629,9 @@ static LevelArgs level_args(const svoslam_camera *c, int level) {
   LevelArgs a;
   a.w = c->width >> level; a.h = c->height >> level;
   const int r0 = c->band_first >> level, r1 = (c->band_first + c->band_rows) >> level;
-  const int last = 1 - c->cur;
+  const int cur = (int)(c->tracked % 3u), last = (int)((c->tracked + 2u) % 3u);  // frames f and f-1
   a.lv = c->vert[last][level]; a.ln = c->norm[last][level];
-  a.cv = c->vert[c->cur][level]; a.cn = c->norm[c->cur][level];
+  a.cv = c->vert[cur][level]; a.cn = c->norm[cur][level];
   a.first = r0 * a.w; a.num = (r1 - r0) * a.w;
   return a;
 }
@@ -605,47 +648,36 @@ int camera_icp_accumulate(svoslam_camera *c, int level, int iter, hipStream_t s)
 int camera_icp_solve(svoslam_camera *c, int level, int iter, hipStream_t s) {
   if (!c || level < 0 || level > 2 || iter < 0 || iter >= kPyramidIters[level]) return SVOSLAM_ERR_INVALID_ARG;
   if (!c->frame_has_icp) return SVOSLAM_OK;
-  cam_solve_kernel<<<1, 64, 0, s>>>(c->d_state, c->d_acc, iter, iter_flags(level, iter), c->ring_slot);
+  cam_solve_kernel<<<1, 64, 0, s>>>(c->d_state, c->d_acc, iter, iter_flags(level, iter));
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
 }
 
 int camera_end(svoslam_camera *c, hipStream_t s) {
   if (!c) return SVOSLAM_ERR_INVALID_ARG;
+  if (c->tracked >= c->prepared) return SVOSLAM_ERR_INVALID_ARG;
   if (!c->frame_has_icp) {  // first frame: no ICP, only the fusion transform (the last solve did it otherwise)
-    cam_frame_end_kernel<<<1, 64, 0, s>>>(c->d_state, 0, c->ring_slot);
+    cam_frame_end_kernel<<<1, 64, 0, s>>>(c->d_state, 0);
     SVO_LAUNCH_CHECK();
   }
-  if (c->pass < 2) c->pass++;  // :176-178
-  c->cur = 1 - c->cur;         // swap current/last, :181-189
+  c->tracked++;  // "swap current/last", :176-189
   c->frame_has_icp = false;
   return SVOSLAM_OK;
 }
 
-// single-GPU frame: two launches per ICP iteration (accumulate; reduce + solve + compose).  A
-// single-launch variant (last-arriving workgroup reduces and solves behind an agent-scope
-// release/acquire) was measured 4 % slower end to end: the two fences cost what the kernel
-// boundary costs, so the simpler form stays.
-int camera_update(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp, int32_t *processed,
-                  hipStream_t s) {
-  (void)d_rgb;
-  if (!c || !d_depth) return SVOSLAM_ERR_INVALID_ARG;
-  if (c->have_stamp && timestamp <= c->latest_stamp) {  // :55-59
-    if (processed) *processed = 0;
-    c->frame_has_icp = false;
-    return SVOSLAM_OK;
-  }
-  c->have_stamp = true;
-  c->latest_stamp = timestamp;
-  if (processed) *processed = 1;
-  const bool has_icp = c->pass >= 1;
-  const int ring_slot = (int)(c->frame_seq & 3u);
-  // the ~50 launches of a frame depend only on these: recorded once per key, then replayed as one graph
+// Pose of the oldest prepared frame: two launches per ICP iteration (accumulate; reduce + solve +
+// compose), recorded once per map set and replayed as one graph.  A single-launch
+// variant (last-arriving workgroup reduces and solves behind an agent-scope release/acquire) was
+// measured 4 % slower end to end: the two fences cost what the kernel boundary costs.
+int camera_track(svoslam_camera *c, hipStream_t s) {
+  if (!c) return SVOSLAM_ERR_INVALID_ARG;
+  if (c->tracked >= c->prepared) return SVOSLAM_ERR_INVALID_ARG;  // nothing prepared
+  const bool has_icp = c->tracked >= 1;
+  const int ring_slot = (int)(c->tracked & 3u);
   GraphKey key;
-  key.add(d_depth).add((unsigned long long)c->cur).add((unsigned long long)ring_slot).add((unsigned long long)has_icp)
+  key.add((unsigned long long)(c->tracked % 3u)).add((unsigned long long)has_icp)
      .add((unsigned long long)c->band_first).add((unsigned long long)c->band_rows);
   auto enqueue = [&]() -> int {
-    SVO_TRY(enqueue_preprocess(c, d_depth, s));
     if (has_icp) {
       for (int level = 2; level >= 0; level--) {  // coarse to fine, :103
         LevelArgs a = level_args(c, level);
@@ -655,22 +687,32 @@ int camera_update(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_r
           const int flags = iter_flags(level, it);
           icp_accumulate_kernel<<<blocks, kIcpThreads, 0, s>>>(a.lv, a.ln, a.cv, a.cn, a.first, end, c->d_state, flags, it,
                                                                c->d_partial);
-          cam_reduce_solve_kernel<<<1, kReduceThreads, 0, s>>>(c->d_state, c->d_partial, blocks, it, flags, ring_slot);
+          cam_reduce_solve_kernel<<<1, kReduceThreads, 0, s>>>(c->d_state, c->d_partial, blocks, it, flags);
         }
       }
     } else {  // first frame: no ICP, only the fusion transform (the last solve does it otherwise)
-      cam_frame_end_kernel<<<1, 64, 0, s>>>(c->d_state, 0, ring_slot);
+      cam_frame_end_kernel<<<1, 64, 0, s>>>(c->d_state, 0);
     }
     SVO_LAUNCH_CHECK();
     return SVOSLAM_OK;
   };
-  SVO_TRY(c->graphs.run(key, s, enqueue));
-  c->frame_seq++;
+  SVO_TRY(c->g_track.run(key, s, enqueue));
   c->ring_slot = ring_slot;
-  if (c->pass < 2) c->pass++;  // :176-178
-  c->cur = 1 - c->cur;         // swap current/last, :181-189
+  c->tracked++;
   c->frame_has_icp = false;
   return SVOSLAM_OK;
+}
+
+// RGBDCamera::update (rgbd_camera.cpp:53): maps, then pose, on one stream
+int camera_update(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp, int32_t *processed,
+                  hipStream_t s) {
+  if (!c) return SVOSLAM_ERR_INVALID_ARG;
+  if (c->prepared != c->tracked) return SVOSLAM_ERR_INVALID_ARG;  // a prepared frame is waiting for camera_track
+  int32_t used = 0;
+  SVO_TRY(camera_prepare(c, d_depth, d_rgb, timestamp, &used, s));
+  if (processed) *processed = used;
+  if (!used) return SVOSLAM_OK;
+  return camera_track(c, s);
 }
 
 int camera_set_band(svoslam_camera *c, int first_row, int rows) {
@@ -712,10 +754,10 @@ int camera_last_system(svoslam_camera *c, float A[36], float b[6], float x[6], h
 // frames have been started, so another stream may read it while the tracker runs ahead
 const float *camera_fusion_transform_device(svoslam_camera *c) { return c ? c->d_state->fusion_ring[c->ring_slot] : nullptr; }
 const float *camera_last_vertex(svoslam_camera *c, int level) {
-  return (c && level >= 0 && level < 3) ? c->vert[1 - c->cur][level] : nullptr;
+  return (c && level >= 0 && level < 3) ? c->vert[(c->tracked + 2u) % 3u][level] : nullptr;
 }
 const float *camera_last_normal(svoslam_camera *c, int level) {
-  return (c && level >= 0 && level < 3) ? c->norm[1 - c->cur][level] : nullptr;
+  return (c && level >= 0 && level < 3) ? c->norm[(c->tracked + 2u) % 3u][level] : nullptr;
 }
 int camera_tracking_lost_count(svoslam_camera *c, int *count, hipStream_t s) {
   if (!c || !count) return SVOSLAM_ERR_INVALID_ARG;

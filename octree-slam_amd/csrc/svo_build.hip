@@ -24,6 +24,7 @@
 //   fillNodes race on duplicate keys (:684)    lowest point index wins (stable sort)
 //   mipmapNodes: n redundant walks x D (:450)  owner lanes only, node indices saved
 //                                              by the fill walk
+#include <stdlib.h>
 #include <string.h>
 
 #include "radix_sort.hpp"
@@ -370,6 +371,106 @@ __global__ void mip_root_kernel(u32 *__restrict__ pool, const PlanCounts *__rest
   if (threadIdx.x == 0 && blockIdx.x == 0 && counts->any_valid) pool[1] = average_tile(pool, 0);
 }
 
+// ---- leaf blend + mip levels of the asynchronous commit in TWO launches ----------------------------
+// The reference (and the blocking path above) runs one launch per mip level because a level reads what
+// the level below wrote.  In the sorted key array the leaves under a node are a contiguous run that
+// starts at the node's owner lane, so a node whose run ends inside its owner's 256-lane workgroup has
+// ALL its touched descendants in that workgroup: the workgroup can finish it level by level behind
+// __syncthreads() (same-CU visibility).  Only a node whose run crosses the end of its owner's
+// workgroup -- at most one per workgroup and level -- is deferred to a second, single-workgroup launch
+// that handles those "straddlers" deepest level first.  Same values as the level-by-level passes.
+constexpr u32 kNoStraddler = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(256) void fill_mip_local_kernel(const u64 *__restrict__ skey, const u32 *__restrict__ sidx, int n,
+                                                             int depth, const unsigned char *__restrict__ leaf_t,
+                                                             const unsigned char *__restrict__ colors, u32 *__restrict__ pool,
+                                                             u32 *__restrict__ strad, int num_tiles) {
+  __shared__ int last_owner[SVOSLAM_MAX_DEPTH + 1];  // per level: last lane of this workgroup owning a node there
+  __shared__ int next_pos, next_c;                   // first head lane after this workgroup and its common-prefix length
+  const int tid = (int)threadIdx.x;
+  const int j = blockIdx.x * 256 + tid;
+  const bool head = j < n && leaf_t[j] != kNotHead;
+  u64 key = 1; int c = 0;
+  if (head) (void)is_head(skey, j, key, c, depth);
+  if (tid <= SVOSLAM_MAX_DEPTH) {
+    last_owner[tid] = -1;
+    if (tid >= 1 && tid < depth) {  // "no straddler" unless a lane says otherwise below
+      strad[2 * ((size_t)tid * num_tiles + blockIdx.x)] = kNoStraddler;
+      strad[2 * ((size_t)tid * num_tiles + blockIdx.x) + 1] = 0u;
+    }
+  }
+  if (tid == 0) next_pos = 0x7FFFFFFF;
+  __syncthreads();
+  if (head)
+    for (int d = c + 1; d < depth; d++) atomicMax(&last_owner[d], j);
+  for (int nb = (int)blockIdx.x + 1; nb < (int)gridDim.x; nb++) {  // normally one iteration
+    const int jj = nb * 256 + tid;
+    if (jj < n && leaf_t[jj] != kNotHead) atomicMin(&next_pos, jj);
+    __syncthreads();
+    const bool found = next_pos != 0x7FFFFFFF;
+    __syncthreads();  // every lane has read next_pos before anyone updates it again
+    if (found) break;
+  }
+  if (tid == 0) {
+    int c2 = -1;  // no later head: every run ends with the array
+    if (next_pos != 0x7FFFFFFF) { u64 k2; c2 = 0; (void)is_head(skey, next_pos, k2, c2, depth); }
+    next_c = c2;
+  }
+  // walk to the leaf (fillNodes, svo.cu:291-382), remembering the owned nodes and their child tiles
+  u32 node_at[SVOSLAM_MAX_DEPTH], child_at[SVOSLAM_MAX_DEPTH];
+#pragma unroll
+  for (int l = 0; l < SVOSLAM_MAX_DEPTH; l++) { node_at[l] = 0; child_at[l] = 0; }
+  if (head) {
+    u32 base = 0, node = 0;
+#pragma unroll
+    for (int lvl = 1; lvl <= SVOSLAM_MAX_DEPTH; lvl++) {
+      if (lvl <= depth) {
+        node = base + ((u32)(key >> (3 * (depth - lvl))) & 7u);
+        if (lvl < depth) {
+          base = pool[2 * (size_t)node] & kMask;
+          node_at[lvl] = node;
+          child_at[lvl] = base;
+        }
+      }
+    }
+    // duplicates: the head of a run of equal keys is the lowest point index (stable sort)
+    const unsigned char *v = colors + 3 * (size_t)sidx[j];
+    pool[2 * (size_t)node + 1] = blend_color256(pool[2 * (size_t)node + 1], v[0], v[1], v[2]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = SVOSLAM_MAX_DEPTH - 1; d >= 1; d--) {
+    if (d < depth) {
+      if (head && c < d) {  // this lane owns its level-d prefix
+        if (j != last_owner[d] || next_c < d) {
+          pool[2 * (size_t)node_at[d] + 1] = average_tile(pool, child_at[d]);
+        } else {  // the run continues in a later workgroup
+          strad[2 * ((size_t)d * num_tiles + blockIdx.x)] = node_at[d];
+          strad[2 * ((size_t)d * num_tiles + blockIdx.x) + 1] = child_at[d];
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// straddling nodes deepest level first, then the root quirk (Q6) and the device-side size
+__global__ __launch_bounds__(1024) void mip_straddle_kernel(u32 *__restrict__ pool, const u32 *__restrict__ strad, int num_tiles,
+                                                            int depth, const PlanCounts *__restrict__ counts,
+                                                            int *__restrict__ d_size) {
+  for (int d = depth - 1; d >= 1; d--) {
+    for (int t = (int)threadIdx.x; t < num_tiles; t += 1024) {
+      const u32 node = strad[2 * ((size_t)d * num_tiles + t)];
+      if (node != kNoStraddler) pool[2 * (size_t)node + 1] = average_tile(pool, strad[2 * ((size_t)d * num_tiles + t) + 1]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (counts->any_valid) pool[1] = average_tile(pool, 0);
+    *d_size += 8 * counts->total_records;
+  }
+}
+
 // ----------------------------------------------------------------------------
 // host driver
 // ----------------------------------------------------------------------------
@@ -695,16 +796,14 @@ int svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int n, int d
   const unsigned char *leaf_t = ws->leaf_t.as<unsigned char>();
   int split_blocks = (int)cdiv(rmax, 256);
   if (split_blocks > 2048) split_blocks = 2048;
-  u32 *path_nodes = ws->path_nodes.as<u32>();
+  SVO_TRY(ws->strad.reserve((size_t)(SVOSLAM_MAX_DEPTH + 1) * (size_t)tiles * 8));
+  u32 *strad = ws->strad.as<u32>();
   auto enqueue = [&]() -> int {
     split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
                                                        ws->rec_pass.as<unsigned char>(), small_bucket_base(ws), small_counts(ws),
                                                        pool->d_data, pool->d_size, depth);
-    pool_size_update_kernel<<<1, 64, 0, stream>>>(pool->d_size, small_counts(ws));
-    fill_kernel<false><<<tiles, 256, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, 0, pool->d_data, path_nodes);
-    for (int d = depth - 1; d >= 1; d--)
-      mip_level_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, d, leaf_t, path_nodes, pool->d_data);
-    mip_root_kernel<<<1, 64, 0, stream>>>(pool->d_data, small_counts(ws));
+    fill_mip_local_kernel<<<tiles, 256, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, tiles);
+    mip_straddle_kernel<<<1, 1024, 0, stream>>>(pool->d_data, strad, tiles, depth, small_counts(ws), pool->d_size);
     SVO_LAUNCH_CHECK();
     return SVOSLAM_OK;
   };

@@ -151,10 +151,11 @@ class SlamPipeline:
 
     # -- software-pipelined stream of frames ------------------------------------------------
     def run_stream(self, depths, rgbs, timestamps, views, on_render=None):
-        """Processes the frames in order on three HIP streams, every frame still going through
+        """Processes the frames in order on four HIP streams, every frame still going through
         track -> back-project -> fuse -> render with the results of frame():
 
-          T  tracker of frame k+1 (bilateral, pyramids, 19 ICP iterations); touches only the camera state
+          P  bilateral filter + vertex/normal pyramids of frame k+2 (three rotating map sets)
+          T  19 ICP iterations of frame k+1; touches only the camera state
           S  back-projection, keys + sort and split planning of frame k+1 (reads the pool's tree)
           M  commit of frame k (splits, leaf blend, mip levels -- the only writer of the pool), raycast of frame k
 
@@ -169,6 +170,7 @@ class SlamPipeline:
             return
         if not hasattr(self, "_s_track"):
             self._s_track, self._s_prep, self._s_map = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+            self._s_maps = torch.cuda.Stream()
             self._ws2 = [self.ws, pkg.Workspace()]
             self._points2 = [self.points, torch.empty_like(self.points)]
             # fixed input addresses per stream: the library replays its launch sequences as HIP graphs keyed
@@ -177,7 +179,7 @@ class SlamPipeline:
             self._in_prep = torch.empty_like(depths[0])
             self._in_rgb = torch.empty_like(rgbs[0])
         cur = torch.cuda.current_stream()
-        for st in (self._s_track, self._s_prep, self._s_map):
+        for st in (self._s_maps, self._s_track, self._s_prep, self._s_map):
             st.wait_stream(cur)
         ev_pose = [torch.cuda.Event() for _ in range(n)]
         ev_bp = [torch.cuda.Event() for _ in range(n)]
@@ -186,12 +188,29 @@ class SlamPipeline:
         fusion_ptr = [0] * n
         npts = self.w * self.h
 
+        four = not self.dist.enabled   # single GPU: the maps of a frame are built on their own stream, one frame ahead
+        ev_maps = [torch.cuda.Event() for _ in range(n)]
+
+        def enqueue_maps(i):
+            """bilateral filter + pyramids of frame i (no dependence on earlier poses)"""
+            with torch.cuda.stream(self._s_maps):
+                if i >= 2:
+                    self._s_maps.wait_event(ev_pose[i - 2])      # its map set was the "last" set of frame i-2
+                self._in_track.copy_(depths[i])
+                if not self.cam.prepare(self._in_track, rgbs[i], timestamps[i]):
+                    raise ValueError("run_stream needs strictly increasing timestamps")
+                ev_maps[i].record()
+
         def enqueue_track(i):
             with torch.cuda.stream(self._s_track):
                 if i >= 4:
                     self._s_track.wait_event(ev_bp[i - 4])       # ring slot i % 4 has been consumed
-                self._in_track.copy_(depths[i])
-                self.track(self._in_track, rgbs[i], timestamps[i])
+                if four:
+                    self._s_track.wait_event(ev_maps[i])
+                    self.cam.track_prepared()
+                else:
+                    self._in_track.copy_(depths[i])
+                    self.track(self._in_track, rgbs[i], timestamps[i])
                 fusion_ptr[i] = self.cam.fusion_transform_ptr()   # ring slot of frame i
                 ev_pose[i].record()
 
@@ -209,11 +228,17 @@ class SlamPipeline:
                 pkg.svo_fuse_plan(ws, npts, self.depth, self.pool)
                 ev_plan[i].record()
 
+        if four:
+            enqueue_maps(0)
         enqueue_track(0)
+        if four and n > 1:
+            enqueue_maps(1)
         enqueue_prepare(0)
         for i in range(n):
             if i + 1 < n:
                 enqueue_track(i + 1)
+            if four and i + 2 < n:
+                enqueue_maps(i + 2)
             with torch.cuda.stream(self._s_map):
                 self._s_map.wait_event(ev_plan[i])
                 self._in_rgb.copy_(rgbs[i])
@@ -227,7 +252,7 @@ class SlamPipeline:
                 self.render(views[i])
                 if on_render is not None:
                     on_render(i, self.image)
-        for st in (self._s_track, self._s_prep, self._s_map):
+        for st in (self._s_maps, self._s_track, self._s_prep, self._s_map):
             cur.wait_stream(st)
 
     def _backproject_with(self, depth, fusion_ptr):

@@ -4,6 +4,10 @@ import importlib.util
 import os
 import sys
 
+# pipeline.run_stream uses four HIP streams; with the runtime's default of 4 hardware queues two of them
+# would share a queue and run in order.  Only effective before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.join(ROOT, "octree-slam_amd")
 
