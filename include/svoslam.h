@@ -224,6 +224,11 @@ int svoslam_cone_trace_svo(uint8_t *d_pos, int32_t width, int32_t height, float 
 int svoslam_cone_trace_svo_band(uint8_t *d_pos, int32_t width, int32_t height, int32_t row_first, int32_t rows,
                                 float fov, const float view[16], const uint32_t *d_octree, const float center[3],
                                 float size, int32_t mode, unsigned long long *d_steps, void *stream);
+/* Measurement aid: while enabled, every cone-trace call brackets its trace kernel (not the small
+ * acceleration-structure build before it) with a pair of HIP events on the launch stream.
+ * _read waits for the logged launches, returns the summed kernel time and their number, and clears the log. */
+int svoslam_cone_trace_timing(int32_t enable);
+int svoslam_cone_trace_timing_read(float *h_ms_sum, int32_t *h_launches);
 
 /* ------------------------------------------------------------------------
  * Sensor image kernels (include/octree_slam/sensor/image_kernels.h:21-55,

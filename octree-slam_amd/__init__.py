@@ -106,6 +106,8 @@ SIGNATURES = {
     "svoslam_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "svoslam_cone_trace_svo": (C.c_int, [_vp, _i32, _i32, _f32, _fp, _vp, _fp, _f32, _i32, _vp, _vp]),
     "svoslam_cone_trace_svo_band": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _fp, _vp, _fp, _f32, _i32, _vp, _vp]),
+    "svoslam_cone_trace_timing": (C.c_int, [_i32]),
+    "svoslam_cone_trace_timing_read": (C.c_int, [_fp, C.POINTER(_i32)]),
     "svoslam_generate_vertex_map": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _f32, _i32, _i32, _vp]),
     "svoslam_generate_vertex_map_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _vp]),
     "svoslam_generate_normal_map": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
@@ -486,6 +488,18 @@ def cone_trace_svo_band(out, row_first, rows, fov, view, pool_ptr, center, size,
                                             C.c_void_p(int(pool_ptr)), _fa(center, 3), float(size), int(mode),
                                             _ptr(counters), _stream()))
     return out
+
+
+def cone_trace_timing(enable):
+    """HIP events around every trace kernel from now on (on its launch stream)"""
+    check(lib().svoslam_cone_trace_timing(1 if enable else 0))
+
+
+def cone_trace_timing_read():
+    """(summed kernel ms, launches) since the last read; blocking"""
+    ms, n = C.c_float(0), C.c_int32(0)
+    check(lib().svoslam_cone_trace_timing_read(C.byref(ms), C.byref(n)))
+    return float(ms.value), int(n.value)
 
 
 # ----------------------------------------------------------------------------- sensor

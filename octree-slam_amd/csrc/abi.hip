@@ -196,6 +196,14 @@ int svoslam_cone_trace_svo_band(uint8_t *d_pos, int32_t width, int32_t height, i
   return cone_trace_svo(d_pos, width, height, row_first, rows, fov, view, d_octree, center, size, mode, d_steps, S(stream));
 }
 
+int svoslam_cone_trace_timing(int32_t enable) { return cone_trace_timing(enable); }
+int svoslam_cone_trace_timing_read(float *h_ms_sum, int32_t *h_launches) {
+  int n = 0;
+  const int rc = cone_trace_timing_read(h_ms_sum, &n);
+  if (h_launches) *h_launches = n;
+  return rc;
+}
+
 int svoslam_generate_vertex_map(const uint16_t *d_depth, float *d_vertex, int32_t width, int32_t height, float fx, float fy,
                                 int32_t img_w, int32_t img_h, void *stream) {
   NEED_DEVICE();

@@ -20,6 +20,7 @@
 //      where the reference's walk stops and the colour word it ends on ("level-6 grid");
 //  (3) the per-step arithmetic is one division and one square root (see step_lod / loop notes).
 #include <cstring>
+#include <vector>
 
 #include "cone_trace.hpp"
 #include "workspace.hpp"
@@ -430,6 +431,43 @@ __global__ __launch_bounds__(kTraceThreads) void cone_trace_kernel(uchar4 *__res
   }
 }
 
+// ---- optional HIP-event timing of the trace kernel alone (bench.py roofline) ----
+static bool g_timing = false;
+static std::vector<hipEvent_t> g_ev;  // pairs (start, stop), one per traced launch since the last read
+static size_t g_ev_used = 0;
+
+int cone_trace_timing(int enable) {
+  g_timing = enable != 0;
+  g_ev_used = 0;
+  return SVOSLAM_OK;
+}
+
+int cone_trace_timing_read(float *ms_sum, int *launches) {
+  if (!ms_sum || !launches) return SVOSLAM_ERR_INVALID_ARG;
+  float total = 0.0f;
+  for (size_t i = 0; i + 1 < g_ev_used; i += 2) {
+    SVO_HIP(hipEventSynchronize(g_ev[i + 1]));
+    float ms = 0.0f;
+    SVO_HIP(hipEventElapsedTime(&ms, g_ev[i], g_ev[i + 1]));
+    total += ms;
+  }
+  *ms_sum = total;
+  *launches = (int)(g_ev_used / 2);
+  g_ev_used = 0;
+  return SVOSLAM_OK;
+}
+
+static int timing_event(hipStream_t stream) {
+  if (!g_timing) return SVOSLAM_OK;
+  if (g_ev_used == g_ev.size()) {
+    hipEvent_t e;
+    SVO_HIP(hipEventCreate(&e));
+    g_ev.push_back(e);
+  }
+  SVO_HIP(hipEventRecord(g_ev[g_ev_used++], stream));
+  return SVOSLAM_OK;
+}
+
 // ---- host side: glm::inverse(view) products of :161-167, pix_scale of :171 ----
 static void mat4_inverse_host(const float *m, float *out);  // below
 
@@ -478,10 +516,12 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   float *d_table = reinterpret_cast<float *>(d_grid + kGridEntries);
   float *alpha_lut = d_table + 3 * (kTabStride + kLdsStride);
   build_accel_kernel<<<cdiv(kGridEntries + 3 * (kTabStride + kLdsStride) + 256, 256), 256, 0, stream>>>(d_octree, d_grid, d_table, alpha_lut, P);
+  SVO_TRY(timing_event(stream));
   if ((mode & 0xFF) == SVOSLAM_RENDER_CARRY)
     cone_trace_kernel<true><<<grid, kTraceThreads, 0, stream>>>(reinterpret_cast<uchar4 *>(d_pos), d_octree, d_grid, d_table, alpha_lut, P, d_steps);
   else
     cone_trace_kernel<false><<<grid, kTraceThreads, 0, stream>>>(reinterpret_cast<uchar4 *>(d_pos), d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+  SVO_TRY(timing_event(stream));
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
 }
