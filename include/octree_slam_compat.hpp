@@ -168,6 +168,40 @@ inline void computeICPCost2(const ICPFrame *last_frame, const ICPFrame &this_fra
 }
 }  // namespace sensor
 
+
+// common_types.h:20-38 (host arrays; non-indexed triangles as Scene::loadObjFile fills them)
+struct Mesh {
+  int vbosize = 0, nbosize = 0, cbosize = 0, ibosize = 0, tbosize = 0;
+  float *vbo = nullptr, *nbo = nullptr, *cbo = nullptr;
+  int *ibo = nullptr;
+  float *tbo = nullptr;
+  BoundingBox bbox;
+};
+struct bmp_texture { vec3 *data; int width, height; };
+
+namespace voxelization {
+// voxelization.h:16-17 / voxelization.cu:24-25
+inline int log_N() { return 8; }
+inline int log_T() { return 3; }
+// voxelization.h:21 / voxelization.cu:381-405
+inline void meshToVoxelGrid(const Mesh &m_in, const bmp_texture *tex, VoxelGrid &grid_out) {
+  svoslam_mesh m;
+  m.vbo = m_in.vbo; m.tbo = m_in.tbo; m.n_tris = m_in.vbosize / 9; m.tbosize = m_in.tbosize;
+  m.bbox0[0] = m_in.bbox.bbox0.x; m.bbox0[1] = m_in.bbox.bbox0.y; m.bbox0[2] = m_in.bbox.bbox0.z;
+  m.bbox1[0] = m_in.bbox.bbox1.x; m.bbox1[1] = m_in.bbox.bbox1.y; m.bbox1[2] = m_in.bbox.bbox1.z;
+  svoslam_texture t{nullptr, 0, 0};
+  if (tex) { t.data = &tex->data->x; t.width = tex->width; t.height = tex->height; }
+  float *ce = nullptr, *co = nullptr, scale = 0.0f;
+  int32_t n = 0;
+  detail::check(svoslam_mesh_to_voxel_grid(detail::Registry::get().workspace(), &m, tex ? &t : nullptr, log_N(), log_T(), &ce, &co,
+                                           nullptr, &n, &scale, nullptr), "meshToVoxelGrid");
+  grid_out.centers = reinterpret_cast<vec4 *>(ce);
+  grid_out.colors = reinterpret_cast<vec4 *>(co);
+  grid_out.size = n;
+  grid_out.scale = scale;
+  grid_out.bbox = m_in.bbox;
+}
+}  // namespace voxelization
 // timing_utils.h:5-10
 inline void startTiming() { detail::check(svoslam_timer_start(nullptr), "startTiming"); }
 inline float stopTiming() { float ms = 0; detail::check(svoslam_timer_stop(nullptr, &ms), "stopTiming"); return ms; }

@@ -174,6 +174,7 @@ void fuse_and_render(const vec3* d_points, const Color256* d_colors, int n, ucha
   VoxelGrid grid; svo::extractVoxelGridFromSVO(pool, pool_size, 12, vec3{0, 1.5f, 0}, 4.096f, grid);
   sensor::ICPFrame a(8, 8), b(8, 8); float A[36], bb[6]; sensor::computeICPCost2(&a, b, A, bb);
   startTiming(); (void)stopTiming();
+  Mesh m; VoxelGrid vg; voxelization::meshToVoxelGrid(m, nullptr, vg); (void)voxelization::log_N();
 }
 int main() {
   try { fuse_and_render(nullptr, nullptr, 0, nullptr); } catch (const std::exception& e) { return 0; }
