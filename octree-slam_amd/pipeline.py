@@ -19,6 +19,8 @@ and transforms its band of points and the bands are all-gathered, after which
 every rank applies the same fusion to its full replica of the node pool (replicas
 stay byte-identical); each rank ray-marches its band of the output image.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -193,6 +195,9 @@ class SlamPipeline:
 
         def enqueue_maps(i):
             """bilateral filter + pyramids of frame i (no dependence on earlier poses)"""
+            if os.environ.get("SVOSLAM_EXPERIMENT_NO_TRACK"):
+                ev_maps[i].record()
+                return
             with torch.cuda.stream(self._s_maps):
                 if i >= 2:
                     self._s_maps.wait_event(ev_pose[i - 2])      # its map set was the "last" set of frame i-2
@@ -207,7 +212,8 @@ class SlamPipeline:
                     self._s_track.wait_event(ev_bp[i - 4])       # ring slot i % 4 has been consumed
                 if four:
                     self._s_track.wait_event(ev_maps[i])
-                    self.cam.track_prepared()
+                    if not os.environ.get("SVOSLAM_EXPERIMENT_NO_TRACK"):
+                        self.cam.track_prepared()
                 else:
                     self._in_track.copy_(depths[i])
                     self.track(self._in_track, rgbs[i], timestamps[i])

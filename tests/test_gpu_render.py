@@ -19,14 +19,15 @@ def env():
     return svoslam_pkg.load(), torch
 
 
-def build_pool(pkg, torch, oracle, depth, frames, n=20000, seed=3, edge=1.0):
+def build_pool(pkg, torch, oracle, depth, frames, n=20000, seed=3, edge=1.0, center=(0, 0, 0), scale=1.0):
     rng = np.random.default_rng(seed)
     ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
     pts, col = surface_cloud(rng, n)
+    pts = (pts * np.float32(scale) + np.asarray(center, np.float32)).astype(np.float32)
     for _ in range(frames):
         tp, tc = torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda()
-        pkg.svo_from_point_cloud(ws, tp, tc, depth, pool, (0, 0, 0), edge)
-        opool.insert_cloud(pts, col, depth, (0, 0, 0), edge)
+        pkg.svo_from_point_cloud(ws, tp, tc, depth, pool, center, edge)
+        opool.insert_cloud(pts, col, depth, center, edge)
     return ws, pool, opool
 
 
@@ -84,3 +85,44 @@ def test_render_640x480_matches_oracle(env, oracle):
     ws, pool, opool = build_pool(pkg, torch, oracle, 9, 2, n=60000)
     view = oracle.look_at((0.2, 0.3, -2.2), (0, 0, 0), (0, 1, 0))
     render_both(pkg, torch, oracle, pool, opool.words(), 640, 480, view, (0, 0, 0), 1.0, 1)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_render_depth16_close_range_and_odd_geometry(env, oracle, mode):
+    """depth-16 pool, root centre / half-edge that are not dyadic, cameras a few centimetres from the surface:
+    the LOD depth exceeds 12, so the walk leaves the LDS split-plane table for the fine (global) one"""
+    pkg, torch = env
+    center, edge = (0.37, -0.21, 0.11), 0.873
+    ws, pool, opool = build_pool(pkg, torch, oracle, 16, 2, n=15000, edge=edge, center=center, scale=0.8)
+    words = opool.words()
+    c = np.asarray(center)
+    for eye, tgt, (w, h) in (((0.0, 0.0, 0.22), (0.0, 0.0, 0.0), (160, 400)), ((0.3, 0.1, 0.5), (0.2, -0.1, 0.1), (64, 48)),
+                             ((0.1, 0.2, -2.0), (0, 0, 0), (80, 60))):
+        view = oracle.look_at(tuple(np.asarray(eye) * 0.8 + c), tuple(np.asarray(tgt) * 0.8 + c), (0, 1, 0))
+        render_both(pkg, torch, oracle, pool, words, w, h, view, center, edge, mode)
+
+
+def test_render_far_from_origin_falls_back_to_the_chain(env, oracle):
+    """root cube far from the origin: its split planes are closer together than one float ulp of the coordinates,
+    the sorted-table bracket cannot be confirmed and the lanes take the reference's own comparison chain"""
+    pkg, torch = env
+    center, edge = (1000.25, 3.5, -777.125), 0.75
+    ws, pool, opool = build_pool(pkg, torch, oracle, 12, 2, n=8000, edge=edge, center=center, scale=0.6)
+    c = np.asarray(center)
+    for eye, tgt in (((0.1, 0.2, -1.4), (0, 0, 0)), ((0.05, 0.0, 0.3), (0.3, 0.1, 0.2))):
+        view = oracle.look_at(tuple(np.asarray(eye) + c), tuple(np.asarray(tgt) + c), (0, 1, 0))
+        render_both(pkg, torch, oracle, pool, opool.words(), 72, 54, view, center, edge, 0)
+
+
+def test_cone_trace_timing_log(env, oracle):
+    pkg, torch = env
+    ws, pool, opool = build_pool(pkg, torch, oracle, 6, 1, n=4000)
+    img = torch.zeros((30, 40, 4), dtype=torch.uint8, device="cuda")
+    view = oracle.look_at((0.1, 0.2, -2.6), (0, 0, 0), (0, 1, 0))
+    pkg.cone_trace_timing(True)
+    for _ in range(3):
+        pkg.cone_trace_svo(img, 45.0, view, pool.data_ptr, (0, 0, 0), 1.0)
+    ms, n = pkg.cone_trace_timing_read()
+    pkg.cone_trace_timing(False)
+    assert n == 3 and 0.0 < ms < 100.0
+    assert pkg.cone_trace_timing_read() == (0.0, 0)
