@@ -195,9 +195,6 @@ class SlamPipeline:
 
         def enqueue_maps(i):
             """bilateral filter + pyramids of frame i (no dependence on earlier poses)"""
-            if os.environ.get("SVOSLAM_EXPERIMENT_NO_TRACK"):
-                ev_maps[i].record()
-                return
             with torch.cuda.stream(self._s_maps):
                 if i >= 2:
                     self._s_maps.wait_event(ev_pose[i - 2])      # its map set was the "last" set of frame i-2
@@ -212,8 +209,7 @@ class SlamPipeline:
                     self._s_track.wait_event(ev_bp[i - 4])       # ring slot i % 4 has been consumed
                 if four:
                     self._s_track.wait_event(ev_maps[i])
-                    if not os.environ.get("SVOSLAM_EXPERIMENT_NO_TRACK"):
-                        self.cam.track_prepared()
+                    self.cam.track_prepared()
                 else:
                     self._in_track.copy_(depths[i])
                     self.track(self._in_track, rgbs[i], timestamps[i])
