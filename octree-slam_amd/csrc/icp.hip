@@ -418,6 +418,109 @@ __device__ inline void solve_step(CamState *st, const double *sums, int slot) {
     for (int i = 0; i < 16; i++) st->chain[slot][i] = this_trans[i];
 }
 
+// ---- the same iteration tail spread over ONE wavefront ---------------------------------------------
+// solveCholesky is a chain of 6 square roots and 27 divisions in binary64 (software sequences of ~30
+// dependent instructions each): executed by one lane it costs ~5 us per ICP iteration, 19 times a frame.
+// Here lane i (< 6) owns row i of A / LU: the 5 quotients of a column, and everything else that is
+// independent in the reference's loops, run side by side; single values travel with v_readlane (the
+// source lanes are compile-time constants).  Every value is produced by the reference's expression
+// with its operand order (float products, double running sums, one rounding to float), so the bits
+// are those of d_solve_cholesky.
+__device__ inline float lane_bcast(float v, int src_lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+// must be called by all 64 lanes of a wavefront; sums = 27 doubles at a uniform address; x[6] on every lane
+__device__ inline void wave_solve_cholesky(const double *sums, float *x, float &a_elem, float &b_elem) {
+  const int lane = (int)(threadIdx.x & 63u);
+  const int row = lane < 6 ? lane : 5;  // spare lanes shadow row 5
+  // A is symmetric, sums hold its upper triangle row by row: index of (i <= j) = i*6 - i*(i-1)/2 + (j - i)
+  float a[6], lu[6], diag[6];
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    const int i = row < c ? row : c, j = row < c ? c : row;
+    a[c] = (float)(sums[i * 6 - (i * (i - 1)) / 2 + (j - i)] * (1.0 / kScaleA));
+    lu[c] = 0.0f;
+  }
+  const float b_own = (float)(sums[21 + row] * (1.0 / kScaleB));
+  {  // element `lane` of the row-major A (for the diagnostics copy), b likewise
+    const int e = lane < 36 ? lane : 35, r = e / 6, c = e % 6;
+    const int i = r < c ? r : c, j = r < c ? c : r;
+    a_elem = (float)(sums[i * 6 - (i * (i - 1)) / 2 + (j - i)] * (1.0 / kScaleA));
+    b_elem = b_own;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) {  // rgbd_camera.cpp:198-209
+    float rk[6];
+#pragma unroll
+    for (int p = 0; p < 6; p++) rk[p] = p < k ? lane_bcast(lu[p], k) : 0.0f;
+    double sum = 0.;
+#pragma unroll
+    for (int p = 0; p < 6; p++) if (p < k) sum += lu[p] * lu[p];
+    const float d_own = (float)sqrt(a[k] - sum);  // right on lane k
+    diag[k] = lane_bcast(d_own, k);
+    double sum2 = 0.;
+#pragma unroll
+    for (int p = 0; p < 6; p++) if (p < k) sum2 += lu[p] * rk[p];
+    const float v = (float)((a[k] - sum2) / diag[k]);  // right on lanes > k
+    lu[k] = lane == k ? diag[k] : (lane > k ? v : 0.0f);
+  }
+  float y[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {  // :210-215, row i on lane i
+    double sum = 0.;
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (k < i) sum += lu[k] * y[k];
+    const float cand = (float)((b_own - sum) / diag[i]);
+    y[i] = lane_bcast(cand, i);
+  }
+  float lt[6];  // column `lane` of LU: lt[k] = LU[k][lane]
+#pragma unroll
+  for (int k = 0; k < 6; k++) lt[k] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 6; c++)
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (k > c) { const float t = lane_bcast(lu[c], k); lt[k] = lane == c ? t : lt[k]; }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {  // :216-221, column i on lane i
+    double sum = 0.;
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (k > i) sum += lt[k] * x[k];
+    const float cand = (float)((y[i] - sum) / diag[i]);
+    x[i] = lane_bcast(cand, i);
+  }
+}
+
+// wave form of solve_step; all 64 lanes of one wavefront call it
+__device__ inline void solve_step_wave(CamState *st, const double *sums, int slot) {
+  const int lane = (int)(threadIdx.x & 63u);
+  float x[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, a_elem, b_elem;
+  wave_solve_cholesky(sums, x, a_elem, b_elem);
+  if (lane < 36) st->lastA[lane] = a_elem;
+  if (lane < 6) { st->lastb[lane] = b_elem; st->lastx[lane] = x[lane < 6 ? lane : 0]; }
+  if (lane != 0) return;
+  if (x[0] != x[0] || x[1] != x[1] || x[2] != x[2] || x[3] != x[3] || x[4] != x[4] || x[5] != x[5]) {
+    st->lost = 1;  // "Camera tracking is lost." -> abandon this level (:148-151)
+    st->tracking_lost_count++;
+    return;
+  }
+  // this_trans = Rz(-x2) * Ry(-x1) * Rx(-x0) * T(x3,x4,x5), glm degrees API (:154-158)
+  float I[16], rz[16], ry[16], rx[16], tr[16], t1[16], t2[16], this_trans[16];
+  d_identity(I);
+  d_rotate_deg(I, -x[2] * 180.0f / 3.14159f, 0.0f, 0.0f, 1.0f, rz);
+  d_rotate_deg(I, -x[1] * 180.0f / 3.14159f, 0.0f, 1.0f, 0.0f, ry);
+  d_rotate_deg(I, -x[0] * 180.0f / 3.14159f, 1.0f, 0.0f, 0.0f, rx);
+  const float tv[3] = {x[3], x[4], x[5]};
+  d_translate(I, tv, tr);
+  d_mat4_mul(rz, ry, t1);
+  d_mat4_mul(t1, rx, t2);
+  d_mat4_mul(t2, tr, this_trans);
+  d_mat4_mul(this_trans, st->update_trans, st->update_trans);  // :160
+  if (slot < kMaxChain)
+    for (int i = 0; i < 16; i++) st->chain[slot][i] = this_trans[i];
+}
+
 // :172-173 pose update (Q17: row-vector products) and the fusion transform of main.cpp:40
 __device__ inline void frame_end_step(CamState *st, int apply_update) {
   const int slot = st->frames_done;  // kept on the device so that the recorded launch sequence is the same for every frame
@@ -460,10 +563,15 @@ __global__ __launch_bounds__(kReduceThreads) void cam_reduce_solve_kernel(CamSta
   __shared__ double red[kReduceThreads / 32][27];
   __shared__ double totals[27];
   reduce_rows(partial, rows, red, totals);
-  if (threadIdx.x != 0) return;
-  level_begin_step(st, flags);
-  if (!st->lost) solve_step(st, totals, slot);
-  if (flags & kFlagLastOfFrame) frame_end_step(st, 1);
+  if (threadIdx.x >= 64) return;  // the tail runs on the first wavefront
+  int lost = 0;
+  if (threadIdx.x == 0) {
+    level_begin_step(st, flags);
+    lost = st->lost;
+  }
+  lost = __builtin_amdgcn_readfirstlane(lost);
+  if (!lost) solve_step_wave(st, totals, slot);
+  if (threadIdx.x == 0 && (flags & kFlagLastOfFrame)) frame_end_step(st, 1);
 }
 
 // multi-GPU iteration tail: acc[] holds the all-reduced sums
@@ -479,10 +587,14 @@ __global__ void cam_solve_kernel(CamState *st, double *acc, int slot, int flags)
     acc[threadIdx.x] = 0.0;
   }
   __syncthreads();
-  if (threadIdx.x) return;
-  level_begin_step(st, flags);
-  if (!st->lost) solve_step(st, sums, slot);
-  if (flags & kFlagLastOfFrame) frame_end_step(st, 1);
+  int lost = 0;
+  if (threadIdx.x == 0) {
+    level_begin_step(st, flags);
+    lost = st->lost;
+  }
+  lost = __builtin_amdgcn_readfirstlane(lost);
+  if (!lost) solve_step_wave(st, sums, slot);
+  if (threadIdx.x == 0 && (flags & kFlagLastOfFrame)) frame_end_step(st, 1);
 }
 
 __global__ void cam_frame_end_kernel(CamState *st, int apply_update) {
@@ -666,9 +778,12 @@ int camera_end(svoslam_camera *c, hipStream_t s) {
 }
 
 // Pose of the oldest prepared frame: two launches per ICP iteration (accumulate; reduce + solve +
-// compose), recorded once per map set and replayed as one graph.  A single-launch
-// variant (last-arriving workgroup reduces and solves behind an agent-scope release/acquire) was
-// measured 4 % slower end to end: the two fences cost what the kernel boundary costs.
+// compose), recorded once per map set and replayed as one graph.  Two single-launch variants were
+// measured and dropped: the last-arriving workgroup reducing and solving behind an agent-scope
+// release/acquire (4 % slower end to end: the fences cost what the kernel boundary costs), and every
+// workgroup finishing the previous iteration redundantly on an LDS copy of the state before
+// accumulating the next (21 us per launch against 11.8 + 7.1: the solve then runs on every CU, in
+// competition with the raycast wavefronts).
 int camera_track(svoslam_camera *c, hipStream_t s) {
   if (!c) return SVOSLAM_ERR_INVALID_ARG;
   if (c->tracked >= c->prepared) return SVOSLAM_ERR_INVALID_ARG;  // nothing prepared

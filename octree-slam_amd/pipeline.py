@@ -171,8 +171,8 @@ class SlamPipeline:
         if n == 0:
             return
         if not hasattr(self, "_s_track"):
-            self._s_track, self._s_prep, self._s_map = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
-            self._s_maps = torch.cuda.Stream()
+            self._s_maps, self._s_track = torch.cuda.Stream(), torch.cuda.Stream()
+            self._s_prep, self._s_map = torch.cuda.Stream(), torch.cuda.Stream()
             self._ws2 = [self.ws, pkg.Workspace()]
             self._points2 = [self.points, torch.empty_like(self.points)]
             # fixed input addresses per stream: the library replays its launch sequences as HIP graphs keyed
@@ -189,6 +189,13 @@ class SlamPipeline:
         ev_commit = [torch.cuda.Event() for _ in range(n)]
         fusion_ptr = [0] * n
         npts = self.w * self.h
+        tl = {} if os.environ.get("SVOSLAM_TIMELINE") else None   # diagnostic: timing events at stage boundaries
+
+        def mark(name, i):
+            if tl is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                tl[(name, i)] = e
 
         four = not self.dist.enabled   # single GPU: the maps of a frame are built on their own stream, one frame ahead
         ev_maps = [torch.cuda.Event() for _ in range(n)]
@@ -198,10 +205,12 @@ class SlamPipeline:
             with torch.cuda.stream(self._s_maps):
                 if i >= 2:
                     self._s_maps.wait_event(ev_pose[i - 2])      # its map set was the "last" set of frame i-2
+                mark("maps0", i)
                 self._in_track.copy_(depths[i])
                 if not self.cam.prepare(self._in_track, rgbs[i], timestamps[i]):
                     raise ValueError("run_stream needs strictly increasing timestamps")
                 ev_maps[i].record()
+                mark("maps1", i)
 
         def enqueue_track(i):
             with torch.cuda.stream(self._s_track):
@@ -209,7 +218,9 @@ class SlamPipeline:
                     self._s_track.wait_event(ev_bp[i - 4])       # ring slot i % 4 has been consumed
                 if four:
                     self._s_track.wait_event(ev_maps[i])
+                    mark("track0", i)
                     self.cam.track_prepared()
+                    mark("track1", i)
                 else:
                     self._in_track.copy_(depths[i])
                     self.track(self._in_track, rgbs[i], timestamps[i])
@@ -220,6 +231,7 @@ class SlamPipeline:
             ws, pts = self._ws2[i & 1], self._points2[i & 1]
             with torch.cuda.stream(self._s_prep):
                 self._s_prep.wait_event(ev_pose[i])
+                mark("prep0", i)
                 self.points = pts
                 self._in_prep.copy_(depths[i])
                 self._backproject_with(self._in_prep, fusion_ptr[i])
@@ -227,8 +239,10 @@ class SlamPipeline:
                 pkg.svo_fuse_sort(ws, pts.view(-1, 3), self.depth, self.center, self.edge)
                 if i > 0:
                     self._s_prep.wait_event(ev_commit[i - 1])    # the tree the plan reads
+                mark("plan0", i)
                 pkg.svo_fuse_plan(ws, npts, self.depth, self.pool)
                 ev_plan[i].record()
+                mark("plan1", i)
 
         if four:
             enqueue_maps(0)
@@ -243,19 +257,26 @@ class SlamPipeline:
                 enqueue_maps(i + 2)
             with torch.cuda.stream(self._s_map):
                 self._s_map.wait_event(ev_plan[i])
+                mark("commit0", i)
                 self._in_rgb.copy_(rgbs[i])
                 pkg.svo_fuse_commit(self._ws2[i & 1], self._in_rgb.view(-1, 3), self.depth, self.pool)
                 ev_commit[i].record()
+                mark("commit1", i)
             if i + 1 < n:
                 enqueue_prepare(i + 1)      # host order: after ev_commit[i] has been recorded
             with torch.cuda.stream(self._s_map):
                 if on_render is not None:
                     on_render(i, None)        # "before render" hook (event timing)
                 self.render(views[i])
+                mark("render1", i)
                 if on_render is not None:
                     on_render(i, self.image)
         for st in (self._s_maps, self._s_track, self._s_prep, self._s_map):
             cur.wait_stream(st)
+        if tl is not None:
+            torch.cuda.synchronize()
+            base = tl[("commit0", 0)]
+            self.timeline = {k: base.elapsed_time(e) for k, e in tl.items()}
 
     def _backproject_with(self, depth, fusion_ptr):
         if not self.dist.enabled:
