@@ -38,7 +38,9 @@ typedef enum {
   SVOSLAM_ERR_OOM = -4,
   SVOSLAM_ERR_DEPTH = -5,      /* max_depth outside [1, SVOSLAM_MAX_DEPTH] */
   SVOSLAM_ERR_POOL_LIMIT = -6, /* pool would exceed 2^30 nodes (30-bit child index) */
-  SVOSLAM_ERR_TRACKING_LOST = -7
+  SVOSLAM_ERR_TRACKING_LOST = -7,
+  SVOSLAM_ERR_IO = -8,         /* file could not be opened / read / written */
+  SVOSLAM_ERR_FORMAT = -9      /* file is not what it should be (magic, size, checksum, structure) */
 } svoslam_status;
 
 #define SVOSLAM_MAX_DEPTH 16
@@ -77,6 +79,15 @@ int svoslam_pool_reserve(svoslam_pool *pool, int32_t capacity_nodes, void *strea
 int svoslam_pool_free(svoslam_pool *pool);
 /* makes pool->size exact again after asynchronous fusion calls (one stream sync + 4-byte readback) */
 int svoslam_pool_sync(svoslam_pool *pool, void *stream);
+/* Checkpoint / resume of a map.  The file is the linear tree as it sits in HBM -- the
+ * layout OctreeNode::pushToGPU assembles (src/world/octree.cpp:41-79) -- behind a 64-byte header
+ * (magic "SVOPOOL1", node count, root centre / half edge / depth, FNV-1a checksum).  Blocking; both wait
+ * for the whole device first.  load() verifies the checksum and that every child tile lies inside the
+ * pool, (re)allocates the pool and returns the root parameters (each may be NULL). */
+int svoslam_pool_save(svoslam_pool *pool, const char *path, const float center[3], float edge_length, int32_t max_depth,
+                      void *stream);
+int svoslam_pool_load(svoslam_pool *pool, const char *path, float center[3], float *edge_length, int32_t *max_depth,
+                      void *stream);
 
 /* Opaque scratch arena reused across calls (sort buffers, plan records...).
  * The reference cudaMallocs ~6+D temporaries per call instead. */
@@ -172,6 +183,31 @@ int svoslam_texture_free(svoslam_texture *tex);
 int svoslam_mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const svoslam_texture *tex, int32_t log_N,
                                int32_t log_T, float **d_centers, float **d_colors, unsigned long long **d_indices,
                                int32_t *n_out, float *scale_out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Recorded-sensor input: replaces sensor::OpenNIDevice
+ * (src/sensor/openni_device.cpp:13-150) as the producer of RawFrame (common_types.h:65-73).
+ * The association file is a TUM-RGB-D style list, one frame per line:
+ *   <timestamp> <file> <timestamp> <file>     (depth and colour image in either order, '#' comments,
+ *   paths relative to the list).  Images: PNG (8-bit RGB, 16-bit grey), binary PGM (16 bit) / PPM.
+ * depth_units_per_metre converts the stored depth to the millimetres of RawFrame (1000 = already mm,
+ * 5000 = TUM).  Timestamps are returned in microseconds.
+ * ---------------------------------------------------------------------- */
+typedef struct svoslam_frame_reader svoslam_frame_reader;
+int svoslam_frame_reader_open(svoslam_frame_reader **reader, const char *association_file, float depth_units_per_metre);
+int svoslam_frame_reader_close(svoslam_frame_reader *reader);
+int svoslam_frame_reader_info(const svoslam_frame_reader *reader, int32_t *width, int32_t *height, int32_t *num_frames);
+int svoslam_frame_reader_rewind(svoslam_frame_reader *reader);
+/* next frame into HOST buffers (width*height uint16 / width*height*3 bytes); *got = 0 at the end of the list */
+int svoslam_frame_reader_next_host(svoslam_frame_reader *reader, uint16_t *h_depth, uint8_t *h_color, long long *timestamp,
+                                   int32_t *got);
+/* OpenNIDevice::readFrame (:93-150): next frame into DEVICE buffers (pinned staging + async upload on `stream`) */
+int svoslam_frame_reader_next(svoslam_frame_reader *reader, uint16_t *d_depth, uint8_t *d_color, long long *timestamp,
+                              int32_t *got, void *stream);
+/* openni_device.cpp:64-65: focal = size / (2 tan(fov / 2)), fov in radians */
+int svoslam_focal_from_fov(int32_t width, int32_t height, float hfov_rad, float vfov_rad, float *fx, float *fy);
+/* one image file into a malloc'ed host buffer (free with free()); 16-bit samples in host byte order */
+int svoslam_image_load(const char *path, void **h_data, int32_t *width, int32_t *height, int32_t *channels, int32_t *bits);
 
 /* ------------------------------------------------------------------------
  * Host objects: world::Scene + world::Octree (include/octree_slam/world/scene.h:20-81,

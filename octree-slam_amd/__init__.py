@@ -74,10 +74,20 @@ SIGNATURES = {
     "svoslam_pool_reserve": (C.c_int, [C.POINTER(_PoolStruct), _i32, _vp]),
     "svoslam_pool_free": (C.c_int, [C.POINTER(_PoolStruct)]),
     "svoslam_pool_sync": (C.c_int, [C.POINTER(_PoolStruct), _vp]),
+    "svoslam_pool_save": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _fp, _f32, _i32, _vp]),
+    "svoslam_pool_load": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _fp, C.POINTER(_f32), C.POINTER(_i32), _vp]),
     "svoslam_svo_from_point_cloud_async": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _fp, _f32, _vp]),
     "svoslam_svo_fuse_sort": (C.c_int, [_vp, _vp, _i32, _i32, _fp, _f32, _vp]),
     "svoslam_svo_fuse_plan": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_commit": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
+    "svoslam_frame_reader_open": (C.c_int, [C.POINTER(_vp), C.c_char_p, _f32]),
+    "svoslam_frame_reader_close": (C.c_int, [_vp]),
+    "svoslam_frame_reader_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "svoslam_frame_reader_rewind": (C.c_int, [_vp]),
+    "svoslam_frame_reader_next_host": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_longlong), C.POINTER(_i32)]),
+    "svoslam_frame_reader_next": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_longlong), C.POINTER(_i32), _vp]),
+    "svoslam_focal_from_fov": (C.c_int, [_i32, _i32, _f32, _f32, _fp, _fp]),
+    "svoslam_image_load": (C.c_int, [C.c_char_p, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "svoslam_workspace_create": (C.c_int, [C.POINTER(_vp)]),
     "svoslam_workspace_destroy": (C.c_int, [_vp]),
     "svoslam_svo_from_point_cloud": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _fp, _f32,
@@ -263,6 +273,17 @@ class Pool:
         if r != 0:
             raise SvoslamError("hipMemcpy H2D failed: %d" % r)
         self._p.size = nodes
+
+    def save(self, path, center, edge_length, max_depth):
+        """checkpoint: linear tree + root parameters (svoslam_pool_save)"""
+        check(lib().svoslam_pool_save(C.byref(self._p), str(path).encode(), _fa(center, 3), float(edge_length), int(max_depth),
+                                      _stream()))
+
+    def load(self, path):
+        """resume from a checkpoint; returns (center, edge_length, max_depth)"""
+        c, e, d = (C.c_float * 3)(), C.c_float(0), C.c_int32(0)
+        check(lib().svoslam_pool_load(C.byref(self._p), str(path).encode(), c, C.byref(e), C.byref(d), _stream()))
+        return tuple(float(v) for v in c), float(e.value), int(d.value)
 
     def close(self):
         if self._p.d_data:
@@ -500,6 +521,68 @@ def cone_trace_timing_read():
     ms, n = C.c_float(0), C.c_int32(0)
     check(lib().svoslam_cone_trace_timing_read(C.byref(ms), C.byref(n)))
     return float(ms.value), int(n.value)
+
+
+# ----------------------------------------------------------------------------- recorded sensor
+def image_load(path):
+    """PNG / PGM / PPM -> numpy array [h, w] uint16 or [h, w, 3] uint8 (host side, no device needed)"""
+    data, w, h, ch, bits = _vp(), _i32(0), _i32(0), _i32(0), _i32(0)
+    check(lib().svoslam_image_load(str(path).encode(), C.byref(data), C.byref(w), C.byref(h), C.byref(ch), C.byref(bits)))
+    try:
+        n = w.value * h.value * ch.value
+        if bits.value == 16:
+            a = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_uint16)), shape=(n,)).copy()
+        else:
+            a = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+    finally:
+        C.CDLL(None).free(data)
+    return a.reshape(h.value, w.value) if ch.value == 1 else a.reshape(h.value, w.value, ch.value)
+
+
+def focal_from_fov(width, height, hfov_rad, vfov_rad):
+    fx, fy = C.c_float(0), C.c_float(0)
+    check(lib().svoslam_focal_from_fov(width, height, float(hfov_rad), float(vfov_rad), C.byref(fx), C.byref(fy)))
+    return float(fx.value), float(fy.value)
+
+
+class FrameReader:
+    """sensor::OpenNIDevice replaced by a TUM-style association list of depth / colour images"""
+
+    def __init__(self, association_file, depth_units_per_metre=1000.0):
+        self._h = _vp()
+        check(lib().svoslam_frame_reader_open(C.byref(self._h), str(association_file).encode(), float(depth_units_per_metre)))
+        w, h, n = _i32(0), _i32(0), _i32(0)
+        check(lib().svoslam_frame_reader_info(self._h, C.byref(w), C.byref(h), C.byref(n)))
+        self.width, self.height, self.num_frames = w.value, h.value, n.value
+
+    def rewind(self):
+        check(lib().svoslam_frame_reader_rewind(self._h))
+
+    def next_host(self):
+        """(depth uint16 [h,w] in mm, rgb uint8 [h,w,3], timestamp_us) or None at the end"""
+        d = np.empty((self.height, self.width), np.uint16)
+        c = np.empty((self.height, self.width, 3), np.uint8)
+        ts, got = C.c_longlong(0), _i32(0)
+        check(lib().svoslam_frame_reader_next_host(self._h, C.c_void_p(d.ctypes.data), C.c_void_p(c.ctypes.data), C.byref(ts),
+                                                   C.byref(got)))
+        return (d, c, int(ts.value)) if got.value else None
+
+    def next_device(self, depth_out, rgb_out):
+        """uploads the next frame into cuda tensors (int16/uint16 [h,w], uint8 [h,w,3]); returns the timestamp or None"""
+        ts, got = C.c_longlong(0), _i32(0)
+        check(lib().svoslam_frame_reader_next(self._h, _ptr(depth_out), _ptr(rgb_out), C.byref(ts), C.byref(got), _stream()))
+        return int(ts.value) if got.value else None
+
+    def close(self):
+        if self._h:
+            lib().svoslam_frame_reader_close(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ----------------------------------------------------------------------------- sensor

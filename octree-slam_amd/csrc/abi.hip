@@ -8,6 +8,7 @@
 #include "icp.hpp"
 #include "image_kernels.hpp"
 #include "mesh.hpp"
+#include "frame_io.hpp"
 #include "svo_build.hpp"
 #include "workspace.hpp"
 
@@ -68,6 +69,8 @@ const char *svoslam_status_string(int status) {
     case SVOSLAM_ERR_DEPTH: return "max_depth outside [1,16]";
     case SVOSLAM_ERR_POOL_LIMIT: return "node pool would exceed 2^30 nodes";
     case SVOSLAM_ERR_TRACKING_LOST: return "camera tracking lost";
+    case SVOSLAM_ERR_IO: return "file could not be opened, read or written";
+    case SVOSLAM_ERR_FORMAT: return "file format error (magic, size, checksum or structure)";
     default: return "unknown status";
   }
 }
@@ -99,6 +102,19 @@ int svoslam_pool_sync(svoslam_pool *pool, void *stream) {
   NEED_DEVICE();
   return pool_sync(pool, S(stream));
 }
+int svoslam_pool_save(svoslam_pool *pool, const char *path, const float center[3], float edge_length, int32_t max_depth,
+                      void *stream) {
+  NEED_DEVICE();
+  return pool_save(pool, path, center, edge_length, max_depth, S(stream));
+}
+int svoslam_pool_load(svoslam_pool *pool, const char *path, float center[3], float *edge_length, int32_t *max_depth,
+                      void *stream) {
+  NEED_DEVICE();
+  int d = 0;
+  const int rc = pool_load(pool, path, center, edge_length, &d, S(stream));
+  if (max_depth) *max_depth = d;
+  return rc;
+}
 int svoslam_svo_from_point_cloud_async(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int32_t n,
                                        int32_t max_depth, svoslam_pool *pool, const float center[3], float edge_length,
                                        void *stream) {
@@ -121,6 +137,53 @@ int svoslam_svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int3
                             void *stream) {
   NEED_DEVICE();
   return svo_fuse_commit(ws, d_colors, n, max_depth, pool, S(stream));
+}
+
+int svoslam_frame_reader_open(svoslam_frame_reader **reader, const char *association_file, float depth_units_per_metre) {
+  return frame_reader_open(reader, association_file, depth_units_per_metre);
+}
+int svoslam_frame_reader_close(svoslam_frame_reader *reader) { return frame_reader_close(reader); }
+int svoslam_frame_reader_info(const svoslam_frame_reader *reader, int32_t *width, int32_t *height, int32_t *num_frames) {
+  int w = 0, h = 0, n = 0;
+  const int rc = frame_reader_info(reader, &w, &h, &n);
+  if (width) *width = w;
+  if (height) *height = h;
+  if (num_frames) *num_frames = n;
+  return rc;
+}
+int svoslam_frame_reader_rewind(svoslam_frame_reader *reader) { return frame_reader_rewind(reader); }
+int svoslam_frame_reader_next_host(svoslam_frame_reader *reader, uint16_t *h_depth, uint8_t *h_color, long long *timestamp,
+                                   int32_t *got) {
+  int g = 0;
+  const int rc = frame_reader_next_host(reader, h_depth, h_color, timestamp, &g);
+  if (got) *got = g;
+  return rc;
+}
+int svoslam_frame_reader_next(svoslam_frame_reader *reader, uint16_t *d_depth, uint8_t *d_color, long long *timestamp,
+                              int32_t *got, void *stream) {
+  NEED_DEVICE();
+  int g = 0;
+  const int rc = frame_reader_next(reader, d_depth, d_color, timestamp, &g, S(stream));
+  if (got) *got = g;
+  return rc;
+}
+int svoslam_focal_from_fov(int32_t width, int32_t height, float hfov_rad, float vfov_rad, float *fx, float *fy) {
+  return focal_from_fov(width, height, hfov_rad, vfov_rad, fx, fy);
+}
+int svoslam_image_load(const char *path, void **h_data, int32_t *width, int32_t *height, int32_t *channels, int32_t *bits) {
+  if (!h_data) return SVOSLAM_ERR_INVALID_ARG;
+  HostImage img;
+  const int rc = image_load(path, img);
+  if (rc != SVOSLAM_OK) return rc;
+  void *p = malloc(img.data.size() ? img.data.size() : 1);
+  if (!p) return SVOSLAM_ERR_OOM;
+  memcpy(p, img.data.data(), img.data.size());
+  *h_data = p;
+  if (width) *width = img.width;
+  if (height) *height = img.height;
+  if (channels) *channels = img.channels;
+  if (bits) *bits = img.bits;
+  return SVOSLAM_OK;
 }
 
 int svoslam_workspace_create(svoslam_workspace **ws) {

@@ -27,6 +27,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cstdio>
+#include <vector>
+
 #include "radix_sort.hpp"
 #include "svo_build.hpp"
 #include "wave_rank.hpp"
@@ -604,6 +607,83 @@ int pool_init(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream) {
 int pool_reserve(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream) {
   if (!pool) return SVOSLAM_ERR_INVALID_ARG;
   return grow_pool(pool, capacity_nodes, stream);
+}
+
+// ---- checkpoint / resume -------------------------------------------------------------
+// The pool IS the reference's linear tree (the layout OctreeNode::pushToGPU assembles, octree.cpp:41-79:
+// 2-word nodes, 0x40000000 children flag, 30-bit child index), so a checkpoint is the node words behind
+// a 64-byte header.  The reference's own (de)serialiser is unfinished (addToLinearTree never sets the
+// flag, octree.cpp:138-160), so there is no reference byte stream to match.
+struct PoolFileHeader {
+  char magic[8];        // "SVOPOOL1"
+  uint32_t version;     // 1
+  int32_t num_nodes;
+  float center[3];
+  float edge_length;    // half edge of the root cube
+  int32_t max_depth;
+  uint32_t reserved;
+  uint64_t checksum;    // FNV-1a over the node words
+  uint8_t pad[16];
+};
+static_assert(sizeof(PoolFileHeader) == 64, "header is 64 bytes");
+
+static uint64_t fnv1a_words(const u32 *w, size_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; i++) h = (h ^ (uint64_t)w[i]) * 1099511628211ull;
+  return h;
+}
+
+int pool_save(svoslam_pool *pool, const char *path, const float center[3], float edge, int depth, hipStream_t stream) {
+  if (!pool || !path || !center || !pool->d_data) return SVOSLAM_ERR_INVALID_ARG;
+  SVO_HIP(hipDeviceSynchronize());  // commits may be in flight on other streams
+  SVO_TRY(pool_sync(pool, stream));
+  const size_t words = 2 * (size_t)pool->size;
+  std::vector<u32> host(words);
+  SVO_HIP(hipMemcpy(host.data(), pool->d_data, words * 4, hipMemcpyDeviceToHost));
+  PoolFileHeader h;
+  memset(&h, 0, sizeof(h));
+  memcpy(h.magic, "SVOPOOL1", 8);
+  h.version = 1; h.num_nodes = pool->size;
+  h.center[0] = center[0]; h.center[1] = center[1]; h.center[2] = center[2];
+  h.edge_length = edge; h.max_depth = depth;
+  h.checksum = fnv1a_words(host.data(), words);
+  FILE *f = fopen(path, "wb");
+  if (!f) return SVOSLAM_ERR_IO;
+  const bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && (words == 0 || fwrite(host.data(), 4, words, f) == words);
+  return (fclose(f) == 0 && ok) ? SVOSLAM_OK : SVOSLAM_ERR_IO;
+}
+
+int pool_load(svoslam_pool *pool, const char *path, float center[3], float *edge, int *depth, hipStream_t stream) {
+  if (!pool || !path) return SVOSLAM_ERR_INVALID_ARG;
+  FILE *f = fopen(path, "rb");
+  if (!f) return SVOSLAM_ERR_IO;
+  PoolFileHeader h;
+  if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SVOPOOL1", 8) != 0 || h.version != 1 || h.num_nodes < 8 ||
+      (h.num_nodes & 7) != 0) {
+    fclose(f);
+    return SVOSLAM_ERR_FORMAT;
+  }
+  const size_t words = 2 * (size_t)h.num_nodes;
+  std::vector<u32> host(words);
+  const bool ok = fread(host.data(), 4, words, f) == words;
+  fclose(f);
+  if (!ok || fnv1a_words(host.data(), words) != h.checksum) return SVOSLAM_ERR_FORMAT;
+  for (size_t i = 0; i < (size_t)h.num_nodes; i++) {  // every child tile must lie inside the pool
+    const u32 w0 = host[2 * i];
+    if ((w0 & kFlag) && ((w0 & kMask) + 8u > (u32)h.num_nodes || ((w0 & kMask) & 7u))) return SVOSLAM_ERR_FORMAT;
+  }
+  SVO_HIP(hipDeviceSynchronize());
+  if (!pool->d_data) SVO_TRY(pool_init(pool, h.num_nodes, stream));
+  SVO_TRY(pool_sync(pool, stream));
+  SVO_TRY(grow_pool(pool, h.num_nodes, stream));
+  SVO_HIP(hipMemcpy(pool->d_data, host.data(), words * 4, hipMemcpyHostToDevice));
+  pool->size = h.num_nodes;
+  pool->pending = 0; pool->pending_bound = 0;
+  if (pool->d_size) SVO_HIP(hipMemcpy(pool->d_size, &pool->size, 4, hipMemcpyHostToDevice));
+  if (center) { center[0] = h.center[0]; center[1] = h.center[1]; center[2] = h.center[2]; }
+  if (edge) *edge = h.edge_length;
+  if (depth) *depth = h.max_depth;
+  return SVOSLAM_OK;
 }
 
 static int reserve_common(svoslam_workspace *ws, int n, int depth) {

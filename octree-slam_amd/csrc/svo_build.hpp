@@ -8,6 +8,8 @@ int pool_init(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream);
 int pool_reserve(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream);
 int pool_sync(svoslam_pool *pool, hipStream_t stream);
 void pool_tracker_destroy(svoslam_pool *pool);
+int pool_save(svoslam_pool *pool, const char *path, const float center[3], float edge, int depth, hipStream_t stream);
+int pool_load(svoslam_pool *pool, const char *path, float center[3], float *edge, int *depth, hipStream_t stream);
 int svo_from_point_cloud_async(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,
                                svoslam_pool *pool, const float center[3], float edge, hipStream_t stream);
 int svo_fuse_sort(svoslam_workspace *ws, const float *d_points, int n, int depth, const float center[3], float edge,

@@ -1,0 +1,90 @@
+"""GPU side of the 8f rows: checkpoint / resume of the node pool and the recorded-sensor reader feeding the
+frame pipeline (files -> device RawFrame -> track + fuse + raycast == the same frames passed as tensors)."""
+import importlib
+
+import numpy as np
+import pytest
+
+from test_frame_io_cpu import png_bytes
+from util import surface_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import svoslam_pkg
+    pkg = svoslam_pkg.load()
+    synth = importlib.import_module("octree_slam_amd.synth")
+    pl = importlib.import_module("octree_slam_amd.pipeline")
+    return pkg, torch, synth, pl
+
+
+def test_pool_checkpoint_round_trip(env, oracle, tmp_path):
+    pkg, torch, synth, pl = env
+    rng = np.random.default_rng(11)
+    pts, col = surface_cloud(rng, 20000)
+    center, edge, depth = (0.1, -0.05, 0.02), 1.25, 9
+    ws, pool = pkg.Workspace(), pkg.Pool()
+    for k in range(3):   # asynchronous calls: save() must first make the size exact
+        pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts + np.float32(0.01 * k)).cuda(), torch.from_numpy(col).cuda(), depth,
+                                       pool, center, edge)
+    path = tmp_path / "map.svopool"
+    pool.save(path, center, edge, depth)
+    words = pool.words()
+    fresh = pkg.Pool()
+    got = fresh.load(path)
+    assert got == (pytest.approx(center), pytest.approx(edge), depth)
+    assert fresh.size == pool.size and np.array_equal(fresh.words(), words)
+    # resume: one more frame into both gives the same pool, and it renders the same
+    more = torch.from_numpy(pts + np.float32(0.05)).cuda()
+    for p in (pool, fresh):
+        pkg.svo_from_point_cloud_async(ws, more, torch.from_numpy(col).cuda(), depth, p, center, edge)
+    assert fresh.size == pool.size and np.array_equal(fresh.words(), pool.words())
+    view = oracle.look_at((0.2, 0.3, -2.2), (0, 0, 0), (0, 1, 0))
+    a = torch.zeros((60, 80, 4), dtype=torch.uint8, device="cuda"); b = torch.zeros_like(a)
+    pkg.cone_trace_svo(a, 45.0, view, pool.data_ptr, center, edge)
+    pkg.cone_trace_svo(b, 45.0, view, fresh.data_ptr, center, edge)
+    assert torch.equal(a, b)
+    # damaged files are refused
+    raw = bytearray(path.read_bytes())
+    raw[200] ^= 1
+    (tmp_path / "bad.svopool").write_bytes(bytes(raw))
+    with pytest.raises(pkg.SvoslamError):
+        pkg.Pool().load(tmp_path / "bad.svopool")
+    (tmp_path / "short.svopool").write_bytes(bytes(raw[:100]))
+    with pytest.raises(pkg.SvoslamError):
+        pkg.Pool().load(tmp_path / "short.svopool")
+
+
+def test_frames_from_files_equal_frames_from_tensors(env, tmp_path):
+    pkg, torch, synth, pl = env
+    w, h, depth, center, edge, n = 160, 120, 8, (0.0, 1.5, 0.0), 4.096, 4
+    (tmp_path / "depth").mkdir(); (tmp_path / "rgb").mkdir()
+    lines, frames = [], []
+    for k in range(n):
+        d, c = synth.render_frame(k, w, h)
+        frames.append((d, c))
+        (tmp_path / "depth" / ("%04d.png" % k)).write_bytes(png_bytes(d.numpy().view(np.uint16)))
+        (tmp_path / "rgb" / ("%04d.png" % k)).write_bytes(png_bytes(c.numpy(), 6))
+        lines.append("%.6f depth/%04d.png %.6f rgb/%04d.png" % (10.0 + k / 30.0, k, 10.0 + k / 30.0, k))
+    (tmp_path / "assoc.txt").write_text("\n".join(lines) + "\n")
+    reader = pkg.FrameReader(tmp_path / "assoc.txt")          # depth already in millimetres
+    assert (reader.width, reader.height, reader.num_frames) == (w, h, n)
+    A = pl.SlamPipeline(w, h, depth, center, edge)
+    B = pl.SlamPipeline(w, h, depth, center, edge)
+    d_dev = torch.empty((h, w), dtype=frames[0][0].dtype, device="cuda")
+    c_dev = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+    last_ts = -1
+    for k in range(n):
+        view = pl.ground_truth_view(k, synth)
+        ts = reader.next_device(d_dev, c_dev)
+        assert ts is not None and ts > last_ts
+        last_ts = ts
+        assert torch.equal(d_dev.cpu(), frames[k][0]) and torch.equal(c_dev.cpu(), frames[k][1])
+        ia = A.frame(frames[k][0].cuda(), frames[k][1].cuda(), ts, view).cpu().numpy()
+        ib = B.frame(d_dev, c_dev, ts, view).cpu().numpy()
+        assert np.array_equal(ia, ib)
+    assert reader.next_device(d_dev, c_dev) is None
+    assert A.pool.size == B.pool.size and np.array_equal(A.pool.words(), B.pool.words())
