@@ -66,3 +66,13 @@ __host__ __device__ inline float dot3(float ax, float ay, float az, float bx, fl
 }
 
 }  // namespace svoslam
+
+// Wavefront issue priority (s_setprio) for the tracker's kernels: its 38 dependent launches per frame are the
+// longest chain of the pipeline and share the SIMDs with the raycast's ~20 wavefronts per CU, which is bound
+// by its slowest rays anyway.  +3 % frames/s; raising the sort / plan / commit / map kernels as well cancels it.
+#ifdef __HIP_DEVICE_COMPILE__
+#define SVO_HIGH_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define SVO_HIGH_PRIO()
+#endif
+

@@ -183,6 +183,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_accumulate_kernel(
     const float *__restrict__ last_v, const float *__restrict__ last_n, const float *__restrict__ cur_v,
     const float *__restrict__ cur_n, int first, int end, const CamState *__restrict__ state, int flags, int chain_len,
     double *__restrict__ partial) {
+  SVO_HIGH_PRIO();
   __shared__ double wsum[kIcpWaves][27];
   __shared__ float chain_s[(kMaxChain + 1) * 16];
   accumulate_block(last_v, last_n, cur_v, cur_n, first, end, state, flags, chain_len, partial, wsum, chain_s);
@@ -209,6 +210,7 @@ __device__ inline void reduce_rows(const double *__restrict__ partial, int rows,
 // acc[27] += column sums (used by the stateless ABI call and the multi-GPU path)
 __global__ __launch_bounds__(kReduceThreads) void icp_reduce_kernel(const double *__restrict__ partial, int rows,
                                                                     double *__restrict__ acc) {
+  SVO_HIGH_PRIO();
   __shared__ double red[kReduceThreads / 32][27];
   __shared__ double totals[27];
   reduce_rows(partial, rows, red, totals);
@@ -560,6 +562,7 @@ __device__ inline void level_begin_step(CamState *st, int flags) {
 // single-GPU iteration tail: sum the workgroup rows, solve, compose -- ONE launch
 __global__ __launch_bounds__(kReduceThreads) void cam_reduce_solve_kernel(CamState *st, const double *__restrict__ partial,
                                                                           int rows, int slot, int flags) {
+  SVO_HIGH_PRIO();
   __shared__ double red[kReduceThreads / 32][27];
   __shared__ double totals[27];
   reduce_rows(partial, rows, red, totals);
@@ -576,6 +579,7 @@ __global__ __launch_bounds__(kReduceThreads) void cam_reduce_solve_kernel(CamSta
 
 // multi-GPU iteration tail: acc[] holds the all-reduced sums
 __global__ void cam_solve_kernel(CamState *st, double *acc, int slot, int flags) {
+  SVO_HIGH_PRIO();
   // Read-and-reset, one element per LANE.  (A single thread doing "sums[i] = acc[i]; acc[i] = 0" gets
   // uniform-address SCALAR loads followed by vector stores of a constant: nothing orders the two memory
   // paths, and the zero was observed to overtake the load -- six of the 27 sums read back as 0 once in a
@@ -598,6 +602,7 @@ __global__ void cam_solve_kernel(CamState *st, double *acc, int slot, int flags)
 }
 
 __global__ void cam_frame_end_kernel(CamState *st, int apply_update) {
+  SVO_HIGH_PRIO();
   if (threadIdx.x || blockIdx.x) return;
   frame_end_step(st, apply_update);
 }
