@@ -69,7 +69,8 @@ __host__ __device__ inline float dot3(float ax, float ay, float az, float bx, fl
 
 // Wavefront issue priority (s_setprio) for the tracker's kernels: its 38 dependent launches per frame are the
 // longest chain of the pipeline and share the SIMDs with the raycast's ~20 wavefronts per CU, which is bound
-// by its slowest rays anyway.  +3 % frames/s; raising the sort / plan / commit / map kernels as well cancels it.
+// by its slowest rays anyway (+3 % frames/s); the three commit kernels of the map stream likewise (+2 %).
+// Raising the sort / plan / map-generation kernels as well cancels the gain.
 #ifdef __HIP_DEVICE_COMPILE__
 #define SVO_HIGH_PRIO() __builtin_amdgcn_s_setprio(3)
 #else

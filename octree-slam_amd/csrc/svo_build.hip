@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void split_all_kernel(const u64 *__restrict__ 
                                                         const unsigned char *__restrict__ rec_pass,
                                                         const u32 *__restrict__ bucket_base, const PlanCounts *__restrict__ counts,
                                                         u32 *__restrict__ pool, const int *__restrict__ d_size, int depth) {
+  SVO_HIGH_PRIO();  // commit kernels sit between two raycasts on the map stream
   const u32 total = (u32)counts->total_records;
   const u32 n0 = (u32)*d_size;
   for (u32 r = blockIdx.x * 256u + threadIdx.x; r < total; r += gridDim.x * 256u) {
@@ -388,6 +389,7 @@ __global__ __launch_bounds__(256) void fill_mip_local_kernel(const u64 *__restri
                                                              int depth, const unsigned char *__restrict__ leaf_t,
                                                              const unsigned char *__restrict__ colors, u32 *__restrict__ pool,
                                                              u32 *__restrict__ strad, int num_tiles) {
+  SVO_HIGH_PRIO();  // commit kernels sit between two raycasts on the map stream
   __shared__ int last_owner[SVOSLAM_MAX_DEPTH + 1];  // per level: last lane of this workgroup owning a node there
   __shared__ int next_pos, next_c;                   // first head lane after this workgroup and its common-prefix length
   const int tid = (int)threadIdx.x;
@@ -461,6 +463,7 @@ __global__ __launch_bounds__(256) void fill_mip_local_kernel(const u64 *__restri
 __global__ __launch_bounds__(1024) void mip_straddle_kernel(u32 *__restrict__ pool, const u32 *__restrict__ strad, int num_tiles,
                                                             int depth, const PlanCounts *__restrict__ counts,
                                                             int *__restrict__ d_size) {
+  SVO_HIGH_PRIO();  // commit kernels sit between two raycasts on the map stream
   for (int d = depth - 1; d >= 1; d--) {
     for (int t = (int)threadIdx.x; t < num_tiles; t += 1024) {
       const u32 node = strad[2 * ((size_t)d * num_tiles + t)];
