@@ -464,10 +464,34 @@ __global__ __launch_bounds__(1024) void mip_straddle_kernel(u32 *__restrict__ po
                                                             int depth, const PlanCounts *__restrict__ counts,
                                                             int *__restrict__ d_size) {
   SVO_HIGH_PRIO();  // commit kernels sit between two raycasts on the map stream
+  // a thread's list entries do not depend on the levels below, so those of the next level are fetched while
+  // this level's tiles are averaged (one dependent load per level instead of two); kSlots entries per thread
+  // in registers cover 4096 workgroups (1 M points), longer lists fall back to the plain loop
+  constexpr int kSlots = 4;
+  const uint2 *list = reinterpret_cast<const uint2 *>(strad);
+  const bool fits = num_tiles <= kSlots * 1024;
+  uint2 cur[kSlots], nxt[kSlots];
+  auto fetch = [&](int d, uint2 *e) {
+#pragma unroll
+    for (int q = 0; q < kSlots; q++) {
+      const int t = (int)threadIdx.x + 1024 * q;
+      e[q] = (d >= 1 && t < num_tiles) ? list[(size_t)d * num_tiles + t] : make_uint2(kNoStraddler, 0u);
+    }
+  };
+  if (fits) fetch(depth - 1, cur);
   for (int d = depth - 1; d >= 1; d--) {
-    for (int t = (int)threadIdx.x; t < num_tiles; t += 1024) {
-      const u32 node = strad[2 * ((size_t)d * num_tiles + t)];
-      if (node != kNoStraddler) pool[2 * (size_t)node + 1] = average_tile(pool, strad[2 * ((size_t)d * num_tiles + t) + 1]);
+    if (fits) {
+      fetch(d - 1, nxt);
+#pragma unroll
+      for (int q = 0; q < kSlots; q++)
+        if (cur[q].x != kNoStraddler) pool[2 * (size_t)cur[q].x + 1] = average_tile(pool, cur[q].y);
+#pragma unroll
+      for (int q = 0; q < kSlots; q++) cur[q] = nxt[q];
+    } else {
+      for (int t = (int)threadIdx.x; t < num_tiles; t += 1024) {
+        const uint2 e = list[(size_t)d * num_tiles + t];
+        if (e.x != kNoStraddler) pool[2 * (size_t)e.x + 1] = average_tile(pool, e.y);
+      }
     }
     __syncthreads();
   }
