@@ -16,8 +16,8 @@
 //  (1) the octant decisions of ALL levels of a sample come from one lookup per axis into
 //      a sorted table of the reference's own split planes (see "split-plane table") instead
 //      of a 3-op-per-axis-per-level dependent chain;
-//  (2) levels 1..6 of the walk are ONE load from a dense 64^3 grid that stores, per cell,
-//      where the reference's walk stops and the colour word it ends on ("level-6 grid");
+//  (2) levels 1..7 of the walk are ONE load from a dense 128^3 grid that stores, per cell,
+//      where the reference's walk stops and the colour word it ends on ("level grid");
 //  (3) the per-step arithmetic is one division and one square root (see step_lod / loop notes).
 #include <cstring>
 #include <vector>
@@ -86,14 +86,18 @@ constexpr int kLdsCells = 1 << kLdsDepth;
 constexpr int kLdsStride = kLdsCells + 3;
 constexpr int kTraceThreads = 512;              // 3 workgroups x 8 waves per CU next to 3 x 49 KB of LDS
 
-// ---- level-6 grid ----------------------------------------------------------
-// Dense 64^3 array indexed by the first six octant bits of each axis (z, y, x).  Entry =
-// outcome of the reference's walk over levels 1..6 on that path:
-//   all six nodes have children:  x = flag | tile index of the level-6 node's children, y = its colour word
-//   first childless node at level st (1..6): x = st, y = that node's colour word
-// so the six dependent loads of the reference become one.  Rebuilt from the pool at the
-// start of every render (the pool is const during it), 2 MB.
-constexpr int kGridLevel = 6;
+// ---- level grid ------------------------------------------------------------
+// Dense (2^G)^3 array, G = kGridLevel = 7, indexed by the first G octant bits of each axis (z, y, x).
+// Entry = outcome of the reference's walk over levels 1..G on that path:
+//   all G nodes have children:  x = flag | tile index of the level-G node's children, y = its colour word
+//   first childless node at level st (1..G): x = st, y = that node's colour word
+// so the first G dependent loads of the reference become one.  Rebuilt from the pool at the
+// start of every render (the pool is const during it): 16.8 MB, ~9 us.  (G = 6: 2 MB / 5 us build but
+// 9 % more trace time; G = 8: 14 % less trace time but 134 MB / 30 us of build per render.)
+#ifndef SVO_GRID_LEVEL
+#define SVO_GRID_LEVEL 7
+#endif
+constexpr int kGridLevel = SVO_GRID_LEVEL;
 constexpr int kGridEntries = 1 << (3 * kGridLevel);
 
 struct TraceParams {
@@ -114,7 +118,8 @@ __global__ __launch_bounds__(256) void build_accel_kernel(const uint32_t *__rest
   int e = blockIdx.x * 256 + threadIdx.x;
   const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
   if (e < kGridEntries) {
-    const uint32_t xi = (uint32_t)e & 63u, yi = ((uint32_t)e >> 6) & 63u, zi = (uint32_t)e >> 12;
+    constexpr uint32_t kAxisMask = (1u << kGridLevel) - 1u;
+    const uint32_t xi = (uint32_t)e & kAxisMask, yi = ((uint32_t)e >> kGridLevel) & kAxisMask, zi = (uint32_t)e >> (2 * kGridLevel);
     uint32_t base = 0;
     uint2 out = make_uint2(0u, 0u);
     for (int l = 1; l <= kGridLevel; l++) {
