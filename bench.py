@@ -12,9 +12,11 @@ mainLoop() (src/main.cpp:31-84) with the tracker enabled -- bilateral + pyramids
 frames are resident in HBM before the timed region.  `--workload cfg4` runs the
 1920x1080 / depth-14 stream of config 4.
 
-With N > 1 the image is cut into N row bands (ICP accumulation, back-projection
-and raycast per band; ICP sums all-reduced, point bands all-gathered, fusion
-applied to every replica), so total work is fixed: scaling = "strong".
+With N > 1 the raycast is cut into N row bands over replicated pools; total work
+is fixed: scaling = "strong".  --exchange none (default): every rank tracks and fuses
+whole frames, no collective in the frame loop.  --exchange allreduce: SURVEY 8e
+(ICP accumulation and back-projection per band; ICP sums all-reduced, point bands
+all-gathered, fusion applied to every replica).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel
 (cone_trace_kernel): algorithmic bytes 4*(levels+steps) + 4*W*H per launch
@@ -93,6 +95,9 @@ def main():
     ap.add_argument("--render-mode", default="reference", choices=["reference", "carry"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="one stream, stages strictly in sequence")
+    ap.add_argument("--exchange", default="none", choices=["none", "allreduce"],
+                    help="N > 1: 'none' = every rank tracks and fuses whole frames, only the raycast is split into row bands; "
+                         "'allreduce' = SURVEY 8e row bands with 19 ICP all-reduces + one point all-gather per frame")
     args = ap.parse_args()
 
     import numpy as np
@@ -117,7 +122,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         tdist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        dist = pl.DistContext(rank, world, force=force_dist)
+        dist = pl.DistContext(rank, world, force=force_dist, exchange=args.exchange)
     arch = pkg.device_arch()
     assert arch and arch.startswith("gfx950"), arch
 
@@ -195,7 +200,10 @@ def main():
             "dtype": "u32/f32 (ICP sums exact fixed-point in f64)", "data": "synthetic",
             "config": {"workload": "%s: synthetic %dx%d RGB-D stream, depth-%d SVO, half-edge %.3f m, bilateral+ICP(19 it)+fuse+raycast(%s mode)"
                                    % (args.workload, width, height, max_depth, edge, args.render_mode),
-                       "parallelism": "row-bands x%d, replicated pool" % world if world > 1 else "single GPU",
+                       "parallelism": ("single GPU" if world == 1 and not force_dist else
+                                       "raycast in %d row bands; tracker + fusion on every rank, no data-path collective" % world
+                                       if args.exchange == "none" else
+                                       "%d row bands: ICP all-reduce (19 per frame) + point all-gather, replicated pool" % world),
                        "overlap": "none" if args.no_overlap else "3 HIP streams: track(k+1) | back-project+sort+plan(k+1) | commit+raycast(k)",
                        "pool_nodes_end": P.pool.size, "mrays_per_s": width * rows / (kern_ms * 1e-3) / 1e6,
                        "tracking_lost_levels": P.cam.tracking_lost_count()},

@@ -12,12 +12,20 @@ Single GPU: everything is enqueued on the current stream; the only host round
 trip of a frame is the 76-byte split-count readback inside the fusion call.
 
 Several GPUs (one process per GPU, torch.distributed over RCCL): the image is cut
-into row bands.  Each rank accumulates the ICP normal equations of its band and
-the 27 exact fixed-point sums are all-reduced (float64 sum: integer-valued, so
-every rank gets the same bits in any reduction order); each rank back-projects
-and transforms its band of points and the bands are all-gathered, after which
-every rank applies the same fusion to its full replica of the node pool (replicas
-stay byte-identical); each rank ray-marches its band of the output image.
+into row bands and each rank ray-marches its band of the output image against its
+own full replica of the node pool.  Two ways to keep the replicas identical
+(DistContext.exchange):
+  "none"       every rank tracks and fuses the whole frame itself -- no collective in the
+               frame loop.  The tracker and the fusion are chains of short dependent launches
+               whose duration hardly depends on the pixel count, so a band saves almost nothing
+               while 19 all-reduces per frame cost ~0.5 ms: this is the faster choice at
+               640x480 and 1080p and the default.
+  "allreduce"  SURVEY 8e: each rank accumulates the ICP normal equations of its band and the
+               27 exact fixed-point sums are all-reduced (float64 sum: integer-valued, so every
+               rank gets the same bits in any reduction order); each rank back-projects and
+               transforms its band of points and the bands are all-gathered, after which every
+               rank applies the same fusion.
+Either way the replicas stay byte-identical to the 1-GPU pool.
 """
 import os
 
@@ -40,8 +48,12 @@ def band_rows(height, rank, world):
 class DistContext:
     """Thin torch.distributed wrapper (backend nccl == RCCL on ROCm; gloo for the CPU tests)."""
 
-    def __init__(self, rank=0, world=1, group=None, force=False):
-        self.rank, self.world, self.group, self.force = rank, world, group, force
+    def __init__(self, rank=0, world=1, group=None, force=False, exchange="none"):
+        """exchange = "none": every rank tracks and fuses the whole frame itself (no collective in the frame loop; only
+        the raycast is split into row bands).  exchange = "allreduce": SURVEY 8e -- ICP accumulation and back-projection
+        per row band, 19 all-reduces of the 27 normal-equation sums and one all-gather of the point bands per frame."""
+        assert exchange in ("none", "allreduce")
+        self.rank, self.world, self.group, self.force, self.exchange = rank, world, group, force, exchange
         if self.enabled:
             # create the RCCL communicator and its streams NOW (first use is lazy and was observed to
             # mis-order against kernels queued around it), then drain the device once
@@ -101,7 +113,8 @@ class SlamPipeline:
         self.image = torch.zeros((height, width, 4), dtype=torch.uint8, device=dev)
         self.counters = torch.zeros(2, dtype=torch.int64, device=dev) if count_steps else None
         self.first, self.rows = band_rows(height, self.dist.rank, self.dist.world)
-        if self.dist.enabled:
+        self.band_exchange = self.dist.enabled and self.dist.exchange == "allreduce"
+        if self.band_exchange:
             self.acc = torch.zeros(27, dtype=torch.float64, device=dev)
             self.cam.set_acc(self.acc)
             self.cam.set_band(self.first, self.rows)
@@ -109,7 +122,7 @@ class SlamPipeline:
 
     # -- stages (each enqueues on the current stream) -------------------------------------
     def track(self, depth, rgb, timestamp):
-        if not self.dist.enabled:
+        if not self.band_exchange:
             return self.cam.update(depth, rgb, timestamp)
         used = self.cam.begin(depth, rgb, timestamp)
         if used:
@@ -197,7 +210,7 @@ class SlamPipeline:
                 e.record()
                 tl[(name, i)] = e
 
-        four = not self.dist.enabled   # single GPU: the maps of a frame are built on their own stream, one frame ahead
+        four = not self.band_exchange   # whole-frame tracker: the maps of a frame are built on their own stream, one frame ahead
         ev_maps = [torch.cuda.Event() for _ in range(n)]
 
         def enqueue_maps(i):
@@ -279,7 +292,7 @@ class SlamPipeline:
             self.timeline = {k: base.elapsed_time(e) for k, e in tl.items()}
 
     def _backproject_with(self, depth, fusion_ptr):
-        if not self.dist.enabled:
+        if not self.band_exchange:
             pkg.generate_vertex_map(depth, self.points, self.focal, self.focal, self.w, self.h)
             pkg.transform_vertex_map_dmat(self.points, fusion_ptr)
         else:

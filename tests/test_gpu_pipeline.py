@@ -54,9 +54,11 @@ def test_frames_match_oracle(env, oracle, w, h, depth, edge, frames, mode):
         assert b[6] == 1.0 and np.array_equal(b[:3], pts[ok].min(0)) and np.array_equal(b[3:6], pts[ok].max(0))
 
 
-def test_row_band_path_equals_single_gpu_path(env):
-    """the multi-GPU code path (stepping tracker + all-reduce, band back-projection + all-gather, band raycast)
-    run with ONE rank over RCCL must reproduce the single-GPU path bit for bit"""
+@pytest.mark.parametrize("exchange", ["allreduce", "none"])
+def test_row_band_path_equals_single_gpu_path(env, exchange):
+    """the multi-GPU code paths -- "allreduce": stepping tracker + all-reduce, band back-projection + all-gather;
+    "none": whole-frame tracker and fusion on every rank; band raycast in both -- run with ONE rank over RCCL must
+    reproduce the single-GPU path bit for bit"""
     pkg, torch, synth, pl = env
     import torch.distributed as dist
     created = False
@@ -68,7 +70,7 @@ def test_row_band_path_equals_single_gpu_path(env):
     try:
         w, h, depth, center, edge = 320, 240, 10, (0.0, 1.5, 0.0), 4.096
         A = pl.SlamPipeline(w, h, depth, center, edge)
-        B = pl.SlamPipeline(w, h, depth, center, edge, dist=pl.DistContext(0, 1, force=True))
+        B = pl.SlamPipeline(w, h, depth, center, edge, dist=pl.DistContext(0, 1, force=True, exchange=exchange))
         for k in range(4):
             d, c = synth.render_frame(k, w, h, device="cuda")
             view = pl.ground_truth_view(k, synth)
