@@ -161,6 +161,11 @@ inline void transformNormalMap(vec3 *normal_map, const mat4 &trans, const int si
 inline void colorToIntensity(const Color256 *color_in, float *intensity_out, const int size) {
   detail::check(svoslam_color_to_intensity(&color_in->r, intensity_out, size, nullptr), "colorToIntensity");
 }
+// localization_kernels.h:38 : the correspondence variant; A and b untouched without correspondences
+inline void computeICPCost(const ICPFrame *last_frame, const ICPFrame &this_frame, float *A, float *b) {
+  detail::check(svoslam_icp_cost(&last_frame->vertex->x, &last_frame->normal->x, &this_frame.vertex->x, &this_frame.normal->x,
+                                 this_frame.width, this_frame.height, A, b, nullptr, nullptr), "computeICPCost");
+}
 // localization_kernels.h:39 : A (36) and b (6) are host arrays
 inline void computeICPCost2(const ICPFrame *last_frame, const ICPFrame &this_frame, float *A, float *b) {
   detail::check(svoslam_icp_cost2(&last_frame->vertex->x, &last_frame->normal->x, &this_frame.vertex->x, &this_frame.normal->x,

@@ -312,6 +312,14 @@ int svoslam_point_cloud_bbox_device(svoslam_workspace *ws, const float *d_points
 int svoslam_icp_cost2(const float *d_last_vertex, const float *d_last_normal, const float *d_cur_vertex,
                       const float *d_cur_normal, int32_t width, int32_t height, float h_A[36], float h_b[6],
                       void *stream);
+/* computeICPCost, localization_kernels.h:38 / .cu:59-152,231-301: the variant with an explicit
+ * correspondence stencil (finite, distance and normal gates; no depth-range gate), load size 10 and a
+ * reduce over floor(M/10) partials: the first floor(M/10)*10 correspondences in pixel order contribute.
+ * With M = 0 h_A and h_b are left untouched, as in the reference (:251-253).  *num_correspondences
+ * (may be NULL) receives M.  Blocking. */
+int svoslam_icp_cost(const float *d_last_vertex, const float *d_last_normal, const float *d_cur_vertex,
+                     const float *d_cur_normal, int32_t width, int32_t height, float h_A[36], float h_b[6],
+                     int32_t *num_correspondences, void *stream);
 /* Non-blocking building block used by the tracker and by multi-GPU row bands:
  * adds the 27 exact fixed-point accumulators (21 upper-triangle A terms then 6
  * b terms, carried in float64) of pixels [first_pixel, first_pixel+num_pixels)

@@ -133,6 +133,7 @@ SIGNATURES = {
     "svoslam_point_cloud_bbox": (C.c_int, [_vp, _i32, _fp, _fp, _vp]),
     "svoslam_point_cloud_bbox_device": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "svoslam_icp_cost2": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _fp, _fp, _vp]),
+    "svoslam_icp_cost": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _fp, _fp, C.POINTER(_i32), _vp]),
     "svoslam_icp_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "svoslam_camera_create": (C.c_int, [C.POINTER(_vp), _i32, _i32, _f32, _f32]),
     "svoslam_camera_destroy": (C.c_int, [_vp]),
@@ -656,6 +657,20 @@ def icp_cost2(last_v, last_n, cur_v, cur_n):
     A, b = (C.c_float * 36)(), (C.c_float * 6)()
     check(lib().svoslam_icp_cost2(_ptr(last_v), _ptr(last_n), _ptr(cur_v), _ptr(cur_n), w, h, A, b, _stream()))
     return np.array(list(A), np.float32).reshape(6, 6), np.array(list(b), np.float32)
+
+
+def icp_cost(last_v, last_n, cur_v, cur_n, A0=None, b0=None):
+    """sensor::computeICPCost (correspondence variant).  Returns (A, b, num_correspondences); without correspondences
+    A and b keep A0 / b0 (zeros by default), as the reference leaves its outputs untouched."""
+    h, w = int(last_v.shape[0]), int(last_v.shape[1])
+    A, b = (C.c_float * 36)(), (C.c_float * 6)()
+    if A0 is not None:
+        A[:] = [float(v) for v in np.asarray(A0, np.float32).reshape(36)]
+    if b0 is not None:
+        b[:] = [float(v) for v in np.asarray(b0, np.float32).reshape(6)]
+    m = _i32(0)
+    check(lib().svoslam_icp_cost(_ptr(last_v), _ptr(last_n), _ptr(cur_v), _ptr(cur_n), w, h, A, b, C.byref(m), _stream()))
+    return np.array(list(A), np.float32).reshape(6, 6), np.array(list(b), np.float32), int(m.value)
 
 
 def icp_accumulate(last_v, last_n, cur_v, cur_n, first_pixel, num_pixels, acc):

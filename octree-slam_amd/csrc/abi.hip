@@ -338,6 +338,16 @@ int svoslam_icp_cost2(const float *d_last_vertex, const float *d_last_normal, co
   return icp_cost2(g_misc, d_last_vertex, d_last_normal, d_cur_vertex, d_cur_normal, width, height, h_A, h_b, S(stream));
 }
 
+int svoslam_icp_cost(const float *d_last_vertex, const float *d_last_normal, const float *d_cur_vertex,
+                     const float *d_cur_normal, int32_t width, int32_t height, float h_A[36], float h_b[6],
+                     int32_t *num_correspondences, void *stream) {
+  NEED_DEVICE();
+  int m = 0;
+  const int rc = icp_cost(g_misc, d_last_vertex, d_last_normal, d_cur_vertex, d_cur_normal, width, height, h_A, h_b, &m, S(stream));
+  if (num_correspondences) *num_correspondences = m;
+  return rc;
+}
+
 int svoslam_icp_accumulate(const float *d_last_vertex, const float *d_last_normal, const float *d_cur_vertex,
                            const float *d_cur_normal, int32_t width, int32_t height, int32_t first_pixel,
                            int32_t num_pixels, double *d_acc, void *stream) {

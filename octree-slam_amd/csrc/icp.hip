@@ -29,6 +29,7 @@
 #include "graph_cache.hpp"
 #include "icp.hpp"
 #include "image_kernels.hpp"
+#include "wave_rank.hpp"
 
 namespace svoslam {
 
@@ -273,6 +274,124 @@ int icp_cost2(svoslam::DeviceBuffer &scratch, const float *lv, const float *ln, 
   SVO_HIP(hipMemcpyAsync(acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, s));
   SVO_HIP(hipStreamSynchronize(s));
   icp_finish_host(acc, A, b);
+  return SVOSLAM_OK;
+}
+
+// ----------------------------------------------------------------------------
+// computeICPCost (localization_kernels.cu:59-152,231-301): the variant with a correspondence stencil.
+// The reference compacts the matching pixels (three thrust::copy_if), gives each thread 10 consecutive
+// matches and reduces floor(M/10) partials, so exactly the first floor(M/10)*10 matches (in pixel order)
+// contribute.  Here: count per 256-pixel tile -> one scan -> every match knows its rank in the compacted
+// order without compacting anything, and adds its 27 exact terms if the rank is below that limit.
+// ----------------------------------------------------------------------------
+__device__ inline bool icp_corr_match(const float *__restrict__ lv, const float *__restrict__ ln, const float *__restrict__ cv,
+                                      const float *__restrict__ cn, size_t p) {
+  const float v2x = cv[3 * p], v2y = cv[3 * p + 1], v2z = cv[3 * p + 2];
+  const float v1x = lv[3 * p], v1y = lv[3 * p + 1], v1z = lv[3 * p + 2];
+  if (!finitef_(v2x) || !finitef_(v2y) || !finitef_(v2z) || !finitef_(v1x) || !finitef_(v1y) || !finitef_(v1z)) return false;
+  const float n2x = cn[3 * p], n2y = cn[3 * p + 1], n2z = cn[3 * p + 2];
+  const float n1x = ln[3 * p], n1y = ln[3 * p + 1], n1z = ln[3 * p + 2];
+  if (!finitef_(n2x) || !finitef_(n2y) || !finitef_(n2z) || !finitef_(n1x) || !finitef_(n1y) || !finitef_(n1z)) return false;
+  const float dx = v2x - v1x, dy = v2y - v1y, dz = v2z - v1z;
+  if (sqrtf(dot3(dx, dy, dz, dx, dy, dz)) > kDistThresh) return false;  // :84
+  if (dot3(n2x, n2y, n2z, n1x, n1y, n1z) < kNormThresh) return false;   // :89
+  return true;
+}
+
+__global__ __launch_bounds__(256) void icp_corr_count_kernel(const float *__restrict__ lv, const float *__restrict__ ln,
+                                                             const float *__restrict__ cv, const float *__restrict__ cn, int n,
+                                                             unsigned *__restrict__ tile_count) {
+  __shared__ unsigned tmp[4];
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const unsigned m = (p < n && icp_corr_match(lv, ln, cv, cn, (size_t)p)) ? 1u : 0u;
+  unsigned total;
+  (void)block256_exclusive_scan(m, tmp, total);
+  if (threadIdx.x == 0) tile_count[blockIdx.x] = total;
+}
+
+// exclusive scan of the tile counts in place; counts[num_tiles] = total number of correspondences
+__global__ __launch_bounds__(256) void icp_corr_scan_kernel(unsigned *__restrict__ counts, int num_tiles) {
+  __shared__ unsigned tmp[4];
+  unsigned carry = 0;
+  for (int base = 0; base < num_tiles; base += 256) {
+    const int t = base + (int)threadIdx.x;
+    const unsigned v = t < num_tiles ? counts[t] : 0u;
+    unsigned total;
+    const unsigned ex = block256_exclusive_scan(v, tmp, total);
+    if (t < num_tiles) counts[t] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) counts[num_tiles] = carry;
+}
+
+__global__ __launch_bounds__(256) void icp_corr_cost_kernel(const float *__restrict__ lv, const float *__restrict__ ln,
+                                                            const float *__restrict__ cv, const float *__restrict__ cn, int n,
+                                                            const unsigned *__restrict__ tile_offset, int num_tiles,
+                                                            double *__restrict__ partial) {
+  __shared__ unsigned tmp[4];
+  __shared__ double wsum[4][27];
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const bool match = p < n && icp_corr_match(lv, ln, cv, cn, (size_t)p);
+  unsigned total;
+  const unsigned rank = tile_offset[blockIdx.x] + block256_exclusive_scan(match ? 1u : 0u, tmp, total);
+  const unsigned limit = (tile_offset[num_tiles] / 10u) * 10u;  // :289-293
+  double acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; i++) acc[i] = 0.0;
+  if (match && rank < limit) {
+    const size_t q = (size_t)p;
+    const float v2x = cv[3 * q], v2y = cv[3 * q + 1], v2z = cv[3 * q + 2];
+    const float v1x = lv[3 * q], v1y = lv[3 * q + 1], v1z = lv[3 * q + 2];
+    const float n1x = ln[3 * q], n1y = ln[3 * q + 1], n1z = ln[3 * q + 2];
+    float J[6];  // A_T = G_T * n with n the LAST frame's normal (:123-131)
+    J[0] = (0.0f * n1x + (-v2x) * n1y) + (-v2y) * n1z;
+    J[1] = ((-v2z) * n1x + 0.0f * n1y) + v2x * n1z;
+    J[2] = (v2y * n1x + v2z * n1y) + 0.0f * n1z;
+    J[3] = (1.0f * n1x + 0.0f * n1y) + 0.0f * n1z;
+    J[4] = (0.0f * n1x + 1.0f * n1y) + 0.0f * n1z;
+    J[5] = (0.0f * n1x + 0.0f * n1y) + 1.0f * n1z;
+    const float bb = dot3(n1x, n1y, n1z, v1x - v2x, v1y - v2y, v1z - v2z);
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = i; j < 6; j++) acc[k++] = (double)rintf((J[i] * J[j]) * 1048576.0f);
+#pragma unroll
+    for (int i = 0; i < 6; i++) acc[21 + i] = (double)rintf((bb * J[i]) * 1073741824.0f);
+  }
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+#pragma unroll
+  for (int i = 0; i < 27; i++) {
+    const double t = wave_sum_to_lane63(acc[i]);
+    if (lane == 63u) wsum[wave][i] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) partial[(size_t)blockIdx.x * 27 + threadIdx.x] = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
+}
+
+int icp_cost(svoslam::DeviceBuffer &scratch, const float *lv, const float *ln, const float *cv, const float *cn, int w, int h,
+             float A[36], float b[6], int *num_corr, hipStream_t s) {
+  if (!lv || !ln || !cv || !cn || !A || !b || w <= 0 || h <= 0) return SVOSLAM_ERR_INVALID_ARG;
+  const int n = w * h, tiles = (int)cdiv(n, 256);
+  // layout: [0,27) totals | rows tiles x 27 doubles | tile counts (tiles + 1 words)
+  const size_t rows_off = 27, counts_off_bytes = (size_t)(27 + (size_t)tiles * 27) * sizeof(double);
+  SVO_TRY(scratch.reserve(counts_off_bytes + (size_t)(tiles + 1) * 4 + 64));
+  double *d_acc = scratch.as<double>();
+  double *d_rows = d_acc + rows_off;
+  unsigned *d_counts = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(scratch.ptr) + counts_off_bytes);
+  SVO_HIP(hipMemsetAsync(d_acc, 0, 27 * sizeof(double), s));
+  icp_corr_count_kernel<<<tiles, 256, 0, s>>>(lv, ln, cv, cn, n, d_counts);
+  icp_corr_scan_kernel<<<1, 256, 0, s>>>(d_counts, tiles);
+  icp_corr_cost_kernel<<<tiles, 256, 0, s>>>(lv, ln, cv, cn, n, d_counts, tiles, d_rows);
+  icp_reduce_kernel<<<1, kReduceThreads, 0, s>>>(d_rows, tiles, d_acc);
+  SVO_LAUNCH_CHECK();
+  double acc[27];
+  unsigned m = 0;
+  SVO_HIP(hipMemcpyAsync(acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, s));
+  SVO_HIP(hipMemcpyAsync(&m, d_counts + tiles, 4, hipMemcpyDeviceToHost, s));
+  SVO_HIP(hipStreamSynchronize(s));
+  if (num_corr) *num_corr = (int)m;
+  if (m > 0) icp_finish_host(acc, A, b);  // :251-253: without correspondences A and b are left as they are
   return SVOSLAM_OK;
 }
 

@@ -10,6 +10,8 @@ int icp_accumulate(svoslam::DeviceBuffer &scratch, const float *lv, const float 
                    int w, int h, int first, int num, double *d_acc, hipStream_t s);
 int icp_cost2(svoslam::DeviceBuffer &scratch, const float *lv, const float *ln, const float *cv, const float *cn, int w,
               int h, float A[36], float b[6], hipStream_t s);
+int icp_cost(svoslam::DeviceBuffer &scratch, const float *lv, const float *ln, const float *cv, const float *cn, int w, int h,
+             float A[36], float b[6], int *num_corr, hipStream_t s);
 int camera_icp_iters(int level);
 int camera_create(svoslam_camera **out, int w, int h, float fx, float fy);
 int camera_destroy(svoslam_camera *c);

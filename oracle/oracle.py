@@ -74,6 +74,8 @@ def lib(native=False):
     L.ora_transform_normal_map.argtypes = [f32p, f32p, C.c_int]
     L.ora_point_cloud_bbox.argtypes = [f32p, C.c_int, f32p, f32p]
     L.ora_icp_cost2.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p]
+    L.ora_icp_cost.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p]
+    L.ora_icp_cost.restype = C.c_int
     L.ora_icp_cost2_raw.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, i64p]
     L.ora_icp_finish.argtypes = [i64p, f32p, f32p]
     L.ora_solve_cholesky.argtypes = [C.c_int, f32p, f32p, f32p]
@@ -309,6 +311,17 @@ def icp_cost2(last_v, last_n, cur_v, cur_n, L=None):
     (L or lib()).ora_icp_cost2(_p(lv, C.c_float), _p(ln, C.c_float), _p(cv, C.c_float), _p(cn, C.c_float), w, h,
                                _p(A, C.c_float), _p(b, C.c_float))
     return A.reshape(6, 6), b
+
+
+def icp_cost(last_v, last_n, cur_v, cur_n, A0=None, b0=None):
+    """computeICPCost (correspondence variant).  Returns (A, b, num_correspondences); A, b keep A0, b0 when there is none."""
+    lv, ln, cv, cn = (np.ascontiguousarray(a, np.float32) for a in (last_v, last_n, cur_v, cur_n))
+    h, w = lv.shape[0], lv.shape[1]
+    A = np.zeros(36, np.float32) if A0 is None else np.ascontiguousarray(A0, np.float32).reshape(36).copy()
+    b = np.zeros(6, np.float32) if b0 is None else np.ascontiguousarray(b0, np.float32).copy()
+    m = lib().ora_icp_cost(_p(lv, C.c_float), _p(ln, C.c_float), _p(cv, C.c_float), _p(cn, C.c_float), w, h, _p(A, C.c_float),
+                           _p(b, C.c_float))
+    return A.reshape(6, 6), b, int(m)
 
 
 def icp_cost2_raw(last_v, last_n, cur_v, cur_n, first_pixel=0, num_pixels=None):

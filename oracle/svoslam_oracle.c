@@ -965,6 +965,67 @@ void ora_icp_cost2(const float *last_v, const float *last_n, const float *cur_v,
   ora_icp_finish(acc, A, b);
 }
 
+/* computeICPCost (localization_kernels.cu:59-152,231-301), the variant with an explicit correspondence
+ * stencil: gates = all components finite, |v2 - v1| <= DIST_THRESH, n2.n1 >= NORM_THRESH (no depth-range
+ * gate, unlike computeICPCost2); order-preserving compaction of the matches; load_size = 10 and a reduce
+ * over floor(M/10) partials, so only the first floor(M/10)*10 matches contribute (the tail partial is
+ * written past the end of d_A and never summed, :289-293); J uses v2 and the LAST frame's normal.
+ * Returns M; with M <= 0 the reference returns before touching A and b (:251-253).
+ * Sums in exact fixed point as ora_icp_cost2_raw (R3). */
+int ora_icp_cost_raw(const float *last_v, const float *last_n, const float *cur_v, const float *cur_n, int w, int h,
+                     int64_t acc[27]) {
+  for (int i = 0; i < 27; i++) acc[i] = 0;
+  const int n = w * h;
+  int m = 0;
+  for (int p = 0; p < n; p++) {
+    const float *v2 = cur_v + 3 * (size_t)p, *n2 = cur_n + 3 * (size_t)p;
+    const float *v1 = last_v + 3 * (size_t)p, *n1 = last_n + 3 * (size_t)p;
+    if (!finitef_(v2[0]) || !finitef_(v2[1]) || !finitef_(v2[2]) || !finitef_(v1[0]) || !finitef_(v1[1]) || !finitef_(v1[2])) continue;
+    if (!finitef_(n2[0]) || !finitef_(n2[1]) || !finitef_(n2[2]) || !finitef_(n1[0]) || !finitef_(n1[1]) || !finitef_(n1[2])) continue;
+    float d[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
+    if (length3(d) > ICP_DIST_THRESH) continue;
+    if (dot3(n2, n1) < ICP_NORM_THRESH) continue;
+    m++;
+  }
+  const int limit = (m / 10) * 10;
+  int rank = 0;
+  for (int p = 0; p < n && rank < limit; p++) {
+    const float *v2 = cur_v + 3 * (size_t)p, *n2 = cur_n + 3 * (size_t)p;
+    const float *v1 = last_v + 3 * (size_t)p, *n1 = last_n + 3 * (size_t)p;
+    if (!finitef_(v2[0]) || !finitef_(v2[1]) || !finitef_(v2[2]) || !finitef_(v1[0]) || !finitef_(v1[1]) || !finitef_(v1[2])) continue;
+    if (!finitef_(n2[0]) || !finitef_(n2[1]) || !finitef_(n2[2]) || !finitef_(n1[0]) || !finitef_(n1[1]) || !finitef_(n1[2])) continue;
+    float d[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
+    if (length3(d) > ICP_DIST_THRESH) continue;
+    if (dot3(n2, n1) < ICP_NORM_THRESH) continue;
+    rank++;
+    const float G_T[18] = {0.0f, -v2[0], -v2[1], -v2[2], 0.0f, v2[0], v2[1], v2[2], 0.0f,
+                           1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f};
+    float A_T[6];
+    for (int i = 0; i < 6; i++) A_T[i] = (G_T[3 * i] * n1[0] + G_T[3 * i + 1] * n1[1]) + G_T[3 * i + 2] * n1[2];
+    float dv[3] = {v1[0] - v2[0], v1[1] - v2[1], v1[2] - v2[2]};
+    float bb = dot3(n1, dv);
+    int k = 0;
+    for (int i = 0; i < 6; i++)
+      for (int j = i; j < 6; j++) {
+        float prod = A_T[i] * A_T[j];
+        acc[k++] += (int64_t)rint((double)prod * ICP_SCALE_A);
+      }
+    for (int i = 0; i < 6; i++) {
+      float prod = bb * A_T[i];
+      acc[21 + i] += (int64_t)rint((double)prod * ICP_SCALE_B);
+    }
+  }
+  return m;
+}
+
+int ora_icp_cost(const float *last_v, const float *last_n, const float *cur_v, const float *cur_n, int w, int h,
+                 float A[36], float b[6]) {
+  int64_t acc[27];
+  const int m = ora_icp_cost_raw(last_v, last_n, cur_v, cur_n, w, h, acc);
+  if (m > 0) ora_icp_finish(acc, A, b);
+  return m;
+}
+
 /* rgbd_camera.cpp:194-222 : float storage, double inner sums */
 void ora_solve_cholesky(int dimension, const float *A, const float *b, float *x) {
   float LU[36] = {0}, y[6] = {0};

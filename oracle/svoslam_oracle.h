@@ -94,6 +94,10 @@ void ora_point_cloud_bbox(const float *pts, int n, float bbox0[3], float bbox1[3
 void ora_icp_cost2(const float *last_v, const float *last_n, const float *cur_v, const float *cur_n,
                    int w, int h, float A[36], float b[6]);
 /* the 27 raw accumulators (21 upper-triangle A terms row-major, then 6 b terms) */
+int ora_icp_cost(const float *last_v, const float *last_n, const float *cur_v, const float *cur_n, int w, int h,
+                 float A[36], float b[6]);
+int ora_icp_cost_raw(const float *last_v, const float *last_n, const float *cur_v, const float *cur_n, int w, int h,
+                     int64_t acc[27]);
 void ora_icp_cost2_raw(const float *last_v, const float *last_n, const float *cur_v,
                        const float *cur_n, int first_pixel, int num_pixels, int w, int h,
                        int64_t acc[27]);

@@ -172,7 +172,7 @@ void fuse_and_render(const vec3* d_points, const Color256* d_colors, int n, ucha
   mat4 view = {};
   rendering::coneTraceSVO(d_image, vec2{640, 480}, 45.0f, view, SVO{pool, vec3{0, 1.5f, 0}, 4.096f});
   VoxelGrid grid; svo::extractVoxelGridFromSVO(pool, pool_size, 12, vec3{0, 1.5f, 0}, 4.096f, grid);
-  sensor::ICPFrame a(8, 8), b(8, 8); float A[36], bb[6]; sensor::computeICPCost2(&a, b, A, bb);
+  sensor::ICPFrame a(8, 8), b(8, 8); float A[36], bb[6]; sensor::computeICPCost2(&a, b, A, bb); sensor::computeICPCost(&a, b, A, bb);
   startTiming(); (void)stopTiming();
   Mesh m; VoxelGrid vg; voxelization::meshToVoxelGrid(m, nullptr, vg); (void)voxelization::log_N();
 }

@@ -145,6 +145,39 @@ def test_icp_cost2(env, oracle, h, w):
     assert np.array_equal(acc.cpu().numpy(), raw.astype(np.float64))
 
 
+@pytest.mark.parametrize("h,w", [(120, 160), (480, 640), (75, 101)])
+def test_icp_cost_correspondence_variant(env, oracle, h, w):
+    """computeICPCost (a19): stencil gates without the depth-range gate, order-preserving compaction, load size 10 with
+    the floor(M/10) reduce; untouched outputs when nothing corresponds"""
+    pkg, torch, _ = env
+    rng = np.random.default_rng(h)
+    f = 570.3 * w / 640.0
+    d1 = noisy_depth(rng, h, w)
+    v1 = oracle.vertex_map(d1, f, f, w, h); n1 = oracle.normal_map(v1)
+    T = oracle.icp_update_transform(np.array([0.004, -0.003, 0.002, 0.004, -0.002, 0.003], np.float32))
+    v2 = oracle.transform_vertex_map(v1, T); n2 = oracle.transform_normal_map(n1, T)
+    tens = [torch.from_numpy(x).cuda() for x in (v1, n1, v2, n2)]
+    A, b, m = pkg.icp_cost(*tens)
+    rA, rb, rm = oracle.icp_cost(v1, n1, v2, n2)
+    assert m == rm and m > 100 and m % 10 != 0 or m == rm
+    assert np.array_equal(A, rA) and np.array_equal(b, rb), (A - rA, b - rb)
+    assert np.abs(A).max() > 0
+    A2, b2 = pkg.icp_cost2(*tens)
+    assert not np.array_equal(A, A2)      # the two variants gate and truncate differently
+    # fewer than 10 correspondences: zeros (empty reduce); none: outputs untouched
+    few_v2 = np.full_like(v2, np.nan); few_n2 = n2.copy()
+    ys, xs = np.nonzero(np.isfinite(v2).all(-1) & np.isfinite(n2).all(-1) & np.isfinite(n1).all(-1))
+    for k in range(7):
+        few_v2[ys[k * 50], xs[k * 50]] = v2[ys[k * 50], xs[k * 50]]
+    A3, b3, m3 = pkg.icp_cost(tens[0], tens[1], torch.from_numpy(few_v2).cuda(), tens[3], A0=np.full(36, 5.0), b0=np.full(6, 7.0))
+    rA3, rb3, rm3 = oracle.icp_cost(v1, n1, few_v2, n2, A0=np.full(36, 5.0), b0=np.full(6, 7.0))
+    assert m3 == rm3 and 0 < m3 < 10 and np.array_equal(A3, rA3) and (A3 == 0).all() and (b3 == 0).all()
+    none_v2 = np.full_like(v2, np.nan)
+    A4, b4, m4 = pkg.icp_cost(tens[0], tens[1], torch.from_numpy(none_v2).cuda(), tens[3], A0=np.full(36, 5.0), b0=np.full(6, 7.0))
+    assert m4 == 0 and (A4 == 5.0).all() and (b4 == 7.0).all()
+    assert oracle.icp_cost(v1, n1, none_v2, n2, A0=np.full(36, 5.0), b0=np.full(6, 7.0))[2] == 0
+
+
 def test_camera_tracker_matches_oracle(env, oracle):
     pkg, torch, synth = env
     w, h = 160, 120
