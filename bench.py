@@ -204,7 +204,7 @@ def main():
                                        "raycast in %d row bands; tracker + fusion on every rank, no data-path collective" % world
                                        if args.exchange == "none" else
                                        "%d row bands: ICP all-reduce (19 per frame) + point all-gather, replicated pool" % world),
-                       "overlap": "none" if args.no_overlap else "3 HIP streams: track(k+1) | back-project+sort+plan(k+1) | commit+raycast(k)",
+                       "overlap": "none" if args.no_overlap else "4 HIP streams: maps(k+2) | ICP(k+1) | back-project+sort+plan(k+1) | commit+raycast(k)",
                        "pool_nodes_end": P.pool.size, "mrays_per_s": width * rows / (kern_ms * 1e-3) / 1e6,
                        "tracking_lost_levels": P.cam.tracking_lost_count()},
             "roofline": {"bound": "hbm", "kernel": "cone_trace_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
