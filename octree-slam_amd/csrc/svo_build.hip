@@ -460,21 +460,28 @@ __global__ __launch_bounds__(256) void fill_mip_local_kernel(const u64 *__restri
 }
 
 // straddling nodes deepest level first, then the root quirk (Q6) and the device-side size
-__global__ __launch_bounds__(1024) void mip_straddle_kernel(u32 *__restrict__ pool, const u32 *__restrict__ strad, int num_tiles,
+#ifndef SVO_STRAD_THREADS
+#define SVO_STRAD_THREADS 1024
+#endif
+#ifndef SVO_STRAD_SLOTS
+#define SVO_STRAD_SLOTS 4
+#endif
+constexpr int kStradThreads = SVO_STRAD_THREADS;
+__global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__restrict__ pool, const u32 *__restrict__ strad, int num_tiles,
                                                             int depth, const PlanCounts *__restrict__ counts,
                                                             int *__restrict__ d_size) {
   SVO_HIGH_PRIO();  // commit kernels sit between two raycasts on the map stream
   // a thread's list entries do not depend on the levels below, so those of the next level are fetched while
   // this level's tiles are averaged (one dependent load per level instead of two); kSlots entries per thread
   // in registers cover 4096 workgroups (1 M points), longer lists fall back to the plain loop
-  constexpr int kSlots = 4;
+  constexpr int kSlots = SVO_STRAD_SLOTS;
   const uint2 *list = reinterpret_cast<const uint2 *>(strad);
-  const bool fits = num_tiles <= kSlots * 1024;
+  const bool fits = num_tiles <= kSlots * kStradThreads;
   uint2 cur[kSlots], nxt[kSlots];
   auto fetch = [&](int d, uint2 *e) {
 #pragma unroll
     for (int q = 0; q < kSlots; q++) {
-      const int t = (int)threadIdx.x + 1024 * q;
+      const int t = (int)threadIdx.x + kStradThreads * q;
       e[q] = (d >= 1 && t < num_tiles) ? list[(size_t)d * num_tiles + t] : make_uint2(kNoStraddler, 0u);
     }
   };
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(1024) void mip_straddle_kernel(u32 *__restrict__ po
 #pragma unroll
       for (int q = 0; q < kSlots; q++) cur[q] = nxt[q];
     } else {
-      for (int t = (int)threadIdx.x; t < num_tiles; t += 1024) {
+      for (int t = (int)threadIdx.x; t < num_tiles; t += kStradThreads) {
         const uint2 e = list[(size_t)d * num_tiles + t];
         if (e.x != kNoStraddler) pool[2 * (size_t)e.x + 1] = average_tile(pool, e.y);
       }
@@ -910,7 +917,7 @@ int svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int n, int d
                                                        ws->rec_pass.as<unsigned char>(), small_bucket_base(ws), small_counts(ws),
                                                        pool->d_data, pool->d_size, depth);
     fill_mip_local_kernel<<<tiles, 256, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, tiles);
-    mip_straddle_kernel<<<1, 1024, 0, stream>>>(pool->d_data, strad, tiles, depth, small_counts(ws), pool->d_size);
+    mip_straddle_kernel<<<1, kStradThreads, 0, stream>>>(pool->d_data, strad, tiles, depth, small_counts(ws), pool->d_size);
     SVO_LAUNCH_CHECK();
     return SVOSLAM_OK;
   };
