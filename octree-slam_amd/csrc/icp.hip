@@ -60,7 +60,10 @@ struct CamState {
 // ----------------------------------------------------------------------------
 constexpr int kIcpThreads = 512;   // 8 wavefronts per workgroup
 constexpr int kIcpWaves = kIcpThreads / kWave;
-constexpr int kMaxIcpBlocks = 256;
+#ifndef SVO_ICP_BLOCKS
+#define SVO_ICP_BLOCKS 256
+#endif
+constexpr int kMaxIcpBlocks = SVO_ICP_BLOCKS;
 
 // iteration flags (host-known)
 constexpr int kFlagLevelStart = 1;  // level < 2: the level's copy is first transformed by update_trans (:116-120)
