@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void fill_mip_local_kernel(const u64 *__restri
 #define SVO_STRAD_THREADS 1024
 #endif
 #ifndef SVO_STRAD_SLOTS
-#define SVO_STRAD_SLOTS 4
+#define SVO_STRAD_SLOTS 8
 #endif
 constexpr int kStradThreads = SVO_STRAD_THREADS;
 __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__restrict__ pool, const u32 *__restrict__ strad, int num_tiles,
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__rest
   SVO_HIGH_PRIO();  // commit kernels sit between two raycasts on the map stream
   // a thread's list entries do not depend on the levels below, so those of the next level are fetched while
   // this level's tiles are averaged (one dependent load per level instead of two); kSlots entries per thread
-  // in registers cover 4096 workgroups (1 M points), longer lists fall back to the plain loop
+  // in registers cover 8192 workgroups (2 M points: 1920x1080), longer lists fall back to the plain loop
   constexpr int kSlots = SVO_STRAD_SLOTS;
   const uint2 *list = reinterpret_cast<const uint2 *>(strad);
   const bool fits = num_tiles <= kSlots * kStradThreads;
