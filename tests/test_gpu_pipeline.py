@@ -124,3 +124,43 @@ def test_stream_overlap_equals_sequential(env, capacity):
             assert np.array_equal(imgs[k].cpu().numpy(), seq_imgs[k]), (rep, k)
         assert A.pool.size == B.pool.size and np.array_equal(A.pool.words(), B.pool.words())
         assert np.array_equal(A.cam.pose()[1], B.cam.pose()[1])
+
+
+def test_phase_api_contracts(env):
+    """the split entry points refuse calls out of order instead of running on stale state"""
+    pkg, torch, synth, pl = env
+    ws, pool = pkg.Workspace(), pkg.Pool()
+    pts = torch.rand((1000, 3), device="cuda") - 0.5
+    col = torch.randint(0, 256, (1000, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(pkg.SvoslamError):      # plan before sort
+        pkg.svo_fuse_plan(ws, 1000, 8, pool)
+    pkg.svo_fuse_sort(ws, pts, 8, (0, 0, 0), 1.0)
+    with pytest.raises(pkg.SvoslamError):      # commit before plan
+        pkg.svo_fuse_commit(ws, col, 8, pool)
+    pkg.svo_fuse_plan(ws, 1000, 8, pool)
+    with pytest.raises(pkg.SvoslamError):      # commit of a different batch size than planned
+        pkg.svo_fuse_commit(ws, col[:500], 8, pool)
+    pkg.svo_fuse_commit(ws, col, 8, pool)
+    with pytest.raises(pkg.SvoslamError):      # a plan is consumed by its commit
+        pkg.svo_fuse_commit(ws, col, 8, pool)
+    ref = pkg.Pool()
+    pkg.svo_from_point_cloud(pkg.Workspace(), pts, col, 8, ref, (0, 0, 0), 1.0)
+    assert pool.size == ref.size and np.array_equal(pool.words(), ref.words())
+    # camera: at most two frames prepared ahead; track needs a prepared frame; update refuses to interleave
+    w, h = 160, 120
+    cam = pkg.Camera(w, h, 142.6, 142.6)
+    frames = [synth.render_frame(k, w, h, device="cuda") for k in range(3)]
+    with pytest.raises(pkg.SvoslamError):
+        cam.track_prepared()
+    assert cam.prepare(frames[0][0], frames[0][1], 0) == 1
+    assert cam.prepare(frames[1][0], frames[1][1], 1) == 1
+    with pytest.raises(pkg.SvoslamError):
+        cam.prepare(frames[2][0], frames[2][1], 2)
+    with pytest.raises(pkg.SvoslamError):
+        cam.update(frames[2][0], frames[2][1], 2)
+    cam.track_prepared(); cam.track_prepared()
+    assert cam.prepare(frames[1][0], frames[1][1], 1) == 0        # stale timestamp: not used (rgbd_camera.cpp:55-59)
+    other = pkg.Camera(w, h, 142.6, 142.6)
+    for k in range(2):
+        other.update(frames[k][0], frames[k][1], k)
+    assert np.array_equal(cam.pose()[1], other.pose()[1]) and np.array_equal(cam.pose()[0], other.pose()[0])
