@@ -75,15 +75,19 @@ __device__ inline float length3(float x, float y, float z) { return sqrtf(dot3(x
 // bracket S[bits-1] < t <= S[bits] is CHECKED; a lane whose bracket is not confirmed
 // (extreme centre/size ratios, NaN) falls back to the reference's own chain.  The table
 // holds exactly the floats the chain produces, so the bits are the reference's bits.
-// Two tables: the first kLdsDepth levels live in LDS (48 KB per workgroup, copied at kernel start) and are
-// consulted every step; levels kLdsDepth+1..kTabDepth come from a global (L2-resident) table only
+// Two tables: the first 11 or 12 levels live in LDS (25 / 49 KB per workgroup, copied at kernel start) and are
+// consulted every step; the levels below them, down to kTabDepth, come from a global (L2-resident) table only
 // when a walk actually goes that deep.
 constexpr int kTabDepth = 16;                   // == SVOSLAM_MAX_DEPTH: every level a pool of this library can have
 constexpr int kTabCells = 1 << kTabDepth;
 constexpr int kTabStride = kTabCells + 3;       // [-inf, -inf, S[0..2^T-2], +inf, +inf]
-constexpr int kLdsDepth = 12;
-constexpr int kLdsCells = 1 << kLdsDepth;
-constexpr int kLdsStride = kLdsCells + 3;
+// The LDS table is compiled for 11 and for 12 levels (25 / 49 KB per workgroup); the host picks 11 when the LOD
+// depth at one metre does not exceed it (640x480 at a 4 m half edge), which leaves the LDS to the kernels of the
+// other streams (+3 % frames/s), and 12 otherwise (1920x1080: 2 % faster than 11).
+constexpr int kLdsDepthMax = 12;
+constexpr int kLdsStrideMax = (1 << kLdsDepthMax) + 3;
+__host__ __device__ constexpr int lds_cells(int d) { return 1 << d; }
+__host__ __device__ constexpr int lds_stride(int d) { return (1 << d) + 3; }
 constexpr int kTraceThreads = 512;              // 3 workgroups x 8 waves per CU next to 3 x 49 KB of LDS
 
 // ---- level grid ------------------------------------------------------------
@@ -108,6 +112,7 @@ struct TraceParams {
   int row_first, row_end;  // rows [row_first, row_end) are traced (row band of a multi-GPU tile split)
   // lookup helpers (host-computed)
   float lo[3], inv_cell, inv_cell_lds;   // guess of the table cell: (t - lo) * inv_cell
+  int lds_depth;                          // levels of the LDS table of this render (11 or 12)
   uint32_t lod_first, lod_span, size_man;  // fast LOD: valid when bits(pix_size) - lod_first <= lod_span
   int size_exp;
 };
@@ -134,10 +139,11 @@ __global__ __launch_bounds__(256) void build_accel_kernel(const uint32_t *__rest
     return;
   }
   e -= kGridEntries;
-  if (e < 3 * (kTabStride + kLdsStride)) {
-    // fine table (kTabDepth levels) followed by the LDS image (kLdsDepth levels)
+  if (e < 3 * (kTabStride + kLdsStrideMax)) {
+    // fine table (kTabDepth levels) followed by the LDS image (P.lds_depth levels)
     const bool fine = e < 3 * kTabStride;
-    const int T = fine ? kTabDepth : kLdsDepth, stride = fine ? kTabStride : kLdsStride;
+    const int T = fine ? kTabDepth : P.lds_depth, stride = fine ? kTabStride : lds_stride(P.lds_depth);
+    if (!fine && e - 3 * kTabStride >= 3 * stride) return;
     const int r = fine ? e : e - 3 * kTabStride;
     const int axis = r / stride, i = r - axis * stride;
     float v;
@@ -159,17 +165,18 @@ __global__ __launch_bounds__(256) void build_accel_kernel(const uint32_t *__rest
     table[e] = v;
     return;
   }
-  e -= 3 * (kTabStride + kLdsStride);
+  e -= 3 * (kTabStride + kLdsStrideMax);
   // (float)alpha / 127.0f of :110-112 for alpha = A - 127 in [-127, 128]: 256 IEEE quotients, computed once
   if (e < 256) alpha_lut[e] = (float)(e - 127) / 127.0f;
 }
 
 struct __attribute__((packed, aligned(4))) Float4U { float a, b, c, d; };
 
-// kLdsDepth octant bits of one coordinate from the LDS table
+// LDSD octant bits of one coordinate from the LDS table
+template <int LDSD>
 __device__ inline uint32_t axis_bits_lds(float t, float lo, float inv_cell, const float *tab, bool &ok) {
   int g = (int)((t - lo) * inv_cell);
-  g = g < 0 ? 0 : (g > kLdsCells - 1 ? kLdsCells - 1 : g);
+  g = g < 0 ? 0 : (g > lds_cells(LDSD) - 1 ? lds_cells(LDSD) - 1 : g);
   const float a = tab[g], b = tab[g + 1], c = tab[g + 2], d = tab[g + 3];  // S[g-2..g+1]
   const bool c0 = a < t, c1 = b < t, c2 = c < t, c3 = d < t;
   ok = ok && c0 && !c3;
@@ -228,10 +235,11 @@ __device__ __forceinline__ void walk_deep(const uint2 *__restrict__ nodes, const
 }
 
 // walk from the root for an LOD depth above the grid level (1 <= depth < kGridLevel)
+template <int LDSD>
 __device__ __forceinline__ void walk_shallow(const uint2 *__restrict__ nodes, uint32_t xb, uint32_t yb, uint32_t zb, int &depth, uint32_t &w1) {
   uint32_t child_idx = 0;
   for (int i = 1; i <= depth; i++) {
-    const int sh = kLdsDepth - i;
+    const int sh = LDSD - i;
     const uint32_t oct = ((xb >> sh) & 1u) | (((yb >> sh) & 1u) << 1) | (((zb >> sh) & 1u) << 2);
     const uint2 nd = nodes[child_idx + oct];
     w1 = nd.y;
@@ -244,12 +252,14 @@ __device__ __forceinline__ void walk_shallow(const uint2 *__restrict__ nodes, ui
 // pixel stays 0 until the ray retires (Q9), so a sample's colour matters only on the step that
 // retires the ray: the march needs alpha alone and the colour is formed once, after the loop.
 // CARRY = true: the local pixel is carried across steps.
-template <bool CARRY>
+template <bool CARRY, int LDSD>
 __global__ __launch_bounds__(kTraceThreads) void cone_trace_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
                                                          const uint2 *__restrict__ grid, const float *__restrict__ table,
                                                          const float *__restrict__ alpha_lut_g, TraceParams P,
                                                          unsigned long long *__restrict__ counters) {
   __shared__ float alpha_lut[256];
+  constexpr int kLdsDepth = LDSD;
+  constexpr int kLdsStride = lds_stride(LDSD);
   __shared__ float lds_tab[3 * kLdsStride];
   if (threadIdx.x < 256) alpha_lut[threadIdx.x] = alpha_lut_g[threadIdx.x];
   {
@@ -308,9 +318,9 @@ __global__ __launch_bounds__(kTraceThreads) void cone_trace_kernel(uchar4 *__res
       }
       // octant bits of every level, per axis
       bool ok = true;
-      uint32_t xb = axis_bits_lds(tx, P.lo[0], P.inv_cell_lds, lds_tab, ok);
-      uint32_t yb = axis_bits_lds(ty, P.lo[1], P.inv_cell_lds, lds_tab + kLdsStride, ok);
-      uint32_t zb = axis_bits_lds(tz, P.lo[2], P.inv_cell_lds, lds_tab + 2 * kLdsStride, ok);
+      uint32_t xb = axis_bits_lds<LDSD>(tx, P.lo[0], P.inv_cell_lds, lds_tab, ok);
+      uint32_t yb = axis_bits_lds<LDSD>(ty, P.lo[1], P.inv_cell_lds, lds_tab + kLdsStride, ok);
+      uint32_t zb = axis_bits_lds<LDSD>(tz, P.lo[2], P.inv_cell_lds, lds_tab + 2 * kLdsStride, ok);
       if (!ok) {
         xb = axis_bits_chain(tx, P.center[0], P.size, kLdsDepth);
         yb = axis_bits_chain(ty, P.center[1], P.size, kLdsDepth);
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(kTraceThreads) void cone_trace_kernel(uchar4 *__res
         }
       } else if (depth >= 1) {
         // LOD coarser than the grid (sample farther than ~size/(32 pix_scale)): the reference's walk from the root
-        walk_shallow(nodes, xb, yb, zb, depth, w1);
+        walk_shallow<LDSD>(nodes, xb, yb, zb, depth, w1);
       } else {
         w1 = octree[1];  // depth <= 0: the reference reads node 0 (:107 with node_idx = 0)
       }
@@ -497,7 +507,11 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   // lookup helpers: the table-cell guess and the operand range of the fast LOD form
   for (int k = 0; k < 3; k++) P.lo[k] = center[k] - size;
   P.inv_cell = (float)kTabCells / (2.0f * size);
-  P.inv_cell_lds = (float)kLdsCells / (2.0f * size);
+  {  // LDS table depth: 11 if the LOD depth one metre from the camera does not exceed it, else 12
+    const float q = size / P.pix_scale;  // = size / pix_size at ray length 1
+    P.lds_depth = (q > 0.0f && q <= 2048.0f) ? 11 : kLdsDepthMax;
+  }
+  P.inv_cell_lds = (float)lds_cells(P.lds_depth) / (2.0f * size);
   {
     uint32_t us;
     memcpy(&us, &size, 4);
@@ -515,17 +529,22 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   }
   dim3 grid(cdiv(width, 32), cdiv(rows, 16));
   static DeviceBuffer accel;  // grid 2 MB + tables 0.8 MB, library-owned (calls from several host threads must be serialised)
-  const size_t accel_bytes = (size_t)kGridEntries * sizeof(uint2) + (size_t)(3 * (kTabStride + kLdsStride) + 256) * sizeof(float) + 64;
+  const size_t accel_bytes = (size_t)kGridEntries * sizeof(uint2) + (size_t)(3 * (kTabStride + kLdsStrideMax) + 256) * sizeof(float) + 64;
   SVO_TRY(accel.reserve(accel_bytes));
   uint2 *d_grid = accel.as<uint2>();
   float *d_table = reinterpret_cast<float *>(d_grid + kGridEntries);
-  float *alpha_lut = d_table + 3 * (kTabStride + kLdsStride);
-  build_accel_kernel<<<cdiv(kGridEntries + 3 * (kTabStride + kLdsStride) + 256, 256), 256, 0, stream>>>(d_octree, d_grid, d_table, alpha_lut, P);
+  float *alpha_lut = d_table + 3 * (kTabStride + kLdsStrideMax);
+  build_accel_kernel<<<cdiv(kGridEntries + 3 * (kTabStride + kLdsStrideMax) + 256, 256), 256, 0, stream>>>(d_octree, d_grid, d_table, alpha_lut, P);
   SVO_TRY(timing_event(stream));
-  if ((mode & 0xFF) == SVOSLAM_RENDER_CARRY)
-    cone_trace_kernel<true><<<grid, kTraceThreads, 0, stream>>>(reinterpret_cast<uchar4 *>(d_pos), d_octree, d_grid, d_table, alpha_lut, P, d_steps);
-  else
-    cone_trace_kernel<false><<<grid, kTraceThreads, 0, stream>>>(reinterpret_cast<uchar4 *>(d_pos), d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+  uchar4 *out = reinterpret_cast<uchar4 *>(d_pos);
+  const bool carry = (mode & 0xFF) == SVOSLAM_RENDER_CARRY;
+  if (P.lds_depth == 11) {
+    if (carry) cone_trace_kernel<true, 11><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    else cone_trace_kernel<false, 11><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+  } else {
+    if (carry) cone_trace_kernel<true, 12><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    else cone_trace_kernel<false, 12><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+  }
   SVO_TRY(timing_event(stream));
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;

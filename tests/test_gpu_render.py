@@ -126,3 +126,16 @@ def test_cone_trace_timing_log(env, oracle):
     pkg.cone_trace_timing(False)
     assert n == 3 and 0.0 < ms < 100.0
     assert pkg.cone_trace_timing_read() == (0.0, 0)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_render_tall_image_large_root_uses_the_12_level_lds_table(env, oracle, mode):
+    """root half edge / pixel size > 2048 (1080-row images of an 8 m cube): the kernel variant with the 12-level LDS
+    table is selected (the other render tests run the 11-level variant)"""
+    pkg, torch = env
+    center, edge = (0.0, 0.0, 0.0), 8.192
+    ws, pool, opool = build_pool(pkg, torch, oracle, 14, 2, n=20000, edge=edge, center=center, scale=5.0)
+    words = opool.words()
+    for eye, tgt in (((0.5, 1.0, -11.0), (0, 0, 0)), ((1.0, 0.5, 2.6), (0.5, -1.0, -1.5))):
+        view = oracle.look_at(eye, tgt, (0, 1, 0))
+        render_both(pkg, torch, oracle, pool, words, 40, 1100, view, center, edge, mode)
