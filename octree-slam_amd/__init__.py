@@ -74,6 +74,8 @@ SIGNATURES = {
     "svoslam_pool_reserve": (C.c_int, [C.POINTER(_PoolStruct), _i32, _vp]),
     "svoslam_pool_free": (C.c_int, [C.POINTER(_PoolStruct)]),
     "svoslam_pool_sync": (C.c_int, [C.POINTER(_PoolStruct), _vp]),
+    "svoslam_pool_reset": (C.c_int, [C.POINTER(_PoolStruct), _vp]),
+    "svoslam_camera_reset": (C.c_int, [_vp]),
     "svoslam_pool_save": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _fp, _f32, _i32, _vp]),
     "svoslam_pool_load": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _fp, C.POINTER(_f32), C.POINTER(_i32), _vp]),
     "svoslam_svo_from_point_cloud_async": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _fp, _f32, _vp]),
@@ -274,6 +276,10 @@ class Pool:
         if r != 0:
             raise SvoslamError("hipMemcpy H2D failed: %d" % r)
         self._p.size = nodes
+
+    def reset(self):
+        """empty map (8 zeroed root children), same allocation"""
+        check(lib().svoslam_pool_reset(C.byref(self._p), _stream()))
 
     def save(self, path, center, edge_length, max_depth):
         """checkpoint: linear tree + root parameters (svoslam_pool_save)"""
@@ -692,6 +698,10 @@ class Camera:
         used = C.c_int32(0)
         check(lib().svoslam_camera_update(self._h, _ptr(depth), _ptr(rgb), int(timestamp), C.byref(used), _stream()))
         return int(used.value)
+
+    def reset(self):
+        """identity pose, no frame seen; buffers and recorded graphs kept"""
+        check(lib().svoslam_camera_reset(self._h))
 
     def prepare(self, depth, rgb, timestamp):
         """first half of update(): bilateral filter + pyramids of the next frame (may run ahead on another stream)"""

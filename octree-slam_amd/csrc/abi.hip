@@ -98,6 +98,14 @@ int svoslam_pool_free(svoslam_pool *pool) {
   pool->d_size = nullptr; pool->pending = 0; pool->pending_bound = 0;
   return SVOSLAM_OK;
 }
+int svoslam_pool_reset(svoslam_pool *pool, void *stream) {
+  NEED_DEVICE();
+  return pool_reset(pool, S(stream));
+}
+int svoslam_camera_reset(svoslam_camera *cam) {
+  NEED_DEVICE();
+  return camera_reset(cam);
+}
 int svoslam_pool_sync(svoslam_pool *pool, void *stream) {
   NEED_DEVICE();
   return pool_sync(pool, S(stream));

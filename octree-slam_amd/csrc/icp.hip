@@ -763,6 +763,9 @@ static const int kPyramidIters[3] = {10, 5, 4};  // rgbd_camera.cpp:19
 
 int camera_icp_iters(int level) { return (level >= 0 && level < 3) ? kPyramidIters[level] : 0; }
 
+int camera_reset(svoslam_camera *c);
+int camera_destroy(svoslam_camera *c);
+
 int camera_create(svoslam_camera **out, int w, int h, float fx, float fy) {
   if (!out || w < 8 || h < 8) return SVOSLAM_ERR_INVALID_ARG;
   SVO_TRY(ensure_device());
@@ -779,6 +782,18 @@ int camera_create(svoslam_camera **out, int w, int h, float fx, float fy) {
   }
   SVO_HIP(hipMalloc((void **)&c->d_state, sizeof(CamState)));
   SVO_HIP(hipMalloc((void **)&c->d_partial, (size_t)kMaxIcpBlocks * 27 * sizeof(double)));
+  c->d_acc = c->d_state->acc;
+  const int rc = camera_reset(c);
+  if (rc != SVOSLAM_OK) { camera_destroy(c); return rc; }
+  *out = c;
+  return SVOSLAM_OK;
+}
+
+// back to the state of a new RGBDCamera (pose identity, no frame seen); device buffers and the recorded
+// launch graphs are kept.  Blocking (waits for the device).
+int camera_reset(svoslam_camera *c) {
+  if (!c) return SVOSLAM_ERR_INVALID_ARG;
+  SVO_HIP(hipDeviceSynchronize());
   CamState init;
   memset(&init, 0, sizeof(init));
   init.orientation[0] = init.orientation[4] = init.orientation[8] = 1.0f;  // glm::mat3() = identity, vec3() = 0
@@ -787,8 +802,10 @@ int camera_create(svoslam_camera **out, int w, int h, float fx, float fy) {
     for (int r = 0; r < 4; r++) init.fusion_ring[r][i] = 1.0f;
   }
   SVO_HIP(hipMemcpy(c->d_state, &init, sizeof(init), hipMemcpyHostToDevice));
-  c->d_acc = c->d_state->acc;
-  *out = c;
+  c->have_stamp = false; c->latest_stamp = 0;
+  c->prepared = 0; c->tracked = 0;
+  c->frame_has_icp = false;
+  c->ring_slot = 0;
   return SVOSLAM_OK;
 }
 

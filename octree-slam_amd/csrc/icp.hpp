@@ -15,6 +15,7 @@ int icp_cost(svoslam::DeviceBuffer &scratch, const float *lv, const float *ln, c
 int camera_icp_iters(int level);
 int camera_create(svoslam_camera **out, int w, int h, float fx, float fy);
 int camera_destroy(svoslam_camera *c);
+int camera_reset(svoslam_camera *c);
 int camera_begin(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp, int32_t *processed, hipStream_t s);
 int camera_prepare(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp, int32_t *processed, hipStream_t s);
 int camera_track(svoslam_camera *c, hipStream_t s);

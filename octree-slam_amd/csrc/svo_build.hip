@@ -638,6 +638,17 @@ int pool_init(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream) {
   return ensure_device_size(pool, stream);
 }
 
+// back to initOctree (8 zeroed root children) keeping the allocation, so recorded launch graphs stay valid.  Blocking.
+int pool_reset(svoslam_pool *pool, hipStream_t stream) {
+  if (!pool || !pool->d_data) return SVOSLAM_ERR_INVALID_ARG;
+  SVO_HIP(hipDeviceSynchronize());
+  SVO_TRY(pool_sync(pool, stream));  // drains the size tracker
+  SVO_HIP(hipMemset(pool->d_data, 0, 64));
+  pool->size = 8; pool->pending = 0; pool->pending_bound = 0;
+  if (pool->d_size) SVO_HIP(hipMemcpy(pool->d_size, &pool->size, 4, hipMemcpyHostToDevice));
+  return SVOSLAM_OK;
+}
+
 int pool_reserve(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream) {
   if (!pool) return SVOSLAM_ERR_INVALID_ARG;
   return grow_pool(pool, capacity_nodes, stream);

@@ -120,6 +120,13 @@ class SlamPipeline:
             self.cam.set_band(self.first, self.rows)
         self.last_stats = None
 
+    def reset(self):
+        """empty map and a fresh tracker; allocations, streams and the launch graphs recorded so far are kept"""
+        self.pool.reset()
+        self.cam.reset()
+        if self.counters is not None:
+            self.counters.zero_()
+
     # -- stages (each enqueues on the current stream) -------------------------------------
     def track(self, depth, rgb, timestamp):
         if not self.band_exchange:

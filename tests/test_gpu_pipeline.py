@@ -164,3 +164,25 @@ def test_phase_api_contracts(env):
     for k in range(2):
         other.update(frames[k][0], frames[k][1], k)
     assert np.array_equal(cam.pose()[1], other.pose()[1]) and np.array_equal(cam.pose()[0], other.pose()[0])
+
+
+def test_pipeline_reset_replays_identically(env):
+    """reset() (bench.py's initialisation pass relies on it): empty map + fresh tracker on the same allocations and
+    recorded graphs reproduce a fresh pipeline bit for bit"""
+    pkg, torch, synth, pl = env
+    w, h, depth, center, edge, n = 160, 120, 8, (0.0, 1.5, 0.0), 4.096, 7
+    frames = [synth.render_frame(k, w, h, device="cuda") for k in range(n)]
+    views = [pl.ground_truth_view(k, synth) for k in range(n)]
+    ds, cs = [f[0] for f in frames], [f[1] for f in frames]
+    A = pl.SlamPipeline(w, h, depth, center, edge)
+    ref = []
+    A.run_stream(ds, cs, list(range(n)), views, on_render=lambda i, im: ref.append(im.clone()) if im is not None else None)
+    torch.cuda.synchronize()
+    words, pose = A.pool.words().copy(), A.cam.pose()
+    A.reset()
+    assert A.pool.size == 8 and not A.pool.words().any()
+    again = []
+    A.run_stream(ds, cs, list(range(n)), views, on_render=lambda i, im: again.append(im.clone()) if im is not None else None)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(ref, again))
+    assert np.array_equal(A.pool.words(), words) and np.array_equal(A.cam.pose()[1], pose[1])
