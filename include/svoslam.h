@@ -82,6 +82,12 @@ int svoslam_pool_free(svoslam_pool *pool);
 int svoslam_pool_reset(svoslam_pool *pool, void *stream);
 /* makes pool->size exact again after asynchronous fusion calls (one stream sync + 4-byte readback) */
 int svoslam_pool_sync(svoslam_pool *pool, void *stream);
+/* Growing the mapped volume (a correct Octree::expandBySize, octree.cpp:362-378 -- the reference
+ * rescales size_ without moving a node, Q16).  One doubling of the root cube towards `toward`: the old
+ * root's children move to a new tile, nodes 0..7 become the new root's children, the one holding the old
+ * root is flagged and coloured with its mean; all other node indices are unchanged.  center[3] and
+ * *edge_length (half edge) are updated; fuse with max_depth + 1 afterwards to keep the resolution.  Blocking. */
+int svoslam_pool_expand(svoslam_pool *pool, float center[3], float *edge_length, const float toward[3], void *stream);
 /* Checkpoint / resume of a map.  The file is the linear tree as it sits in HBM -- the
  * layout OctreeNode::pushToGPU assembles (src/world/octree.cpp:41-79) -- behind a 64-byte header
  * (magic "SVOPOOL1", node count, root centre / half edge / depth, FNV-1a checksum).  Blocking; both wait

@@ -75,6 +75,7 @@ SIGNATURES = {
     "svoslam_pool_free": (C.c_int, [C.POINTER(_PoolStruct)]),
     "svoslam_pool_sync": (C.c_int, [C.POINTER(_PoolStruct), _vp]),
     "svoslam_pool_reset": (C.c_int, [C.POINTER(_PoolStruct), _vp]),
+    "svoslam_pool_expand": (C.c_int, [C.POINTER(_PoolStruct), _fp, C.POINTER(_f32), _fp, _vp]),
     "svoslam_camera_reset": (C.c_int, [_vp]),
     "svoslam_pool_save": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _fp, _f32, _i32, _vp]),
     "svoslam_pool_load": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _fp, C.POINTER(_f32), C.POINTER(_i32), _vp]),
@@ -280,6 +281,13 @@ class Pool:
     def reset(self):
         """empty map (8 zeroed root children), same allocation"""
         check(lib().svoslam_pool_reset(C.byref(self._p), _stream()))
+
+    def expand(self, center, edge_length, toward):
+        """doubles the root cube towards `toward` (re-rooting); returns the new (center, edge_length)"""
+        c = _fa(center, 3)
+        e = C.c_float(float(edge_length))
+        check(lib().svoslam_pool_expand(C.byref(self._p), c, C.byref(e), _fa(toward, 3), _stream()))
+        return tuple(float(v) for v in c), float(e.value)
 
     def save(self, path, center, edge_length, max_depth):
         """checkpoint: linear tree + root parameters (svoslam_pool_save)"""

@@ -106,6 +106,10 @@ int svoslam_camera_reset(svoslam_camera *cam) {
   NEED_DEVICE();
   return camera_reset(cam);
 }
+int svoslam_pool_expand(svoslam_pool *pool, float center[3], float *edge_length, const float toward[3], void *stream) {
+  NEED_DEVICE();
+  return pool_expand(pool, center, edge_length, toward, S(stream));
+}
 int svoslam_pool_sync(svoslam_pool *pool, void *stream) {
   NEED_DEVICE();
   return pool_sync(pool, S(stream));

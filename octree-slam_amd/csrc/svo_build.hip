@@ -638,6 +638,55 @@ int pool_init(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream) {
   return ensure_device_size(pool, stream);
 }
 
+// ---- growing the root ("a correct expandBySize that re-roots the GPU pool") -------------
+// The reference's Octree::expandBySize (octree.cpp:362-378) multiplies size_ and, for a GPU-backed root,
+// moves nothing (Q16): the old nodes then describe the wrong region.  Re-rooting the linear tree is local:
+// the 8 children of the old root (nodes 0..7) move to a fresh tile at the end of the pool, nodes 0..7
+// become the children of the NEW root -- all empty except the octant that holds the old root, which gets
+// the children flag, the index of that tile and the mean colour its mip pass would give it.  Every other
+// node keeps its index, so nothing below has to change.
+__global__ void reroot_kernel(u32 *__restrict__ pool, int *__restrict__ d_size, int n0, int octant) {
+  __shared__ uint2 old[8];
+  uint2 *nodes = reinterpret_cast<uint2 *>(pool);
+  if (threadIdx.x < 8) {
+    old[threadIdx.x] = nodes[threadIdx.x];
+    nodes[n0 + threadIdx.x] = old[threadIdx.x];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) nodes[threadIdx.x] = make_uint2(0u, 0u);  // initOctree, svo.cu:24-31
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    nodes[octant] = make_uint2(kFlag | ((u32)n0 & kMask), average_tile(pool, (u32)n0));
+    if (d_size) *d_size = n0 + 8;
+  }
+}
+
+// One doubling of the root cube towards `toward` (per axis: the side on which toward lies relative to the
+// centre).  center / edge are updated to the new root; the caller fuses with max_depth + 1 from now on to keep
+// its resolution.  Blocking.
+int pool_expand(svoslam_pool *pool, float center[3], float *edge, const float toward[3], hipStream_t stream) {
+  if (!pool || !pool->d_data || !center || !edge || !toward || !(*edge > 0.0f)) return SVOSLAM_ERR_INVALID_ARG;
+  SVO_HIP(hipDeviceSynchronize());
+  SVO_TRY(pool_sync(pool, stream));
+  if ((int64_t)pool->size + 8 > (int64_t)kMask + 1) return SVOSLAM_ERR_POOL_LIMIT;
+  SVO_TRY(grow_pool(pool, (int64_t)pool->size + 8, stream));
+  // the old root becomes the child on the side AWAY from the growth: octant bit = old centre > new centre
+  int octant = 0;
+  float nc[3];
+  for (int k = 0; k < 3; k++) {
+    const bool grow_plus = toward[k] > center[k];
+    nc[k] = center[k] + (grow_plus ? *edge : -*edge);
+    if (center[k] > nc[k]) octant |= 1 << k;
+  }
+  reroot_kernel<<<1, 64, 0, stream>>>(pool->d_data, pool->d_size, pool->size, octant);
+  SVO_LAUNCH_CHECK();
+  SVO_HIP(hipStreamSynchronize(stream));
+  pool->size += 8;
+  for (int k = 0; k < 3; k++) center[k] = nc[k];
+  *edge = *edge * 2.0f;
+  return SVOSLAM_OK;
+}
+
 // back to initOctree (8 zeroed root children) keeping the allocation, so recorded launch graphs stay valid.  Blocking.
 int pool_reset(svoslam_pool *pool, hipStream_t stream) {
   if (!pool || !pool->d_data) return SVOSLAM_ERR_INVALID_ARG;

@@ -8,6 +8,7 @@ int pool_init(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream);
 int pool_reserve(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream);
 int pool_sync(svoslam_pool *pool, hipStream_t stream);
 int pool_reset(svoslam_pool *pool, hipStream_t stream);
+int pool_expand(svoslam_pool *pool, float center[3], float *edge, const float toward[3], hipStream_t stream);
 void pool_tracker_destroy(svoslam_pool *pool);
 int pool_save(svoslam_pool *pool, const char *path, const float center[3], float edge, int depth, hipStream_t stream);
 int pool_load(svoslam_pool *pool, const char *path, float center[3], float *edge, int *depth, hipStream_t stream);

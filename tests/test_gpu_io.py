@@ -88,3 +88,39 @@ def test_frames_from_files_equal_frames_from_tensors(env, tmp_path):
         assert np.array_equal(ia, ib)
     assert reader.next_device(d_dev, c_dev) is None
     assert A.pool.size == B.pool.size and np.array_equal(A.pool.words(), B.pool.words())
+
+
+def test_pool_expand_reroots_the_map(env, oracle):
+    """doubling the root cube keeps every voxel where it was (extraction at depth + 1 == extraction at depth before),
+    renders the same image, and points beyond the old cube can then be fused"""
+    pkg, torch, synth, pl = env
+    rng = np.random.default_rng(5)
+    pts, col = surface_cloud(rng, 15000)
+    center, edge, depth = (0.0, 0.0, 0.0), 1.0, 8
+    ws, pool = pkg.Workspace(), pkg.Pool()
+    tp, tc = torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda()
+    for _ in range(2):
+        pkg.svo_from_point_cloud(ws, tp, tc, depth, pool, center, edge)
+    c0, k0 = pkg.extract_voxel_grid(ws, pool, depth, center, edge)
+    size0 = pool.size
+    view = oracle.look_at((0.2, 0.3, -2.4), (0, 0, 0), (0, 1, 0))
+    before = torch.zeros((96, 128, 4), dtype=torch.uint8, device="cuda")
+    pkg.cone_trace_svo(before, 45.0, view, pool.data_ptr, center, edge)
+    center2, edge2 = pool.expand(center, edge, toward=(5.0, -5.0, 5.0))
+    assert center2 == (1.0, -1.0, 1.0) and edge2 == 2.0 and pool.size == size0 + 8
+    words = pool.words().reshape(-1, 2)
+    flagged = [i for i in range(8) if words[i, 0] & 0x40000000]
+    assert flagged == [2] and (words[2, 0] & 0x3FFFFFFF) == size0     # old centre is at -x, +y, -z of the new one: octant 0b010
+    c1, k1 = pkg.extract_voxel_grid(ws, pool, depth + 1, center2, edge2)
+    a0 = np.concatenate([c0, k0], 1); a1 = np.concatenate([c1, k1], 1)
+    assert a0.shape == a1.shape
+    o0 = np.lexsort(np.round(a0[:, :3] * 4096).T); o1 = np.lexsort(np.round(a1[:, :3] * 4096).T)
+    assert np.allclose(a0[o0], a1[o1], rtol=0, atol=1e-5)
+    after = torch.zeros_like(before)
+    pkg.cone_trace_svo(after, 45.0, view, pool.data_ptr, center2, edge2)
+    assert (after != before).any(dim=2).float().mean().item() < 0.01    # same map, new root: (nearly) the same image
+    far = torch.from_numpy((pts + np.float32([2.0, -2.0, 2.0])).astype(np.float32)).cuda()   # outside the old cube
+    st = pkg.svo_from_point_cloud(ws, far, tc, depth + 1, pool, center2, edge2)
+    assert st.num_split > 0
+    c2, _ = pkg.extract_voxel_grid(ws, pool, depth + 1, center2, edge2)
+    assert c2.shape[0] > c1.shape[0] and (c2[:, 0] > 1.0).any()
