@@ -8,8 +8,10 @@ call of main.cpp:35 enabled:
     scene_->addPointCloudToOctree(...) -> svoFromPointCloud   main.cpp:44 / octree.cpp:290
     cuda_renderer_->coneTraceSVO(svo, camera)                 main.cpp:56-58
 
-Single GPU: everything is enqueued on the current stream; the only host round
-trip of a frame is the 76-byte split-count readback inside the fusion call.
+Single GPU: frame() enqueues everything on the current stream with no host round trip
+(asynchronous fusion; the pool size stays on the device); run_stream() processes a
+sequence of frames on four HIP streams (map generation, ICP, fusion preparation, commit +
+raycast) with the same results.
 
 Several GPUs (one process per GPU, torch.distributed over RCCL): the image is cut
 into row bands and each rank ray-marches its band of the output image against its

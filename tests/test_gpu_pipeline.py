@@ -103,8 +103,8 @@ def test_band_render_tiles_assemble_full_image(env, oracle):
 
 @pytest.mark.parametrize("capacity", [1 << 20, 1 << 12])
 def test_stream_overlap_equals_sequential(env, capacity):
-    """run_stream (tracker of frame k+1, preparation of frame k+1 and commit + raycast of frame k on three HIP
-    streams) must give exactly the images, pool and poses of the strictly sequential frame() loop -- also when
+    """run_stream (maps of frame k+2, ICP of frame k+1, preparation of frame k+1 and commit + raycast of frame k on
+    four HIP streams) must give exactly the images, pool and poses of the strictly sequential frame() loop -- also when
     the pool has to grow in the middle of the stream (capacity 4096 nodes)"""
     pkg, torch, synth, pl = env
     w, h, depth, center, edge = 320, 240, 10, (0.0, 1.5, 0.0), 4.096
