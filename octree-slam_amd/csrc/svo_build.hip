@@ -378,14 +378,18 @@ __global__ void mip_root_kernel(u32 *__restrict__ pool, const PlanCounts *__rest
 // ---- leaf blend + mip levels of the asynchronous commit in TWO launches ----------------------------
 // The reference (and the blocking path above) runs one launch per mip level because a level reads what
 // the level below wrote.  In the sorted key array the leaves under a node are a contiguous run that
-// starts at the node's owner lane, so a node whose run ends inside its owner's 256-lane workgroup has
+// starts at the node's owner lane, so a node whose run ends inside its owner's (1024-lane) workgroup has
 // ALL its touched descendants in that workgroup: the workgroup can finish it level by level behind
 // __syncthreads() (same-CU visibility).  Only a node whose run crosses the end of its owner's
 // workgroup -- at most one per workgroup and level -- is deferred to a second, single-workgroup launch
 // that handles those "straddlers" deepest level first.  Same values as the level-by-level passes.
 constexpr u32 kNoStraddler = 0xFFFFFFFFu;
 
-__global__ __launch_bounds__(256) void fill_mip_local_kernel(const u64 *__restrict__ skey, const u32 *__restrict__ sidx, int n,
+#ifndef SVO_FILL_THREADS
+#define SVO_FILL_THREADS 1024
+#endif
+constexpr int kFillThreads = SVO_FILL_THREADS;  // leaves per workgroup: fewer, longer runs of leaves -> fewer straddlers
+__global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 *__restrict__ skey, const u32 *__restrict__ sidx, int n,
                                                              int depth, const unsigned char *__restrict__ leaf_t,
                                                              const unsigned char *__restrict__ colors, u32 *__restrict__ pool,
                                                              u32 *__restrict__ strad, int num_tiles) {
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(256) void fill_mip_local_kernel(const u64 *__restri
   __shared__ int last_owner[SVOSLAM_MAX_DEPTH + 1];  // per level: last lane of this workgroup owning a node there
   __shared__ int next_pos, next_c;                   // first head lane after this workgroup and its common-prefix length
   const int tid = (int)threadIdx.x;
-  const int j = blockIdx.x * 256 + tid;
+  const int j = blockIdx.x * kFillThreads + tid;
   const bool head = j < n && leaf_t[j] != kNotHead;
   u64 key = 1; int c = 0;
   if (head) (void)is_head(skey, j, key, c, depth);
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(256) void fill_mip_local_kernel(const u64 *__restri
   if (head)
     for (int d = c + 1; d < depth; d++) atomicMax(&last_owner[d], j);
   for (int nb = (int)blockIdx.x + 1; nb < (int)gridDim.x; nb++) {  // normally one iteration
-    const int jj = nb * 256 + tid;
+    const int jj = nb * kFillThreads + tid;
     if (jj < n && leaf_t[jj] != kNotHead) atomicMin(&next_pos, jj);
     __syncthreads();
     const bool found = next_pos != 0x7FFFFFFF;
@@ -970,14 +974,15 @@ int svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int n, int d
   const unsigned char *leaf_t = ws->leaf_t.as<unsigned char>();
   int split_blocks = (int)cdiv(rmax, 256);
   if (split_blocks > 2048) split_blocks = 2048;
-  SVO_TRY(ws->strad.reserve((size_t)(SVOSLAM_MAX_DEPTH + 1) * (size_t)tiles * 8));
+  const int fill_tiles = (int)cdiv(n, kFillThreads);
+  SVO_TRY(ws->strad.reserve((size_t)(SVOSLAM_MAX_DEPTH + 1) * (size_t)fill_tiles * 8));
   u32 *strad = ws->strad.as<u32>();
   auto enqueue = [&]() -> int {
     split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
                                                        ws->rec_pass.as<unsigned char>(), small_bucket_base(ws), small_counts(ws),
                                                        pool->d_data, pool->d_size, depth);
-    fill_mip_local_kernel<<<tiles, 256, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, tiles);
-    mip_straddle_kernel<<<1, kStradThreads, 0, stream>>>(pool->d_data, strad, tiles, depth, small_counts(ws), pool->d_size);
+    fill_mip_local_kernel<<<fill_tiles, kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles);
+    mip_straddle_kernel<<<1, kStradThreads, 0, stream>>>(pool->d_data, strad, fill_tiles, depth, small_counts(ws), pool->d_size);
     SVO_LAUNCH_CHECK();
     return SVOSLAM_OK;
   };
