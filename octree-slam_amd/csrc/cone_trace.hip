@@ -88,7 +88,11 @@ constexpr int kLdsDepthMax = 12;
 constexpr int kLdsStrideMax = (1 << kLdsDepthMax) + 3;
 __host__ __device__ constexpr int lds_cells(int d) { return 1 << d; }
 __host__ __device__ constexpr int lds_stride(int d) { return (1 << d) + 3; }
-constexpr int kTraceThreads = 512;              // 3 workgroups x 8 waves per CU next to 3 x 49 KB of LDS
+constexpr int kTraceThreads = 512;              // 11-level table: 4 workgroups x 8 waves per CU (25 KB of LDS each)
+#ifndef SVO_TRACE_THREADS12
+#define SVO_TRACE_THREADS12 512
+#endif
+constexpr int kTraceThreads12 = SVO_TRACE_THREADS12;  // 12-level table (49 KB)
 
 // ---- level grid ------------------------------------------------------------
 // Dense (2^G)^3 array, G = kGridLevel = 7, indexed by the first G octant bits of each axis (z, y, x).
@@ -252,8 +256,8 @@ __device__ __forceinline__ void walk_shallow(const uint2 *__restrict__ nodes, ui
 // pixel stays 0 until the ray retires (Q9), so a sample's colour matters only on the step that
 // retires the ray: the march needs alpha alone and the colour is formed once, after the loop.
 // CARRY = true: the local pixel is carried across steps.
-template <bool CARRY, int LDSD>
-__global__ __launch_bounds__(kTraceThreads) void cone_trace_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
+template <bool CARRY, int LDSD, int THREADS>
+__global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
                                                          const uint2 *__restrict__ grid, const float *__restrict__ table,
                                                          const float *__restrict__ alpha_lut_g, TraceParams P,
                                                          unsigned long long *__restrict__ counters) {
@@ -264,13 +268,13 @@ __global__ __launch_bounds__(kTraceThreads) void cone_trace_kernel(uchar4 *__res
   if (threadIdx.x < 256) alpha_lut[threadIdx.x] = alpha_lut_g[threadIdx.x];
   {
     const float *src = table + 3 * kTabStride;  // LDS image follows the fine table
-    for (int i = threadIdx.x; i < 3 * kLdsStride; i += kTraceThreads) lds_tab[i] = src[i];
+    for (int i = threadIdx.x; i < 3 * kLdsStride; i += THREADS) lds_tab[i] = src[i];
   }
   __syncthreads();
-  // 32x16 pixel workgroup, one 8x8 tile per wavefront
+  // 32 x (THREADS / 32) pixel workgroup, one 8x8 tile per wavefront
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const int px = blockIdx.x * 32 + (int)(wave & 3u) * 8 + (int)(lane & 7u);
-  const int py = P.row_first + blockIdx.y * 16 + (int)(wave >> 2) * 8 + (int)(lane >> 3);
+  const int py = P.row_first + blockIdx.y * (THREADS / 32) + (int)(wave >> 2) * 8 + (int)(lane >> 3);
   uint32_t my_steps = 0, my_levels = 0;
   if (px < P.width && py < P.row_end) {
     const int idx = py * P.width + px;
@@ -527,7 +531,6 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
       P.lod_span = 0u;
     }
   }
-  dim3 grid(cdiv(width, 32), cdiv(rows, 16));
   static DeviceBuffer accel;  // grid 2 MB + tables 0.8 MB, library-owned (calls from several host threads must be serialised)
   const size_t accel_bytes = (size_t)kGridEntries * sizeof(uint2) + (size_t)(3 * (kTabStride + kLdsStrideMax) + 256) * sizeof(float) + 64;
   SVO_TRY(accel.reserve(accel_bytes));
@@ -539,11 +542,13 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   uchar4 *out = reinterpret_cast<uchar4 *>(d_pos);
   const bool carry = (mode & 0xFF) == SVOSLAM_RENDER_CARRY;
   if (P.lds_depth == 11) {
-    if (carry) cone_trace_kernel<true, 11><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
-    else cone_trace_kernel<false, 11><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    const dim3 grid(cdiv(width, 32), cdiv(rows, kTraceThreads / 32));
+    if (carry) cone_trace_kernel<true, 11, kTraceThreads><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    else cone_trace_kernel<false, 11, kTraceThreads><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
   } else {
-    if (carry) cone_trace_kernel<true, 12><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
-    else cone_trace_kernel<false, 12><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    const dim3 grid(cdiv(width, 32), cdiv(rows, kTraceThreads12 / 32));
+    if (carry) cone_trace_kernel<true, 12, kTraceThreads12><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    else cone_trace_kernel<false, 12, kTraceThreads12><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
   }
   SVO_TRY(timing_event(stream));
   SVO_LAUNCH_CHECK();
