@@ -95,7 +95,7 @@ constexpr int kTraceThreads = 512;              // 11-level table: 4 workgroups 
 constexpr int kTraceThreads12 = SVO_TRACE_THREADS12;  // 12-level table (49 KB)
 
 // ---- level grid ------------------------------------------------------------
-// Dense (2^G)^3 array, G = kGridLevel = 7, indexed by the first G octant bits of each axis (z, y, x).
+// Dense (2^G)^3 array, G = 7 (8 for renders of a megapixel and more), indexed by the first G octant bits of each axis (z, y, x).
 // Entry = outcome of the reference's walk over levels 1..G on that path:
 //   all G nodes have children:  x = flag | tile index of the level-G node's children, y = its colour word
 //   first childless node at level st (1..G): x = st, y = that node's colour word
@@ -105,8 +105,9 @@ constexpr int kTraceThreads12 = SVO_TRACE_THREADS12;  // 12-level table (49 KB)
 #ifndef SVO_GRID_LEVEL
 #define SVO_GRID_LEVEL 7
 #endif
-constexpr int kGridLevel = SVO_GRID_LEVEL;
-constexpr int kGridEntries = 1 << (3 * kGridLevel);
+constexpr int kGridLevelSmall = SVO_GRID_LEVEL;   // 128^3 cells, 16.8 MB, ~9 us to rebuild
+constexpr int kGridLevelLarge = 8;                // 256^3 cells, 134 MB, ~30 us: pays off when the march itself is long (>= 1 M rays)
+__host__ __device__ constexpr int grid_entries(int g) { return 1 << (3 * g); }
 
 struct TraceParams {
   float origin[3], x_dir[3], y_dir[3];
@@ -121,18 +122,19 @@ struct TraceParams {
   int size_exp;
 };
 
+template <int GRID>
 __global__ __launch_bounds__(256) void build_accel_kernel(const uint32_t *__restrict__ octree, uint2 *__restrict__ grid,
                                                          float *__restrict__ table, float *__restrict__ alpha_lut,
                                                          TraceParams P) {
   int e = blockIdx.x * 256 + threadIdx.x;
   const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
-  if (e < kGridEntries) {
-    constexpr uint32_t kAxisMask = (1u << kGridLevel) - 1u;
-    const uint32_t xi = (uint32_t)e & kAxisMask, yi = ((uint32_t)e >> kGridLevel) & kAxisMask, zi = (uint32_t)e >> (2 * kGridLevel);
+  if (e < grid_entries(GRID)) {
+    constexpr uint32_t kAxisMask = (1u << GRID) - 1u;
+    const uint32_t xi = (uint32_t)e & kAxisMask, yi = ((uint32_t)e >> GRID) & kAxisMask, zi = (uint32_t)e >> (2 * GRID);
     uint32_t base = 0;
     uint2 out = make_uint2(0u, 0u);
-    for (int l = 1; l <= kGridLevel; l++) {
-      const int sh = kGridLevel - l;
+    for (int l = 1; l <= GRID; l++) {
+      const int sh = GRID - l;
       const uint32_t oct = ((xi >> sh) & 1u) | (((yi >> sh) & 1u) << 1) | (((zi >> sh) & 1u) << 2);
       const uint2 nd = nodes[base + oct];
       if (!(nd.x & kFlag)) { out = make_uint2((uint32_t)l, nd.y); break; }
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void build_accel_kernel(const uint32_t *__rest
     grid[e] = out;
     return;
   }
-  e -= kGridEntries;
+  e -= grid_entries(GRID);
   if (e < 3 * (kTabStride + kLdsStrideMax)) {
     // fine table (kTabDepth levels) followed by the LDS image (P.lds_depth levels)
     const bool fine = e < 3 * kTabStride;
@@ -238,7 +240,7 @@ __device__ __forceinline__ void walk_deep(const uint2 *__restrict__ nodes, const
   }
 }
 
-// walk from the root for an LOD depth above the grid level (1 <= depth < kGridLevel)
+// walk from the root for an LOD depth above the grid level (1 <= depth < grid level)
 template <int LDSD>
 __device__ __forceinline__ void walk_shallow(const uint2 *__restrict__ nodes, uint32_t xb, uint32_t yb, uint32_t zb, int &depth, uint32_t &w1) {
   uint32_t child_idx = 0;
@@ -256,13 +258,14 @@ __device__ __forceinline__ void walk_shallow(const uint2 *__restrict__ nodes, ui
 // pixel stays 0 until the ray retires (Q9), so a sample's colour matters only on the step that
 // retires the ray: the march needs alpha alone and the colour is formed once, after the loop.
 // CARRY = true: the local pixel is carried across steps.
-template <bool CARRY, int LDSD, int THREADS>
+template <bool CARRY, int LDSD, int THREADS, int GRID>
 __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
                                                          const uint2 *__restrict__ grid, const float *__restrict__ table,
                                                          const float *__restrict__ alpha_lut_g, TraceParams P,
                                                          unsigned long long *__restrict__ counters) {
   __shared__ float alpha_lut[256];
   constexpr int kLdsDepth = LDSD;
+  constexpr int kGridLevel = GRID;
   constexpr int kLdsStride = lds_stride(LDSD);
   __shared__ float lds_tab[3 * kLdsStride];
   if (threadIdx.x < 256) alpha_lut[threadIdx.x] = alpha_lut_g[threadIdx.x];
@@ -531,24 +534,32 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
       P.lod_span = 0u;
     }
   }
-  static DeviceBuffer accel;  // grid 2 MB + tables 0.8 MB, library-owned (calls from several host threads must be serialised)
-  const size_t accel_bytes = (size_t)kGridEntries * sizeof(uint2) + (size_t)(3 * (kTabStride + kLdsStrideMax) + 256) * sizeof(float) + 64;
+  static DeviceBuffer accel;  // grid 16.8 / 134 MB + tables 0.9 MB, library-owned (calls from several host threads must be serialised)
+  const bool large = (long long)width * rows >= (1ll << 20) && P.lds_depth == kLdsDepthMax;  // e.g. 1920x1080 frames
+  const int grid_cells = grid_entries(large ? kGridLevelLarge : kGridLevelSmall);
+  const size_t accel_bytes = (size_t)grid_cells * sizeof(uint2) + (size_t)(3 * (kTabStride + kLdsStrideMax) + 256) * sizeof(float) + 64;
   SVO_TRY(accel.reserve(accel_bytes));
   uint2 *d_grid = accel.as<uint2>();
-  float *d_table = reinterpret_cast<float *>(d_grid + kGridEntries);
+  float *d_table = reinterpret_cast<float *>(d_grid + grid_cells);
   float *alpha_lut = d_table + 3 * (kTabStride + kLdsStrideMax);
-  build_accel_kernel<<<cdiv(kGridEntries + 3 * (kTabStride + kLdsStrideMax) + 256, 256), 256, 0, stream>>>(d_octree, d_grid, d_table, alpha_lut, P);
+  const int build_blocks = (int)cdiv(grid_cells + 3 * (kTabStride + kLdsStrideMax) + 256, 256);
+  if (large) build_accel_kernel<kGridLevelLarge><<<build_blocks, 256, 0, stream>>>(d_octree, d_grid, d_table, alpha_lut, P);
+  else build_accel_kernel<kGridLevelSmall><<<build_blocks, 256, 0, stream>>>(d_octree, d_grid, d_table, alpha_lut, P);
   SVO_TRY(timing_event(stream));
   uchar4 *out = reinterpret_cast<uchar4 *>(d_pos);
   const bool carry = (mode & 0xFF) == SVOSLAM_RENDER_CARRY;
   if (P.lds_depth == 11) {
     const dim3 grid(cdiv(width, 32), cdiv(rows, kTraceThreads / 32));
-    if (carry) cone_trace_kernel<true, 11, kTraceThreads><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
-    else cone_trace_kernel<false, 11, kTraceThreads><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    if (carry) cone_trace_kernel<true, 11, kTraceThreads, kGridLevelSmall><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    else cone_trace_kernel<false, 11, kTraceThreads, kGridLevelSmall><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+  } else if (!large) {
+    const dim3 grid(cdiv(width, 32), cdiv(rows, kTraceThreads12 / 32));
+    if (carry) cone_trace_kernel<true, 12, kTraceThreads12, kGridLevelSmall><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    else cone_trace_kernel<false, 12, kTraceThreads12, kGridLevelSmall><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
   } else {
     const dim3 grid(cdiv(width, 32), cdiv(rows, kTraceThreads12 / 32));
-    if (carry) cone_trace_kernel<true, 12, kTraceThreads12><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
-    else cone_trace_kernel<false, 12, kTraceThreads12><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    if (carry) cone_trace_kernel<true, 12, kTraceThreads12, kGridLevelLarge><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    else cone_trace_kernel<false, 12, kTraceThreads12, kGridLevelLarge><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
   }
   SVO_TRY(timing_event(stream));
   SVO_LAUNCH_CHECK();

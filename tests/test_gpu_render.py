@@ -139,3 +139,12 @@ def test_render_tall_image_large_root_uses_the_12_level_lds_table(env, oracle, m
     for eye, tgt in (((0.5, 1.0, -11.0), (0, 0, 0)), ((1.0, 0.5, 2.6), (0.5, -1.0, -1.5))):
         view = oracle.look_at(eye, tgt, (0, 1, 0))
         render_both(pkg, torch, oracle, pool, words, 40, 1100, view, center, edge, mode)
+
+
+def test_render_megapixel_uses_the_level8_grid(env, oracle):
+    """>= 2^20 rays with the 12-level table: the 256^3 grid variant is selected"""
+    pkg, torch = env
+    center, edge = (0.0, 0.0, 0.0), 8.192
+    ws, pool, opool = build_pool(pkg, torch, oracle, 14, 2, n=30000, edge=edge, center=center, scale=5.0)
+    view = oracle.look_at((0.5, 1.0, -11.0), (0, 0, 0), (0, 1, 0))
+    render_both(pkg, torch, oracle, pool, opool.words(), 960, 1100, view, center, edge, 0)
