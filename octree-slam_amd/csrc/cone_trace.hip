@@ -535,7 +535,11 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
     }
   }
   static DeviceBuffer accel;  // grid 16.8 / 134 MB + tables 0.9 MB, library-owned (calls from several host threads must be serialised)
-  const bool large = (long long)width * rows >= (1ll << 20) && P.lds_depth == kLdsDepthMax;  // e.g. 1920x1080 frames
+#ifdef SVO_FORCE_GRID8
+  const bool large = true;
+#else
+  const bool large = (long long)width * rows >= (1ll << 20);  // e.g. 1920x1080 frames
+#endif
   const int grid_cells = grid_entries(large ? kGridLevelLarge : kGridLevelSmall);
   const size_t accel_bytes = (size_t)grid_cells * sizeof(uint2) + (size_t)(3 * (kTabStride + kLdsStrideMax) + 256) * sizeof(float) + 64;
   SVO_TRY(accel.reserve(accel_bytes));
@@ -548,7 +552,11 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   SVO_TRY(timing_event(stream));
   uchar4 *out = reinterpret_cast<uchar4 *>(d_pos);
   const bool carry = (mode & 0xFF) == SVOSLAM_RENDER_CARRY;
-  if (P.lds_depth == 11) {
+  if (P.lds_depth == 11 && large) {
+    const dim3 grid(cdiv(width, 32), cdiv(rows, kTraceThreads / 32));
+    if (carry) cone_trace_kernel<true, 11, kTraceThreads, kGridLevelLarge><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    else cone_trace_kernel<false, 11, kTraceThreads, kGridLevelLarge><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+  } else if (P.lds_depth == 11) {
     const dim3 grid(cdiv(width, 32), cdiv(rows, kTraceThreads / 32));
     if (carry) cone_trace_kernel<true, 11, kTraceThreads, kGridLevelSmall><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
     else cone_trace_kernel<false, 11, kTraceThreads, kGridLevelSmall><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
