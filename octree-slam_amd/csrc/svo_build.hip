@@ -176,7 +176,6 @@ __global__ __launch_bounds__(256) void plan_emit_kernel(const u64 *__restrict__ 
     }
   }
   // phase A: per-wave record counts per (pass, depth) bucket
-#pragma unroll
   for (int d = 1; d <= SVOSLAM_MAX_DEPTH; d++) {
     if (d > depth) break;
     const bool valid = d >= lo && d <= hi;
@@ -193,7 +192,6 @@ __global__ __launch_bounds__(256) void plan_emit_kernel(const u64 *__restrict__ 
   }
   __syncthreads();
   // phase B: emit records at their reference rank
-#pragma unroll
   for (int d = 1; d <= SVOSLAM_MAX_DEPTH; d++) {
     if (d > depth) break;
     const bool valid = d >= lo && d <= hi;
@@ -970,7 +968,6 @@ int svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int n, int d
   const int64_t rmax = max_records(n, depth);
   const u64 *skey = ws->sorted_keys;
   const u32 *sidx = ws->sorted_idx;
-  const int tiles = (int)cdiv(n, 256);
   const unsigned char *leaf_t = ws->leaf_t.as<unsigned char>();
   int split_blocks = (int)cdiv(rmax, 256);
   if (split_blocks > 2048) split_blocks = 2048;
