@@ -3,7 +3,8 @@
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
 cpu_baseline leg of bench.py.  The product (octree-slam_amd/) never imports it.
 Parity status: unpinned by the reference (no reference tests exist); pinned by
-the SURVEY.md Appendix C known-answer vectors in tests/golden/.
+the SURVEY.md Appendix C known-answer vectors in tests/golden/.  The OBJ loader alone is
+pinned by the reference's own code (oracle/_ref/libobjref.so, reference_obj_load below).
 """
 import ctypes as C
 import os
@@ -447,6 +448,41 @@ def mesh_load_obj(path):
         raise IOError(path)
     vbo = _take(vb, (n, 3, 3), np.float32)
     tbo = _take(tb, (tsz.value // 6, 3, 2), np.float32) if tsz.value > 0 else None
+    return {"vbo": vbo, "tbo": tbo, "bbox0": b0, "bbox1": b1}
+
+
+_REF_OBJ = None
+
+
+def build_reference_obj_loader():
+    """make -C oracle ref: the reference's own objUtil sources + ref_obj_shim.cpp -> oracle/_ref/libobjref.so"""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+    return os.path.join(_HERE, "_ref", "libobjref.so")
+
+
+def reference_obj_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libobjref.so"))
+
+
+def reference_obj_load(path):
+    """The REFERENCE's loader (compiled from /root/reference, see ref_obj_shim.cpp), same dict as mesh_load_obj.
+    Malformed files are undefined behaviour there (face index 0, empty tokens): feed it well-formed input."""
+    global _REF_OBJ
+    if _REF_OBJ is None:
+        _REF_OBJ = C.CDLL(os.path.join(_HERE, "_ref", "libobjref.so"))
+        _REF_OBJ.ref_obj_load.restype = C.c_int
+        _REF_OBJ.ref_obj_free.argtypes = [C.c_void_p]
+    vb, tb = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+    tsz = C.c_int(0)
+    b0, b1 = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    n = _REF_OBJ.ref_obj_load(str(path).encode(), C.byref(vb), C.byref(tb), C.byref(tsz), _p(b0, C.c_float), _p(b1, C.c_float))
+    if n < 0:
+        raise IOError(path)
+    vbo = np.ctypeslib.as_array(vb, (max(n, 1) * 9,))[:n * 9].copy().reshape(n, 3, 3)
+    tbo = np.ctypeslib.as_array(tb, (tsz.value,)).copy().reshape(-1, 3, 2) if tsz.value > 0 else None
+    _REF_OBJ.ref_obj_free(vb)
+    if tsz.value > 0:
+        _REF_OBJ.ref_obj_free(tb)
     return {"vbo": vbo, "tbo": tbo, "bbox0": b0, "bbox1": b1}
 
 

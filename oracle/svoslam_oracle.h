@@ -11,6 +11,11 @@
  * this image (CUDA 6.5 + Thrust + VoxelPipe + OpenNI + GL).  The
  * oracle is pinned instead against the hand-derived known-answer vectors of
  * SURVEY.md Appendix C (tests/golden/kat_*.json, tests/test_oracle_kat.py).
+ * One exception is pinned by the reference itself: the OBJ loader
+ * (ora_mesh_load_obj) is checked bit for bit against the reference's own
+ * objUtil sources, compiled where they lie into oracle/_ref/libobjref.so
+ * (`make ref`, ref_obj_shim.cpp; tests/test_ref_obj_loader.py and the digests
+ * of its output in tests/golden/ref_obj_loader.json).
  *
  * Every function cites the reference file:line it restates (paths relative to
  * the reference checkout).  Plain single-thread C, no SIMD intrinsics.

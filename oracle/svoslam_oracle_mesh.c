@@ -4,7 +4,9 @@
  * (src/world/scene.cpp:35-62) and meshToVoxelGrid (src/world/voxelization/voxelization.cu:50-139,
  * 219-236,381-405) with the VoxelPipe THIN_RASTER / NO_BLENDING / FP32S rule it instantiates
  * (external/include/voxelpipe/coarse.h:59-102, utils.h:185-254, fine.h:130-152,239-365,936-959,
- * tile.h:45-51).  TEST INFRASTRUCTURE ONLY; parity unpinned by the reference (see svoslam_oracle.h).
+ * tile.h:45-51).  TEST INFRASTRUCTURE ONLY.  The OBJ loader is pinned against the reference's own objUtil
+ * build (oracle/_ref, tests/test_ref_obj_loader.py); the voxelizer's parity is unpinned by the reference
+ * (see svoslam_oracle.h).
  *
  * Deterministic resolution: NO_BLENDING is a plain store (last writer wins, a race between
  * triangles that share a voxel); the oracle lets the HIGHEST triangle id win.

@@ -84,3 +84,37 @@ def write_bmp(path, w=64, h=64, seed=0):
     with open(path, "wb") as fp:
         fp.write(hdr + data)
     return path
+
+
+# Well-formed corner cases of the OBJ grammar the reference's loader accepts (objloader.cpp:24-130):
+# 'v/vt' faces, 3-component vt, comment/group/material lines, exponents, a w component, CRLF line ends,
+# a file without a trailing newline, faces with more than four vertices (dropped by buildVBOs).
+QUIRK_OBJS = {
+    "vt_only": "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0.5\nvt 0 0\nvt 1 0\nvt 0 1\nvt 1 1\nf 1/1 2/2 3/3\nf 2/2 4/4 3/3\n",
+    "quad_tex": "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0.25\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 0 1\nf 1/1/1 2/2/1 3/3/1 4/4/1\n",
+    "quad_plain": "v 0 0 0\nv 2 0 0\nv 2 0 2\nv 0 0.5 2\nf 1 2 3 4\nf 4 3 2 1\n",
+    "poly5": "v 0 0 0\nv 1 0 0\nv 1.5 1 0\nv 0.5 2 0.3\nv -0.5 1 0\nf 1 2 3 4 5\nf 1 2 3\n",
+    "comments": "# hello\n\no thing\ng grp\nusemtl m\ns off\nv 0 0 0\nv 1 0 0\nv 0 1 0\n# mid\nf 1 2 3\n",
+    "sci": "v 1e-1 0 0\nv 1.5E0 2e-2 0\nv 0 1 -3.25e-1\nf 1 2 3\n",
+    "vw": "v 0 0 0 1\nv 1 0 0 1\nv 0 1 0 1\nf 1 2 3\n",
+    "vt3": "v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0 0\nvt 1 0 0\nvt 0 1 0\nf 1/1 2/2 3/3\n",
+    "crlf": "v 0 0 0\r\nv 1 0 0\r\nv 0 1 0\r\nf 1 2 3\r\n",
+    "noeol": "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3",
+    "neg_y": "v 0 -3 0\nv 1 -2 5\nv 0 1 7\nf 1 2 3\n",
+    "tetra": "v 0 0 0\nv 2 0 0\nv 0 2 0\nv 0 0 2\nf 1 2 3\nf 1 3 4\nf 1 4 2\nf 2 4 3\n",
+}
+
+
+def write_generated_objs(directory):
+    """every generated OBJ of the loader tests -> {name: path} (deterministic bytes)"""
+    import os
+    out = {"cube": write_cube_obj(os.path.join(directory, "cube.obj")),
+           "sphere": write_sphere_obj(os.path.join(directory, "sphere.obj")),
+           "sphere_tris": write_sphere_obj(os.path.join(directory, "sphere_tris.obj"), rings=9, segs=7, quads=False),
+           "soup": write_soup_obj(os.path.join(directory, "soup.obj"))}
+    for name, text in QUIRK_OBJS.items():
+        path = os.path.join(directory, "quirk_%s.obj" % name)
+        with open(path, "wb") as fp:
+            fp.write(text.encode())
+        out["quirk_" + name] = path
+    return out
