@@ -104,75 +104,109 @@ __global__ __launch_bounds__(256) void tri_scanline_count_kernel(const float *__
   counts[t] = (u32)(S.hi[S.V] - S.lo[S.V] + 1);
 }
 
-// fine.h:936-959: does the triangle's plane cross the tile?
-__device__ inline bool tile_plane_test(const TriSetup &S, const GridParams &G, int tx, int ty, int tz) {
-  const float T = (float)G.T;
-  const float c0 = S.n[0] > 0 ? G.delta[0] * T : 0.0f, c1 = S.n[1] > 0 ? G.delta[1] * T : 0.0f, c2 = S.n[2] > 0 ? G.delta[2] * T : 0.0f;
-  const float r1 = S.n[0] * (c0 - S.v0[0]) + S.n[1] * (c1 - S.v0[1]) + S.n[2] * (c2 - S.v0[2]);
-  const float r2 = S.n[0] * (G.delta[0] * T - c0 - S.v0[0]) + S.n[1] * (G.delta[1] * T - c1 - S.v0[1]) + S.n[2] * (G.delta[2] * T - c2 - S.v0[2]);
-  const float np = S.n[0] * (G.bbox0[0] + (float)tx * G.delta[0]) + S.n[1] * (G.bbox0[1] + (float)ty * G.delta[1]) + S.n[2] * (G.bbox0[2] + (float)tz * G.delta[2]);
-  return (np + r1) * (np + r2) <= 0.0f;
-}
+// One workgroup per 256 consecutive (triangle, scanline) pairs.  EMIT = false: count the fragments of each
+// scanline; EMIT = true: write them at the scanned offsets.  Per cell the rule is VoxelPipe's: conservative
+// 2-D edge functions give a u range per scanline (compute_scanline_bounds, fine.h:130-152), the plane gives
+// ONE w per (u, v) (rasterize_scanline, fine.h:318-341), kept if the tile that holds (u, v, w) overlaps the
+// triangle's integer bbox and passes the tile/plane test.
+// Each thread sets up its own scanline (u range, plane) into LDS; the cells of all 256 scanlines are then
+// walked by the whole workgroup (cell c -> scanline by search in the LDS prefix of the u-range lengths), so a
+// 65536-cell scanline of a long thin triangle costs 256 iterations, not 65536.  Fragments of one scanline have
+// distinct cells, so their order inside the scanline's slot range does not matter (LDS atomic slot counter).
+struct ScanlineSetup {
+  int t, v, min_u, axis, tw_lo, tw_hi;
+  float px, py, pz, vf, n[3], r1, r2;
+};
 
-// One thread per (triangle, scanline).  EMIT = false: count the fragments; EMIT = true: write them
-// at the scanned offsets.  Per cell the rule is VoxelPipe's: conservative 2-D edge functions give a
-// u range per scanline (compute_scanline_bounds, fine.h:130-152), the plane gives ONE w per (u, v)
-// (rasterize_scanline, fine.h:318-341), kept if the tile that holds (u, v, w) overlaps the triangle's
-// integer bbox and passes the tile/plane test.
 template <bool EMIT>
 __global__ __launch_bounds__(256) void scanline_kernel(const float *__restrict__ vbo, int n_tris,
                                                        const u32 *__restrict__ tri_start, u32 total_scanlines, GridParams G,
                                                        u32 *__restrict__ frag_count, const u32 *__restrict__ frag_start,
                                                        u64 *__restrict__ frag_key, u32 *__restrict__ frag_tri) {
+  __shared__ ScanlineSetup setup[256];
+  __shared__ u32 cell_prefix[257], slot[256], out_base[256], tmp[4];
   const u32 s = blockIdx.x * 256u + threadIdx.x;
-  if (s >= total_scanlines) return;
-  // triangle of this scanline: last t with tri_start[t] <= s
-  int lo = 0, hi = n_tris - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (tri_start[mid] <= s) lo = mid; else hi = mid - 1;
-  }
-  const int t = lo;
-  TriSetup S;
-  setup_triangle(vbo, t, G, S);
-  const int v = S.lo[S.V] + (int)(s - tri_start[t]);
-  const float b[3] = {S.a[0] + (float)v * S.ndv[0], S.a[1] + (float)v * S.ndv[1], S.a[2] + (float)v * S.ndv[2]};
-  int min_u = S.lo[S.U], max_u = S.hi[S.U];
-  bool invalid = false;
+  u32 len = 0;
+  if (s < total_scanlines) {
+    // triangle of this scanline: last t with tri_start[t] <= s
+    int lo = 0, hi = n_tris - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (tri_start[mid] <= s) lo = mid; else hi = mid - 1;
+    }
+    const int t = lo;
+    TriSetup S;
+    setup_triangle(vbo, t, G, S);
+    const int v = S.lo[S.V] + (int)(s - tri_start[t]);
+    const float b[3] = {S.a[0] + (float)v * S.ndv[0], S.a[1] + (float)v * S.ndv[1], S.a[2] + (float)v * S.ndv[2]};
+    int min_u = S.lo[S.U], max_u = S.hi[S.U];
+    bool invalid = false;
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
-    if (S.ndu[k] > 0.0f) { const int c = (int)ceilf(-b[k] * S.inv_du[k]); min_u = c > min_u ? c : min_u; }
-    else if (S.ndu[k] < 0.0f) { const int c = (int)(-b[k] * S.inv_du[k]); max_u = c < max_u ? c : max_u; }
-    else if (b[k] < 0.0f) invalid = true;
+    for (int k = 0; k < 3; k++) {
+      if (S.ndu[k] > 0.0f) { const int c = (int)ceilf(-b[k] * S.inv_du[k]); min_u = c > min_u ? c : min_u; }
+      else if (S.ndu[k] < 0.0f) { const int c = (int)(-b[k] * S.inv_du[k]); max_u = c < max_u ? c : max_u; }
+      else if (b[k] < 0.0f) invalid = true;
+    }
+    if (!invalid && max_u >= min_u) len = (u32)(max_u - min_u + 1);
+    ScanlineSetup &Q = setup[threadIdx.x];
+    Q.t = t; Q.v = v; Q.min_u = min_u; Q.axis = S.axis;
+    Q.tw_lo = S.lo[S.W] >> G.log_T; Q.tw_hi = S.hi[S.W] >> G.log_T;
+    Q.px = S.px; Q.py = S.py; Q.pz = S.pz;
+    Q.vf = ((float)v + 0.5f) * pick(G.delta, S.V);
+    Q.n[0] = S.n[0]; Q.n[1] = S.n[1]; Q.n[2] = S.n[2];
+    // fine.h:936-959, the two tile-independent terms of the plane/tile test
+    const float T = (float)G.T;
+    const float c0 = S.n[0] > 0 ? G.delta[0] * T : 0.0f, c1 = S.n[1] > 0 ? G.delta[1] * T : 0.0f, c2 = S.n[2] > 0 ? G.delta[2] * T : 0.0f;
+    Q.r1 = S.n[0] * (c0 - S.v0[0]) + S.n[1] * (c1 - S.v0[1]) + S.n[2] * (c2 - S.v0[2]);
+    Q.r2 = S.n[0] * (G.delta[0] * T - c0 - S.v0[0]) + S.n[1] * (G.delta[1] * T - c1 - S.v0[1]) + S.n[2] * (G.delta[2] * T - c2 - S.v0[2]);
   }
-  u32 count = 0;
-  u32 pos = EMIT ? frag_start[s] : 0u;
-  if (!invalid) {
-    const float vf = ((float)v + 0.5f) * pick(G.delta, S.V);
-    const int M = 1 << (G.log_N - G.log_T);
-    for (int u = min_u; u <= max_u; ++u) {
-      const float uf = ((float)u + 0.5f) * pick(G.delta, S.U);
-      const float wf = S.pz - (S.px * uf + S.py * vf);
-      const int w = (int)(wf * pick(G.inv_delta, S.W));
-      int xyz[3];
-      xyz[S.U] = u; xyz[S.V] = v; xyz[S.W] = w;
-      // the tile holding (u, v, w) must be one of the tiles of the triangle's integer bbox ...
-      const int tw = w >> G.log_T;
-      if (w < 0 || tw < (S.lo[S.W] >> G.log_T) || tw > (S.hi[S.W] >> G.log_T)) continue;
-      // ... and pass the plane test
-      const int tx = (xyz[0] >> G.log_T) << G.log_T, ty = (xyz[1] >> G.log_T) << G.log_T, tz = (xyz[2] >> G.log_T) << G.log_T;
-      if (!tile_plane_test(S, G, tx, ty, tz)) continue;
-      if (EMIT) {
-        const u64 tile = (u64)(xyz[0] >> G.log_T) + (u64)M * (u64)(xyz[1] >> G.log_T) + (u64)M * M * (u64)(xyz[2] >> G.log_T);
-        const u64 pix = (u64)(xyz[0] & (G.T - 1)) + (u64)G.T * (u64)(xyz[1] & (G.T - 1)) + (u64)G.T * G.T * (u64)(xyz[2] & (G.T - 1));
-        frag_key[pos] = tile * (u64)G.T * G.T * G.T + pix;  // fb index of voxelization.cu:141-164
-        frag_tri[pos] = (u32)t;
-        pos++;
+  u32 total_cells;
+  const u32 ex = block256_exclusive_scan(len, tmp, total_cells);
+  cell_prefix[threadIdx.x] = ex;
+  if (threadIdx.x == 255) cell_prefix[256] = total_cells;
+  slot[threadIdx.x] = 0;
+  out_base[threadIdx.x] = (EMIT && s < total_scanlines) ? frag_start[s] : 0u;
+  __syncthreads();
+
+  const int M = 1 << (G.log_N - G.log_T);
+  u32 sl = 0;
+  for (u32 c = threadIdx.x; c < total_cells; c += 256u) {
+    if (!(cell_prefix[sl] <= c && c < cell_prefix[sl + 1])) {  // last sl with cell_prefix[sl] <= c
+      u32 lo = 0, hi = 255;
+      while (lo < hi) {
+        const u32 mid = (lo + hi + 1) >> 1;
+        if (cell_prefix[mid] <= c) lo = mid; else hi = mid - 1;
       }
-      count++;
+      sl = lo;
+    }
+    const ScanlineSetup &Q = setup[sl];
+    const int W = Q.axis, U = W == 0 ? 1 : 0, V = W == 2 ? 1 : 2;
+    const int u = Q.min_u + (int)(c - cell_prefix[sl]);
+    const float uf = ((float)u + 0.5f) * pick(G.delta, U);
+    const float wf = Q.pz - (Q.px * uf + Q.py * Q.vf);
+    const int w = (int)(wf * pick(G.inv_delta, W));
+    int xyz[3];
+    xyz[U] = u; xyz[V] = Q.v; xyz[W] = w;
+    // the tile holding (u, v, w) must be one of the tiles of the triangle's integer bbox ...
+    const int tw = w >> G.log_T;
+    if (w < 0 || tw < Q.tw_lo || tw > Q.tw_hi) continue;
+    // ... and pass the plane test
+    const int tx = (xyz[0] >> G.log_T) << G.log_T, ty = (xyz[1] >> G.log_T) << G.log_T, tz = (xyz[2] >> G.log_T) << G.log_T;
+    const float np = Q.n[0] * (G.bbox0[0] + (float)tx * G.delta[0]) + Q.n[1] * (G.bbox0[1] + (float)ty * G.delta[1]) + Q.n[2] * (G.bbox0[2] + (float)tz * G.delta[2]);
+    if (!((np + Q.r1) * (np + Q.r2) <= 0.0f)) continue;
+    const u32 k = atomicAdd(&slot[sl], 1u);
+    if (EMIT) {
+      const u64 tile = (u64)(xyz[0] >> G.log_T) + (u64)M * (u64)(xyz[1] >> G.log_T) + (u64)M * M * (u64)(xyz[2] >> G.log_T);
+      const u64 pix = (u64)(xyz[0] & (G.T - 1)) + (u64)G.T * (u64)(xyz[1] & (G.T - 1)) + (u64)G.T * G.T * (u64)(xyz[2] & (G.T - 1));
+      const u32 pos = out_base[sl] + k;
+      frag_key[pos] = tile * (u64)G.T * G.T * G.T + pix;  // fb index of voxelization.cu:141-164
+      frag_tri[pos] = (u32)Q.t;
     }
   }
-  if (!EMIT) frag_count[s] = count;
+  if (!EMIT) {
+    __syncthreads();
+    if (s < total_scanlines) frag_count[s] = slot[threadIdx.x];
+  }
 }
 
 // last fragment of each run of equal cell indices (stable sort: highest triangle id) -> flag + tile count
@@ -278,7 +312,7 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   u32 *tri_start = ws->leaf_f.as<u32>();
   u32 *d_total = ws->small.as<u32>();
   tri_scanline_count_kernel<<<cdiv(n_tris, 256), 256, 0, stream>>>(dv.as<float>(), n_tris, G, tri_start);
-  row_scan_rows1(tri_start, n_tris, d_total, stream);
+  SVO_TRY(exclusive_scan_u32(ws, tri_start, (u32)n_tris, d_total, stream));
   u32 total_scan = 0;
   SVO_HIP(hipMemcpyAsync(&total_scan, d_total, 4, hipMemcpyDeviceToHost, stream));
   SVO_HIP(hipStreamSynchronize(stream));
@@ -288,7 +322,7 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   u32 *frag_start = ws->rec_front.as<u32>();
   scanline_kernel<false><<<cdiv(total_scan, 256), 256, 0, stream>>>(dv.as<float>(), n_tris, tri_start, total_scan, G, frag_start,
                                                                    nullptr, nullptr, nullptr);
-  row_scan_rows1(frag_start, (int)total_scan, d_total, stream);
+  SVO_TRY(exclusive_scan_u32(ws, frag_start, total_scan, d_total, stream));
   u32 total_frag = 0;
   SVO_HIP(hipMemcpyAsync(&total_frag, d_total, 4, hipMemcpyDeviceToHost, stream));
   SVO_HIP(hipStreamSynchronize(stream));
@@ -309,7 +343,7 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   const int tiles = (int)cdiv(nf, 256);
   u32 *tile_cnt = ws->tile_hist.as<u32>();
   voxel_flag_kernel<<<tiles, 256, 0, stream>>>(skey, (u32)nf, tile_cnt);
-  row_scan_rows1(tile_cnt, tiles, d_total, stream);
+  SVO_TRY(exclusive_scan_u32(ws, tile_cnt, (u32)tiles, d_total, stream));
   u32 n_vox = 0;
   SVO_HIP(hipMemcpyAsync(&n_vox, d_total, 4, hipMemcpyDeviceToHost, stream));
   SVO_HIP(hipStreamSynchronize(stream));

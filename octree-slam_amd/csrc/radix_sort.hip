@@ -117,6 +117,54 @@ __global__ __launch_bounds__(256) void radix_downsweep_kernel(const unsigned lon
   }
 }
 
+// Long arrays: exclusive scan in chunks of 256 threads x 8 items.  Pass 1 sums each chunk, a single
+// workgroup scans the chunk sums (row_scan_kernel), pass 2 scans inside the chunks on top of them.
+constexpr int kScanItems = 8;
+constexpr int kScanChunk = 256 * kScanItems;
+
+__global__ __launch_bounds__(256) void scan_chunk_sum_kernel(const unsigned *__restrict__ data, unsigned n,
+                                                             unsigned *__restrict__ sums) {
+  __shared__ unsigned tmp[4];
+  const unsigned base = blockIdx.x * (unsigned)kScanChunk + threadIdx.x * kScanItems;
+  unsigned v = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) v += base + k < n ? data[base + k] : 0u;
+  unsigned total;
+  (void)block256_exclusive_scan(v, tmp, total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void scan_chunk_apply_kernel(unsigned *__restrict__ data, unsigned n,
+                                                               const unsigned *__restrict__ sums) {
+  __shared__ unsigned tmp[4];
+  const unsigned base = blockIdx.x * (unsigned)kScanChunk + threadIdx.x * kScanItems;
+  unsigned item[kScanItems], v = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) { item[k] = base + k < n ? data[base + k] : 0u; v += item[k]; }
+  unsigned total;
+  unsigned run = sums[blockIdx.x] + block256_exclusive_scan(v, tmp, total);
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    if (base + k < n) data[base + k] = run;
+    run += item[k];
+  }
+}
+
+int exclusive_scan_u32(svoslam_workspace *ws, unsigned *data, unsigned n, unsigned *total, hipStream_t stream) {
+  if (n <= 4u * kScanChunk) {
+    row_scan_kernel<<<1, 256, 0, stream>>>(data, (int)n, total);
+    return SVOSLAM_OK;
+  }
+  const unsigned chunks = (unsigned)cdiv(n, kScanChunk);
+  SVO_TRY(ws->scan_tmp.reserve((size_t)chunks * 4));
+  unsigned *sums = ws->scan_tmp.as<unsigned>();
+  scan_chunk_sum_kernel<<<chunks, 256, 0, stream>>>(data, n, sums);
+  row_scan_kernel<<<1, 256, 0, stream>>>(sums, (int)chunks, total);
+  scan_chunk_apply_kernel<<<chunks, 256, 0, stream>>>(data, n, sums);
+  SVO_LAUNCH_CHECK();
+  return SVOSLAM_OK;
+}
+
 int radix_sort_num_tiles(int n) { return (int)cdiv(n, kSortTile); }
 
 void row_scan_rows(unsigned *rows, int num_tiles, unsigned *totals, hipStream_t stream) {

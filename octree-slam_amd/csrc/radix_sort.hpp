@@ -17,4 +17,6 @@ int radix_sort_output(svoslam_workspace *ws, int n, int num_bits, unsigned long 
 void row_scan_rows(unsigned *rows, int num_tiles, unsigned *totals, hipStream_t stream);
 // Same for a single row.
 void row_scan_rows1(unsigned *row, int num_tiles, unsigned *total, hipStream_t stream);
+// in-place exclusive scan of data[0..n) on any number of workgroups; *total (device) = the sum
+int exclusive_scan_u32(svoslam_workspace *ws, unsigned *data, unsigned n, unsigned *total, hipStream_t stream);
 }  // namespace svoslam

@@ -118,3 +118,52 @@ def write_generated_objs(directory):
             fp.write(text.encode())
         out["quirk_" + name] = path
     return out
+
+
+def write_colonnade_obj(path, n_cols=8, length=40.0, col_radius=0.15, col_height=4.0, segs=12, z_off=1.5,
+                        beam=0.2, slab=None):
+    """Stand-in for config 5's crytek-sponza (sponza.obj is not in the reference checkout): two rows of
+    n_cols prismatic columns (quad sides, triangle-fan caps) along x, a lintel box on each row and
+    optionally a floor slab (x half-width, z half-width); textured ('v/vt' faces).  x is the longest axis,
+    so the voxel grid edge is `length`."""
+    vs, vts, faces = [], [], []
+
+    def add_v(p, t):
+        vs.append(p)
+        vts.append(t)
+        return len(vs)
+
+    def box(x0, x1, y0, y1, z0, z1):
+        c = [add_v((x, y, z), ((x - x0) / max(x1 - x0, 1e-9) * 0.999, (y - y0 + z - z0) / max(y1 - y0 + z1 - z0, 1e-9) * 0.999))
+             for x in (x0, x1) for y in (y0, y1) for z in (z0, z1)]
+        for a, b, cc, d in ((0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)):
+            faces.append((c[a], c[b], c[cc], c[d]))
+
+    pitch = length / n_cols
+    for row, z in enumerate((-z_off, z_off)):
+        for k in range(n_cols):
+            cx = -length / 2 + pitch * (k + 0.5)
+            ring0, ring1 = [], []
+            for s in range(segs):
+                a = 2 * np.pi * s / segs + 0.1 * row
+                px, pz = cx + col_radius * np.cos(a), z + col_radius * np.sin(a)
+                ring0.append(add_v((px, 0.0, pz), (s / segs * 0.999, 0.0)))
+                ring1.append(add_v((px, col_height, pz), (s / segs * 0.999, 0.999)))
+            top = add_v((cx, col_height, z), (0.5, 0.5))
+            for s in range(segs):
+                t = (s + 1) % segs
+                faces.append((ring0[s], ring0[t], ring1[t], ring1[s]))
+                faces.append((ring1[s], ring1[t], top))
+        if beam:
+            box(-length / 2, length / 2, col_height, col_height + beam, z - beam / 2, z + beam / 2)
+    if slab:
+        box(-slab[0], slab[0], -0.05, 0.0, -slab[1], slab[1])
+    with open(path, "w") as fp:
+        fp.write("# generated colonnade\n")
+        for p in vs:
+            fp.write("v %.6f %.6f %.6f\n" % p)
+        for t in vts:
+            fp.write("vt %.6f %.6f\n" % t)
+        for f in faces:
+            fp.write("f " + " ".join("%d/%d" % (k, k) for k in f) + "\n")
+    return path

@@ -114,3 +114,43 @@ def test_scene_point_cloud_path(env, oracle):
     ed = int(np.ceil(np.log2(np.float64(f32(size) / f32(0.01)))))
     rce, rco = opool.extract(ed, center, size)
     assert np.array_equal(gce.view(np.uint32), rce.view(np.uint32)) and np.array_equal(gco.view(np.uint32), rco.view(np.uint32))
+
+
+def test_config5_style_depth16_4k_bands(env, oracle, tmp_path):
+    """config 5's shape (sponza.obj is not in the reference checkout: a procedural colonnade stands in): sparse
+    voxelization at 2^16 per axis -> depth-16 SVO -> 3840x2160 cone trace, whole and in 8 bands of 270 rows,
+    pool and image against the oracle.  The mesh is a needle-thin variant so that the oracle's 7.8 M voxels /
+    8.3 M rays stay within seconds; tools/mesh_bench.py times the 318 M-voxel variant."""
+    pkg, torch = env
+    log_n, (w, h) = 16, (3840, 2160)
+    path = meshgen.write_colonnade_obj(tmp_path / "col.obj", n_cols=1, length=8.0, col_radius=0.0003, col_height=2.0, segs=6,
+                                       z_off=1.0, beam=0.0002)
+    tex_path = meshgen.write_bmp(tmp_path / "t.bmp", 256, 256)
+    scene = pkg.Scene()
+    scene.load_obj(path)
+    scene.load_bmp(tex_path)
+    scene.voxelize_meshes(octree=True, log_n=log_n)
+    omesh, otex = oracle.mesh_load_obj(str(path)), oracle.load_bmp(str(tex_path))
+    opool, center, size, ece, eco, scale = oracle_scene(oracle, omesh, otex, log_n)
+    svo = scene.svo()
+    assert svo["max_depth"] == log_n and svo["num_nodes"] == opool.size > 1000000
+    gw, cw = scene.pool_words(), opool.words()
+    assert np.array_equal(gw, cw), describe_mismatch(gw, cw)
+    gce, gco, gscale = scene.voxel_grid()
+    assert gscale == scale and np.array_equal(gce.view(np.uint32), ece.view(np.uint32)) and np.array_equal(gco.view(np.uint32), eco.view(np.uint32))
+    # close to a column foot, so that the cone LOD reaches depth 16 (voxel 0.12 mm, pixel footprint 0.36 mrad)
+    target = ece[len(ece) // 3, :3].astype(np.float64)
+    view = oracle.look_at(tuple(target + np.array((0.004, 0.003, -0.012))), tuple(target), (0, 1, 0))
+    for mode in (0, 1):
+        img = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+        pkg.cone_trace_svo(img, 45.0, view, svo["data_ptr"], center, size, mode, counters=cnt)
+        ref, steps, levels = oracle.cone_trace(opool, w, h, 45.0, view, center, size, mode)
+        got = img.cpu().numpy()
+        assert np.array_equal(got, ref), describe_mismatch(got, ref)
+        assert [int(x) for x in cnt.cpu()] == [steps, levels]
+        band = torch.zeros_like(img)
+        for b in range(8):
+            pkg.cone_trace_svo_band(band, b * 270, 270, 45.0, view, svo["data_ptr"], center, size, mode)
+        assert torch.equal(band, img)
+    assert (ref[..., :3].sum(-1) > 0).sum() > 1000      # the column is in view (carry mode)
