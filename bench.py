@@ -134,7 +134,7 @@ def main():
     views = [pl.ground_truth_view(k, synth) for k in range(total)]
     mode = pkg.RENDER_REFERENCE if args.render_mode == "reference" else pkg.RENDER_CARRY
     P = pl.SlamPipeline(width, height, max_depth, center, edge, render_mode=mode, dist=dist, count_steps=True,
-                        pool_capacity_nodes=(1 << 30) - 8 if args.workload == "cfg4" else 1 << 28)   # 8.6 GB / 2.1 GB of 288 GB: room for
+                        pool_capacity_nodes=(1 << 30) - 8)   # the whole 30-bit index range of the node format, 8.6 GB of 288 GB: room for
     # the worst-case reservation of the frames in flight (sum_d min(8^d, n) splits per frame), so no fusion waits for a size readback
 
     def barrier():

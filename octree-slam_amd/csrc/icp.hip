@@ -506,42 +506,6 @@ __device__ inline void d_solve_cholesky(const float *A, const float *b, float *x
   }
 }
 
-// one ICP iteration's host part (rgbd_camera.cpp:143-160) from the 27 fixed-point sums
-__device__ inline void solve_step(CamState *st, const double *sums, int slot) {
-  float A[36], b[6], x[6];
-  int k = 0;
-  for (int i = 0; i < 6; i++)
-    for (int j = i; j < 6; j++) {
-      const float v = (float)(sums[k++] * (1.0 / kScaleA));
-      A[6 * i + j] = v;
-      A[6 * j + i] = v;
-    }
-  for (int i = 0; i < 6; i++) b[i] = (float)(sums[21 + i] * (1.0 / kScaleB));
-  for (int i = 0; i < 6; i++) x[i] = 0.0f;
-  d_solve_cholesky(A, b, x);
-  for (int i = 0; i < 36; i++) st->lastA[i] = A[i];
-  for (int i = 0; i < 6; i++) { st->lastb[i] = b[i]; st->lastx[i] = x[i]; }
-  if (x[0] != x[0] || x[1] != x[1] || x[2] != x[2] || x[3] != x[3] || x[4] != x[4] || x[5] != x[5]) {
-    st->lost = 1;  // "Camera tracking is lost." -> abandon this level (:148-151)
-    st->tracking_lost_count++;
-    return;
-  }
-  // this_trans = Rz(-x2) * Ry(-x1) * Rx(-x0) * T(x3,x4,x5), glm degrees API (:154-158)
-  float I[16], rz[16], ry[16], rx[16], tr[16], t1[16], t2[16], this_trans[16];
-  d_identity(I);
-  d_rotate_deg(I, -x[2] * 180.0f / 3.14159f, 0.0f, 0.0f, 1.0f, rz);
-  d_rotate_deg(I, -x[1] * 180.0f / 3.14159f, 0.0f, 1.0f, 0.0f, ry);
-  d_rotate_deg(I, -x[0] * 180.0f / 3.14159f, 1.0f, 0.0f, 0.0f, rx);
-  const float tv[3] = {x[3], x[4], x[5]};
-  d_translate(I, tv, tr);
-  d_mat4_mul(rz, ry, t1);
-  d_mat4_mul(t1, rx, t2);
-  d_mat4_mul(t2, tr, this_trans);
-  d_mat4_mul(this_trans, st->update_trans, st->update_trans);  // :160
-  if (slot < kMaxChain)
-    for (int i = 0; i < 16; i++) st->chain[slot][i] = this_trans[i];
-}
-
 // ---- the same iteration tail spread over ONE wavefront ---------------------------------------------
 // solveCholesky is a chain of 6 square roots and 27 divisions in binary64 (software sequences of ~30
 // dependent instructions each): executed by one lane it costs ~5 us per ICP iteration, 19 times a frame.
@@ -616,49 +580,26 @@ __device__ inline void wave_solve_cholesky(const double *sums, float *x, float &
   }
 }
 
-// wave form of solve_step; all 64 lanes of one wavefront call it
-__device__ inline void solve_step_wave(CamState *st, const double *sums, int slot) {
-  const int lane = (int)(threadIdx.x & 63u);
-  float x[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, a_elem, b_elem;
-  wave_solve_cholesky(sums, x, a_elem, b_elem);
-  if (lane < 36) st->lastA[lane] = a_elem;
-  if (lane < 6) { st->lastb[lane] = b_elem; st->lastx[lane] = x[lane < 6 ? lane : 0]; }
-  if (lane != 0) return;
-  if (x[0] != x[0] || x[1] != x[1] || x[2] != x[2] || x[3] != x[3] || x[4] != x[4] || x[5] != x[5]) {
-    st->lost = 1;  // "Camera tracking is lost." -> abandon this level (:148-151)
-    st->tracking_lost_count++;
-    return;
-  }
-  // this_trans = Rz(-x2) * Ry(-x1) * Rx(-x0) * T(x3,x4,x5), glm degrees API (:154-158)
-  float I[16], rz[16], ry[16], rx[16], tr[16], t1[16], t2[16], this_trans[16];
-  d_identity(I);
-  d_rotate_deg(I, -x[2] * 180.0f / 3.14159f, 0.0f, 0.0f, 1.0f, rz);
-  d_rotate_deg(I, -x[1] * 180.0f / 3.14159f, 0.0f, 1.0f, 0.0f, ry);
-  d_rotate_deg(I, -x[0] * 180.0f / 3.14159f, 1.0f, 0.0f, 0.0f, rx);
-  const float tv[3] = {x[3], x[4], x[5]};
-  d_translate(I, tv, tr);
-  d_mat4_mul(rz, ry, t1);
-  d_mat4_mul(t1, rx, t2);
-  d_mat4_mul(t2, tr, this_trans);
-  d_mat4_mul(this_trans, st->update_trans, st->update_trans);  // :160
-  if (slot < kMaxChain)
-    for (int i = 0; i < 16; i++) st->chain[slot][i] = this_trans[i];
+// element e = 4 * col + row of glm operator*(mat4, mat4) (type_mat4x4.inl:753-775): the expression of d_mat4_mul
+__device__ inline float mat4_mul_elem(const volatile float *a, const volatile float *b, int e) {
+  const int c = e >> 2, row = e & 3;
+  return ((a[row] * b[4 * c] + a[4 + row] * b[4 * c + 1]) + a[8 + row] * b[4 * c + 2]) + a[12 + row] * b[4 * c + 3];
 }
 
-// :172-173 pose update (Q17: row-vector products) and the fusion transform of main.cpp:40
-__device__ inline void frame_end_step(CamState *st, int apply_update) {
+// :172-173 pose update (Q17: row-vector products) and the fusion transform of main.cpp:40; m = update_trans
+__device__ inline void frame_end_step(CamState *st, int apply_update, const volatile float *m) {
   const int slot = st->frames_done;  // kept on the device so that the recorded launch sequence is the same for every frame
   if (apply_update) {
-    const float *m = st->update_trans;
     const float v[4] = {st->position[0], st->position[1], st->position[2], 1.0f};
     float np[3];
     for (int i = 0; i < 3; i++) np[i] = ((m[4 * i] * v[0] + m[4 * i + 1] * v[1]) + m[4 * i + 2] * v[2]) + m[4 * i + 3] * v[3];
     st->position[0] = np[0]; st->position[1] = np[1]; st->position[2] = np[2];
-    float o4[16], no[16];
+    float o4[16], mm[16], no[16];
     d_identity(o4);
     for (int c = 0; c < 3; c++)
       for (int r = 0; r < 3; r++) o4[4 * c + r] = st->orientation[3 * c + r];
-    d_mat4_mul(o4, m, no);
+    for (int i = 0; i < 16; i++) mm[i] = m[i];
+    d_mat4_mul(o4, mm, no);
     for (int c = 0; c < 3; c++)
       for (int r = 0; r < 3; r++) st->orientation[3 * c + r] = no[4 * c + r];
   }
@@ -673,11 +614,70 @@ __device__ inline void frame_end_step(CamState *st, int apply_update) {
   st->frames_done = slot + 1;
 }
 
-__device__ inline void level_begin_step(CamState *st, int flags) {
-  if (flags & kFlagFirstOfFrame) d_identity(st->update_trans);  // rgbd_camera.cpp:100
+// One ICP iteration's host part (rgbd_camera.cpp:100, :116-120, :143-160, :172-173) on ONE wavefront; all 64 lanes
+// call it.  sums = the 27 fixed-point sums (LDS), sm = 128 floats of LDS scratch.  The 4x4 matrices live one
+// element per lane (lanes 0..15): the three rotations are built side by side on lanes 0..2, the four matrix
+// products of :154-160 cost one LDS round trip each instead of 64 dependent multiply-adds on a single lane
+// (the tail used to take ~3 of the launch's 8.6 us).  Every element is the reference's expression, unchanged.
+constexpr int kTailScratch = 128;
+__device__ inline void iteration_tail_wave(CamState *st, const double *sums, int slot, int flags, volatile float *sm) {
+  const int lane = (int)(threadIdx.x & 63u), e = lane & 15;
+  // level start (:100, :116-120): update_trans element e on lane e
+  float ut = (flags & kFlagFirstOfFrame) ? ((e % 5 == 0) ? 1.0f : 0.0f) : st->update_trans[e];
+  int lost = 0;
   if (flags & kFlagFirstIter) {
-    for (int i = 0; i < 16; i++) st->level_start[i] = st->update_trans[i];  // :116-120
-    st->lost = 0;
+    if (lane < 16) st->level_start[e] = ut;
+    if (lane == 0) st->lost = 0;
+  } else {
+    lost = st->lost;
+  }
+  if ((flags & kFlagFirstOfFrame) && lane < 16) st->update_trans[e] = ut;
+  if (!lost) {
+    float x[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, a_elem, b_elem;
+    wave_solve_cholesky(sums, x, a_elem, b_elem);
+    if (lane < 36) st->lastA[lane] = a_elem;
+    if (lane < 6) { st->lastb[lane] = b_elem; st->lastx[lane] = x[lane < 6 ? lane : 0]; }
+    if (x[0] != x[0] || x[1] != x[1] || x[2] != x[2] || x[3] != x[3] || x[4] != x[4] || x[5] != x[5]) {
+      if (lane == 0) {
+        st->lost = 1;  // "Camera tracking is lost." -> abandon this level (:148-151)
+        st->tracking_lost_count++;
+      }
+    } else {
+      // this_trans = Rz(-x2) * Ry(-x1) * Rx(-x0) * T(x3,x4,x5), glm degrees API (:154-158)
+      const int k = lane < 2 ? lane : 2;  // lane 0: Rz, lane 1: Ry, lanes 2..: Rx
+      const float xk = k == 0 ? x[2] : (k == 1 ? x[1] : x[0]);
+      float I[16], R[16], tr[16];
+      d_identity(I);
+      d_rotate_deg(I, -xk * 180.0f / 3.14159f, k == 2 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 0 ? 1.0f : 0.0f, R);
+      const float tv[3] = {x[3], x[4], x[5]};
+      d_translate(I, tv, tr);
+      if (lane < 3)
+        for (int i = 0; i < 16; i++) sm[16 * lane + i] = R[i];
+      if (lane == 3)
+        for (int i = 0; i < 16; i++) sm[48 + i] = tr[i];
+      if (lane < 16) sm[112 + e] = ut;
+      __builtin_amdgcn_wave_barrier();
+      const float t1 = mat4_mul_elem(sm, sm + 16, e);          // Rz * Ry
+      if (lane < 16) sm[64 + e] = t1;
+      __builtin_amdgcn_wave_barrier();
+      const float t2 = mat4_mul_elem(sm + 64, sm + 32, e);     // * Rx
+      if (lane < 16) sm[80 + e] = t2;
+      __builtin_amdgcn_wave_barrier();
+      const float tt = mat4_mul_elem(sm + 80, sm + 48, e);     // * T  = this_trans
+      if (lane < 16) sm[96 + e] = tt;
+      __builtin_amdgcn_wave_barrier();
+      ut = mat4_mul_elem(sm + 96, sm + 112, e);                // update_trans = this_trans * update_trans (:160)
+      if (lane < 16) {
+        st->update_trans[e] = ut;
+        if (slot < kMaxChain) st->chain[slot][e] = tt;
+      }
+    }
+  }
+  if (flags & kFlagLastOfFrame) {
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16) sm[112 + e] = ut;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) frame_end_step(st, 1, sm + 112);
   }
 }
 
@@ -687,16 +687,10 @@ __global__ __launch_bounds__(kReduceThreads) void cam_reduce_solve_kernel(CamSta
   SVO_HIGH_PRIO();
   __shared__ double red[kReduceThreads / 32][27];
   __shared__ double totals[27];
+  __shared__ float tail_sm[kTailScratch];
   reduce_rows(partial, rows, red, totals);
   if (threadIdx.x >= 64) return;  // the tail runs on the first wavefront
-  int lost = 0;
-  if (threadIdx.x == 0) {
-    level_begin_step(st, flags);
-    lost = st->lost;
-  }
-  lost = __builtin_amdgcn_readfirstlane(lost);
-  if (!lost) solve_step_wave(st, totals, slot);
-  if (threadIdx.x == 0 && (flags & kFlagLastOfFrame)) frame_end_step(st, 1);
+  iteration_tail_wave(st, totals, slot, flags, tail_sm);
 }
 
 // multi-GPU iteration tail: acc[] holds the all-reduced sums
@@ -707,26 +701,21 @@ __global__ void cam_solve_kernel(CamState *st, double *acc, int slot, int flags)
   // paths, and the zero was observed to overtake the load -- six of the 27 sums read back as 0 once in a
   // few hundred frames.  A lane's vector load and store of one address stay in order.)
   __shared__ double sums[27];
+  __shared__ float tail_sm[kTailScratch];
   if (blockIdx.x) return;
   if (threadIdx.x < 27) {
     sums[threadIdx.x] = acc[threadIdx.x];
     acc[threadIdx.x] = 0.0;
   }
   __syncthreads();
-  int lost = 0;
-  if (threadIdx.x == 0) {
-    level_begin_step(st, flags);
-    lost = st->lost;
-  }
-  lost = __builtin_amdgcn_readfirstlane(lost);
-  if (!lost) solve_step_wave(st, sums, slot);
-  if (threadIdx.x == 0 && (flags & kFlagLastOfFrame)) frame_end_step(st, 1);
+  if (threadIdx.x >= 64) return;
+  iteration_tail_wave(st, sums, slot, flags, tail_sm);
 }
 
 __global__ void cam_frame_end_kernel(CamState *st, int apply_update) {
   SVO_HIGH_PRIO();
   if (threadIdx.x || blockIdx.x) return;
-  frame_end_step(st, apply_update);
+  frame_end_step(st, apply_update, st->update_trans);
 }
 
 }  // namespace svoslam
