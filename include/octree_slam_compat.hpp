@@ -206,6 +206,25 @@ inline void meshToVoxelGrid(const Mesh &m_in, const bmp_texture *tex, VoxelGrid 
   grid_out.scale = scale;
   grid_out.bbox = m_in.bbox;
 }
+// voxelization.h:13,19 / voxelization.cu:325-379: m_out's arrays are malloc'ed host memory, as in the reference
+const float CUBE_MESH_SCALE = 0.1f;
+inline void voxelGridToMesh(const VoxelGrid &grid, const Mesh &m_cube, Mesh &m_out) {
+  if (m_cube.vbosize != m_cube.nbosize) throw std::runtime_error("voxelGridToMesh: cube vbo and nbo have different sizes");
+  const size_t nv = (size_t)grid.size * m_cube.vbosize, ni = (size_t)grid.size * m_cube.ibosize;
+  void *dv = nullptr, *di = nullptr, *dn = nullptr, *dc = nullptr;
+  detail::check(svoslam_malloc(&dv, (nv ? nv : 1) * 4), "voxelGridToMesh"); detail::check(svoslam_malloc(&dn, (nv ? nv : 1) * 4), "voxelGridToMesh");
+  detail::check(svoslam_malloc(&dc, (nv ? nv : 1) * 4), "voxelGridToMesh"); detail::check(svoslam_malloc(&di, (ni ? ni : 1) * 4), "voxelGridToMesh");
+  const float scale = (grid.bbox.bbox1.x - grid.bbox.bbox0.x) / float(1 << log_N()) / 2.0f / CUBE_MESH_SCALE;  // computeScale / CUBE_MESH_SCALE
+  detail::check(svoslam_voxel_grid_to_mesh(detail::Registry::get().workspace(), &grid.centers->x, &grid.colors->x, grid.size, scale,
+                                           m_cube.vbo, m_cube.vbosize, m_cube.ibo, m_cube.ibosize, m_cube.nbo, (float *)dv, (int32_t *)di,
+                                           (float *)dn, (float *)dc, nullptr), "voxelGridToMesh");
+  m_out.vbosize = (int)nv; m_out.ibosize = (int)ni; m_out.nbosize = (int)nv; m_out.cbosize = (int)nv;
+  m_out.vbo = (float *)malloc((nv ? nv : 1) * 4); m_out.ibo = (int *)malloc((ni ? ni : 1) * 4);
+  m_out.nbo = (float *)malloc((nv ? nv : 1) * 4); m_out.cbo = (float *)malloc((nv ? nv : 1) * 4);
+  detail::check(svoslam_memcpy_d2h(m_out.vbo, dv, nv * 4), "voxelGridToMesh"); detail::check(svoslam_memcpy_d2h(m_out.ibo, di, ni * 4), "voxelGridToMesh");
+  detail::check(svoslam_memcpy_d2h(m_out.nbo, dn, nv * 4), "voxelGridToMesh"); detail::check(svoslam_memcpy_d2h(m_out.cbo, dc, nv * 4), "voxelGridToMesh");
+  svoslam_free(dv); svoslam_free(di); svoslam_free(dn); svoslam_free(dc);
+}
 }  // namespace voxelization
 // timing_utils.h:5-10
 inline void startTiming() { detail::check(svoslam_timer_start(nullptr), "startTiming"); }

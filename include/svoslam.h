@@ -156,8 +156,10 @@ int svoslam_extract_voxel_grid(svoslam_workspace *ws, const svoslam_pool *pool, 
                                const float center[3], float edge_length, float **d_centers, float **d_colors,
                                int32_t *n_out, void *stream);
 int svoslam_free(void *d_ptr);
-/* device allocation for callers that do not link the HIP runtime themselves */
+/* device allocation / copies for callers that do not link the HIP runtime themselves (blocking copies) */
 int svoslam_malloc(void **d_ptr, size_t bytes);
+int svoslam_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);
+int svoslam_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
 
 /* ------------------------------------------------------------------------
  * Mesh path (configs 1, 2, 5): OBJ/BMP loading and mesh -> voxel grid
@@ -192,6 +194,16 @@ int svoslam_texture_free(svoslam_texture *tex);
 int svoslam_mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const svoslam_texture *tex, int32_t log_N,
                                int32_t log_T, float **d_centers, float **d_colors, unsigned long long **d_indices,
                                int32_t *n_out, float *scale_out, void *stream);
+
+/* replaces voxelization::voxelGridToMesh (include/octree_slam/world/voxelization/voxelization.h:19,
+ * src/world/voxelization/voxelization.cu:184-217, :325-379; SURVEY 8f.4, a display aid): one copy of the cube mesh
+ * (host arrays: cube_vbosize floats of positions and of normals, cube_ibosize indices) per voxel, positions
+ * cube * scale_factor + centre, colours replicated per vertex component, indices + idx * cube_ibosize (the
+ * reference's offset).  scale_factor = computeScale(bbox) / CUBE_MESH_SCALE (0.1) in the reference.  Outputs are
+ * device arrays of the caller: n * cube_vbosize floats (vbo, nbo, cbo), n * cube_ibosize ints (ibo).  Blocking. */
+int svoslam_voxel_grid_to_mesh(svoslam_workspace *ws, const float *d_centers, const float *d_colors, int32_t n, float scale_factor,
+                               const float *cube_vbo, int32_t cube_vbosize, const int32_t *cube_ibo, int32_t cube_ibosize,
+                               const float *cube_nbo, float *d_vbo, int32_t *d_ibo, float *d_nbo, float *d_cbo, void *stream);
 
 /* ------------------------------------------------------------------------
  * Recorded-sensor input: replaces sensor::OpenNIDevice

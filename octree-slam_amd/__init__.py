@@ -105,6 +105,9 @@ SIGNATURES = {
     "svoslam_texture_free": (C.c_int, [C.POINTER(TextureStruct)]),
     "svoslam_mesh_to_voxel_grid": (C.c_int, [_vp, C.POINTER(MeshStruct), C.POINTER(TextureStruct), _i32, _i32, C.POINTER(_vp),
                                              C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _fp, _vp]),
+    "svoslam_voxel_grid_to_mesh": (C.c_int, [_vp, _vp, _vp, _i32, _f32, _fp, _i32, C.POINTER(C.c_int32), _i32, _fp, _vp, _vp, _vp, _vp, _vp]),
+    "svoslam_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "svoslam_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
     "svoslam_scene_create": (C.c_int, [C.POINTER(_vp)]),
     "svoslam_scene_destroy": (C.c_int, [_vp]),
     "svoslam_scene_load_obj": (C.c_int, [_vp, C.c_char_p]),
@@ -450,6 +453,23 @@ def mesh_to_voxel_grid(ws, mesh, tex, log_n, log_t=3, want_indices=True):
             _hip().hipMemcpy(C.c_void_p(idx.ctypes.data), pi, C.c_size_t(cnt * 8), 2)
             lib().svoslam_free(pi)
     return ce, co, idx, float(scale.value)
+
+
+def voxel_grid_to_mesh(ws, centers, colors, scale_factor, cube_vbo, cube_ibo, cube_nbo):
+    """voxelization::voxelGridToMesh: centers, colors cuda float32 [n,4]; cube arrays numpy -> cuda (vbo, ibo, nbo, cbo)."""
+    import torch
+    cv = np.ascontiguousarray(cube_vbo, np.float32).reshape(-1)
+    cn = np.ascontiguousarray(cube_nbo, np.float32).reshape(-1)
+    ci = np.ascontiguousarray(cube_ibo, np.int32).reshape(-1)
+    if cv.size != cn.size:
+        raise ValueError("cube vbo and nbo have different sizes")
+    n = int(centers.shape[0])
+    vbo, nbo, cbo = (torch.empty(n * cv.size, dtype=torch.float32, device="cuda") for _ in range(3))
+    ibo = torch.empty(n * ci.size, dtype=torch.int32, device="cuda")
+    check(lib().svoslam_voxel_grid_to_mesh(ws._h, _ptr(centers), _ptr(colors), n, float(scale_factor),
+                                           cv.ctypes.data_as(_fp), cv.size, ci.ctypes.data_as(C.POINTER(C.c_int32)), ci.size,
+                                           cn.ctypes.data_as(_fp), _ptr(vbo), _ptr(ibo), _ptr(nbo), _ptr(cbo), _stream()))
+    return vbo, ibo, nbo, cbo
 
 
 class Scene:

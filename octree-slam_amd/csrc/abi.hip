@@ -250,10 +250,34 @@ int svoslam_mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, 
   return mesh_to_voxel_grid(ws, mesh, tex, log_N, log_T, d_centers, d_colors, d_indices, n_out, scale_out, S(stream));
 }
 
+int svoslam_voxel_grid_to_mesh(svoslam_workspace *ws, const float *d_centers, const float *d_colors, int32_t n, float scale_factor,
+                               const float *cube_vbo, int32_t cube_vbosize, const int32_t *cube_ibo, int32_t cube_ibosize,
+                               const float *cube_nbo, float *d_vbo, int32_t *d_ibo, float *d_nbo, float *d_cbo, void *stream) {
+  NEED_DEVICE();
+  return voxel_grid_to_mesh(ws, d_centers, d_colors, n, scale_factor, cube_vbo, cube_vbosize, cube_ibo, cube_ibosize, cube_nbo, d_vbo,
+                            d_ibo, d_nbo, d_cbo, S(stream));
+}
+
 int svoslam_malloc(void **d_ptr, size_t bytes) {
   NEED_DEVICE();
   if (!d_ptr) return SVOSLAM_ERR_INVALID_ARG;
   SVO_HIP(hipMalloc(d_ptr, bytes));
+  return SVOSLAM_OK;
+}
+
+int svoslam_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes) {
+  NEED_DEVICE();
+  if (bytes == 0) return SVOSLAM_OK;
+  if (!d_dst || !h_src) return SVOSLAM_ERR_INVALID_ARG;
+  SVO_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return SVOSLAM_OK;
+}
+
+int svoslam_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes) {
+  NEED_DEVICE();
+  if (bytes == 0) return SVOSLAM_OK;
+  if (!h_dst || !d_src) return SVOSLAM_ERR_INVALID_ARG;
+  SVO_HIP(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
   return SVOSLAM_OK;
 }
 

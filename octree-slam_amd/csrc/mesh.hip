@@ -361,6 +361,55 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   return SVOSLAM_OK;
 }
 
+// voxelization::voxelGridToMesh (voxelization.cu:325-379) / createCubeMesh (:184-217): one copy of the cube mesh per voxel.
+// The reference runs one thread per voxel over all of its floats (stride-vbosize stores); here one thread per
+// output element, so every store of a wavefront is contiguous.  The index offset is the reference's own
+// (idx * cube_ibosize, not the vertex offset).
+__global__ __launch_bounds__(256) void cube_mesh_kernel(const float4 *__restrict__ centers, const float4 *__restrict__ colors,
+                                                       float scale_factor, long long total_v, long long total_i,
+                                                       const float *__restrict__ cube_vbo, int cube_vbosize,
+                                                       const int *__restrict__ cube_ibo, int cube_ibosize,
+                                                       const float *__restrict__ cube_nbo, float *__restrict__ out_vbo,
+                                                       int *__restrict__ out_ibo, float *__restrict__ out_nbo,
+                                                       float *__restrict__ out_cbo) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t < total_v) {
+    const int idx = (int)(t / cube_vbosize), i = (int)(t - (long long)idx * cube_vbosize), a = i % 3;
+    const float4 c = centers[idx], k = colors[idx];
+    out_vbo[t] = cube_vbo[i] * scale_factor + (a == 0 ? c.x : (a == 1 ? c.y : c.z));
+    out_cbo[t] = a == 0 ? k.x : (a == 1 ? k.y : k.z);
+    out_nbo[t] = cube_nbo[i];
+  }
+  if (t < total_i) {
+    const int idx = (int)(t / cube_ibosize), i = (int)(t - (long long)idx * cube_ibosize);
+    out_ibo[t] = cube_ibo[i] + idx * cube_ibosize;
+  }
+}
+
+int voxel_grid_to_mesh(svoslam_workspace *ws, const float *d_centers, const float *d_colors, int n, float scale_factor,
+                       const float *cube_vbo, int cube_vbosize, const int *cube_ibo, int cube_ibosize, const float *cube_nbo,
+                       float *d_vbo, int *d_ibo, float *d_nbo, float *d_cbo, hipStream_t stream) {
+  if (!ws || n < 0 || cube_vbosize <= 0 || cube_ibosize <= 0 || !cube_vbo || !cube_ibo || !cube_nbo) return SVOSLAM_ERR_INVALID_ARG;
+  if (n == 0) return SVOSLAM_OK;
+  if (!d_centers || !d_colors || !d_vbo || !d_ibo || !d_nbo || !d_cbo) return SVOSLAM_ERR_INVALID_ARG;
+  if ((long long)n * cube_ibosize > 0x7FFFFFFFll) return SVOSLAM_ERR_INVALID_ARG;  // the reference's int offsets
+  DeviceBuffer &dc = ws->misc;
+  SVO_TRY(dc.reserve((size_t)(2 * cube_vbosize + cube_ibosize) * 4));
+  float *dv = dc.as<float>(), *dn = dv + cube_vbosize;
+  int *di = reinterpret_cast<int *>(dn + cube_vbosize);
+  SVO_HIP(hipMemcpyAsync(dv, cube_vbo, (size_t)cube_vbosize * 4, hipMemcpyHostToDevice, stream));
+  SVO_HIP(hipMemcpyAsync(dn, cube_nbo, (size_t)cube_vbosize * 4, hipMemcpyHostToDevice, stream));
+  SVO_HIP(hipMemcpyAsync(di, cube_ibo, (size_t)cube_ibosize * 4, hipMemcpyHostToDevice, stream));
+  const long long total_v = (long long)n * cube_vbosize, total_i = (long long)n * cube_ibosize;
+  const long long total = total_v > total_i ? total_v : total_i;
+  cube_mesh_kernel<<<(unsigned)cdiv(total, 256), 256, 0, stream>>>(reinterpret_cast<const float4 *>(d_centers),
+                                                                  reinterpret_cast<const float4 *>(d_colors), scale_factor, total_v,
+                                                                  total_i, dv, cube_vbosize, di, cube_ibosize, dn, d_vbo, d_ibo, d_nbo, d_cbo);
+  SVO_LAUNCH_CHECK();
+  SVO_HIP(hipStreamSynchronize(stream));  // the staged cube arrays are pageable host memory of the caller
+  return SVOSLAM_OK;
+}
+
 // ----------------------------------------------------------------------------
 // host loaders
 // ----------------------------------------------------------------------------

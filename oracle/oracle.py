@@ -451,6 +451,20 @@ def mesh_load_obj(path):
     return {"vbo": vbo, "tbo": tbo, "bbox0": b0, "bbox1": b1}
 
 
+def voxel_grid_to_mesh(centers, colors, scale_factor, cube_vbo, cube_ibo, cube_nbo):
+    """voxelGridToMesh -> (vbo, ibo, nbo, cbo) flat arrays"""
+    ce, co = _f32(centers).reshape(-1, 4), _f32(colors).reshape(-1, 4)
+    cv, cn = _f32(cube_vbo).reshape(-1), _f32(cube_nbo).reshape(-1)
+    ci = np.ascontiguousarray(cube_ibo, dtype=np.int32).reshape(-1)
+    n = ce.shape[0]
+    vbo, nbo, cbo = (np.empty(n * cv.size, np.float32) for _ in range(3))
+    ibo = np.empty(n * ci.size, np.int32)
+    lib().ora_voxel_grid_to_mesh(_p(ce, C.c_float), _p(co, C.c_float), n, C.c_float(scale_factor), _p(cv, C.c_float), cv.size,
+                                 _p(ci, C.c_int), ci.size, _p(cn, C.c_float), _p(vbo, C.c_float), _p(ibo, C.c_int),
+                                 _p(nbo, C.c_float), _p(cbo, C.c_float))
+    return vbo, ibo, nbo, cbo
+
+
 _REF_OBJ = None
 
 

@@ -143,6 +143,15 @@ int ora_mesh_to_voxel_grid(const float *vbo, int n_tris, const float *tbo, int t
                            int tex_h, const float bbox0[3], const float bbox1[3], int log_N, int log_T,
                            float **centers, float **colors, int64_t **indices);
 
+/* voxelization::voxelGridToMesh / createCubeMesh (src/world/voxelization/voxelization.cu:184-217, :325-379):
+ * one copy of the cube mesh per voxel, scaled by scale_factor = computeScale(bbox) / CUBE_MESH_SCALE and
+ * moved to the voxel centre; colours replicated per vertex component; indices offset by idx * cube_ibosize
+ * (the reference's own offset, kept).  Outputs hold n * cube_vbosize floats (vbo, nbo, cbo) and
+ * n * cube_ibosize ints (ibo), allocated by the caller. */
+void ora_voxel_grid_to_mesh(const float *centers, const float *colors, int n, float scale_factor, const float *cube_vbo,
+                            int cube_vbosize, const int *cube_ibo, int cube_ibosize, const float *cube_nbo, float *out_vbo,
+                            int *out_ibo, float *out_nbo, float *out_cbo);
+
 #ifdef __cplusplus
 }
 #endif

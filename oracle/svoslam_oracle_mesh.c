@@ -356,3 +356,20 @@ int ora_mesh_to_voxel_grid(const float *vbo, int n_tris, const float *tbo, int t
   free(frags);
   return (int)count;
 }
+
+/* createCubeMesh, voxelization.cu:184-217 */
+void ora_voxel_grid_to_mesh(const float *centers, const float *colors, int n, float scale_factor, const float *cube_vbo,
+                            int cube_vbosize, const int *cube_ibo, int cube_ibosize, const float *cube_nbo, float *out_vbo,
+                            int *out_ibo, float *out_nbo, float *out_cbo) {
+  for (int idx = 0; idx < n; idx++) {
+    const int vbo_offset = idx * cube_vbosize, ibo_offset = idx * cube_ibosize;
+    const float *c = centers + 4 * (size_t)idx, *k = colors + 4 * (size_t)idx;
+    for (int i = 0; i < cube_vbosize; i++) {
+      const int a = i % 3;
+      out_vbo[vbo_offset + i] = cube_vbo[i] * scale_factor + c[a];
+      out_cbo[vbo_offset + i] = k[a];
+      out_nbo[vbo_offset + i] = cube_nbo[i];
+    }
+    for (int i = 0; i < cube_ibosize; i++) out_ibo[ibo_offset + i] = cube_ibo[i] + ibo_offset;
+  }
+}

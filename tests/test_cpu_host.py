@@ -175,6 +175,7 @@ void fuse_and_render(const vec3* d_points, const Color256* d_colors, int n, ucha
   sensor::ICPFrame a(8, 8), b(8, 8); float A[36], bb[6]; sensor::computeICPCost2(&a, b, A, bb); sensor::computeICPCost(&a, b, A, bb);
   startTiming(); (void)stopTiming();
   Mesh m; VoxelGrid vg; voxelization::meshToVoxelGrid(m, nullptr, vg); (void)voxelization::log_N();
+  Mesh cube, cubes; voxelization::voxelGridToMesh(vg, cube, cubes);
 }
 int main() {
   try { fuse_and_render(nullptr, nullptr, 0, nullptr); } catch (const std::exception& e) { return 0; }

@@ -154,3 +154,30 @@ def test_config5_style_depth16_4k_bands(env, oracle, tmp_path):
             pkg.cone_trace_svo_band(band, b * 270, 270, 45.0, view, svo["data_ptr"], center, size, mode)
         assert torch.equal(band, img)
     assert (ref[..., :3].sum(-1) > 0).sum() > 1000      # the column is in view (carry mode)
+
+
+def test_voxel_grid_to_mesh(env, oracle, tmp_path):
+    """voxelization::voxelGridToMesh: a cube mesh instanced per voxel of a voxelized mesh (vbo/ibo/nbo/cbo bit-exact)"""
+    pkg, torch = env
+    path = meshgen.write_sphere_obj(tmp_path / "s.obj")
+    tex_path = meshgen.write_bmp(tmp_path / "t.bmp")
+    mesh, tex = pkg.Mesh(path), pkg.Texture(tex_path)
+    ws = pkg.Workspace()
+    ce, co, _, scale = pkg.mesh_to_voxel_grid(ws, mesh, tex, 7, want_indices=False)
+    assert ce.shape[0] > 1000
+    cube = oracle.mesh_load_obj(str(meshgen.write_cube_obj(tmp_path / "cube.obj", h=1.0)))
+    cube_vbo = cube["vbo"].reshape(-1)
+    rng = np.random.default_rng(3)
+    cube_nbo = rng.standard_normal(cube_vbo.size).astype(np.float32)   # any per-vertex normals: they are copied through
+    cube_ibo = np.arange(cube_vbo.size // 3, dtype=np.int32)
+    factor = float(np.float32(scale) / np.float32(0.1))                  # computeScale / CUBE_MESH_SCALE
+    vbo, ibo, nbo, cbo = pkg.voxel_grid_to_mesh(ws, ce, co, factor, cube_vbo, cube_ibo, cube_nbo)
+    rv, ri, rn, rc = oracle.voxel_grid_to_mesh(ce.cpu().numpy(), co.cpu().numpy(), factor, cube_vbo, cube_ibo, cube_nbo)
+    assert np.array_equal(vbo.cpu().numpy().view(np.uint32), rv.view(np.uint32))
+    assert np.array_equal(ibo.cpu().numpy(), ri)
+    assert np.array_equal(nbo.cpu().numpy().view(np.uint32), rn.view(np.uint32))
+    assert np.array_equal(cbo.cpu().numpy().view(np.uint32), rc.view(np.uint32))
+    # an empty grid is accepted
+    e = torch.zeros((0, 4), dtype=torch.float32, device="cuda")
+    v0, i0, n0, c0 = pkg.voxel_grid_to_mesh(ws, e, e, factor, cube_vbo, cube_ibo, cube_nbo)
+    assert v0.numel() == 0 and i0.numel() == 0
