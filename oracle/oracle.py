@@ -97,6 +97,8 @@ def lib(native=False):
     L.ora_camera_pose.argtypes = [C.c_void_p, f32p, f32p]
     L.ora_camera_fusion_transform.argtypes = [C.c_void_p, f32p]
     L.ora_camera_last_system.argtypes = [C.c_void_p, f32p, f32p, f32p]
+    L.ora_camera_tracking_lost_count.restype = C.c_int
+    L.ora_camera_tracking_lost_count.argtypes = [C.c_void_p]
     L.ora_mesh_load_obj.restype = C.c_int
     L.ora_mesh_load_obj.argtypes = [C.c_char_p, C.POINTER(f32p), C.POINTER(f32p), C.POINTER(C.c_int), f32p, f32p]
     L.ora_load_bmp.restype = C.c_int
@@ -408,6 +410,9 @@ class Camera:
         p = np.empty(3, np.float32); o = np.empty(9, np.float32)
         self._L.ora_camera_pose(self._c, _p(p, C.c_float), _p(o, C.c_float))
         return p, o
+
+    def tracking_lost_count(self):
+        return int(self._L.ora_camera_tracking_lost_count(self._c))
 
     def fusion_transform(self):
         m = np.empty(16, np.float32)

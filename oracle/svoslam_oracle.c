@@ -1082,6 +1082,7 @@ struct ora_camera {
   float orientation[9]; /* column-major mat3 */
   float *last_v[PYR], *last_n[PYR], *cur_v[PYR], *cur_n[PYR];
   float lastA[36], lastb[6], lastx[6];
+  int lost_count; /* levels abandoned with "Camera tracking is lost." (rgbd_camera.cpp:148-151) */
 };
 
 ora_camera *ora_camera_create(int w, int h, float fx, float fy) {
@@ -1142,7 +1143,7 @@ int ora_camera_update(ora_camera *c, const uint16_t *depth, const uint8_t *rgb, 
         ora_icp_cost2(c->last_v[i], c->last_n[i], fv, fn, w, h, A1, b1);
         ora_solve_cholesky(6, A1, b1, x);
         memcpy(c->lastA, A1, sizeof(A1)); memcpy(c->lastb, b1, sizeof(b1)); memcpy(c->lastx, x, sizeof(x));
-        if (x[0] != x[0] || x[1] != x[1] || x[2] != x[2] || x[3] != x[3] || x[4] != x[4] || x[5] != x[5]) break;
+        if (x[0] != x[0] || x[1] != x[1] || x[2] != x[2] || x[3] != x[3] || x[4] != x[4] || x[5] != x[5]) { c->lost_count++; break; }
         float this_trans[16];
         ora_icp_update_transform(x, this_trans);
         ora_mat4_mul(this_trans, update_trans, update_trans);
@@ -1171,6 +1172,8 @@ int ora_camera_update(ora_camera *c, const uint16_t *depth, const uint8_t *rgb, 
   }
   return 1;
 }
+
+int ora_camera_tracking_lost_count(const ora_camera *c) { return c->lost_count; }
 
 void ora_camera_pose(const ora_camera *c, float position[3], float orientation[9]) {
   memcpy(position, c->position, sizeof(float) * 3);

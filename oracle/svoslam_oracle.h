@@ -128,6 +128,7 @@ void ora_camera_destroy(ora_camera *c);
 /* returns 1 if the frame was processed, 0 if skipped (stale timestamp) */
 int ora_camera_update(ora_camera *c, const uint16_t *depth, const uint8_t *rgb, long long timestamp);
 void ora_camera_pose(const ora_camera *c, float position[3], float orientation[9]);
+int ora_camera_tracking_lost_count(const ora_camera *c);
 /* model matrix used by main.cpp:40 : mat4(orientation) * translate(I, position) */
 void ora_camera_fusion_transform(const ora_camera *c, float out[16]);
 /* last A,b,x of the last processed frame, for tests */

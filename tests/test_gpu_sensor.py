@@ -253,3 +253,47 @@ def test_camera_tracker_full_size_matches_oracle_and_is_repeatable(env, oracle):
         runs.append((np.stack(poses), cam.tracking_lost_count()))
     assert np.array_equal(runs[0][0].view(np.uint32), runs[1][0].view(np.uint32))
     assert runs[0][1] == runs[1][1]
+
+
+def test_camera_tracking_lost_matches_oracle(env, oracle):
+    """'Camera tracking is lost' (rgbd_camera.cpp:148-151): a frame without valid depth has no correspondences, the
+    6x6 system is zero, Cholesky divides 0 by 0 and every pyramid level is abandoned on its first iteration; a frame
+    with depth only in one corner loses some levels only.  Pose, last system, counters and the frames after the
+    loss must match the oracle bit for bit (NaN == NaN); also through the stepping API."""
+    pkg, torch, synth = env
+    w, h = 160, 120
+    f = synth.focal_length(w)
+    cam, cam_s, ocam = pkg.Camera(w, h, f, f), pkg.Camera(w, h, f, f), oracle.Camera(w, h, f, f)
+    acc = torch.zeros(27, dtype=torch.float64, device="cuda")
+    cam_s.set_acc(acc)
+    lost_seen = 0
+    for k in range(7):
+        d, c = synth.render_frame(3 * k, w, h)
+        d = d.clone()
+        if k == 2:
+            d.zero_()                                   # nothing valid
+        if k == 4:
+            d[:, 12:] = 0                               # a sliver of the image: too little for the fine levels or all
+            d[40:, :] = 0
+        dn = d.numpy().view(np.uint16)
+        assert cam.update(d.cuda(), c.cuda(), k) == ocam.update(dn, c.numpy(), k) == 1
+        assert cam_s.begin(d.cuda(), c.cuda(), k) == 1
+        for level in (2, 1, 0):
+            for it in range(pkg.PYRAMID_ITERS[level]):
+                cam_s.icp_accumulate(level, it)
+                cam_s.icp_solve(level, it)
+        cam_s.end()
+        for cc in (cam, cam_s):
+            p, o = cc.pose(); rp, ro = ocam.pose()
+            assert np.array_equal(p.view(np.uint32), rp.view(np.uint32)), (k, p, rp)
+            assert np.array_equal(o.view(np.uint32), ro.view(np.uint32)), (k, o, ro)
+            assert cc.tracking_lost_count() == ocam.tracking_lost_count(), k
+            if k >= 1:
+                A, b, x = cc.last_system(); rA, rb, rx = ocam.last_system()
+                # NaN == NaN: the sign / payload of a generated NaN is the FPU's choice (x86 host code in the reference)
+                assert np.array_equal(A, rA, equal_nan=True) and np.array_equal(b, rb, equal_nan=True)
+                assert np.array_equal(x, rx, equal_nan=True), (k, x, rx)
+            fus = pkg.copy_from_device(cc.fusion_transform_ptr(), (16,), np.float32)
+            assert np.array_equal(fus.view(np.uint32), ocam.fusion_transform().view(np.uint32))
+        lost_seen = ocam.tracking_lost_count()
+    assert lost_seen >= 6                                # frames 2 and 3 (no valid partner) lose all three levels each
