@@ -31,7 +31,20 @@ struct int2_t { int x, y; };
 struct uchar4_t { unsigned char x, y, z, w; };
 
 struct Color256 { uint8_t r, g, b; };                         // common_types.h:49-53
-struct BoundingBox { vec3 bbox0{0, 0, 0}, bbox1{0, 0, 0}; };  // common_types.h:8-18
+struct BoundingBox {                                          // common_types.h:8-18, common_types.cu:8-34
+  vec3 bbox0{0, 0, 0}, bbox1{0, 0, 0};
+  bool contains(const BoundingBox &o) const {
+    return bbox0.x <= o.bbox0.x && bbox0.y <= o.bbox0.y && bbox0.z <= o.bbox0.z && bbox1.x >= o.bbox1.x && bbox1.y >= o.bbox1.y &&
+           bbox1.z >= o.bbox1.z;
+  }
+  float distanceOutside(const BoundingBox &o) const {           // as written in the reference (:22-34), operand order kept
+    float r = 0.0f;
+    r = r > o.bbox0.x - bbox0.x ? r : o.bbox0.x - bbox0.x; r = r > o.bbox0.y - bbox0.y ? r : o.bbox0.y - bbox0.y;
+    r = r > o.bbox0.z - bbox0.z ? r : o.bbox0.z - bbox0.z; r = r > bbox1.x - o.bbox1.x ? r : bbox1.x - o.bbox1.x;
+    r = r > bbox1.y - o.bbox1.y ? r : bbox1.y - o.bbox1.y; r = r > bbox1.z - o.bbox1.z ? r : bbox1.z - o.bbox1.z;
+    return r;
+  }
+};
 struct VoxelGrid {                                            // common_types.h:55-63
   vec4 *centers = nullptr;
   vec4 *colors = nullptr;
@@ -39,6 +52,23 @@ struct VoxelGrid {                                            // common_types.h:
   float scale = 0.0f;
   BoundingBox bbox;
   ~VoxelGrid() { if (size > 0) { svoslam_free(centers); svoslam_free(colors); } }
+};
+struct RawFrame {                                             // common_types.h:65-73, common_types.cu:36-45
+  RawFrame(const int w, const int h) : height(h), width(w) {
+    void *c = nullptr, *d = nullptr;
+    if (svoslam_malloc(&c, (size_t)w * h * sizeof(Color256)) != 0 || svoslam_malloc(&d, (size_t)w * h * sizeof(uint16_t)) != 0) {
+      svoslam_free(c);
+      throw std::runtime_error("RawFrame: device allocation failed");
+    }
+    color = static_cast<Color256 *>(c); depth = static_cast<uint16_t *>(d);
+  }
+  ~RawFrame() { svoslam_free(color); svoslam_free(depth); }
+  RawFrame(const RawFrame &) = delete;
+  RawFrame &operator=(const RawFrame &) = delete;
+  Color256 *color = nullptr;
+  uint16_t *depth = nullptr;
+  int height, width;
+  long long timestamp = 0;
 };
 struct SVO { unsigned int *data; vec3 center; float size; };  // common_types.h:75-79
 
@@ -157,6 +187,34 @@ inline void transformVertexMap(vec3 *vertex_map, const mat4 &trans, const int si
 }
 inline void transformNormalMap(vec3 *normal_map, const mat4 &trans, const int size) {
   detail::check(svoslam_transform_normal_map(&normal_map->x, trans.m, size, nullptr), "transformNormalMap");
+}
+// image_kernels.h:36-42: in place, the (width/2 x height/2) result overwrites the head of data
+namespace sub_detail {
+template <class T, class F> inline void subsample_with(F f, T *data, int width, int height, const char *what) {
+  void *tmp = nullptr;
+  octree_slam::detail::check(svoslam_malloc(&tmp, (size_t)(width / 2) * (height / 2) * sizeof(T) + 16), what);
+  const int rc = f(data, static_cast<T *>(tmp), width, height, nullptr);
+  svoslam_free(tmp);
+  octree_slam::detail::check(rc, what);
+}
+}  // namespace sub_detail
+template <class T> void subsample(T *data, const int width, const int height);
+template <> inline void subsample<float>(float *data, const int width, const int height) {
+  sub_detail::subsample_with<float>(svoslam_subsample_f32, data, width, height, "subsample<float>");
+}
+template <> inline void subsample<Color256>(Color256 *data, const int width, const int height) {
+  void *tmp = nullptr;
+  octree_slam::detail::check(svoslam_malloc(&tmp, (size_t)(width / 2) * (height / 2) * 3 + 16), "subsample<Color256>");
+  const int rc = svoslam_subsample_rgb8(&data->r, static_cast<uint8_t *>(tmp), width, height, nullptr);
+  svoslam_free(tmp);
+  octree_slam::detail::check(rc, "subsample<Color256>");
+}
+template <class T> void subsampleDepth(T *data, const int width, const int height);
+template <> inline void subsampleDepth<uint16_t>(uint16_t *data, const int width, const int height) {
+  sub_detail::subsample_with<uint16_t>(svoslam_subsample_depth_u16, data, width, height, "subsampleDepth<uint16_t>");
+}
+template <> inline void subsampleDepth<float>(float *data, const int width, const int height) {
+  sub_detail::subsample_with<float>(svoslam_subsample_depth_f32, data, width, height, "subsampleDepth<float>");
 }
 inline void colorToIntensity(const Color256 *color_in, float *intensity_out, const int size) {
   detail::check(svoslam_color_to_intensity(&color_in->r, intensity_out, size, nullptr), "colorToIntensity");

@@ -176,6 +176,11 @@ void fuse_and_render(const vec3* d_points, const Color256* d_colors, int n, ucha
   startTiming(); (void)stopTiming();
   Mesh m; VoxelGrid vg; voxelization::meshToVoxelGrid(m, nullptr, vg); (void)voxelization::log_N();
   Mesh cube, cubes; voxelization::voxelGridToMesh(vg, cube, cubes);
+  BoundingBox outer, inner; outer.bbox1 = vec3{2, 2, 2}; inner.bbox0 = vec3{-1, 0.5f, 0.5f}; inner.bbox1 = vec3{1, 1, 3};
+  if (outer.contains(inner) || outer.distanceOutside(inner) != -1.0f + 0.0f && outer.distanceOutside(inner) != 0.0f) {}
+  RawFrame frame(8, 8);
+  sensor::subsampleDepth<uint16_t>(frame.depth, 8, 8); sensor::subsample<Color256>(frame.color, 8, 8);
+  float* fl = nullptr; sensor::subsample<float>(fl, 0, 0); sensor::subsampleDepth<float>(fl, 0, 0);
 }
 int main() {
   try { fuse_and_render(nullptr, nullptr, 0, nullptr); } catch (const std::exception& e) { return 0; }
