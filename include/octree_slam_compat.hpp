@@ -27,6 +27,7 @@ struct vec2 { float x, y; };
 struct vec3 { float x, y, z; };
 struct vec4 { float x, y, z, w; };
 struct mat4 { float m[16]; };  // column-major, m[4*col + row]
+struct mat3 { float m[9]; };   // column-major, m[3*col + row]
 struct int2_t { int x, y; };
 struct uchar4_t { unsigned char x, y, z, w; };
 
@@ -229,6 +230,33 @@ inline void computeICPCost2(const ICPFrame *last_frame, const ICPFrame &this_fra
   detail::check(svoslam_icp_cost2(&last_frame->vertex->x, &last_frame->normal->x, &this_frame.vertex->x, &this_frame.normal->x,
                                   this_frame.width, this_frame.height, A, b, nullptr), "computeICPCost2");
 }
+// rgbd_camera.h:17-84 / rgbd_camera.cpp:41-222: the same state machine, resident on the device (no host round trips)
+class RGBDCamera {
+public:
+  RGBDCamera(const int width, const int height, const vec2 &focal_length) {
+    detail::check(svoslam_camera_create(&cam_, width, height, focal_length.x, focal_length.y), "RGBDCamera");
+  }
+  ~RGBDCamera() { svoslam_camera_destroy(cam_); }
+  RGBDCamera(const RGBDCamera &) = delete;
+  RGBDCamera &operator=(const RGBDCamera &) = delete;
+  const vec3 position() const { pose(); return position_; }
+  const mat3 orientation() const { pose(); return orientation_; }
+  // frames whose timestamp is not newer than the latest processed one are skipped (rgbd_camera.cpp:55-58)
+  void update(const RawFrame *this_frame) {
+    int32_t used = 0;
+    detail::check(svoslam_camera_update(cam_, this_frame->depth, &this_frame->color->r, this_frame->timestamp, &used, nullptr),
+                  "RGBDCamera::update");
+  }
+  // main.cpp:40: mat4(orientation) * translate(mat4(1), position), as a device pointer (stays valid; updated by update())
+  const float *fusionTransformDevice() const { return svoslam_camera_fusion_transform_device(cam_); }
+  svoslam_camera *handle() const { return cam_; }
+
+private:
+  void pose() const { detail::check(svoslam_camera_pose(cam_, &position_.x, orientation_.m, nullptr), "RGBDCamera::pose"); }
+  svoslam_camera *cam_ = nullptr;
+  mutable vec3 position_{0, 0, 0};
+  mutable mat3 orientation_{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+};
 }  // namespace sensor
 
 
@@ -284,6 +312,44 @@ inline void voxelGridToMesh(const VoxelGrid &grid, const Mesh &m_cube, Mesh &m_o
   svoslam_free(dv); svoslam_free(di); svoslam_free(dn); svoslam_free(dc);
 }
 }  // namespace voxelization
+namespace world {
+// scene.h:22-79 / scene.cpp: OBJ / BMP loading, mesh voxelization into the octree, point-cloud insertion, SVO view
+class Scene {
+public:
+  Scene() { detail::check(svoslam_scene_create(&scene_), "Scene"); }
+  ~Scene() { svoslam_scene_destroy(scene_); }
+  Scene(const Scene &) = delete;
+  Scene &operator=(const Scene &) = delete;
+  void loadObjFile(const std::string &filename) { detail::check(svoslam_scene_load_obj(scene_, filename.c_str()), "Scene::loadObjFile"); }
+  void loadBMP(const std::string &filename) { detail::check(svoslam_scene_load_bmp(scene_, filename.c_str()), "Scene::loadBMP"); }
+  void voxelizeMeshes(const bool octree = false) {
+    detail::check(svoslam_scene_voxelize_meshes(scene_, octree ? 1 : 0, 0, nullptr), "Scene::voxelizeMeshes");
+  }
+  void extractVoxelGridFromOctree() { detail::check(svoslam_scene_extract_voxel_grid(scene_, nullptr), "Scene::extractVoxelGridFromOctree"); }
+  void addPointCloudToOctree(const vec3 &origin, const vec3 *points, const Color256 *colors, const int size, const BoundingBox &bbox) {
+    detail::check(svoslam_scene_add_point_cloud(scene_, &origin.x, &points->x, &colors->r, size, &bbox.bbox0.x, &bbox.bbox1.x, nullptr),
+                  "Scene::addPointCloudToOctree");
+  }
+  // non-owning view of the scene's voxel grid (the reference returns a reference to its own VoxelGrid)
+  struct VoxelGridView { const vec4 *centers; const vec4 *colors; int size; float scale; };
+  VoxelGridView voxel_grid() const {
+    const float *ce = nullptr, *co = nullptr; int32_t n = 0; float scale = 0.0f;
+    detail::check(svoslam_scene_voxel_grid(scene_, &ce, &co, &n, &scale), "Scene::voxel_grid");
+    return VoxelGridView{reinterpret_cast<const vec4 *>(ce), reinterpret_cast<const vec4 *>(co), n, scale};
+  }
+  // Octree::extractSVO (octree.cpp:339-360) ignores its bbox argument as well
+  SVO svo(const BoundingBox & = BoundingBox()) const {
+    const uint32_t *data = nullptr; float c[3] = {0, 0, 0}, size = 0.0f; int32_t nodes = 0, depth = 0;
+    detail::check(svoslam_scene_svo(scene_, &data, c, &size, &nodes, &depth), "Scene::svo");
+    return SVO{const_cast<unsigned int *>(data), vec3{c[0], c[1], c[2]}, size};
+  }
+  svoslam_scene *handle() const { return scene_; }
+
+private:
+  svoslam_scene *scene_ = nullptr;
+};
+}  // namespace world
+
 // timing_utils.h:5-10
 inline void startTiming() { detail::check(svoslam_timer_start(nullptr), "startTiming"); }
 inline float stopTiming() { float ms = 0; detail::check(svoslam_timer_stop(nullptr, &ms), "stopTiming"); return ms; }

@@ -65,6 +65,29 @@ int main(int argc, char** argv) {
   }
   float A[36], b[6]; sensor::computeICPCost2(&f0, f1, A, b); wr(out, A, 36); wr(out, b, 6);
   BoundingBox bb; sensor::computePointCloudBoundingBox(f1.vertex, w * h, bb); wr(out, &bb.bbox0.x, 3); wr(out, &bb.bbox1.x, 3);
+  // --- mainLoop (main.cpp:31-84) with the class mirrors: track, back-project, bbox, insert, view
+  { sensor::RGBDCamera cam(w, h, vec2{fx, fx}); world::Scene scene;
+    for (int k = 0; k < 2; k++) {
+      RawFrame raw(w, h); raw.timestamp = k;
+      svoslam_memcpy_h2d(raw.depth, dsrc[k], (size_t)w * h * 2);
+      std::vector<unsigned char> rgb((size_t)w * h * 3, (unsigned char)(90 + 60 * k)); svoslam_memcpy_h2d(raw.color, rgb.data(), rgb.size());
+      cam.update(&raw);
+      vec3* cloud = nullptr; svoslam_malloc((void**)&cloud, (size_t)w * h * sizeof(vec3));
+      sensor::generateVertexMap(raw.depth, cloud, w, h, vec2{fx, fx}, int2_t{w, h});
+      const vec3 p = cam.position(); const mat3 o = cam.orientation();
+      mat4 T; for (int i = 0; i < 16; i++) T.m[i] = 0.0f;                       // mat4(orientation) * translate(I, position)
+      svoslam_memcpy_d2h(T.m, cam.fusionTransformDevice(), 64);
+      sensor::transformVertexMap(cloud, T, w * h);
+      BoundingBox bb2; sensor::computePointCloudBoundingBox(cloud, w * h, bb2);
+      scene.addPointCloudToOctree(p, cloud, raw.color, w * h, bb2);
+      wr(out, &p.x, 3); wr(out, o.m, 9); wr(out, T.m, 16); wr(out, &bb2.bbox0.x, 3); wr(out, &bb2.bbox1.x, 3);
+      svoslam_free(cloud);
+    }
+    SVO s = scene.svo();
+    wr(out, &s.center.x, 3); wr(out, &s.size, 1);
+    rendering::coneTraceSVO(d_img, vec2{(float)w, (float)h}, 45.0f, vm, s);
+    svoslam_memcpy_d2h(img.data(), d_img, img.size() * 4); wr(out, img.data(), img.size());
+  }
   fclose(out); svoslam_free(d_pts); svoslam_free(d_col); svoslam_free(d_img); svoslam_free(pool);
   return 0;
 }
@@ -124,4 +147,33 @@ def test_reference_style_cpp_caller(tmp_path, oracle):
     assert np.array_equal(take(np.float32, 36), rA.reshape(-1)) and np.array_equal(take(np.float32, 6), rb)
     b0, b1 = oracle.point_cloud_bbox(vm[1].reshape(-1, 3))
     assert np.array_equal(take(np.float32, 3), b0) and np.array_equal(take(np.float32, 3), b1)
+    # main loop with RGBDCamera + Scene
+    ocam = oracle.Camera(w, h, float(f), float(f))
+    opool2, depth2, c2, size2 = None, None, None, None
+    for k, d in enumerate((d0, d1)):
+        rgb = np.full((h, w, 3), 90 + 60 * k, np.uint8)
+        assert ocam.update(d, rgb, k) == 1
+        rp, ro = ocam.pose()
+        assert np.array_equal(take(np.float32, 3), rp) and np.array_equal(take(np.float32, 9), ro)
+        T = ocam.fusion_transform()
+        assert np.array_equal(take(np.float32, 16), T)
+        cloud = oracle.transform_vertex_map(oracle.vertex_map(d, f, f, w, h), T).reshape(-1, 3)
+        b0, b1 = oracle.point_cloud_bbox(cloud)
+        assert np.array_equal(take(np.float32, 3), b0) and np.array_equal(take(np.float32, 3), b1)
+        if k == 0:   # Scene::addPointCloudToOctree: tree from the first cloud's box, resolution 0.01 (scene.cpp:100-103)
+            c2, size2 = (b1 + b0) / np.float32(2.0), float(b1[0])
+            depth2 = int(np.ceil(np.log2(np.float64(np.float32(size2) / np.float32(0.01)))))
+            opool2 = oracle.Pool()
+        else:        # scene.cpp:104-108 + Octree::expandBySize (octree.cpp:362-378): the root is only rescaled (Q16)
+            t0, t1 = c2 - np.float32(size2), c2 + np.float32(size2)
+            if not ((t0 <= b0).all() and (t1 >= b1).all()):
+                r = np.float32(max(0.0, *(t0 - b0), *(b1 - t1)))
+                layers = int(np.log(np.ceil((np.float32(size2) + r) / np.float32(size2))) / np.log(np.float32(2.0)))
+                assert layers >= 1      # this stream does leave the first frame's box
+                size2 = float(np.float32(2.0) ** np.float32(layers) * np.float32(size2))
+                depth2 = int(np.ceil(np.log2(np.float64(np.float32(size2) / np.float32(0.01)))))
+        opool2.insert_cloud(cloud, rgb.reshape(-1, 3), depth2, c2, size2)
+    assert np.array_equal(take(np.float32, 3), c2) and take(np.float32, 1)[0] == np.float32(size2)
+    ref2, _, _ = oracle.cone_trace(opool2, w, h, 45.0, view, c2, size2, oracle.RENDER_REFERENCE)
+    assert np.array_equal(take(np.uint8, w * h * 4).reshape(h, w, 4), ref2)
     assert pos == len(raw)
