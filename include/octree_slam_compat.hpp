@@ -167,6 +167,17 @@ struct ICPFrame {  // localization_kernels.h:17-24
   ~ICPFrame() { svoslam_free(vertex); svoslam_free(normal); }
   vec3 *vertex; vec3 *normal; int width; int height;
 };
+struct RGBDFrame {  // localization_kernels.h:26-33
+  RGBDFrame(const int w, const int h) : width(w), height(h) {
+    detail::check(svoslam_malloc((void **)&intensity, sizeof(float) * (size_t)w * h), "RGBDFrame");
+    detail::check(svoslam_malloc((void **)&vertex, sizeof(vec3) * (size_t)w * h), "RGBDFrame");
+  }
+  ~RGBDFrame() { svoslam_free(intensity); svoslam_free(vertex); }
+  float *intensity; vec3 *vertex; int width; int height;
+};
+// localization_kernels.h:42 / localization_kernels.cu:328-331: an empty stub in the reference (A and b are left untouched);
+// kept so that callers link
+inline void computeRGBDCost(const RGBDFrame *, const RGBDFrame &, float *, float *) {}
 // image_kernels.h:24-55
 inline void generateVertexMap(const uint16_t *depth_pixels, vec3 *vertex_map, const int width, const int height,
                               const vec2 focal_length, const int2_t img_size) {

@@ -181,6 +181,7 @@ void fuse_and_render(const vec3* d_points, const Color256* d_colors, int n, ucha
   RawFrame frame(8, 8);
   sensor::subsampleDepth<uint16_t>(frame.depth, 8, 8); sensor::subsample<Color256>(frame.color, 8, 8);
   float* fl = nullptr; sensor::subsample<float>(fl, 0, 0); sensor::subsampleDepth<float>(fl, 0, 0);
+  sensor::RGBDFrame ra(8, 8), rb(8, 8); sensor::computeRGBDCost(&ra, rb, A, bb);
   sensor::RGBDCamera cam(8, 8, vec2{570.3f, 570.3f}); cam.update(&frame); (void)cam.position(); (void)cam.orientation();
   world::Scene scene; scene.loadObjFile("x.obj"); scene.voxelizeMeshes(true); (void)scene.svo(); (void)scene.voxel_grid();
   scene.addPointCloudToOctree(vec3{0, 0, 0}, d_points, d_colors, n, outer); scene.extractVoxelGridFromOctree();
