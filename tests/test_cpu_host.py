@@ -196,3 +196,23 @@ int main() {
     subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-L", libdir, "-lsvoslam_hip",
                            "-Wl,-rpath," + libdir, "-o", str(exe)])
     assert subprocess.call([str(exe)]) == 0
+
+
+def test_bench_line_contract():
+    """the committed bench line (profiles/r01_bench_cfg3.json, written by bench.py on the GPU box) carries every
+    field of the driver's contract plus the roofline and cpu_baseline objects, with consistent values"""
+    import json
+    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_cfg3.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["vs_baseline"] is None and line["data"] == "synthetic"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert abs(line["value"] * line["ms_per_step"] / 1e3 - 1.0) < 1e-6        # frames/s x s/frame
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
+    assert abs(r["alg_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9 - r["achieved"]) < 1e-6 * r["achieved"]
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
