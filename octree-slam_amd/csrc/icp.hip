@@ -620,16 +620,29 @@ __device__ inline void frame_end_step(CamState *st, int apply_update, const vola
 // products of :154-160 cost one LDS round trip each instead of 64 dependent multiply-adds on a single lane
 // (the tail used to take ~3 of the launch's 8.6 us).  Every element is the reference's expression, unchanged.
 constexpr int kTailScratch = 128;
-__device__ inline void iteration_tail_wave(CamState *st, const double *sums, int slot, int flags, volatile float *sm) {
+// state words the tail needs, fetched by the caller BEFORE it waits for the sums (one round trip instead of two;
+// a global access costs ~2 us while a raycast is running)
+struct TailPrefetch { float ut; int lost; };
+__device__ inline TailPrefetch tail_prefetch(const CamState *st, int flags) {
+  TailPrefetch p;
+  const int e = (int)(threadIdx.x & 15u);
+  p.ut = st->update_trans[e];
+  p.lost = st->lost;
+  (void)flags;
+  return p;
+}
+
+__device__ inline void iteration_tail_wave(CamState *st, const double *sums, int slot, int flags, volatile float *sm,
+                                           const TailPrefetch &pre) {
   const int lane = (int)(threadIdx.x & 63u), e = lane & 15;
   // level start (:100, :116-120): update_trans element e on lane e
-  float ut = (flags & kFlagFirstOfFrame) ? ((e % 5 == 0) ? 1.0f : 0.0f) : st->update_trans[e];
+  float ut = (flags & kFlagFirstOfFrame) ? ((e % 5 == 0) ? 1.0f : 0.0f) : pre.ut;
   int lost = 0;
   if (flags & kFlagFirstIter) {
     if (lane < 16) st->level_start[e] = ut;
     if (lane == 0) st->lost = 0;
   } else {
-    lost = st->lost;
+    lost = pre.lost;
   }
   if ((flags & kFlagFirstOfFrame) && lane < 16) st->update_trans[e] = ut;
   if (!lost) {
@@ -688,9 +701,10 @@ __global__ __launch_bounds__(kReduceThreads) void cam_reduce_solve_kernel(CamSta
   __shared__ double red[kReduceThreads / 32][27];
   __shared__ double totals[27];
   __shared__ float tail_sm[kTailScratch];
+  const TailPrefetch pre = tail_prefetch(st, flags);  // written by the previous launch
   reduce_rows(partial, rows, red, totals);
   if (threadIdx.x >= 64) return;  // the tail runs on the first wavefront
-  iteration_tail_wave(st, totals, slot, flags, tail_sm);
+  iteration_tail_wave(st, totals, slot, flags, tail_sm, pre);
 }
 
 // multi-GPU iteration tail: acc[] holds the all-reduced sums
@@ -703,13 +717,14 @@ __global__ void cam_solve_kernel(CamState *st, double *acc, int slot, int flags)
   __shared__ double sums[27];
   __shared__ float tail_sm[kTailScratch];
   if (blockIdx.x) return;
+  const TailPrefetch pre = tail_prefetch(st, flags);
   if (threadIdx.x < 27) {
     sums[threadIdx.x] = acc[threadIdx.x];
     acc[threadIdx.x] = 0.0;
   }
   __syncthreads();
   if (threadIdx.x >= 64) return;
-  iteration_tail_wave(st, sums, slot, flags, tail_sm);
+  iteration_tail_wave(st, sums, slot, flags, tail_sm, pre);
 }
 
 __global__ void cam_frame_end_kernel(CamState *st, int apply_update) {
