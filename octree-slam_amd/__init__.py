@@ -108,6 +108,9 @@ SIGNATURES = {
     "svoslam_voxel_grid_to_mesh": (C.c_int, [_vp, _vp, _vp, _i32, _f32, _fp, _i32, C.POINTER(C.c_int32), _i32, _fp, _vp, _vp, _vp, _vp, _vp]),
     "svoslam_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
     "svoslam_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "svoslam_runner_create": (C.c_int, [C.POINTER(_vp), _vp, C.POINTER(_PoolStruct), _i32, _i32, _i32, _fp, _f32, _f32, _f32, _i32]),
+    "svoslam_runner_destroy": (C.c_int, [_vp]),
+    "svoslam_runner_run": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_longlong), _fp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "svoslam_scene_create": (C.c_int, [C.POINTER(_vp)]),
     "svoslam_scene_destroy": (C.c_int, [_vp]),
     "svoslam_scene_load_obj": (C.c_int, [_vp, C.c_char_p]),
@@ -470,6 +473,37 @@ def voxel_grid_to_mesh(ws, centers, colors, scale_factor, cube_vbo, cube_ibo, cu
                                            cv.ctypes.data_as(_fp), cv.size, ci.ctypes.data_as(C.POINTER(C.c_int32)), ci.size,
                                            cn.ctypes.data_as(_fp), _ptr(vbo), _ptr(ibo), _ptr(nbo), _ptr(cbo), _stream()))
     return vbo, ibo, nbo, cbo
+
+
+class Runner:
+    """Native frame scheduler (csrc/runner.hip): track -> back-project -> fuse -> raycast of a list of frames on four
+    HIP streams, enqueued by ONE call."""
+
+    def __init__(self, cam, pool, width, height, max_depth, center, edge, fx, fy, render_mode):
+        self._h = C.c_void_p()
+        self._cam, self._pool = cam, pool          # keep the handles alive
+        check(lib().svoslam_runner_create(C.byref(self._h), cam._h, C.byref(pool._p), width, height, max_depth, _fa(center, 3),
+                                          float(edge), float(fx), float(fy), int(render_mode)))
+
+    def run(self, depths, rgbs, timestamps, views, image, row_first, rows, counters=None):
+        n = len(timestamps)
+        dp = (C.c_void_p * n)(*[d.data_ptr() for d in depths])
+        rp = (C.c_void_p * n)(*[r.data_ptr() for r in rgbs])
+        ts = (C.c_longlong * n)(*[int(t) for t in timestamps])
+        vw = np.ascontiguousarray(np.stack([np.asarray(v, np.float32).reshape(16) for v in views]), np.float32)
+        check(lib().svoslam_runner_run(self._h, dp, rp, ts, vw.ctypes.data_as(_fp), n, _ptr(image), int(row_first), int(rows),
+                                       _ptr(counters), _stream()))
+
+    def close(self):
+        if self._h:
+            lib().svoslam_runner_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Scene:

@@ -186,3 +186,49 @@ def test_pipeline_reset_replays_identically(env):
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(ref, again))
     assert np.array_equal(A.pool.words(), words) and np.array_equal(A.cam.pose()[1], pose[1])
+
+
+@pytest.mark.parametrize("capacity,band", [(1 << 22, None), (4096, None), (1 << 22, (2, 5))])
+def test_native_runner_equals_sequential(env, capacity, band):
+    """the frame scheduler inside the library (csrc/runner.hip, what run_stream uses without hooks) against the
+    sequential frame() loop: last image, pool, pose and step counters bit for bit -- in several chunks, across a
+    pool growth (capacity 4096), for one row band of five (what a rank of a multi-GPU job renders), and against the
+    scripted scheduler"""
+    pkg, torch, synth, pl = env
+    w, h, depth, center, edge = 320, 240, 10, (0.0, 1.5, 0.0), 4.096
+    n = 23
+    frames = [synth.render_frame(k, w, h, device="cuda") for k in range(n)]
+    views = [pl.ground_truth_view(k, synth) for k in range(n)]
+    ds, cs = [f[0] for f in frames], [f[1] for f in frames]
+    A = pl.SlamPipeline(w, h, depth, center, edge, count_steps=True)
+    for k in range(n):
+        ref = A.frame(ds[k], cs[k], k, views[k])
+    ref = ref.cpu().numpy().copy()
+    for rep in range(2):
+        B = pl.SlamPipeline(w, h, depth, center, edge, pool_capacity_nodes=capacity, count_steps=band is None)
+        if band is not None:
+            B.first, B.rows = pl.band_rows(h, band[0], band[1])
+            B.dist.force = True
+        for a in range(0, n, 9):                      # three calls back to back, no synchronisation in between
+            b = min(n, a + 9)
+            B.run_stream(ds[a:b], cs[a:b], list(range(a, b)), views[a:b])
+        assert hasattr(B, "_runner")                  # the native path was taken
+        torch.cuda.synchronize()
+        got = B.image.cpu().numpy()
+        rows = slice(B.first, B.first + B.rows)
+        assert np.array_equal(got[rows], ref[rows]), rep
+        assert A.pool.size == B.pool.size and np.array_equal(A.pool.words(), B.pool.words())
+        assert np.array_equal(A.cam.pose()[0], B.cam.pose()[0]) and np.array_equal(A.cam.pose()[1], B.cam.pose()[1])
+        if band is None:
+            assert A.counters.tolist() == B.counters.tolist()
+    os.environ["SVOSLAM_PY_SCHEDULER"] = "1"
+    try:
+        C_ = pl.SlamPipeline(w, h, depth, center, edge)
+        C_.run_stream(ds, cs, list(range(n)), views)
+        torch.cuda.synchronize()
+        assert not hasattr(C_, "_runner")
+        assert np.array_equal(C_.image.cpu().numpy(), ref) and np.array_equal(C_.pool.words(), A.pool.words())
+    finally:
+        del os.environ["SVOSLAM_PY_SCHEDULER"]
+    with pytest.raises(pkg.SvoslamError):             # timestamps must increase
+        B.run_stream(ds[:2], cs[:2], [0, 0], views[:2])
