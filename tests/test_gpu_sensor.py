@@ -297,3 +297,26 @@ def test_camera_tracking_lost_matches_oracle(env, oracle):
             assert np.array_equal(fus.view(np.uint32), ocam.fusion_transform().view(np.uint32))
         lost_seen = ocam.tracking_lost_count()
     assert lost_seen >= 6                                # frames 2 and 3 (no valid partner) lose all three levels each
+
+
+def test_timer_start_stop(env):
+    """startTiming / stopTiming (timing_utils.cu:11-32): a HIP-event pair around stream work; the elapsed time
+    covers the kernels enqueued between the two calls"""
+    pkg, torch, _ = env
+    import ctypes as C
+    L = pkg.lib()
+    x = torch.zeros((1080, 1920), dtype=torch.int16, device="cuda")
+    out = torch.zeros_like(x)
+    torch.cuda.synchronize()
+    ms = C.c_float(-1.0)
+    pkg.check(L.svoslam_timer_start(pkg._stream()))
+    pkg.check(L.svoslam_timer_stop(pkg._stream(), C.byref(ms)))
+    empty = ms.value
+    assert 0.0 <= empty < 5.0
+    pkg.check(L.svoslam_timer_start(pkg._stream()))
+    for _ in range(20):
+        pkg.bilateral_filter(x, out)
+    pkg.check(L.svoslam_timer_stop(pkg._stream(), C.byref(ms)))
+    assert ms.value > empty and ms.value > 0.05          # 20 bilateral passes over 2 M pixels
+    assert ms.value < 1000.0
+    assert L.svoslam_timer_stop(pkg._stream(), None) != 0     # null output pointer is refused
