@@ -391,6 +391,10 @@ int svoslam_camera_set_acc(svoslam_camera *cam, double *d_acc);
 /* number of pyramid levels abandoned because the solve returned NaN
  * ("Camera tracking is lost.", rgbd_camera.cpp:148-151).  Blocking. */
 int svoslam_camera_tracking_lost_count(svoslam_camera *cam, int32_t *count, void *stream);
+/* diagnostic (libraries built with -DSVO_TRK_PROF; zeros otherwise): device clock stamps of the last tracked frame's
+ * one-launch tracker, h_stamps[32][8] = per ICP iteration {solver: start, fan-in done, rows summed, published;
+ * worker 0: start, terms done, row stored, broadcast received}.  Blocking. */
+int svoslam_camera_track_profile(svoslam_camera *cam, unsigned long long *h_stamps, void *stream);
 int svoslam_camera_icp_solve(svoslam_camera *cam, int32_t level, int32_t iter, void *stream);
 int svoslam_camera_end(svoslam_camera *cam, void *stream);
 /* position() / orientation() accessors, rgbd_camera.h:33-36.  Blocking (D2H). */

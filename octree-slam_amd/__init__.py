@@ -163,6 +163,7 @@ SIGNATURES = {
     "svoslam_camera_last_vertex": (_vp, [_vp, _i32]),
     "svoslam_camera_last_normal": (_vp, [_vp, _i32]),
     "svoslam_camera_tracking_lost_count": (C.c_int, [_vp, C.POINTER(_i32), _vp]),
+    "svoslam_camera_track_profile": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), _vp]),
     "svoslam_timer_start": (C.c_int, [_vp]),
     "svoslam_timer_stop": (C.c_int, [_vp, _fp]),
 }
@@ -815,6 +816,12 @@ class Camera:
 
     def last_normal_ptr(self, level):
         return int(lib().svoslam_camera_last_normal(self._h, level))
+
+    def track_profile(self):
+        """device clock stamps [32, 8] of the last one-launch tracker (SVO_TRK_PROF builds; zeros otherwise)"""
+        out = np.zeros((32, 8), np.uint64)
+        check(lib().svoslam_camera_track_profile(self._h, out.ctypes.data_as(C.POINTER(C.c_ulonglong)), _stream()))
+        return out
 
     def tracking_lost_count(self):
         n = C.c_int32(0)

@@ -25,6 +25,10 @@ FLAGS = [
 ]
 
 
+# experiments: extra -D flags for every translation unit (rebuild with force=True)
+FLAGS += os.environ.get("SVOSLAM_EXTRA_HIPCC_FLAGS", "").split()
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 

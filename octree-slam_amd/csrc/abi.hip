@@ -433,6 +433,10 @@ int svoslam_camera_tracking_lost_count(svoslam_camera *cam, int32_t *count, void
   return camera_tracking_lost_count(cam, count, S(stream));
 }
 
+int svoslam_camera_track_profile(svoslam_camera *cam, unsigned long long *h_stamps, void *stream) {
+  return camera_track_profile(cam, h_stamps, S(stream));
+}
+
 // startTiming / stopTiming (src/timing_utils.cu:11-32) on hipEvents
 int svoslam_timer_start(void *stream) {
   NEED_DEVICE();

@@ -28,32 +28,15 @@
 
 #include "graph_cache.hpp"
 #include "icp.hpp"
+#include "icp_device.hpp"
 #include "image_kernels.hpp"
+#include "track_persistent.hpp"
 #include "wave_rank.hpp"
 
 namespace svoslam {
 
-__device__ constexpr float kDistThresh = 0.1f;   // localization_kernels.cu:17
-__device__ constexpr float kNormThresh = 0.87f;  // :18
-constexpr double kScaleA = 1048576.0;            // 2^20
-constexpr double kScaleB = 1073741824.0;         // 2^30
-constexpr int kMaxChain = 10;                    // max(PYRAMID_ITERS)
+// (tracker state, wave reductions, Cholesky and pose composition: icp_device.hpp)
 
-struct CamState {
-  double acc[27];
-  float update_trans[16];
-  float level_start[16];
-  float chain[kMaxChain][16];
-  float position[3];
-  float orientation[9];
-  float fusion[16];
-  float fusion_ring[4][16];  // fusion transform of the last 4 frames (slot = frame sequence & 3): lets the
-                             // mapping stream read frame k's pose while the tracking stream is on frame k+1
-  float lastA[36], lastb[6], lastx[6];
-  int frames_done;          // frames whose pose is final; the next frame's pose goes to fusion_ring[frames_done & 3]
-  int lost;                 // NaN seen at this pyramid level (rgbd_camera.cpp:148-151)
-  int tracking_lost_count;  // levels abandoned so far
-};
 
 // ----------------------------------------------------------------------------
 // accumulate
@@ -65,32 +48,6 @@ constexpr int kIcpWaves = kIcpThreads / kWave;
 #endif
 constexpr int kMaxIcpBlocks = SVO_ICP_BLOCKS;
 
-// iteration flags (host-known)
-constexpr int kFlagLevelStart = 1;  // level < 2: the level's copy is first transformed by update_trans (:116-120)
-constexpr int kFlagFirstIter = 2;   // iteration 0 of its level
-constexpr int kFlagFirstOfFrame = 4;
-constexpr int kFlagLastOfFrame = 8;
-
-// Sum of a double over the 64 lanes of a wavefront with DPP moves only (VALU; no LDS traffic):
-// row_shr 1,2,4,8 leave each 16-lane row's sum in its last lane, row_bcast15 / row_bcast31 carry
-// them on; the total ends up in lane 63.  Every addend is an integer-valued double, so the order
-// of the additions does not matter (exact).
-template <int CTRL, int ROW_MASK>
-__device__ inline double dpp_add(double v) {
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int slo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, true);
-  const int shi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, true);
-  return v + __hiloint2double(shi, slo);
-}
-__device__ inline double wave_sum_to_lane63(double v) {
-  v = dpp_add<0x111, 0xF>(v);  // row_shr:1
-  v = dpp_add<0x112, 0xF>(v);  // row_shr:2
-  v = dpp_add<0x114, 0xF>(v);  // row_shr:4
-  v = dpp_add<0x118, 0xF>(v);  // row_shr:8
-  v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
-  v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
-  return v;
-}
 
 // Body of the accumulate kernel.  The 27 sums of a lane are reduced across the wavefront in registers
 // (DPP) and across the 8 wavefronts through a 1.7 KB LDS array.  (Earlier forms: 27 x 6 ds_bpermute
@@ -131,38 +88,7 @@ __device__ inline void accumulate_block(const float *__restrict__ last_v, const 
         mat4_mul_point(chain_s + 16 * k, n2x, n2y, n2z, 0.0f, ox, oy, oz);
         n2x = ox; n2y = oy; n2z = oz;
       }
-      // gates, localization_kernels.cu:186-205
-      if (!finitef_(v2x) || !finitef_(v2y) || !finitef_(v2z) || !finitef_(v1x) || !finitef_(v1y) || !finitef_(v1z) ||
-          (v1z < 0.1f) || (v2z < 0.1f) || (v1z > 10.0f) || (v2z > 10.0f))
-        continue;
-      if (!finitef_(n2x) || !finitef_(n2y) || !finitef_(n2z) || !finitef_(n1x) || !finitef_(n1y) || !finitef_(n1z)) continue;
-      const float dx = v2x - v1x, dy = v2y - v1y, dz = v2z - v1z;
-      if (sqrtf(dot3(dx, dy, dz, dx, dy, dz)) > kDistThresh) continue;
-      if (dot3(n2x, n2y, n2z, n1x, n1y, n1z) < kNormThresh) continue;
-      // A_T = G_T * n1 with the G_T rows of :208-213 (Q14), products in source order
-      float J[6];
-      J[0] = (0.0f * n1x + (-v2x) * n1y) + (-v2y) * n1z;
-      J[1] = ((-v2z) * n1x + 0.0f * n1y) + v2x * n1z;
-      J[2] = (v2y * n1x + v2z * n1y) + 0.0f * n1z;
-      J[3] = (1.0f * n1x + 0.0f * n1y) + 0.0f * n1z;
-      J[4] = (0.0f * n1x + 1.0f * n1y) + 0.0f * n1z;
-      J[5] = (0.0f * n1x + 0.0f * n1y) + 1.0f * n1z;
-      const float bb = dot3(n1x, n1y, n1z, v1x - v2x, v1y - v2y, v1z - v2z);
-      // fixed point: prod * 2^k is exact in binary32 (power-of-two scale), rintf gives the same
-      // integer as rint((double)prod * 2^k) of the specification
-      int k = 0;
-#pragma unroll
-      for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int j = i; j < 6; j++) {
-          const float prod = J[i] * J[j];
-          acc[k++] += (double)rintf(prod * 1048576.0f);
-        }
-#pragma unroll
-      for (int i = 0; i < 6; i++) {
-        const float prod = bb * J[i];
-        acc[21 + i] += (double)rintf(prod * 1073741824.0f);
-      }
+      icp_pixel_terms(v1x, v1y, v1z, n1x, n1y, n1z, v2x, v2y, v2z, n2x, n2y, n2z, acc);
     }
   }
   // workgroup -> one 27-double row; every partial is an integer-valued double (exact, order-free).
@@ -398,301 +324,6 @@ int icp_cost(svoslam::DeviceBuffer &scratch, const float *lv, const float *ln, c
   return SVOSLAM_OK;
 }
 
-// ----------------------------------------------------------------------------
-// device-resident solve + pose composition (one lane)
-// ----------------------------------------------------------------------------
-__device__ inline void d_identity(float *m) {
-  for (int i = 0; i < 16; i++) m[i] = 0.0f;
-  m[0] = m[5] = m[10] = m[15] = 1.0f;
-}
-// glm operator*(mat4, mat4), type_mat4x4.inl:753-775
-__device__ inline void d_mat4_mul(const float *a, const float *b, float *out) {
-  float r[16];
-  for (int c = 0; c < 4; c++)
-    for (int row = 0; row < 4; row++)
-      r[4 * c + row] = ((a[row] * b[4 * c] + a[4 + row] * b[4 * c + 1]) + a[8 + row] * b[4 * c + 2]) + a[12 + row] * b[4 * c + 3];
-  for (int i = 0; i < 16; i++) out[i] = r[i];
-}
-// glm::translate, gtc/matrix_transform.inl:35-45
-__device__ inline void d_translate(const float *m, const float *v, float *out) {
-  float r[16];
-  for (int i = 0; i < 16; i++) r[i] = m[i];
-  for (int row = 0; row < 4; row++) r[12 + row] = ((m[row] * v[0] + m[4 + row] * v[1]) + m[8 + row] * v[2]) + m[12 + row];
-  for (int i = 0; i < 16; i++) out[i] = r[i];
-}
-// Deterministic sin/cos in binary64 with explicit fma (Cody-Waite by pi/2 + fdlibm
-// kernels), rounded once to binary32; the CPU oracle evaluates the same sequence.
-// The reference calls the host libm through glm::rotate (matrix_transform.inl:60-61).
-__device__ inline void d_sincos(float af, float &s_out, float &c_out) {
-  const double x = (double)af;
-  const double kd = rint(x * 0.63661977236758134308);
-  double r = fma(kd, -1.57079632673412561417e+00, x);
-  r = fma(kd, -6.07710050650619224932e-11, r);
-  const double z = r * r;
-  double sp = 1.58969099521155010221e-10;
-  sp = fma(sp, z, -2.50507602534068634195e-08);
-  sp = fma(sp, z, 2.75573137070700676789e-06);
-  sp = fma(sp, z, -1.98412698298579493134e-04);
-  sp = fma(sp, z, 8.33333333332248946124e-03);
-  sp = fma(sp, z, -1.66666666666666324348e-01);
-  const double sn = fma(r * z, sp, r);
-  double cp = -1.13596475577881948265e-11;
-  cp = fma(cp, z, 2.08757232129817482790e-09);
-  cp = fma(cp, z, -2.75573143513906633035e-07);
-  cp = fma(cp, z, 2.48015872894767294178e-05);
-  cp = fma(cp, z, -1.38888888888741095749e-03);
-  cp = fma(cp, z, 4.16666666666666019037e-02);
-  const double cs = fma(z * z, cp, fma(z, -0.5, 1.0));
-  const long long k = (long long)kd;
-  double s, c;
-  switch ((int)(k & 3)) {
-    case 0: s = sn; c = cs; break;
-    case 1: s = cs; c = -sn; break;
-    case 2: s = -sn; c = -cs; break;
-    default: s = -cs; c = sn; break;
-  }
-  s_out = (float)s;
-  c_out = (float)c;
-}
-// glm::rotate (degrees API), gtc/matrix_transform.inl:47-86
-__device__ inline void d_rotate_deg(const float *m, float angle, float vx, float vy, float vz, float *out) {
-  const float a = angle * 0.01745329251994329576923690768489f;
-  float c, s;
-  d_sincos(a, s, c);
-  const float inv = 1.0f / sqrtf((vx * vx + vy * vy) + vz * vz);
-  const float axis[3] = {vx * inv, vy * inv, vz * inv};
-  const float temp[3] = {(1.0f - c) * axis[0], (1.0f - c) * axis[1], (1.0f - c) * axis[2]};
-  float R[3][3];
-  R[0][0] = c + temp[0] * axis[0];
-  R[0][1] = 0 + temp[0] * axis[1] + s * axis[2];
-  R[0][2] = 0 + temp[0] * axis[2] - s * axis[1];
-  R[1][0] = 0 + temp[1] * axis[0] - s * axis[2];
-  R[1][1] = c + temp[1] * axis[1];
-  R[1][2] = 0 + temp[1] * axis[2] + s * axis[0];
-  R[2][0] = 0 + temp[2] * axis[0] + s * axis[1];
-  R[2][1] = 0 + temp[2] * axis[1] - s * axis[0];
-  R[2][2] = c + temp[2] * axis[2];
-  float r[16];
-  for (int col = 0; col < 3; col++)
-    for (int row = 0; row < 4; row++) r[4 * col + row] = (m[row] * R[col][0] + m[4 + row] * R[col][1]) + m[8 + row] * R[col][2];
-  for (int row = 0; row < 4; row++) r[12 + row] = m[12 + row];
-  for (int i = 0; i < 16; i++) out[i] = r[i];
-}
-
-// RGBDCamera::solveCholesky, rgbd_camera.cpp:194-222 (float storage, double inner sums)
-__device__ inline void d_solve_cholesky(const float *A, const float *b, float *x) {
-  float LU[36], y[6];
-  for (int i = 0; i < 36; i++) LU[i] = 0.0f;
-  for (int i = 0; i < 6; i++) y[i] = 0.0f;
-  for (int k = 0; k < 6; ++k) {
-    double sum = 0.;
-    for (int p = 0; p < k; ++p) sum += LU[k * 6 + p] * LU[k * 6 + p];
-    LU[k * 6 + k] = (float)sqrt(A[k * 6 + k] - sum);
-    for (int i = k + 1; i < 6; ++i) {
-      double sum2 = 0.;
-      for (int p = 0; p < k; ++p) sum2 += LU[i * 6 + p] * LU[k * 6 + p];
-      LU[i * 6 + k] = (float)((A[i * 6 + k] - sum2) / LU[k * 6 + k]);
-    }
-  }
-  for (int i = 0; i < 6; ++i) {
-    double sum = 0.;
-    for (int k = 0; k < i; ++k) sum += LU[i * 6 + k] * y[k];
-    y[i] = (float)((b[i] - sum) / LU[i * 6 + i]);
-  }
-  for (int i = 5; i >= 0; --i) {
-    double sum = 0.;
-    for (int k = i + 1; k < 6; ++k) sum += LU[k * 6 + i] * x[k];
-    x[i] = (float)((y[i] - sum) / LU[i * 6 + i]);
-  }
-}
-
-// ---- the same iteration tail spread over ONE wavefront ---------------------------------------------
-// solveCholesky is a chain of 6 square roots and 27 divisions in binary64 (software sequences of ~30
-// dependent instructions each): executed by one lane it costs ~5 us per ICP iteration, 19 times a frame.
-// Here lane i (< 6) owns row i of A / LU: the 5 quotients of a column, and everything else that is
-// independent in the reference's loops, run side by side; single values travel with v_readlane (the
-// source lanes are compile-time constants).  Every value is produced by the reference's expression
-// with its operand order (float products, double running sums, one rounding to float), so the bits
-// are those of d_solve_cholesky.
-__device__ inline float lane_bcast(float v, int src_lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
-}
-
-// must be called by all 64 lanes of a wavefront; sums = 27 doubles at a uniform address; x[6] on every lane
-__device__ inline void wave_solve_cholesky(const double *sums, float *x, float &a_elem, float &b_elem) {
-  const int lane = (int)(threadIdx.x & 63u);
-  const int row = lane < 6 ? lane : 5;  // spare lanes shadow row 5
-  // A is symmetric, sums hold its upper triangle row by row: index of (i <= j) = i*6 - i*(i-1)/2 + (j - i)
-  float a[6], lu[6], diag[6];
-#pragma unroll
-  for (int c = 0; c < 6; c++) {
-    const int i = row < c ? row : c, j = row < c ? c : row;
-    a[c] = (float)(sums[i * 6 - (i * (i - 1)) / 2 + (j - i)] * (1.0 / kScaleA));
-    lu[c] = 0.0f;
-  }
-  const float b_own = (float)(sums[21 + row] * (1.0 / kScaleB));
-  {  // element `lane` of the row-major A (for the diagnostics copy), b likewise
-    const int e = lane < 36 ? lane : 35, r = e / 6, c = e % 6;
-    const int i = r < c ? r : c, j = r < c ? c : r;
-    a_elem = (float)(sums[i * 6 - (i * (i - 1)) / 2 + (j - i)] * (1.0 / kScaleA));
-    b_elem = b_own;
-  }
-#pragma unroll
-  for (int k = 0; k < 6; k++) {  // rgbd_camera.cpp:198-209
-    float rk[6];
-#pragma unroll
-    for (int p = 0; p < 6; p++) rk[p] = p < k ? lane_bcast(lu[p], k) : 0.0f;
-    double sum = 0.;
-#pragma unroll
-    for (int p = 0; p < 6; p++) if (p < k) sum += lu[p] * lu[p];
-    const float d_own = (float)sqrt(a[k] - sum);  // right on lane k
-    diag[k] = lane_bcast(d_own, k);
-    double sum2 = 0.;
-#pragma unroll
-    for (int p = 0; p < 6; p++) if (p < k) sum2 += lu[p] * rk[p];
-    const float v = (float)((a[k] - sum2) / diag[k]);  // right on lanes > k
-    lu[k] = lane == k ? diag[k] : (lane > k ? v : 0.0f);
-  }
-  float y[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) {  // :210-215, row i on lane i
-    double sum = 0.;
-#pragma unroll
-    for (int k = 0; k < 6; k++) if (k < i) sum += lu[k] * y[k];
-    const float cand = (float)((b_own - sum) / diag[i]);
-    y[i] = lane_bcast(cand, i);
-  }
-  float lt[6];  // column `lane` of LU: lt[k] = LU[k][lane]
-#pragma unroll
-  for (int k = 0; k < 6; k++) lt[k] = 0.0f;
-#pragma unroll
-  for (int c = 0; c < 6; c++)
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-      if (k > c) { const float t = lane_bcast(lu[c], k); lt[k] = lane == c ? t : lt[k]; }
-#pragma unroll
-  for (int i = 5; i >= 0; --i) {  // :216-221, column i on lane i
-    double sum = 0.;
-#pragma unroll
-    for (int k = 0; k < 6; k++) if (k > i) sum += lt[k] * x[k];
-    const float cand = (float)((y[i] - sum) / diag[i]);
-    x[i] = lane_bcast(cand, i);
-  }
-}
-
-// element e = 4 * col + row of glm operator*(mat4, mat4) (type_mat4x4.inl:753-775): the expression of d_mat4_mul
-__device__ inline float mat4_mul_elem(const volatile float *a, const volatile float *b, int e) {
-  const int c = e >> 2, row = e & 3;
-  return ((a[row] * b[4 * c] + a[4 + row] * b[4 * c + 1]) + a[8 + row] * b[4 * c + 2]) + a[12 + row] * b[4 * c + 3];
-}
-
-// :172-173 pose update (Q17: row-vector products) and the fusion transform of main.cpp:40; m = update_trans
-__device__ inline void frame_end_step(CamState *st, int apply_update, const volatile float *m) {
-  const int slot = st->frames_done;  // kept on the device so that the recorded launch sequence is the same for every frame
-  if (apply_update) {
-    const float v[4] = {st->position[0], st->position[1], st->position[2], 1.0f};
-    float np[3];
-    for (int i = 0; i < 3; i++) np[i] = ((m[4 * i] * v[0] + m[4 * i + 1] * v[1]) + m[4 * i + 2] * v[2]) + m[4 * i + 3] * v[3];
-    st->position[0] = np[0]; st->position[1] = np[1]; st->position[2] = np[2];
-    float o4[16], mm[16], no[16];
-    d_identity(o4);
-    for (int c = 0; c < 3; c++)
-      for (int r = 0; r < 3; r++) o4[4 * c + r] = st->orientation[3 * c + r];
-    for (int i = 0; i < 16; i++) mm[i] = m[i];
-    d_mat4_mul(o4, mm, no);
-    for (int c = 0; c < 3; c++)
-      for (int r = 0; r < 3; r++) st->orientation[3 * c + r] = no[4 * c + r];
-  }
-  float o4[16], I[16], t[16];
-  d_identity(o4);
-  for (int c = 0; c < 3; c++)
-    for (int r = 0; r < 3; r++) o4[4 * c + r] = st->orientation[3 * c + r];
-  d_identity(I);
-  d_translate(I, st->position, t);
-  d_mat4_mul(o4, t, st->fusion);
-  for (int i = 0; i < 16; i++) st->fusion_ring[slot & 3][i] = st->fusion[i];
-  st->frames_done = slot + 1;
-}
-
-// One ICP iteration's host part (rgbd_camera.cpp:100, :116-120, :143-160, :172-173) on ONE wavefront; all 64 lanes
-// call it.  sums = the 27 fixed-point sums (LDS), sm = 128 floats of LDS scratch.  The 4x4 matrices live one
-// element per lane (lanes 0..15): the three rotations are built side by side on lanes 0..2, the four matrix
-// products of :154-160 cost one LDS round trip each instead of 64 dependent multiply-adds on a single lane
-// (the tail used to take ~3 of the launch's 8.6 us).  Every element is the reference's expression, unchanged.
-constexpr int kTailScratch = 128;
-// state words the tail needs, fetched by the caller BEFORE it waits for the sums (one round trip instead of two;
-// a global access costs ~2 us while a raycast is running)
-struct TailPrefetch { float ut; int lost; };
-__device__ inline TailPrefetch tail_prefetch(const CamState *st, int flags) {
-  TailPrefetch p;
-  const int e = (int)(threadIdx.x & 15u);
-  p.ut = st->update_trans[e];
-  p.lost = st->lost;
-  (void)flags;
-  return p;
-}
-
-__device__ inline void iteration_tail_wave(CamState *st, const double *sums, int slot, int flags, volatile float *sm,
-                                           const TailPrefetch &pre) {
-  const int lane = (int)(threadIdx.x & 63u), e = lane & 15;
-  // level start (:100, :116-120): update_trans element e on lane e
-  float ut = (flags & kFlagFirstOfFrame) ? ((e % 5 == 0) ? 1.0f : 0.0f) : pre.ut;
-  int lost = 0;
-  if (flags & kFlagFirstIter) {
-    if (lane < 16) st->level_start[e] = ut;
-    if (lane == 0) st->lost = 0;
-  } else {
-    lost = pre.lost;
-  }
-  if ((flags & kFlagFirstOfFrame) && lane < 16) st->update_trans[e] = ut;
-  if (!lost) {
-    float x[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, a_elem, b_elem;
-    wave_solve_cholesky(sums, x, a_elem, b_elem);
-    if (lane < 36) st->lastA[lane] = a_elem;
-    if (lane < 6) { st->lastb[lane] = b_elem; st->lastx[lane] = x[lane < 6 ? lane : 0]; }
-    if (x[0] != x[0] || x[1] != x[1] || x[2] != x[2] || x[3] != x[3] || x[4] != x[4] || x[5] != x[5]) {
-      if (lane == 0) {
-        st->lost = 1;  // "Camera tracking is lost." -> abandon this level (:148-151)
-        st->tracking_lost_count++;
-      }
-    } else {
-      // this_trans = Rz(-x2) * Ry(-x1) * Rx(-x0) * T(x3,x4,x5), glm degrees API (:154-158)
-      const int k = lane < 2 ? lane : 2;  // lane 0: Rz, lane 1: Ry, lanes 2..: Rx
-      const float xk = k == 0 ? x[2] : (k == 1 ? x[1] : x[0]);
-      float I[16], R[16], tr[16];
-      d_identity(I);
-      d_rotate_deg(I, -xk * 180.0f / 3.14159f, k == 2 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 0 ? 1.0f : 0.0f, R);
-      const float tv[3] = {x[3], x[4], x[5]};
-      d_translate(I, tv, tr);
-      if (lane < 3)
-        for (int i = 0; i < 16; i++) sm[16 * lane + i] = R[i];
-      if (lane == 3)
-        for (int i = 0; i < 16; i++) sm[48 + i] = tr[i];
-      if (lane < 16) sm[112 + e] = ut;
-      __builtin_amdgcn_wave_barrier();
-      const float t1 = mat4_mul_elem(sm, sm + 16, e);          // Rz * Ry
-      if (lane < 16) sm[64 + e] = t1;
-      __builtin_amdgcn_wave_barrier();
-      const float t2 = mat4_mul_elem(sm + 64, sm + 32, e);     // * Rx
-      if (lane < 16) sm[80 + e] = t2;
-      __builtin_amdgcn_wave_barrier();
-      const float tt = mat4_mul_elem(sm + 80, sm + 48, e);     // * T  = this_trans
-      if (lane < 16) sm[96 + e] = tt;
-      __builtin_amdgcn_wave_barrier();
-      ut = mat4_mul_elem(sm + 96, sm + 112, e);                // update_trans = this_trans * update_trans (:160)
-      if (lane < 16) {
-        st->update_trans[e] = ut;
-        if (slot < kMaxChain) st->chain[slot][e] = tt;
-      }
-    }
-  }
-  if (flags & kFlagLastOfFrame) {
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 16) sm[112 + e] = ut;
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) frame_end_step(st, 1, sm + 112);
-  }
-}
 
 // single-GPU iteration tail: sum the workgroup rows, solve, compose -- ONE launch
 __global__ __launch_bounds__(kReduceThreads) void cam_reduce_solve_kernel(CamState *st, const double *__restrict__ partial,
@@ -759,6 +390,12 @@ struct svoslam_camera {
   bool frame_has_icp = false;
   int ring_slot = 0;       // fusion_ring slot of the frame being / last tracked
   svoslam::GraphCache g_prep, g_track;  // recorded launch sequences (graph_cache.hpp)
+  // one-launch tracker (track_persistent.hip)
+  svoslam::TrackSync *d_sync = nullptr;
+  double *d_rows = nullptr;
+  unsigned *d_tickets = nullptr;
+  hipStream_t cap_stream = nullptr;  // stream whose resident-workgroup capacity is cached below
+  int capacity = 0;
 };
 
 namespace svoslam {
@@ -786,6 +423,9 @@ int camera_create(svoslam_camera **out, int w, int h, float fx, float fy) {
   }
   SVO_HIP(hipMalloc((void **)&c->d_state, sizeof(CamState)));
   SVO_HIP(hipMalloc((void **)&c->d_partial, (size_t)kMaxIcpBlocks * 27 * sizeof(double)));
+  SVO_HIP(hipMalloc((void **)&c->d_sync, sizeof(TrackSync)));
+  SVO_HIP(hipMalloc((void **)&c->d_tickets, track_persistent_ticket_bytes()));
+  SVO_HIP(hipMalloc((void **)&c->d_rows, (size_t)(kTrkMaxWorkers + 1) * 27 * sizeof(double)));
   c->d_acc = c->d_state->acc;
   const int rc = camera_reset(c);
   if (rc != SVOSLAM_OK) { camera_destroy(c); return rc; }
@@ -806,6 +446,8 @@ int camera_reset(svoslam_camera *c) {
     for (int r = 0; r < 4; r++) init.fusion_ring[r][i] = 1.0f;
   }
   SVO_HIP(hipMemcpy(c->d_state, &init, sizeof(init), hipMemcpyHostToDevice));
+  SVO_HIP(hipMemset(c->d_sync, 0, sizeof(TrackSync)));
+  SVO_HIP(hipMemset(c->d_tickets, 0, track_persistent_ticket_bytes()));
   c->have_stamp = false; c->latest_stamp = 0;
   c->prepared = 0; c->tracked = 0;
   c->frame_has_icp = false;
@@ -824,6 +466,9 @@ int camera_destroy(svoslam_camera *c) {
   }
   if (c->d_state) (void)hipFree(c->d_state);
   if (c->d_partial) (void)hipFree(c->d_partial);
+  if (c->d_sync) (void)hipFree(c->d_sync);
+  if (c->d_tickets) (void)hipFree(c->d_tickets);
+  if (c->d_rows) (void)hipFree(c->d_rows);
   delete c;
   return SVOSLAM_OK;
 }
@@ -925,18 +570,46 @@ int camera_end(svoslam_camera *c, hipStream_t s) {
   return SVOSLAM_OK;
 }
 
-// Pose of the oldest prepared frame: two launches per ICP iteration (accumulate; reduce + solve +
-// compose), recorded once per map set and replayed as one graph.  Two single-launch variants were
-// measured and dropped: the last-arriving workgroup reducing and solving behind an agent-scope
-// release/acquire (4 % slower end to end: the fences cost what the kernel boundary costs), and every
-// workgroup finishing the previous iteration redundantly on an LDS copy of the state before
-// accumulating the next (21 us per launch against 11.8 + 7.1: the solve then runs on every CU, in
-// competition with the raycast wavefronts).
+// Pose of the oldest prepared frame.  Default: ONE launch for the 19 iterations (track_persistent.hip).
+// SVOSLAM_TRACK_CHAIN=1 selects the launch chain instead -- two launches per ICP iteration (accumulate; reduce +
+// solve + compose), recorded once per map set and replayed as one graph; same bits, ~2x the time.  (Measured and
+// dropped in round 1 for the chain: the last-arriving workgroup solving behind an agent-scope release/acquire, and
+// every workgroup finishing the previous iteration redundantly.)
+static bool track_chain_forced() {
+  static const bool on = [] { const char *e = getenv("SVOSLAM_TRACK_CHAIN"); return e && e[0] == '1'; }();
+  return on;
+}
+
+static int track_one_launch(svoslam_camera *c, hipStream_t s) {
+  TrackArgs A;
+  for (int level = 0; level < 3; level++) {
+    LevelArgs a = level_args(c, level);
+    int end;
+    (void)accumulate_range(a.w, a.h, a.first, a.num, end);
+    A.level[level].lv = a.lv; A.level[level].ln = a.ln; A.level[level].cv = a.cv; A.level[level].cn = a.cn;
+    A.level[level].first = a.first; A.level[level].end = end > a.first ? end : a.first;
+    A.iters[level] = kPyramidIters[level];
+  }
+  if (c->capacity == 0 || c->cap_stream != s) {
+    SVO_TRY(track_persistent_capacity(s, &c->capacity));
+    c->cap_stream = s;
+  }
+  SVO_TRY(track_persistent_plan(A, c->capacity));
+  return track_persistent_launch(c->d_state, c->d_sync, c->d_tickets, c->d_rows, A, s);
+}
+
 int camera_track(svoslam_camera *c, hipStream_t s) {
   if (!c) return SVOSLAM_ERR_INVALID_ARG;
   if (c->tracked >= c->prepared) return SVOSLAM_ERR_INVALID_ARG;  // nothing prepared
   const bool has_icp = c->tracked >= 1;
   const int ring_slot = (int)(c->tracked & 3u);
+  if (has_icp && !track_chain_forced()) {
+    SVO_TRY(track_one_launch(c, s));
+    c->ring_slot = ring_slot;
+    c->tracked++;
+    c->frame_has_icp = false;
+    return SVOSLAM_OK;
+  }
   GraphKey key;
   key.add((unsigned long long)(c->tracked % 3u)).add((unsigned long long)has_icp)
      .add((unsigned long long)c->band_first).add((unsigned long long)c->band_rows);
@@ -992,11 +665,24 @@ int camera_set_acc(svoslam_camera *c, double *d_acc) {
 
 double *camera_acc(svoslam_camera *c) { return c ? c->d_acc : nullptr; }
 
+// a bounded spin of the one-launch tracker gave up (should never happen: report it instead of a garbage pose)
+static int check_tracker_health(svoslam_camera *c, hipStream_t s) {
+  TrackSync sy;
+  SVO_HIP(hipMemcpyAsync(&sy, c->d_sync, sizeof(sy), hipMemcpyDeviceToHost, s));
+  SVO_HIP(hipStreamSynchronize(s));
+  if (sy.fail != 0u) {
+    set_last_error("one-launch tracker: a workgroup hand-off timed out (camera_reset clears it)", hipErrorLaunchTimeOut);
+    return SVOSLAM_ERR_HIP;
+  }
+  return SVOSLAM_OK;
+}
+
 int camera_pose(svoslam_camera *c, float pos[3], float ori[9], hipStream_t s) {
   if (!c || !pos || !ori) return SVOSLAM_ERR_INVALID_ARG;
   CamState st;
   SVO_HIP(hipMemcpyAsync(&st, c->d_state, sizeof(st), hipMemcpyDeviceToHost, s));
   SVO_HIP(hipStreamSynchronize(s));
+  SVO_TRY(check_tracker_health(c, s));
   memcpy(pos, st.position, sizeof(st.position));
   memcpy(ori, st.orientation, sizeof(st.orientation));
   return SVOSLAM_OK;
@@ -1022,11 +708,17 @@ const float *camera_last_vertex(svoslam_camera *c, int level) {
 const float *camera_last_normal(svoslam_camera *c, int level) {
   return (c && level >= 0 && level < 3) ? c->norm[(c->tracked + 2u) % 3u][level] : nullptr;
 }
+int camera_track_profile(svoslam_camera *c, unsigned long long *h_stamps, hipStream_t s) {
+  if (!c || !h_stamps) return SVOSLAM_ERR_INVALID_ARG;
+  return track_persistent_profile(c->d_sync, h_stamps, s);
+}
+
 int camera_tracking_lost_count(svoslam_camera *c, int *count, hipStream_t s) {
   if (!c || !count) return SVOSLAM_ERR_INVALID_ARG;
   CamState st;
   SVO_HIP(hipMemcpyAsync(&st, c->d_state, sizeof(st), hipMemcpyDeviceToHost, s));
   SVO_HIP(hipStreamSynchronize(s));
+  SVO_TRY(check_tracker_health(c, s));
   *count = st.tracking_lost_count;
   return SVOSLAM_OK;
 }

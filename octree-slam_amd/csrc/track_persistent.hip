@@ -1,0 +1,466 @@
+// track_persistent.hip -- the 19 ICP iterations of RGBDCamera::update (src/sensor/rgbd_camera.cpp:103-168) in ONE launch.
+//
+// The launch-chain tracker (icp.hip) spends a frame in 38 dependent launches of 5-13 us each (profiles/
+// r02_tracker_chain_timeline_before.txt): every iteration re-reads 48 B per pixel, replays the growing chain of
+// rigid updates on it, and pays two kernel boundaries.  Here the pixels of a pyramid level stay in REGISTERS for all
+// iterations of the level (the reference rewrites both maps in HBM after every iteration, :163-167; a lane applies
+// the same 4x4 product to the values it holds -- same operands, same order, same floats), and the iterations are
+// separated by one fan-in / one broadcast inside the launch instead of two kernel boundaries:
+//
+//   workgroup 0 ("solver")        polls the epoch's arrival counter, sums the workers' 27-double rows (exact:
+//                                 integer-valued, R3), runs the 6x6 Cholesky + pose composition on one wavefront
+//                                 (icp_device.hpp, unchanged) and publishes this_trans / update_trans / lost as
+//                                 33 eight-byte {tag = epoch, value} granules -- the data is its own flag;
+//   workgroups 1..W ("workers")   accumulate their pixels' terms, reduce them to one row (DPP + LDS), store it
+//                                 write-through (sc1), drain, bump the counter, then sweep the granules until every
+//                                 tag matches and apply this_trans to their registers.
+//
+// Every shared word is accessed with agent-scope (sc1) loads / stores only, so the exchange does not depend on which
+// XCD a workgroup runs on (cdna_hip_programming.md Guideline 16, forms R1 for the rows and R2 for the broadcast).
+// Nothing is zeroed per launch: tags carry a device-resident generation (replay-safe), the two banks of arrival
+// counters alternate and the solver clears the idle one.  The solver is the only writer of CamState, from one CU.
+// All spins are bounded; a give-up code in TrackSync::fail makes every later call of the camera return an error.
+//
+// Images too large for registers (1920x1080 at level 0: 16 pixels per lane) fall back, per level, to re-reading the
+// maps and replaying the chain from LDS, still inside the one launch.
+#include <stdlib.h>
+
+#include "icp_device.hpp"
+#include "track_persistent.hpp"
+
+namespace svoslam {
+
+constexpr int kTrkWaves = kTrkThreads / kWave;
+constexpr int kGranules = 33;  // 16 this_trans + 16 update_trans + flags
+constexpr unsigned kSpinLimit = 1u << 22;  // ~ seconds; the tracker itself takes ~0.2 ms
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+__device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned ld_agent32(const unsigned *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent64(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent32(unsigned *p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// arrival counter of (bank, epoch, x = blockIdx & 7): 512 bytes apart so that the eight counters of an epoch live in
+// different memory channels (device-scope atomics on one address serialise at ~12 ns each)
+constexpr int kTicketStride = 128;  // unsigneds
+__device__ __host__ inline size_t ticket_index(unsigned bank, int e, int x) { return ((size_t)(bank * 32u + (unsigned)e) * 8u + (unsigned)x) * kTicketStride; }
+__device__ inline unsigned *ticket_of(unsigned *tickets, unsigned bank, int e, int x) { return tickets + ticket_index(bank, e, x); }
+
+// one wavefront: wait until all kGranules tags equal `tag`; values -> LDS out[0..33).  Returns false on give-up.
+__device__ inline bool sweep_broadcast(TrackSync *sy, unsigned tag, float *out, int *out_flags) {
+  const int lane = (int)(threadIdx.x & 63u);
+  const int g = lane < kGranules ? lane : kGranules - 1;
+  for (unsigned spins = 0;; spins++) {
+    const unsigned long long x = ld_agent64(&sy->granule[g]);
+    const bool ok = (unsigned)(x >> 32) == tag;
+    if (__all(ok)) {
+      if (lane < 32) out[lane] = __uint_as_float((unsigned)x);
+      if (lane == 32) *out_flags = (int)(unsigned)x;
+      return true;
+    }
+    if ((spins & 63u) == 63u) {
+      if (ld_agent32(&sy->fail) != 0u) return false;
+      if (spins > kSpinLimit) { if (lane == 0) st_agent32(&sy->fail, 2u); return false; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+
+// ---- transposed accumulation --------------------------------------------------------------------------------------
+// A lane does not own a pixel's 27 sums (54 VGPRs of doubles and a 27 x 6-step cross-lane reduction per iteration):
+// it owns ONE term.  Every lane forms the gates, J[6] and b of its pixel (localization_kernels.cu:186-226) and puts
+// them as one 32-byte row into LDS; then lane (t, half) walks the 32 rows of its half of the wavefront and adds
+// rint(fl(J_i * J_j) * 2^20) (or rint(fl(b * J_i) * 2^30)) of every pixel to its single accumulator.  Same products,
+// same exact integer-valued addends, any order (R3); what is left to combine per workgroup is 16 partials per term.
+constexpr int kRowFloats = 8;  // J0..J5, b, 0
+
+struct TermLane { int off_a, off_b; float scale; };  // byte offsets inside a row
+__device__ inline TermLane term_of_lane(int t) {
+  TermLane L;
+  if (t < 21) {  // (i, j), i <= j, row-major upper triangle: the order of Mat6x7's A entries in the 27 sums
+    int i = 0, r = t;
+    for (; i < 6; i++) { const int len = 6 - i; if (r < len) break; r -= len; }
+    L.off_a = 4 * i; L.off_b = 4 * (i + r); L.scale = 1048576.0f;
+  } else if (t < 27) {
+    L.off_a = 4 * 6; L.off_b = 4 * (t - 21); L.scale = 1073741824.0f;  // b * J[i]
+  } else {
+    L.off_a = 4 * 7; L.off_b = 4 * 7; L.scale = 1.0f;  // idle lanes read the zero pad
+  }
+  return L;
+}
+
+// gates + Jacobian row of one pixel pair -> row[0..8) (zeros when a gate rejects the pair)
+__device__ __forceinline__ void icp_pixel_row(float v1x, float v1y, float v1z, float n1x, float n1y, float n1z, float v2x,
+                                              float v2y, float v2z, float n2x, float n2y, float n2z, float *row) {
+  bool ok = finitef_(v2x) && finitef_(v2y) && finitef_(v2z) && finitef_(v1x) && finitef_(v1y) && finitef_(v1z) &&
+            !(v1z < 0.1f) && !(v2z < 0.1f) && !(v1z > 10.0f) && !(v2z > 10.0f);
+  ok = ok && finitef_(n2x) && finitef_(n2y) && finitef_(n2z) && finitef_(n1x) && finitef_(n1y) && finitef_(n1z);
+  const float dx = v2x - v1x, dy = v2y - v1y, dz = v2z - v1z;
+  ok = ok && !(sqrtf(dot3(dx, dy, dz, dx, dy, dz)) > kDistThresh);
+  ok = ok && !(dot3(n2x, n2y, n2z, n1x, n1y, n1z) < kNormThresh);
+  float J[6];
+  J[0] = (0.0f * n1x + (-v2x) * n1y) + (-v2y) * n1z;
+  J[1] = ((-v2z) * n1x + 0.0f * n1y) + v2x * n1z;
+  J[2] = (v2y * n1x + v2z * n1y) + 0.0f * n1z;
+  J[3] = (1.0f * n1x + 0.0f * n1y) + 0.0f * n1z;
+  J[4] = (0.0f * n1x + 1.0f * n1y) + 0.0f * n1z;
+  J[5] = (0.0f * n1x + 0.0f * n1y) + 1.0f * n1z;
+  const float bb = dot3(n1x, n1y, n1z, v1x - v2x, v1y - v2y, v1z - v2z);
+  float4 lo, hi;
+  lo.x = ok ? J[0] : 0.0f; lo.y = ok ? J[1] : 0.0f; lo.z = ok ? J[2] : 0.0f; lo.w = ok ? J[3] : 0.0f;
+  hi.x = ok ? J[4] : 0.0f; hi.y = ok ? J[5] : 0.0f; hi.z = ok ? bb : 0.0f; hi.w = 0.0f;
+  *reinterpret_cast<float4 *>(row) = lo;
+  *reinterpret_cast<float4 *>(row + 4) = hi;
+}
+
+// lane (t, half): add its term of the 32 rows of its half (rows = this wavefront's 64 x 8 floats) to acc0 / acc1
+__device__ __forceinline__ void accumulate_rows(const float *rows, const TermLane &T, int half, double &acc0, double &acc1) {
+  const char *base = reinterpret_cast<const char *>(rows) + half * 32 * kRowFloats * 4;
+#pragma unroll
+  for (int p = 0; p < 32; p += 2) {
+    const float a0 = *reinterpret_cast<const float *>(base + p * kRowFloats * 4 + T.off_a);
+    const float b0 = *reinterpret_cast<const float *>(base + p * kRowFloats * 4 + T.off_b);
+    const float a1 = *reinterpret_cast<const float *>(base + (p + 1) * kRowFloats * 4 + T.off_a);
+    const float b1 = *reinterpret_cast<const float *>(base + (p + 1) * kRowFloats * 4 + T.off_b);
+    const float p0 = a0 * b0, p1 = a1 * b1;
+    acc0 += (double)rintf(p0 * T.scale);
+    acc1 += (double)rintf(p1 * T.scale);
+  }
+}
+
+#ifdef SVO_TRK_PROF
+#define TRK_STAMP(cond, e, k) do { if (cond) sy->prof[(e) & 31][k] = (unsigned long long)clock64(); } while (0)
+#else
+#define TRK_STAMP(cond, e, k) do { } while (0)
+#endif
+
+// the solver's iteration tail as a real call: its ~70 VGPRs and the workers' register-resident pixels are then
+// allocated independently (inlined, the allocator spills the tail's values around the 255-VGPR worker body)
+__device__ __attribute__((noinline)) TailResult solver_tail(CamState *st, const double *totals, int it, int flags, float *tail_sm,
+                                                            float pre_ut, int pre_lost) {
+  TailPrefetch pre;
+  pre.ut = pre_ut; pre.lost = pre_lost;
+  return iteration_tail_wave(st, totals, it, flags, tail_sm, pre);
+}
+
+struct PixelSet {  // one lane's pixels of the current level
+  float v1[kTrkSlots][3], n1[kTrkSlots][3], v2[kTrkSlots][3], n2[kTrkSlots][3];
+};
+
+__global__ __launch_bounds__(kTrkThreads) void track_persistent_kernel(CamState *st, TrackSync *sy, unsigned *tickets, double *rows, TrackArgs A) {
+  SVO_HIGH_PRIO();
+  __shared__ double wsum[16][27];          // workers: per-(wave, half) term sums; solver: row-group sums
+  __shared__ __attribute__((aligned(16))) float rows_s[kTrkWaves * 64 * kRowFloats];  // one 32-byte row per pixel in flight
+  __shared__ double totals[27];
+  __shared__ float bc[32];                 // this_trans[16], update_trans[16] of the current epoch
+  __shared__ int bc_flags;                 // bit 0: level lost, bit 1: this_trans valid
+  __shared__ float chain_s[(kMaxChain + 1) * 16];
+  __shared__ float tail_sm[kTailScratch];
+  __shared__ int s_fail;
+  const unsigned gen = ld_agent32(&sy->gen);
+  const unsigned bank = gen & 1u;
+  const int tid = (int)threadIdx.x;
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if (tid < 16) bc[16 + tid] = (tid % 5 == 0) ? 1.0f : 0.0f;  // update_trans = identity at the start of a frame (:100)
+  if (tid == 0) { bc_flags = 0; s_fail = 0; }
+  __syncthreads();
+
+  if (blockIdx.x == 0) {
+    // ------------------------------------------------------------------ solver
+    if (tid < 256) *ticket_of(tickets, bank ^ 1u, tid >> 3, tid & 7) = 0u;  // the next launch's counters (kernel boundary)
+    int e = 0;
+    for (int level = 2; level >= 0; level--) {
+      const int P = A.participants[level];
+      for (int it = 0; it < A.iters[level]; it++) {
+        e++;
+        TRK_STAMP(tid == 0, e, 0);
+        if (wave == 0) {  // fan-in: every participant has stored its row and drained
+          // arrivals are counted per (blockIdx & 7) on eight counters in different memory channels; lane x polls counter x
+          const int x = (int)(lane & 7u);
+          const int first_wid = (x + 7) & 7;  // smallest wid with ((wid + 1) & 7) == x
+          const int expect = P > first_wid ? (P - first_wid + 7) / 8 : 0;
+          bool ok = true;
+          for (unsigned spins = 0;; spins++) {
+            if (__all((int)ld_agent32(ticket_of(tickets, bank, e, x)) >= expect)) break;
+            if ((spins & 63u) == 63u && (ld_agent32(&sy->fail) != 0u || spins > kSpinLimit)) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (!ok && lane == 0) { st_agent32(&sy->fail, 1u); s_fail = 1; }
+        }
+        __syncthreads();
+        if (s_fail) return;
+        TRK_STAMP(tid == 0, e, 1);
+        {  // column sums of rows[P][27] (exact), 16 row groups x 32 columns; all of a thread's loads are issued before
+           // the first is used (a load-add loop costs one memory round trip per row: 2.7 us for 150 rows)
+          const int col = tid & 31, grp = tid >> 5;
+          constexpr int kRowsPerThread = (kTrkMaxWorkers + 15) / 16;
+          const unsigned long long *src = reinterpret_cast<const unsigned long long *>(rows) + col;
+          unsigned long long raw[kRowsPerThread];
+#pragma unroll
+          for (int k = 0; k < kRowsPerThread; k++) {
+            const int r = grp + 16 * k;
+            raw[k] = (col < 27 && r < P) ? ld_agent64(src + (size_t)r * 27) : 0ull;
+          }
+          double s = 0.0;
+#pragma unroll
+          for (int k = 0; k < kRowsPerThread; k++) s += __longlong_as_double((long long)raw[k]);
+          if (col < 27) wsum[grp][col] = s;
+          __syncthreads();
+          if (tid < 27) {
+            double t = 0.0;
+#pragma unroll
+            for (int g = 0; g < kTrkThreads / 32; g++) t += wsum[g][tid];
+            totals[tid] = t;
+          }
+          __syncthreads();
+        }
+        TRK_STAMP(tid == 0, e, 2);
+        if (wave == 0) {
+          int flags = 0;
+          if (level < 2) flags |= kFlagLevelStart;
+          if (it == 0) flags |= kFlagFirstIter;
+          if (level == 2 && it == 0) flags |= kFlagFirstOfFrame;
+          if (level == 0 && it == A.iters[0] - 1) flags |= kFlagLastOfFrame;
+          const TailResult res = solver_tail(st, totals, it, flags, tail_sm, bc[16 + (lane & 15u)], bc_flags & 1);
+          const unsigned tag = gen * 32u + (unsigned)e;
+          const unsigned fl = (unsigned)(res.lost ? 1 : 0) | (unsigned)(res.solved ? 2 : 0);
+          const unsigned val = lane < 16 ? __float_as_uint(res.tt) : (lane < 32 ? __float_as_uint(res.ut) : fl);
+          if (lane < (unsigned)kGranules) st_agent64(&sy->granule[lane], ((unsigned long long)tag << 32) | val);
+          if (lane < 16) bc[16 + lane] = res.ut;
+          if (lane == 0) bc_flags = (int)fl;
+          TRK_STAMP(lane == 0, e, 3);
+        }
+        __syncthreads();
+      }
+    }
+    if (tid == 0) sy->gen = gen + 1u;  // read by the next launch only
+    return;
+  }
+
+  // -------------------------------------------------------------------- workers
+  // Participation is a suffix of the levels (participants[] grows towards the finest level, which every worker
+  // takes part in).  A worker sits out the coarser levels WITHOUT following their epochs -- the participants may be
+  // several epochs ahead of a worker that has not even started -- and joins by waiting for the last epoch of the
+  // level before its first one: that broadcast cannot be overwritten before this worker arrives at the next epoch.
+  const int wid = (int)blockIdx.x - 1;
+  const int term = (int)(lane & 31u), half = (int)(lane >> 5);
+  const TermLane T = term_of_lane(term);
+  int e = 0;
+  bool joined = false;
+  for (int level = 2; level >= 0; level--) {
+    const TrackLevel L = A.level[level];
+    const int P = A.participants[level], slots = A.slots[level];
+    const bool part = wid < P;
+    if (!part) { e += A.iters[level]; continue; }
+    if (!joined && e > 0) {
+      if (wave == 0) {
+        const bool ok = sweep_broadcast(sy, gen * 32u + (unsigned)e, bc, &bc_flags);
+        if (!ok && lane == 0) s_fail = 1;
+      }
+      __syncthreads();
+      if (s_fail) return;
+    }
+    joined = true;
+    const bool in_regs = slots <= kTrkSlots;
+    PixelSet px;
+    int nchain = 0;
+    if (in_regs) {
+#pragma unroll
+      for (int k = 0; k < kTrkSlots; k++) {
+        const long long p = (long long)L.first + ((long long)k * P + wid) * kTrkThreads + tid;
+        const bool have = k < slots && p < (long long)L.end;
+        const size_t q = have ? (size_t)p : (size_t)L.first;
+        if (k < slots) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            px.v1[k][c] = L.lv[3 * q + c]; px.n1[k][c] = L.ln[3 * q + c];
+            px.v2[k][c] = L.cv[3 * q + c]; px.n2[k][c] = L.cn[3 * q + c];
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; c++) px.v1[k][c] = px.n1[k][c] = px.v2[k][c] = px.n2[k][c] = 0.0f;
+        }
+        if (!have) px.v1[k][0] = __builtin_nanf("");  // never passes the gates
+        if (level < 2) {  // the level's copy is first transformed by update_trans as the coarser level left it (:116-120)
+          float ox, oy, oz;
+          mat4_mul_point(bc + 16, px.v2[k][0], px.v2[k][1], px.v2[k][2], 1.0f, ox, oy, oz);
+          px.v2[k][0] = ox; px.v2[k][1] = oy; px.v2[k][2] = oz;
+          mat4_mul_point(bc + 16, px.n2[k][0], px.n2[k][1], px.n2[k][2], 0.0f, ox, oy, oz);
+          px.n2[k][0] = ox; px.n2[k][1] = oy; px.n2[k][2] = oz;
+        }
+      }
+    } else if (level < 2) {
+      if (tid < 16) chain_s[tid] = bc[16 + tid];
+      nchain = 1;
+    }
+    __syncthreads();
+    bool lost = false;
+    for (int it = 0; it < A.iters[level]; it++) {
+      e++;
+      TRK_STAMP(wid == 0 && tid == 0, e, 4);
+      {
+        double acc0 = 0.0, acc1 = 0.0;
+        float *my_rows = rows_s + wave * (64 * kRowFloats);
+        if (!lost) {
+          if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < kTrkSlots; k++) {
+              if (k < slots) {
+                icp_pixel_row(px.v1[k][0], px.v1[k][1], px.v1[k][2], px.n1[k][0], px.n1[k][1], px.n1[k][2], px.v2[k][0],
+                              px.v2[k][1], px.v2[k][2], px.n2[k][0], px.n2[k][1], px.n2[k][2], my_rows + lane * kRowFloats);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // the rows of this wavefront are read by its own lanes only
+                accumulate_rows(my_rows, T, half, acc0, acc1);
+                __builtin_amdgcn_wave_barrier();
+              }
+            }
+          } else {
+            for (int k = 0; k < slots; k++) {  // uniform trip count: every lane writes a row (zeros past the end)
+              const long long p = (long long)L.first + ((long long)k * P + wid) * kTrkThreads + tid;
+              const bool have = p < (long long)L.end;
+              const size_t q = have ? (size_t)p : (size_t)L.first;
+              float v2x = L.cv[3 * q], v2y = L.cv[3 * q + 1], v2z = L.cv[3 * q + 2];
+              float n2x = L.cn[3 * q], n2y = L.cn[3 * q + 1], n2z = L.cn[3 * q + 2];
+              float v1x = L.lv[3 * q];
+              const float v1y = L.lv[3 * q + 1], v1z = L.lv[3 * q + 2];
+              const float n1x = L.ln[3 * q], n1y = L.ln[3 * q + 1], n1z = L.ln[3 * q + 2];
+              if (!have) v1x = __builtin_nanf("");
+              for (int c = 0; c < nchain; c++) {  // transformVertexMap / transformNormalMap replayed
+                float ox, oy, oz;
+                mat4_mul_point(chain_s + 16 * c, v2x, v2y, v2z, 1.0f, ox, oy, oz);
+                v2x = ox; v2y = oy; v2z = oz;
+                mat4_mul_point(chain_s + 16 * c, n2x, n2y, n2z, 0.0f, ox, oy, oz);
+                n2x = ox; n2y = oy; n2z = oz;
+              }
+              icp_pixel_row(v1x, v1y, v1z, n1x, n1y, n1z, v2x, v2y, v2z, n2x, n2y, n2z, my_rows + lane * kRowFloats);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              accumulate_rows(my_rows, T, half, acc0, acc1);
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+        }
+        TRK_STAMP(wid == 0 && tid == 0, e, 5);
+        if (term < 27) wsum[wave * 2 + half][term] = acc0 + acc1;
+        __syncthreads();
+        if (wave == 0) {
+          if (tid < 27) {
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 2 * kTrkWaves; w++) v += wsum[w][tid];
+            st_agent64(reinterpret_cast<unsigned long long *>(rows) + (size_t)wid * 27 + tid, (unsigned long long)__double_as_longlong(v));
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row has left this CU before the arrival is counted
+          if (tid == 0) __hip_atomic_fetch_add(ticket_of(tickets, bank, e, (int)(blockIdx.x & 7u)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          TRK_STAMP(wid == 0 && tid == 0, e, 6);
+        }
+      }
+      if (wave == 0) {
+        const bool ok = sweep_broadcast(sy, gen * 32u + (unsigned)e, bc, &bc_flags);
+        if (!ok && lane == 0) s_fail = 1;
+      }
+      __syncthreads();
+      if (s_fail) return;
+      TRK_STAMP(wid == 0 && tid == 0, e, 7);
+      const int fl = bc_flags;
+      lost = (fl & 1) != 0;
+      if (fl & 2) {  // this_trans of the iteration: transformVertexMap / transformNormalMap (:163-167)
+        if (in_regs) {
+#pragma unroll
+          for (int k = 0; k < kTrkSlots; k++)
+            if (k < slots) {
+              float ox, oy, oz;
+              mat4_mul_point(bc, px.v2[k][0], px.v2[k][1], px.v2[k][2], 1.0f, ox, oy, oz);
+              px.v2[k][0] = ox; px.v2[k][1] = oy; px.v2[k][2] = oz;
+              mat4_mul_point(bc, px.n2[k][0], px.n2[k][1], px.n2[k][2], 0.0f, ox, oy, oz);
+              px.n2[k][0] = ox; px.n2[k][1] = oy; px.n2[k][2] = oz;
+            }
+        } else if (nchain <= kMaxChain) {
+          if (tid < 16) chain_s[16 * nchain + tid] = bc[tid];
+          nchain++;
+        }
+      }
+      __syncthreads();  // bc / chain_s are rewritten in the next epoch
+    }
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------
+static int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return (e && e[0]) ? atoi(e) : dflt;
+}
+
+int track_persistent_capacity(hipStream_t s, int *max_workgroups) {
+  // resident workgroups the launch may count on: occupancy x the CUs the stream may use
+  static int per_cu = -1;
+  if (per_cu < 0) {
+    int n = 0;
+    SVO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, track_persistent_kernel, kTrkThreads, 0));
+    per_cu = n;
+  }
+  int dev = 0, cus = 0;
+  SVO_HIP(hipGetDevice(&dev));
+  SVO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (s != nullptr && hipExtStreamGetCUMask(s, 8, mask) == hipSuccess) {
+    int bits = 0;
+    for (int i = 0; i < 8; i++) bits += __builtin_popcount(mask[i]);
+    if (bits > 0 && bits < cus) cus = bits;
+  } else {
+    (void)hipGetLastError();
+  }
+  *max_workgroups = per_cu * cus;
+  return SVOSLAM_OK;
+}
+
+int track_persistent_plan(TrackArgs &A, int capacity) {
+  // workers: the finest level decides (kTrkSlots pixels per lane); coarser levels use as many of them as give a lane
+  // two pixels.  All workers take part in the finest (last) level.
+  const int slots_target = env_int("SVOSLAM_TRACK_SLOTS", kTrkSlots);
+  int cap = env_int("SVOSLAM_TRACK_WORKERS", kTrkMaxWorkers);
+  if (cap > capacity - 1) cap = capacity - 1;
+  if (cap < 1) return SVOSLAM_ERR_INVALID_ARG;
+  const long long n0 = A.level[0].end > A.level[0].first ? (long long)A.level[0].end - A.level[0].first : 0;
+  long long W = (n0 + (long long)kTrkThreads * slots_target - 1) / ((long long)kTrkThreads * slots_target);
+  if (W < 1) W = 1;
+  if (W > cap) W = cap;
+  A.workers = (int)W;
+  for (int l = 0; l < 3; l++) {
+    const long long n = A.level[l].end > A.level[l].first ? (long long)A.level[l].end - A.level[l].first : 0;
+    long long P = l == 0 ? W : (n + 2 * kTrkThreads - 1) / (2 * kTrkThreads);
+    if (P < 1) P = 1;
+    if (P > W) P = W;
+    A.participants[l] = (int)P;
+    A.slots[l] = (int)((n + P * kTrkThreads - 1) / (P * kTrkThreads));
+  }
+  return SVOSLAM_OK;
+}
+
+int track_persistent_profile(const TrackSync *d_sync, unsigned long long *out, hipStream_t s) {
+  if (!d_sync || !out) return SVOSLAM_ERR_INVALID_ARG;
+  SVO_HIP(hipMemcpyAsync(out, d_sync->prof, sizeof(d_sync->prof), hipMemcpyDeviceToHost, s));
+  SVO_HIP(hipStreamSynchronize(s));
+  return SVOSLAM_OK;
+}
+
+size_t track_persistent_ticket_bytes() { return ticket_index(2, 0, 0) * sizeof(unsigned); }
+
+int track_persistent_launch(CamState *st, TrackSync *sy, unsigned *tickets, double *rows, const TrackArgs &A, hipStream_t s) {
+  track_persistent_kernel<<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, tickets, rows, A);
+  SVO_LAUNCH_CHECK();
+  return SVOSLAM_OK;
+}
+
+}  // namespace svoslam

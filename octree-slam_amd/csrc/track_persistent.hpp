@@ -1,0 +1,41 @@
+// track_persistent.hpp -- see track_persistent.hip
+#pragma once
+#include "common.hpp"
+
+namespace svoslam {
+
+struct CamState;
+
+constexpr int kTrkThreads = 512;     // 8 wavefronts, 2 per SIMD: up to 256 VGPRs for the register-resident pixels
+#ifndef SVO_TRK_SLOTS
+#define SVO_TRK_SLOTS 4
+#endif
+constexpr int kTrkSlots = SVO_TRK_SLOTS;  // pixels of a level a lane may keep in registers (x 12 floats)
+constexpr int kTrkMaxWorkers = 247;  // + the solver workgroup <= one per CU on an idle device
+
+// words shared between the workgroups of one launch; zeroed (with the arrival counters, two banks of which the solver
+// clears the idle one) once when the camera is created / reset
+struct TrackSync {
+  unsigned long long granule[64];  // {tag = generation * 32 + epoch, value}: this_trans, update_trans, flags
+  unsigned gen;                    // launches so far (device-resident: the launch is replay-safe)
+  unsigned fail;                   // give-up code of a bounded spin (0 = none)
+  unsigned pad[2];
+  unsigned long long prof[32][8];  // SVO_TRK_PROF builds: s_memtime stamps per epoch (solver 0..3, worker 0 4..7)
+};
+
+struct TrackLevel { const float *lv, *ln, *cv, *cn; int first, end; };
+struct TrackArgs {
+  TrackLevel level[3];
+  int iters[3];
+  int workers;           // workgroups 1..workers; workgroup 0 solves
+  int participants[3];   // workers taking part at each level (a prefix)
+  int slots[3];          // pixels per lane at each level
+};
+
+int track_persistent_capacity(hipStream_t s, int *max_workgroups);
+int track_persistent_plan(TrackArgs &A, int capacity);
+int track_persistent_profile(const TrackSync *d_sync, unsigned long long *out, hipStream_t s);
+size_t track_persistent_ticket_bytes();  // arrival counters: [2 banks][32 epochs][8], zeroed with TrackSync
+int track_persistent_launch(CamState *st, TrackSync *sy, unsigned *tickets, double *rows, const TrackArgs &A, hipStream_t s);
+
+}  // namespace svoslam
