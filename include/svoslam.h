@@ -53,8 +53,6 @@ const char *svoslam_status_string(int status);
 const char *svoslam_last_error(void);
 /* name of the device the library runs on, e.g. "gfx950:..."; NULL if none */
 const char *svoslam_device_arch(void);
-/* number of HIP kernels compiled into the library (build sanity) */
-int svoslam_kernel_count(void);
 
 /* ------------------------------------------------------------------------
  * Node pool.  Same layout as the reference (common_types.h:75-79, svo.cu):
@@ -95,6 +93,12 @@ int svoslam_pool_expand(svoslam_pool *pool, float center[3], float *edge_length,
  * pool, (re)allocates the pool and returns the root parameters (each may be NULL). */
 int svoslam_pool_save(svoslam_pool *pool, const char *path, const float center[3], float edge_length, int32_t max_depth,
                       void *stream);
+/* Replaces the pool's contents by num_nodes host nodes (2 words each, reference format; child pointers validated) and
+ * resets all size bookkeeping incl. the device-resident size the asynchronous fusion allocates from.  Blocking. */
+int svoslam_pool_set_nodes(svoslam_pool *pool, const uint32_t *h_words, int32_t num_nodes, void *stream);
+/* dst becomes a byte-identical replica of src (nodes, size, at least src's capacity); dst may be zero-initialised.
+ * Blocking (waits for the device). */
+int svoslam_pool_copy(svoslam_pool *dst, svoslam_pool *src, void *stream);
 int svoslam_pool_load(svoslam_pool *pool, const char *path, float center[3], float *edge_length, int32_t *max_depth,
                       void *stream);
 
@@ -142,6 +146,12 @@ int svoslam_svo_fuse_sort(svoslam_workspace *ws, const float *d_points, int32_t 
 int svoslam_svo_fuse_plan(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream);
 int svoslam_svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int32_t n, int32_t max_depth,
                             svoslam_pool *pool, void *stream);
+/* The planned commit applied to one of several BYTE-IDENTICAL replicas of a map (a plan made against any replica in
+ * the state before this commit fits all of them: same tree, same tile numbering).  Each application uses its own
+ * slot (0 or 1; applications with different slots may run concurrently), all but the last pass keep_plan != 0.
+ * Replicas must have been given the same capacity.  svoslam_svo_fuse_commit == (slot 0, keep_plan 0). */
+int svoslam_svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, int32_t n, int32_t max_depth,
+                               svoslam_pool *pool, int32_t slot, int32_t keep_plan, void *stream);
 
 /* replaces svo::svoFromVoxelGrid (svo.h:14, svo.cu:584-640).  d_centers,
  * d_colors: n x vec4 (VoxelGrid, common_types.h:55-63). */
@@ -281,6 +291,12 @@ int svoslam_cone_trace_svo(uint8_t *d_pos, int32_t width, int32_t height, float 
 int svoslam_cone_trace_svo_band(uint8_t *d_pos, int32_t width, int32_t height, int32_t row_first, int32_t rows,
                                 float fov, const float view[16], const uint32_t *d_octree, const float center[3],
                                 float size, int32_t mode, unsigned long long *d_steps, void *stream);
+/* Re-entrancy: the per-render acceleration data (level grid, split-plane tables) lives in a library-owned buffer PER
+ * STREAM (17 MB, 135 MB for renders of a megapixel and more): renders enqueued on one stream share it in stream order,
+ * renders on different streams never touch each other's; calls may come from several host threads.  The timing log
+ * below and svoslam_timer_* are process-wide.  _release frees the buffer of one stream (all_streams != 0: of every
+ * stream) once the caller has synchronised it. */
+int svoslam_cone_trace_release(void *stream, int32_t all_streams);
 /* Measurement aid: while enabled, every cone-trace call brackets its trace kernel (not the small
  * acceleration-structure build before it) with a pair of HIP events on the launch stream.
  * _read waits for the logged launches, returns the summed kernel time and their number, and clears the log. */
@@ -391,6 +407,9 @@ int svoslam_camera_set_acc(svoslam_camera *cam, double *d_acc);
 /* number of pyramid levels abandoned because the solve returned NaN
  * ("Camera tracking is lost.", rgbd_camera.cpp:148-151).  Blocking. */
 int svoslam_camera_tracking_lost_count(svoslam_camera *cam, int32_t *count, void *stream);
+/* the newest timestamp the camera has accepted (rgbd_camera.cpp:55-59 skips frames that are not newer); *have = 0
+ * before the first frame.  Host state, no device access. */
+int svoslam_camera_latest_timestamp(svoslam_camera *cam, int32_t *have, long long *timestamp);
 /* diagnostic (libraries built with -DSVO_TRK_PROF; zeros otherwise): device clock stamps of the last tracked frame's
  * one-launch tracker, h_stamps[32][8] = per ICP iteration {solver: start, fan-in done, rows summed, published;
  * worker 0: start, terms done, row stored, broadcast received}.  Blocking. */
@@ -425,6 +444,10 @@ typedef struct svoslam_runner svoslam_runner;
 int svoslam_runner_create(svoslam_runner **runner, svoslam_camera *cam, svoslam_pool *pool, int32_t width, int32_t height,
                           int32_t max_depth, const float center[3], float edge_length, float fx, float fy, int32_t render_mode);
 int svoslam_runner_destroy(svoslam_runner *runner);
+/* diagnostic (runner created with SVOSLAM_RUNNER_TIMELINE=1 in the environment): HIP-event times in ms of the stage
+ * boundaries of the last call, relative to its first mark: h_ms[frame][10] = {maps begin, maps end, track begin, pose,
+ * prepare begin, plan begin, plan end, commit begin, commit end, march end}.  Blocking. */
+int svoslam_runner_timeline(svoslam_runner *runner, float *h_ms, int32_t max_frames, int32_t *frames);
 int svoslam_runner_run(svoslam_runner *runner, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs,
                        const long long *timestamps, const float *views, int32_t n, uint8_t *d_image, int32_t row_first,
                        int32_t rows, unsigned long long *d_steps, void *caller_stream);

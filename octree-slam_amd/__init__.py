@@ -69,7 +69,6 @@ SIGNATURES = {
     "svoslam_status_string": (C.c_char_p, [C.c_int]),
     "svoslam_last_error": (C.c_char_p, []),
     "svoslam_device_arch": (C.c_char_p, []),
-    "svoslam_kernel_count": (C.c_int, []),
     "svoslam_pool_init": (C.c_int, [C.POINTER(_PoolStruct), _i32, _vp]),
     "svoslam_pool_reserve": (C.c_int, [C.POINTER(_PoolStruct), _i32, _vp]),
     "svoslam_pool_free": (C.c_int, [C.POINTER(_PoolStruct)]),
@@ -78,11 +77,14 @@ SIGNATURES = {
     "svoslam_pool_expand": (C.c_int, [C.POINTER(_PoolStruct), _fp, C.POINTER(_f32), _fp, _vp]),
     "svoslam_camera_reset": (C.c_int, [_vp]),
     "svoslam_pool_save": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _fp, _f32, _i32, _vp]),
+    "svoslam_pool_set_nodes": (C.c_int, [C.POINTER(_PoolStruct), C.POINTER(C.c_uint32), _i32, _vp]),
+    "svoslam_pool_copy": (C.c_int, [C.POINTER(_PoolStruct), C.POINTER(_PoolStruct), _vp]),
     "svoslam_pool_load": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _fp, C.POINTER(_f32), C.POINTER(_i32), _vp]),
     "svoslam_svo_from_point_cloud_async": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _fp, _f32, _vp]),
     "svoslam_svo_fuse_sort": (C.c_int, [_vp, _vp, _i32, _i32, _fp, _f32, _vp]),
     "svoslam_svo_fuse_plan": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_commit": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
+    "svoslam_svo_fuse_commit_to": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _i32, _i32, _vp]),
     "svoslam_frame_reader_open": (C.c_int, [C.POINTER(_vp), C.c_char_p, _f32]),
     "svoslam_frame_reader_close": (C.c_int, [_vp]),
     "svoslam_frame_reader_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
@@ -110,6 +112,7 @@ SIGNATURES = {
     "svoslam_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
     "svoslam_runner_create": (C.c_int, [C.POINTER(_vp), _vp, C.POINTER(_PoolStruct), _i32, _i32, _i32, _fp, _f32, _f32, _f32, _i32]),
     "svoslam_runner_destroy": (C.c_int, [_vp]),
+    "svoslam_runner_timeline": (C.c_int, [_vp, _fp, _i32, C.POINTER(_i32)]),
     "svoslam_runner_run": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_longlong), _fp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "svoslam_scene_create": (C.c_int, [C.POINTER(_vp)]),
     "svoslam_scene_destroy": (C.c_int, [_vp]),
@@ -125,6 +128,7 @@ SIGNATURES = {
     "svoslam_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "svoslam_cone_trace_svo": (C.c_int, [_vp, _i32, _i32, _f32, _fp, _vp, _fp, _f32, _i32, _vp, _vp]),
     "svoslam_cone_trace_svo_band": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _fp, _vp, _fp, _f32, _i32, _vp, _vp]),
+    "svoslam_cone_trace_release": (C.c_int, [_vp, _i32]),
     "svoslam_cone_trace_timing": (C.c_int, [_i32]),
     "svoslam_cone_trace_timing_read": (C.c_int, [_fp, C.POINTER(_i32)]),
     "svoslam_generate_vertex_map": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _f32, _i32, _i32, _vp]),
@@ -163,6 +167,7 @@ SIGNATURES = {
     "svoslam_camera_last_vertex": (_vp, [_vp, _i32]),
     "svoslam_camera_last_normal": (_vp, [_vp, _i32]),
     "svoslam_camera_tracking_lost_count": (C.c_int, [_vp, C.POINTER(_i32), _vp]),
+    "svoslam_camera_latest_timestamp": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(C.c_longlong)]),
     "svoslam_camera_track_profile": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), _vp]),
     "svoslam_timer_start": (C.c_int, [_vp]),
     "svoslam_timer_stop": (C.c_int, [_vp, _fp]),
@@ -275,15 +280,14 @@ class Pool:
         return out
 
     def set_words(self, words):
-        import torch
-        torch.cuda.synchronize()
+        """replace the pool's contents (svoslam_pool_set_nodes: validates child pointers, resets the device-resident size
+        and the reservations of asynchronous fusions, so fusing into the loaded tree allocates after it)"""
         words = np.ascontiguousarray(words, dtype=np.uint32)
-        nodes = words.size // 2
-        self.reserve(nodes)
-        r = _hip().hipMemcpy(C.c_void_p(self.data_ptr), C.c_void_p(words.ctypes.data), C.c_size_t(words.nbytes), 1)
-        if r != 0:
-            raise SvoslamError("hipMemcpy H2D failed: %d" % r)
-        self._p.size = nodes
+        check(lib().svoslam_pool_set_nodes(C.byref(self._p), words.ctypes.data_as(C.POINTER(C.c_uint32)), words.size // 2, _stream()))
+
+    def copy_from(self, other):
+        """become a byte-identical replica of `other` (blocking)"""
+        check(lib().svoslam_pool_copy(C.byref(self._p), C.byref(other._p), _stream()))
 
     def reset(self):
         """empty map (8 zeroed root children), same allocation"""
@@ -361,6 +365,13 @@ def svo_fuse_commit(ws, colors, max_depth, pool):
     """phase 3: splits, leaf blend, mip levels (writes the pool)."""
     n = int(colors.shape[0]) if colors is not None else 0
     check(lib().svoslam_svo_fuse_commit(ws._h, _ptr(colors), n, max_depth, C.byref(pool._p), _stream()))
+
+
+def svo_fuse_commit_to(ws, colors, max_depth, pool, slot, keep_plan):
+    """phase 3 applied to one of several identical replicas of the map (see svoslam.h)"""
+    n = int(colors.shape[0]) if colors is not None else 0
+    check(lib().svoslam_svo_fuse_commit_to(ws._h, _ptr(colors), n, max_depth, C.byref(pool._p), int(slot), 1 if keep_plan else 0,
+                                           _stream()))
 
 
 def svo_from_voxel_grid(ws, centers, colors, max_depth, pool, center, edge_length):
@@ -494,6 +505,13 @@ class Runner:
         vw = np.ascontiguousarray(np.stack([np.asarray(v, np.float32).reshape(16) for v in views]), np.float32)
         check(lib().svoslam_runner_run(self._h, dp, rp, ts, vw.ctypes.data_as(_fp), n, _ptr(image), int(row_first), int(rows),
                                        _ptr(counters), _stream()))
+
+    def timeline(self, max_frames=4096):
+        """[frames, 10] stage times in ms of the last run (SVOSLAM_RUNNER_TIMELINE=1)"""
+        out = np.full((max_frames, 10), -1.0, np.float32)
+        n = _i32(0)
+        check(lib().svoslam_runner_timeline(self._h, out.ctypes.data_as(_fp), max_frames, C.byref(n)))
+        return out[: n.value]
 
     def close(self):
         if self._h:

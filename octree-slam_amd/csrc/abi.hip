@@ -79,8 +79,6 @@ const char *svoslam_last_error(void) { return g_last_error; }
 
 const char *svoslam_device_arch(void) { return ensure_device() == SVOSLAM_OK ? g_arch : nullptr; }
 
-int svoslam_kernel_count(void) { return 33; }
-
 int svoslam_pool_init(svoslam_pool *pool, int32_t capacity_nodes, void *stream) {
   NEED_DEVICE();
   return pool_init(pool, capacity_nodes, S(stream));
@@ -119,6 +117,14 @@ int svoslam_pool_save(svoslam_pool *pool, const char *path, const float center[3
   NEED_DEVICE();
   return pool_save(pool, path, center, edge_length, max_depth, S(stream));
 }
+int svoslam_pool_set_nodes(svoslam_pool *pool, const uint32_t *h_words, int32_t num_nodes, void *stream) {
+  NEED_DEVICE();
+  return pool_set_nodes(pool, h_words, num_nodes, S(stream));
+}
+int svoslam_pool_copy(svoslam_pool *dst, svoslam_pool *src, void *stream) {
+  NEED_DEVICE();
+  return pool_copy(dst, src, S(stream));
+}
 int svoslam_pool_load(svoslam_pool *pool, const char *path, float center[3], float *edge_length, int32_t *max_depth,
                       void *stream) {
   NEED_DEVICE();
@@ -149,6 +155,11 @@ int svoslam_svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int3
                             void *stream) {
   NEED_DEVICE();
   return svo_fuse_commit(ws, d_colors, n, max_depth, pool, S(stream));
+}
+int svoslam_svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, int32_t n, int32_t max_depth, svoslam_pool *pool,
+                               int32_t slot, int32_t keep_plan, void *stream) {
+  NEED_DEVICE();
+  return svo_fuse_commit_to(ws, d_colors, n, max_depth, pool, slot, keep_plan != 0, S(stream));
 }
 
 int svoslam_frame_reader_open(svoslam_frame_reader **reader, const char *association_file, float depth_units_per_metre) {
@@ -295,6 +306,7 @@ int svoslam_cone_trace_svo_band(uint8_t *d_pos, int32_t width, int32_t height, i
   return cone_trace_svo(d_pos, width, height, row_first, rows, fov, view, d_octree, center, size, mode, d_steps, S(stream));
 }
 
+int svoslam_cone_trace_release(void *stream, int32_t all_streams) { return cone_trace_release(S(stream), all_streams != 0); }
 int svoslam_cone_trace_timing(int32_t enable) { return cone_trace_timing(enable); }
 int svoslam_cone_trace_timing_read(float *h_ms_sum, int32_t *h_launches) {
   int n = 0;
@@ -433,6 +445,9 @@ int svoslam_camera_tracking_lost_count(svoslam_camera *cam, int32_t *count, void
   return camera_tracking_lost_count(cam, count, S(stream));
 }
 
+int svoslam_camera_latest_timestamp(svoslam_camera *cam, int32_t *have, long long *timestamp) {
+  return camera_latest_timestamp(cam, have, timestamp);
+}
 int svoslam_camera_track_profile(svoslam_camera *cam, unsigned long long *h_stamps, void *stream) {
   return camera_track_profile(cam, h_stamps, S(stream));
 }

@@ -20,6 +20,9 @@
 //      where the reference's walk stops and the colour word it ends on ("level grid");
 //  (3) the per-step arithmetic is one division and one square root (see step_lod / loop notes).
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "cone_trace.hpp"
@@ -472,11 +475,13 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
 }
 
 // ---- optional HIP-event timing of the trace kernel alone (bench.py roofline) ----
+static std::mutex g_timing_mu;        // renders may be enqueued from several host threads / on several streams
 static bool g_timing = false;
 static std::vector<hipEvent_t> g_ev;  // pairs (start, stop), one per traced launch since the last read
 static size_t g_ev_used = 0;
 
 int cone_trace_timing(int enable) {
+  std::lock_guard<std::mutex> lock(g_timing_mu);
   g_timing = enable != 0;
   g_ev_used = 0;
   return SVOSLAM_OK;
@@ -484,6 +489,7 @@ int cone_trace_timing(int enable) {
 
 int cone_trace_timing_read(float *ms_sum, int *launches) {
   if (!ms_sum || !launches) return SVOSLAM_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(g_timing_mu);
   float total = 0.0f;
   for (size_t i = 0; i + 1 < g_ev_used; i += 2) {
     SVO_HIP(hipEventSynchronize(g_ev[i + 1]));
@@ -498,6 +504,7 @@ int cone_trace_timing_read(float *ms_sum, int *launches) {
 }
 
 static int timing_event(hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_timing_mu);
   if (!g_timing) return SVOSLAM_OK;
   if (g_ev_used == g_ev.size()) {
     hipEvent_t e;
@@ -517,6 +524,31 @@ static unsigned xcd_mapping(TraceParams &P, int tiles_x, int tiles_y) {
   }
   P.xcd_w = 0; P.xcd_h = tiles_x;
   return (unsigned)(tiles_x * tiles_y);
+}
+
+// ---- per-stream acceleration buffers ----
+static std::mutex g_accel_mu;
+static std::map<hipStream_t, std::unique_ptr<DeviceBuffer>> g_accel;
+
+static int accel_for_stream(hipStream_t stream, DeviceBuffer **out) {
+  std::lock_guard<std::mutex> lock(g_accel_mu);
+  auto it = g_accel.find(stream);
+  if (it == g_accel.end()) it = g_accel.emplace(stream, std::unique_ptr<DeviceBuffer>(new DeviceBuffer())).first;
+  *out = it->second.get();
+  return SVOSLAM_OK;
+}
+
+// frees the acceleration buffer of one stream (nullptr: of every stream); the caller has synchronised the stream(s)
+int cone_trace_release(hipStream_t stream, bool all) {
+  std::lock_guard<std::mutex> lock(g_accel_mu);
+  if (all) {
+    for (auto &kv : g_accel) kv.second->release();
+    g_accel.clear();
+  } else {
+    auto it = g_accel.find(stream);
+    if (it != g_accel.end()) { it->second->release(); g_accel.erase(it); }
+  }
+  return SVOSLAM_OK;
 }
 
 // ---- host side: glm::inverse(view) products of :161-167, pix_scale of :171 ----
@@ -563,7 +595,13 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
       P.lod_span = 0u;
     }
   }
-  static DeviceBuffer accel;  // grid 16.8 / 134 MB + tables 0.9 MB, library-owned (calls from several host threads must be serialised)
+  // Acceleration data of the render (grid 16.8 / 134 MB + tables 0.9 MB): one buffer PER STREAM, owned by the library.
+  // Renders on one stream are ordered by the stream and may share it; renders on different streams (two pools, two
+  // pipelines, a user stream next to the runner's) each get their own, so none rebuilds a grid another is marching
+  // through.  The map is guarded for calls from several host threads.  Buffers live until svoslam_cone_trace_release().
+  DeviceBuffer *accel_ptr = nullptr;
+  SVO_TRY(accel_for_stream(stream, &accel_ptr));
+  DeviceBuffer &accel = *accel_ptr;
 #ifdef SVO_FORCE_GRID8
   const bool large = true;
 #else

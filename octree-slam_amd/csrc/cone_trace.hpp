@@ -10,4 +10,6 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
 // HIP-event timing of the trace kernel alone, on the stream it is launched on (roofline measurement)
 int cone_trace_timing(int enable);
 int cone_trace_timing_read(float *ms_sum, int *launches);  // blocking; resets the log
+// frees the per-stream acceleration buffer(s); the caller has synchronised the stream(s)
+int cone_trace_release(hipStream_t stream, bool all);
 }  // namespace svoslam

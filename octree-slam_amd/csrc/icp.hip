@@ -580,6 +580,13 @@ static bool track_chain_forced() {
   return on;
 }
 
+static bool track_one_launch_forced() {
+  static const bool on = [] { const char *e = getenv("SVOSLAM_TRACK_ONE_LAUNCH"); return e && e[0] == '1'; }();
+  return on;
+}
+
+// > 0: the image is too large for the register-resident form (1920x1080: 16 pixels per lane at the finest level, which
+// would be re-read from HBM every iteration inside the one launch: measured 525 frames/s against 718 with the chain)
 static int track_one_launch(svoslam_camera *c, hipStream_t s) {
   TrackArgs A;
   for (int level = 0; level < 3; level++) {
@@ -595,6 +602,7 @@ static int track_one_launch(svoslam_camera *c, hipStream_t s) {
     c->cap_stream = s;
   }
   SVO_TRY(track_persistent_plan(A, c->capacity));
+  if (A.slots[0] > kTrkSlots && !track_one_launch_forced()) return 1;  // caller falls back to the launch chain
   return track_persistent_launch(c->d_state, c->d_sync, c->d_tickets, c->d_rows, A, s);
 }
 
@@ -604,11 +612,14 @@ int camera_track(svoslam_camera *c, hipStream_t s) {
   const bool has_icp = c->tracked >= 1;
   const int ring_slot = (int)(c->tracked & 3u);
   if (has_icp && !track_chain_forced()) {
-    SVO_TRY(track_one_launch(c, s));
-    c->ring_slot = ring_slot;
-    c->tracked++;
-    c->frame_has_icp = false;
-    return SVOSLAM_OK;
+    const int rc = track_one_launch(c, s);
+    if (rc < 0) return rc;
+    if (rc == 0) {
+      c->ring_slot = ring_slot;
+      c->tracked++;
+      c->frame_has_icp = false;
+      return SVOSLAM_OK;
+    }
   }
   GraphKey key;
   key.add((unsigned long long)(c->tracked % 3u)).add((unsigned long long)has_icp)
@@ -708,6 +719,13 @@ const float *camera_last_vertex(svoslam_camera *c, int level) {
 const float *camera_last_normal(svoslam_camera *c, int level) {
   return (c && level >= 0 && level < 3) ? c->norm[(c->tracked + 2u) % 3u][level] : nullptr;
 }
+int camera_latest_timestamp(svoslam_camera *c, int32_t *have, long long *timestamp) {
+  if (!c || !have || !timestamp) return SVOSLAM_ERR_INVALID_ARG;
+  *have = c->have_stamp ? 1 : 0;
+  *timestamp = c->latest_stamp;
+  return SVOSLAM_OK;
+}
+
 int camera_track_profile(svoslam_camera *c, unsigned long long *h_stamps, hipStream_t s) {
   if (!c || !h_stamps) return SVOSLAM_ERR_INVALID_ARG;
   return track_persistent_profile(c->d_sync, h_stamps, s);

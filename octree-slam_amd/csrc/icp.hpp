@@ -32,5 +32,6 @@ const float *camera_fusion_transform_device(svoslam_camera *c);
 const float *camera_last_vertex(svoslam_camera *c, int level);
 const float *camera_last_normal(svoslam_camera *c, int level);
 int camera_tracking_lost_count(svoslam_camera *c, int *count, hipStream_t s);
+int camera_latest_timestamp(svoslam_camera *c, int32_t *have, long long *timestamp);
 int camera_track_profile(svoslam_camera *c, unsigned long long *h_stamps, hipStream_t s);
 }  // namespace svoslam

@@ -510,6 +510,22 @@ int mesh_load_obj(const char *path, svoslam_mesh *out) {
       zmax = q[2] > zmax ? q[2] : zmax; zmin = q[2] < zmin ? q[2] : zmin;
     }
   }
+  // The reference's loader indexes points / texture coordinates with whatever the file says (objloader.cpp: negative,
+  // zero or too large indices and faces of fewer than three corners read out of bounds).  Behind a public C ABI that
+  // takes a caller-supplied path such a file is refused instead: every index must name an existing element, a face
+  // needs three corners, and a file that textures some faces must texture all of them (tstart is per face).
+  const int ntcs = (int)tcs.size() / 4;
+  for (int k = 0; k < nfaces; k++)
+    if (fstart[k + 1] - fstart[k] < 3) return SVOSLAM_ERR_FORMAT;
+  for (int v : fidx)
+    if (v < 0 || v >= npts) return SVOSLAM_ERR_FORMAT;
+  if (have_tex_faces) {
+    if ((int)tstart.size() != nfaces + 1) return SVOSLAM_ERR_FORMAT;
+    for (int k = 0; k < nfaces; k++)
+      if (tstart[k + 1] - tstart[k] < 3) return SVOSLAM_ERR_FORMAT;
+    for (int v : tidx)
+      if (v < 0 || v >= ntcs) return SVOSLAM_ERR_FORMAT;
+  }
   std::vector<float> V, T;
   const bool has_texture = have_tex_faces && tstart.size() > 1;
   for (int k = 0; k < nfaces; k++) {  // obj::buildVBOs, obj.cpp:33-110
@@ -559,8 +575,8 @@ int texture_load_bmp(const char *path, svoslam_texture *out) {
   const size_t size = (size_t)3 * w * h;
   std::vector<unsigned char> raw(size, 0);
   const size_t got = fread(raw.data(), 1, size, f);
-  (void)got;
   fclose(f);
+  if (got != size) return SVOSLAM_ERR_FORMAT;  // truncated file (the reference would use a partly uninitialised texture)
   out->data = (float *)malloc(sizeof(float) * size);
   for (size_t i = 0; i < size; i += 3) {
     out->data[i] = (int)raw[i + 2] / 255.0f;

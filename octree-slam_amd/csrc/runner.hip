@@ -1,42 +1,74 @@
 // runner.hip -- native frame scheduler of the SLAM loop (main.cpp:31-84 per frame: track -> back-project ->
-// fuse -> raycast), software-pipelined over four HIP streams:
+// fuse -> raycast), software-pipelined over HIP streams:
 //
-//   P  bilateral filter + vertex/normal pyramids of frame k+2 (three rotating map sets in the camera)
-//   T  19 ICP iterations of frame k+1; touches only the camera state
-//   S  back-projection, keys + sort and split planning of frame k+1 (reads the pool's tree)
-//   M  commit of frame k (splits, leaf blend, mip levels -- the only writer of the pool), raycast of frame k
+//   P   bilateral filter + vertex/normal pyramids of frame k+2 (three rotating map sets in the camera)
+//   T   the ICP iterations of frame k+1 (one launch); touches only the camera state
+//   S   back-projection, keys + sort and split planning of frame k+1 (reads a pool's tree)
+//   M0  commits to replica 0 of the map, raycasts of the even frames
+//   M1  commits to replica 1 of the map, raycasts of the odd frames
 //
-// Cross-stream order (events): S waits for the pose of its frame (from T) and, before planning, for the commit
-// of the previous frame (from M); M waits for the plan of its frame; T waits, before it overwrites a slot of the
-// 4-deep pose ring, for the back-projection that read that slot; P waits for the pose of frame k-2 (whose "last"
-// map set it overwrites).  The same schedule as octree-slam_amd/pipeline.py::SlamPipeline.run_stream, which it
-// replaces on the hot path: the Python loop needed 0.45 ms of host time per frame -- the whole frame time --
-// for ~25 calls; here a frame costs the host about ten graph launches and a dozen event operations.
+// Two replicas of the map.  A frame's raycast (~0.3 ms: bound by the dependent-load latency of its longest rays, not by
+// CUs) and the next frame's commit cannot touch one pool at the same time, and with one pool their sum is the frame
+// period.  The scheduler therefore keeps a second, byte-identical replica of the caller's pool: every plan is applied
+// to both (svoslam_svo_fuse_commit_to -- the commit is a deterministic function of plan + pool, so the replicas stay
+// identical), and the frames are ray-marched on them alternately.  While frame k is marched on replica k & 1 the
+// commits of frames k+1 and k+2 go to the other one, so each replica carries two commits and one raycast per TWO
+// frames.  Cost: the commit kernels run twice and the map takes twice the HBM (a few GB of 288).
+// MEASURED (round 2, cfg3, profiles/r02_runner_timeline_*.txt): with ONE replica the M stream bounds the frame at
+// commit 0.133 ms + build/march 0.272 ms = 0.405 ms; with TWO the replica streams do overlap but every kernel gets
+// slower -- march 0.27 -> 0.41 ms, commit 0.13 -> 0.22-0.29 ms, maps 0.10 -> 0.37 ms -- because the march keeps
+// ~4800 wavefronts (66 % of the VGPR file) resident for its whole duration and the tracker's 151 workgroups want
+// the other half: 0.52-0.55 ms per frame against 0.41-0.43.  The schedule is therefore OPT-IN (SVOSLAM_RUNNER_REPLICAS=2;
+// it is also the single-GPU form of pipelining the stages over several GPUs, where each replica has a GPU to itself);
+// the default is one pool.
+//
+// Cross-stream order (events): S waits for the pose of its frame (from T) and, before planning, for commit k-1 on the
+// replica it reads; an M stream waits for the plan of the frame it commits; T waits, before it overwrites a slot of
+// the 4-deep pose ring, for the back-projection that read that slot; P waits for the pose of frame k-2 (whose "last"
+// map set it overwrites); S waits, before it reuses a workspace / point buffer / colour staging buffer (rings of three),
+// for both commits of the frame that used them.  Results are those of calling the stages one after the other.
 //
 // Built on the public C ABI (include/svoslam.h) only: every stage is the call a reference-style host would make.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
 #include "common.hpp"
 #include "../../include/svoslam.h"
 
+namespace {
+constexpr int kRing = 3;  // frames whose fusion may be in flight: workspaces, point clouds, colour staging
+}
+
 struct svoslam_runner {
   svoslam_camera *cam = nullptr;
-  svoslam_pool *pool = nullptr;
+  svoslam_pool *pool = nullptr;     // replica 0: the caller's pool
+  svoslam_pool replica1;            // replica 1 (owned); d_data == nullptr while unused
+  int replicas = 1;
   int w = 0, h = 0, depth = 0, mode = 0;
   float center[3] = {0, 0, 0}, edge = 0, fx = 0, fy = 0, fov = 45.0f;
-  hipStream_t s_maps = nullptr, s_track = nullptr, s_prep = nullptr, s_map = nullptr;
-  svoslam_workspace *ws[2] = {nullptr, nullptr};
-  float *points[2] = {nullptr, nullptr};  // back-projected clouds of the two frames in flight
-  float *bbox = nullptr;                  // 7 floats (main.cpp:44)
+  hipStream_t s_maps = nullptr, s_track = nullptr, s_prep = nullptr, s_map[2] = {nullptr, nullptr};
+  svoslam_workspace *ws[kRing] = {nullptr, nullptr, nullptr};
+  float *points[kRing] = {nullptr, nullptr, nullptr};  // back-projected clouds of the frames in flight
+  uint8_t *in_rgb[kRing] = {nullptr, nullptr, nullptr};
+  float *bbox = nullptr;                   // 7 floats (main.cpp:44)
+  uint8_t *scratch_image[2] = {nullptr, nullptr};  // raycasts of all but the last frame of a call
   // fixed input addresses per stream: the library replays its launch sequences as HIP graphs keyed on the
   // pointers it is given (graph_cache.hpp), so every frame is copied into a staging buffer first
   uint16_t *in_track = nullptr, *in_prep = nullptr;
-  uint8_t *in_rgb = nullptr;
   std::vector<hipEvent_t> events;  // pool, grown on demand
-  hipEvent_t ev_begin = nullptr, ev_end[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_begin = nullptr, ev_end[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipStream_t last_caller = nullptr;
+  bool ran = false;
+  // SVOSLAM_RUNNER_TIMELINE=1: timing events at the stage boundaries of the last call (svoslam_runner_timeline)
+  bool timeline = false;
+  std::vector<hipEvent_t> tl_events;
+  int tl_frames = 0;
 };
+
+namespace { constexpr int kTlStages = 10; }  // maps0 maps1 track0 track1 prep0 plan0 plan1 commit0 commit1(first replica) ray1
 
 namespace {
 
@@ -49,6 +81,8 @@ int ensure_events(svoslam_runner *r, size_t n) {
   return SVOSLAM_OK;
 }
 
+svoslam_pool *replica(svoslam_runner *r, int k) { return k == 0 ? r->pool : &r->replica1; }
+
 }  // namespace
 
 extern "C" {
@@ -58,23 +92,30 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
   if (!out || !cam || !pool || !center || width <= 0 || height <= 0) return SVOSLAM_ERR_INVALID_ARG;
   if (max_depth < 1 || max_depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
   svoslam_runner *r = new svoslam_runner();
+  memset(&r->replica1, 0, sizeof(r->replica1));
   r->cam = cam; r->pool = pool; r->w = width; r->h = height; r->depth = max_depth; r->mode = render_mode;
   for (int k = 0; k < 3; k++) r->center[k] = center[k];
   r->edge = edge_length; r->fx = fx; r->fy = fy;
+  const char *e = getenv("SVOSLAM_RUNNER_REPLICAS");
+  r->replicas = (e && e[0] == '2') ? 2 : 1;
+  const char *tl = getenv("SVOSLAM_RUNNER_TIMELINE");
+  r->timeline = tl && tl[0] == '1';
   *out = r;
   const size_t n = (size_t)width * height;
-  for (hipStream_t *s : {&r->s_maps, &r->s_track, &r->s_prep, &r->s_map}) SVO_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
-  for (int k = 0; k < 2; k++) {
+  for (hipStream_t *s : {&r->s_maps, &r->s_track, &r->s_prep, &r->s_map[0], &r->s_map[1]})
+    SVO_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+  for (int k = 0; k < kRing; k++) {
     SVO_TRY(svoslam_workspace_create(&r->ws[k]));
     SVO_HIP(hipMalloc((void **)&r->points[k], n * 12));
+    SVO_HIP(hipMalloc((void **)&r->in_rgb[k], n * 3));
   }
+  for (int k = 0; k < 2; k++) SVO_HIP(hipMalloc((void **)&r->scratch_image[k], n * 4));
   SVO_HIP(hipMalloc((void **)&r->bbox, 7 * 4));
   SVO_HIP(hipMemset(r->bbox, 0, 7 * 4));
   SVO_HIP(hipMalloc((void **)&r->in_track, n * 2));
   SVO_HIP(hipMalloc((void **)&r->in_prep, n * 2));
-  SVO_HIP(hipMalloc((void **)&r->in_rgb, n * 3));
   SVO_HIP(hipEventCreateWithFlags(&r->ev_begin, hipEventDisableTiming));
-  for (int k = 0; k < 4; k++) SVO_HIP(hipEventCreateWithFlags(&r->ev_end[k], hipEventDisableTiming));
+  for (int k = 0; k < 5; k++) SVO_HIP(hipEventCreateWithFlags(&r->ev_end[k], hipEventDisableTiming));
   return SVOSLAM_OK;
 }
 
@@ -82,91 +123,185 @@ int svoslam_runner_destroy(svoslam_runner *r) {
   if (!r) return SVOSLAM_OK;
   (void)hipDeviceSynchronize();
   for (hipEvent_t e : r->events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : r->tl_events) (void)hipEventDestroy(e);
   if (r->ev_begin) (void)hipEventDestroy(r->ev_begin);
-  for (int k = 0; k < 4; k++) if (r->ev_end[k]) (void)hipEventDestroy(r->ev_end[k]);
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < 5; k++) if (r->ev_end[k]) (void)hipEventDestroy(r->ev_end[k]);
+  for (int k = 0; k < kRing; k++) {
     if (r->ws[k]) svoslam_workspace_destroy(r->ws[k]);
     (void)hipFree(r->points[k]);
+    (void)hipFree(r->in_rgb[k]);
   }
-  (void)hipFree(r->bbox); (void)hipFree(r->in_track); (void)hipFree(r->in_prep); (void)hipFree(r->in_rgb);
-  for (hipStream_t s : {r->s_maps, r->s_track, r->s_prep, r->s_map}) if (s) (void)hipStreamDestroy(s);
+  for (int k = 0; k < 2; k++) (void)hipFree(r->scratch_image[k]);
+  (void)hipFree(r->bbox); (void)hipFree(r->in_track); (void)hipFree(r->in_prep);
+  for (hipStream_t s : {r->s_maps, r->s_track, r->s_prep, r->s_map[0], r->s_map[1]})
+    if (s) { (void)svoslam_cone_trace_release(s, 0); (void)hipStreamDestroy(s); }
+  if (r->replica1.d_data) (void)svoslam_pool_free(&r->replica1);
   delete r;
   return SVOSLAM_OK;
 }
 
-// Enqueues n frames (device-resident depth u16 / RGB888 images, strictly increasing timestamps, one view matrix
-// per frame for the raycast) and returns without waiting.  Work starts after everything already queued on
-// caller_stream and caller_stream is made to wait for all of it: the caller synchronises that stream (or the
-// device) to read d_image -- rows [row_first, row_first + rows) of the LAST frame's raycast -- the pool and the pose.
+// Enqueues n frames (device-resident depth u16 / RGB888 images, strictly increasing timestamps newer than any the
+// camera has seen, one view matrix per frame for the raycast) and returns without waiting for them.  Work starts after
+// everything already queued on caller_stream and caller_stream is made to wait for all of it: the caller synchronises
+// that stream (or the device) to read d_image -- rows [row_first, row_first + rows) of the LAST frame's raycast (the
+// earlier frames of the call are marched into internal buffers) -- the pool and the pose.
 // d_steps (optional): 2 x u64 step / level counters accumulated over all raycasts.
+// All arguments are validated BEFORE anything is enqueued; if a stage fails later, the streams are still joined to
+// caller_stream before the error is returned.  Calls on one runner must use one caller_stream (checked).  With two
+// replicas the call first brings replica 1 up to date with the caller's pool (blocking device copy).
 int svoslam_runner_run(svoslam_runner *r, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs, const long long *timestamps,
                        const float *views, int32_t n, uint8_t *d_image, int32_t row_first, int32_t rows,
                        unsigned long long *d_steps, void *caller_stream) {
   if (!r || n < 0 || (n > 0 && (!d_depths || !d_rgbs || !timestamps || !views || !d_image))) return SVOSLAM_ERR_INVALID_ARG;
   if (n == 0) return SVOSLAM_OK;
+  if (row_first < 0 || rows < 0 || row_first + rows > r->h) return SVOSLAM_ERR_INVALID_ARG;
   hipStream_t cur = reinterpret_cast<hipStream_t>(caller_stream);
+  if (r->ran && cur != r->last_caller) return SVOSLAM_ERR_INVALID_ARG;  // the join below orders calls on ONE caller stream only
+  {  // timestamps: strictly increasing and newer than the camera's latest (a stale frame would be skipped mid-pipeline)
+    int32_t have = 0; long long latest = 0;
+    SVO_TRY(svoslam_camera_latest_timestamp(r->cam, &have, &latest));
+    for (int i = 0; i < n; i++) {
+      if (!d_depths[i] || !d_rgbs[i]) return SVOSLAM_ERR_INVALID_ARG;
+      if ((i == 0 && have && timestamps[0] <= latest) || (i > 0 && timestamps[i] <= timestamps[i - 1])) return SVOSLAM_ERR_INVALID_ARG;
+    }
+  }
   const size_t px = (size_t)r->w * r->h;
   const int npts = (int)px;
-  // events of this call: pose, back-projection, plan, commit, maps of every frame
-  SVO_TRY(ensure_events(r, 5 * (size_t)n));
-  hipEvent_t *ev_pose = r->events.data(), *ev_bp = ev_pose + n, *ev_plan = ev_bp + n, *ev_commit = ev_plan + n, *ev_maps = ev_commit + n;
+  const int R = r->replicas;
+  if (R == 2) {
+    // replica 1 := the caller's pool as it is now (the caller may have fused, loaded or reset it since the last call)
+    SVO_HIP(hipStreamSynchronize(cur));
+    const int rc = svoslam_pool_copy(&r->replica1, r->pool, cur);
+    if (rc != SVOSLAM_OK) return rc;
+  }
+  // events of this call: maps, pose, back-projection, plan of every frame; commit of every frame on every replica
+  SVO_TRY(ensure_events(r, 7 * (size_t)n));
+  hipEvent_t *ev_maps = r->events.data(), *ev_pose = ev_maps + n, *ev_bp = ev_pose + n, *ev_plan = ev_bp + n;
+  hipEvent_t *ev_commit[2] = {ev_plan + n, ev_plan + 2 * (size_t)n};
+  hipEvent_t *ev_ray = ev_plan + 3 * (size_t)n;
+  static const bool serial_marches = [] { const char *e = getenv("SVOSLAM_RUNNER_CONCURRENT_MARCHES"); return !(e && e[0] == '1'); }();
   std::vector<const float *> fusion_ptr((size_t)n, nullptr);
+  r->ran = true; r->last_caller = cur;
+  if (r->timeline) {
+    while (r->tl_events.size() < (size_t)kTlStages * n) {
+      hipEvent_t e;
+      SVO_HIP(hipEventCreate(&e));
+      r->tl_events.push_back(e);
+    }
+    r->tl_frames = n;
+  }
+  auto mark = [&](int i, int stage, hipStream_t s) { if (r->timeline) (void)hipEventRecord(r->tl_events[(size_t)i * kTlStages + stage], s); };
   SVO_HIP(hipEventRecord(r->ev_begin, cur));
-  for (hipStream_t s : {r->s_maps, r->s_track, r->s_prep, r->s_map}) SVO_HIP(hipStreamWaitEvent(s, r->ev_begin, 0));
+  hipStream_t all[5] = {r->s_maps, r->s_track, r->s_prep, r->s_map[0], r->s_map[1]};
+  for (hipStream_t s : all) SVO_HIP(hipStreamWaitEvent(s, r->ev_begin, 0));
 
   auto enqueue_maps = [&](int i) -> int {  // bilateral filter + pyramids of frame i (no dependence on earlier poses)
     if (i >= 2) SVO_HIP(hipStreamWaitEvent(r->s_maps, ev_pose[i - 2], 0));  // its map set was the "last" set of frame i-2
+    mark(i, 0, r->s_maps);
     SVO_HIP(hipMemcpyAsync(r->in_track, d_depths[i], px * 2, hipMemcpyDeviceToDevice, r->s_maps));
     int32_t used = 0;
     SVO_TRY(svoslam_camera_prepare(r->cam, r->in_track, d_rgbs[i], timestamps[i], &used, r->s_maps));
-    if (!used) return SVOSLAM_ERR_INVALID_ARG;  // timestamps must increase strictly
+    if (!used) return SVOSLAM_ERR_INVALID_ARG;  // cannot happen after the validation above
     SVO_HIP(hipEventRecord(ev_maps[i], r->s_maps));
+    mark(i, 1, r->s_maps);
     return SVOSLAM_OK;
   };
   auto enqueue_track = [&](int i) -> int {
     if (i >= 4) SVO_HIP(hipStreamWaitEvent(r->s_track, ev_bp[i - 4], 0));  // ring slot i % 4 has been consumed
     SVO_HIP(hipStreamWaitEvent(r->s_track, ev_maps[i], 0));
+    mark(i, 2, r->s_track);
     SVO_TRY(svoslam_camera_track(r->cam, r->s_track));
     fusion_ptr[i] = svoslam_camera_fusion_transform_device(r->cam);  // ring slot of frame i
     SVO_HIP(hipEventRecord(ev_pose[i], r->s_track));
+    mark(i, 3, r->s_track);
     return SVOSLAM_OK;
   };
   auto enqueue_prepare = [&](int i) -> int {
-    svoslam_workspace *ws = r->ws[i & 1];
-    float *pts = r->points[i & 1];
+    svoslam_workspace *ws = r->ws[i % kRing];
+    float *pts = r->points[i % kRing];
     SVO_HIP(hipStreamWaitEvent(r->s_prep, ev_pose[i], 0));
+    if (i >= kRing)  // the ring slot's previous user: both of its commits are done with workspace, points and colours
+      for (int k = 0; k < R; k++) SVO_HIP(hipStreamWaitEvent(r->s_prep, ev_commit[k][i - kRing], 0));
+    mark(i, 4, r->s_prep);
     SVO_HIP(hipMemcpyAsync(r->in_prep, d_depths[i], px * 2, hipMemcpyDeviceToDevice, r->s_prep));
+    SVO_HIP(hipMemcpyAsync(r->in_rgb[i % kRing], d_rgbs[i], px * 3, hipMemcpyDeviceToDevice, r->s_prep));
     SVO_TRY(svoslam_generate_vertex_map(r->in_prep, pts, r->w, r->h, r->fx, r->fy, r->w, r->h, r->s_prep));  // main.cpp:39
     SVO_TRY(svoslam_transform_vertex_map_dmat(pts, fusion_ptr[i], npts, r->s_prep));                         // main.cpp:40-41
     SVO_TRY(svoslam_point_cloud_bbox_device(r->ws[0], pts, npts, r->bbox, r->s_prep));                       // main.cpp:44
     SVO_HIP(hipEventRecord(ev_bp[i], r->s_prep));
     SVO_TRY(svoslam_svo_fuse_sort(ws, pts, npts, r->depth, r->center, r->edge, r->s_prep));
-    if (i > 0) SVO_HIP(hipStreamWaitEvent(r->s_prep, ev_commit[i - 1], 0));  // the tree the plan reads
-    SVO_TRY(svoslam_svo_fuse_plan(ws, npts, r->depth, r->pool, r->s_prep));
+    // the plan reads the replica that receives commit i-1 FIRST (the one frame i-1 is marched on); the march only reads
+    const int src = i > 0 ? ((i - 1) & (R - 1)) : 0;
+    if (i > 0) SVO_HIP(hipStreamWaitEvent(r->s_prep, ev_commit[src][i - 1], 0));
+    mark(i, 5, r->s_prep);
+    svoslam_pool *planned = replica(r, src);
+    const int32_t cap_before = planned->capacity;
+    SVO_TRY(svoslam_svo_fuse_plan(ws, npts, r->depth, planned, r->s_prep));
+    if (R == 2 && planned->capacity != cap_before) {
+      // the plan had to grow its replica (it waited for the whole device to do so): the other one follows
+      svoslam_pool *other = replica(r, src ^ 1);
+      SVO_HIP(hipDeviceSynchronize());
+      SVO_TRY(svoslam_pool_reserve(other, planned->capacity, r->s_prep));
+    }
     SVO_HIP(hipEventRecord(ev_plan[i], r->s_prep));
+    mark(i, 6, r->s_prep);
     return SVOSLAM_OK;
   };
+  auto enqueue_commit = [&](int i, int k, bool last) -> int {
+    SVO_HIP(hipStreamWaitEvent(r->s_map[k], ev_plan[i], 0));
+    if (k == (i & (R - 1))) mark(i, 7, r->s_map[k]);
+    SVO_TRY(svoslam_svo_fuse_commit_to(r->ws[i % kRing], r->in_rgb[i % kRing], npts, r->depth, replica(r, k), k, last ? 0 : 1, r->s_map[k]));
+    SVO_HIP(hipEventRecord(ev_commit[k][i], r->s_map[k]));
+    if (k == (i & (R - 1))) mark(i, 8, r->s_map[k]);
+    return SVOSLAM_OK;
+  };
+  auto enqueue_all = [&]() -> int {
+    SVO_TRY(enqueue_maps(0));
+    SVO_TRY(enqueue_track(0));
+    if (n > 1) SVO_TRY(enqueue_maps(1));
+    SVO_TRY(enqueue_prepare(0));
+    for (int i = 0; i < n; i++) {
+      if (i + 1 < n) SVO_TRY(enqueue_track(i + 1));
+      if (i + 2 < n) SVO_TRY(enqueue_maps(i + 2));
+      const int a = i & (R - 1);  // the replica frame i is marched on: it gets commit i first
+      SVO_TRY(enqueue_commit(i, a, R == 1));
+      if (i + 1 < n) SVO_TRY(enqueue_prepare(i + 1));  // host order: after ev_commit[a][i] has been recorded
+      // one march at a time: two of them (1200 workgroups) leave no CU for the tracker's and the fusion's workgroups
+      if (R == 2 && serial_marches && i > 0) SVO_HIP(hipStreamWaitEvent(r->s_map[a], ev_ray[i - 1], 0));
+      uint8_t *img = (i == n - 1) ? d_image : r->scratch_image[a];
+      SVO_TRY(svoslam_cone_trace_svo_band(img, r->w, r->h, row_first, rows, r->fov, views + 16 * (size_t)i, replica(r, a)->d_data,
+                                          r->center, r->edge, r->mode, d_steps, r->s_map[a]));
+      SVO_HIP(hipEventRecord(ev_ray[i], r->s_map[a]));
+      mark(i, 9, r->s_map[a]);
+      if (R == 2) SVO_TRY(enqueue_commit(i, a ^ 1, true));  // behind the march of frame i-1 on that replica
+    }
+    return SVOSLAM_OK;
+  };
+  const int rc = enqueue_all();
+  // join, also after an error: whatever was enqueued is ordered before the caller's next work
+  for (int k = 0; k < 5; k++) {
+    if (hipEventRecord(r->ev_end[k], all[k]) == hipSuccess) (void)hipStreamWaitEvent(cur, r->ev_end[k], 0);
+  }
+  if (rc != SVOSLAM_OK) (void)hipDeviceSynchronize();  // leave nothing in flight behind a failed call
+  return rc;
+}
 
-  SVO_TRY(enqueue_maps(0));
-  SVO_TRY(enqueue_track(0));
-  if (n > 1) SVO_TRY(enqueue_maps(1));
-  SVO_TRY(enqueue_prepare(0));
-  for (int i = 0; i < n; i++) {
-    if (i + 1 < n) SVO_TRY(enqueue_track(i + 1));
-    if (i + 2 < n) SVO_TRY(enqueue_maps(i + 2));
-    SVO_HIP(hipStreamWaitEvent(r->s_map, ev_plan[i], 0));
-    SVO_HIP(hipMemcpyAsync(r->in_rgb, d_rgbs[i], px * 3, hipMemcpyDeviceToDevice, r->s_map));
-    SVO_TRY(svoslam_svo_fuse_commit(r->ws[i & 1], r->in_rgb, npts, r->depth, r->pool, r->s_map));
-    SVO_HIP(hipEventRecord(ev_commit[i], r->s_map));
-    if (i + 1 < n) SVO_TRY(enqueue_prepare(i + 1));  // host order: after ev_commit[i] has been recorded
-    SVO_TRY(svoslam_cone_trace_svo_band(d_image, r->w, r->h, row_first, rows, r->fov, views + 16 * (size_t)i, r->pool->d_data,
-                                        r->center, r->edge, r->mode, d_steps, r->s_map));
-  }
-  hipStream_t ss[4] = {r->s_maps, r->s_track, r->s_prep, r->s_map};
-  for (int k = 0; k < 4; k++) {
-    SVO_HIP(hipEventRecord(r->ev_end[k], ss[k]));
-    SVO_HIP(hipStreamWaitEvent(cur, r->ev_end[k], 0));
-  }
+// diagnostic: milliseconds of the stage marks of the last call relative to its first mark, h_ms[frames][10] =
+// {maps begin, maps end, track begin, pose, prepare begin, plan begin, plan end, commit begin, commit end, march end}
+// (-1 where unavailable); needs SVOSLAM_RUNNER_TIMELINE=1 at creation.  Blocking.
+int svoslam_runner_timeline(svoslam_runner *r, float *h_ms, int32_t max_frames, int32_t *frames) {
+  if (!r || !h_ms || !frames) return SVOSLAM_ERR_INVALID_ARG;
+  *frames = 0;
+  if (!r->timeline || r->tl_frames == 0) return SVOSLAM_OK;
+  SVO_HIP(hipDeviceSynchronize());
+  const int n = r->tl_frames < max_frames ? r->tl_frames : max_frames;
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < kTlStages; k++) {
+      float ms = -1.0f;
+      if (hipEventElapsedTime(&ms, r->tl_events[0], r->tl_events[(size_t)i * kTlStages + k]) != hipSuccess) { (void)hipGetLastError(); ms = -1.0f; }
+      h_ms[(size_t)i * kTlStages + k] = ms;
+    }
+  *frames = n;
   return SVOSLAM_OK;
 }
 

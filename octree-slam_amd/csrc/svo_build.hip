@@ -749,6 +749,47 @@ int pool_save(svoslam_pool *pool, const char *path, const float center[3], float
   return (fclose(f) == 0 && ok) ? SVOSLAM_OK : SVOSLAM_ERR_IO;
 }
 
+// Replaces the pool's contents by num_nodes host nodes (a linear tree in the reference format): validates the child
+// pointers, waits for everything in flight, and resets ALL size bookkeeping -- host size, device-resident size,
+// reservations of asynchronous fusions.  Blocking.
+int pool_set_nodes(svoslam_pool *pool, const uint32_t *h_words, int32_t num_nodes, hipStream_t stream) {
+  if (!pool || !h_words || num_nodes < 8 || (num_nodes & 7) != 0) return SVOSLAM_ERR_INVALID_ARG;
+  for (size_t i = 0; i < (size_t)num_nodes; i++) {  // every child tile must lie inside the pool
+    const u32 w0 = h_words[2 * i];
+    if ((w0 & kFlag) && ((w0 & kMask) + 8u > (u32)num_nodes || ((w0 & kMask) & 7u))) return SVOSLAM_ERR_FORMAT;
+  }
+  SVO_HIP(hipDeviceSynchronize());
+  if (!pool->d_data) SVO_TRY(pool_init(pool, num_nodes, stream));
+  SVO_TRY(pool_sync(pool, stream));
+  SVO_TRY(grow_pool(pool, num_nodes, stream));
+  SVO_HIP(hipMemcpy(pool->d_data, h_words, (size_t)num_nodes * 8, hipMemcpyHostToDevice));
+  pool->size = num_nodes;
+  pool->pending = 0; pool->pending_bound = 0;
+  if (pool->d_size) SVO_HIP(hipMemcpy(pool->d_size, &pool->size, 4, hipMemcpyHostToDevice));
+  return SVOSLAM_OK;
+}
+
+// dst becomes a byte-identical replica of src (same nodes, same size, at least the same capacity).  Blocking: waits
+// for the device (either pool may have work in flight on any stream).
+int pool_copy(svoslam_pool *dst, svoslam_pool *src, hipStream_t stream) {
+  if (!dst || !src || dst == src || !src->d_data) return SVOSLAM_ERR_INVALID_ARG;
+  SVO_HIP(hipDeviceSynchronize());
+  SVO_TRY(pool_sync(src, stream));
+  if (!dst->d_data) SVO_TRY(pool_init(dst, src->capacity, stream));
+  SVO_TRY(pool_sync(dst, stream));
+  if (dst->capacity < src->capacity) {
+    dst->size = 0;  // nothing worth copying over to the larger allocation
+    SVO_TRY(grow_pool(dst, src->capacity, stream));
+  }
+  SVO_HIP(hipMemcpy(dst->d_data, src->d_data, (size_t)src->size * 8, hipMemcpyDeviceToDevice));
+  SVO_HIP(hipDeviceSynchronize());
+  dst->size = src->size;
+  dst->pending = 0; dst->pending_bound = 0;
+  SVO_TRY(ensure_device_size(dst, stream));
+  SVO_HIP(hipMemcpy(dst->d_size, &dst->size, 4, hipMemcpyHostToDevice));
+  return SVOSLAM_OK;
+}
+
 int pool_load(svoslam_pool *pool, const char *path, float center[3], float *edge, int *depth, hipStream_t stream) {
   if (!pool || !path) return SVOSLAM_ERR_INVALID_ARG;
   FILE *f = fopen(path, "rb");
@@ -764,18 +805,7 @@ int pool_load(svoslam_pool *pool, const char *path, float center[3], float *edge
   const bool ok = fread(host.data(), 4, words, f) == words;
   fclose(f);
   if (!ok || fnv1a_words(host.data(), words) != h.checksum) return SVOSLAM_ERR_FORMAT;
-  for (size_t i = 0; i < (size_t)h.num_nodes; i++) {  // every child tile must lie inside the pool
-    const u32 w0 = host[2 * i];
-    if ((w0 & kFlag) && ((w0 & kMask) + 8u > (u32)h.num_nodes || ((w0 & kMask) & 7u))) return SVOSLAM_ERR_FORMAT;
-  }
-  SVO_HIP(hipDeviceSynchronize());
-  if (!pool->d_data) SVO_TRY(pool_init(pool, h.num_nodes, stream));
-  SVO_TRY(pool_sync(pool, stream));
-  SVO_TRY(grow_pool(pool, h.num_nodes, stream));
-  SVO_HIP(hipMemcpy(pool->d_data, host.data(), words * 4, hipMemcpyHostToDevice));
-  pool->size = h.num_nodes;
-  pool->pending = 0; pool->pending_bound = 0;
-  if (pool->d_size) SVO_HIP(hipMemcpy(pool->d_size, &pool->size, 4, hipMemcpyHostToDevice));
+  SVO_TRY(pool_set_nodes(pool, host.data(), h.num_nodes, stream));
   if (center) { center[0] = h.center[0]; center[1] = h.center[1]; center[2] = h.center[2]; }
   if (edge) *edge = h.edge_length;
   if (depth) *depth = h.max_depth;
@@ -955,25 +985,40 @@ int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, h
   key.add(skey).add((unsigned long long)n).add((unsigned long long)depth).add(pool->d_data).add(ws->layout_hash());
   SVO_TRY(ws->g_plan.run(key, stream, enqueue));
   ws->planned_n = n;
+  ws->planned_pool = pool;
   pool->pending_bound += 8 * rmax;  // reserved from now on
   return SVOSLAM_OK;
 }
 
-int svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, hipStream_t stream) {
-  if (!ws || !pool || n < 0 || (n > 0 && !d_colors)) return SVOSLAM_ERR_INVALID_ARG;
+// Applies the planned commit to `pool`.  slot / keep_plan serve callers that keep several byte-identical replicas of
+// one map (the frame scheduler ray-marches one replica while the next frame is committed to the other): the same plan
+// -- made against ANY of the replicas in the state before this commit -- is applied to each of them, every
+// application with its own slot (0 or 1: the scratch list of the mip pass) and all but the last with keep_plan.
+int svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, int slot,
+                       bool keep_plan, hipStream_t stream) {
+  if (!ws || !pool || n < 0 || (n > 0 && !d_colors) || slot < 0 || slot > 1) return SVOSLAM_ERR_INVALID_ARG;
   if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
   if (ws->planned_n != n) return SVOSLAM_ERR_INVALID_ARG;  // svo_fuse_plan has not run for this batch
-  ws->planned_n = -1;
+  if (!keep_plan) ws->planned_n = -1;
   if (n == 0) return SVOSLAM_OK;
   const int64_t rmax = max_records(n, depth);
+  if (pool != ws->planned_pool) {  // a replica the plan did not look at: same tree, same worst case, its own bookkeeping
+    SVO_TRY(ensure_device_size(pool, stream));
+    if ((int64_t)pool->size + pool->pending_bound + 8 * rmax > pool->capacity) {
+      SVO_TRY(tracker_poll(pool, true));
+      if ((int64_t)pool->size + pool->pending_bound + 8 * rmax > pool->capacity) return SVOSLAM_ERR_POOL_LIMIT;  // replicas must be reserved alike
+    }
+    pool->pending_bound += 8 * rmax;
+  }
   const u64 *skey = ws->sorted_keys;
   const u32 *sidx = ws->sorted_idx;
   const unsigned char *leaf_t = ws->leaf_t.as<unsigned char>();
   int split_blocks = (int)cdiv(rmax, 256);
   if (split_blocks > 2048) split_blocks = 2048;
   const int fill_tiles = (int)cdiv(n, kFillThreads);
-  SVO_TRY(ws->strad.reserve((size_t)(SVOSLAM_MAX_DEPTH + 1) * (size_t)fill_tiles * 8));
-  u32 *strad = ws->strad.as<u32>();
+  DeviceBuffer &sb = slot == 0 ? ws->strad : ws->strad_b;
+  SVO_TRY(sb.reserve((size_t)(SVOSLAM_MAX_DEPTH + 1) * (size_t)fill_tiles * 8));
+  u32 *strad = sb.as<u32>();
   auto enqueue = [&]() -> int {
     split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
                                                        ws->rec_pass.as<unsigned char>(), small_bucket_base(ws), small_counts(ws),
@@ -985,10 +1030,14 @@ int svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int n, int d
   };
   GraphKey key;
   key.add(skey).add(d_colors).add((unsigned long long)n).add((unsigned long long)depth).add(pool->d_data).add(pool->d_size)
-     .add(ws->layout_hash());
+     .add((unsigned long long)slot).add(ws->layout_hash());
   SVO_TRY(ws->g_commit.run(key, stream, enqueue));
   pool->pending += 1;
   return tracker_push(pool, 8 * rmax, stream);
+}
+
+int svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, hipStream_t stream) {
+  return svo_fuse_commit_to(ws, d_colors, n, depth, pool, 0, false, stream);
 }
 
 int svo_from_point_cloud_async(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,

@@ -11,12 +11,16 @@ int pool_reset(svoslam_pool *pool, hipStream_t stream);
 int pool_expand(svoslam_pool *pool, float center[3], float *edge, const float toward[3], hipStream_t stream);
 void pool_tracker_destroy(svoslam_pool *pool);
 int pool_save(svoslam_pool *pool, const char *path, const float center[3], float edge, int depth, hipStream_t stream);
+int pool_set_nodes(svoslam_pool *pool, const uint32_t *h_words, int32_t num_nodes, hipStream_t stream);
+int pool_copy(svoslam_pool *dst, svoslam_pool *src, hipStream_t stream);
 int pool_load(svoslam_pool *pool, const char *path, float center[3], float *edge, int *depth, hipStream_t stream);
 int svo_from_point_cloud_async(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,
                                svoslam_pool *pool, const float center[3], float edge, hipStream_t stream);
 int svo_fuse_sort(svoslam_workspace *ws, const float *d_points, int n, int depth, const float center[3], float edge,
                   hipStream_t stream);
 int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream);
+int svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, int slot, bool keep_plan,
+                       hipStream_t stream);
 int svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, hipStream_t stream);
 int svo_from_point_cloud(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,
                          svoslam_pool *pool, const float center[3], float edge, svoslam_fuse_stats *stats,

@@ -45,6 +45,7 @@ struct svoslam_workspace {
   svoslam::DeviceBuffer rec_pass;                         // async path: pass of each record
   svoslam::DeviceBuffer path_nodes;                       // [(D-1)][n] node index per owned depth (mip lists)
   svoslam::DeviceBuffer strad;                            // [D][tiles][2] nodes whose leaf run crosses a workgroup (async commit)
+  svoslam::DeviceBuffer strad_b;                          // the same for the commit of the plan to a second replica of the pool
   svoslam::DeviceBuffer bfs_a, bfs_b, bfs_mask, bfs_ptr;  // extraction
   svoslam::DeviceBuffer misc;                             // bbox partials etc.
   svoslam::DeviceBuffer scan_tmp;                         // chunk sums of exclusive_scan_u32
@@ -53,18 +54,19 @@ struct svoslam_workspace {
   const unsigned long long *sorted_keys = nullptr;
   const unsigned int *sorted_idx = nullptr;
   int planned_n = -1;
+  const void *planned_pool = nullptr;                      // the pool svo_fuse_plan read (its reservation is already booked)
   svoslam::GraphCache g_sort, g_plan, g_commit;            // recorded launch sequences of the three phases
   // every buffer address the recorded phases bake in (a reallocation makes a new key)
   unsigned long long layout_hash() const {
     const void *p[] = {keys_a.ptr, keys_b.ptr, vals_a.ptr, vals_b.ptr, tile_hist.ptr, small.ptr, leaf_t.ptr, leaf_f.ptr,
-                       rec_key.ptr, rec_front.ptr, rec_pass.ptr, path_nodes.ptr, strad.ptr};
+                       rec_key.ptr, rec_front.ptr, rec_pass.ptr, path_nodes.ptr, strad.ptr, strad_b.ptr};
     unsigned long long h = 1469598103934665603ull;
     for (const void *q : p) h = (h ^ (unsigned long long)(uintptr_t)q) * 1099511628211ull;
     return h;
   }
   void release_all() {
     keys_a.release(); keys_b.release(); vals_a.release(); vals_b.release(); tile_hist.release(); small.release();
-    leaf_t.release(); leaf_f.release(); rec_key.release(); rec_front.release(); path_nodes.release(); strad.release();
+    leaf_t.release(); leaf_f.release(); rec_key.release(); rec_front.release(); path_nodes.release(); strad.release(); strad_b.release();
     rec_pass.release();
     bfs_a.release(); bfs_b.release(); bfs_mask.release(); bfs_ptr.release(); misc.release(); scan_tmp.release();
     if (h_counts) { (void)hipHostFree(h_counts); h_counts = nullptr; }

@@ -320,3 +320,48 @@ def test_timer_start_stop(env):
     assert ms.value > empty and ms.value > 0.05          # 20 bilateral passes over 2 M pixels
     assert ms.value < 1000.0
     assert L.svoslam_timer_stop(pkg._stream(), None) != 0     # null output pointer is refused
+
+
+def test_one_launch_tracker_streaming_mode_in_subprocess(oracle):
+    """the one-launch tracker's fallback for levels that do not fit the registers (pixels re-read every iteration, chain
+    replayed from LDS) is taken by default only above 640x480-class images, where the launch chain is used instead; forced
+    here (4 workers -> 10 pixels per lane at 160x120) in a child process, against the oracle's poses"""
+    import json
+    import subprocess
+    import sys
+    import os
+    import importlib
+    import svoslam_pkg
+    svoslam_pkg.load()
+    synth = importlib.import_module("octree_slam_amd.synth")
+    w, h, n = 160, 120, 5
+    f = synth.focal_length(w)
+    ocam = oracle.Camera(w, h, f, f)
+    want = []
+    for k in range(n):
+        d, c = synth.render_frame(2 * k, w, h)
+        ocam.update(d.numpy().view(np.uint16), c.numpy(), k)
+        p, o = ocam.pose()
+        want.append([p.view(np.uint32).tolist(), o.view(np.uint32).tolist()])
+    code = r'''
+import sys, json, importlib, numpy as np
+sys.path.insert(0, %r)
+import svoslam_pkg
+pkg = svoslam_pkg.load()
+synth = importlib.import_module("octree_slam_amd.synth")
+w, h, n = 160, 120, 5
+f = synth.focal_length(w)
+cam = pkg.Camera(w, h, f, f)
+out = []
+for k in range(n):
+    d, c = synth.render_frame(2 * k, w, h)      # CPU generator: the frames the parent gave the oracle
+    cam.update(d.cuda(), c.cuda(), k)
+    p, o = cam.pose()
+    out.append([p.view(np.uint32).tolist(), o.view(np.uint32).tolist()])
+print("RESULT" + json.dumps(out))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SVOSLAM_TRACK_ONE_LAUNCH="1", SVOSLAM_TRACK_WORKERS="4")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0]
+    assert json.loads(line[6:]) == want
