@@ -1,0 +1,28 @@
+import sys, os, numpy as np, torch, importlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ["SVOSLAM_RUNNER_TIMELINE"] = "1"
+import svoslam_pkg
+pkg = svoslam_pkg.load()
+synth = importlib.import_module("octree_slam_amd.synth")
+pl = importlib.import_module("octree_slam_amd.pipeline")
+W, H, D, edge = 640, 480, 12, 4.096
+K = 60
+depth, rgb = synth.render_stream(K, W, H, device="cuda")
+views = [pl.ground_truth_view(k, synth) for k in range(K)]
+P = pl.SlamPipeline(W, H, D, (0, 1.5, 0), edge, pool_capacity_nodes=(1 << 30) - 8)
+P.run_stream(depth[:6], rgb[:6], list(range(6)), views[:6]); torch.cuda.synchronize(); P.reset()
+import time
+t0 = time.perf_counter()
+P.run_stream(depth, rgb, list(range(K)), views); torch.cuda.synchronize()
+print("ms/frame %.3f" % ((time.perf_counter() - t0) / K * 1e3))
+tl = P._runner.timeline()
+names = ["maps0", "maps1", "trk0", "pose", "prep0", "plan0", "plan1", "com0", "com1", "ray1"]
+print("frame " + " ".join("%8s" % n for n in names))
+for i in range(40, 46):
+    print("%5d " % i + " ".join("%8.3f" % (tl[i][k] - tl[40][0]) for k in range(10)))
+d = np.diff(tl[20:58, 9]); print("march-end period: mean %.3f ms" % d.mean())
+print("durations (mean, frames 20..58): maps %.3f track %.3f bp+sort %.3f plan %.3f commit %.3f commit->ray end %.3f" % (
+    (tl[20:58,1]-tl[20:58,0]).mean(), (tl[20:58,3]-tl[20:58,2]).mean(), (tl[20:58,5]-tl[20:58,4]).mean(), (tl[20:58,6]-tl[20:58,5]).mean(),
+    (tl[20:58,8]-tl[20:58,7]).mean(), (tl[20:58,9]-tl[20:58,8]).mean()))
+print("waits: pose->prep0 %.3f  plan1->com0 %.3f  ray1(prev)->com0 %.3f" % ((tl[20:58,4]-tl[20:58,3]).mean(), (tl[20:58,7]-tl[20:58,6]).mean(), (tl[21:58,7]-tl[20:57,9]).mean()))
