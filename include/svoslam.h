@@ -93,6 +93,10 @@ int svoslam_pool_expand(svoslam_pool *pool, float center[3], float *edge_length,
  * pool, (re)allocates the pool and returns the root parameters (each may be NULL). */
 int svoslam_pool_save(svoslam_pool *pool, const char *path, const float center[3], float edge_length, int32_t max_depth,
                       void *stream);
+/* Tells the library that the pool's node memory was written behind its back (e.g. a hipMemcpy into pool->d_data):
+ * derived data it keeps per pool -- the level grid of the ray march -- is rebuilt at the next render.  Pools must
+ * otherwise be modified through the library only.  Host state only, no device access. */
+int svoslam_pool_touch(svoslam_pool *pool);
 /* Replaces the pool's contents by num_nodes host nodes (2 words each, reference format; child pointers validated) and
  * resets all size bookkeeping incl. the device-resident size the asynchronous fusion allocates from.  Blocking. */
 int svoslam_pool_set_nodes(svoslam_pool *pool, const uint32_t *h_words, int32_t num_nodes, void *stream);

@@ -77,6 +77,7 @@ SIGNATURES = {
     "svoslam_pool_expand": (C.c_int, [C.POINTER(_PoolStruct), _fp, C.POINTER(_f32), _fp, _vp]),
     "svoslam_camera_reset": (C.c_int, [_vp]),
     "svoslam_pool_save": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _fp, _f32, _i32, _vp]),
+    "svoslam_pool_touch": (C.c_int, [C.POINTER(_PoolStruct)]),
     "svoslam_pool_set_nodes": (C.c_int, [C.POINTER(_PoolStruct), C.POINTER(C.c_uint32), _i32, _vp]),
     "svoslam_pool_copy": (C.c_int, [C.POINTER(_PoolStruct), C.POINTER(_PoolStruct), _vp]),
     "svoslam_pool_load": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _fp, C.POINTER(_f32), C.POINTER(_i32), _vp]),

@@ -9,6 +9,7 @@
 #include "image_kernels.hpp"
 #include "mesh.hpp"
 #include "frame_io.hpp"
+#include "pool_grid.hpp"
 #include "svo_build.hpp"
 #include "workspace.hpp"
 
@@ -89,6 +90,7 @@ int svoslam_pool_reserve(svoslam_pool *pool, int32_t capacity_nodes, void *strea
 }
 int svoslam_pool_free(svoslam_pool *pool) {
   if (!pool) return SVOSLAM_ERR_INVALID_ARG;
+  pool_accel_unregister(pool);
   if (pool->d_data) SVO_HIP(hipFree(pool->d_data));
   if (pool->d_size) SVO_HIP(hipFree(pool->d_size));
   pool_tracker_destroy(pool);
@@ -107,6 +109,11 @@ int svoslam_camera_reset(svoslam_camera *cam) {
 int svoslam_pool_expand(svoslam_pool *pool, float center[3], float *edge_length, const float toward[3], void *stream) {
   NEED_DEVICE();
   return pool_expand(pool, center, edge_length, toward, S(stream));
+}
+int svoslam_pool_touch(svoslam_pool *pool) {
+  if (!pool) return SVOSLAM_ERR_INVALID_ARG;
+  pool_accel_invalidate(pool);
+  return SVOSLAM_OK;
 }
 int svoslam_pool_sync(svoslam_pool *pool, void *stream) {
   NEED_DEVICE();

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "cone_trace.hpp"
+#include "pool_grid.hpp"
 #include "workspace.hpp"
 
 namespace svoslam {
@@ -126,29 +127,8 @@ struct TraceParams {
   int size_exp;
 };
 
-template <int GRID>
-__global__ __launch_bounds__(256) void build_accel_kernel(const uint32_t *__restrict__ octree, uint2 *__restrict__ grid,
-                                                         float *__restrict__ table, float *__restrict__ alpha_lut,
-                                                         TraceParams P) {
-  int e = blockIdx.x * 256 + threadIdx.x;
-  const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
-  if (e < grid_entries(GRID)) {
-    constexpr uint32_t kAxisMask = (1u << GRID) - 1u;
-    const uint32_t xi = (uint32_t)e & kAxisMask, yi = ((uint32_t)e >> GRID) & kAxisMask, zi = (uint32_t)e >> (2 * GRID);
-    uint32_t base = 0;
-    uint2 out = make_uint2(0u, 0u);
-    for (int l = 1; l <= GRID; l++) {
-      const int sh = GRID - l;
-      const uint32_t oct = ((xi >> sh) & 1u) | (((yi >> sh) & 1u) << 1) | (((zi >> sh) & 1u) << 2);
-      const uint2 nd = nodes[base + oct];
-      if (!(nd.x & kFlag)) { out = make_uint2((uint32_t)l, nd.y); break; }
-      base = nd.x & kMask;
-      out = make_uint2(kFlag | base, nd.y);
-    }
-    grid[e] = out;
-    return;
-  }
-  e -= grid_entries(GRID);
+// entry e of [fine table | LDS image | alpha LUT] (see "split-plane table")
+__device__ inline void build_table_entry(int e, float *__restrict__ table, float *__restrict__ alpha_lut, const TraceParams &P) {
   if (e < 3 * (kTabStride + kLdsStrideMax)) {
     // fine table (kTabDepth levels) followed by the LDS image (P.lds_depth levels)
     const bool fine = e < 3 * kTabStride;
@@ -178,6 +158,37 @@ __global__ __launch_bounds__(256) void build_accel_kernel(const uint32_t *__rest
   e -= 3 * (kTabStride + kLdsStrideMax);
   // (float)alpha / 127.0f of :110-112 for alpha = A - 127 in [-127, 128]: 256 IEEE quotients, computed once
   if (e < 256) alpha_lut[e] = (float)(e - 127) / 127.0f;
+}
+
+template <int GRID>
+__global__ __launch_bounds__(256) void build_accel_kernel(const uint32_t *__restrict__ octree, uint2 *__restrict__ grid,
+                                                         float *__restrict__ table, float *__restrict__ alpha_lut,
+                                                         TraceParams P) {
+  int e = blockIdx.x * 256 + threadIdx.x;
+  const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
+  if (e < grid_entries(GRID)) {
+    constexpr uint32_t kAxisMask = (1u << GRID) - 1u;
+    const uint32_t xi = (uint32_t)e & kAxisMask, yi = ((uint32_t)e >> GRID) & kAxisMask, zi = (uint32_t)e >> (2 * GRID);
+    uint32_t base = 0;
+    uint2 out = make_uint2(0u, 0u);
+    for (int l = 1; l <= GRID; l++) {
+      const int sh = GRID - l;
+      const uint32_t oct = ((xi >> sh) & 1u) | (((yi >> sh) & 1u) << 1) | (((zi >> sh) & 1u) << 2);
+      const uint2 nd = nodes[base + oct];
+      if (!(nd.x & kFlag)) { out = make_uint2((uint32_t)l, nd.y); break; }
+      base = nd.x & kMask;
+      out = make_uint2(kFlag | base, nd.y);
+    }
+    grid[e] = out;
+    return;
+  }
+  e -= grid_entries(GRID);
+  build_table_entry(e, table, alpha_lut, P);
+}
+
+// split-plane tables + alpha LUT only: for pools whose level grid is maintained incrementally (pool_grid.hpp)
+__global__ __launch_bounds__(256) void build_tables_kernel(float *__restrict__ table, float *__restrict__ alpha_lut, TraceParams P) {
+  build_table_entry((int)(blockIdx.x * 256 + threadIdx.x), table, alpha_lut, P);
 }
 
 struct __attribute__((packed, aligned(4))) Float4U { float a, b, c, d; };
@@ -527,13 +538,21 @@ static unsigned xcd_mapping(TraceParams &P, int tiles_x, int tiles_y) {
 }
 
 // ---- per-stream acceleration buffers ----
+struct StreamAccel {
+  DeviceBuffer buf;
+  // what the tables in `buf` were built for (they depend on the root cube only, not on the tree)
+  bool tables_valid = false;
+  const float *tables_at = nullptr;
+  int lds_depth = 0;
+  float size = 0.0f, center[3] = {0.0f, 0.0f, 0.0f};
+};
 static std::mutex g_accel_mu;
-static std::map<hipStream_t, std::unique_ptr<DeviceBuffer>> g_accel;
+static std::map<hipStream_t, std::unique_ptr<StreamAccel>> g_accel;
 
-static int accel_for_stream(hipStream_t stream, DeviceBuffer **out) {
+static int accel_for_stream(hipStream_t stream, StreamAccel **out) {
   std::lock_guard<std::mutex> lock(g_accel_mu);
   auto it = g_accel.find(stream);
-  if (it == g_accel.end()) it = g_accel.emplace(stream, std::unique_ptr<DeviceBuffer>(new DeviceBuffer())).first;
+  if (it == g_accel.end()) it = g_accel.emplace(stream, std::unique_ptr<StreamAccel>(new StreamAccel())).first;
   *out = it->second.get();
   return SVOSLAM_OK;
 }
@@ -542,11 +561,11 @@ static int accel_for_stream(hipStream_t stream, DeviceBuffer **out) {
 int cone_trace_release(hipStream_t stream, bool all) {
   std::lock_guard<std::mutex> lock(g_accel_mu);
   if (all) {
-    for (auto &kv : g_accel) kv.second->release();
+    for (auto &kv : g_accel) kv.second->buf.release();
     g_accel.clear();
   } else {
     auto it = g_accel.find(stream);
-    if (it != g_accel.end()) { it->second->release(); g_accel.erase(it); }
+    if (it != g_accel.end()) { it->second->buf.release(); g_accel.erase(it); }
   }
   return SVOSLAM_OK;
 }
@@ -595,27 +614,44 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
       P.lod_span = 0u;
     }
   }
-  // Acceleration data of the render (grid 16.8 / 134 MB + tables 0.9 MB): one buffer PER STREAM, owned by the library.
-  // Renders on one stream are ordered by the stream and may share it; renders on different streams (two pools, two
-  // pipelines, a user stream next to the runner's) each get their own, so none rebuilds a grid another is marching
-  // through.  The map is guarded for calls from several host threads.  Buffers live until svoslam_cone_trace_release().
-  DeviceBuffer *accel_ptr = nullptr;
-  SVO_TRY(accel_for_stream(stream, &accel_ptr));
-  DeviceBuffer &accel = *accel_ptr;
+  // Acceleration data of the render.
+  //  * Level grid: pools the library knows (anything it allocated: svoslam_pool_init / fusion / scene) carry a level-8
+  //    grid that commits keep up to date block by block (pool_grid.hpp): the render only refreshes the dirty blocks.
+  //    Foreign node memory gets a grid rebuilt for this render (level 7, or 8 for a megapixel and more) in the
+  //    per-stream buffer below.
+  //  * Split-plane tables + alpha LUT (0.9 MB): per STREAM, library-owned, rebuilt when centre / size / LDS depth
+  //    differ from what the stream's buffer holds.  Renders on one stream are ordered by the stream and share it;
+  //    renders on different streams each get their own, so none rebuilds data another is marching through.
+  StreamAccel *sa = nullptr;
+  SVO_TRY(accel_for_stream(stream, &sa));
+  DeviceBuffer &accel = sa->buf;
+  PoolAccel *pa = pool_accel_find(d_octree);
 #ifdef SVO_FORCE_GRID8
   const bool large = true;
 #else
-  const bool large = (long long)width * rows >= (1ll << 20);  // e.g. 1920x1080 frames
+  const bool large = pa != nullptr || (long long)width * rows >= (1ll << 20);  // e.g. 1920x1080 frames
 #endif
-  const int grid_cells = grid_entries(large ? kGridLevelLarge : kGridLevelSmall);
-  const size_t accel_bytes = (size_t)grid_cells * sizeof(uint2) + (size_t)(3 * (kTabStride + kLdsStrideMax) + 256) * sizeof(float) + 64;
+  const int own_cells = pa ? 0 : grid_entries(large ? kGridLevelLarge : kGridLevelSmall);
+  const size_t accel_bytes = (size_t)own_cells * sizeof(uint2) + (size_t)(3 * (kTabStride + kLdsStrideMax) + 256) * sizeof(float) + 64;
+  const void *before = accel.ptr;
   SVO_TRY(accel.reserve(accel_bytes));
-  uint2 *d_grid = accel.as<uint2>();
-  float *d_table = reinterpret_cast<float *>(d_grid + grid_cells);
+  if (accel.ptr != before) sa->tables_valid = false;
+  uint2 *own_grid = accel.as<uint2>();
+  float *d_table = reinterpret_cast<float *>(own_grid + own_cells);
   float *alpha_lut = d_table + 3 * (kTabStride + kLdsStrideMax);
-  const int build_blocks = (int)cdiv(grid_cells + 3 * (kTabStride + kLdsStrideMax) + 256, 256);
-  if (large) build_accel_kernel<kGridLevelLarge><<<build_blocks, 256, 0, stream>>>(d_octree, d_grid, d_table, alpha_lut, P);
-  else build_accel_kernel<kGridLevelSmall><<<build_blocks, 256, 0, stream>>>(d_octree, d_grid, d_table, alpha_lut, P);
+  const uint2 *d_grid = own_grid;
+  const bool tables_match = sa->tables_valid && sa->tables_at == d_table && sa->lds_depth == P.lds_depth && sa->size == size &&
+                            sa->center[0] == center[0] && sa->center[1] == center[1] && sa->center[2] == center[2];
+  if (pa) {
+    SVO_TRY(pool_accel_refresh(pa, d_octree, stream, &d_grid));
+    if (!tables_match) build_tables_kernel<<<(int)cdiv(3 * (kTabStride + kLdsStrideMax) + 256, 256), 256, 0, stream>>>(d_table, alpha_lut, P);
+  } else {
+    const int build_blocks = (int)cdiv(own_cells + 3 * (kTabStride + kLdsStrideMax) + 256, 256);
+    if (large) build_accel_kernel<kGridLevelLarge><<<build_blocks, 256, 0, stream>>>(d_octree, own_grid, d_table, alpha_lut, P);
+    else build_accel_kernel<kGridLevelSmall><<<build_blocks, 256, 0, stream>>>(d_octree, own_grid, d_table, alpha_lut, P);
+  }
+  sa->tables_valid = true; sa->tables_at = d_table; sa->lds_depth = P.lds_depth; sa->size = size;
+  for (int k = 0; k < 3; k++) sa->center[k] = center[k];
   SVO_TRY(timing_event(stream));
   uchar4 *out = reinterpret_cast<uchar4 *>(d_pos);
   const bool carry = (mode & 0xFF) == SVOSLAM_RENDER_CARRY;

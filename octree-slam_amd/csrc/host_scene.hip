@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "host_scene.hpp"
+#include "pool_grid.hpp"
 #include "mesh.hpp"
 #include "svo_build.hpp"
 
@@ -43,6 +44,7 @@ Octree::Octree(const float resolution, const float center[3], const float size) 
 }
 
 Octree::~Octree() {
+  svoslam::pool_accel_unregister(&pool_);
   if (pool_.d_data) (void)hipFree(pool_.d_data);
   if (pool_.d_size) (void)hipFree(pool_.d_size);
 }

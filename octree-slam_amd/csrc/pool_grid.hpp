@@ -1,0 +1,116 @@
+// pool_grid.hpp -- the level grid of the ray march as a PROPERTY OF THE POOL, maintained incrementally.
+//
+// Round 1 rebuilt a dense level-7 grid (16.8 MB, 9-12 us) from the pool at the start of every render and used the
+// level-8 one (134 MB, 30 us to rebuild, 14 % less march time) only for megapixel renders.  A fusion changes the
+// outcome of the walk over levels 1..8 only below the level-5 prefixes of the keys it inserted (a few hundred 25 cm
+// blocks of 8^3 cells per frame at 640x480), so the grid now belongs to the pool: every commit marks the level-5
+// blocks it touches in a 4 KB bitmap, and the next render rebuilds just those blocks (8 cells per lane, one walk
+// each) before it marches -- level 8 for every render, no per-render rebuild.
+//
+// What a commit can change, and why block marking covers it (G = 8, B = 5):
+//  * colour words of nodes on the path of an inserted key (leaf blend, mip averages): entries hold the colour of the
+//    node a walk STOPS on (first childless node, or the level-G node), all of them descendants of the key's level-B
+//    prefix -- or nodes above level B that have children, which no entry refers to;
+//  * a split gives a childless node at level l eight children: the sibling tiles lie inside the key's level-B block
+//    when l >= B; a split at l < B re-labels the whole cube of the split node, so all 8^(B-l) blocks under it are
+//    marked (first frames of a map only).
+// Every other way of changing a pool (blocking fusion, voxel grids, load / set_nodes / copy / reset / expand)
+// invalidates the grid as a whole; it is rebuilt in full by the next render.  Memory written behind the library's
+// back (hipMemcpy into svoslam_pool.d_data) must be followed by svoslam_pool_touch().
+#pragma once
+#include "common.hpp"
+#include "workspace.hpp"
+
+namespace svoslam {
+
+constexpr int kPoolGridLevel = 8;                          // (2^8)^3 cells x 8 B = 134 MB per pool that is rendered
+constexpr int kPoolGridBlockLevel = 5;                     // dirty tracking granularity: (2^5)^3 = 32768 blocks of 8^3 cells
+constexpr int kPoolGridBlocks = 1 << (3 * kPoolGridBlockLevel);
+constexpr int kPoolGridDirtyWords = kPoolGridBlocks / 32;  // 4 KB bitmap
+
+struct PoolAccel {
+  DeviceBuffer grid;          // uint2[2^(3 G)], empty until the pool is rendered for the first time
+  uint32_t *d_dirty = nullptr;  // device: bitmap over the level-B blocks [kPoolGridDirtyWords], then the compacted list of the
+                                // marked blocks [kPoolGridBlocks] and its length [1] (written at the end of every commit)
+  bool valid = false;         // false: rebuild everything at the next render
+};
+
+// registry (guarded by a mutex inside), keyed by the address of the node memory: pools are known from pool_init
+// (or their first growth) to pool_free
+void pool_accel_register(svoslam_pool *pool);
+void pool_accel_rebind(const uint32_t *old_data, const uint32_t *new_data);  // the nodes moved to a larger allocation
+void pool_accel_unregister(svoslam_pool *pool);
+void pool_accel_invalidate(svoslam_pool *pool);
+uint32_t *pool_accel_dirty_bitmap(svoslam_pool *pool);   // nullptr while the pool has no grid (commits then mark nothing)
+PoolAccel *pool_accel_find(const uint32_t *d_data);      // the registered pool whose nodes start at d_data, or nullptr
+
+// enqueue on `stream`: bring the grid of `pa` up to date with its pool (full build or dirty blocks only); returns the grid
+int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stream, const uint2 **d_grid);
+
+constexpr int kPoolGridListOffset = kPoolGridDirtyWords;                     // words
+constexpr int kPoolGridCountOffset = kPoolGridDirtyWords + kPoolGridBlocks;  // words
+constexpr int kPoolGridStateWords = kPoolGridCountOffset + 4;
+
+#ifdef __HIPCC__
+// called by ALL threads of ONE workgroup of `threads` (a multiple of 64, <= 1024) lanes after the commit's marks are
+// complete: list of the marked blocks (bits stay set until a render has rebuilt the block) behind the bitmap
+__device__ inline void pool_grid_compact(uint32_t *dirty, int threads) {
+  __shared__ uint32_t wave_total[16];
+  __shared__ uint32_t running;
+  uint32_t *list = dirty + kPoolGridListOffset;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = threads >> 6;
+  if (tid == 0) running = 0u;
+  __syncthreads();
+  for (int base = 0; base < kPoolGridDirtyWords; base += threads) {
+    const int w = base + tid;
+    const uint32_t bits = w < kPoolGridDirtyWords ? dirty[w] : 0u;
+    const uint32_t cnt = (uint32_t)__popc(bits);
+    uint32_t incl = cnt;  // inclusive scan over the wavefront
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    uint32_t off = running;
+    for (int k = 0; k < wave; k++) off += wave_total[k];
+    uint32_t pos = off + incl - cnt, b = bits;
+    while (b) {
+      const int bit = __ffs((int)b) - 1;
+      b &= b - 1u;
+      list[pos++] = (uint32_t)w * 32u + (uint32_t)bit;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t t = running;
+      for (int k = 0; k < nwaves; k++) t += wave_total[k];
+      running = t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) dirty[kPoolGridCountOffset] = running;
+}
+
+// mark the level-B blocks under the node whose key prefix has `levels` octant triplets (key = 1 d1 d2 ... in base 8,
+// first level in the highest digit); levels >= B marks exactly one block
+__device__ inline void pool_grid_mark(uint32_t *dirty, unsigned long long key, int levels) {
+  constexpr int B = kPoolGridBlockLevel;
+  const int use = levels < B ? levels : B;
+  uint32_t x = 0, y = 0, z = 0;
+  for (int k = 1; k <= use; k++) {
+    const uint32_t oct = (uint32_t)(key >> (3 * (levels - k))) & 7u;
+    x = (x << 1) | (oct & 1u); y = (y << 1) | ((oct >> 1) & 1u); z = (z << 1) | (oct >> 2);
+  }
+  const int sh = B - use;  // free low bits per axis
+  const uint32_t n = 1u << sh;
+  for (uint32_t dz = 0; dz < n; dz++)
+    for (uint32_t dy = 0; dy < n; dy++)
+      for (uint32_t dx = 0; dx < n; dx++) {
+        const uint32_t b = ((((z << sh) | dz) << (2 * B)) | (((y << sh) | dy) << B)) | ((x << sh) | dx);
+        atomicOr(&dirty[b >> 5], 1u << (b & 31u));
+      }
+}
+#endif
+
+}  // namespace svoslam

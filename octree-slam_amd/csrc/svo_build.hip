@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "radix_sort.hpp"
+#include "pool_grid.hpp"
 #include "svo_build.hpp"
 #include "wave_rank.hpp"
 
@@ -220,7 +221,8 @@ __global__ __launch_bounds__(256) void plan_emit_kernel(const u64 *__restrict__ 
 __global__ __launch_bounds__(256) void split_all_kernel(const u64 *__restrict__ rec_key, const u32 *__restrict__ rec_front,
                                                         const unsigned char *__restrict__ rec_pass,
                                                         const u32 *__restrict__ bucket_base, const PlanCounts *__restrict__ counts,
-                                                        u32 *__restrict__ pool, const int *__restrict__ d_size, int depth) {
+                                                        u32 *__restrict__ pool, const int *__restrict__ d_size, int depth,
+                                                        u32 *__restrict__ grid_dirty) {
   SVO_HIGH_PRIO();  // commit kernels sit between two raycasts on the map stream
   const u32 total = (u32)counts->total_records;
   const u32 n0 = (u32)*d_size;
@@ -228,6 +230,8 @@ __global__ __launch_bounds__(256) void split_all_kernel(const u64 *__restrict__ 
     const u64 key = rec_key[r];
     const int pass = rec_pass[r];
     const int d = (63 - __clzll((long long)key)) / 3;
+    // level grid of the ray march (pool_grid.hpp): a split above the block level re-labels the whole cube of its node
+    if (grid_dirty && d < kPoolGridBlockLevel) pool_grid_mark(grid_dirty, key, d);
     const u32 child = n0 + 8u * r;
     if (pass == 0) pool[2 * (size_t)rec_front[r]] = kFlag + (child & kMask);
     u32 w0[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
@@ -390,7 +394,7 @@ constexpr int kFillThreads = SVO_FILL_THREADS;  // leaves per workgroup: fewer, 
 __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 *__restrict__ skey, const u32 *__restrict__ sidx, int n,
                                                              int depth, const unsigned char *__restrict__ leaf_t,
                                                              const unsigned char *__restrict__ colors, u32 *__restrict__ pool,
-                                                             u32 *__restrict__ strad, int num_tiles) {
+                                                             u32 *__restrict__ strad, int num_tiles, u32 *__restrict__ grid_dirty) {
   SVO_HIGH_PRIO();  // commit kernels sit between two raycasts on the map stream
   __shared__ int last_owner[SVOSLAM_MAX_DEPTH + 1];  // per level: last lane of this workgroup owning a node there
   __shared__ int next_pos, next_c;                   // first head lane after this workgroup and its common-prefix length
@@ -399,6 +403,9 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   const bool head = j < n && leaf_t[j] != kNotHead;
   u64 key = 1; int c = 0;
   if (head) (void)is_head(skey, j, key, c, depth);
+  // level grid of the ray march (pool_grid.hpp): everything this key changes lies below its level-5 prefix; the first
+  // head of a run of keys sharing that prefix marks the block
+  if (grid_dirty && head && c < kPoolGridBlockLevel) pool_grid_mark(grid_dirty, key, depth);
   if (tid <= SVOSLAM_MAX_DEPTH) {
     last_owner[tid] = -1;
     if (tid >= 1 && tid < depth) {  // "no straddler" unless a lane says otherwise below
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
 constexpr int kStradThreads = SVO_STRAD_THREADS;
 __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__restrict__ pool, const u32 *__restrict__ strad, int num_tiles,
                                                             int depth, const PlanCounts *__restrict__ counts,
-                                                            int *__restrict__ d_size) {
+                                                            int *__restrict__ d_size, u32 *__restrict__ grid_dirty) {
   SVO_HIGH_PRIO();  // commit kernels sit between two raycasts on the map stream
   // a thread's list entries do not depend on the levels below, so those of the next level are fetched while
   // this level's tiles are averaged (one dependent load per level instead of two); kSlots entries per thread
@@ -508,6 +515,9 @@ __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__rest
     if (counts->any_valid) pool[1] = average_tile(pool, 0);
     *d_size += 8 * counts->total_records;
   }
+  // last kernel of the commit: every mark of this commit is in the bitmap (kernel boundaries); list the marked blocks
+  // for the next render's refresh of the level grid (pool_grid.hpp)
+  if (grid_dirty) pool_grid_compact(grid_dirty, kStradThreads);
 }
 
 // ----------------------------------------------------------------------------
@@ -623,6 +633,7 @@ static int grow_pool(svoslam_pool *pool, int64_t need_nodes, hipStream_t stream)
   if (pool->d_data && pool->size > 0)
     SVO_HIP(hipMemcpyAsync(fresh, pool->d_data, (size_t)pool->size * 8, hipMemcpyDeviceToDevice, stream));
   SVO_HIP(hipStreamSynchronize(stream));
+  pool_accel_rebind(pool->d_data, fresh);
   if (pool->d_data) SVO_HIP(hipFree(pool->d_data));
   pool->d_data = fresh;
   pool->capacity = (int32_t)cap;
@@ -635,6 +646,7 @@ int pool_init(svoslam_pool *pool, int32_t capacity_nodes, hipStream_t stream) {
   pool->d_data = nullptr; pool->size = 0; pool->capacity = 0;
   pool->d_size = nullptr; pool->pending = 0; pool->pending_bound = 0; pool->tracker = nullptr;
   SVO_TRY(grow_pool(pool, capacity_nodes, stream));
+  pool_accel_register(pool);
   SVO_HIP(hipMemsetAsync(pool->d_data, 0, 64, stream));  // initOctree, svo.cu:24-31
   pool->size = 8;
   return ensure_device_size(pool, stream);
@@ -682,6 +694,7 @@ int pool_expand(svoslam_pool *pool, float center[3], float *edge, const float to
   }
   reroot_kernel<<<1, 64, 0, stream>>>(pool->d_data, pool->d_size, pool->size, octant);
   SVO_LAUNCH_CHECK();
+  pool_accel_invalidate(pool);  // every cell of the level grid now lies one level deeper
   SVO_HIP(hipStreamSynchronize(stream));
   pool->size += 8;
   for (int k = 0; k < 3; k++) center[k] = nc[k];
@@ -695,6 +708,7 @@ int pool_reset(svoslam_pool *pool, hipStream_t stream) {
   SVO_HIP(hipDeviceSynchronize());
   SVO_TRY(pool_sync(pool, stream));  // drains the size tracker
   SVO_HIP(hipMemset(pool->d_data, 0, 64));
+  pool_accel_invalidate(pool);
   pool->size = 8; pool->pending = 0; pool->pending_bound = 0;
   if (pool->d_size) SVO_HIP(hipMemcpy(pool->d_size, &pool->size, 4, hipMemcpyHostToDevice));
   return SVOSLAM_OK;
@@ -763,6 +777,7 @@ int pool_set_nodes(svoslam_pool *pool, const uint32_t *h_words, int32_t num_node
   SVO_TRY(pool_sync(pool, stream));
   SVO_TRY(grow_pool(pool, num_nodes, stream));
   SVO_HIP(hipMemcpy(pool->d_data, h_words, (size_t)num_nodes * 8, hipMemcpyHostToDevice));
+  pool_accel_invalidate(pool);
   pool->size = num_nodes;
   pool->pending = 0; pool->pending_bound = 0;
   if (pool->d_size) SVO_HIP(hipMemcpy(pool->d_size, &pool->size, 4, hipMemcpyHostToDevice));
@@ -782,6 +797,7 @@ int pool_copy(svoslam_pool *dst, svoslam_pool *src, hipStream_t stream) {
     SVO_TRY(grow_pool(dst, src->capacity, stream));
   }
   SVO_HIP(hipMemcpy(dst->d_data, src->d_data, (size_t)src->size * 8, hipMemcpyDeviceToDevice));
+  pool_accel_invalidate(dst);
   SVO_HIP(hipDeviceSynchronize());
   dst->size = src->size;
   dst->pending = 0; dst->pending_bound = 0;
@@ -837,6 +853,7 @@ static inline int *small_any(svoslam_workspace *ws) { return reinterpret_cast<in
 // keys of the n inputs are in ws->keys_a
 static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, const void *d_colors, bool vec4,
                       bool color_by_position, svoslam_fuse_stats *stats, hipStream_t stream) {
+  pool_accel_invalidate(pool);  // the blocking path does not track what it touches: the next render rebuilds the level grid
   SVO_TRY(pool_sync(pool, stream));
   u64 *skey = nullptr; u32 *sidx = nullptr;
   SVO_TRY(radix_sort_pairs(ws, n, 3 * depth + 1, stream, &skey, &sidx));
@@ -1019,18 +1036,20 @@ int svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   DeviceBuffer &sb = slot == 0 ? ws->strad : ws->strad_b;
   SVO_TRY(sb.reserve((size_t)(SVOSLAM_MAX_DEPTH + 1) * (size_t)fill_tiles * 8));
   u32 *strad = sb.as<u32>();
+  u32 *grid_dirty = pool_accel_dirty_bitmap(pool);  // nullptr unless the pool has an up-to-date level grid to maintain
   auto enqueue = [&]() -> int {
     split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
                                                        ws->rec_pass.as<unsigned char>(), small_bucket_base(ws), small_counts(ws),
-                                                       pool->d_data, pool->d_size, depth);
-    fill_mip_local_kernel<<<fill_tiles, kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles);
-    mip_straddle_kernel<<<1, kStradThreads, 0, stream>>>(pool->d_data, strad, fill_tiles, depth, small_counts(ws), pool->d_size);
+                                                       pool->d_data, pool->d_size, depth, grid_dirty);
+    fill_mip_local_kernel<<<fill_tiles, kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
+                                                                   grid_dirty);
+    mip_straddle_kernel<<<1, kStradThreads, 0, stream>>>(pool->d_data, strad, fill_tiles, depth, small_counts(ws), pool->d_size, grid_dirty);
     SVO_LAUNCH_CHECK();
     return SVOSLAM_OK;
   };
   GraphKey key;
   key.add(skey).add(d_colors).add((unsigned long long)n).add((unsigned long long)depth).add(pool->d_data).add(pool->d_size)
-     .add((unsigned long long)slot).add(ws->layout_hash());
+     .add((unsigned long long)slot).add(grid_dirty).add(ws->layout_hash());
   SVO_TRY(ws->g_commit.run(key, stream, enqueue));
   pool->pending += 1;
   return tracker_push(pool, 8 * rmax, stream);

@@ -170,3 +170,57 @@ def test_obj_loader_refuses_bad_indices(env, tmp_path):
         p.write_text(base + faces)
         with pytest.raises(pkg.SvoslamError):
             pkg.Mesh(p)
+
+
+@pytest.mark.parametrize("depth", [3, 5, 6, 9])
+def test_incremental_level_grid_follows_async_fusions(env, oracle, depth):
+    """the level grid of the ray march belongs to the pool and is refreshed block by block (pool_grid.hpp): after every
+    asynchronous fusion -- first frames with splits near the root, trees shallower than the block level, colour-only
+    updates of an old map -- the render must equal the oracle's; also after the blocking path (whole-grid rebuild)"""
+    pkg, torch, synth, pl = env
+    rng = np.random.default_rng(depth)
+    ws, pool, opool = pkg.Workspace(), pkg.Pool(1 << 20), oracle.Pool()
+    view = oracle.look_at((0.3, 0.2, -2.4), (0, 0, 0), (0, 1, 0))
+    w, h = 96, 72
+    img = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    for k in range(7):
+        n = 300 if k < 2 else 20000          # sparse first frames: large childless cubes get split later
+        pts, col = surface_cloud(rng, n)
+        if k == 5:
+            pts = np.ascontiguousarray(prev)          # same cloud again: colours / alpha only (plus the Q4 splits)
+        prev = pts
+        tp, tc = torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda()
+        if k == 4:
+            pkg.svo_from_point_cloud(ws, tp, tc, depth, pool, (0, 0, 0), 1.0)      # blocking path
+        else:
+            pkg.svo_from_point_cloud_async(ws, tp, tc, depth, pool, (0, 0, 0), 1.0)
+        opool.insert_cloud(pts, col, depth, (0, 0, 0), 1.0)
+        for mode in (1, 0):
+            pkg.cone_trace_svo(img, 45.0, view, pool.data_ptr, (0, 0, 0), 1.0, mode)
+            ref, _, _ = oracle.cone_trace(opool, w, h, 45.0, view, (0, 0, 0), 1.0, mode)
+            got = img.cpu().numpy()
+            assert np.array_equal(got, ref), (k, mode, describe_mismatch(got, ref))
+    assert np.array_equal(pool.words(), opool.words())
+
+
+def test_pool_touch_after_external_write(env, oracle):
+    """node memory written behind the library's back: svoslam_pool_touch makes the next render rebuild the grid"""
+    pkg, torch, synth, pl = env
+    a = build_pool(pkg, torch, 21, 8, frames=7, n=60000)      # a denser, older map: visibly different render
+    b = build_pool(pkg, torch, 22, 8)
+    wa, wb = a.words().copy(), b.words().copy()
+    view = oracle.look_at((0.1, 0.2, -2.6), (0, 0, 0), (0, 1, 0))
+    w, h = 96, 72
+    img = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    pkg.cone_trace_svo(img, 45.0, view, a.data_ptr, (0, 0, 0), 1.0, 1)
+    ra, _, _ = oracle.cone_trace(wa, w, h, 45.0, view, (0, 0, 0), 1.0, 1)
+    assert np.array_equal(img.cpu().numpy(), ra)
+    n = min(wa.size, wb.size)
+    assert a.capacity * 2 >= wb.size
+    import ctypes as C
+    torch.cuda.synchronize()
+    pkg._hip().hipMemcpy(C.c_void_p(a.data_ptr), C.c_void_p(wb.ctypes.data), C.c_size_t(wb.nbytes), 1)   # raw overwrite
+    pkg.check(pkg.lib().svoslam_pool_touch(C.byref(a._p)))
+    pkg.cone_trace_svo(img, 45.0, view, a.data_ptr, (0, 0, 0), 1.0, 1)
+    rb, _, _ = oracle.cone_trace(wb, w, h, 45.0, view, (0, 0, 0), 1.0, 1)
+    assert np.array_equal(img.cpu().numpy(), rb) and not np.array_equal(ra, rb)
