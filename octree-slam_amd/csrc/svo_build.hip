@@ -478,7 +478,8 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
 constexpr int kStradThreads = SVO_STRAD_THREADS;
 __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__restrict__ pool, const u32 *__restrict__ strad, int num_tiles,
                                                             int depth, const PlanCounts *__restrict__ counts,
-                                                            int *__restrict__ d_size, u32 *__restrict__ grid_dirty) {
+                                                            int *__restrict__ d_size, u32 *__restrict__ grid_dirty,
+                                                            int32_t *__restrict__ h_sizes, int *__restrict__ d_slot) {
   SVO_HIGH_PRIO();  // commit kernels sit between two raycasts on the map stream
   // a thread's list entries do not depend on the levels below, so those of the next level are fetched while
   // this level's tiles are averaged (one dependent load per level instead of two); kSlots entries per thread
@@ -513,7 +514,13 @@ __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__rest
   }
   if (threadIdx.x == 0) {
     if (counts->any_valid) pool[1] = average_tile(pool, 0);
-    *d_size += 8 * counts->total_records;
+    const int size_now = *d_size + 8 * counts->total_records;
+    *d_size = size_now;
+    if (h_sizes) {  // the host learns the size from pinned memory behind the commit's event (PoolTracker)
+      const int sl = *d_slot;
+      h_sizes[sl] = size_now;
+      *d_slot = (sl + 1) % 8;
+    }
   }
   // last kernel of the commit: every mark of this commit is in the bitmap (kernel boundaries); list the marked blocks
   // for the next render's refresh of the level grid (pool_grid.hpp)
@@ -528,8 +535,9 @@ __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__rest
 // the events: each completed one makes pool->size current up to that commit and releases its worst-case
 // reservation, so the host learns the true size a frame or two late WITHOUT ever waiting for the device.
 struct PoolTracker {
-  static constexpr int kSlots = 8;
-  int32_t *h_size = nullptr;  // pinned [kSlots]
+  static constexpr int kSlots = 8;  // == the modulus in mip_straddle_kernel
+  int32_t *h_size = nullptr;  // pinned, device-visible [kSlots]: the commit's last kernel stores the new size itself
+  int *d_slot = nullptr;      // device: slot the next commit writes (advances with `next` below, once per commit)
   hipEvent_t ev[kSlots];
   struct InFlight { int slot; int64_t bound; };
   InFlight q[kSlots];  // oldest first
@@ -545,6 +553,7 @@ static int tracker_create(svoslam_pool *pool) {
   for (int i = 0; i < PoolTracker::kSlots; i++) {
     if (hipEventCreateWithFlags(&t->ev[i], hipEventDisableTiming) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
   }
+  if (hipMalloc((void **)&t->d_slot, 4) != hipSuccess || hipMemset(t->d_slot, 0, 4) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
   pool->tracker = t;
   return SVOSLAM_OK;
 }
@@ -554,6 +563,7 @@ void pool_tracker_destroy(svoslam_pool *pool) {
   if (!t) return;
   for (int i = 0; i < PoolTracker::kSlots; i++) (void)hipEventDestroy(t->ev[i]);
   if (t->h_size) (void)hipHostFree(t->h_size);
+  if (t->d_slot) (void)hipFree(t->d_slot);
   delete t;
   pool->tracker = nullptr;
 }
@@ -590,7 +600,7 @@ static int tracker_push(svoslam_pool *pool, int64_t bound, hipStream_t stream) {
   }
   const int slot = t->next;
   t->next = (t->next + 1) % PoolTracker::kSlots;
-  SVO_HIP(hipMemcpyAsync(&t->h_size[slot], pool->d_size, 4, hipMemcpyDeviceToHost, stream));
+  (void)slot;  // h_size[slot] is stored by mip_straddle_kernel (no copy operation between the commit and the next render)
   SVO_HIP(hipEventRecord(t->ev[slot], stream));
   t->q[t->count].slot = slot;
   t->q[t->count].bound = bound;
@@ -1037,19 +1047,22 @@ int svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   SVO_TRY(sb.reserve((size_t)(SVOSLAM_MAX_DEPTH + 1) * (size_t)fill_tiles * 8));
   u32 *strad = sb.as<u32>();
   u32 *grid_dirty = pool_accel_dirty_bitmap(pool);  // nullptr unless the pool has an up-to-date level grid to maintain
+  SVO_TRY(ensure_device_size(pool, stream));         // (creates the size tracker)
+  PoolTracker *trk = tracker_of(pool);
   auto enqueue = [&]() -> int {
     split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
                                                        ws->rec_pass.as<unsigned char>(), small_bucket_base(ws), small_counts(ws),
                                                        pool->d_data, pool->d_size, depth, grid_dirty);
     fill_mip_local_kernel<<<fill_tiles, kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
                                                                    grid_dirty);
-    mip_straddle_kernel<<<1, kStradThreads, 0, stream>>>(pool->d_data, strad, fill_tiles, depth, small_counts(ws), pool->d_size, grid_dirty);
+    mip_straddle_kernel<<<1, kStradThreads, 0, stream>>>(pool->d_data, strad, fill_tiles, depth, small_counts(ws), pool->d_size, grid_dirty,
+                                                         trk ? trk->h_size : nullptr, trk ? trk->d_slot : nullptr);
     SVO_LAUNCH_CHECK();
     return SVOSLAM_OK;
   };
   GraphKey key;
   key.add(skey).add(d_colors).add((unsigned long long)n).add((unsigned long long)depth).add(pool->d_data).add(pool->d_size)
-     .add((unsigned long long)slot).add(grid_dirty).add(ws->layout_hash());
+     .add((unsigned long long)slot).add(grid_dirty).add(trk ? (const void *)trk->h_size : nullptr).add(ws->layout_hash());
   SVO_TRY(ws->g_commit.run(key, stream, enqueue));
   pool->pending += 1;
   return tracker_push(pool, 8 * rmax, stream);
