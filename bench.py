@@ -34,7 +34,6 @@ import time
 # The frame pipeline uses four HIP streams next to the default one; the HIP runtime multiplexes streams
 # onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams sharing a queue run in order.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-os.environ.setdefault("SVOSLAM_RUNNER_TIMELINE", "1")   # HIP-event marks at the stage boundaries (svoslam_runner_timeline): `stages`
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -102,7 +101,12 @@ def main():
     ap.add_argument("--exchange", default="none", choices=["none", "allreduce"],
                     help="N > 1: 'none' = every rank tracks and fuses whole frames, only the raycast is split into row bands; "
                          "'allreduce' = SURVEY 8e row bands with 19 ICP all-reduces + one point all-gather per frame")
+    ap.add_argument("--stages", action="store_true",
+                    help="add `stages` (per-stage durations from HIP-event marks at the stage boundaries, svoslam_runner_timeline); "
+                         "the ~10 extra event records per frame cost ~6 %% of the frame rate, so they are off for the headline line")
     args = ap.parse_args()
+    if args.stages:
+        os.environ["SVOSLAM_RUNNER_TIMELINE"] = "1"
 
     import numpy as np
     import torch

@@ -14,6 +14,8 @@ P="$OUT/$TAG"
 
 echo "== bench lines"
 python $R/bench.py --steps 100 --warmup 5 2>/dev/null | line > ${P}_bench_cfg3.json
+python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --stages 2>/dev/null | line > ${P}_bench_cfg3_with_stages.json
+python $R/bench.py --workload cfg4 --steps 40 --warmup 5 --no-cpu-baseline --stages 2>/dev/null | line > ${P}_bench_cfg4_with_stages.json
 python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_driver_args_20frames.json
 python $R/bench.py --steps 300 --warmup 5 --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_300frames.json
 python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --include-h2d 2>/dev/null | line > ${P}_bench_cfg3_include_h2d.json
