@@ -348,6 +348,25 @@ int svoslam_point_cloud_bbox_device(svoslam_workspace *ws, const float *d_points
  * ICP (include/octree_slam/sensor/localization_kernels.h:17-42,
  * src/sensor/localization_kernels.cu)
  * ---------------------------------------------------------------------- */
+/* Photometric RGB-D term.  The reference DECLARES gradient / difference (image_kernels.h:45-49) and
+ * computeRGBDCost (localization_kernels.h:42) but ships no definition of the first two, an empty body for the third
+ * (localization_kernels.cu:328-331) and its call site commented out (rgbd_camera.cpp:126-141; W_RGBD = 0.1, :20).
+ * There is no reference behaviour to match; the specification is this build's own (restated in
+ * oracle/svoslam_oracle.c):
+ *   gradient    Sobel 3x3 / 8 on interior pixels, (0,0) on the border; d_gradient = (gx, gy) per pixel
+ *   difference  out = in1 - in2
+ *   rgbd_cost   same-index association as computeICPCost2 (no reprojection), gates = finite + depth range + distance;
+ *               r = I_last - I_cur; J = G_T * (gx du/dv + gy dv/dv) with the LAST frame's gradient, the pinhole
+ *               derivative at the CURRENT vertex and the geometric term's own G_T rows (:208-213), so that both systems
+ *               share one parametrisation; exact fixed-point sums.  fx, fy and the full image size are extra
+ *               parameters (the reference's RGBDFrame carries no intrinsics).  Blocking (h_A, h_b on the host).
+ *   svoslam_camera_set_rgbd(cam, 1), before the first frame: every ICP iteration solves A1 + W_RGBD A2, b1 + W_RGBD b2
+ *   (the commented-out block of rgbd_camera.cpp:130-141); default off = the reference as shipped. */
+int svoslam_gradient(const float *d_intensity, float *d_gradient, int32_t width, int32_t height, void *stream);
+int svoslam_difference(const float *d_in1, const float *d_in2, float *d_out, int32_t n, void *stream);
+int svoslam_rgbd_cost(const float *d_last_intensity, const float *d_last_gradient, const float *d_last_vertex,
+                      const float *d_cur_intensity, const float *d_cur_vertex, int32_t width, int32_t height, float fx, float fy,
+                      int32_t img_width, int32_t img_height, float h_A[36], float h_b[6], void *stream);
 /* computeICPCost2, localization_kernels.h:39 / .cu:154-229,303-326.  h_A (36) and
  * h_b (6) are host outputs as in the reference.  Blocking. */
 int svoslam_icp_cost2(const float *d_last_vertex, const float *d_last_normal, const float *d_cur_vertex,
@@ -411,6 +430,8 @@ int svoslam_camera_set_acc(svoslam_camera *cam, double *d_acc);
 /* number of pyramid levels abandoned because the solve returned NaN
  * ("Camera tracking is lost.", rgbd_camera.cpp:148-151).  Blocking. */
 int svoslam_camera_tracking_lost_count(svoslam_camera *cam, int32_t *count, void *stream);
+/* switches the photometric RGB-D term on (see svoslam_rgbd_cost above); only before the first frame */
+int svoslam_camera_set_rgbd(svoslam_camera *cam, int32_t enable);
 /* the newest timestamp the camera has accepted (rgbd_camera.cpp:55-59 skips frames that are not newer); *have = 0
  * before the first frame.  Host state, no device access. */
 int svoslam_camera_latest_timestamp(svoslam_camera *cam, int32_t *have, long long *timestamp);

@@ -146,6 +146,10 @@ SIGNATURES = {
     "svoslam_transform_vertex_map_dmat": (C.c_int, [_vp, _vp, _i32, _vp]),
     "svoslam_point_cloud_bbox": (C.c_int, [_vp, _i32, _fp, _fp, _vp]),
     "svoslam_point_cloud_bbox_device": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
+    "svoslam_gradient": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "svoslam_difference": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
+    "svoslam_rgbd_cost": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _i32, _i32, _fp, _fp, _vp]),
+    "svoslam_camera_set_rgbd": (C.c_int, [_vp, _i32]),
     "svoslam_icp_cost2": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _fp, _fp, _vp]),
     "svoslam_icp_cost": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _fp, _fp, C.POINTER(_i32), _vp]),
     "svoslam_icp_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -740,6 +744,27 @@ def point_cloud_bbox_device(ws, points, out7):
     return out7
 
 
+def gradient(intensity, out):
+    """Sobel / 8 of a float image [h, w] into out [h, w, 2] (own specification, see svoslam.h)"""
+    h, w = int(intensity.shape[0]), int(intensity.shape[1])
+    check(lib().svoslam_gradient(_ptr(intensity), _ptr(out), w, h, _stream()))
+    return out
+
+
+def difference(a, b, out):
+    check(lib().svoslam_difference(_ptr(a), _ptr(b), _ptr(out), int(out.numel()), _stream()))
+    return out
+
+
+def rgbd_cost(last_i, last_g, last_v, cur_i, cur_v, fx, fy, img_w, img_h):
+    """photometric normal equations (computeRGBDCost, own specification) -> (A [6,6], b [6])"""
+    h, w = int(last_i.shape[0]), int(last_i.shape[1])
+    A, b = (C.c_float * 36)(), (C.c_float * 6)()
+    check(lib().svoslam_rgbd_cost(_ptr(last_i), _ptr(last_g), _ptr(last_v), _ptr(cur_i), _ptr(cur_v), w, h, float(fx), float(fy),
+                                  int(img_w), int(img_h), A, b, _stream()))
+    return np.array(list(A), np.float32).reshape(6, 6), np.array(list(b), np.float32)
+
+
 def icp_cost2(last_v, last_n, cur_v, cur_n):
     h, w = int(last_v.shape[0]), int(last_v.shape[1])
     A, b = (C.c_float * 36)(), (C.c_float * 6)()
@@ -780,6 +805,10 @@ class Camera:
         used = C.c_int32(0)
         check(lib().svoslam_camera_update(self._h, _ptr(depth), _ptr(rgb), int(timestamp), C.byref(used), _stream()))
         return int(used.value)
+
+    def set_rgbd(self, enable=True):
+        """photometric RGB-D term in every ICP iteration (rgbd_camera.cpp:126-141 switched on); before the first frame"""
+        check(lib().svoslam_camera_set_rgbd(self._h, 1 if enable else 0))
 
     def reset(self):
         """identity pose, no frame seen; buffers and recorded graphs kept"""

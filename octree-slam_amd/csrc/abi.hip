@@ -360,6 +360,14 @@ int svoslam_color_to_intensity(const uint8_t *d_rgb, float *d_out, int32_t n, vo
   NEED_DEVICE();
   return color_to_intensity(d_rgb, d_out, n, S(stream));
 }
+int svoslam_gradient(const float *d_intensity, float *d_gradient, int32_t width, int32_t height, void *stream) {
+  NEED_DEVICE();
+  return gradient(d_intensity, d_gradient, width, height, S(stream));
+}
+int svoslam_difference(const float *d_in1, const float *d_in2, float *d_out, int32_t n, void *stream) {
+  NEED_DEVICE();
+  return difference(d_in1, d_in2, d_out, n, S(stream));
+}
 int svoslam_transform_vertex_map(float *d_vertex, const float trans[16], int32_t n, void *stream) {
   NEED_DEVICE();
   return transform_vertex_map(d_vertex, trans, n, S(stream));
@@ -391,6 +399,18 @@ int svoslam_icp_cost2(const float *d_last_vertex, const float *d_last_normal, co
                       const float *d_cur_normal, int32_t width, int32_t height, float h_A[36], float h_b[6], void *stream) {
   NEED_DEVICE();
   return icp_cost2(g_misc, d_last_vertex, d_last_normal, d_cur_vertex, d_cur_normal, width, height, h_A, h_b, S(stream));
+}
+
+int svoslam_rgbd_cost(const float *d_last_intensity, const float *d_last_gradient, const float *d_last_vertex,
+                      const float *d_cur_intensity, const float *d_cur_vertex, int32_t width, int32_t height, float fx, float fy,
+                      int32_t img_width, int32_t img_height, float h_A[36], float h_b[6], void *stream) {
+  NEED_DEVICE();
+  return rgbd_cost(g_misc, d_last_intensity, d_last_gradient, d_last_vertex, d_cur_intensity, d_cur_vertex, width, height, fx, fy,
+                   img_width, img_height, h_A, h_b, S(stream));
+}
+int svoslam_camera_set_rgbd(svoslam_camera *cam, int32_t enable) {
+  NEED_DEVICE();
+  return camera_set_rgbd(cam, enable);
 }
 
 int svoslam_icp_cost(const float *d_last_vertex, const float *d_last_normal, const float *d_cur_vertex,

@@ -119,6 +119,58 @@ __global__ __launch_bounds__(kIcpThreads) void icp_accumulate_kernel(
   accumulate_block(last_v, last_n, cur_v, cur_n, first, end, state, flags, chain_len, partial, wsum, chain_s);
 }
 
+// photometric terms of the same pixels (own specification, icp_device.hpp rgbd_pixel_terms): the current vertex goes
+// through the same replayed transform chain as in accumulate_block, so both systems linearise at the same estimate
+__global__ __launch_bounds__(kIcpThreads) void rgbd_accumulate_kernel(
+    const float *__restrict__ last_i, const float *__restrict__ last_g, const float *__restrict__ last_v,
+    const float *__restrict__ cur_i, const float *__restrict__ cur_v, int first, int end, float fx, float fy, float sx, float sy,
+    const CamState *__restrict__ state, int flags, int chain_len, double *__restrict__ partial) {
+  SVO_HIGH_PRIO();
+  __shared__ double wsum[kIcpWaves][27];
+  __shared__ float chain_s[(kMaxChain + 1) * 16];
+  int nchain = 0;
+  bool lost = false;
+  if (state) {
+    lost = !(flags & kFlagFirstIter) && state->lost != 0;
+    if (flags & kFlagLevelStart) {
+      const float *src = (flags & kFlagFirstIter) ? state->update_trans : state->level_start;
+      if (threadIdx.x < 16) chain_s[threadIdx.x] = src[threadIdx.x];
+      nchain = 1;
+    }
+    for (int i = threadIdx.x; i < chain_len * 16; i += kIcpThreads) chain_s[nchain * 16 + i] = (&state->chain[0][0])[i];
+    nchain += chain_len;
+  }
+  __syncthreads();
+  double acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; i++) acc[i] = 0.0;
+  if (!lost) {
+    for (int p = first + blockIdx.x * kIcpThreads + threadIdx.x; p < end; p += gridDim.x * kIcpThreads) {
+      float v2x = cur_v[3 * (size_t)p], v2y = cur_v[3 * (size_t)p + 1], v2z = cur_v[3 * (size_t)p + 2];
+      for (int k = 0; k < nchain; k++) {
+        float ox, oy, oz;
+        mat4_mul_point(chain_s + 16 * k, v2x, v2y, v2z, 1.0f, ox, oy, oz);
+        v2x = ox; v2y = oy; v2z = oz;
+      }
+      rgbd_pixel_terms(last_v[3 * (size_t)p], last_v[3 * (size_t)p + 1], last_v[3 * (size_t)p + 2], v2x, v2y, v2z,
+                       last_g[2 * (size_t)p], last_g[2 * (size_t)p + 1], last_i[p] - cur_i[p], fx, fy, sx, sy, acc);
+    }
+  }
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+#pragma unroll
+  for (int i = 0; i < 27; i++) {
+    const double t = wave_sum_to_lane63(acc[i]);
+    if (lane == 63u) wsum[wave][i] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < kIcpWaves; w++) v += wsum[w][threadIdx.x];
+    partial[(size_t)blockIdx.x * 27 + threadIdx.x] = v;
+  }
+}
+
 // column sums of partial[rows][27] into LDS totals[27] (exact integer-valued sums);
 // blockDim.x / 32 row groups x 32 columns, all loads of a thread independent (<= 8 rows each)
 constexpr int kReduceThreads = 1024;
@@ -203,6 +255,36 @@ int icp_cost2(svoslam::DeviceBuffer &scratch, const float *lv, const float *ln, 
   SVO_HIP(hipMemcpyAsync(acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, s));
   SVO_HIP(hipStreamSynchronize(s));
   icp_finish_host(acc, A, b);
+  return SVOSLAM_OK;
+}
+
+// computeRGBDCost (declared localization_kernels.h:42; empty in the reference, :328-331): own specification, see
+// icp_device.hpp.  last_g = gradient() of last_i.  Blocking (A, b to the host).
+int rgbd_cost(svoslam::DeviceBuffer &scratch, const float *last_i, const float *last_g, const float *last_v, const float *cur_i,
+              const float *cur_v, int w, int h, float fx, float fy, int img_w, int img_h, float A[36], float b[6], hipStream_t s) {
+  if (!last_i || !last_g || !last_v || !cur_i || !cur_v || !A || !b || w <= 0 || h <= 0 || img_w < w || img_h < h)
+    return SVOSLAM_ERR_INVALID_ARG;
+  SVO_TRY(scratch.reserve((size_t)(kMaxIcpBlocks + 1) * 27 * sizeof(double)));
+  double *d_acc = scratch.as<double>();
+  SVO_HIP(hipMemsetAsync(d_acc, 0, 27 * sizeof(double), s));
+  const int n = w * h;
+  int blocks = (int)cdiv(n, kIcpThreads);
+  if (blocks > kMaxIcpBlocks) blocks = kMaxIcpBlocks;
+  rgbd_accumulate_kernel<<<blocks, kIcpThreads, 0, s>>>(last_i, last_g, last_v, cur_i, cur_v, 0, n, fx, fy, (float)(img_w / w),
+                                                        (float)(img_h / h), nullptr, 0, 0, d_acc + 27);
+  icp_reduce_kernel<<<1, kReduceThreads, 0, s>>>(d_acc + 27, blocks, d_acc);
+  SVO_LAUNCH_CHECK();
+  double acc[27];
+  SVO_HIP(hipMemcpyAsync(acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, s));
+  SVO_HIP(hipStreamSynchronize(s));
+  int k = 0;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++) {
+      const float v = (float)(acc[k++] * (1.0 / kScaleRgbdA));
+      A[6 * i + j] = v;
+      A[6 * j + i] = v;
+    }
+  for (int i = 0; i < 6; i++) b[i] = (float)(acc[21 + i] * (1.0 / kScaleRgbdB));
   return SVOSLAM_OK;
 }
 
@@ -327,15 +409,17 @@ int icp_cost(svoslam::DeviceBuffer &scratch, const float *lv, const float *ln, c
 
 // single-GPU iteration tail: sum the workgroup rows, solve, compose -- ONE launch
 __global__ __launch_bounds__(kReduceThreads) void cam_reduce_solve_kernel(CamState *st, const double *__restrict__ partial,
-                                                                          int rows, int slot, int flags) {
+                                                                          int rows, int slot, int flags,
+                                                                          const double *__restrict__ partial2, int rows2) {
   SVO_HIGH_PRIO();
   __shared__ double red[kReduceThreads / 32][27];
-  __shared__ double totals[27];
+  __shared__ double totals[27], totals2[27];
   __shared__ float tail_sm[kTailScratch];
   const TailPrefetch pre = tail_prefetch(st, flags);  // written by the previous launch
   reduce_rows(partial, rows, red, totals);
+  if (partial2) reduce_rows(partial2, rows2, red, totals2);  // photometric system (W_RGBD x it is added in the solve)
   if (threadIdx.x >= 64) return;  // the tail runs on the first wavefront
-  iteration_tail_wave(st, totals, slot, flags, tail_sm, pre);
+  iteration_tail_wave(st, totals, slot, flags, tail_sm, pre, partial2 ? totals2 : nullptr);
 }
 
 // multi-GPU iteration tail: acc[] holds the all-reduced sums
@@ -390,6 +474,13 @@ struct svoslam_camera {
   bool frame_has_icp = false;
   int ring_slot = 0;       // fusion_ring slot of the frame being / last tracked
   svoslam::GraphCache g_prep, g_track;  // recorded launch sequences (graph_cache.hpp)
+  // photometric RGB-D term (off by default = the reference, which ships it commented out): intensity and Sobel
+  // gradient pyramids per map set, rows of the photometric accumulate kernel
+  bool rgbd = false;
+  float *inten[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  float *grad[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  float *tmp_inten = nullptr, *tmp_inten2 = nullptr;
+  double *d_partial2 = nullptr;
   // one-launch tracker (track_persistent.hip)
   svoslam::TrackSync *d_sync = nullptr;
   double *d_rows = nullptr;
@@ -466,6 +557,14 @@ int camera_destroy(svoslam_camera *c) {
   }
   if (c->d_state) (void)hipFree(c->d_state);
   if (c->d_partial) (void)hipFree(c->d_partial);
+  for (int st = 0; st < 3; st++)
+    for (int i = 0; i < 3; i++) {
+      if (c->inten[st][i]) (void)hipFree(c->inten[st][i]);
+      if (c->grad[st][i]) (void)hipFree(c->grad[st][i]);
+    }
+  if (c->tmp_inten) (void)hipFree(c->tmp_inten);
+  if (c->tmp_inten2) (void)hipFree(c->tmp_inten2);
+  if (c->d_partial2) (void)hipFree(c->d_partial2);
   if (c->d_sync) (void)hipFree(c->d_sync);
   if (c->d_tickets) (void)hipFree(c->d_tickets);
   if (c->d_rows) (void)hipFree(c->d_rows);
@@ -474,8 +573,17 @@ int camera_destroy(svoslam_camera *c) {
 }
 
 // bilateral filter + the three pyramid levels of the incoming frame (rgbd_camera.cpp:62-93) into map set `set`
-static int enqueue_preprocess(const svoslam_camera *c, const uint16_t *d_depth, int set, hipStream_t s) {
+static int enqueue_preprocess(const svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, int set, hipStream_t s) {
   const int W = c->width, H = c->height;
+  if (c->rgbd) {  // :66-69, 85, 90: intensity pyramid by plain 2x2 subsampling; Sobel gradient of every level
+    SVO_TRY(color_to_intensity(d_rgb, c->tmp_inten, W * H, s));
+    for (int i = 0; i < 3; i++) {
+      const int w = W >> i, h = H >> i;
+      SVO_HIP(hipMemcpyAsync(c->inten[set][i], c->tmp_inten, (size_t)w * h * 4, hipMemcpyDeviceToDevice, s));
+      SVO_TRY(gradient(c->inten[set][i], c->grad[set][i], w, h, s));
+      if (i != 2) SVO_TRY(subsample_f32(c->tmp_inten, c->tmp_inten2, w, h, s));
+    }
+  }
   SVO_TRY(bilateral_filter(d_depth, c->filt[0], W, H, s));  // :62-64
   for (int i = 0; i < 3; i++) {                             // :72-93
     const int w = W >> i, h = H >> i;
@@ -490,8 +598,8 @@ static int enqueue_preprocess(const svoslam_camera *c, const uint16_t *d_depth, 
 // three before it (whose "last" set it overwrites) and before the camera_track of its own frame.
 int camera_prepare(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp, int32_t *processed,
                    hipStream_t s) {
-  (void)d_rgb;  // intensity only feeds the unimplemented RGB-D term (localization_kernels.cu:328-331)
   if (!c || !d_depth) return SVOSLAM_ERR_INVALID_ARG;
+  if (c->rgbd && !d_rgb) return SVOSLAM_ERR_INVALID_ARG;  // (without the photometric term the colours are not looked at)
   if (c->have_stamp && timestamp <= c->latest_stamp) {  // :55-59
     if (processed) *processed = 0;
     return SVOSLAM_OK;
@@ -502,8 +610,8 @@ int camera_prepare(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_
   if (processed) *processed = 1;
   const int set = (int)(c->prepared % 3u);
   GraphKey key;
-  key.add(d_depth).add((unsigned long long)set);
-  SVO_TRY(c->g_prep.run(key, s, [&]() -> int { return enqueue_preprocess(c, d_depth, set, s); }));
+  key.add(d_depth).add((unsigned long long)set).add(c->rgbd ? d_rgb : nullptr);
+  SVO_TRY(c->g_prep.run(key, s, [&]() -> int { return enqueue_preprocess(c, d_depth, d_rgb, set, s); }));
   c->prepared++;
   return SVOSLAM_OK;
 }
@@ -513,6 +621,7 @@ int camera_begin(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rg
   if (!c) return SVOSLAM_ERR_INVALID_ARG;
   int32_t used = 0;
   if (c->prepared != c->tracked) return SVOSLAM_ERR_INVALID_ARG;  // a prepared frame is waiting for camera_track
+  if (c->rgbd) return SVOSLAM_ERR_INVALID_ARG;  // the stepping API carries the geometric system only
   SVO_TRY(camera_prepare(c, d_depth, d_rgb, timestamp, &used, s));
   if (processed) *processed = used;
   c->frame_has_icp = used && c->tracked >= 1;
@@ -611,7 +720,7 @@ int camera_track(svoslam_camera *c, hipStream_t s) {
   if (c->tracked >= c->prepared) return SVOSLAM_ERR_INVALID_ARG;  // nothing prepared
   const bool has_icp = c->tracked >= 1;
   const int ring_slot = (int)(c->tracked & 3u);
-  if (has_icp && !track_chain_forced()) {
+  if (has_icp && !track_chain_forced() && !c->rgbd) {
     const int rc = track_one_launch(c, s);
     if (rc < 0) return rc;
     if (rc == 0) {
@@ -623,18 +732,25 @@ int camera_track(svoslam_camera *c, hipStream_t s) {
   }
   GraphKey key;
   key.add((unsigned long long)(c->tracked % 3u)).add((unsigned long long)has_icp)
-     .add((unsigned long long)c->band_first).add((unsigned long long)c->band_rows);
+     .add((unsigned long long)c->band_first).add((unsigned long long)c->band_rows).add((unsigned long long)c->rgbd);
   auto enqueue = [&]() -> int {
     if (has_icp) {
       for (int level = 2; level >= 0; level--) {  // coarse to fine, :103
         LevelArgs a = level_args(c, level);
         int end;
         const int blocks = accumulate_range(a.w, a.h, a.first, a.num, end);
+        const int cur = (int)(c->tracked % 3u), last = (int)((c->tracked + 2u) % 3u);
+        int blocks2 = (int)cdiv(a.w * a.h, kIcpThreads);
+        if (blocks2 > kMaxIcpBlocks) blocks2 = kMaxIcpBlocks;
         for (int it = 0; it < kPyramidIters[level]; it++) {
           const int flags = iter_flags(level, it);
           icp_accumulate_kernel<<<blocks, kIcpThreads, 0, s>>>(a.lv, a.ln, a.cv, a.cn, a.first, end, c->d_state, flags, it,
                                                                c->d_partial);
-          cam_reduce_solve_kernel<<<1, kReduceThreads, 0, s>>>(c->d_state, c->d_partial, blocks, it, flags);
+          if (c->rgbd)  // rgbd_camera.cpp:126-128 (there commented out): the photometric system of the same estimate
+            rgbd_accumulate_kernel<<<blocks2, kIcpThreads, 0, s>>>(c->inten[last][level], c->grad[last][level], a.lv, c->inten[cur][level],
+                                                                   a.cv, 0, a.w * a.h, c->fx, c->fy, (float)(c->width / a.w),
+                                                                   (float)(c->height / a.h), c->d_state, flags, it, c->d_partial2);
+          cam_reduce_solve_kernel<<<1, kReduceThreads, 0, s>>>(c->d_state, c->d_partial, blocks, it, flags, c->rgbd ? c->d_partial2 : nullptr, blocks2);
         }
       }
     } else {  // first frame: no ICP, only the fusion transform (the last solve does it otherwise)
@@ -660,6 +776,27 @@ int camera_update(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_r
   if (processed) *processed = used;
   if (!used) return SVOSLAM_OK;
   return camera_track(c, s);
+}
+
+// RGBDCamera with the photometric term of rgbd_camera.cpp:126-141 switched on (W_RGBD = 0.1); before the first frame only
+int camera_set_rgbd(svoslam_camera *c, int enable) {
+  if (!c) return SVOSLAM_ERR_INVALID_ARG;
+  if (c->prepared != 0 && (enable != 0) != c->rgbd) return SVOSLAM_ERR_INVALID_ARG;
+  if (enable && !c->tmp_inten) {
+    const size_t n0 = (size_t)c->width * c->height;
+    SVO_HIP(hipMalloc((void **)&c->tmp_inten, n0 * 4));
+    SVO_HIP(hipMalloc((void **)&c->tmp_inten2, n0));
+    SVO_HIP(hipMalloc((void **)&c->d_partial2, (size_t)kMaxIcpBlocks * 27 * sizeof(double)));
+    for (int i = 0; i < 3; i++) {
+      const size_t n = (size_t)(c->width >> i) * (size_t)(c->height >> i);
+      for (int st = 0; st < 3; st++) {
+        SVO_HIP(hipMalloc((void **)&c->inten[st][i], n * 4));
+        SVO_HIP(hipMalloc((void **)&c->grad[st][i], n * 8));
+      }
+    }
+  }
+  c->rgbd = enable != 0;
+  return SVOSLAM_OK;
 }
 
 int camera_set_band(svoslam_camera *c, int first_row, int rows) {

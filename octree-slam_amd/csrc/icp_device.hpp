@@ -13,6 +13,10 @@ __device__ constexpr float kNormThresh = 0.87f;  // :18
 constexpr double kScaleA = 1048576.0;            // 2^20
 constexpr double kScaleB = 1073741824.0;         // 2^30
 constexpr int kMaxChain = 10;                    // max(PYRAMID_ITERS)
+// photometric RGB-D term (own specification, oracle/svoslam_oracle.c "photometric RGB-D term")
+__device__ constexpr float kWeightRgbd = 0.1f;   // W_RGBD, rgbd_camera.cpp:20
+constexpr double kScaleRgbdA = 256.0;            // 2^8
+constexpr double kScaleRgbdB = 1048576.0;        // 2^20
 
 struct CamState {
   double acc[27];
@@ -93,6 +97,44 @@ __device__ __forceinline__ void icp_pixel_terms(float v1x, float v1y, float v1z,
   for (int i = 0; i < 6; i++) {
     const float prod = bb * J[i];
     const float q = rintf(prod * 1073741824.0f);
+    acc[21 + i] += (double)(ok ? q : 0.0f);
+  }
+}
+
+// The 27 exact terms of the photometric system for one pixel (oracle: ora_rgbd_cost_raw): same-index association,
+// residual r = I_last - I_cur, Jacobian through the pinhole derivative at the current vertex and the geometric term's
+// own G_T rows.  ax = (fx / z) / sx, ay = (fy / z) / sy with sx, sy the level's pixel pitch in full-resolution pixels.
+__device__ __forceinline__ void rgbd_pixel_terms(float v1x, float v1y, float v1z, float v2x, float v2y, float v2z, float gx, float gy,
+                                                 float r, float fx, float fy, float sx, float sy, double (&acc)[27]) {
+  bool ok = finitef_(v2x) && finitef_(v2y) && finitef_(v2z) && finitef_(v1x) && finitef_(v1y) && finitef_(v1z) &&
+            !(v1z < 0.1f) && !(v2z < 0.1f) && !(v1z > 10.0f) && !(v2z > 10.0f);
+  const float dx = v2x - v1x, dy = v2y - v1y, dz = v2z - v1z;
+  ok = ok && !(sqrtf(dot3(dx, dy, dz, dx, dy, dz)) > kDistThresh);
+  const float iz = 1.0f / v2z;
+  const float ax = (fx * iz) / sx, ay = (fy * iz) / sy;
+  const float wx = gx * ax;
+  const float wy = -(gy * ay);
+  const float wz = (gy * ay) * (v2y * iz) - (gx * ax) * (v2x * iz);
+  float J[6];
+  J[0] = (0.0f * wx + (-v2x) * wy) + (-v2y) * wz;
+  J[1] = ((-v2z) * wx + 0.0f * wy) + v2x * wz;
+  J[2] = (v2y * wx + v2z * wy) + 0.0f * wz;
+  J[3] = (1.0f * wx + 0.0f * wy) + 0.0f * wz;
+  J[4] = (0.0f * wx + 1.0f * wy) + 0.0f * wz;
+  J[5] = (0.0f * wx + 0.0f * wy) + 1.0f * wz;
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = i; j < 6; j++) {
+      const float prod = J[i] * J[j];
+      const float q = rintf(prod * 256.0f);
+      acc[k++] += (double)(ok ? q : 0.0f);
+    }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const float prod = r * J[i];
+    const float q = rintf(prod * 1048576.0f);
     acc[21 + i] += (double)(ok ? q : 0.0f);
   }
 }
@@ -218,7 +260,8 @@ __device__ inline float lane_bcast(float v, int src_lane) {
 }
 
 // must be called by all 64 lanes of a wavefront; sums = 27 doubles at a uniform address; x[6] on every lane
-__device__ inline void wave_solve_cholesky(const double *sums, float *x, float &a_elem, float &b_elem) {
+// sums2 (optional): the photometric system's 27 sums; A = A1 + W_RGBD * A2, b likewise (rgbd_camera.cpp:130-141)
+__device__ inline void wave_solve_cholesky(const double *sums, const double *sums2, float *x, float &a_elem, float &b_elem) {
   const int lane = (int)(threadIdx.x & 63u);
   const int row = lane < 6 ? lane : 5;  // spare lanes shadow row 5
   // A is symmetric, sums hold its upper triangle row by row: index of (i <= j) = i*6 - i*(i-1)/2 + (j - i)
@@ -226,14 +269,19 @@ __device__ inline void wave_solve_cholesky(const double *sums, float *x, float &
 #pragma unroll
   for (int c = 0; c < 6; c++) {
     const int i = row < c ? row : c, j = row < c ? c : row;
-    a[c] = (float)(sums[i * 6 - (i * (i - 1)) / 2 + (j - i)] * (1.0 / kScaleA));
+    const int idx = i * 6 - (i * (i - 1)) / 2 + (j - i);
+    a[c] = (float)(sums[idx] * (1.0 / kScaleA));
+    if (sums2) a[c] = a[c] + kWeightRgbd * (float)(sums2[idx] * (1.0 / kScaleRgbdA));
     lu[c] = 0.0f;
   }
-  const float b_own = (float)(sums[21 + row] * (1.0 / kScaleB));
+  float b_own = (float)(sums[21 + row] * (1.0 / kScaleB));
+  if (sums2) b_own = b_own + kWeightRgbd * (float)(sums2[21 + row] * (1.0 / kScaleRgbdB));
   {  // element `lane` of the row-major A (for the diagnostics copy), b likewise
     const int e = lane < 36 ? lane : 35, r = e / 6, c = e % 6;
     const int i = r < c ? r : c, j = r < c ? c : r;
-    a_elem = (float)(sums[i * 6 - (i * (i - 1)) / 2 + (j - i)] * (1.0 / kScaleA));
+    const int idx = i * 6 - (i * (i - 1)) / 2 + (j - i);
+    a_elem = (float)(sums[idx] * (1.0 / kScaleA));
+    if (sums2) a_elem = a_elem + kWeightRgbd * (float)(sums2[idx] * (1.0 / kScaleRgbdA));
     b_elem = b_own;
   }
 #pragma unroll
@@ -335,7 +383,7 @@ __device__ inline TailPrefetch tail_prefetch(const CamState *st, int flags) {
 }
 
 __device__ inline TailResult iteration_tail_wave(CamState *st, const double *sums, int slot, int flags, volatile float *sm,
-                                                 const TailPrefetch &pre) {
+                                                 const TailPrefetch &pre, const double *sums2 = nullptr) {
   TailResult res;
   res.tt = 0.0f; res.solved = 0;
   const int lane = (int)(threadIdx.x & 63u), e = lane & 15;
@@ -351,7 +399,7 @@ __device__ inline TailResult iteration_tail_wave(CamState *st, const double *sum
   if ((flags & kFlagFirstOfFrame) && lane < 16) st->update_trans[e] = ut;
   if (!lost) {
     float x[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, a_elem, b_elem;
-    wave_solve_cholesky(sums, x, a_elem, b_elem);
+    wave_solve_cholesky(sums, sums2, x, a_elem, b_elem);
     if (lane < 36) st->lastA[lane] = a_elem;
     if (lane < 6) { st->lastb[lane] = b_elem; st->lastx[lane] = x[lane < 6 ? lane : 0]; }
     if (x[0] != x[0] || x[1] != x[1] || x[2] != x[2] || x[3] != x[3] || x[4] != x[4] || x[5] != x[5]) {

@@ -183,6 +183,28 @@ __global__ __launch_bounds__(256) void color_to_intensity_kernel(const uint8_t *
   out[i] = (r * 0.299f + b * 0.587f) + b * 0.114f;
 }
 
+// gradient / difference: declared by the reference (image_kernels.h:45-49), never defined; this build's own
+// specification (oracle: ora_gradient / ora_difference): Sobel 3x3 / 8 on interior pixels, (0,0) on the border
+__global__ __launch_bounds__(256) void gradient_kernel(const float *__restrict__ in, float2 *__restrict__ grad, int w, int h) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= w * h) return;
+  const int x = i % w, y = i / w;
+  float2 g = make_float2(0.0f, 0.0f);
+  if (x > 0 && y > 0 && x < w - 1 && y < h - 1) {
+    const float *r0 = in + (size_t)(y - 1) * w + x, *r1 = in + (size_t)y * w + x, *r2 = in + (size_t)(y + 1) * w + x;
+    const float gx = ((r0[1] - r0[-1]) + 2.0f * (r1[1] - r1[-1])) + (r2[1] - r2[-1]);
+    const float gy = ((r2[-1] - r0[-1]) + 2.0f * (r2[0] - r0[0])) + (r2[1] - r0[1]);
+    g = make_float2(gx * 0.125f, gy * 0.125f);
+  }
+  grad[i] = g;
+}
+
+__global__ __launch_bounds__(256) void difference_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                         float *__restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = a[i] - b[i];
+}
+
 // ----------------------------------------------------------------------------
 // rigid transforms (image_kernels.cu:206-234) ; Q19: INF * 0 -> NaN
 // ----------------------------------------------------------------------------
@@ -350,6 +372,22 @@ int color_to_intensity(const uint8_t *d_rgb, float *d_out, int n, hipStream_t s)
   if (!d_rgb || !d_out || n < 0) return SVOSLAM_ERR_INVALID_ARG;
   if (n == 0) return SVOSLAM_OK;
   color_to_intensity_kernel<<<cdiv(n, 256), 256, 0, s>>>(d_rgb, d_out, n);
+  SVO_LAUNCH_CHECK();
+  return SVOSLAM_OK;
+}
+
+int gradient(const float *d_in, float *d_grad2, int w, int h, hipStream_t s) {
+  if (!d_in || !d_grad2) return SVOSLAM_ERR_INVALID_ARG;
+  CHECK_DIMS(w, h);
+  gradient_kernel<<<cdiv((long long)w * h, 256), 256, 0, s>>>(d_in, reinterpret_cast<float2 *>(d_grad2), w, h);
+  SVO_LAUNCH_CHECK();
+  return SVOSLAM_OK;
+}
+
+int difference(const float *d_in1, const float *d_in2, float *d_out, int n, hipStream_t s) {
+  if (!d_in1 || !d_in2 || !d_out || n < 0) return SVOSLAM_ERR_INVALID_ARG;
+  if (n == 0) return SVOSLAM_OK;
+  difference_kernel<<<cdiv(n, 256), 256, 0, s>>>(d_in1, d_in2, d_out, n);
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
 }

@@ -18,6 +18,8 @@ int subsample_depth_f32(float *d_data, float *d_tmp, int w, int h, hipStream_t s
 int subsample_depth_u16_to(const uint16_t *d_in, uint16_t *d_out, int w, int h, hipStream_t s);
 int subsample_f32(float *d_data, float *d_tmp, int w, int h, hipStream_t s);
 int subsample_rgb8(uint8_t *d_data, uint8_t *d_tmp, int w, int h, hipStream_t s);
+int gradient(const float *d_in, float *d_grad2, int w, int h, hipStream_t s);       // Sobel / 8, (gx, gy) per pixel
+int difference(const float *d_in1, const float *d_in2, float *d_out, int n, hipStream_t s);
 int color_to_intensity(const uint8_t *d_rgb, float *d_out, int n, hipStream_t s);
 int transform_vertex_map(float *d_v, const float trans[16], int n, hipStream_t s);
 int transform_normal_map(float *d_v, const float trans[16], int n, hipStream_t s);

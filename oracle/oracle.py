@@ -75,6 +75,10 @@ def lib(native=False):
     L.ora_transform_normal_map.argtypes = [f32p, f32p, C.c_int]
     L.ora_point_cloud_bbox.argtypes = [f32p, C.c_int, f32p, f32p]
     L.ora_icp_cost2.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p]
+    L.ora_gradient.argtypes = [f32p, f32p, C.c_int, C.c_int]
+    L.ora_difference.argtypes = [f32p, f32p, f32p, C.c_int]
+    L.ora_rgbd_cost.argtypes = [f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, f32p, f32p]
+    L.ora_camera_set_rgbd.argtypes = [C.c_void_p, C.c_int]
     L.ora_icp_cost.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p]
     L.ora_icp_cost.restype = C.c_int
     L.ora_icp_cost2_raw.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, i64p]
@@ -307,6 +311,31 @@ def point_cloud_bbox(points, bbox0=(0, 0, 0), bbox1=(0, 0, 0)):
     return b0, b1
 
 
+def gradient(img):
+    """Sobel / 8 (own specification of the reference's declared-only gradient()) -> [h, w, 2]"""
+    a = _f32(img)
+    h, w = a.shape
+    out = np.zeros((h, w, 2), np.float32)
+    lib().ora_gradient(_p(a, C.c_float), _p(out, C.c_float), w, h)
+    return out
+
+
+def difference(a, b):
+    a, b = _f32(a), _f32(b)
+    out = np.zeros_like(a)
+    lib().ora_difference(_p(a, C.c_float), _p(b, C.c_float), _p(out, C.c_float), a.size)
+    return out
+
+
+def rgbd_cost(last_i, last_g, last_v, cur_i, cur_v, fx, fy, img_w, img_h):
+    li, lg, lv, ci, cv = (_f32(x) for x in (last_i, last_g, last_v, cur_i, cur_v))
+    h, w = li.shape
+    A, b = np.zeros(36, np.float32), np.zeros(6, np.float32)
+    lib().ora_rgbd_cost(_p(li, C.c_float), _p(lg, C.c_float), _p(lv, C.c_float), _p(ci, C.c_float), _p(cv, C.c_float), w, h,
+                        C.c_float(fx), C.c_float(fy), img_w, img_h, _p(A, C.c_float), _p(b, C.c_float))
+    return A.reshape(6, 6), b
+
+
 def icp_cost2(last_v, last_n, cur_v, cur_n, L=None):
     lv, ln, cv, cn = _f32(last_v), _f32(last_n), _f32(cur_v), _f32(cur_n)
     h, w, _ = lv.shape
@@ -410,6 +439,9 @@ class Camera:
         p = np.empty(3, np.float32); o = np.empty(9, np.float32)
         self._L.ora_camera_pose(self._c, _p(p, C.c_float), _p(o, C.c_float))
         return p, o
+
+    def set_rgbd(self, enable=True):
+        self._L.ora_camera_set_rgbd(self._c, 1 if enable else 0)
 
     def tracking_lost_count(self):
         return int(self._L.ora_camera_tracking_lost_count(self._c))

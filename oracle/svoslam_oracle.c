@@ -1073,6 +1073,91 @@ void ora_icp_update_transform(const float x[6], float out[16]) {
 #define PYR 3
 static const int PYRAMID_ITERS[PYR] = {10, 5, 4};
 
+/* ---- photometric RGB-D term -------------------------------------------------------------------------
+ * The reference DECLARES gradient / difference (image_kernels.h:45-49) and computeRGBDCost (localization_kernels.h:42)
+ * but ships no definition of the first two and an empty body for the third (localization_kernels.cu:328-331); the call
+ * site is commented out (rgbd_camera.cpp:126-141), W_RGBD = 0.1 (:20).  There is NO reference behaviour to match: what
+ * follows is this build's own specification, restated here as the checker of the HIP kernels.
+ *   gradient    Sobel 3x3 / 8 on interior pixels, (0,0) on the border
+ *   difference  out = in1 - in2
+ *   rgbd cost   same-index association like computeICPCost2 (no reprojection); residual r = I_last - I_cur; Jacobian
+ *               J = G_T * (gx * du/dv + gy * dv/dv) with the last frame's gradient, the pinhole derivative at the
+ *               current (already transformed) vertex and the SAME G_T rows as the geometric term (:208-213, Q14), so
+ *               that both systems share one parametrisation; exact fixed-point sums (2^8 for A, 2^20 for b). */
+#define ORA_W_RGBD 0.1f
+#define RGBD_SCALE_A 256.0
+#define RGBD_SCALE_B 1048576.0
+
+void ora_gradient(const float *in, float *grad, int w, int h) {
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      float *g = grad + 2 * ((size_t)y * w + x);
+      if (x == 0 || y == 0 || x == w - 1 || y == h - 1) { g[0] = 0.0f; g[1] = 0.0f; continue; }
+      const float *r0 = in + (size_t)(y - 1) * w + x, *r1 = in + (size_t)y * w + x, *r2 = in + (size_t)(y + 1) * w + x;
+      float gx = ((r0[1] - r0[-1]) + 2.0f * (r1[1] - r1[-1])) + (r2[1] - r2[-1]);
+      float gy = ((r2[-1] - r0[-1]) + 2.0f * (r2[0] - r0[0])) + (r2[1] - r0[1]);
+      g[0] = gx * 0.125f; g[1] = gy * 0.125f;
+    }
+}
+
+void ora_difference(const float *in1, const float *in2, float *out, int n) {
+  for (int i = 0; i < n; i++) out[i] = in1[i] - in2[i];
+}
+
+void ora_rgbd_cost_raw(const float *last_i, const float *last_g, const float *last_v, const float *cur_i, const float *cur_v,
+                       int w, int h, float fx, float fy, int img_w, int img_h, int64_t acc[27]) {
+  for (int i = 0; i < 27; i++) acc[i] = 0;
+  const float sx = (float)(img_w / w), sy = (float)(img_h / h); /* level pixels per full-resolution pixel, as generateVertexMap */
+  for (int p = 0; p < w * h; p++) {
+    const float *v2 = cur_v + 3 * (size_t)p, *v1 = last_v + 3 * (size_t)p;
+    if (!finitef_(v2[0]) || !finitef_(v2[1]) || !finitef_(v2[2]) || !finitef_(v1[0]) || !finitef_(v1[1]) ||
+        !finitef_(v1[2]) || (v1[2] < 0.1f) || (v2[2] < 0.1f) || (v1[2] > 10.0f) || (v2[2] > 10.0f))
+      continue;
+    float d[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
+    if (length3(d) > ICP_DIST_THRESH) continue;
+    const float gx = last_g[2 * (size_t)p], gy = last_g[2 * (size_t)p + 1];
+    const float r = last_i[p] - cur_i[p];
+    const float iz = 1.0f / v2[2];
+    const float ax = (fx * iz) / sx, ay = (fy * iz) / sy; /* d u / d X,  -(d v / d Y) */
+    float wv[3];
+    wv[0] = gx * ax;
+    wv[1] = -(gy * ay);
+    wv[2] = (gy * ay) * (v2[1] * iz) - (gx * ax) * (v2[0] * iz);
+    const float G_T[18] = {0.0f, -v2[0], -v2[1], -v2[2], 0.0f, v2[0], v2[1], v2[2], 0.0f,
+                           1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f};
+    float J[6];
+    for (int i = 0; i < 6; i++) J[i] = (G_T[3 * i] * wv[0] + G_T[3 * i + 1] * wv[1]) + G_T[3 * i + 2] * wv[2];
+    int k = 0;
+    for (int i = 0; i < 6; i++)
+      for (int j = i; j < 6; j++) {
+        float prod = J[i] * J[j];
+        acc[k++] += (int64_t)rint((double)prod * RGBD_SCALE_A);
+      }
+    for (int i = 0; i < 6; i++) {
+      float prod = r * J[i];
+      acc[21 + i] += (int64_t)rint((double)prod * RGBD_SCALE_B);
+    }
+  }
+}
+
+void ora_rgbd_finish(const int64_t acc[27], float A[36], float b[6]) {
+  int k = 0;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++) {
+      float v = (float)((double)acc[k++] * (1.0 / RGBD_SCALE_A));
+      A[6 * i + j] = v;
+      A[6 * j + i] = v;
+    }
+  for (int i = 0; i < 6; i++) b[i] = (float)((double)acc[21 + i] * (1.0 / RGBD_SCALE_B));
+}
+
+void ora_rgbd_cost(const float *last_i, const float *last_g, const float *last_v, const float *cur_i, const float *cur_v, int w, int h,
+                   float fx, float fy, int img_w, int img_h, float A[36], float b[6]) {
+  int64_t acc[27];
+  ora_rgbd_cost_raw(last_i, last_g, last_v, cur_i, cur_v, w, h, fx, fy, img_w, img_h, acc);
+  ora_rgbd_finish(acc, A, b);
+}
+
 struct ora_camera {
   int width, height;
   float fx, fy;
@@ -1083,6 +1168,9 @@ struct ora_camera {
   float *last_v[PYR], *last_n[PYR], *cur_v[PYR], *cur_n[PYR];
   float lastA[36], lastb[6], lastx[6];
   int lost_count; /* levels abandoned with "Camera tracking is lost." (rgbd_camera.cpp:148-151) */
+  /* photometric RGB-D term (off by default = the reference, which ships it commented out) */
+  int rgbd;
+  float *last_i[PYR], *cur_i[PYR], *last_g[PYR], *cur_g[PYR]; /* intensity and its Sobel gradient per level */
 };
 
 ora_camera *ora_camera_create(int w, int h, float fx, float fy) {
@@ -1103,6 +1191,7 @@ ora_camera *ora_camera_create(int w, int h, float fx, float fy) {
 void ora_camera_destroy(ora_camera *c) {
   if (!c) return;
   for (int i = 0; i < PYR; i++) { free(c->last_v[i]); free(c->last_n[i]); free(c->cur_v[i]); free(c->cur_n[i]); }
+  for (int i = 0; i < PYR; i++) { free(c->last_i[i]); free(c->cur_i[i]); free(c->last_g[i]); free(c->cur_g[i]); }
   free(c);
 }
 
@@ -1113,10 +1202,20 @@ static void mat3_to_mat4(const float m3[9], float m4[16]) {
 }
 
 int ora_camera_update(ora_camera *c, const uint16_t *depth, const uint8_t *rgb, long long timestamp) {
-  (void)rgb; /* intensity feeds only the unimplemented RGB-D term (localization_kernels.cu:328-331) */
   if (timestamp <= c->latest_stamp) return 0;
   c->latest_stamp = timestamp;
   const int W = c->width, H = c->height;
+  if (c->rgbd) { /* rgbd_camera.cpp:66-69,85,90: intensity pyramid by plain 2x2 subsampling; + Sobel gradient per level */
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)W * H);
+    ora_color_to_intensity(rgb, tmp, W * H);
+    for (int i = 0; i < PYR; i++) {
+      int w = W >> i, h = H >> i;
+      memcpy(c->cur_i[i], tmp, sizeof(float) * (size_t)w * h);
+      ora_gradient(c->cur_i[i], c->cur_g[i], w, h);
+      if (i != PYR - 1) ora_subsample_f32(tmp, w, h);
+    }
+    free(tmp);
+  }
   uint16_t *filtered = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)W * H);
   ora_bilateral_filter(depth, filtered, W, H);
   for (int i = 0; i < PYR; i++) { /* rgbd_camera.cpp:72-93 */
@@ -1141,6 +1240,12 @@ int ora_camera_update(ora_camera *c, const uint16_t *depth, const uint8_t *rgb, 
       for (int j = 0; j < PYRAMID_ITERS[i]; j++) {
         float A1[36], b1[6], x[6];
         ora_icp_cost2(c->last_v[i], c->last_n[i], fv, fn, w, h, A1, b1);
+        if (c->rgbd) { /* rgbd_camera.cpp:126-141 with W_RGBD (:20) applied to the photometric system */
+          float A2[36], b2[6];
+          ora_rgbd_cost(c->last_i[i], c->last_g[i], c->last_v[i], c->cur_i[i], fv, w, h, c->fx, c->fy, W, H, A2, b2);
+          for (int k = 0; k < 36; k++) A1[k] = A1[k] + ORA_W_RGBD * A2[k];
+          for (int k = 0; k < 6; k++) b1[k] = b1[k] + ORA_W_RGBD * b2[k];
+        }
         ora_solve_cholesky(6, A1, b1, x);
         memcpy(c->lastA, A1, sizeof(A1)); memcpy(c->lastb, b1, sizeof(b1)); memcpy(c->lastx, x, sizeof(x));
         if (x[0] != x[0] || x[1] != x[1] || x[2] != x[2] || x[3] != x[3] || x[4] != x[4] || x[5] != x[5]) { c->lost_count++; break; }
@@ -1169,8 +1274,21 @@ int ora_camera_update(ora_camera *c, const uint16_t *depth, const uint8_t *rgb, 
     float *t;
     t = c->cur_v[i]; c->cur_v[i] = c->last_v[i]; c->last_v[i] = t;
     t = c->cur_n[i]; c->cur_n[i] = c->last_n[i]; c->last_n[i] = t;
+    t = c->cur_i[i]; c->cur_i[i] = c->last_i[i]; c->last_i[i] = t;
+    t = c->cur_g[i]; c->cur_g[i] = c->last_g[i]; c->last_g[i] = t;
   }
   return 1;
+}
+
+void ora_camera_set_rgbd(ora_camera *c, int enable) {
+  c->rgbd = enable != 0;
+  for (int i = 0; i < PYR && enable; i++) {
+    size_t n = (size_t)(c->width >> i) * (size_t)(c->height >> i);
+    if (!c->last_i[i]) {
+      c->last_i[i] = (float *)calloc(n, sizeof(float)); c->cur_i[i] = (float *)calloc(n, sizeof(float));
+      c->last_g[i] = (float *)calloc(2 * n, sizeof(float)); c->cur_g[i] = (float *)calloc(2 * n, sizeof(float));
+    }
+  }
 }
 
 int ora_camera_tracking_lost_count(const ora_camera *c) { return c->lost_count; }

@@ -107,6 +107,15 @@ void ora_icp_cost2_raw(const float *last_v, const float *last_n, const float *cu
                        const float *cur_n, int first_pixel, int num_pixels, int w, int h,
                        int64_t acc[27]);
 void ora_icp_finish(const int64_t acc[27], float A[36], float b[6]);
+/* photometric RGB-D term: this build's own specification (the reference declares, never defines: image_kernels.h:45-49,
+ * localization_kernels.cu:328-331, rgbd_camera.cpp:126-141) */
+void ora_gradient(const float *in, float *grad2, int w, int h);
+void ora_difference(const float *in1, const float *in2, float *out, int n);
+void ora_rgbd_cost_raw(const float *last_i, const float *last_g, const float *last_v, const float *cur_i, const float *cur_v,
+                       int w, int h, float fx, float fy, int img_w, int img_h, int64_t acc[27]);
+void ora_rgbd_finish(const int64_t acc[27], float A[36], float b[6]);
+void ora_rgbd_cost(const float *last_i, const float *last_g, const float *last_v, const float *cur_i, const float *cur_v, int w, int h,
+                   float fx, float fy, int img_w, int img_h, float A[36], float b[6]);
 /* rgbd_camera.cpp:194-222 */
 void ora_solve_cholesky(int dim, const float *A, const float *b, float *x);
 
@@ -129,6 +138,7 @@ void ora_camera_destroy(ora_camera *c);
 int ora_camera_update(ora_camera *c, const uint16_t *depth, const uint8_t *rgb, long long timestamp);
 void ora_camera_pose(const ora_camera *c, float position[3], float orientation[9]);
 int ora_camera_tracking_lost_count(const ora_camera *c);
+void ora_camera_set_rgbd(ora_camera *c, int enable); /* adds W_RGBD x the photometric system to every ICP iteration */
 /* model matrix used by main.cpp:40 : mat4(orientation) * translate(I, position) */
 void ora_camera_fusion_transform(const ora_camera *c, float out[16]);
 /* last A,b,x of the last processed frame, for tests */

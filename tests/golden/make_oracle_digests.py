@@ -50,6 +50,23 @@ def compute():
     out["icp_cost2_60x80"] = {"sha256": digest(A, b)}
     A, b, m = ora.icp_cost(v1, n1, v2, n2)
     out["icp_cost_60x80"] = {"correspondences": int(m), "sha256": digest(A, b)}
+    # photometric RGB-D term (own specification)
+    i1 = (0.5 + 0.4 * np.sin(xx / 5.0) * np.cos(yy / 7.0)).astype(np.float32)
+    i2 = (0.5 + 0.4 * np.sin((xx + 0.7) / 5.0) * np.cos(yy / 7.0)).astype(np.float32)
+    g1 = ora.gradient(i1)
+    out["gradient_60x80"] = {"sha256": digest(g1)}
+    A, b = ora.rgbd_cost(i1, g1, v1, i2, v2, f, f, w, h)
+    out["rgbd_cost_60x80"] = {"sha256": digest(A, b)}
+    import importlib
+    import svoslam_pkg
+    svoslam_pkg.load()
+    synth = importlib.import_module("octree_slam_amd.synth")
+    cam = ora.Camera(160, 120, 142.575, 142.575)
+    cam.set_rgbd(True)
+    for k in range(4):
+        d, c = synth.render_frame(k, 160, 120)
+        cam.update(d.numpy().view(np.uint16), c.numpy(), k)
+    out["camera_rgbd_160x120_4frames"] = {"sha256": digest(*cam.pose(), *cam.last_system())}
     return out
 
 
