@@ -177,7 +177,16 @@ struct RGBDFrame {  // localization_kernels.h:26-33
 };
 // localization_kernels.h:42 / localization_kernels.cu:328-331: an empty stub in the reference (A and b are left untouched);
 // kept so that callers link
+// localization_kernels.h:42: an empty body in the reference (localization_kernels.cu:328-331), kept so (the frames
+// carry no intrinsics).  The overload below is this library's own photometric term (svoslam.h "Photometric RGB-D term"):
+// last_gradient = gradient() of last_frame->intensity; fx, fy in pixels of the full img_width x img_height image.
 inline void computeRGBDCost(const RGBDFrame *, const RGBDFrame &, float *, float *) {}
+inline void computeRGBDCost(const RGBDFrame *last_frame, const vec2 *last_gradient, const RGBDFrame &this_frame, const vec2 &focal_length,
+                            const int img_width, const int img_height, float *A, float *b) {
+  detail::check(svoslam_rgbd_cost(last_frame->intensity, &last_gradient->x, &last_frame->vertex->x, this_frame.intensity,
+                                  &this_frame.vertex->x, this_frame.width, this_frame.height, focal_length.x, focal_length.y, img_width,
+                                  img_height, A, b, nullptr), "computeRGBDCost");
+}
 // image_kernels.h:24-55
 inline void generateVertexMap(const uint16_t *depth_pixels, vec3 *vertex_map, const int width, const int height,
                               const vec2 focal_length, const int2_t img_size) {
@@ -227,6 +236,13 @@ template <> inline void subsampleDepth<uint16_t>(uint16_t *data, const int width
 }
 template <> inline void subsampleDepth<float>(float *data, const int width, const int height) {
   sub_detail::subsample_with<float>(svoslam_subsample_depth_f32, data, width, height, "subsampleDepth<float>");
+}
+// image_kernels.h:45-49: declared by the reference, defined nowhere; own specification (Sobel / 8; in1 - in2)
+inline void gradient(const float *intensity_in, vec2 *gradient_out, const int width, const int height) {
+  detail::check(svoslam_gradient(intensity_in, &gradient_out->x, width, height, nullptr), "gradient");
+}
+inline void difference(const float *in1, const float *in2, float *out, const int size) {
+  detail::check(svoslam_difference(in1, in2, out, size, nullptr), "difference");
 }
 inline void colorToIntensity(const Color256 *color_in, float *intensity_out, const int size) {
   detail::check(svoslam_color_to_intensity(&color_in->r, intensity_out, size, nullptr), "colorToIntensity");
