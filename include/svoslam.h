@@ -100,6 +100,20 @@ int svoslam_pool_touch(svoslam_pool *pool);
 /* Replaces the pool's contents by num_nodes host nodes (2 words each, reference format; child pointers validated) and
  * resets all size bookkeeping incl. the device-resident size the asynchronous fusion allocates from.  Blocking. */
 int svoslam_pool_set_nodes(svoslam_pool *pool, const uint32_t *h_words, int32_t num_nodes, void *stream);
+/* Out-of-core paging of sub-trees through the linear-tree format (the reference's unfinished
+ * OctreeNode::pushToGPU / pullToCPU / addToLinearTree / pullFromLinearTree, src/world/octree.cpp:41-169).
+ * evict: the sub-tree below the node reached by `path` (octants 0..7 from the root, `levels` of them; the node must have
+ *   children) is written to `file` as a stand-alone linear tree (2-word nodes, bit 30 = children, low 30 bits = index
+ *   of the first child inside the file's own array, the sub-tree's 8 top nodes first) plus the original tile indices;
+ *   in the pool the node becomes childless (it keeps its colour word) and the tiles are zeroed.
+ * restore: the tiles return to the indices they came from; the pool is then bit-identical to one that was never
+ *   paged, also when other parts of the map were fused meanwhile (resume == uninterrupted).  Refused with
+ *   SVOSLAM_ERR_INVALID_ARG when the cube has been fused into while it was out.
+ * svoslam_subtree_file_nodes: the file's linear tree as host words (free() them) -- a pool of its own for
+ *   svoslam_pool_set_nodes.  Node indices are never re-used, so eviction does not shrink the allocation.  Blocking. */
+int svoslam_pool_evict_subtree(svoslam_pool *pool, const uint8_t *path, int32_t levels, const char *file, void *stream);
+int svoslam_pool_restore_subtree(svoslam_pool *pool, const char *file, void *stream);
+int svoslam_subtree_file_nodes(const char *file, uint32_t **h_words, int32_t *num_nodes);
 /* dst becomes a byte-identical replica of src (nodes, size, at least src's capacity); dst may be zero-initialised.
  * Blocking (waits for the device). */
 int svoslam_pool_copy(svoslam_pool *dst, svoslam_pool *src, void *stream);

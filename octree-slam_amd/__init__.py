@@ -79,6 +79,9 @@ SIGNATURES = {
     "svoslam_pool_save": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _fp, _f32, _i32, _vp]),
     "svoslam_pool_touch": (C.c_int, [C.POINTER(_PoolStruct)]),
     "svoslam_pool_set_nodes": (C.c_int, [C.POINTER(_PoolStruct), C.POINTER(C.c_uint32), _i32, _vp]),
+    "svoslam_pool_evict_subtree": (C.c_int, [C.POINTER(_PoolStruct), C.POINTER(C.c_uint8), _i32, C.c_char_p, _vp]),
+    "svoslam_pool_restore_subtree": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _vp]),
+    "svoslam_subtree_file_nodes": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(_i32)]),
     "svoslam_pool_copy": (C.c_int, [C.POINTER(_PoolStruct), C.POINTER(_PoolStruct), _vp]),
     "svoslam_pool_load": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _fp, C.POINTER(_f32), C.POINTER(_i32), _vp]),
     "svoslam_svo_from_point_cloud_async": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _fp, _f32, _vp]),
@@ -289,6 +292,14 @@ class Pool:
         and the reservations of asynchronous fusions, so fusing into the loaded tree allocates after it)"""
         words = np.ascontiguousarray(words, dtype=np.uint32)
         check(lib().svoslam_pool_set_nodes(C.byref(self._p), words.ctypes.data_as(C.POINTER(C.c_uint32)), words.size // 2, _stream()))
+
+    def evict_subtree(self, path, file):
+        """page the sub-tree below the node reached by the octant `path` out to `file` (svoslam_pool_evict_subtree)"""
+        p = (C.c_uint8 * len(path))(*[int(o) for o in path])
+        check(lib().svoslam_pool_evict_subtree(C.byref(self._p), p, len(path), str(file).encode(), _stream()))
+
+    def restore_subtree(self, file):
+        check(lib().svoslam_pool_restore_subtree(C.byref(self._p), str(file).encode(), _stream()))
 
     def copy_from(self, other):
         """become a byte-identical replica of `other` (blocking)"""
@@ -886,6 +897,16 @@ class Camera:
             self.close()
         except Exception:
             pass
+
+
+def subtree_file_words(file):
+    """the stand-alone linear tree stored in a paged-out sub-tree file, as uint32 words (2 per node)"""
+    w, n = C.POINTER(C.c_uint32)(), _i32(0)
+    check(lib().svoslam_subtree_file_nodes(str(file).encode(), C.byref(w), C.byref(n)))
+    try:
+        return np.ctypeslib.as_array(w, shape=(2 * n.value,)).copy()
+    finally:
+        C.CDLL(None).free(w)
 
 
 def copy_from_device(ptr, shape, dtype):

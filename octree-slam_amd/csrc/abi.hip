@@ -128,6 +128,15 @@ int svoslam_pool_set_nodes(svoslam_pool *pool, const uint32_t *h_words, int32_t 
   NEED_DEVICE();
   return pool_set_nodes(pool, h_words, num_nodes, S(stream));
 }
+int svoslam_pool_evict_subtree(svoslam_pool *pool, const uint8_t *path, int32_t levels, const char *file, void *stream) {
+  NEED_DEVICE();
+  return pool_evict_subtree(pool, path, levels, file, S(stream));
+}
+int svoslam_pool_restore_subtree(svoslam_pool *pool, const char *file, void *stream) {
+  NEED_DEVICE();
+  return pool_restore_subtree(pool, file, S(stream));
+}
+int svoslam_subtree_file_nodes(const char *file, uint32_t **h_words, int32_t *num_nodes) { return subtree_file_nodes(file, h_words, num_nodes); }
 int svoslam_pool_copy(svoslam_pool *dst, svoslam_pool *src, void *stream) {
   NEED_DEVICE();
   return pool_copy(dst, src, S(stream));

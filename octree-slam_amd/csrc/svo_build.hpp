@@ -13,6 +13,10 @@ void pool_tracker_destroy(svoslam_pool *pool);
 int pool_save(svoslam_pool *pool, const char *path, const float center[3], float edge, int depth, hipStream_t stream);
 int pool_set_nodes(svoslam_pool *pool, const uint32_t *h_words, int32_t num_nodes, hipStream_t stream);
 int pool_copy(svoslam_pool *dst, svoslam_pool *src, hipStream_t stream);
+// out-of-core paging of sub-trees (pool_paging.hip)
+int pool_evict_subtree(svoslam_pool *pool, const uint8_t *path, int levels, const char *file, hipStream_t stream);
+int pool_restore_subtree(svoslam_pool *pool, const char *file, hipStream_t stream);
+int subtree_file_nodes(const char *file, uint32_t **h_words, int32_t *num_nodes);
 int pool_load(svoslam_pool *pool, const char *path, float center[3], float *edge, int *depth, hipStream_t stream);
 int svo_from_point_cloud_async(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,
                                svoslam_pool *pool, const float center[3], float edge, hipStream_t stream);

@@ -124,3 +124,69 @@ def test_pool_expand_reroots_the_map(env, oracle):
     assert st.num_split > 0
     c2, _ = pkg.extract_voxel_grid(ws, pool, depth + 1, center2, edge2)
     assert c2.shape[0] > c1.shape[0] and (c2[:, 0] > 1.0).any()
+
+
+def test_subtree_paging_resume_equals_uninterrupted(env, oracle, tmp_path):
+    """a sub-tree paged out through the linear-tree format and back.  While it is out, the node is a leaf with
+    its mip colour and another part of the map is fused into; after the restore the pool is bit-identical to the twin
+    that was never paged (resume == uninterrupted).  The file's linear tree is a pool of its own (same nodes as the
+    sub-tree, relative indices).  Fusing INTO the evicted cube makes the restore refuse."""
+    pkg, torch = env[0], env[1]
+    rng = np.random.default_rng(31)
+    depth = 8
+
+    def cloud(lo, hi, n):
+        p = (rng.random((n, 3)) * (np.array(hi) - np.array(lo)) + np.array(lo)).astype(np.float32)
+        return torch.from_numpy(p).cuda(), torch.from_numpy(rng.integers(0, 256, (n, 3), dtype=np.uint8)).cuda()
+
+    left = [cloud((-0.9, -0.9, -0.9), (-0.1, 0.9, 0.9), 30000) for _ in range(2)]      # x < 0: octants with bit 0 clear
+    right = [cloud((0.1, -0.9, -0.9), (0.9, 0.9, 0.9), 30000) for _ in range(3)]       # x > 0
+    A, B = pkg.Pool(1 << 20), pkg.Pool(1 << 20)
+    wsa, wsb = pkg.Workspace(), pkg.Workspace()
+    for p, c in (left[0], right[0]):
+        pkg.svo_from_point_cloud_async(wsa, p, c, depth, A, (0, 0, 0), 1.0)
+        pkg.svo_from_point_cloud_async(wsb, p, c, depth, B, (0, 0, 0), 1.0)
+    before = A.words().copy()
+    assert np.array_equal(before, B.words())
+    path = [1]                                   # root child 1 = (x > 0, y < 0, z < 0): holds part of `right`
+    f = tmp_path / "sub.svosub"
+    A.evict_subtree(path, f)
+    after = A.words()
+    assert after.size == before.size and (after[2 * 1] & pkg.FLAG_CHILDREN) == 0 and after[2 * 1 + 1] == before[2 * 1 + 1]
+    assert (before[2 * 1] & pkg.FLAG_CHILDREN) and not np.array_equal(after, before)
+    # the file's linear tree: a pool of its own whose top tile is the evicted node's children
+    sub = pkg.subtree_file_words(f)
+    top = int(before[2 * 1] & pkg.CHILD_MASK)
+    assert np.array_equal(sub[1:16:2], before[2 * top + 1:2 * top + 16:2])           # colours of the 8 top nodes
+    n_sub = sub.size // 2
+    assert (after == 0).sum() - (before == 0).sum() >= n_sub                          # its tiles were cleared in the pool
+    S = pkg.Pool()
+    S.set_words(sub)
+    img = torch.zeros((48, 64, 4), dtype=torch.uint8, device="cuda")
+    view = oracle.look_at((0.1, 0.2, -2.5), (0, 0, 0), (0, 1, 0))
+    pkg.cone_trace_svo(img, 45.0, view, S.data_ptr, (0.5, -0.5, -0.5), 0.5, pkg.RENDER_CARRY)     # renders as a map of its own
+    ref, _, _ = oracle.cone_trace(sub, 64, 48, 45.0, view, (0.5, -0.5, -0.5), 0.5, oracle.RENDER_CARRY)
+    assert np.array_equal(img.cpu().numpy(), ref)
+    # the evicted map renders (the node is a leaf now) and equals the oracle on the same words
+    pkg.cone_trace_svo(img, 45.0, view, A.data_ptr, (0, 0, 0), 1.0, pkg.RENDER_CARRY)
+    ref, _, _ = oracle.cone_trace(after, 64, 48, 45.0, view, (0, 0, 0), 1.0, oracle.RENDER_CARRY)
+    assert np.array_equal(img.cpu().numpy(), ref)
+    # fuse elsewhere (x < 0) on both, then restore: identical to the uninterrupted twin
+    pkg.svo_from_point_cloud_async(wsa, left[1][0], left[1][1], depth, A, (0, 0, 0), 1.0)
+    pkg.svo_from_point_cloud_async(wsb, left[1][0], left[1][1], depth, B, (0, 0, 0), 1.0)
+    A.restore_subtree(f)
+    assert A.size == B.size and np.array_equal(A.words(), B.words())
+    pkg.svo_from_point_cloud_async(wsa, right[1][0], right[1][1], depth, A, (0, 0, 0), 1.0)      # and the map goes on
+    pkg.svo_from_point_cloud_async(wsb, right[1][0], right[1][1], depth, B, (0, 0, 0), 1.0)
+    assert np.array_equal(A.words(), B.words())
+    pkg.cone_trace_svo(img, 45.0, view, A.data_ptr, (0, 0, 0), 1.0, pkg.RENDER_CARRY)
+    ref, _, _ = oracle.cone_trace(B.words(), 64, 48, 45.0, view, (0, 0, 0), 1.0, oracle.RENDER_CARRY)
+    assert np.array_equal(img.cpu().numpy(), ref)
+    # fusing into the evicted cube, then restoring: refused
+    g = tmp_path / "sub2.svosub"
+    A.evict_subtree(path, g)
+    pkg.svo_from_point_cloud_async(wsa, right[2][0], right[2][1], depth, A, (0, 0, 0), 1.0)
+    with pytest.raises(pkg.SvoslamError):
+        A.restore_subtree(g)
+    with pytest.raises(pkg.SvoslamError):
+        A.evict_subtree([0, 0, 0, 0, 0, 0, 0, 0, 0], tmp_path / "none.svosub")       # a path that leaves the tree
