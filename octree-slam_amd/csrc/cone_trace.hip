@@ -278,6 +278,9 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
                                                          const uint2 *__restrict__ grid, const float *__restrict__ table,
                                                          const float *__restrict__ alpha_lut_g, TraceParams P,
                                                          unsigned long long *__restrict__ counters) {
+#ifdef SVO_MARCH_PRIO
+  __builtin_amdgcn_s_setprio(SVO_MARCH_PRIO);
+#endif
   __shared__ float alpha_lut[256];
   constexpr int kLdsDepth = LDSD;
   constexpr int kGridLevel = GRID;

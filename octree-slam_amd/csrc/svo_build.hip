@@ -388,9 +388,11 @@ __global__ void mip_root_kernel(u32 *__restrict__ pool, const PlanCounts *__rest
 constexpr u32 kNoStraddler = 0xFFFFFFFFu;
 
 #ifndef SVO_FILL_THREADS
-#define SVO_FILL_THREADS 1024
+#define SVO_FILL_THREADS 512
 #endif
-constexpr int kFillThreads = SVO_FILL_THREADS;  // leaves per workgroup: fewer, longer runs of leaves -> fewer straddlers
+constexpr int kFillThreads = SVO_FILL_THREADS;  // leaves per workgroup.  Larger: fewer straddlers for the single-workgroup second launch;
+// smaller: more workgroups resident next to the tracker's (which pin 150 CUs).  Measured at cfg3, fill + straddle us:
+// 1024 -> 54 + 20, 512 -> 45 + 23, 256 -> 37 + 32; 2418 / 2481 / 2477 frames/s.
 __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 *__restrict__ skey, const u32 *__restrict__ sidx, int n,
                                                              int depth, const unsigned char *__restrict__ leaf_t,
                                                              const unsigned char *__restrict__ colors, u32 *__restrict__ pool,

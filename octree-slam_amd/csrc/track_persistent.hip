@@ -162,7 +162,9 @@ struct PixelSet {  // one lane's pixels of the current level
 #define SVO_TRK_MIN_WAVES 2
 #endif
 __global__ __launch_bounds__(kTrkThreads, SVO_TRK_MIN_WAVES) void track_persistent_kernel(CamState *st, TrackSync *sy, unsigned *tickets, double *rows, TrackArgs A) {
+#ifndef SVO_TRK_NO_PRIO
   SVO_HIGH_PRIO();
+#endif
   __shared__ double wsum[16][27];          // workers: per-(wave, half) term sums; solver: row-group sums
   __shared__ __attribute__((aligned(16))) float rows_s[kTrkWaves * 64 * kRowFloats];  // one 32-byte row per pixel in flight
   __shared__ double totals[27];
