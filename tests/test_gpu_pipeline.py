@@ -232,3 +232,41 @@ def test_native_runner_equals_sequential(env, capacity, band):
         del os.environ["SVOSLAM_PY_SCHEDULER"]
     with pytest.raises(pkg.SvoslamError):             # timestamps must increase
         B.run_stream(ds[:2], cs[:2], [0, 0], views[:2])
+
+
+def test_graph_replay_and_chain_tracker_in_subprocess(env):
+    """HIP-graph replay of the launch sequences (SVOSLAM_GRAPHS=1; off by default since round 2) together with the
+    launch-chain tracker (SVOSLAM_TRACK_CHAIN=1), in a child process: same final image, pool and pose as the default
+    (direct launches, one-launch tracker) in this process"""
+    import hashlib
+    import json
+    import subprocess
+    import sys
+    pkg, torch, synth, pl = env
+    code = r'''
+import sys, json, hashlib, importlib, numpy as np, torch
+sys.path.insert(0, %r)
+import svoslam_pkg
+pkg = svoslam_pkg.load()
+synth = importlib.import_module("octree_slam_amd.synth")
+pl = importlib.import_module("octree_slam_amd.pipeline")
+w, h, depth, center, edge, n = 160, 120, 8, (0.0, 1.5, 0.0), 4.096, 11
+frames = [synth.render_frame(k, w, h) for k in range(n)]
+ds, cs = [f[0].cuda() for f in frames], [f[1].cuda() for f in frames]
+views = [pl.ground_truth_view(k, synth) for k in range(n)]
+P = pl.SlamPipeline(w, h, depth, center, edge)
+P.run_stream(ds[:6], cs[:6], list(range(6)), views[:6])
+P.run_stream(ds[6:], cs[6:], list(range(6, n)), views[6:])
+torch.cuda.synchronize()
+sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+print("RESULT" + json.dumps([sha(P.image.cpu().numpy()), sha(P.pool.words()), sha(P.cam.pose()[1]), int(P.pool.size)]))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def run(extra):
+        e = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0][6:])
+    base = run({})
+    assert run({"SVOSLAM_GRAPHS": "1", "SVOSLAM_TRACK_CHAIN": "1"}) == base
+    assert run({"SVOSLAM_GRAPHS": "1"}) == base
+    assert base[3] > 8
