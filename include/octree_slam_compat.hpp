@@ -82,11 +82,20 @@ inline void check(int status, const char *what) {
 struct Registry {
   std::mutex mu;
   std::map<unsigned int *, int> capacity;
+  std::mutex ws_mu;                                           // the one workspace serves one call at a time
   svoslam_workspace *ws = nullptr;
   static Registry &get() { static Registry r; return r; }
-  svoslam_workspace *workspace() {
+  // the shared workspace, locked until the end of the full expression (the blocking call it is passed to): callers
+  // on several host threads are serialised here instead of racing on its scratch buffers
+  struct LockedWorkspace {
+    std::unique_lock<std::mutex> held;
+    svoslam_workspace *ws;
+    operator svoslam_workspace *() const { return ws; }
+  };
+  LockedWorkspace workspace() {
+    std::unique_lock<std::mutex> held(ws_mu);
     if (!ws) check(svoslam_workspace_create(&ws), "svoslam_workspace_create");
-    return ws;
+    return LockedWorkspace{std::move(held), ws};
   }
   svoslam_pool open(unsigned int *data, int size) {
     std::lock_guard<std::mutex> g(mu);
