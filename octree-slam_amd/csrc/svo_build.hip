@@ -393,6 +393,11 @@ constexpr u32 kNoStraddler = 0xFFFFFFFFu;
 constexpr int kFillThreads = SVO_FILL_THREADS;  // leaves per workgroup.  Larger: fewer straddlers for the single-workgroup second launch;
 // smaller: more workgroups resident next to the tracker's (which pin 150 CUs).  Measured at cfg3, fill + straddle us:
 // 1024 -> 54 + 20, 512 -> 45 + 23, 256 -> 37 + 32; 2418 / 2481 / 2477 frames/s.
+#ifdef SVO_FILL_PROF
+#define FILL_STAMP(k) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[k] = wall_clock64(); }
+#else
+#define FILL_STAMP(k)
+#endif
 __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 *__restrict__ skey, const u32 *__restrict__ sidx, int n,
                                                              int depth, const unsigned char *__restrict__ leaf_t,
                                                              const unsigned char *__restrict__ colors, u32 *__restrict__ pool,
@@ -401,10 +406,23 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   __shared__ int last_owner[SVOSLAM_MAX_DEPTH + 1];  // per level: last lane of this workgroup owning a node there
   __shared__ int next_pos, next_c;                   // first head lane after this workgroup and its common-prefix length
   const int tid = (int)threadIdx.x;
+#ifdef SVO_FILL_PROF
+  unsigned long long stamp[8];
+  FILL_STAMP(0)
+#endif
   const int j = blockIdx.x * kFillThreads + tid;
-  const bool head = j < n && leaf_t[j] != kNotHead;
+  // Everything the setup needs from memory is requested at once (one round trip instead of four in sequence): this
+  // lane's key pair and point index, and the key pair of the lane at the same place in the next workgroup, one of
+  // which is the first head after this workgroup (normally; the loop below covers a workgroup without any head).
+  const int jn = j + kFillThreads;
+  const unsigned char lt = j < n ? leaf_t[j] : kNotHead;
+  const unsigned char ltn = jn < n ? leaf_t[jn] : kNotHead;
+  const u64 key_j = j < n ? skey[j] : 1ull, key_p = (j > 0 && j < n) ? skey[j - 1] : 1ull;
+  const u64 key_n = jn < n ? skey[jn] : 1ull, key_np = jn < n ? skey[jn - 1] : 1ull;
+  const u32 point = j < n ? sidx[j] : 0u;
+  const bool head = lt != kNotHead;
   u64 key = 1; int c = 0;
-  if (head) (void)is_head(skey, j, key, c, depth);
+  if (head) { key = key_j; c = (key_p == 1ull) ? 0 : common_levels(key_j, key_p, depth); }  // is_head() on the values in hand
   // level grid of the ray march (pool_grid.hpp): everything this key changes lies below its level-5 prefix; the first
   // head of a run of keys sharing that prefix marks the block
   if (grid_dirty && head && c < kPoolGridBlockLevel) pool_grid_mark(grid_dirty, key, depth);
@@ -415,28 +433,38 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
       strad[2 * ((size_t)tid * num_tiles + blockIdx.x) + 1] = 0u;
     }
   }
-  if (tid == 0) next_pos = 0x7FFFFFFF;
+  if (tid == 0) { next_pos = 0x7FFFFFFF; next_c = -1; }  // no later head: every run ends with the array
   __syncthreads();
   if (head)
     for (int d = c + 1; d < depth; d++) atomicMax(&last_owner[d], j);
-  for (int nb = (int)blockIdx.x + 1; nb < (int)gridDim.x; nb++) {  // normally one iteration
-    const int jj = nb * kFillThreads + tid;
-    if (jj < n && leaf_t[jj] != kNotHead) atomicMin(&next_pos, jj);
-    __syncthreads();
-    const bool found = next_pos != 0x7FFFFFFF;
-    __syncthreads();  // every lane has read next_pos before anyone updates it again
-    if (found) break;
+  if (ltn != kNotHead) atomicMin(&next_pos, jn);
+  __syncthreads();
+  if (next_pos == 0x7FFFFFFF) {  // no head in the next workgroup (all duplicates / invalid points): look further
+    for (int nb = (int)blockIdx.x + 2; nb < (int)gridDim.x; nb++) {
+      const int jj = nb * kFillThreads + tid;
+      if (jj < n && leaf_t[jj] != kNotHead) atomicMin(&next_pos, jj);
+      __syncthreads();
+      const bool found = next_pos != 0x7FFFFFFF;
+      __syncthreads();  // every lane has read next_pos before anyone updates it again
+      if (found) break;
+    }
+    if (tid == 0 && next_pos != 0x7FFFFFFF) {
+      u64 k2; int c2 = 0;
+      (void)is_head(skey, next_pos, k2, c2, depth);
+      next_c = c2;
+    }
+  } else if (jn == next_pos) {
+    next_c = (key_np == 1ull) ? 0 : common_levels(key_n, key_np, depth);
   }
-  if (tid == 0) {
-    int c2 = -1;  // no later head: every run ends with the array
-    if (next_pos != 0x7FFFFFFF) { u64 k2; c2 = 0; (void)is_head(skey, next_pos, k2, c2, depth); }
-    next_c = c2;
-  }
+  FILL_STAMP(1)
   // walk to the leaf (fillNodes, svo.cu:291-382), remembering the owned nodes and their child tiles
   u32 node_at[SVOSLAM_MAX_DEPTH], child_at[SVOSLAM_MAX_DEPTH];
 #pragma unroll
   for (int l = 0; l < SVOSLAM_MAX_DEPTH; l++) { node_at[l] = 0; child_at[l] = 0; }
   if (head) {
+    // duplicates: the head of a run of equal keys is the lowest point index (stable sort)
+    const unsigned char *v = colors + 3 * (size_t)point;
+    const unsigned char cr = v[0], cg = v[1], cb = v[2];  // in flight during the walk
     u32 base = 0, node = 0;
 #pragma unroll
     for (int lvl = 1; lvl <= SVOSLAM_MAX_DEPTH; lvl++) {
@@ -449,11 +477,12 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
         }
       }
     }
-    // duplicates: the head of a run of equal keys is the lowest point index (stable sort)
-    const unsigned char *v = colors + 3 * (size_t)sidx[j];
-    pool[2 * (size_t)node + 1] = blend_color256(pool[2 * (size_t)node + 1], v[0], v[1], v[2]);
+    FILL_STAMP(2)
+    pool[2 * (size_t)node + 1] = blend_color256(pool[2 * (size_t)node + 1], cr, cg, cb);
   }
+  FILL_STAMP(3)
   __syncthreads();
+  FILL_STAMP(4)
 #pragma unroll
   for (int d = SVOSLAM_MAX_DEPTH - 1; d >= 1; d--) {
     if (d < depth) {
@@ -468,6 +497,12 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
       __syncthreads();
     }
   }
+#ifdef SVO_FILL_PROF
+  FILL_STAMP(5)
+  if (tid == 0 && (blockIdx.x % 37) == 0)
+    printf("fillprof wg %d of %d: start %llu setup %llu descent %llu leaf %llu sync %llu mip %llu (x10 ns)\n", (int)blockIdx.x, (int)gridDim.x,
+           stamp[0] % 100000000ull, stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4]);
+#endif
 }
 
 // straddling nodes deepest level first, then the root quirk (Q6) and the device-side size
