@@ -255,6 +255,34 @@ __device__ __forceinline__ void walk_deep(const uint2 *__restrict__ nodes, const
   }
 }
 
+// walk below the LDS table's levels, octant bits continued from the table by the reference's own chain (:93-104): the
+// threshold of the level-T decision is the table entry at the even rank (the centre c_(T-1) of the level T-1 node; entry
+// (2p + 2) for prefix p, see build_table_entry), and every further centre is c_l = c_(l-1) +- size / 2^l -- the very
+// additions the reference performs, so the bits are the reference's without the three 16-byte gathers of the fine table
+template <int LDSD>
+__device__ __forceinline__ void walk_deep_chain(const uint2 *__restrict__ nodes, const float *lds_tab, const TraceParams &P, float tx, float ty,
+                                             float tz, uint32_t xb, uint32_t yb, uint32_t zb, uint32_t child_idx, int &depth, uint32_t &w1) {
+  constexpr int kStride = lds_stride(LDSD);
+  float ts = ldexpf(P.size, -LDSD);  // size / 2^T: T exact halvings
+  float cx = lds_tab[(xb & ~1u) + 2u], cy = lds_tab[kStride + (yb & ~1u) + 2u], cz = lds_tab[2 * kStride + (zb & ~1u) + 2u];
+  cx += ts * ((xb & 1u) ? 1.0f : -1.0f);
+  cy += ts * ((yb & 1u) ? 1.0f : -1.0f);
+  cz += ts * ((zb & 1u) ? 1.0f : -1.0f);
+  for (int i = LDSD + 1; i <= depth; i++) {
+    const bool hx = tx > cx, hy = ty > cy, hz = tz > cz;
+    const uint32_t oct = (uint32_t)hx | ((uint32_t)hy << 1) | ((uint32_t)hz << 2);
+    uint2 nd = nodes[child_idx + oct];
+    asm volatile("" : "+v"(nd.y));
+    w1 = nd.y;
+    if (!(nd.x & kFlag)) { depth = i; break; }
+    child_idx = nd.x & kMask;
+    ts *= 0.5f;
+    cx += ts * (hx ? 1.0f : -1.0f);
+    cy += ts * (hy ? 1.0f : -1.0f);
+    cz += ts * (hz ? 1.0f : -1.0f);
+  }
+}
+
 // walk from the root for an LOD depth above the grid level (1 <= depth < grid level)
 template <int LDSD>
 __device__ __forceinline__ void walk_shallow(const uint2 *__restrict__ nodes, uint32_t xb, uint32_t yb, uint32_t zb, int &depth, uint32_t &w1) {
@@ -398,8 +426,10 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
             if (!(nd.x & kFlag)) { depth = l; stopped = true; break; }
             child_idx = nd.x & kMask;
           }
-          if (!stopped && depth > kLdsDepth)  // below the LDS table's levels
-            walk_deep(nodes, table, P, tx, ty, tz, kLdsDepth + 1, child_idx, depth, w1);
+          if (!stopped && depth > kLdsDepth) {  // below the LDS table's levels
+            if (ok) walk_deep_chain<LDSD>(nodes, lds_tab, P, tx, ty, tz, xb, yb, zb, child_idx, depth, w1);
+            else walk_deep(nodes, table, P, tx, ty, tz, kLdsDepth + 1, child_idx, depth, w1);  // bracket not confirmed (never seen): the fine table
+          }
         }
       } else if (depth >= 1) {
         // LOD coarser than the grid (sample farther than ~size/(32 pix_scale)): the reference's walk from the root
@@ -597,9 +627,11 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   // lookup helpers: the table-cell guess and the operand range of the fast LOD form
   for (int k = 0; k < 3; k++) P.lo[k] = center[k] - size;
   P.inv_cell = (float)kTabCells / (2.0f * size);
-  {  // LDS table depth: 11 if the LOD depth one metre from the camera does not exceed it, else 12
-    const float q = size / P.pix_scale;  // = size / pix_size at ray length 1
-    P.lds_depth = (q > 0.0f && q <= 2048.0f) ? 11 : kLdsDepthMax;
+  {  // LDS table depth.  Levels below it continue the table by the reference's chain (walk_deep_chain), so 11 levels
+     // (24 KB) serve every render; the 12-level table (49 KB) makes a 1920x1080 / depth-14 march 8 % shorter on its own
+     // but costs the frame loop 4 % (fewer workgroups of the other stages fit beside it): SVOSLAM_MARCH_LDS_DEPTH=12
+    static const int forced = [] { const char *e = getenv("SVOSLAM_MARCH_LDS_DEPTH"); return e ? atoi(e) : 0; }();
+    P.lds_depth = forced == kLdsDepthMax ? kLdsDepthMax : 11;
   }
   P.inv_cell_lds = (float)lds_cells(P.lds_depth) / (2.0f * size);
   {
