@@ -61,6 +61,7 @@ struct svoslam_runner {
   std::vector<hipEvent_t> events;  // pool, grown on demand
   hipEvent_t ev_begin = nullptr, ev_end[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t last_caller = nullptr;
+  int lead = 3;  // commits the host may run ahead of the device (see svoslam_runner_run)
   bool ran = false;
   // SVOSLAM_RUNNER_TIMELINE=1: timing events at the stage boundaries of the last call (svoslam_runner_timeline)
   bool maps_on_track_stream = false;  // SVOSLAM_RUNNER_MAPS_STREAM=0: maps of a frame right before its ICP on stream T (saves an
@@ -70,7 +71,8 @@ struct svoslam_runner {
   int tl_frames = 0;
 };
 
-namespace { constexpr int kTlStages = 10; }  // maps0 maps1 track0 track1 prep0 plan0 plan1 commit0 commit1(first replica) ray1
+namespace { constexpr int kTlStages = 10; }
+  // maps0 maps1 track0 track1 prep0 plan0 plan1 commit0 commit1(first replica) ray1
 
 namespace {
 
@@ -104,6 +106,8 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
   r->maps_on_track_stream = ms && ms[0] == '0';
   const char *tl = getenv("SVOSLAM_RUNNER_TIMELINE");
   r->timeline = tl && tl[0] == '1';
+  const char *ld = getenv("SVOSLAM_RUNNER_LEAD");
+  if (ld) r->lead = atoi(ld) < 0 ? 0 : atoi(ld);
   *out = r;
   const size_t n = (size_t)width * height;
   for (hipStream_t *s : {&r->s_maps, &r->s_track, &r->s_prep, &r->s_map[0], &r->s_map[1]})
@@ -270,6 +274,12 @@ int svoslam_runner_run(svoslam_runner *r, const uint16_t *const *d_depths, const
       if (i + 1 < n) SVO_TRY(enqueue_track(i + 1));
       if (i + 2 < n) SVO_TRY(enqueue_maps(i + 2));  // (one stream: behind track i+1, ahead of track i+2 -- two map sets ahead at most)
       const int a = i & (R - 1);  // the replica frame i is marched on: it gets commit i first
+      // The host stays at most `lead` commits ahead of the device (default 3; SVOSLAM_RUNNER_LEAD=0: as far as the
+      // pool's size ring allows, 8).  Whatever has been enqueued when the host STOPS enqueuing drains at 0.6 ms per
+      // frame instead of 0.32 (measured with HIP events per stage: the kernels themselves keep their durations and the
+      // clock stays at 2.4 GHz, the gaps between them grow; AMD_DIRECT_DISPATCH=0 does not show it but costs 10 % in
+      // steady state).  With a lead of 8 frames that tail was 8 of the 20 frames of a short call: 2130 -> 2580 frames/s.
+      if (r->lead > 0 && i >= r->lead) SVO_HIP(hipEventSynchronize(ev_commit[a][i - r->lead]));
       SVO_TRY(enqueue_commit(i, a, R == 1));
       if (i + 1 < n) SVO_TRY(enqueue_prepare(i + 1));  // host order: after ev_commit[a][i] has been recorded
       // one march at a time: two of them (1200 workgroups) leave no CU for the tracker's and the fusion's workgroups
