@@ -129,9 +129,10 @@ def test_cone_trace_timing_log(env, oracle):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-def test_render_tall_image_large_root_uses_the_12_level_lds_table(env, oracle, mode):
-    """root half edge / pixel size > 2048 (1080-row images of an 8 m cube): the kernel variant with the 12-level LDS
-    table is selected (the other render tests run the 11-level variant)"""
+def test_render_tall_image_large_root_walks_three_levels_below_the_lds_table(env, oracle, mode):
+    """1080-row images of an 8 m cube at depth 14: LOD depths 12..14, i.e. up to three levels below the 11-level LDS
+    table, continued by the centre chain (round 1 selected a 12-level table here; it is now opt-in, see the
+    subprocess test below)"""
     pkg, torch = env
     center, edge = (0.0, 0.0, 0.0), 8.192
     ws, pool, opool = build_pool(pkg, torch, oracle, 14, 2, n=20000, edge=edge, center=center, scale=5.0)
@@ -142,9 +143,42 @@ def test_render_tall_image_large_root_uses_the_12_level_lds_table(env, oracle, m
 
 
 def test_render_megapixel_uses_the_level8_grid(env, oracle):
-    """>= 2^20 rays with the 12-level table: the 256^3 grid variant is selected"""
+    """>= 2^20 rays: the 256^3 grid variant is selected (rendering memory that is not a registered pool)"""
     pkg, torch = env
     center, edge = (0.0, 0.0, 0.0), 8.192
     ws, pool, opool = build_pool(pkg, torch, oracle, 14, 2, n=30000, edge=edge, center=center, scale=5.0)
     view = oracle.look_at((0.5, 1.0, -11.0), (0, 0, 0), (0, 1, 0))
     render_both(pkg, torch, oracle, pool, opool.words(), 960, 1100, view, center, edge, 0)
+
+
+def test_render_with_the_12_level_lds_table_in_subprocess(env, oracle):
+    """SVOSLAM_MARCH_LDS_DEPTH=12 (the 49 KB table, two chained levels at depth 14) in a child process: the same bytes
+    as the default 11-level table in this process, which is checked against the oracle"""
+    import hashlib
+    import subprocess
+    import sys
+    pkg, torch = env
+    center, edge = (0.0, 0.0, 0.0), 8.192
+    ws, pool, opool = build_pool(pkg, torch, oracle, 14, 2, n=20000, edge=edge, center=center, scale=5.0)
+    view = oracle.look_at((1.0, 0.5, 2.6), (0.5, -1.0, -1.5), (0, 1, 0))
+    got = render_both(pkg, torch, oracle, pool, opool.words(), 40, 1100, view, center, edge, 1)
+    want = hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest()
+    words_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "svoslam_lds12_words.npy")
+    np.save(words_path, np.asarray(opool.words(), np.uint32))
+    code = r'''
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, %r)
+import svoslam_pkg
+pkg = svoslam_pkg.load()
+words = torch.from_numpy(np.load(%r).view(np.int32)).cuda()
+img = torch.full((1100, 40, 4), 7, dtype=torch.uint8, device="cuda")
+pkg.cone_trace_svo(img, 45.0, np.array(%r, np.float32), words.data_ptr(), %r, %r, 1)
+torch.cuda.synchronize()
+print("RESULT" + hashlib.sha256(np.ascontiguousarray(img.cpu().numpy()).tobytes()).hexdigest())
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), words_path, [float(x) for x in np.asarray(view).reshape(-1)],
+       tuple(center), edge)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SVOSLAM_MARCH_LDS_DEPTH="12"), capture_output=True, text=True,
+                       timeout=600)
+    os.remove(words_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0][6:] == want
