@@ -66,6 +66,30 @@ __device__ inline uint32_t f2u8(float f) { return __float2uint_rz(f) & 0xFFu; }
 
 __device__ inline float length3(float x, float y, float z) { return sqrtf(dot3(x, y, z, x, y, z)); }
 
+// The compiler's correctly rounded a / b and sqrt(x) without their range handling (v_div_scale x 2, v_div_fixup: 3 of 11
+// instructions; the 2^32 pre-scaling of tiny arguments and the zero / infinity class test of sqrt: 7 of 16) -- the same
+// v_rcp / v_sqrt seeds and the same FMA corrections, hence the same bits whenever that handling is the identity: b and the
+// quotient far from the ends of the exponent range, x >= 2^-96 (+inf passes through).  Used on the march's length
+// recurrence only, whose operands are ray_len in [0.002, 10] and ray_len + size / 2^depth; see march_update().
+__device__ __forceinline__ float div_rn_midrange(float a, float b) {
+  const float r0 = __builtin_amdgcn_rcpf(b);
+  const float e0 = fmaf(-b, r0, 1.0f);
+  const float r1 = fmaf(e0, r0, r0);
+  const float q0 = a * r1;
+  const float e1 = fmaf(-b, q0, a);
+  const float q1 = fmaf(e1, r1, q0);
+  const float e2 = fmaf(-b, q1, a);
+  return fmaf(e2, r1, q1);
+}
+__device__ __forceinline__ float sqrt_rn_midrange(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rd = fmaf(-sd, s, x), ru = fmaf(-su, s, x);
+  float out = rd <= 0.0f ? sd : s;
+  out = ru > 0.0f ? su : out;
+  return out;
+}
+
 // ---- split-plane table ----------------------------------------------------
 // The reference decides the octant at every level by comparing the sample with a centre
 // it builds on the way down: c_0 = centre, c_l = fl(c_{l-1} +/- size/2^l)
@@ -363,6 +387,9 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
     // glm::length(ray) is evaluated at :67 and again at :131 on the advanced ray; the second value is
     // the first value of the next step (same operands), so it is computed once and carried.
     float ray_len = length3(rx, ry, rz);
+    // root cubes of ordinary size: size / 2^depth for depth >= -60 stays below 2^81, quotients and squares of the
+    // length recurrence cannot reach the exponent range's ends except by overflowing to +inf, which both forms return
+    const bool midrange = P.size >= 9.5367431640625e-07f && P.size <= 1048576.0f;
     uint32_t oct_val = 0;
     int alpha = 0;
     bool range_exit = false;
@@ -458,9 +485,15 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
       if (retired) break;
       // oct_size / pow(2.0f, depth) (:126): division by a power of two == exact scaling
       const float new_dist = (depth >= -100 && depth <= 100) ? ldexpf(P.size, -depth) : P.size / ldexpf(1.0f, depth);
-      const float s = (ray_len + new_dist) / ray_len;
-      rx *= s; ry *= s; rz *= s;
-      ray_len = length3(rx, ry, rz);
+      if (midrange && depth >= -60) {  // (uniform && per-lane, no branch: both forms are a dozen instructions)
+        const float s = div_rn_midrange(ray_len + new_dist, ray_len);
+        rx *= s; ry *= s; rz *= s;
+        ray_len = sqrt_rn_midrange(dot3(rx, ry, rz, rx, ry, rz));
+      } else {
+        const float s = (ray_len + new_dist) / ray_len;
+        rx *= s; ry *= s; rz *= s;
+        ray_len = length3(rx, ry, rz);
+      }
       asm volatile("" :: "v"(ray_len));
       PROF_T(3)
       if (ray_len > kMaxRange) { range_exit = true; break; }
