@@ -232,3 +232,27 @@ def test_async_fusion_many_frames_without_sync(env, oracle):
         pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), 9, pool, (0, 0, 0), 1.0)
         opool.insert_cloud(pts, col, 9, (0, 0, 0), 1.0)
     assert_pools_equal(pool, opool)
+
+
+def test_async_fusion_long_runs_of_duplicates_and_invalid_points(env, oracle):
+    """runs of equal keys and of rejected points longer than a fill workgroup (512 sorted keys): whole workgroups of
+    the commit's leaf kernel without a single head, so the 'first head after this workgroup' is several workgroups
+    away (its fallback search), and straddling nodes whose run continues across them"""
+    pkg, torch = env
+    rng = np.random.default_rng(4242)
+    ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
+    center, edge, depth = (0.0, 0.0, 0.0), 1.0, 9
+    for f in range(3):
+        base, col = surface_cloud(rng, 6000)
+        heavy = base[rng.integers(0, 6000, 6)]                       # six points repeated 700-1900 times each
+        reps = [np.repeat(h[None, :], int(k), 0) for h, k in zip(heavy, (700, 1100, 1900, 800, 1300, 1000))]
+        bad = np.full((1500, 3), np.nan, np.float32)                # a long run of rejected points (key 1)
+        outside = np.full((900, 3), 5.0, np.float32)                # outside the root cube
+        pts = np.concatenate([base] + reps + [bad, outside]).astype(np.float32)
+        pts += np.float32(0.002 * f)
+        colors = rng.integers(0, 256, (len(pts), 3), dtype=np.uint8)
+        perm = rng.permutation(len(pts))
+        pts, colors = pts[perm], colors[perm]
+        pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(colors).cuda(), depth, pool, center, edge)
+        opool.insert_cloud(pts, colors, depth, center, edge)
+        assert_pools_equal(pool, opool)
