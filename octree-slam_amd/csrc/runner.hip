@@ -203,14 +203,17 @@ int svoslam_runner_run(svoslam_runner *r, const uint16_t *const *d_depths, const
   hipStream_t all[5] = {r->s_maps, r->s_track, r->s_prep, r->s_map[0], r->s_map[1]};
   for (hipStream_t s : all) SVO_HIP(hipStreamWaitEvent(s, r->ev_begin, 0));
 
+  static const bool staged = [] { const char *e = getenv("SVOSLAM_GRAPHS"); return e && e[0] == '1'; }();
   const bool one_stream = r->maps_on_track_stream;
   hipStream_t s_maps = one_stream ? r->s_track : r->s_maps;
   auto enqueue_maps = [&](int i) -> int {  // bilateral filter + pyramids of frame i (no dependence on earlier poses)
     if (!one_stream && i >= 2) SVO_HIP(hipStreamWaitEvent(s_maps, ev_pose[i - 2], 0));  // its map set was the "last" set of frame i-2
     mark(i, 0, s_maps);
-    SVO_HIP(hipMemcpyAsync(r->in_track, d_depths[i], px * 2, hipMemcpyDeviceToDevice, s_maps));
+    // fixed input addresses only where the library replays recorded launch sequences (graphs are keyed on pointers);
+    // the caller's frames stay valid for the whole call (its stream is joined at the end)
+    if (staged) SVO_HIP(hipMemcpyAsync(r->in_track, d_depths[i], px * 2, hipMemcpyDeviceToDevice, s_maps));
     int32_t used = 0;
-    SVO_TRY(svoslam_camera_prepare(r->cam, r->in_track, d_rgbs[i], timestamps[i], &used, s_maps));
+    SVO_TRY(svoslam_camera_prepare(r->cam, staged ? r->in_track : d_depths[i], d_rgbs[i], timestamps[i], &used, s_maps));
     if (!used) return SVOSLAM_ERR_INVALID_ARG;  // cannot happen after the validation above
     if (!one_stream) SVO_HIP(hipEventRecord(ev_maps[i], s_maps));
     mark(i, 1, s_maps);
@@ -233,9 +236,11 @@ int svoslam_runner_run(svoslam_runner *r, const uint16_t *const *d_depths, const
     if (i >= kRing)  // the ring slot's previous user: both of its commits are done with workspace, points and colours
       for (int k = 0; k < R; k++) SVO_HIP(hipStreamWaitEvent(r->s_prep, ev_commit[k][i - kRing], 0));
     mark(i, 4, r->s_prep);
-    SVO_HIP(hipMemcpyAsync(r->in_prep, d_depths[i], px * 2, hipMemcpyDeviceToDevice, r->s_prep));
-    SVO_HIP(hipMemcpyAsync(r->in_rgb[i % kRing], d_rgbs[i], px * 3, hipMemcpyDeviceToDevice, r->s_prep));
-    SVO_TRY(svoslam_generate_vertex_map(r->in_prep, pts, r->w, r->h, r->fx, r->fy, r->w, r->h, r->s_prep));  // main.cpp:39
+    if (staged) {
+      SVO_HIP(hipMemcpyAsync(r->in_prep, d_depths[i], px * 2, hipMemcpyDeviceToDevice, r->s_prep));
+      SVO_HIP(hipMemcpyAsync(r->in_rgb[i % kRing], d_rgbs[i], px * 3, hipMemcpyDeviceToDevice, r->s_prep));
+    }
+    SVO_TRY(svoslam_generate_vertex_map(staged ? r->in_prep : d_depths[i], pts, r->w, r->h, r->fx, r->fy, r->w, r->h, r->s_prep));  // main.cpp:39
     SVO_TRY(svoslam_transform_vertex_map_dmat(pts, fusion_ptr[i], npts, r->s_prep));                         // main.cpp:40-41
     SVO_TRY(svoslam_point_cloud_bbox_device(r->ws[0], pts, npts, r->bbox, r->s_prep));                       // main.cpp:44
     SVO_HIP(hipEventRecord(ev_bp[i], r->s_prep));
@@ -260,7 +265,8 @@ int svoslam_runner_run(svoslam_runner *r, const uint16_t *const *d_depths, const
   auto enqueue_commit = [&](int i, int k, bool last) -> int {
     SVO_HIP(hipStreamWaitEvent(r->s_map[k], ev_plan[i], 0));
     if (k == (i & (R - 1))) mark(i, 7, r->s_map[k]);
-    SVO_TRY(svoslam_svo_fuse_commit_to(r->ws[i % kRing], r->in_rgb[i % kRing], npts, r->depth, replica(r, k), k, last ? 0 : 1, r->s_map[k]));
+    SVO_TRY(svoslam_svo_fuse_commit_to(r->ws[i % kRing], staged ? r->in_rgb[i % kRing] : d_rgbs[i], npts, r->depth, replica(r, k), k,
+                                       last ? 0 : 1, r->s_map[k]));
     SVO_HIP(hipEventRecord(ev_commit[k][i], r->s_map[k]));
     if (k == (i & (R - 1))) mark(i, 8, r->s_map[k]);
     return SVOSLAM_OK;
