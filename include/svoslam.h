@@ -170,6 +170,17 @@ int svoslam_svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int3
  * Replicas must have been given the same capacity.  svoslam_svo_fuse_commit == (slot 0, keep_plan 0). */
 int svoslam_svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, int32_t n, int32_t max_depth,
                                svoslam_pool *pool, int32_t slot, int32_t keep_plan, void *stream);
+/* The commit in two halves, for callers that ray-march the map while the next frame is being fused (the frame
+ * scheduler): svoslam_svo_fuse_commit_deferred does all the work of the commit -- splitNodes, fillNodes, mipmapNodes,
+ * svo.cu:239-465 -- without a store a concurrent cone trace of the pool in its present state can observe (new tiles
+ * lie beyond the pool's size, colour words go to a shadow array of 8 bytes per node of capacity, the links of the
+ * first-pass split nodes wait); svoslam_svo_fuse_apply (same workspace, before it is used again; any stream ordered
+ * after the deferred call AND after the last reader of the old state) publishes it in one short launch.  Between the
+ * two the pool may be read (old state) but not fused into, saved or resized; one deferred commit per pool at a time.
+ * deferred + apply == svoslam_svo_fuse_commit, byte for byte. */
+int svoslam_svo_fuse_commit_deferred(svoslam_workspace *ws, const uint8_t *d_colors, int32_t n, int32_t max_depth,
+                                     svoslam_pool *pool, void *stream);
+int svoslam_svo_fuse_apply(svoslam_workspace *ws, svoslam_pool *pool, void *stream);
 
 /* replaces svo::svoFromVoxelGrid (svo.h:14, svo.cu:584-640).  d_centers,
  * d_colors: n x vec4 (VoxelGrid, common_types.h:55-63). */

@@ -89,6 +89,8 @@ SIGNATURES = {
     "svoslam_svo_fuse_plan": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_commit": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_commit_to": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _i32, _i32, _vp]),
+    "svoslam_svo_fuse_commit_deferred": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
+    "svoslam_svo_fuse_apply": (C.c_int, [_vp, C.POINTER(_PoolStruct), _vp]),
     "svoslam_frame_reader_open": (C.c_int, [C.POINTER(_vp), C.c_char_p, _f32]),
     "svoslam_frame_reader_close": (C.c_int, [_vp]),
     "svoslam_frame_reader_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
@@ -388,6 +390,16 @@ def svo_fuse_commit_to(ws, colors, max_depth, pool, slot, keep_plan):
     n = int(colors.shape[0]) if colors is not None else 0
     check(lib().svoslam_svo_fuse_commit_to(ws._h, _ptr(colors), n, max_depth, C.byref(pool._p), int(slot), 1 if keep_plan else 0,
                                            _stream()))
+
+
+def svo_fuse_commit_deferred(ws, colors, max_depth, pool):
+    """phase 3 without a store a concurrent render of the pool's present state can see; svo_fuse_apply publishes it"""
+    n = int(colors.shape[0]) if colors is not None else 0
+    check(lib().svoslam_svo_fuse_commit_deferred(ws._h, _ptr(colors), n, max_depth, C.byref(pool._p), _stream()))
+
+
+def svo_fuse_apply(ws, pool):
+    check(lib().svoslam_svo_fuse_apply(ws._h, C.byref(pool._p), _stream()))
 
 
 def svo_from_voxel_grid(ws, centers, colors, max_depth, pool, center, edge_length):

@@ -177,6 +177,15 @@ int svoslam_svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, i
   NEED_DEVICE();
   return svo_fuse_commit_to(ws, d_colors, n, max_depth, pool, slot, keep_plan != 0, S(stream));
 }
+int svoslam_svo_fuse_commit_deferred(svoslam_workspace *ws, const uint8_t *d_colors, int32_t n, int32_t max_depth, svoslam_pool *pool,
+                                     void *stream) {
+  NEED_DEVICE();
+  return svo_fuse_commit_deferred(ws, d_colors, n, max_depth, pool, S(stream));
+}
+int svoslam_svo_fuse_apply(svoslam_workspace *ws, svoslam_pool *pool, void *stream) {
+  NEED_DEVICE();
+  return svo_fuse_apply(ws, pool, S(stream));
+}
 
 int svoslam_frame_reader_open(svoslam_frame_reader **reader, const char *association_file, float depth_units_per_metre) {
   return frame_reader_open(reader, association_file, depth_units_per_metre);

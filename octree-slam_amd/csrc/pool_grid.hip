@@ -32,7 +32,8 @@ void pool_accel_rebind(const uint32_t *old_data, const uint32_t *new_data) {
   auto stale = g_accel.find(new_data);
   if (stale != g_accel.end()) {  // an entry left behind by memory freed without svoslam_pool_free
     stale->second->grid.release();
-    if (stale->second->d_dirty) (void)hipFree(stale->second->d_dirty);
+    stale->second->shadow.release();
+    for (uint32_t *d : stale->second->d_dirty) if (d) (void)hipFree(d);
     g_accel.erase(stale);
   }
   auto it = old_data ? g_accel.find(old_data) : g_accel.end();
@@ -51,7 +52,8 @@ void pool_accel_unregister(svoslam_pool *pool) {
   auto it = g_accel.find(pool->d_data);
   if (it == g_accel.end()) return;
   it->second->grid.release();
-  if (it->second->d_dirty) (void)hipFree(it->second->d_dirty);
+  it->second->shadow.release();
+  for (uint32_t *d : it->second->d_dirty) if (d) (void)hipFree(d);
   g_accel.erase(it);
 }
 
@@ -62,12 +64,70 @@ void pool_accel_invalidate(svoslam_pool *pool) {
   if (it != g_accel.end()) it->second->valid = false;
 }
 
-uint32_t *pool_accel_dirty_bitmap(svoslam_pool *pool) {
+static bool ensure_dirty_states(PoolAccel *pa) {
+  for (int k = 0; k < 2; k++) {
+    if (pa->d_dirty[k]) continue;
+    if (hipMalloc((void **)&pa->d_dirty[k], kPoolGridStateWords * 4) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipMemset(pa->d_dirty[k], 0, kPoolGridStateWords * 4) != hipSuccess) { (void)hipGetLastError(); return false; }
+  }
+  return true;
+}
+
+// Commits mark from the first one on, whether or not a grid exists yet: whether the NEXT render builds the grid in full
+// is decided when that render is enqueued, which may be after the commit was (the scheduler enqueues the deferred
+// commit of frame k+1 before the render of frame k).
+uint32_t *pool_accel_dirty_bitmap(svoslam_pool *pool, int parity) {
   if (!pool || !pool->d_data) return nullptr;
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_accel.find(pool->d_data);
-  if (it == g_accel.end() || !it->second->valid) return nullptr;  // nothing to keep up to date (a full build is pending anyway)
-  return it->second->d_dirty;
+  if (it == g_accel.end() || !ensure_dirty_states(it->second.get())) return nullptr;
+  return it->second->d_dirty[parity & 1];
+}
+
+int pool_shadow_begin(svoslam_pool *pool, hipStream_t stream, unsigned long long **d_shadow, uint32_t *epoch) {
+  if (!pool || !pool->d_data || !d_shadow || !epoch) return SVOSLAM_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_accel.find(pool->d_data);
+  if (it == g_accel.end()) return SVOSLAM_ERR_INVALID_ARG;  // not a pool of this library
+  PoolAccel *pa = it->second.get();
+  if (pa->deferred_pending) return SVOSLAM_ERR_INVALID_ARG;  // one deferred commit at a time: apply it first
+  if (pa->shadow_nodes < (size_t)pool->capacity) {
+    // (never between a deferred commit and its apply: the pool only grows with nothing in flight)
+    pa->shadow.release();
+    SVO_TRY(pa->shadow.reserve((size_t)pool->capacity * 8));
+    SVO_HIP(hipMemsetAsync(pa->shadow.ptr, 0, (size_t)pool->capacity * 8, stream));  // epoch 0 is never current
+    pa->shadow_nodes = (size_t)pool->capacity;
+    pa->epoch = 0;
+  }
+  pa->epoch += 1;
+  pa->deferred_pending = true;
+  *d_shadow = pa->shadow.as<unsigned long long>();
+  *epoch = pa->epoch;
+  return SVOSLAM_OK;
+}
+
+int pool_shadow_current(svoslam_pool *pool, unsigned long long **d_shadow, uint32_t *epoch) {
+  if (!pool || !pool->d_data || !d_shadow || !epoch) return SVOSLAM_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_accel.find(pool->d_data);
+  if (it == g_accel.end() || !it->second->deferred_pending) return SVOSLAM_ERR_INVALID_ARG;
+  *d_shadow = it->second->shadow.as<unsigned long long>();
+  *epoch = it->second->epoch;
+  return SVOSLAM_OK;
+}
+
+void pool_shadow_end(svoslam_pool *pool) {
+  if (!pool || !pool->d_data) return;
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_accel.find(pool->d_data);
+  if (it != g_accel.end()) it->second->deferred_pending = false;
+}
+
+bool pool_shadow_pending(svoslam_pool *pool) {
+  if (!pool || !pool->d_data) return false;
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_accel.find(pool->d_data);
+  return it != g_accel.end() && it->second->deferred_pending;
 }
 
 PoolAccel *pool_accel_find(const uint32_t *d_data) {
@@ -96,13 +156,14 @@ __device__ inline uint2 grid_entry(const uint2 *__restrict__ nodes, uint32_t xi,
 }
 
 __global__ __launch_bounds__(256) void pool_grid_build_kernel(const uint32_t *__restrict__ octree, uint2 *__restrict__ grid,
-                                                              uint32_t *__restrict__ dirty) {
+                                                              uint32_t *__restrict__ dirty_a, uint32_t *__restrict__ dirty_b) {
   constexpr int G = kPoolGridLevel;
   constexpr uint32_t kAxisMask = (1u << G) - 1u;
   const uint32_t e = blockIdx.x * 256u + threadIdx.x;
   grid[e] = grid_entry(reinterpret_cast<const uint2 *>(octree), e & kAxisMask, (e >> G) & kAxisMask, e >> (2 * G));
-  if (e < (uint32_t)kPoolGridDirtyWords) dirty[e] = 0u;
-  if (e == 0) dirty[kPoolGridCountOffset] = 0u;
+  // every mark made so far is served by this build (not those of a deferred commit still running: dirty_b == nullptr)
+  if (e < (uint32_t)kPoolGridDirtyWords) { dirty_a[e] = 0u; if (dirty_b) dirty_b[e] = 0u; }
+  if (e == 0) { dirty_a[kPoolGridCountOffset] = 0u; if (dirty_b) dirty_b[kPoolGridCountOffset] = 0u; }
 }
 
 // one WORKGROUP per listed block (the list is compacted from the bitmap at the end of every commit), one cell per lane:
@@ -133,19 +194,29 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
   if (!pa || !d_octree || !d_grid) return SVOSLAM_ERR_INVALID_ARG;
   constexpr size_t kCells = (size_t)1 << (3 * kPoolGridLevel);
   bool fresh = false;
+  uint32_t *serve[2] = {nullptr, nullptr};  // the dirty states this render consumes
   {
     std::lock_guard<std::mutex> lock(g_mu);
     if (!pa->grid.ptr) {
       SVO_TRY(pa->grid.reserve(kCells * sizeof(uint2)));
-      SVO_HIP(hipMalloc((void **)&pa->d_dirty, kPoolGridStateWords * 4));
       pa->valid = false;
     }
+    if (!ensure_dirty_states(pa)) return SVOSLAM_ERR_HIP;
     fresh = !pa->valid;
-    pa->valid = true;  // commits enqueued from now on mark their blocks
+    pa->valid = true;
+    if (pa->deferred_pending) {  // that commit's marks (parity of its epoch) belong to the render after its apply
+      serve[0] = pa->d_dirty[(pa->epoch + 1u) & 1u];
+    } else {
+      serve[0] = pa->d_dirty[0]; serve[1] = pa->d_dirty[1];
+    }
   }
   uint2 *grid = pa->grid.as<uint2>();
-  if (fresh) pool_grid_build_kernel<<<(unsigned)(kCells / 256), 256, 0, stream>>>(d_octree, grid, pa->d_dirty);
-  else pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, pa->d_dirty);
+  if (fresh) {
+    pool_grid_build_kernel<<<(unsigned)(kCells / 256), 256, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
+  } else {
+    for (uint32_t *d : serve)
+      if (d) pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, d);
+  }
   SVO_LAUNCH_CHECK();
   *d_grid = grid;
   return SVOSLAM_OK;

@@ -30,9 +30,18 @@ constexpr int kPoolGridDirtyWords = kPoolGridBlocks / 32;  // 4 KB bitmap
 
 struct PoolAccel {
   DeviceBuffer grid;          // uint2[2^(3 G)], empty until the pool is rendered for the first time
-  uint32_t *d_dirty = nullptr;  // device: bitmap over the level-B blocks [kPoolGridDirtyWords], then the compacted list of the
-                                // marked blocks [kPoolGridBlocks] and its length [1] (written at the end of every commit)
+  // device, two of them: bitmap over the level-B blocks [kPoolGridDirtyWords], then the compacted list of the marked
+  // blocks [kPoolGridBlocks] and its length [1] (written at the end of every commit).  Direct commits mark state 0, a
+  // deferred commit the state of its epoch's parity -- it runs next to the render of the previous frame, whose
+  // refresh must neither see nor clear its marks: a refresh leaves the state of a pending deferred commit alone.
+  uint32_t *d_dirty[2] = {nullptr, nullptr};
   bool valid = false;         // false: rebuild everything at the next render
+  // deferred commits (svo_build.hip, svo_fuse_commit_deferred / svo_fuse_apply): colour words a commit computes while the
+  // previous frame is still being ray-marched; entry = epoch << 32 | word, valid for the commit whose epoch it carries
+  DeviceBuffer shadow;
+  size_t shadow_nodes = 0;
+  uint32_t epoch = 0;
+  bool deferred_pending = false;
 };
 
 // registry (guarded by a mutex inside), keyed by the address of the node memory: pools are known from pool_init
@@ -41,8 +50,14 @@ void pool_accel_register(svoslam_pool *pool);
 void pool_accel_rebind(const uint32_t *old_data, const uint32_t *new_data);  // the nodes moved to a larger allocation
 void pool_accel_unregister(svoslam_pool *pool);
 void pool_accel_invalidate(svoslam_pool *pool);
-uint32_t *pool_accel_dirty_bitmap(svoslam_pool *pool);   // nullptr while the pool has no grid (commits then mark nothing)
+uint32_t *pool_accel_dirty_bitmap(svoslam_pool *pool, int parity);  // nullptr for memory that is not a registered pool
 PoolAccel *pool_accel_find(const uint32_t *d_data);      // the registered pool whose nodes start at d_data, or nullptr
+
+// shadow words of the pool (allocated and zeroed on first use / growth), the epoch of the commit that starts now
+int pool_shadow_begin(svoslam_pool *pool, hipStream_t stream, unsigned long long **d_shadow, uint32_t *epoch);
+int pool_shadow_current(svoslam_pool *pool, unsigned long long **d_shadow, uint32_t *epoch);  // of the pending deferred commit
+void pool_shadow_end(svoslam_pool *pool);
+bool pool_shadow_pending(svoslam_pool *pool);
 
 // enqueue on `stream`: bring the grid of `pa` up to date with its pool (full build or dirty blocks only); returns the grid
 int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stream, const uint2 **d_grid);

@@ -222,10 +222,13 @@ __global__ __launch_bounds__(256) void split_all_kernel(const u64 *__restrict__ 
                                                         const unsigned char *__restrict__ rec_pass,
                                                         const u32 *__restrict__ bucket_base, const PlanCounts *__restrict__ counts,
                                                         u32 *__restrict__ pool, const int *__restrict__ d_size, int depth,
-                                                        u32 *__restrict__ grid_dirty) {
+                                                        u32 *__restrict__ grid_dirty, u32 *__restrict__ n0_saved) {
   SVO_HIGH_PRIO();  // commit kernels sit between two raycasts on the map stream
   const u32 total = (u32)counts->total_records;
   const u32 n0 = (u32)*d_size;
+  // n0_saved != nullptr: deferred commit -- the links of the pass-0 records (the only words of this kernel a concurrent
+  // ray march could see) are left to commit_apply_kernel, which needs the first tile index
+  if (n0_saved && blockIdx.x == 0 && threadIdx.x == 0) *n0_saved = n0;
   for (u32 r = blockIdx.x * 256u + threadIdx.x; r < total; r += gridDim.x * 256u) {
     const u64 key = rec_key[r];
     const int pass = rec_pass[r];
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256) void split_all_kernel(const u64 *__restrict__ 
     // level grid of the ray march (pool_grid.hpp): a split above the block level re-labels the whole cube of its node
     if (grid_dirty && d < kPoolGridBlockLevel) pool_grid_mark(grid_dirty, key, d);
     const u32 child = n0 + 8u * r;
-    if (pass == 0) pool[2 * (size_t)rec_front[r]] = kFlag + (child & kMask);
+    if (pass == 0 && !n0_saved) pool[2 * (size_t)rec_front[r]] = kFlag + (child & kMask);
     u32 w0[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     if (d + 1 <= depth - 1) {  // children at depth d+1 can only be records while d+1 < D
       const u32 b = bucket_id(pass + 1, d + 1);
@@ -359,6 +362,31 @@ __device__ inline u32 average_tile(const u32 *__restrict__ pool, u32 child_base)
   return (r >> 3) + ((g >> 3) << 8) + ((b >> 3) << 16) + (a << 24);
 }
 
+// the same over the words a deferred commit sees: a child written by THIS commit has its word in the shadow array
+// (entry = epoch << 32 | word), every other child keeps the pool's word
+__device__ inline u32 average_tile_deferred(const u32 *__restrict__ pool, const unsigned long long *__restrict__ shadow, u32 epoch,
+                                            u32 child_base) {
+  const uint4 *tile = reinterpret_cast<const uint4 *>(pool + 2 * (size_t)child_base);
+  const uint4 *sh = reinterpret_cast<const uint4 *>(shadow + child_base);  // 8 entries of 8 bytes: {word, epoch} pairs
+  u32 r = 0, g = 0, b = 0, a = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const uint4 v = tile[q];
+    const uint4 t = sh[q];
+    const u32 w1a = t.y == epoch ? t.x : v.y, w1b = t.w == epoch ? t.z : v.w;
+    r += (w1a & 0xFF) + (w1b & 0xFF);
+    g += ((w1a >> 8) & 0xFF) + ((w1b >> 8) & 0xFF);
+    b += ((w1a >> 16) & 0xFF) + ((w1b >> 16) & 0xFF);
+    const u32 aa = w1a >> 24, ab = w1b >> 24;
+    a = a > aa ? a : aa;
+    a = a > ab ? a : ab;
+  }
+  return (r >> 3) + ((g >> 3) << 8) + ((b >> 3) << 16) + (a << 24);
+}
+__device__ inline void shadow_store(unsigned long long *__restrict__ shadow, u32 epoch, u32 node, u32 word) {
+  shadow[node] = ((unsigned long long)epoch << 32) | word;
+}
+
 __global__ __launch_bounds__(256) void mip_level_kernel(const u64 *__restrict__ skey, int n, int depth, int d,
                                                         const unsigned char *__restrict__ leaf_t,
                                                         const u32 *__restrict__ path_nodes, u32 *__restrict__ pool) {
@@ -401,7 +429,15 @@ constexpr int kFillThreads = SVO_FILL_THREADS;  // leaves per workgroup.  Larger
 __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 *__restrict__ skey, const u32 *__restrict__ sidx, int n,
                                                              int depth, const unsigned char *__restrict__ leaf_t,
                                                              const unsigned char *__restrict__ colors, u32 *__restrict__ pool,
-                                                             u32 *__restrict__ strad, int num_tiles, u32 *__restrict__ grid_dirty) {
+                                                             u32 *__restrict__ strad, int num_tiles, u32 *__restrict__ grid_dirty,
+                                                             unsigned long long *__restrict__ shadow, u32 epoch,
+                                                             u32 *__restrict__ apply_nodes, const u64 *__restrict__ rec_key,
+                                                             const u32 *__restrict__ bucket_base, const u32 *__restrict__ n0_saved) {
+  // shadow != nullptr: deferred commit.  Every colour word goes to shadow[node] instead of the pool, children are read
+  // through average_tile_deferred, and apply_nodes[(level - 1) * n + j] names the node lane j wrote at that level
+  // (level `depth` = the leaf; kNoStraddler = none) for commit_apply_kernel.  The link from the key's frontier node
+  // (the first node on its path without children, depth leaf_t[j]) to its new child tile is not in the pool yet either:
+  // the tile is n0 + 8 x (rank of the pass-0 record of that prefix), found by key in the record bucket (0, leaf_t[j]).
   SVO_HIGH_PRIO();  // commit kernels sit between two raycasts on the map stream
   __shared__ int last_owner[SVOSLAM_MAX_DEPTH + 1];  // per level: last lane of this workgroup owning a node there
   __shared__ int next_pos, next_c;                   // first head lane after this workgroup and its common-prefix length
@@ -457,6 +493,19 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
     next_c = (key_np == 1ull) ? 0 : common_levels(key_n, key_np, depth);
   }
   FILL_STAMP(1)
+  int frontier = 0;       // level whose link is deferred (0: none)
+  u32 frontier_child = 0;
+  if (shadow && head && lt != kNoSplit && (int)lt < depth) {
+    frontier = (int)lt;
+    const u64 prefix = key >> (3 * (depth - frontier));
+    const u32 b = bucket_id(0, frontier);
+    u32 lo = bucket_base[b], hi = bucket_base[b + 1];
+    while (lo < hi) {  // the record exists: every head's path is split down to depth - 1
+      const u32 mid = (lo + hi) >> 1;
+      if (rec_key[mid] < prefix) lo = mid + 1; else hi = mid;
+    }
+    frontier_child = *n0_saved + 8u * lo;
+  }
   // walk to the leaf (fillNodes, svo.cu:291-382), remembering the owned nodes and their child tiles
   u32 node_at[SVOSLAM_MAX_DEPTH], child_at[SVOSLAM_MAX_DEPTH];
 #pragma unroll
@@ -472,28 +521,40 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
         node = base + ((u32)(key >> (3 * (depth - lvl))) & 7u);
         if (lvl < depth) {
           base = pool[2 * (size_t)node] & kMask;
+          if (lvl == frontier) base = frontier_child & kMask;
           node_at[lvl] = node;
           child_at[lvl] = base;
         }
       }
     }
     FILL_STAMP(2)
-    pool[2 * (size_t)node + 1] = blend_color256(pool[2 * (size_t)node + 1], cr, cg, cb);
+    const u32 word = blend_color256(pool[2 * (size_t)node + 1], cr, cg, cb);
+    if (shadow) shadow_store(shadow, epoch, node, word);
+    else pool[2 * (size_t)node + 1] = word;
+    node_at[0] = node;  // (slot 0 is free: the root is not a lane's node)
   }
+  if (shadow && j < n) apply_nodes[(size_t)(depth - 1) * n + j] = head ? node_at[0] : kNoStraddler;
   FILL_STAMP(3)
   __syncthreads();
   FILL_STAMP(4)
 #pragma unroll
   for (int d = SVOSLAM_MAX_DEPTH - 1; d >= 1; d--) {
     if (d < depth) {
+      u32 wrote = kNoStraddler;
       if (head && c < d) {  // this lane owns its level-d prefix
         if (j != last_owner[d] || next_c < d) {
-          pool[2 * (size_t)node_at[d] + 1] = average_tile(pool, child_at[d]);
+          if (shadow) {
+            shadow_store(shadow, epoch, node_at[d], average_tile_deferred(pool, shadow, epoch, child_at[d]));
+            wrote = node_at[d];
+          } else {
+            pool[2 * (size_t)node_at[d] + 1] = average_tile(pool, child_at[d]);
+          }
         } else {  // the run continues in a later workgroup
           strad[2 * ((size_t)d * num_tiles + blockIdx.x)] = node_at[d];
           strad[2 * ((size_t)d * num_tiles + blockIdx.x) + 1] = child_at[d];
         }
       }
+      if (shadow && j < n) apply_nodes[(size_t)(d - 1) * n + j] = wrote;
       __syncthreads();
     }
   }
@@ -516,8 +577,15 @@ constexpr int kStradThreads = SVO_STRAD_THREADS;
 __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__restrict__ pool, const u32 *__restrict__ strad, int num_tiles,
                                                             int depth, const PlanCounts *__restrict__ counts,
                                                             int *__restrict__ d_size, u32 *__restrict__ grid_dirty,
-                                                            int32_t *__restrict__ h_sizes, int *__restrict__ d_slot) {
+                                                            int32_t *__restrict__ h_sizes, int *__restrict__ d_slot,
+                                                            unsigned long long *__restrict__ shadow, u32 epoch) {
   SVO_HIGH_PRIO();  // commit kernels sit between two raycasts on the map stream
+  // shadow != nullptr: deferred commit (see fill_mip_local_kernel); the list entries double as the apply list
+  auto average = [&](u32 child_base) { return shadow ? average_tile_deferred(pool, shadow, epoch, child_base) : average_tile(pool, child_base); };
+  auto store = [&](u32 node, u32 word) {
+    if (shadow) shadow_store(shadow, epoch, node, word);
+    else pool[2 * (size_t)node + 1] = word;
+  };
   // a thread's list entries do not depend on the levels below, so those of the next level are fetched while
   // this level's tiles are averaged (one dependent load per level instead of two); kSlots entries per thread
   // in registers cover 8192 workgroups (2 M points: 1920x1080), longer lists fall back to the plain loop
@@ -538,19 +606,19 @@ __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__rest
       fetch(d - 1, nxt);
 #pragma unroll
       for (int q = 0; q < kSlots; q++)
-        if (cur[q].x != kNoStraddler) pool[2 * (size_t)cur[q].x + 1] = average_tile(pool, cur[q].y);
+        if (cur[q].x != kNoStraddler) store(cur[q].x, average(cur[q].y));
 #pragma unroll
       for (int q = 0; q < kSlots; q++) cur[q] = nxt[q];
     } else {
       for (int t = (int)threadIdx.x; t < num_tiles; t += kStradThreads) {
         const uint2 e = list[(size_t)d * num_tiles + t];
-        if (e.x != kNoStraddler) pool[2 * (size_t)e.x + 1] = average_tile(pool, e.y);
+        if (e.x != kNoStraddler) store(e.x, average(e.y));
       }
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    if (counts->any_valid) pool[1] = average_tile(pool, 0);
+    if (counts->any_valid) store(0u, average(0u));
     const int size_now = *d_size + 8 * counts->total_records;
     *d_size = size_now;
     if (h_sizes) {  // the host learns the size from pinned memory behind the commit's event (PoolTracker)
@@ -562,6 +630,32 @@ __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__rest
   // last kernel of the commit: every mark of this commit is in the bitmap (kernel boundaries); list the marked blocks
   // for the next render's refresh of the level grid (pool_grid.hpp)
   if (grid_dirty) pool_grid_compact(grid_dirty, kStradThreads);
+}
+
+// Second half of a deferred commit: everything the commit computed while the previous frame was being ray-marched
+// becomes visible -- the colour words from the shadow array (apply_nodes: one slot per sorted key and level; the
+// straddler list; the root), and the links of the pass-0 split records to their (already initialised) child tiles.
+// Every word is written once; ~0.6 M scattered 4-byte stores at 640x480.
+__global__ __launch_bounds__(256) void commit_apply_kernel(u32 *__restrict__ pool, const unsigned long long *__restrict__ shadow,
+                                                           const u32 *__restrict__ apply_nodes, long long slots,
+                                                           const u32 *__restrict__ strad, int strad_first, int strad_end,
+                                                           const u32 *__restrict__ rec_front, const unsigned char *__restrict__ rec_pass,
+                                                           const PlanCounts *__restrict__ counts, const u32 *__restrict__ n0_saved) {
+  SVO_HIGH_PRIO();
+  const long long stride = (long long)gridDim.x * 256, t0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (long long i = t0; i < slots; i += stride) {
+    const u32 node = apply_nodes[i];
+    if (node != kNoStraddler) pool[2 * (size_t)node + 1] = (u32)shadow[node];
+  }
+  for (long long i = strad_first + t0; i < strad_end; i += stride) {
+    const u32 node = strad[2 * i];
+    if (node != kNoStraddler) pool[2 * (size_t)node + 1] = (u32)shadow[node];
+  }
+  const long long total = counts->total_records;
+  const u32 n0 = *n0_saved;
+  for (long long r = t0; r < total; r += stride)
+    if (rec_pass[r] == 0) pool[2 * (size_t)rec_front[r]] = kFlag + ((n0 + 8u * (u32)r) & kMask);
+  if (t0 == 0 && counts->any_valid) pool[1] = (u32)shadow[0];
 }
 
 // ----------------------------------------------------------------------------
@@ -891,11 +985,12 @@ static int reserve_common(svoslam_workspace *ws, int n, int depth) {
   return SVOSLAM_OK;
 }
 
-// layout of ws->small (u32 words): [0,256) totals | [256,513) bucket_base | [520..) PlanCounts | [640] any_valid
+// layout of ws->small (u32 words): [0,256) totals | [256,513) bucket_base | [520..) PlanCounts | [640] any_valid | [648] n0
 static inline u32 *small_totals(svoslam_workspace *ws) { return ws->small.as<u32>(); }
 static inline u32 *small_bucket_base(svoslam_workspace *ws) { return ws->small.as<u32>() + 256; }
 static inline PlanCounts *small_counts(svoslam_workspace *ws) { return reinterpret_cast<PlanCounts *>(ws->small.as<u32>() + 520); }
 static inline int *small_any(svoslam_workspace *ws) { return reinterpret_cast<int *>(ws->small.as<u32>() + 640); }
+static inline u32 *small_n0(svoslam_workspace *ws) { return ws->small.as<u32>() + 648; }  // deferred commit: first new tile
 
 // keys of the n inputs are in ws->keys_a
 static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, const void *d_colors, bool vec4,
@@ -1058,13 +1153,18 @@ int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, h
 // one map (the frame scheduler ray-marches one replica while the next frame is committed to the other): the same plan
 // -- made against ANY of the replicas in the state before this commit -- is applied to each of them, every
 // application with its own slot (0 or 1: the scratch list of the mip pass) and all but the last with keep_plan.
-int svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, int slot,
-                       bool keep_plan, hipStream_t stream) {
+static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, int slot,
+                       bool keep_plan, bool deferred, hipStream_t stream) {
   if (!ws || !pool || n < 0 || (n > 0 && !d_colors) || slot < 0 || slot > 1) return SVOSLAM_ERR_INVALID_ARG;
+  if (pool_shadow_pending(pool)) return SVOSLAM_ERR_INVALID_ARG;  // a deferred commit of this pool has not been applied
   if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
   if (ws->planned_n != n) return SVOSLAM_ERR_INVALID_ARG;  // svo_fuse_plan has not run for this batch
   if (!keep_plan) ws->planned_n = -1;
-  if (n == 0) return SVOSLAM_OK;
+  ws->deferred_pool = nullptr;
+  if (n == 0) {
+    if (deferred) { ws->deferred_pool = pool; ws->deferred_n = 0; }
+    return SVOSLAM_OK;
+  }
   const int64_t rmax = max_records(n, depth);
   if (pool != ws->planned_pool) {  // a replica the plan did not look at: same tree, same worst case, its own bookkeeping
     SVO_TRY(ensure_device_size(pool, stream));
@@ -1083,20 +1183,34 @@ int svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   DeviceBuffer &sb = slot == 0 ? ws->strad : ws->strad_b;
   SVO_TRY(sb.reserve((size_t)(SVOSLAM_MAX_DEPTH + 1) * (size_t)fill_tiles * 8));
   u32 *strad = sb.as<u32>();
-  u32 *grid_dirty = pool_accel_dirty_bitmap(pool);  // nullptr unless the pool has an up-to-date level grid to maintain
   SVO_TRY(ensure_device_size(pool, stream));         // (creates the size tracker)
   PoolTracker *trk = tracker_of(pool);
+  unsigned long long *shadow = nullptr;
+  u32 epoch = 0, *apply_nodes = nullptr;
+  if (deferred) {
+    SVO_TRY(ws->apply_nodes.reserve((size_t)n * (size_t)depth * 4));
+    apply_nodes = ws->apply_nodes.as<u32>();
+    SVO_TRY(pool_shadow_begin(pool, stream, &shadow, &epoch));
+    ws->deferred_pool = pool; ws->deferred_n = n; ws->deferred_depth = depth; ws->deferred_tiles = fill_tiles;
+  }
+  u32 *grid_dirty = pool_accel_dirty_bitmap(pool, deferred ? (int)(epoch & 1u) : 0);  // nullptr: not a registered pool
   auto enqueue = [&]() -> int {
     split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
                                                        ws->rec_pass.as<unsigned char>(), small_bucket_base(ws), small_counts(ws),
-                                                       pool->d_data, pool->d_size, depth, grid_dirty);
+                                                       pool->d_data, pool->d_size, depth, grid_dirty, deferred ? small_n0(ws) : nullptr);
     fill_mip_local_kernel<<<fill_tiles, kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
-                                                                   grid_dirty);
+                                                                   grid_dirty, shadow, epoch, apply_nodes, ws->rec_key.as<u64>(),
+                                                                   small_bucket_base(ws), small_n0(ws));
     mip_straddle_kernel<<<1, kStradThreads, 0, stream>>>(pool->d_data, strad, fill_tiles, depth, small_counts(ws), pool->d_size, grid_dirty,
-                                                         trk ? trk->h_size : nullptr, trk ? trk->d_slot : nullptr);
+                                                         trk ? trk->h_size : nullptr, trk ? trk->d_slot : nullptr, shadow, epoch);
     SVO_LAUNCH_CHECK();
     return SVOSLAM_OK;
   };
+  if (deferred) {  // the epoch changes with every call: not a recorded sequence
+    SVO_TRY(enqueue());
+    pool->pending += 1;
+    return tracker_push(pool, 8 * rmax, stream);
+  }
   GraphKey key;
   key.add(skey).add(d_colors).add((unsigned long long)n).add((unsigned long long)depth).add(pool->d_data).add(pool->d_size)
      .add((unsigned long long)slot).add(grid_dirty).add(trk ? (const void *)trk->h_size : nullptr).add(ws->layout_hash());
@@ -1105,8 +1219,43 @@ int svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   return tracker_push(pool, 8 * rmax, stream);
 }
 
+int svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, int slot,
+                       bool keep_plan, hipStream_t stream) {
+  return commit_impl(ws, d_colors, n, depth, pool, slot, keep_plan, false, stream);
+}
+
 int svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, hipStream_t stream) {
-  return svo_fuse_commit_to(ws, d_colors, n, depth, pool, 0, false, stream);
+  return commit_impl(ws, d_colors, n, depth, pool, 0, false, false, stream);
+}
+
+// Deferred commit: the commit's whole computation (splits, leaf blends, mip levels) WITHOUT a single store a ray march
+// of the pool in its present state could observe -- new tiles lie beyond the pool's size, colour words go to a shadow
+// array, the links of the pass-0 records wait -- so it may run while the previous frame is still being rendered.
+// svo_fuse_apply (same workspace, before the workspace is used again) then publishes it with one short launch; the
+// pool must not be read by anything that expects the new state, nor written, in between.  Same final pool contents as
+// svo_fuse_commit.  Used by the frame scheduler: its map stream carries apply + march instead of commit + march.
+int svo_fuse_commit_deferred(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, hipStream_t stream) {
+  return commit_impl(ws, d_colors, n, depth, pool, 0, false, true, stream);
+}
+
+int svo_fuse_apply(svoslam_workspace *ws, svoslam_pool *pool, hipStream_t stream) {
+  if (!ws || !pool || ws->deferred_pool != pool) return SVOSLAM_ERR_INVALID_ARG;
+  ws->deferred_pool = nullptr;
+  const int n = ws->deferred_n, depth = ws->deferred_depth, tiles = ws->deferred_tiles;
+  if (n == 0) return SVOSLAM_OK;
+  unsigned long long *shadow = nullptr;
+  u32 epoch = 0;
+  SVO_TRY(pool_shadow_current(pool, &shadow, &epoch));
+  const long long slots = (long long)n * depth;
+  int blocks = (int)cdiv(slots, 256 * 4);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  commit_apply_kernel<<<blocks, 256, 0, stream>>>(pool->d_data, shadow, ws->apply_nodes.as<u32>(), slots, ws->strad.as<u32>(), tiles,
+                                                  depth * tiles, ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>(),
+                                                  small_counts(ws), small_n0(ws));
+  SVO_LAUNCH_CHECK();
+  pool_shadow_end(pool);
+  return SVOSLAM_OK;
 }
 
 int svo_from_point_cloud_async(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,

@@ -26,6 +26,8 @@ int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, h
 int svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, int slot, bool keep_plan,
                        hipStream_t stream);
 int svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, hipStream_t stream);
+int svo_fuse_commit_deferred(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, hipStream_t stream);
+int svo_fuse_apply(svoslam_workspace *ws, svoslam_pool *pool, hipStream_t stream);
 int svo_from_point_cloud(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,
                          svoslam_pool *pool, const float center[3], float edge, svoslam_fuse_stats *stats,
                          hipStream_t stream);

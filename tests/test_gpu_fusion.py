@@ -256,3 +256,41 @@ def test_async_fusion_long_runs_of_duplicates_and_invalid_points(env, oracle):
         pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(colors).cuda(), depth, pool, center, edge)
         opool.insert_cloud(pts, colors, depth, center, edge)
         assert_pools_equal(pool, opool)
+
+
+@pytest.mark.parametrize("depth,n,frames", [(2, 500, 3), (6, 20000, 4), (10, 40000, 4), (12, 60000, 3), (16, 20000, 2)])
+def test_deferred_commit_then_apply_matches_oracle(env, oracle, depth, n, frames):
+    """svoslam_svo_fuse_commit_deferred leaves every node below the pool's size as it was (what a concurrent ray march
+    reads), svoslam_svo_fuse_apply then makes the pool the oracle's; a render between the two sees the old map"""
+    pkg, torch = env
+    rng = np.random.default_rng(900 + depth)
+    ws, pool = pkg.Workspace(), pkg.Pool()
+    opool = oracle.Pool()
+    center, edge = (0.05, -0.02, 0.01), 1.0
+    view = oracle.look_at((0.2, 0.3, -2.2), (0, 0, 0), (0, 1, 0))
+    for f in range(frames):
+        pts, col = (surface_cloud(rng, n) if f % 2 == 0 else random_cloud(rng, n, nan_every=53, dup_frac=0.1))
+        pts = pts + np.float32(0.003 * f)
+        tp, tc = torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda()
+        if f == 0:  # (the first fusion creates the pool)
+            pkg.svo_from_point_cloud_async(ws, tp, tc, depth, pool, center, edge)
+            opool.insert_cloud(pts, col, depth, center, edge)
+            continue
+        size_before = pool.size
+        before = pool.words().copy()
+        img_before = torch.zeros((30, 40, 4), dtype=torch.uint8, device="cuda")
+        pkg.cone_trace_svo(img_before, 45.0, view, pool.data_ptr, center, edge, 1)
+        pkg.svo_fuse_sort(ws, tp, depth, center, edge)
+        pkg.svo_fuse_plan(ws, n, depth, pool)
+        pkg.svo_fuse_commit_deferred(ws, tc, depth, pool)
+        img_mid = torch.zeros((30, 40, 4), dtype=torch.uint8, device="cuda")
+        pkg.cone_trace_svo(img_mid, 45.0, view, pool.data_ptr, center, edge, 1)
+        torch.cuda.synchronize()
+        mid = pool.words()[: 2 * size_before]
+        assert np.array_equal(mid, before[: 2 * size_before])       # nothing visible yet
+        assert torch.equal(img_mid, img_before)
+        with pytest.raises(pkg.SvoslamError):                      # one deferred commit at a time
+            pkg.svo_fuse_plan(ws, n, depth, pool); pkg.svo_fuse_commit(ws, tc, depth, pool)
+        pkg.svo_fuse_apply(ws, pool)
+        opool.insert_cloud(pts, col, depth, center, edge)
+        assert_pools_equal(pool, opool)
