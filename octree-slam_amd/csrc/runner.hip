@@ -62,6 +62,7 @@ struct svoslam_runner {
   hipEvent_t ev_begin = nullptr, ev_end[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t last_caller = nullptr;
   int lead = 3;  // commits the host may run ahead of the device (see svoslam_runner_run)
+  bool deferred = false;  // SVOSLAM_RUNNER_DEFERRED=1 (one replica): the commit of frame k+1 is computed during the march of frame k
   bool ran = false;
   // SVOSLAM_RUNNER_TIMELINE=1: timing events at the stage boundaries of the last call (svoslam_runner_timeline)
   bool maps_on_track_stream = false;  // SVOSLAM_RUNNER_MAPS_STREAM=0: maps of a frame right before its ICP on stream T (saves an
@@ -106,6 +107,8 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
   r->maps_on_track_stream = ms && ms[0] == '0';
   const char *tl = getenv("SVOSLAM_RUNNER_TIMELINE");
   r->timeline = tl && tl[0] == '1';
+  const char *df = getenv("SVOSLAM_RUNNER_DEFERRED");
+  r->deferred = df && df[0] == '1';
   const char *ld = getenv("SVOSLAM_RUNNER_LEAD");
   if (ld) r->lead = atoi(ld) < 0 ? 0 : atoi(ld);
   *out = r;
@@ -271,7 +274,52 @@ int svoslam_runner_run(svoslam_runner *r, const uint16_t *const *d_depths, const
     if (k == (i & (R - 1))) mark(i, 8, r->s_map[k]);
     return SVOSLAM_OK;
   };
+  // One replica, deferred commits (SVOSLAM_RUNNER_DEFERRED=1): stream C computes the commit of frame k+1 -- splits, leaf
+  // blends, mip levels, into memory the march cannot see (svoslam_svo_fuse_commit_deferred) -- WHILE stream M ray-marches
+  // frame k; M then publishes it with one short launch (svoslam_svo_fuse_apply) and marches frame k+1.  The map stream
+  // carries apply + grid refresh + march instead of commit + grid refresh + march.  Measured: the march beside a commit
+  // takes 0.32 ms instead of 0.28 and the commit 0.27 instead of 0.11 (both are latency chains through the same L2 /
+  // HBM), so the period barely moves: cfg3 100 frames 2430 -> 2560 frames/s, 20 frames 2550 -> 2290, cfg4 742 -> 634.
+  // Off by default.
+  hipStream_t s_compute = r->s_map[1];
+  auto enqueue_compute = [&](int i) -> int {
+    SVO_HIP(hipStreamWaitEvent(s_compute, ev_plan[i], 0));
+    mark(i, 7, s_compute);
+    SVO_TRY(svoslam_svo_fuse_commit_deferred(r->ws[i % kRing], staged ? r->in_rgb[i % kRing] : d_rgbs[i], npts, r->depth, r->pool, s_compute));
+    SVO_HIP(hipEventRecord(ev_commit[1][i], s_compute));
+    return SVOSLAM_OK;
+  };
+  auto enqueue_apply = [&](int i) -> int {
+    SVO_HIP(hipStreamWaitEvent(r->s_map[0], ev_commit[1][i], 0));
+    SVO_TRY(svoslam_svo_fuse_apply(r->ws[i % kRing], r->pool, r->s_map[0]));
+    SVO_HIP(hipEventRecord(ev_commit[0][i], r->s_map[0]));
+    mark(i, 8, r->s_map[0]);
+    return SVOSLAM_OK;
+  };
+  auto enqueue_all_deferred = [&]() -> int {
+    SVO_TRY(enqueue_maps(0));
+    SVO_TRY(enqueue_track(0));
+    if (n > 1) SVO_TRY(enqueue_maps(1));
+    SVO_TRY(enqueue_prepare(0));
+    SVO_TRY(enqueue_compute(0));
+    for (int i = 0; i < n; i++) {
+      if (i + 1 < n) SVO_TRY(enqueue_track(i + 1));
+      if (i + 2 < n) SVO_TRY(enqueue_maps(i + 2));
+      if (r->lead > 0 && i >= r->lead) SVO_HIP(hipEventSynchronize(ev_commit[0][i - r->lead]));  // (see the other schedule)
+      SVO_TRY(enqueue_apply(i));
+      if (i + 1 < n) {
+        SVO_TRY(enqueue_prepare(i + 1));  // its plan waits for apply i
+        SVO_TRY(enqueue_compute(i + 1));  // host order: BEFORE the march of frame i, whose grid refresh must leave this commit's marks alone
+      }
+      uint8_t *img = (i == n - 1) ? d_image : r->scratch_image[0];
+      SVO_TRY(svoslam_cone_trace_svo_band(img, r->w, r->h, row_first, rows, r->fov, views + 16 * (size_t)i, r->pool->d_data,
+                                          r->center, r->edge, r->mode, d_steps, r->s_map[0]));
+      mark(i, 9, r->s_map[0]);
+    }
+    return SVOSLAM_OK;
+  };
   auto enqueue_all = [&]() -> int {
+    if (R == 1 && r->deferred) return enqueue_all_deferred();
     SVO_TRY(enqueue_maps(0));
     SVO_TRY(enqueue_track(0));
     if (n > 1) SVO_TRY(enqueue_maps(1));

@@ -269,4 +269,7 @@ print("RESULT" + json.dumps([sha(P.image.cpu().numpy()), sha(P.pool.words()), sh
     base = run({})
     assert run({"SVOSLAM_GRAPHS": "1", "SVOSLAM_TRACK_CHAIN": "1"}) == base
     assert run({"SVOSLAM_GRAPHS": "1"}) == base
+    # the scheduler with deferred commits (commit of frame k+1 computed beside the march of frame k, then applied)
+    assert run({"SVOSLAM_RUNNER_DEFERRED": "1"}) == base
+    assert run({"SVOSLAM_RUNNER_DEFERRED": "1", "SVOSLAM_RUNNER_LEAD": "0"}) == base
     assert base[3] > 8
