@@ -12,11 +12,16 @@ mainLoop() (src/main.cpp:31-84) with the tracker enabled -- bilateral + pyramids
 frames are resident in HBM before the timed region.  `--workload cfg4` runs the
 1920x1080 / depth-14 stream of config 4.
 
-With N > 1 the raycast is cut into N row bands over replicated pools; total work
-is fixed: scaling = "strong".  --exchange none (default): every rank tracks and fuses
-whole frames, no collective in the frame loop.  --exchange allreduce: SURVEY 8e
-(ICP accumulation and back-projection per band; ICP sums all-reduced, point bands
-all-gathered, fusion applied to every replica).
+With N > 1 the total work is fixed: scaling = "strong".  --exchange deltas (default
+for N > 1): frames are tracked in parallel -- rank k % N runs the
+19 ICP iterations of frame k (a function of depth images k-1 and k only) and ray-marches
+it; the 80-byte update_trans records are all-gathered over RCCL, every rank composes the
+same poses and applies every fusion to its own replica of the map.  --exchange none:
+every rank tracks and fuses whole frames, only the raycast is cut into N row bands, no
+collective in the frame loop.  --exchange allreduce: SURVEY 8e (ICP accumulation and
+back-projection per band; ICP sums all-reduced, point bands all-gathered, fusion applied
+to every replica).  --emulate-rank R/N: rank R of an N-rank "deltas" session on ONE GPU,
+the other ranks' records precomputed outside the timed region (what one rank of N costs).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel
 (cone_trace_kernel): algorithmic bytes 4*(levels+steps) + 4*W*H per launch
@@ -98,9 +103,13 @@ def main():
     ap.add_argument("--include-h2d", action="store_true",
                     help="frames start in pinned HOST memory and are uploaded inside the timed region (the reference's frame "
                          "includes the 1.5 MB cudaMemcpy of openni_device.cpp:122,144); default: frames resident in HBM")
-    ap.add_argument("--exchange", default="none", choices=["none", "allreduce"],
-                    help="N > 1: 'none' = every rank tracks and fuses whole frames, only the raycast is split into row bands; "
-                         "'allreduce' = SURVEY 8e row bands with 19 ICP all-reduces + one point all-gather per frame")
+    ap.add_argument("--exchange", default=None, choices=["deltas", "none", "allreduce"],
+                    help="N > 1: 'deltas' (default) = frame-parallel tracking, all-gather of update_trans records, every rank fuses "
+                         "every frame and ray-marches its own; 'none' = every rank tracks and fuses whole frames, only the raycast "
+                         "is split into row bands; 'allreduce' = SURVEY 8e row bands with 19 ICP all-reduces + one point all-gather "
+                         "per frame")
+    ap.add_argument("--emulate-rank", default=None, metavar="R/N",
+                    help="one GPU: run rank R of an N-rank 'deltas' session, the other ranks' records precomputed (untimed)")
     ap.add_argument("--stages", action="store_true",
                     help="add `stages` (per-stage durations from HIP-event marks at the stage boundaries, svoslam_runner_timeline); "
                          "the ~10 extra event records per frame cost ~6 %% of the frame rate, so they are off for the headline line")
@@ -125,7 +134,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     force_dist = os.environ.get("SVOSLAM_FORCE_DIST") == "1"   # exercise the row-band/RCCL code path on one GPU
-    if world > 1 or force_dist:
+    if args.exchange is None:
+        args.exchange = "deltas" if world > 1 else "none"
+    if args.no_overlap and (args.exchange == "deltas" or args.emulate_rank):
+        raise SystemExit("--no-overlap has no frame-sharded form: use --exchange none")
+    emu = None
+    if args.emulate_rank:
+        er, en = (int(x) for x in args.emulate_rank.split("/"))
+        assert world == 1 and 0 <= er < en
+        emu = pl.EmulatedRank(er, en)
+        dist = emu
+        args.exchange = "deltas"
+    elif world > 1 or force_dist:
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -145,8 +165,21 @@ def main():
                         pool_capacity_nodes=(1 << 30) - 8)   # the whole 30-bit index range of the node format, 8.6 GB of 288 GB: room for
     # the worst-case reservation of the frames in flight (sum_d min(8^d, n) splits per frame), so no fusion waits for a size readback
 
+    per_rank = None
+    if emu is not None:   # the records the other ranks would deliver, for the whole stream
+        per_rank = max(1, 16 // emu.world)
+        dcam = pkg.Camera(width, height, P.focal, P.focal)
+        table = torch.zeros((total, pkg.DELTA_FLOATS), dtype=torch.float32, device="cuda")
+        for k in range(1, total):
+            dcam.pair_delta(depth[k - 1], rgb[k - 1], depth[k], rgb[k], table[k])
+        torch.cuda.synchronize()
+
+    def expect(lo, hi):
+        if emu is not None:
+            emu.expect(table[lo:hi], lo, per_rank)
+
     def barrier():
-        if world > 1 or force_dist:
+        if (world > 1 or force_dist) and emu is None:
             import torch.distributed as tdist
             tdist.barrier()
         torch.cuda.synchronize()
@@ -157,6 +190,7 @@ def main():
     # the W warm-up and K timed frames below start from an empty map exactly as they would without this pass.
     if not args.no_overlap:
         ninit = min(6, total)
+        expect(0, ninit)
         P.run_stream(depth[:ninit], rgb[:ninit], list(range(ninit)), views[:ninit])
         barrier()
         P.reset()
@@ -165,6 +199,7 @@ def main():
         for k in range(Wm):
             P.frame(depth[k], rgb[k], k, views[k])
     else:
+        expect(0, Wm)
         P.run_stream(depth[:Wm], rgb[:Wm], list(range(Wm)), views[:Wm])
     barrier()
     P.counters.zero_()
@@ -189,6 +224,7 @@ def main():
     else:
         # four HIP streams (pipeline.run_stream); every frame still goes through
         # track -> back-project -> fuse -> render with the same results
+        expect(Wm, total)
         P.run_stream(depth[Wm:], rgb[Wm:], list(range(Wm, total)), views[Wm:])
     barrier()
     elapsed = time.perf_counter() - t0
@@ -202,16 +238,18 @@ def main():
     steps, levels = (int(x) for x in P.counters.cpu().tolist())
     kern_total_ms, kern_launches = pkg.cone_trace_timing_read()
     pkg.cone_trace_timing(False)
-    assert kern_launches == K, (kern_launches, K)
-    kern_ms = kern_total_ms / K
+    sharded = getattr(P, "frame_sharded", False)
+    marches = P.marched_last_call if sharded else K      # frame-sharded: this rank ray-marches its own frames only
+    assert kern_launches == marches and marches > 0, (kern_launches, marches)
+    kern_ms = kern_total_ms / marches
     rows = P.rows
-    alg_bytes = (4.0 * (levels + steps) + 4.0 * width * rows * K) / K     # per launch (this rank's band)
+    alg_bytes = (4.0 * (levels + steps) + 4.0 * width * rows * marches) / marches     # per launch (this rank's band / frames)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
     traffic, traffic_source = None, None
     try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be sampled from inside the process)
         tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        t = tj.get(args.workload, {}).get("cone_trace_kernel") if world == 1 else None
+        t = tj.get(args.workload, {}).get("cone_trace_kernel") if (world == 1 and emu is None) else None
         if t:
             traffic = (2.0 * t["fetch_kb"] + t["write_kb"]) * 1024.0
             traffic_source = "not sampled in this run: 2 x FETCH_SIZE + WRITE_SIZE of %s" % t["source"]
@@ -243,7 +281,12 @@ def main():
             "dtype": "u32/f32 (ICP sums exact fixed-point in f64)", "data": "synthetic",
             "config": {"workload": "%s: synthetic %dx%d RGB-D stream, depth-%d SVO, half-edge %.3f m, bilateral+ICP(19 it)+fuse+raycast(%s mode)"
                                    % (args.workload, width, height, max_depth, edge, args.render_mode),
-                       "parallelism": ("single GPU" if world == 1 and not force_dist else
+                       "parallelism": ("EMULATED rank %d of %d (one GPU; the other ranks' update_trans records precomputed): frames tracked "
+                                       "and ray-marched by rank k %% N, every fusion applied here" % (emu.rank, emu.world) if emu is not None else
+                                       "single GPU" if world == 1 and not force_dist else
+                                       "frames tracked + ray-marched by rank k %% %d, all-gather of 80-byte update_trans records "
+                                       "(one per chunk of frames), every rank applies every fusion to its replica" % world
+                                       if args.exchange == "deltas" else
                                        "raycast in %d row bands; tracker + fusion on every rank, no data-path collective" % world
                                        if args.exchange == "none" else
                                        "%d row bands: ICP all-reduce (19 per frame) + point all-gather, replicated pool" % world),

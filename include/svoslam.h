@@ -439,6 +439,21 @@ int svoslam_camera_update(svoslam_camera *cam, const uint16_t *d_depth, const ui
 int svoslam_camera_prepare(svoslam_camera *cam, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp,
                            int32_t *processed, void *stream);
 int svoslam_camera_track(svoslam_camera *cam, void *stream);
+/* Frame-parallel tracking (several GPUs, or several streams of one).  RGBDCamera::update starts update_trans at the
+ * identity for every frame (rgbd_camera.cpp:100) and iterates on the maps of frames k-1 and k only (:103-168): a frame's
+ * ICP is a function of two depth images; only :172-173 (position, orientation *= update_trans) chain the frames.
+ *   pair_delta()  runs :62-168 for the pair (prev, cur) and writes SVOSLAM_DELTA_FLOATS floats to d_delta: update_trans
+ *                 (mat4, column-major), the number of pyramid levels abandoned (:148-151) as int32 bits, 3 x padding.
+ *                 `cam` serves as scratch (map sets, tracker); its pose afterwards means nothing and it must not be fed by
+ *                 update() / apply_delta().  Non-blocking.
+ *   apply_delta() :172-173 + main.cpp:40 for a delta from anywhere: a stream of apply_delta(pair_delta(k-1, k)) leaves the
+ *                 camera exactly where a stream of update(k) leaves it.  d_delta = NULL, or the camera's first frame (no
+ *                 ICP: `pass >= 1`, :99): pose unchanged.  A camera is fed either by update() or by apply_delta(), not both
+ *                 (reset in between).  *processed as for update().  Non-blocking. */
+#define SVOSLAM_DELTA_FLOATS 20
+int svoslam_camera_pair_delta(svoslam_camera *cam, const uint16_t *d_depth_prev, const uint8_t *d_rgb_prev, const uint16_t *d_depth_cur,
+                              const uint8_t *d_rgb_cur, float *d_delta, void *stream);
+int svoslam_camera_apply_delta(svoslam_camera *cam, const float *d_delta, long long timestamp, int32_t *processed, void *stream);
 /* Multi-GPU stepping: update() split at the all-reduce points.  begin() builds
  * the pyramids; for level = 2,1,0 and it = 0..iters(level)-1 call
  * icp_accumulate() [adds this band's 27 doubles into svoslam_camera_acc()], then
@@ -501,6 +516,18 @@ int svoslam_runner_timeline(svoslam_runner *runner, float *h_ms, int32_t max_fra
 int svoslam_runner_run(svoslam_runner *runner, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs,
                        const long long *timestamps, const float *views, int32_t n, uint8_t *d_image, int32_t row_first,
                        int32_t rows, unsigned long long *d_steps, void *caller_stream);
+/* The same loop for ONE RANK of a frame-sharded session (frames are tracked in parallel, one process
+ * per GPU, each with a full replica of the map).  The poses come from svoslam_camera_apply_delta(d_deltas[i]) -- n device
+ * pointers to SVOSLAM_DELTA_FLOATS floats, produced by svoslam_camera_pair_delta on whichever rank tracked frame i and
+ * all-gathered; delta_events (optional; n hipEvent_t, NULL entries allowed): what the pose stream waits for before it reads
+ * d_deltas[i] -- so the runner's camera never sees a depth image; EVERY frame is back-projected, planned and committed
+ * (the replicas stay byte-identical), and only the frames with march[i] != 0 (march = NULL: all) are ray-marched, frame i
+ * into d_images[i].  Entry 0 of d_deltas is ignored for a camera's first frame.  Needs the default one-replica,
+ * direct-commit schedule. */
+int svoslam_runner_run_sharded(svoslam_runner *runner, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs,
+                               const long long *timestamps, const float *views, int32_t n, const float *const *d_deltas,
+                               void *const *delta_events, const uint8_t *march, uint8_t *const *d_images, int32_t row_first,
+                               int32_t rows, unsigned long long *d_steps, void *caller_stream);
 
 /* ------------------------------------------------------------------------
  * Timing hook: replaces startTiming/stopTiming (include/octree_slam/

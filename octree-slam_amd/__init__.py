@@ -25,6 +25,7 @@ CHILD_MASK = 0x3FFFFFFF
 RENDER_REFERENCE = 0
 RENDER_CARRY = 1
 PYRAMID_ITERS = (10, 5, 4)  # rgbd_camera.cpp:19, index = pyramid level
+DELTA_FLOATS = 20  # SVOSLAM_DELTA_FLOATS: update_trans[16], levels lost (int32 bits), 3 x padding
 
 
 class SvoslamError(RuntimeError):
@@ -120,6 +121,8 @@ SIGNATURES = {
     "svoslam_runner_destroy": (C.c_int, [_vp]),
     "svoslam_runner_timeline": (C.c_int, [_vp, _fp, _i32, C.POINTER(_i32)]),
     "svoslam_runner_run": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_longlong), _fp, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "svoslam_runner_run_sharded": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_longlong), _fp, _i32, C.POINTER(_vp),
+                                             C.POINTER(_vp), C.POINTER(C.c_uint8), C.POINTER(_vp), _i32, _i32, _vp, _vp]),
     "svoslam_scene_create": (C.c_int, [C.POINTER(_vp)]),
     "svoslam_scene_destroy": (C.c_int, [_vp]),
     "svoslam_scene_load_obj": (C.c_int, [_vp, C.c_char_p]),
@@ -166,6 +169,8 @@ SIGNATURES = {
     "svoslam_camera_begin": (C.c_int, [_vp, _vp, _vp, C.c_longlong, C.POINTER(_i32), _vp]),
     "svoslam_camera_prepare": (C.c_int, [_vp, _vp, _vp, C.c_longlong, C.POINTER(_i32), _vp]),
     "svoslam_camera_track": (C.c_int, [_vp, _vp]),
+    "svoslam_camera_pair_delta": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "svoslam_camera_apply_delta": (C.c_int, [_vp, _vp, C.c_longlong, C.POINTER(_i32), _vp]),
     "svoslam_camera_icp_iters": (C.c_int, [_i32]),
     "svoslam_camera_icp_accumulate": (C.c_int, [_vp, _i32, _i32, _vp]),
     "svoslam_camera_acc": (_vp, [_vp]),
@@ -534,6 +539,23 @@ class Runner:
         check(lib().svoslam_runner_run(self._h, dp, rp, ts, vw.ctypes.data_as(_fp), n, _ptr(image), int(row_first), int(rows),
                                        _ptr(counters), _stream()))
 
+    def run_sharded(self, depths, rgbs, timestamps, views, deltas, delta_events, march, images, row_first, rows, counters=None):
+        """one rank of a frame-sharded session (svoslam_runner_run_sharded): deltas = per-frame tensors (or None) of
+        DELTA_FLOATS floats, delta_events = per-frame torch.cuda.Event (recorded) or None, march = per-frame bool,
+        images = per-frame output tensor (or None where march is False)"""
+        n = len(timestamps)
+        dp = (C.c_void_p * n)(*[d.data_ptr() for d in depths])
+        rp = (C.c_void_p * n)(*[r.data_ptr() for r in rgbs])
+        ts = (C.c_longlong * n)(*[int(t) for t in timestamps])
+        vw = np.ascontiguousarray(np.stack([np.asarray(v, np.float32).reshape(16) for v in views]), np.float32)
+        dl = (C.c_void_p * n)(*[(d.data_ptr() if d is not None else None) for d in deltas])
+        ev = (C.c_void_p * n)(*[(e.cuda_event if e is not None else None) for e in delta_events]) if delta_events is not None else None
+        mf = (C.c_uint8 * n)(*[1 if m else 0 for m in march])
+        im = (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in images])
+        self._keep = (depths, rgbs, deltas, delta_events, images)   # alive until the next call (the work is asynchronous)
+        check(lib().svoslam_runner_run_sharded(self._h, dp, rp, ts, vw.ctypes.data_as(_fp), n, dl, ev, mf, im, int(row_first), int(rows),
+                                               _ptr(counters), _stream()))
+
     def timeline(self, max_frames=4096):
         """[frames, 10] stage times in ms of the last run (SVOSLAM_RUNNER_TIMELINE=1)"""
         out = np.full((max_frames, 10), -1.0, np.float32)
@@ -841,6 +863,17 @@ class Camera:
         """first half of update(): bilateral filter + pyramids of the next frame (may run ahead on another stream)"""
         used = C.c_int32(0)
         check(lib().svoslam_camera_prepare(self._h, _ptr(depth), _ptr(rgb), int(timestamp), C.byref(used), _stream()))
+        return int(used.value)
+
+    def pair_delta(self, depth_prev, rgb_prev, depth_cur, rgb_cur, out):
+        """update_trans of frame `cur` tracked against frame `prev` -> out (DELTA_FLOATS floats); this camera is scratch"""
+        check(lib().svoslam_camera_pair_delta(self._h, _ptr(depth_prev), _ptr(rgb_prev), _ptr(depth_cur), _ptr(rgb_cur), _ptr(out),
+                                              _stream()))
+
+    def apply_delta(self, delta, timestamp):
+        """the pose step of update() for a frame tracked elsewhere (delta = None: pose unchanged)"""
+        used = C.c_int32(0)
+        check(lib().svoslam_camera_apply_delta(self._h, _ptr(delta), int(timestamp), C.byref(used), _stream()))
         return int(used.value)
 
     def track_prepared(self):

@@ -464,6 +464,13 @@ int svoslam_camera_prepare(svoslam_camera *cam, const uint16_t *d_depth, const u
   return camera_prepare(cam, d_depth, d_rgb, timestamp, processed, S(stream));
 }
 int svoslam_camera_track(svoslam_camera *cam, void *stream) { return camera_track(cam, S(stream)); }
+int svoslam_camera_pair_delta(svoslam_camera *cam, const uint16_t *d_depth_prev, const uint8_t *d_rgb_prev, const uint16_t *d_depth_cur,
+                              const uint8_t *d_rgb_cur, float *d_delta, void *stream) {
+  return camera_pair_delta(cam, d_depth_prev, d_rgb_prev, d_depth_cur, d_rgb_cur, d_delta, S(stream));
+}
+int svoslam_camera_apply_delta(svoslam_camera *cam, const float *d_delta, long long timestamp, int32_t *processed, void *stream) {
+  return camera_apply_delta(cam, d_delta, timestamp, processed, S(stream));
+}
 int svoslam_camera_begin(svoslam_camera *cam, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp,
                          int32_t *processed, void *stream) {
   return camera_begin(cam, d_depth, d_rgb, timestamp, processed, S(stream));

@@ -448,6 +448,36 @@ __global__ void cam_frame_end_kernel(CamState *st, int apply_update) {
   frame_end_step(st, apply_update, st->update_trans);
 }
 
+// ---- frame-parallel tracking (multi-GPU) ---------------------------------------
+// RGBDCamera::update starts update_trans at the identity for every frame (rgbd_camera.cpp:100) and iterates on the
+// vertex / normal maps of frames k-1 and k only: the 19 ICP iterations of a frame are a pure function of TWO DEPTH
+// IMAGES, independent of every earlier pose.  Only :172-173 (position, orientation *= update_trans) chain the frames.
+// So frames can be tracked in any order, on any GPU: delta_export_kernel hands out a frame's update_trans (+ the number of
+// pyramid levels it abandoned), cam_apply_delta_kernel is :172-173 + main.cpp:40 for a matrix from anywhere.
+constexpr int kDeltaFloats = 20;  // update_trans[16], levels lost (int bits), 3 pad: 80 bytes per frame
+__global__ void delta_export_kernel(CamState *st, float *__restrict__ out) {
+  const int e = (int)threadIdx.x;
+  if (blockIdx.x || e >= kDeltaFloats) return;
+  float v = 0.0f;
+  if (e < 16) v = st->update_trans[e];
+  else if (e == 16) v = __int_as_float(st->tracking_lost_count);
+  out[e] = v;
+  if (e == 16) st->tracking_lost_count = 0;  // a delta camera counts per frame
+}
+
+__global__ void cam_apply_delta_kernel(CamState *st, const float *__restrict__ delta) {
+  SVO_HIGH_PRIO();
+  if (threadIdx.x || blockIdx.x) return;
+  if (delta) {
+    float m[16];
+    for (int i = 0; i < 16; i++) { m[i] = delta[i]; st->update_trans[i] = m[i]; }
+    st->tracking_lost_count += __float_as_int(delta[16]);
+    frame_end_step(st, 1, m);
+  } else {
+    frame_end_step(st, 0, st->update_trans);  // a camera's first frame: no ICP (rgbd_camera.cpp:99 `pass >= 1`)
+  }
+}
+
 }  // namespace svoslam
 
 // ----------------------------------------------------------------------------
@@ -487,6 +517,7 @@ struct svoslam_camera {
   unsigned *d_tickets = nullptr;
   hipStream_t cap_stream = nullptr;  // stream whose resident-workgroup capacity is cached below
   int capacity = 0;
+  bool delta_fed = false;  // poses come from camera_apply_delta: there are no maps of the previous frame to track against
 };
 
 namespace svoslam {
@@ -543,6 +574,7 @@ int camera_reset(svoslam_camera *c) {
   c->prepared = 0; c->tracked = 0;
   c->frame_has_icp = false;
   c->ring_slot = 0;
+  c->delta_fed = false;
   return SVOSLAM_OK;
 }
 
@@ -600,6 +632,7 @@ int camera_prepare(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_
                    hipStream_t s) {
   if (!c || !d_depth) return SVOSLAM_ERR_INVALID_ARG;
   if (c->rgbd && !d_rgb) return SVOSLAM_ERR_INVALID_ARG;  // (without the photometric term the colours are not looked at)
+  if (c->delta_fed) return SVOSLAM_ERR_INVALID_ARG;  // fed by camera_apply_delta: no maps of the previous frame here
   if (c->have_stamp && timestamp <= c->latest_stamp) {  // :55-59
     if (processed) *processed = 0;
     return SVOSLAM_OK;
@@ -776,6 +809,56 @@ int camera_update(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_r
   if (processed) *processed = used;
   if (!used) return SVOSLAM_OK;
   return camera_track(c, s);
+}
+
+// update_trans of the frame `cur` against the frame `prev` (rgbd_camera.cpp:62-168 for that pair of images), written to
+// d_delta[20] (layout: delta_export_kernel).  The camera serves as a "delta camera": its map sets 0 / 1 and its tracker
+// are used, its pose afterwards means nothing, its frame counters are left at zero -- keep a second camera for the pose
+// (camera_apply_delta).  Non-blocking.
+int camera_pair_delta(svoslam_camera *c, const uint16_t *d_depth_prev, const uint8_t *d_rgb_prev, const uint16_t *d_depth_cur,
+                      const uint8_t *d_rgb_cur, float *d_delta, hipStream_t s) {
+  if (!c || !d_depth_prev || !d_depth_cur || !d_delta) return SVOSLAM_ERR_INVALID_ARG;
+  if (c->rgbd && (!d_rgb_prev || !d_rgb_cur)) return SVOSLAM_ERR_INVALID_ARG;
+  if (c->prepared != 0 || c->tracked != 0) return SVOSLAM_ERR_INVALID_ARG;  // a camera that has seen update() / apply_delta()
+  for (int set = 0; set < 2; set++) {
+    const uint16_t *d = set ? d_depth_cur : d_depth_prev;
+    const uint8_t *rgb = set ? d_rgb_cur : d_rgb_prev;
+    GraphKey key;
+    key.add(d).add((unsigned long long)set).add(c->rgbd ? rgb : nullptr);
+    SVO_TRY(c->g_prep.run(key, s, [&]() -> int { return enqueue_preprocess(c, d, rgb, set, s); }));
+  }
+  c->prepared = 2; c->tracked = 1;  // level_args(): current maps = set 1, last maps = set 0
+  const int rc = camera_track(c, s);
+  c->prepared = 0; c->tracked = 0; c->frame_has_icp = false;
+  SVO_TRY(rc);
+  delta_export_kernel<<<1, 64, 0, s>>>(c->d_state, d_delta);
+  SVO_LAUNCH_CHECK();
+  return SVOSLAM_OK;
+}
+
+// The pose step of RGBDCamera::update for a frame tracked elsewhere: position / orientation *= update_trans
+// (rgbd_camera.cpp:172-173), fusion transform into the pose ring (main.cpp:40), lost-level count.  d_delta = nullptr (or a
+// camera's first frame, which has no ICP: `pass >= 1`, :99) leaves the pose as it is.  Same device code as the tracker's
+// own frame end (frame_end_step), so a stream of apply_delta(pair_delta(k-1, k)) equals a stream of update(k) bit for bit.
+int camera_apply_delta(svoslam_camera *c, const float *d_delta, long long timestamp, int32_t *processed, hipStream_t s) {
+  if (!c) return SVOSLAM_ERR_INVALID_ARG;
+  if (c->prepared != c->tracked) return SVOSLAM_ERR_INVALID_ARG;  // a prepared frame is waiting for camera_track
+  if (c->tracked > 0 && !c->delta_fed) return SVOSLAM_ERR_INVALID_ARG;  // either update() or apply_delta() feeds a camera
+  if (c->have_stamp && timestamp <= c->latest_stamp) {  // :55-59
+    if (processed) *processed = 0;
+    return SVOSLAM_OK;
+  }
+  c->delta_fed = true;
+  c->have_stamp = true;
+  c->latest_stamp = timestamp;
+  if (processed) *processed = 1;
+  cam_apply_delta_kernel<<<1, 64, 0, s>>>(c->d_state, c->tracked >= 1 ? d_delta : nullptr);
+  SVO_LAUNCH_CHECK();
+  c->ring_slot = (int)(c->tracked & 3u);
+  c->tracked++;
+  c->prepared++;
+  c->frame_has_icp = false;
+  return SVOSLAM_OK;
 }
 
 // RGBDCamera with the photometric term of rgbd_camera.cpp:126-141 switched on (W_RGBD = 0.1); before the first frame only

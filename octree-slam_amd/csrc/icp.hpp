@@ -23,6 +23,9 @@ int camera_icp_accumulate(svoslam_camera *c, int level, int iter, hipStream_t s)
 int camera_icp_solve(svoslam_camera *c, int level, int iter, hipStream_t s);
 int camera_end(svoslam_camera *c, hipStream_t s);
 int camera_update(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_rgb, long long timestamp, int32_t *processed, hipStream_t s);
+int camera_pair_delta(svoslam_camera *c, const uint16_t *d_depth_prev, const uint8_t *d_rgb_prev, const uint16_t *d_depth_cur,
+                      const uint8_t *d_rgb_cur, float *d_delta, hipStream_t s);
+int camera_apply_delta(svoslam_camera *c, const float *d_delta, long long timestamp, int32_t *processed, hipStream_t s);
 int camera_set_rgbd(svoslam_camera *c, int enable);
 int rgbd_cost(svoslam::DeviceBuffer &scratch, const float *last_i, const float *last_g, const float *last_v, const float *cur_i,
               const float *cur_v, int w, int h, float fx, float fy, int img_w, int img_h, float A[36], float b[6], hipStream_t s);

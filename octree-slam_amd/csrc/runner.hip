@@ -160,12 +160,24 @@ int svoslam_runner_destroy(svoslam_runner *r) {
 // All arguments are validated BEFORE anything is enqueued; if a stage fails later, the streams are still joined to
 // caller_stream before the error is returned.  Calls on one runner must use one caller_stream (checked).  With two
 // replicas the call first brings replica 1 up to date with the caller's pool (blocking device copy).
-int svoslam_runner_run(svoslam_runner *r, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs, const long long *timestamps,
-                       const float *views, int32_t n, uint8_t *d_image, int32_t row_first, int32_t rows,
-                       unsigned long long *d_steps, void *caller_stream) {
-  if (!r || n < 0 || (n > 0 && (!d_depths || !d_rgbs || !timestamps || !views || !d_image))) return SVOSLAM_ERR_INVALID_ARG;
+//
+// Sharded form (svoslam_runner_run_sharded): d_deltas != nullptr.  The poses come from
+// svoslam_camera_apply_delta(d_deltas[i]) instead of the tracker -- the frames were tracked elsewhere (other ranks, other
+// streams: svoslam_camera_pair_delta), delta_events[i] (optional) is what stream T waits for before it reads d_deltas[i] --
+// the camera is never handed a depth image, every commit is applied, and only the frames with march[i] != 0 are ray-marched,
+// into d_images[i].
+static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs, const long long *timestamps,
+                           const float *views, int32_t n, uint8_t *d_image, int32_t row_first, int32_t rows,
+                           unsigned long long *d_steps, void *caller_stream, const float *const *d_deltas,
+                           void *const *delta_events, const uint8_t *march, uint8_t *const *d_images) {
+  const bool sharded = d_deltas != nullptr;
+  if (!r || n < 0 || (n > 0 && (!d_depths || !d_rgbs || !timestamps || !views || (!d_image && !d_images)))) return SVOSLAM_ERR_INVALID_ARG;
   if (n == 0) return SVOSLAM_OK;
   if (row_first < 0 || rows < 0 || row_first + rows > r->h) return SVOSLAM_ERR_INVALID_ARG;
+  if (sharded && (r->replicas != 1 || r->deferred)) return SVOSLAM_ERR_INVALID_ARG;
+  if (d_images)
+    for (int i = 0; i < n; i++)
+      if ((!march || march[i]) && !d_images[i]) return SVOSLAM_ERR_INVALID_ARG;
   hipStream_t cur = reinterpret_cast<hipStream_t>(caller_stream);
   if (r->ran && cur != r->last_caller) return SVOSLAM_ERR_INVALID_ARG;  // the join below orders calls on ONE caller stream only
   {  // timestamps: strictly increasing and newer than the camera's latest (a stale frame would be skipped mid-pipeline)
@@ -207,9 +219,10 @@ int svoslam_runner_run(svoslam_runner *r, const uint16_t *const *d_depths, const
   for (hipStream_t s : all) SVO_HIP(hipStreamWaitEvent(s, r->ev_begin, 0));
 
   static const bool staged = [] { const char *e = getenv("SVOSLAM_GRAPHS"); return e && e[0] == '1'; }();
-  const bool one_stream = r->maps_on_track_stream;
+  const bool one_stream = r->maps_on_track_stream && !sharded;
   hipStream_t s_maps = one_stream ? r->s_track : r->s_maps;
   auto enqueue_maps = [&](int i) -> int {  // bilateral filter + pyramids of frame i (no dependence on earlier poses)
+    if (sharded) return SVOSLAM_OK;  // tracked elsewhere: this camera only composes poses
     if (!one_stream && i >= 2) SVO_HIP(hipStreamWaitEvent(s_maps, ev_pose[i - 2], 0));  // its map set was the "last" set of frame i-2
     mark(i, 0, s_maps);
     // fixed input addresses only where the library replays recorded launch sequences (graphs are keyed on pointers);
@@ -224,9 +237,17 @@ int svoslam_runner_run(svoslam_runner *r, const uint16_t *const *d_depths, const
   };
   auto enqueue_track = [&](int i) -> int {
     if (i >= 4) SVO_HIP(hipStreamWaitEvent(r->s_track, ev_bp[i - 4], 0));  // ring slot i % 4 has been consumed
-    if (!one_stream) SVO_HIP(hipStreamWaitEvent(r->s_track, ev_maps[i], 0));
+    if (!one_stream && !sharded) SVO_HIP(hipStreamWaitEvent(r->s_track, ev_maps[i], 0));
+    if (sharded) { mark(i, 0, r->s_track); mark(i, 1, r->s_track); }  // (no maps here; keeps the timeline's origin)
     mark(i, 2, r->s_track);
-    SVO_TRY(svoslam_camera_track(r->cam, r->s_track));
+    if (sharded) {
+      if (delta_events && delta_events[i]) SVO_HIP(hipStreamWaitEvent(r->s_track, reinterpret_cast<hipEvent_t>(delta_events[i]), 0));
+      int32_t used = 0;
+      SVO_TRY(svoslam_camera_apply_delta(r->cam, d_deltas[i], timestamps[i], &used, r->s_track));
+      if (!used) return SVOSLAM_ERR_INVALID_ARG;  // cannot happen after the validation above
+    } else {
+      SVO_TRY(svoslam_camera_track(r->cam, r->s_track));
+    }
     fusion_ptr[i] = svoslam_camera_fusion_transform_device(r->cam);  // ring slot of frame i
     SVO_HIP(hipEventRecord(ev_pose[i], r->s_track));
     mark(i, 3, r->s_track);
@@ -311,9 +332,11 @@ int svoslam_runner_run(svoslam_runner *r, const uint16_t *const *d_depths, const
         SVO_TRY(enqueue_prepare(i + 1));  // its plan waits for apply i
         SVO_TRY(enqueue_compute(i + 1));  // host order: BEFORE the march of frame i, whose grid refresh must leave this commit's marks alone
       }
-      uint8_t *img = (i == n - 1) ? d_image : r->scratch_image[0];
-      SVO_TRY(svoslam_cone_trace_svo_band(img, r->w, r->h, row_first, rows, r->fov, views + 16 * (size_t)i, r->pool->d_data,
-                                          r->center, r->edge, r->mode, d_steps, r->s_map[0]));
+      if (!march || march[i]) {
+        uint8_t *img = d_images ? d_images[i] : ((i == n - 1) ? d_image : r->scratch_image[0]);
+        SVO_TRY(svoslam_cone_trace_svo_band(img, r->w, r->h, row_first, rows, r->fov, views + 16 * (size_t)i, r->pool->d_data,
+                                            r->center, r->edge, r->mode, d_steps, r->s_map[0]));
+      }
       mark(i, 9, r->s_map[0]);
     }
     return SVOSLAM_OK;
@@ -338,9 +361,11 @@ int svoslam_runner_run(svoslam_runner *r, const uint16_t *const *d_depths, const
       if (i + 1 < n) SVO_TRY(enqueue_prepare(i + 1));  // host order: after ev_commit[a][i] has been recorded
       // one march at a time: two of them (1200 workgroups) leave no CU for the tracker's and the fusion's workgroups
       if (R == 2 && serial_marches && i > 0) SVO_HIP(hipStreamWaitEvent(r->s_map[a], ev_ray[i - 1], 0));
-      uint8_t *img = (i == n - 1) ? d_image : r->scratch_image[a];
-      SVO_TRY(svoslam_cone_trace_svo_band(img, r->w, r->h, row_first, rows, r->fov, views + 16 * (size_t)i, replica(r, a)->d_data,
-                                          r->center, r->edge, r->mode, d_steps, r->s_map[a]));
+      if (!march || march[i]) {
+        uint8_t *img = d_images ? d_images[i] : ((i == n - 1) ? d_image : r->scratch_image[a]);
+        SVO_TRY(svoslam_cone_trace_svo_band(img, r->w, r->h, row_first, rows, r->fov, views + 16 * (size_t)i, replica(r, a)->d_data,
+                                            r->center, r->edge, r->mode, d_steps, r->s_map[a]));
+      }
       if (R == 2) SVO_HIP(hipEventRecord(ev_ray[i], r->s_map[a]));
       mark(i, 9, r->s_map[a]);
       if (R == 2) SVO_TRY(enqueue_commit(i, a ^ 1, true));  // behind the march of frame i-1 on that replica
@@ -354,6 +379,23 @@ int svoslam_runner_run(svoslam_runner *r, const uint16_t *const *d_depths, const
   }
   if (rc != SVOSLAM_OK) (void)hipDeviceSynchronize();  // leave nothing in flight behind a failed call
   return rc;
+}
+
+int svoslam_runner_run(svoslam_runner *r, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs, const long long *timestamps,
+                       const float *views, int32_t n, uint8_t *d_image, int32_t row_first, int32_t rows,
+                       unsigned long long *d_steps, void *caller_stream) {
+  if (n > 0 && !d_image) return SVOSLAM_ERR_INVALID_ARG;
+  return runner_run_impl(r, d_depths, d_rgbs, timestamps, views, n, d_image, row_first, rows, d_steps, caller_stream, nullptr, nullptr,
+                         nullptr, nullptr);
+}
+
+int svoslam_runner_run_sharded(svoslam_runner *r, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs,
+                               const long long *timestamps, const float *views, int32_t n, const float *const *d_deltas,
+                               void *const *delta_events, const uint8_t *march, uint8_t *const *d_images, int32_t row_first,
+                               int32_t rows, unsigned long long *d_steps, void *caller_stream) {
+  if (n > 0 && (!d_deltas || !d_images)) return SVOSLAM_ERR_INVALID_ARG;
+  return runner_run_impl(r, d_depths, d_rgbs, timestamps, views, n, nullptr, row_first, rows, d_steps, caller_stream, d_deltas,
+                         delta_events, march, d_images);
 }
 
 // diagnostic: milliseconds of the stage marks of the last call relative to its first mark, h_ms[frames][10] =

@@ -27,6 +27,11 @@ own full replica of the node pool.  Two ways to keep the replicas identical
                rank gets the same bits in any reduction order); each rank back-projects and
                transforms its band of points and the bands are all-gathered, after which every
                rank applies the same fusion.
+  "deltas"     frame-parallel tracking (the default of bench.py for N > 1).  The ICP of frame k
+               starts from the identity and reads the maps of frames k-1 and k only (rgbd_camera.cpp:100-168), so rank
+               k % N tracks frame k (svoslam_camera_pair_delta) and ray-marches it; the 80-byte update_trans records
+               are all-gathered (one small collective per chunk of frames), every rank composes the same pose chain
+               (svoslam_camera_apply_delta) and applies every fusion to its own replica.  No stage runs on a band.
 Either way the replicas stay byte-identical to the 1-GPU pool.
 """
 import os
@@ -37,6 +42,23 @@ import torch
 import octree_slam_amd as pkg
 
 FOV = 45.0  # glfw_camera_controller.h:13 default
+
+
+def frame_shards(n, first_index, world, per_rank):
+    """Frame-sharded schedule of n frames whose global indices start at first_index: frame i belongs to rank
+    (first_index + i) % world, which tracks it against frame i-1 and ray-marches it.  The frames are cut into chunks of
+    world * per_rank; returns [(begin, end, slots)] with slots[i - begin] = (owner rank, row of that rank's delta block)."""
+    chunks, size = [], world * per_rank
+    for a in range(0, n, size):
+        b = min(n, a + size)
+        rows = [0] * world
+        slots = []
+        for i in range(a, b):
+            r = (first_index + i) % world
+            slots.append((r, rows[r]))
+            rows[r] += 1
+        chunks.append((a, b, slots))
+    return chunks
 
 
 def band_rows(height, rank, world):
@@ -54,7 +76,7 @@ class DistContext:
         """exchange = "none": every rank tracks and fuses the whole frame itself (no collective in the frame loop; only
         the raycast is split into row bands).  exchange = "allreduce": SURVEY 8e -- ICP accumulation and back-projection
         per row band, 19 all-reduces of the 27 normal-equation sums and one all-gather of the point bands per frame."""
-        assert exchange in ("none", "allreduce")
+        assert exchange in ("none", "allreduce", "deltas")
         self.rank, self.world, self.group, self.force, self.exchange = rank, world, group, force, exchange
         if self.enabled:
             # create the RCCL communicator and its streams NOW (first use is lazy and was observed to
@@ -78,6 +100,15 @@ class DistContext:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def all_gather_deltas(self, out, mine):
+        """out[world, m, DELTA_FLOATS] <- every rank's mine[m, DELTA_FLOATS] (enqueued on the current stream)"""
+        if self.enabled:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(out.view(-1), mine.view(-1), group=self.group)
+        else:
+            out.view(-1).copy_(mine.view(-1))
+        return out
+
     def all_gather_rows(self, full, height):
         """`full` is [height, ...]; each rank has filled its own band; returns with all bands filled.
         Bands may differ by one row, so gather into per-rank views of padded size."""
@@ -98,6 +129,35 @@ class DistContext:
         return full
 
 
+class EmulatedRank:
+    """Rank `rank` of a `world`-rank frame-sharded session WITHOUT a process group (tests; bench.py --emulate-rank on a
+    one-GPU box): the all-gather delivers this rank's own records and takes the other ranks' from `table` -- one record
+    per frame of the next run_stream call, produced beforehand by svoslam_camera_pair_delta (what RCCL would deliver)."""
+    enabled, exchange, force, group = False, "deltas", False, None
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        self.table, self.first, self.per_rank, self.calls = None, 0, 1, 0
+
+    def expect(self, table, first_index, per_rank):
+        """records [n, DELTA_FLOATS] of the frames of the next call, whose first frame has global index first_index"""
+        self.table, self.first, self.per_rank, self.calls = table, first_index, per_rank, 0
+
+    def all_gather_deltas(self, out, mine):
+        size = self.world * self.per_rank
+        a = self.calls * size
+        rows = [0] * self.world
+        out.zero_()
+        for i in range(a, min(self.table.shape[0], a + size)):
+            r = (self.first + i) % self.world
+            if r != self.rank:
+                out[r, rows[r]] = self.table[i]
+            rows[r] += 1
+        out[self.rank] = mine          # this rank's own records: produced here, on the delta stream
+        self.calls += 1
+        return out
+
+
 class SlamPipeline:
     def __init__(self, width, height, max_depth, center, half_edge, render_mode=pkg.RENDER_REFERENCE, dist=None,
                  pool_capacity_nodes=1 << 20, count_steps=False):
@@ -114,7 +174,13 @@ class SlamPipeline:
         self.bbox = torch.zeros(7, dtype=torch.float32, device=dev)
         self.image = torch.zeros((height, width, 4), dtype=torch.uint8, device=dev)
         self.counters = torch.zeros(2, dtype=torch.int64, device=dev) if count_steps else None
-        self.first, self.rows = band_rows(height, self.dist.rank, self.dist.world)
+        self.frame_sharded = self.dist.exchange == "deltas"   # (also without a process group: world 1, or an emulated rank)
+        if self.frame_sharded:
+            self.first, self.rows = 0, height                    # whole images of this rank's frames
+            self.delta_cam = pkg.Camera(width, height, self.focal, self.focal)   # scratch camera of pair_delta
+            self.frames_seen, self._prev = 0, None
+        else:
+            self.first, self.rows = band_rows(height, self.dist.rank, self.dist.world)
         self.band_exchange = self.dist.enabled and self.dist.exchange == "allreduce"
         if self.band_exchange:
             self.acc = torch.zeros(27, dtype=torch.float64, device=dev)
@@ -126,6 +192,9 @@ class SlamPipeline:
         """empty map and a fresh tracker; allocations, streams and the launch graphs recorded so far are kept"""
         self.pool.reset()
         self.cam.reset()
+        if self.frame_sharded:
+            self.delta_cam.reset()
+            self.frames_seen, self._prev = 0, None
         if self.counters is not None:
             self.counters.zero_()
 
@@ -192,6 +261,9 @@ class SlamPipeline:
         n = len(timestamps)
         if n == 0:
             return
+        if self.frame_sharded:
+            assert on_render is None
+            return self.run_stream_sharded(depths, rgbs, timestamps, views)
         if (not self.band_exchange and on_render is None and not os.environ.get("SVOSLAM_TIMELINE")
                 and os.environ.get("SVOSLAM_PY_SCHEDULER") != "1"):
             # the same schedule inside the library (csrc/runner.hip): one call, ~0.1 ms of host time per frame
@@ -308,6 +380,57 @@ class SlamPipeline:
             torch.cuda.synchronize()
             base = tl[("commit0", 0)]
             self.timeline = {k: base.elapsed_time(e) for k, e in tl.items()}
+
+    def run_stream_sharded(self, depths, rgbs, timestamps, views, images=None, per_rank=None):
+        """One rank of a frame-sharded session (exchange "deltas").  Frame g (counted from the camera's first frame)
+        belongs to rank g % world:
+          D  that rank tracks it against frame g-1 -- maps of both + 19 ICP iterations on the scratch camera
+             (svoslam_camera_pair_delta), a function of the two depth images only -- in chunks of world * per_rank frames,
+             each followed by ONE all-gather of the ranks' 80-byte update_trans records;
+          then the native runner (svoslam_runner_run_sharded) on its usual streams: T composes the poses of ALL frames from
+          the gathered records (waiting for a chunk's all-gather), S back-projects / sorts / plans and M commits ALL frames
+          (every rank keeps a byte-identical replica of the map), M ray-marches this rank's frames only.
+        Everything is enqueued up front: D runs ahead of the fusion as far as the records go.  images: per-frame output
+        tensors for the frames of this rank (default: self.image for each).  Poses, replicas and images are those of the
+        one-GPU loop."""
+        n = len(timestamps)
+        world, rank = self.dist.world, self.dist.rank
+        if per_rank is None:
+            per_rank = max(1, 16 // world)
+        if not hasattr(self, "_runner"):
+            self._runner = pkg.Runner(self.cam, self.pool, self.w, self.h, self.depth, self.center, self.edge, self.focal,
+                                      self.focal, self.mode)
+            self._s_delta = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        self._s_delta.wait_stream(cur)
+        g0 = self.frames_seen
+        deltas, events, march, outs = [None] * n, [None] * n, [False] * n, [None] * n
+        keep = []
+        for (a, b, slots) in frame_shards(n, g0, world, per_rank):
+            mine = torch.zeros((per_rank, pkg.DELTA_FLOATS), dtype=torch.float32, device="cuda")
+            allr = torch.empty((world, per_rank, pkg.DELTA_FLOATS), dtype=torch.float32, device="cuda")
+            with torch.cuda.stream(self._s_delta):
+                for i in range(a, b):
+                    r, row = slots[i - a]
+                    if r == rank and g0 + i > 0:   # (a camera's first frame has no ICP)
+                        pd, pr = (depths[i - 1], rgbs[i - 1]) if i > 0 else self._prev
+                        self.delta_cam.pair_delta(pd, pr, depths[i], rgbs[i], mine[row])
+                self.dist.all_gather_deltas(allr, mine)
+                ev = torch.cuda.Event()
+                ev.record()
+            keep.append((mine, allr))
+            for i in range(a, b):
+                r, row = slots[i - a]
+                deltas[i] = allr[r, row]
+                march[i] = r == rank
+                if march[i]:
+                    outs[i] = images[i] if images is not None else self.image
+            events[a] = ev      # the pose stream is in order: the chunk's first frame waits for the gather
+        self._runner.run_sharded(depths, rgbs, timestamps, views, deltas, events, march, outs, 0, self.h, self.counters)
+        self._keep_sharded = keep
+        self._prev = (depths[n - 1], rgbs[n - 1])
+        self.frames_seen = g0 + n
+        self.marched_last_call = sum(march)
 
     def _backproject_with(self, depth, fusion_ptr):
         if not self.band_exchange:

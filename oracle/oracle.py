@@ -99,6 +99,9 @@ def lib(native=False):
     L.ora_camera_update.restype = C.c_int
     L.ora_camera_update.argtypes = [C.c_void_p, u16p, u8p, C.c_longlong]
     L.ora_camera_pose.argtypes = [C.c_void_p, f32p, f32p]
+    L.ora_camera_last_update.argtypes = [C.c_void_p, f32p]
+    L.ora_camera_apply_delta.restype = C.c_int
+    L.ora_camera_apply_delta.argtypes = [C.c_void_p, f32p, C.c_int, C.c_longlong]
     L.ora_camera_fusion_transform.argtypes = [C.c_void_p, f32p]
     L.ora_camera_last_system.argtypes = [C.c_void_p, f32p, f32p, f32p]
     L.ora_camera_tracking_lost_count.restype = C.c_int
@@ -439,6 +442,19 @@ class Camera:
         p = np.empty(3, np.float32); o = np.empty(9, np.float32)
         self._L.ora_camera_pose(self._c, _p(p, C.c_float), _p(o, C.c_float))
         return p, o
+
+    def last_update(self):
+        """update_trans of the frame most recently tracked (identity for a first frame)"""
+        m = np.empty(16, np.float32)
+        self._L.ora_camera_last_update(self._c, _p(m, C.c_float))
+        return m
+
+    def apply_delta(self, update_trans, levels_lost, timestamp):
+        """the pose step of update() for a frame tracked elsewhere (update_trans None: pose unchanged)"""
+        if update_trans is None:
+            return self._L.ora_camera_apply_delta(self._c, None, 0, timestamp)
+        m = np.ascontiguousarray(update_trans, dtype=np.float32)
+        return self._L.ora_camera_apply_delta(self._c, _p(m, C.c_float), int(levels_lost), timestamp)
 
     def set_rgbd(self, enable=True):
         self._L.ora_camera_set_rgbd(self._c, 1 if enable else 0)

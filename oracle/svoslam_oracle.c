@@ -1168,6 +1168,7 @@ struct ora_camera {
   float *last_v[PYR], *last_n[PYR], *cur_v[PYR], *cur_n[PYR];
   float lastA[36], lastb[6], lastx[6];
   int lost_count; /* levels abandoned with "Camera tracking is lost." (rgbd_camera.cpp:148-151) */
+  float last_update[16]; /* update_trans of the frame most recently tracked (identity for a first frame) */
   /* photometric RGB-D term (off by default = the reference, which ships it commented out) */
   int rgbd;
   float *last_i[PYR], *cur_i[PYR], *last_g[PYR], *cur_g[PYR]; /* intensity and its Sobel gradient per level */
@@ -1199,6 +1200,36 @@ static void mat3_to_mat4(const float m3[9], float m4[16]) {
   ora_mat4_identity(m4);
   for (int c = 0; c < 3; c++)
     for (int r = 0; r < 3; r++) m4[4 * c + r] = m3[3 * c + r];
+}
+
+/* rgbd_camera.cpp:172-173 (Q17: row-vector products) */
+static void pose_step(ora_camera *c, const float update_trans[16]) {
+  float p4[4] = {c->position[0], c->position[1], c->position[2], 1.0f}, np[4];
+  vec4_mul_mat4(p4, update_trans, np);
+  c->position[0] = np[0]; c->position[1] = np[1]; c->position[2] = np[2];
+  float o4[16], no[16];
+  mat3_to_mat4(c->orientation, o4);
+  ora_mat4_mul(o4, update_trans, no);
+  for (int cc = 0; cc < 3; cc++)
+    for (int r = 0; r < 3; r++) c->orientation[3 * cc + r] = no[4 * cc + r];
+}
+
+/* Frame-parallel tracking.  update_trans starts at the identity for every frame (:100) and the ICP
+ * loop reads the maps of the last and the current frame only (:103-168): a frame's update_trans is a function of two
+ * depth images, and only :172-173 chain the frames.  last_update() exposes a tracked frame's update_trans;
+ * apply_delta() is :55-59 + :172-173 for an update_trans from anywhere (NULL, or a camera's first frame -- `pass >= 1`,
+ * :99 -- leaves the pose alone) plus the levels it abandoned. */
+void ora_camera_last_update(const ora_camera *c, float out[16]) { memcpy(out, c->last_update, sizeof(c->last_update)); }
+
+int ora_camera_apply_delta(ora_camera *c, const float *update_trans, int levels_lost, long long timestamp) {
+  if (timestamp <= c->latest_stamp) return 0;
+  c->latest_stamp = timestamp;
+  if (c->pass >= 1 && update_trans) {
+    pose_step(c, update_trans);
+    c->lost_count += levels_lost;
+  }
+  if (c->pass < 2) c->pass++;
+  return 1;
 }
 
 int ora_camera_update(ora_camera *c, const uint16_t *depth, const uint8_t *rgb, long long timestamp) {
@@ -1259,15 +1290,10 @@ int ora_camera_update(ora_camera *c, const uint16_t *depth, const uint8_t *rgb, 
       }
       free(fv); free(fn);
     }
-    /* :172-173 (Q17: row-vector products) */
-    float p4[4] = {c->position[0], c->position[1], c->position[2], 1.0f}, np[4];
-    vec4_mul_mat4(p4, update_trans, np);
-    c->position[0] = np[0]; c->position[1] = np[1]; c->position[2] = np[2];
-    float o4[16], no[16];
-    mat3_to_mat4(c->orientation, o4);
-    ora_mat4_mul(o4, update_trans, no);
-    for (int cc = 0; cc < 3; cc++)
-      for (int r = 0; r < 3; r++) c->orientation[3 * cc + r] = no[4 * cc + r];
+    memcpy(c->last_update, update_trans, sizeof(update_trans));
+    pose_step(c, update_trans);
+  } else {
+    ora_mat4_identity(c->last_update);
   }
   if (c->pass < 2) c->pass++;
   for (int i = 0; i < PYR; i++) { /* :181-189 */

@@ -137,6 +137,9 @@ void ora_camera_destroy(ora_camera *c);
 /* returns 1 if the frame was processed, 0 if skipped (stale timestamp) */
 int ora_camera_update(ora_camera *c, const uint16_t *depth, const uint8_t *rgb, long long timestamp);
 void ora_camera_pose(const ora_camera *c, float position[3], float orientation[9]);
+/* frame-parallel tracking: a tracked frame's update_trans, and the pose step for an update_trans from anywhere */
+void ora_camera_last_update(const ora_camera *c, float out[16]);
+int ora_camera_apply_delta(ora_camera *c, const float *update_trans, int levels_lost, long long timestamp);
 int ora_camera_tracking_lost_count(const ora_camera *c);
 void ora_camera_set_rgbd(ora_camera *c, int enable); /* adds W_RGBD x the photometric system to every ICP iteration */
 /* model matrix used by main.cpp:40 : mat4(orientation) * translate(I, position) */

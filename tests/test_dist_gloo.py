@@ -90,3 +90,90 @@ def test_band_rows_partition():
             for (f0, n0), (f1, _) in zip(bands[:-1], bands[1:]):
                 assert f0 + n0 == f1
             assert max(b[1] for b in bands) - min(b[1] for b in bands) <= 1
+
+
+# ---- frame-sharded tracking (exchange "deltas") -----------------------------------------
+def _delta_worker(rank, world, port, n, w, h, per_rank, out_dir):
+    """Each rank tracks the frames g with g % world == rank as PAIRS (g-1, g) on a scratch oracle camera, the update_trans
+    records are all-gathered chunk by chunk with pipeline.frame_shards' layout, every rank composes the pose chain with
+    apply_delta: poses, fusion transforms and lost counts must equal the sequential oracle camera's, bit for bit."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import svoslam_pkg
+    svoslam_pkg.load()
+    pl = importlib.import_module("octree_slam_amd.pipeline")
+    synth = importlib.import_module("octree_slam_amd.synth")
+    from oracle import oracle as ora
+    ctx = pl.DistContext(rank, world, exchange="deltas")
+    depth, rgb = synth.render_stream(n, w, h, device="cpu")
+    depth = depth.numpy().view(np.uint16).copy()
+    depth[4, :, : w // 2] = 0  # a frame with half its pixels missing: ICP on what is left
+    depth[5] = 0               # a frame without any measurement: frames 5 and 6 abandon every level (singular systems)
+    rgb = rgb.numpy()
+    f = synth.focal_length(w)
+    FL = 20                    # == octree_slam_amd.DELTA_FLOATS
+    cam = ora.Camera(w, h, f, f)
+    poses = []
+    for (a, b, slots) in pl.frame_shards(n, 0, world, per_rank):
+        mine = torch.zeros((per_rank, FL), dtype=torch.float32)
+        for i in range(a, b):
+            r, row = slots[i - a]
+            if r == rank and i > 0:
+                scratch = ora.Camera(w, h, f, f)
+                scratch.update(depth[i - 1], rgb[i - 1], 0)
+                scratch.update(depth[i], rgb[i], 1)
+                rec = np.zeros(FL, np.float32)
+                rec[:16] = scratch.last_update()
+                rec[16:17] = np.array([scratch.tracking_lost_count()], np.int32).view(np.float32)
+                mine[row] = torch.from_numpy(rec)
+        allr = torch.empty((world, per_rank, FL), dtype=torch.float32)
+        ctx.all_gather_deltas(allr, mine)
+        for i in range(a, b):
+            r, row = slots[i - a]
+            rec = allr[r, row].numpy()
+            cam.apply_delta(None if i == 0 else rec[:16], int(rec[16:17].view(np.int32)[0]), i)
+            p, o = cam.pose()
+            poses.append(np.concatenate([p, o, cam.fusion_transform(), [cam.tracking_lost_count()]]))
+    ref = ora.Camera(w, h, f, f)
+    want = []
+    for i in range(n):
+        ref.update(depth[i], rgb[i], i)
+        p, o = ref.pose()
+        want.append(np.concatenate([p, o, ref.fusion_transform(), [ref.tracking_lost_count()]]))
+    got, want = np.array(poses, np.float32), np.array(want, np.float32)
+    ok = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+    moved = bool(np.abs(want[-1][3:12] - want[3][3:12]).max() > 0) and bool(want[-1][-1] == 6)   # tracked again after the gap
+    np.save(os.path.join(out_dir, "delta_rank%d.npy" % rank), np.array([ok, moved]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("per_rank", [1, 3])
+def test_two_rank_frame_sharded_tracking_gloo(tmp_path, per_rank):
+    world, port = 2, _free_port()
+    mp.spawn(_delta_worker, args=(world, port, 8, 160, 120, per_rank, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        ok, moved = np.load(os.path.join(str(tmp_path), "delta_rank%d.npy" % r))
+        assert ok and moved, (r, ok, moved)
+
+
+def test_frame_shards_cover_every_frame_once():
+    import sys
+    sys.path.insert(0, ROOT)
+    import svoslam_pkg
+    svoslam_pkg.load()
+    pl = importlib.import_module("octree_slam_amd.pipeline")
+    for n in (1, 5, 16, 37):
+        for world in (1, 2, 3, 8):
+            for per_rank in (1, 2, 5):
+                for first in (0, 3):
+                    seen, covered = set(), 0
+                    for (a, b, slots) in pl.frame_shards(n, first, world, per_rank):
+                        assert a == covered and b - a == len(slots) <= world * per_rank
+                        covered = b
+                        for i, (r, row) in zip(range(a, b), slots):
+                            assert r == (first + i) % world and 0 <= row < per_rank
+                            assert (a, r, row) not in seen          # one record per slot of the gathered block
+                            seen.add((a, r, row))
+                    assert covered == n

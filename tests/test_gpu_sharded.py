@@ -1,0 +1,158 @@
+"""Frame-sharded sessions (exchange "deltas") on the GPU: a frame's ICP is a function of two depth
+images, so svoslam_camera_pair_delta may run anywhere and svoslam_camera_apply_delta composes the poses.  Checked
+against the ordinary tracker, the CPU oracle, and -- for whole sessions -- the one-GPU frame loop, with the ranks of a
+2- and a 3-rank session run one after the other on the one GPU there is (each with its own pool, cameras and runner;
+pipeline.EmulatedRank stands in for the all-gather: the other ranks' records come from a table)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from util import describe_mismatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import svoslam_pkg
+    pkg = svoslam_pkg.load()
+    synth = importlib.import_module("octree_slam_amd.synth")
+    pl = importlib.import_module("octree_slam_amd.pipeline")
+    return pkg, torch, synth, pl
+
+
+def _stream(synth, torch, n, w, h):
+    depth, rgb = synth.render_stream(n, w, h, device="cuda")
+    return depth, rgb
+
+
+def _cam_state(cam, torch, pkg):
+    p, o = cam.pose()
+    m = pkg.copy_from_device(cam.fusion_transform_ptr(), (16,), np.float32)
+    return np.concatenate([p, o, m, [cam.tracking_lost_count()]]).astype(np.float32)
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (640, 480)])
+def test_pair_delta_then_apply_equals_update_and_oracle(env, oracle, w, h):
+    """apply_delta(pair_delta(k-1, k)) == update(k): pose, fusion transform, lost count, bit for bit, through a frame
+    that abandons every pyramid level; and == the oracle's update_trans per frame"""
+    pkg, torch, synth, pl = env
+    n = 7
+    depth, rgb = _stream(synth, torch, n, w, h)
+    depth[4] = 0            # no measurement: frames 4 and 5 abandon every level
+    f = synth.focal_length(w)
+    A, D, P = pkg.Camera(w, h, f, f), pkg.Camera(w, h, f, f), pkg.Camera(w, h, f, f)
+    ocam = oracle.Camera(w, h, f, f)
+    rec = torch.zeros((n, pkg.DELTA_FLOATS), dtype=torch.float32, device="cuda")
+    for k in range(n):
+        assert A.update(depth[k], rgb[k], k) == 1
+        if k > 0:
+            D.pair_delta(depth[k - 1], rgb[k - 1], depth[k], rgb[k], rec[k])
+        assert P.apply_delta(rec[k] if k > 0 else None, k) == 1
+        a, p = _cam_state(A, torch, pkg), _cam_state(P, torch, pkg)
+        assert np.array_equal(a.view(np.uint32), p.view(np.uint32)), (k, a, p)
+        ocam.update(depth[k].cpu().numpy().view(np.uint16), rgb[k].cpu().numpy(), k)
+        if k > 0:
+            r = rec[k].cpu().numpy()
+            assert np.array_equal(r[:16].view(np.uint32), ocam.last_update().view(np.uint32)), k
+        op, oo = ocam.pose()
+        assert np.array_equal(p[3:12].view(np.uint32), oo.view(np.uint32)) and int(p[-1]) == ocam.tracking_lost_count()
+    assert int(_cam_state(P, torch, pkg)[-1]) == 6
+    # records do not depend on the order they are produced in, nor on what the scratch camera did before
+    again = torch.zeros_like(rec)
+    for k in (5, 2, 6, 1, 3, 4):
+        D.pair_delta(depth[k - 1], rgb[k - 1], depth[k], rgb[k], again[k])
+    assert torch.equal(rec.view(torch.int32)[1:], again.view(torch.int32)[1:])
+    # stale timestamps are skipped like update() skips them; update() and apply_delta() do not mix on one camera
+    assert P.apply_delta(rec[1], 3) == 0
+    with pytest.raises(pkg.SvoslamError):
+        A.apply_delta(rec[1], 100)
+    with pytest.raises(pkg.SvoslamError):
+        P.update(depth[0], rgb[0], 100)
+    with pytest.raises(pkg.SvoslamError):
+        P.pair_delta(depth[0], rgb[0], depth[1], rgb[1], again[0])
+
+
+@pytest.mark.parametrize("world,per_rank,w,h,depth", [(2, 2, 320, 240, 10), (3, 1, 160, 120, 8)])
+def test_sharded_session_equals_single_gpu_session(env, world, per_rank, w, h, depth):
+    """every rank of a frame-sharded session: poses and map replica equal the one-GPU session's after every call, the
+    frames it ray-marches equal the one-GPU images; across ranks every frame is marched exactly once.  Two calls (the
+    second starts mid-stream: its first frame is tracked against the last frame of the first call)."""
+    pkg, torch, synth, pl = env
+    center, edge = (0.0, 1.5, 0.0), 4.096
+    n1, n2 = 7, 6
+    n = n1 + n2
+    dstack, cstack = _stream(synth, torch, n, w, h)
+    views = [pl.ground_truth_view(k, synth) for k in range(n)]
+    # one-GPU session: images of all frames, pool and pose after each part
+    A = pl.SlamPipeline(w, h, depth, center, edge)
+    ref_img, ref_state = [], []
+    for k in range(n):
+        ref_img.append(A.frame(dstack[k], cstack[k], k, views[k]).cpu().numpy().copy())
+        if k in (n1 - 1, n - 1):
+            ref_state.append((A.pool.size, A.pool.words().copy(), _cam_state(A.cam, torch, pkg)))
+    # the records a session would exchange
+    f = synth.focal_length(w)
+    D = pkg.Camera(w, h, f, f)
+    table = torch.zeros((n, pkg.DELTA_FLOATS), dtype=torch.float32, device="cuda")
+    for k in range(1, n):
+        D.pair_delta(dstack[k - 1], cstack[k - 1], dstack[k], cstack[k], table[k])
+    torch.cuda.synchronize()
+    marched = np.zeros(n, np.int32)
+    for rank in range(world):
+        B = pl.SlamPipeline(w, h, depth, center, edge, dist=pl.EmulatedRank(rank, world))
+        for part, (lo, hi) in enumerate(((0, n1), (n1, n))):
+            B.dist.expect(table[lo:hi], lo, per_rank)
+            imgs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(lo, hi)]
+            B.run_stream_sharded(list(dstack[lo:hi]), list(cstack[lo:hi]), list(range(lo, hi)), views[lo:hi], images=imgs,
+                                 per_rank=per_rank)
+            torch.cuda.synchronize()
+            size, words, state = ref_state[part]
+            assert B.pool.size == size and np.array_equal(B.pool.words(), words), (rank, part)
+            got = _cam_state(B.cam, torch, pkg)
+            assert np.array_equal(got.view(np.uint32), state.view(np.uint32)), (rank, part, got, state)
+            for k in range(lo, hi):
+                if k % world == rank:
+                    marched[k] += 1
+                    assert np.array_equal(imgs[k - lo].cpu().numpy(), ref_img[k]), (rank, k, describe_mismatch(imgs[k - lo].cpu().numpy(), ref_img[k]))
+                else:
+                    assert int(imgs[k - lo].max()) == 0      # not this rank's frame: untouched
+    assert (marched == 1).all()
+
+
+def test_sharded_path_over_rccl_one_rank(env):
+    """exchange "deltas" through torch.distributed (RCCL, one rank): run_stream == the single-GPU run_stream"""
+    pkg, torch, synth, pl = env
+    import torch.distributed as dist
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29543")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        w, h, depth, center, edge = 320, 240, 10, (0.0, 1.5, 0.0), 4.096
+        n = 9
+        dstack, cstack = _stream(synth, torch, n, w, h)
+        views = [pl.ground_truth_view(k, synth) for k in range(n)]
+        A = pl.SlamPipeline(w, h, depth, center, edge, count_steps=True)
+        B = pl.SlamPipeline(w, h, depth, center, edge, count_steps=True, dist=pl.DistContext(0, 1, force=True, exchange="deltas"))
+        for P in (A, B):
+            P.run_stream(list(dstack[:5]), list(cstack[:5]), list(range(5)), views[:5])
+            P.run_stream(list(dstack[5:]), list(cstack[5:]), list(range(5, n)), views[5:])
+            torch.cuda.synchronize()
+        assert np.array_equal(A.image.cpu().numpy(), B.image.cpu().numpy())
+        assert A.pool.size == B.pool.size and np.array_equal(A.pool.words(), B.pool.words())
+        assert np.array_equal(_cam_state(A.cam, torch, pkg).view(np.uint32), _cam_state(B.cam, torch, pkg).view(np.uint32))
+        assert torch.equal(A.counters, B.counters) and int(A.counters[0]) > 0
+        B.reset(); A.reset()
+        for P in (A, B):
+            P.run_stream(list(dstack[:4]), list(cstack[:4]), list(range(4)), views[:4])
+            torch.cuda.synchronize()
+        assert np.array_equal(A.image.cpu().numpy(), B.image.cpu().numpy()) and np.array_equal(A.pool.words(), B.pool.words())
+    finally:
+        if created:
+            dist.destroy_process_group()
