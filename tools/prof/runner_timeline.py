@@ -10,9 +10,21 @@ W, H, D, edge = 640, 480, 12, 4.096
 K = 60
 depth, rgb = synth.render_stream(K, W, H, device="cuda")
 views = [pl.ground_truth_view(k, synth) for k in range(K)]
-P = pl.SlamPipeline(W, H, D, (0, 1.5, 0), edge, pool_capacity_nodes=(1 << 30) - 8)
+emu = None
+if len(sys.argv) > 1:    # "R/N": rank R of an N-rank frame-sharded session, emulated on this GPU (pipeline.EmulatedRank)
+    er, en = (int(x) for x in sys.argv[1].split("/"))
+    emu = pl.EmulatedRank(er, en)
+    dcam = pkg.Camera(W, H, synth.focal_length(W), synth.focal_length(W))
+    table = torch.zeros((K, pkg.DELTA_FLOATS), dtype=torch.float32, device="cuda")
+    for k in range(1, K):
+        dcam.pair_delta(depth[k - 1], rgb[k - 1], depth[k], rgb[k], table[k])
+    torch.cuda.synchronize()
+    print("emulated rank %d of %d (frame-sharded: maps* / trk0 / pose columns = the pose composition only)" % (er, en))
+P = pl.SlamPipeline(W, H, D, (0, 1.5, 0), edge, pool_capacity_nodes=(1 << 30) - 8, dist=emu)
+if emu: emu.expect(table[:6], 0, max(1, 16 // emu.world))
 P.run_stream(depth[:6], rgb[:6], list(range(6)), views[:6]); torch.cuda.synchronize(); P.reset()
 import time
+if emu: emu.expect(table, 0, max(1, 16 // emu.world))
 t0 = time.perf_counter()
 P.run_stream(depth, rgb, list(range(K)), views); torch.cuda.synchronize()
 print("ms/frame %.3f" % ((time.perf_counter() - t0) / K * 1e3))
