@@ -161,6 +161,14 @@ int svoslam_svo_from_point_cloud_async(svoslam_workspace *ws, const float *d_poi
  * the same time need a workspace each.  If plan has to grow the pool it first waits for the whole device. */
 int svoslam_svo_fuse_sort(svoslam_workspace *ws, const float *d_points, int32_t n, int32_t max_depth,
                           const float center[3], float edge_length, void *stream);
+/* The sort phase fed by a raw depth frame: generateVertexMap (image_kernels.cu:24-58), transformVertexMap by the
+ * DEVICE-resident mat4 d_pose (main.cpp:40-41), computePointCloudBoundingBox (image_kernels.cu:60-102; main.cpp:43) and
+ * computeKeys (svo.cu:33-66) in ONE launch, without a point cloud in memory, then the sort: same sorted keys as
+ * generate_vertex_map -> transform_vertex_map_dmat -> point_cloud_bbox_device -> svo_fuse_sort.  d_bbox7 (optional) =
+ * {min xyz, max xyz, any}.  Needs 3 max_depth + 1 + ceil(log2(width height)) <= 64 (SVOSLAM_ERR_INVALID_ARG otherwise). */
+int svoslam_svo_fuse_sort_frame(svoslam_workspace *ws, const uint16_t *d_depth, const float *d_pose, int32_t width, int32_t height,
+                                float fx, float fy, int32_t max_depth, const float center[3], float edge_length, float *d_bbox7,
+                                void *stream);
 int svoslam_svo_fuse_plan(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream);
 int svoslam_svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int32_t n, int32_t max_depth,
                             svoslam_pool *pool, void *stream);
@@ -516,6 +524,9 @@ int svoslam_runner_timeline(svoslam_runner *runner, float *h_ms, int32_t max_fra
 int svoslam_runner_run(svoslam_runner *runner, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs,
                        const long long *timestamps, const float *views, int32_t n, uint8_t *d_image, int32_t row_first,
                        int32_t rows, unsigned long long *d_steps, void *caller_stream);
+/* the bounding box the loop computed for the last frame enqueued (computePointCloudBoundingBox, main.cpp:43):
+ * {min xyz, max xyz, any point}.  Blocking. */
+int svoslam_runner_bbox(svoslam_runner *runner, float h_bbox7[7]);
 /* The same loop for ONE RANK of a frame-sharded session (frames are tracked in parallel, one process
  * per GPU, each with a full replica of the map).  The poses come from svoslam_camera_apply_delta(d_deltas[i]) -- n device
  * pointers to SVOSLAM_DELTA_FLOATS floats, produced by svoslam_camera_pair_delta on whichever rank tracked frame i and

@@ -87,6 +87,7 @@ SIGNATURES = {
     "svoslam_pool_load": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _fp, C.POINTER(_f32), C.POINTER(_i32), _vp]),
     "svoslam_svo_from_point_cloud_async": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _fp, _f32, _vp]),
     "svoslam_svo_fuse_sort": (C.c_int, [_vp, _vp, _i32, _i32, _fp, _f32, _vp]),
+    "svoslam_svo_fuse_sort_frame": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _i32, _fp, _f32, _vp, _vp]),
     "svoslam_svo_fuse_plan": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_commit": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_commit_to": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _i32, _i32, _vp]),
@@ -121,6 +122,7 @@ SIGNATURES = {
     "svoslam_runner_destroy": (C.c_int, [_vp]),
     "svoslam_runner_timeline": (C.c_int, [_vp, _fp, _i32, C.POINTER(_i32)]),
     "svoslam_runner_run": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_longlong), _fp, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "svoslam_runner_bbox": (C.c_int, [_vp, _fp]),
     "svoslam_runner_run_sharded": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_longlong), _fp, _i32, C.POINTER(_vp),
                                              C.POINTER(_vp), C.POINTER(C.c_uint8), C.POINTER(_vp), _i32, _i32, _vp, _vp]),
     "svoslam_scene_create": (C.c_int, [C.POINTER(_vp)]),
@@ -379,6 +381,13 @@ def svo_fuse_sort(ws, points, max_depth, center, edge_length):
     check(lib().svoslam_svo_fuse_sort(ws._h, _ptr(points), n, max_depth, _fa(center, 3), float(edge_length), _stream()))
 
 
+def svo_fuse_sort_frame(ws, depth_image, pose_ptr, fx, fy, max_depth, center, edge_length, bbox7=None):
+    """sort phase straight from a depth frame and a device-resident pose (vertex map + transform + bbox + keys in one launch)"""
+    h, w = depth_image.shape[-2], depth_image.shape[-1]
+    check(lib().svoslam_svo_fuse_sort_frame(ws._h, _ptr(depth_image), C.c_void_p(int(pose_ptr)), w, h, float(fx), float(fy),
+                                            int(max_depth), _fa(center, 3), float(edge_length), _ptr(bbox7), _stream()))
+
+
 def svo_fuse_plan(ws, n, max_depth, pool):
     """phase 2: split planning against the pool's current tree (reads the pool)."""
     check(lib().svoslam_svo_fuse_plan(ws._h, int(n), max_depth, C.byref(pool._p), _stream()))
@@ -555,6 +564,12 @@ class Runner:
         self._keep = (depths, rgbs, deltas, delta_events, images)   # alive until the next call (the work is asynchronous)
         check(lib().svoslam_runner_run_sharded(self._h, dp, rp, ts, vw.ctypes.data_as(_fp), n, dl, ev, mf, im, int(row_first), int(rows),
                                                _ptr(counters), _stream()))
+
+    def bbox(self):
+        """{min xyz, max xyz, any} of the last frame's point cloud (main.cpp:43)"""
+        b = (C.c_float * 7)()
+        check(lib().svoslam_runner_bbox(self._h, b))
+        return np.array(list(b), np.float32)
 
     def timeline(self, max_frames=4096):
         """[frames, 10] stage times in ms of the last run (SVOSLAM_RUNNER_TIMELINE=1)"""

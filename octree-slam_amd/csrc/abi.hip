@@ -163,6 +163,13 @@ int svoslam_svo_fuse_sort(svoslam_workspace *ws, const float *d_points, int32_t 
   if (!center) return SVOSLAM_ERR_INVALID_ARG;
   return svo_fuse_sort(ws, d_points, n, max_depth, center, edge_length, S(stream));
 }
+int svoslam_svo_fuse_sort_frame(svoslam_workspace *ws, const uint16_t *d_depth, const float *d_pose, int32_t width, int32_t height,
+                                float fx, float fy, int32_t max_depth, const float center[3], float edge_length, float *d_bbox7,
+                                void *stream) {
+  NEED_DEVICE();
+  if (!center) return SVOSLAM_ERR_INVALID_ARG;
+  return svo_fuse_sort_frame(ws, d_depth, d_pose, width, height, fx, fy, max_depth, center, edge_length, d_bbox7, S(stream));
+}
 int svoslam_svo_fuse_plan(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream) {
   NEED_DEVICE();
   return svo_fuse_plan(ws, n, max_depth, pool, S(stream));

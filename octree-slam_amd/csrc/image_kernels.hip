@@ -5,20 +5,13 @@
 #include <math.h>
 
 #include "image_kernels.hpp"
+#include "image_device.hpp"
 
 namespace svoslam {
 
 // ----------------------------------------------------------------------------
 // vertex / normal maps (image_kernels.cu:24-58, 104-139)
 // ----------------------------------------------------------------------------
-__device__ inline void vertex_from_depth(int depth, int x, int y, int width, int height, float fx, float fy, int img_w,
-                                         int img_h, float &vx, float &vy, float &vz) {
-  if (depth == 0 || depth > 15000) { vx = vy = vz = INFINITY; return; }
-  const float milli = 0.001f;
-  vx = (float)((img_w / width) * x - img_w / 2) * (float)depth / fx * milli;
-  vy = (float)(img_h / 2 - (img_h / height) * y) * (float)depth / fy * milli;
-  vz = (float)depth * milli;
-}
 
 __global__ __launch_bounds__(256) void vertex_map_kernel(const uint16_t *__restrict__ depth, float *__restrict__ vmap,
                                                          int width, int height, float fx, float fy, int img_w, int img_h,

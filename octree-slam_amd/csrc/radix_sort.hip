@@ -165,6 +165,218 @@ int exclusive_scan_u32(svoslam_workspace *ws, unsigned *data, unsigned n, unsign
   return SVOSLAM_OK;
 }
 
+// ---- packed sort (round 2): the asynchronous fusion's keys ---------------------------------------------
+// A depth-D Morton key is 3D + 1 bits and a point index ceil(log2 n) bits: at 640x480 / depth 12 that is 37 + 19, at
+// 1920x1080 / depth 14 43 + 21 = 64.  Where both fit one 64-bit word the sort carries (key << idx_bits | index)
+// and no value array -- 8 instead of 12 bytes per element and pass -- with digits of up to 11 bits: 4 passes instead of
+// 5 (depth 12) or 6 (depth 14).  Tiles of 2048 keys keep the [tile][digit] histograms (written as whole rows, read as
+// whole rows) small next to the keys; the column scan over the tiles is its own launch (one coalesced pass on bins / 64
+// workgroups: folding it into the downsweep was measured slower).  The first pass's histogram comes
+// from whoever writes the keys (svo_build.hip: keys_packed_kernel); the last pass unpacks into the (key, index) arrays
+// the planner reads.  Stable by construction: equal keys differ in their index bits' original order.
+constexpr int kPkThreads = 512, kPkWaves = kPkThreads / 64;
+constexpr int kPkIPT = 4;
+constexpr int kPkTile = kPkThreads * kPkIPT;  // 2048: at 640x480 150 workgroups of 8 wavefronts (tiles of 4096 keys on 256 threads
+// were measured 1.8x slower per pass: too few wavefronts in flight for a latency-bound kernel)
+
+int radix_packed_tile() { return kPkTile; }
+int radix_packed_threads() { return kPkThreads; }
+int radix_packed_tiles(int n) { return (int)cdiv(n, kPkTile); }
+int radix_packed_passes(int key_bits) { int p = (key_bits + kPackedMaxBits - 1) / kPackedMaxBits; return p < 1 ? 1 : p; }
+int radix_packed_first_bits(int key_bits) {
+  const int p = radix_packed_passes(key_bits);
+  const int w = (key_bits + p - 1) / p;
+  return w < 1 ? 1 : w;
+}
+
+__global__ __launch_bounds__(kPkThreads) void packed_upsweep_kernel(const unsigned long long *__restrict__ keys, int n, int shift, int bits,
+                                                                    unsigned *__restrict__ tile_hist) {
+  __shared__ unsigned hist[kPackedMaxBins];
+  const int bins = 1 << bits;
+  for (int d = threadIdx.x; d < bins; d += kPkThreads) hist[d] = 0;
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * kPkTile;
+  const unsigned mask = (unsigned)bins - 1u;
+#pragma unroll
+  for (int r = 0; r < kPkIPT; r++) {
+    const long long idx = base + r * kPkThreads + threadIdx.x;
+    if (idx < n) atomicAdd(&hist[(unsigned)(keys[idx] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < bins; d += kPkThreads) tile_hist[(size_t)blockIdx.x * bins + d] = hist[d];
+}
+
+// hist[t][d] (t < tiles, d < bins) -> exclusive prefix over t, in place; totals[d] = column sum.  One workgroup of 16
+// wavefronts per 64 digits: wavefront w scans the tiles [w C, (w + 1) C) of its 64 columns (256-byte row segments).
+__global__ __launch_bounds__(1024) void packed_column_scan_kernel(unsigned *__restrict__ hist, int tiles, int bins,
+                                                                  unsigned *__restrict__ totals) {
+  __shared__ unsigned csum[16][64];
+  const int lane = (int)(threadIdx.x & 63u), w = (int)(threadIdx.x >> 6);
+  const int d = blockIdx.x * 64 + lane;
+  const int C = (tiles + 15) / 16;
+  const int t0 = w * C, t1 = (t0 + C < tiles) ? t0 + C : tiles;
+  const bool col = d < bins;
+  unsigned sum = 0;
+  for (int t = t0; t < t1; t += 8) {
+    unsigned v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = (col && t + k < t1) ? hist[(size_t)(t + k) * bins + d] : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += v[k];
+  }
+  csum[w][lane] = sum;
+  __syncthreads();
+  unsigned run = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const unsigned c = csum[k][lane];
+    if (k < w) run += c;
+    total += c;
+  }
+  for (int t = t0; t < t1; t += 8) {
+    unsigned v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = (col && t + k < t1) ? hist[(size_t)(t + k) * bins + d] : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (col && t + k < t1) hist[(size_t)(t + k) * bins + d] = run;
+      run += v[k];
+    }
+  }
+  if (w == 0 && col) totals[d] = total;
+}
+
+template <bool LAST>
+__global__ __launch_bounds__(kPkThreads) void packed_downsweep_kernel(const unsigned long long *__restrict__ in,
+                                                                      unsigned long long *__restrict__ out_keys,
+                                                                      unsigned *__restrict__ out_vals, int n, int shift, int bits,
+                                                                      int idx_bits, const unsigned *__restrict__ tile_prefix,
+                                                                      const unsigned *__restrict__ totals) {
+  __shared__ unsigned short cnt[kPkWaves][kPackedMaxBins];  // per-wave digit counters (<= 256), then per-wave exclusive offsets
+  __shared__ unsigned dbase[kPackedMaxBins];                // global output base of each digit for this tile
+  __shared__ unsigned wsum[kPkWaves];
+  const int bins = 1 << bits;
+  const unsigned mask = (unsigned)bins - 1u;
+  const int tile = blockIdx.x;
+  const unsigned wave = threadIdx.x >> 6, lane = lane_id();
+  // keys first: their latency covers the digit-base scan
+  const long long base = (long long)tile * kPkTile + (long long)wave * (kWave * kPkIPT);
+  unsigned long long k[kPkIPT];
+#pragma unroll
+  for (int r = 0; r < kPkIPT; r++) {
+    const long long idx = base + r * kWave + lane;
+    k[r] = idx < n ? in[idx] : ~0ull;
+  }
+  for (int d = threadIdx.x; d < bins; d += kPkThreads) {
+#pragma unroll
+    for (int w = 0; w < kPkWaves; w++) cnt[w][d] = 0;
+  }
+  {  // exclusive scan of the digit totals: thread t owns the `per` consecutive digits from t * per
+    const int per = (bins + kPkThreads - 1) / kPkThreads;
+    const int d0 = (int)threadIdx.x * per;
+    unsigned own = 0;
+    for (int q = 0; q < per; q++) own += d0 + q < bins ? totals[d0 + q] : 0u;
+    const unsigned inc = wave_inclusive_scan(own);
+    if (lane == kWave - 1) wsum[wave] = inc;
+    __syncthreads();
+    unsigned run = inc - own;
+#pragma unroll
+    for (int w = 0; w < kPkWaves; w++) run += (unsigned)w < wave ? wsum[w] : 0u;
+    for (int q = 0; q < per; q++) {
+      if (d0 + q < bins) {
+        dbase[d0 + q] = run + tile_prefix[(size_t)tile * bins + d0 + q];
+        run += totals[d0 + q];
+      }
+    }
+  }
+  __syncthreads();
+  unsigned short pre[kPkIPT];
+  volatile unsigned short *wc = cnt[wave];
+  const unsigned long long lt = lanemask_lt();
+#pragma unroll
+  for (int r = 0; r < kPkIPT; r++) {
+    const bool ok = base + r * kWave + lane < n;
+    const unsigned dig = (unsigned)(k[r] >> shift) & mask;
+    unsigned long long peers = __ballot(ok);
+    for (int b = 0; b < bits; b++) {
+      const bool bit = (dig >> b) & 1u;
+      const unsigned long long m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    pre[r] = 0;
+    if (ok) {
+      const unsigned old = wc[dig];
+      const unsigned rank = __popcll(peers & lt);
+      pre[r] = (unsigned short)(old + rank);
+      if (rank == 0) wc[dig] = (unsigned short)(old + __popcll(peers));
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < bins; d += kPkThreads) {  // exclusive offsets of each wave's share of digit d
+    unsigned run = 0;
+#pragma unroll
+    for (int w = 0; w < kPkWaves; w++) {
+      const unsigned t = cnt[w][d];
+      cnt[w][d] = (unsigned short)run;
+      run += t;
+    }
+  }
+  __syncthreads();
+  const unsigned long long imask = (1ull << idx_bits) - 1ull;
+#pragma unroll
+  for (int r = 0; r < kPkIPT; r++) {
+    if (base + r * kWave + lane < n) {
+      const unsigned dig = (unsigned)(k[r] >> shift) & mask;
+      const unsigned pos = dbase[dig] + cnt[wave][dig] + pre[r];
+      if (LAST) {
+        out_keys[pos] = k[r] >> idx_bits;
+        out_vals[pos] = (unsigned)(k[r] & imask);
+      } else {
+        out_keys[pos] = k[r];
+      }
+    }
+  }
+}
+
+// Sorts the n packed words of ws->keys_a on their key bits [idx_bits, idx_bits + key_bits).  ws->tile_hist already holds
+// the first pass's histograms ([tile][1 << radix_packed_first_bits(key_bits)], tiles of radix_packed_tile() elements).
+// Output: keys (unpacked) in keys_a or keys_b, indices in vals_a.
+int radix_sort_packed(svoslam_workspace *ws, int n, int key_bits, int idx_bits, hipStream_t stream, unsigned long long **sorted_keys,
+                      unsigned **sorted_vals) {
+  unsigned long long *ka = ws->keys_a.as<unsigned long long>(), *kb = ws->keys_b.as<unsigned long long>();
+  unsigned *tile_hist = ws->tile_hist.as<unsigned>();
+  const int tiles = radix_packed_tiles(n);
+  const int passes = radix_packed_passes(key_bits);
+  unsigned *totals = tile_hist + (size_t)tiles * kPackedMaxBins;  // behind the largest histogram matrix
+  int bit = 0;
+  for (int p = 0; p < passes; p++) {
+    const int remaining_bits = key_bits - bit, remaining_passes = passes - p;
+    int width = (remaining_bits + remaining_passes - 1) / remaining_passes;
+    if (width < 1) width = 1;
+    const int bins = 1 << width, shift = idx_bits + bit;
+    if (p > 0) packed_upsweep_kernel<<<tiles, kPkThreads, 0, stream>>>(ka, n, shift, width, tile_hist);
+    packed_column_scan_kernel<<<(bins + 63) / 64, 1024, 0, stream>>>(tile_hist, tiles, bins, totals);
+    if (p == passes - 1)
+      packed_downsweep_kernel<true><<<tiles, kPkThreads, 0, stream>>>(ka, kb, ws->vals_a.as<unsigned>(), n, shift, width, idx_bits, tile_hist, totals);
+    else
+      packed_downsweep_kernel<false><<<tiles, kPkThreads, 0, stream>>>(ka, kb, nullptr, n, shift, width, idx_bits, tile_hist, totals);
+    SVO_LAUNCH_CHECK();
+    unsigned long long *tk = ka; ka = kb; kb = tk;
+    bit += width;
+  }
+  *sorted_keys = ka;
+  *sorted_vals = ws->vals_a.as<unsigned>();
+  return SVOSLAM_OK;
+}
+
+int radix_sort_packed_output(svoslam_workspace *ws, int key_bits, unsigned long long **sorted_keys, unsigned **sorted_vals) {
+  const bool in_b = (radix_packed_passes(key_bits) & 1) != 0;
+  *sorted_keys = in_b ? ws->keys_b.as<unsigned long long>() : ws->keys_a.as<unsigned long long>();
+  *sorted_vals = ws->vals_a.as<unsigned>();
+  return SVOSLAM_OK;
+}
+
 int radix_sort_num_tiles(int n) { return (int)cdiv(n, kSortTile); }
 
 void row_scan_rows(unsigned *rows, int num_tiles, unsigned *totals, hipStream_t stream) {

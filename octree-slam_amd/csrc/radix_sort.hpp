@@ -13,6 +13,20 @@ int radix_sort_pairs(svoslam_workspace *ws, int n, int num_bits, hipStream_t str
                      unsigned long long **sorted_keys, unsigned **sorted_vals, bool iota_vals = true);
 // Where that sort leaves its result (depends only on the pass count).
 int radix_sort_output(svoslam_workspace *ws, int n, int num_bits, unsigned long long **sorted_keys, unsigned **sorted_vals);
+// Packed form (see radix_sort.hip): n words (key << idx_bits | index) in ws->keys_a, first-pass histograms in
+// ws->tile_hist ([tile][1 << radix_packed_first_bits(key_bits)] for tiles of radix_packed_tile() elements; reserve
+// radix_packed_hist_words(n) words).  Output: unpacked keys in keys_a / keys_b, indices in vals_a.
+constexpr int kPackedMaxBits = 11;
+constexpr int kPackedMaxBins = 1 << kPackedMaxBits;
+int radix_packed_tile();
+int radix_packed_threads();
+int radix_packed_tiles(int n);
+int radix_packed_passes(int key_bits);
+int radix_packed_first_bits(int key_bits);
+inline size_t radix_packed_hist_words(int n) { return ((size_t)radix_packed_tiles(n) + 1) * kPackedMaxBins; }
+int radix_sort_packed(svoslam_workspace *ws, int n, int key_bits, int idx_bits, hipStream_t stream,
+                      unsigned long long **sorted_keys, unsigned **sorted_vals);
+int radix_sort_packed_output(svoslam_workspace *ws, int key_bits, unsigned long long **sorted_keys, unsigned **sorted_vals);
 // In-place exclusive scan of each of 256 rows of num_tiles counters; row totals to totals[256].
 void row_scan_rows(unsigned *rows, int num_tiles, unsigned *totals, hipStream_t stream);
 // Same for a single row.

@@ -62,6 +62,7 @@ struct svoslam_runner {
   hipEvent_t ev_begin = nullptr, ev_end[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t last_caller = nullptr;
   int lead = 3;  // commits the host may run ahead of the device (see svoslam_runner_run)
+  bool fused_front = false;  // back-projection + bounding box + keys in one launch (SVOSLAM_RUNNER_FUSED_FRONT=0: the four stand-alone calls)
   bool deferred = false;  // SVOSLAM_RUNNER_DEFERRED=1 (one replica): the commit of frame k+1 is computed during the march of frame k
   bool ran = false;
   // SVOSLAM_RUNNER_TIMELINE=1: timing events at the stage boundaries of the last call (svoslam_runner_timeline)
@@ -109,6 +110,12 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
   r->timeline = tl && tl[0] == '1';
   const char *df = getenv("SVOSLAM_RUNNER_DEFERRED");
   r->deferred = df && df[0] == '1';
+  {
+    int idx_bits = 1;
+    while ((1ll << idx_bits) < (long long)width * height) idx_bits++;
+    const char *ff = getenv("SVOSLAM_RUNNER_FUSED_FRONT"), *sp = getenv("SVOSLAM_SORT_PAIRS");
+    r->fused_front = 3 * max_depth + 1 + idx_bits <= 64 && !(ff && ff[0] == '0') && !(sp && sp[0] == '1');
+  }
   const char *ld = getenv("SVOSLAM_RUNNER_LEAD");
   if (ld) r->lead = atoi(ld) < 0 ? 0 : atoi(ld);
   *out = r;
@@ -271,11 +278,18 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
       SVO_HIP(hipMemcpyAsync(r->in_prep, d_depths[i], px * 2, hipMemcpyDeviceToDevice, r->s_prep));
       SVO_HIP(hipMemcpyAsync(r->in_rgb[i % kRing], d_rgbs[i], px * 3, hipMemcpyDeviceToDevice, r->s_prep));
     }
-    SVO_TRY(svoslam_generate_vertex_map(staged ? r->in_prep : d_depths[i], pts, r->w, r->h, r->fx, r->fy, r->w, r->h, r->s_prep));  // main.cpp:39
-    SVO_TRY(svoslam_transform_vertex_map_dmat(pts, fusion_ptr[i], npts, r->s_prep));                         // main.cpp:40-41
-    SVO_TRY(svoslam_point_cloud_bbox_device(r->ws[0], pts, npts, r->bbox, r->s_prep));                       // main.cpp:44
-    SVO_HIP(hipEventRecord(ev_bp[i], r->s_prep));
-    SVO_TRY(svoslam_svo_fuse_sort(ws, pts, npts, r->depth, r->center, r->edge, r->s_prep));
+    if (r->fused_front) {
+      // main.cpp:39-44 + computeKeys in one launch, no point cloud in memory (svoslam_svo_fuse_sort_frame), then the sort
+      SVO_TRY(svoslam_svo_fuse_sort_frame(ws, staged ? r->in_prep : d_depths[i], fusion_ptr[i], r->w, r->h, r->fx, r->fy, r->depth,
+                                          r->center, r->edge, r->bbox, r->s_prep));
+      SVO_HIP(hipEventRecord(ev_bp[i], r->s_prep));
+    } else {
+      SVO_TRY(svoslam_generate_vertex_map(staged ? r->in_prep : d_depths[i], pts, r->w, r->h, r->fx, r->fy, r->w, r->h, r->s_prep));  // main.cpp:39
+      SVO_TRY(svoslam_transform_vertex_map_dmat(pts, fusion_ptr[i], npts, r->s_prep));                         // main.cpp:40-41
+      SVO_TRY(svoslam_point_cloud_bbox_device(r->ws[0], pts, npts, r->bbox, r->s_prep));                       // main.cpp:44
+      SVO_HIP(hipEventRecord(ev_bp[i], r->s_prep));
+      SVO_TRY(svoslam_svo_fuse_sort(ws, pts, npts, r->depth, r->center, r->edge, r->s_prep));
+    }
     if (plan_on_map) {  // the plan moves to the map stream (enqueue_commit): see there
       mark(i, 5, r->s_prep);
       SVO_HIP(hipEventRecord(ev_plan[i], r->s_prep));
@@ -416,6 +430,14 @@ int svoslam_runner_run_sharded(svoslam_runner *r, const uint16_t *const *d_depth
   if (n > 0 && (!d_deltas || !d_images)) return SVOSLAM_ERR_INVALID_ARG;
   return runner_run_impl(r, d_depths, d_rgbs, timestamps, views, n, nullptr, row_first, rows, d_steps, caller_stream, d_deltas,
                          delta_events, march, d_images);
+}
+
+// computePointCloudBoundingBox of the last frame enqueued (main.cpp:43): {min xyz, max xyz, any}.  Blocking.
+int svoslam_runner_bbox(svoslam_runner *r, float h_bbox7[7]) {
+  if (!r || !h_bbox7) return SVOSLAM_ERR_INVALID_ARG;
+  SVO_HIP(hipDeviceSynchronize());
+  SVO_HIP(hipMemcpy(h_bbox7, r->bbox, 7 * 4, hipMemcpyDeviceToHost));
+  return SVOSLAM_OK;
 }
 
 // diagnostic: milliseconds of the stage marks of the last call relative to its first mark, h_ms[frames][10] =

@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "radix_sort.hpp"
+#include "image_device.hpp"
 #include "pool_grid.hpp"
 #include "svo_build.hpp"
 #include "wave_rank.hpp"
@@ -65,6 +66,120 @@ __global__ __launch_bounds__(256) void compute_keys_kernel(const float *__restri
     }
   }
   keys[i] = morton;
+}
+
+// Keys for the packed sort (radix_sort.hip): word = key << idx_bits | point index, plus the first pass's digit histogram of
+// each 4096-element tile.  FROM_DEPTH: the whole front end of a frame's fusion in one launch -- generateVertexMap,
+// transformVertexMap by a device-resident pose, computePointCloudBoundingBox (main.cpp:39-44) and computeKeys, every
+// expression as in the stand-alone kernels (vertex_map_kernel, transform_kernel, bbox_partial_kernel, compute_keys_kernel)
+// -- without a point cloud in memory: 1.2 MB of depth in, 2.4 MB of keys out instead of 3 x 3.6 MB of points.
+struct FrameSource { const uint16_t *depth; const float *pose; int w, h; float fx, fy; };
+
+constexpr int kKeysThreads = 512, kKeysIPT = 4;  // == the packed sort's tile (radix_packed_tile(): checked by the host)
+template <bool FROM_DEPTH>
+__global__ __launch_bounds__(kKeysThreads) void keys_packed_kernel(const float *__restrict__ pts, FrameSource fs, int n, int depth, float cx0,
+                                                          float cy0, float cz0, float edge0, int idx_bits, int bits0,
+                                                          u64 *__restrict__ packed, u32 *__restrict__ tile_hist,
+                                                          float *__restrict__ bbox_partial, unsigned *__restrict__ bbox_ticket,
+                                                          float *__restrict__ bbox_out) {
+  __shared__ u32 hist[kPackedMaxBins];
+  __shared__ float sm[kKeysThreads / 64][7];
+  __shared__ int is_last;
+  const int bins = 1 << bits0;
+  for (int d = threadIdx.x; d < bins; d += kKeysThreads) hist[d] = 0;
+  __syncthreads();
+  const int tile_elems = kKeysThreads * kKeysIPT;
+  float m[16];
+  if (FROM_DEPTH) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) m[k] = fs.pose[k];
+  }
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  float cnt = 0;
+#pragma unroll
+  for (int r = 0; r < kKeysIPT; r++) {
+    const int i = blockIdx.x * tile_elems + r * kKeysThreads + (int)threadIdx.x;
+    if (i >= n) break;
+    float px, py, pz;
+    if (FROM_DEPTH) {
+      float vx, vy, vz;
+      vertex_from_depth(fs.depth[i], i % fs.w, i / fs.w, fs.w, fs.h, fs.fx, fs.fy, fs.w, fs.h, vx, vy, vz);
+      mat4_mul_point(m, vx, vy, vz, 1.0f, px, py, pz);
+      if (finitef_(px) && finitef_(pz)) {  // computePointCloudBoundingBox (image_kernels.cu:60-102, Q1)
+        lo[0] = fminf(px, lo[0]); lo[1] = fminf(py, lo[1]); lo[2] = fminf(pz, lo[2]);
+        hi[0] = fmaxf(px, hi[0]); hi[1] = fmaxf(py, hi[1]); hi[2] = fmaxf(pz, hi[2]);
+        cnt = 1;
+      }
+    } else {
+      px = pts[3 * (size_t)i]; py = pts[3 * (size_t)i + 1]; pz = pts[3 * (size_t)i + 2];
+    }
+    u64 morton = 1;
+    if (finitef_(px) && finitef_(pz)) {  // Q1 (svo.cu:38): x, z, z
+      float cx = cx0, cy = cy0, cz = cz0, edge = edge0;
+      for (int l = 0; l < depth; l++) {
+        const bool x = px > cx, y = py > cy, z = pz > cz;
+        morton = (morton << 3) + (u64)(x + 2 * y + 4 * z);
+        edge /= 2.0f;
+        cx += edge * (x ? 1 : -1);
+        cy += edge * (y ? 1 : -1);
+        cz += edge * (z ? 1 : -1);
+      }
+    }
+    packed[i] = (morton << idx_bits) | (u64)(unsigned)i;
+    atomicAdd(&hist[(u32)morton & ((u32)bins - 1u)], 1u);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < bins; d += kKeysThreads) tile_hist[(size_t)blockIdx.x * bins + d] = hist[d];
+  if (!FROM_DEPTH || !bbox_out) return;
+  // bounding box: workgroup partial, the last workgroup to arrive folds the partials (min / max: exact in any order).
+  // Partials travel as agent-scope (sc1) stores and loads on both sides; the ticket is taken after they have completed.
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      lo[k] = fminf(lo[k], __shfl_down(lo[k], o));
+      hi[k] = fmaxf(hi[k], __shfl_down(hi[k], o));
+    }
+    cnt = fmaxf(cnt, __shfl_down(cnt, o));
+  }
+  const unsigned wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < 3; k++) { sm[wave][k] = lo[k]; sm[wave][3 + k] = hi[k]; }
+    sm[wave][6] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kKeysThreads / 64; w++) {
+      for (int k = 0; k < 3; k++) { sm[0][k] = fminf(sm[0][k], sm[w][k]); sm[0][3 + k] = fmaxf(sm[0][3 + k], sm[w][3 + k]); }
+      sm[0][6] = fmaxf(sm[0][6], sm[w][6]);
+    }
+    for (int k = 0; k < 7; k++)
+      __hip_atomic_store(&bbox_partial[blockIdx.x * 7 + k], sm[0][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(bbox_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = t == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last || threadIdx.x >= 64) return;
+  float r[7] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY, 0};
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += 64) {
+    float v[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) v[k] = __hip_atomic_load(&bbox_partial[b * 7 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { r[k] = fminf(r[k], v[k]); r[3 + k] = fmaxf(r[3 + k], v[3 + k]); }
+    r[6] = fmaxf(r[6], v[6]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { r[k] = fminf(r[k], __shfl_down(r[k], o)); r[3 + k] = fmaxf(r[3 + k], __shfl_down(r[3 + k], o)); }
+    r[6] = fmaxf(r[6], __shfl_down(r[6], o));
+  }
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < 7; k++) bbox_out[k] = r[k];
+    __hip_atomic_store(bbox_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  }
 }
 
 // ----------------------------------------------------------------------------
@@ -1069,9 +1184,20 @@ static int64_t max_records(int n, int depth) {
 // A caller that renders between fusions can run sort + plan of frame k+1 on another stream while frame
 // k is ray-marched (the pool is only read), and commit when the render is done; results are those of
 // the one-call form.  Phases of one fusion share one workspace; concurrent fusions need their own.
-int svo_fuse_sort(svoslam_workspace *ws, const float *d_points, int n, int depth, const float center[3], float edge,
-                  hipStream_t stream) {
-  if (!ws || n < 0 || (n > 0 && !d_points)) return SVOSLAM_ERR_INVALID_ARG;
+static int packed_idx_bits(int n) {
+  int b = 1;
+  while ((1ll << b) < (long long)n) b++;
+  return b;
+}
+// SVOSLAM_SORT_PAIRS=1: the (key, index) pair sort of round 1 for every fusion (A/B measurements, tests)
+static bool sort_pairs_forced() {
+  static const bool on = [] { const char *e = getenv("SVOSLAM_SORT_PAIRS"); return e && e[0] == '1'; }();
+  return on;
+}
+
+// keys + sort of one batch: from a point array (fs == nullptr) or straight from a depth image and a device-resident pose
+static int fuse_sort_impl(svoslam_workspace *ws, const float *d_points, const FrameSource *fs, int n, int depth, const float center[3],
+                          float edge, float *d_bbox7, hipStream_t stream) {
   if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
   ws->sorted_keys = nullptr; ws->sorted_idx = nullptr; ws->planned_n = -1;
   if (n == 0) return SVOSLAM_OK;
@@ -1081,20 +1207,73 @@ int svo_fuse_sort(svoslam_workspace *ws, const float *d_points, int n, int depth
   SVO_TRY(ws->rec_key.reserve((size_t)rmax * 8));
   SVO_TRY(ws->rec_front.reserve((size_t)rmax * 4));
   SVO_TRY(ws->rec_pass.reserve((size_t)rmax));
+  const int key_bits = 3 * depth + 1, idx_bits = packed_idx_bits(n);
+  const bool packed = key_bits + idx_bits <= 64 && !sort_pairs_forced();
+  if (!packed && fs) return SVOSLAM_ERR_INVALID_ARG;  // (callers fall back to the stand-alone kernels + svo_fuse_sort)
+  const int tiles = radix_packed_tiles(n);
+  if (radix_packed_tile() != kKeysThreads * kKeysIPT) return SVOSLAM_ERR_INVALID_ARG;  // the first histogram is per sort tile
+  unsigned *ticket = nullptr;
+  float *partial = nullptr;
+  if (packed) {
+    SVO_TRY(ws->tile_hist.reserve(radix_packed_hist_words(n) * 4));
+    if (fs && d_bbox7) {
+      const size_t need = (size_t)(8 + 7 * (size_t)tiles) * 4;
+      if (need > ws->frame_bbox.bytes) {
+        SVO_TRY(ws->frame_bbox.reserve(need));
+        SVO_HIP(hipMemset(ws->frame_bbox.ptr, 0, ws->frame_bbox.bytes));  // the ticket starts at zero (blocking; once per size)
+      }
+      ticket = ws->frame_bbox.as<unsigned>();
+      partial = ws->frame_bbox.as<float>() + 8;
+    }
+  }
   u64 *skey = nullptr; u32 *sidx = nullptr;
   auto enqueue = [&]() -> int {
-    compute_keys_kernel<3><<<cdiv(n, 256), 256, 0, stream>>>(d_points, n, depth, center[0], center[1], center[2], edge, ws->keys_a.as<u64>());
-    SVO_TRY(radix_sort_pairs(ws, n, 3 * depth + 1, stream, &skey, &sidx));
+    if (packed) {
+      const int bits0 = radix_packed_first_bits(key_bits);
+      if (fs)
+        keys_packed_kernel<true><<<tiles, kKeysThreads, 0, stream>>>(nullptr, *fs, n, depth, center[0], center[1], center[2], edge, idx_bits, bits0,
+                                                            ws->keys_a.as<u64>(), ws->tile_hist.as<u32>(), partial, ticket, d_bbox7);
+      else
+        keys_packed_kernel<false><<<tiles, kKeysThreads, 0, stream>>>(d_points, FrameSource{}, n, depth, center[0], center[1], center[2], edge,
+                                                             idx_bits, bits0, ws->keys_a.as<u64>(), ws->tile_hist.as<u32>(), nullptr,
+                                                             nullptr, nullptr);
+      SVO_TRY(radix_sort_packed(ws, n, key_bits, idx_bits, stream, &skey, &sidx));
+    } else {
+      compute_keys_kernel<3><<<cdiv(n, 256), 256, 0, stream>>>(d_points, n, depth, center[0], center[1], center[2], edge, ws->keys_a.as<u64>());
+      SVO_TRY(radix_sort_pairs(ws, n, key_bits, stream, &skey, &sidx));
+    }
     SVO_LAUNCH_CHECK();
     return SVOSLAM_OK;
   };
   GraphKey key;
-  key.add(d_points).add((unsigned long long)n).add((unsigned long long)depth).addf(center[0]).addf(center[1]).addf(center[2])
-     .addf(edge).add(ws->layout_hash());
+  key.add(fs ? (const void *)fs->depth : (const void *)d_points).add((unsigned long long)n).add((unsigned long long)depth)
+     .addf(center[0]).addf(center[1]).addf(center[2]).addf(edge).add(ws->layout_hash()).add(fs ? fs->pose : nullptr).add(d_bbox7)
+     .add(ws->frame_bbox.ptr);
   SVO_TRY(ws->g_sort.run(key, stream, enqueue));
-  if (!skey) SVO_TRY(radix_sort_output(ws, n, 3 * depth + 1, &skey, &sidx));  // replayed: where the recorded sort leaves its result
+  if (!skey) {  // replayed: where the recorded sort leaves its result
+    if (packed) SVO_TRY(radix_sort_packed_output(ws, key_bits, &skey, &sidx));
+    else SVO_TRY(radix_sort_output(ws, n, key_bits, &skey, &sidx));
+  }
   ws->sorted_keys = skey; ws->sorted_idx = sidx;
   return SVOSLAM_OK;
+}
+
+int svo_fuse_sort(svoslam_workspace *ws, const float *d_points, int n, int depth, const float center[3], float edge,
+                  hipStream_t stream) {
+  if (!ws || n < 0 || (n > 0 && !d_points)) return SVOSLAM_ERR_INVALID_ARG;
+  return fuse_sort_impl(ws, d_points, nullptr, n, depth, center, edge, nullptr, stream);
+}
+
+// The sort phase fed by a raw depth image: generateVertexMap + transformVertexMap(d_pose) + computePointCloudBoundingBox
+// + computeKeys (main.cpp:39-44, svo.cu:33-66) in one launch, no point cloud in memory, then the sort.  d_bbox7 (optional):
+// {min xyz, max xyz, any} as svoslam_point_cloud_bbox_device writes it.  Needs 3 depth + 1 + ceil(log2(w h)) <= 64
+// (SVOSLAM_ERR_INVALID_ARG otherwise: use the stand-alone calls).
+int svo_fuse_sort_frame(svoslam_workspace *ws, const uint16_t *d_depth, const float *d_pose, int w, int h, float fx, float fy, int depth,
+                        const float center[3], float edge, float *d_bbox7, hipStream_t stream) {
+  if (!ws || !d_depth || !d_pose || w <= 0 || h <= 0 || (long long)w * h > 0x7FFFFFFFll) return SVOSLAM_ERR_INVALID_ARG;
+  FrameSource fs;
+  fs.depth = d_depth; fs.pose = d_pose; fs.w = w; fs.h = h; fs.fx = fx; fs.fy = fy;
+  return fuse_sort_impl(ws, nullptr, &fs, w * h, depth, center, edge, d_bbox7, stream);
 }
 
 int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream) {

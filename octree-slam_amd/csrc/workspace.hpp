@@ -53,6 +53,7 @@ struct svoslam_workspace {
   svoslam::DeviceBuffer bfs_a, bfs_b, bfs_mask, bfs_ptr;  // extraction
   svoslam::DeviceBuffer misc;                             // bbox partials etc.
   svoslam::DeviceBuffer scan_tmp;                         // chunk sums of exclusive_scan_u32
+  svoslam::DeviceBuffer frame_bbox;                       // fused fusion front end: arrival ticket (word 0) + workgroup bounding boxes
   svoslam::PlanCounts *h_counts = nullptr;                // pinned host
   // phased fusion (svo_fuse_sort -> plan -> commit): where the sort left its output, what has been planned
   const unsigned long long *sorted_keys = nullptr;
@@ -72,7 +73,7 @@ struct svoslam_workspace {
     keys_a.release(); keys_b.release(); vals_a.release(); vals_b.release(); tile_hist.release(); small.release();
     leaf_t.release(); leaf_f.release(); rec_key.release(); rec_front.release(); path_nodes.release(); strad.release(); strad_b.release();
     rec_pass.release(); apply_nodes.release();
-    bfs_a.release(); bfs_b.release(); bfs_mask.release(); bfs_ptr.release(); misc.release(); scan_tmp.release();
+    bfs_a.release(); bfs_b.release(); bfs_mask.release(); bfs_ptr.release(); misc.release(); scan_tmp.release(); frame_bbox.release();
     if (h_counts) { (void)hipHostFree(h_counts); h_counts = nullptr; }
     g_sort.clear(); g_plan.clear(); g_commit.clear();
   }

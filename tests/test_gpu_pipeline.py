@@ -221,6 +221,9 @@ def test_native_runner_equals_sequential(env, capacity, band):
         assert np.array_equal(A.cam.pose()[0], B.cam.pose()[0]) and np.array_equal(A.cam.pose()[1], B.cam.pose()[1])
         if band is None:
             assert A.counters.tolist() == B.counters.tolist()
+        # computePointCloudBoundingBox of the last frame: the runner's fused front end (svoslam_svo_fuse_sort_frame)
+        # against the stand-alone kernel of the sequential loop
+        assert np.array_equal(B._runner.bbox(), A.bbox.cpu().numpy()) and B._runner.bbox()[6] == 1.0
     os.environ["SVOSLAM_PY_SCHEDULER"] = "1"
     try:
         C_ = pl.SlamPipeline(w, h, depth, center, edge)
