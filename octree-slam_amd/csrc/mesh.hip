@@ -307,7 +307,7 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   SVO_TRY(dx.reserve((size_t)(tw * th > 0 ? tw * th : 1) * 12));
   if (tw * th > 0) SVO_HIP(hipMemcpyAsync(dx.ptr, tex->data, (size_t)tw * th * 12, hipMemcpyHostToDevice, stream));
   // scanlines per triangle -> exclusive scan
-  SVO_TRY(ws->small.reserve(4096));
+  SVO_TRY(ws->reserve_small());
   SVO_TRY(ws->leaf_f.reserve((size_t)n_tris * 4));
   u32 *tri_start = ws->leaf_f.as<u32>();
   u32 *d_total = ws->small.as<u32>();

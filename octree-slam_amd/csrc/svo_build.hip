@@ -227,14 +227,18 @@ __device__ inline void record_range(int t, int c, int depth, int &lo, int &hi) {
 
 __device__ inline u32 bucket_id(int p, int d) { return (u32)(p * 16 + (d - 1)); }
 
-__global__ __launch_bounds__(256) void plan_count_kernel(const u64 *__restrict__ skey, int n, int depth,
-                                                         const u32 *__restrict__ pool, unsigned char *__restrict__ leaf_t,
-                                                         u32 *__restrict__ leaf_f, u32 *__restrict__ tile_hist,
-                                                         int num_tiles, int *__restrict__ any_valid) {
+// Plan tiles are 512 sorted keys (8 wavefronts): half the [bucket][tile] counters of 256-key tiles to write,
+// scan and read back.  (1024-thread workgroups were measured 3x slower in the frame loop -- plan_emit 17 -> 57 us: next to the
+// march and the tracker a 16-wavefront workgroup rarely finds a CU with room for all of it.)
+constexpr int kPlanThreads = 512, kPlanWaves = kPlanThreads / 64;
+__global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(const u64 *__restrict__ skey, int n, int depth,
+                                                                  const u32 *__restrict__ pool, unsigned char *__restrict__ leaf_t,
+                                                                  u32 *__restrict__ leaf_f, u32 *__restrict__ tile_hist,
+                                                                  int num_tiles, int *__restrict__ any_valid) {
   __shared__ u32 hist[256];
-  hist[threadIdx.x] = 0;
+  if (threadIdx.x < 256) hist[threadIdx.x] = 0;
   __syncthreads();
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.x * kPlanThreads + threadIdx.x;
   if (j < n) {
     u64 key; int c = 0;
     if (is_head(skey, j, key, c, depth)) {
@@ -251,35 +255,66 @@ __global__ __launch_bounds__(256) void plan_count_kernel(const u64 *__restrict__
     }
   }
   __syncthreads();
-  tile_hist[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];
+  if (threadIdx.x < 256) tile_hist[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];
 }
 
-// bucket totals -> bucket bases in reference order (pass major, depth minor), pass ranges
-__global__ __launch_bounds__(256) void plan_finish_kernel(const u32 *__restrict__ totals, u32 *__restrict__ bucket_base,
-                                                          PlanCounts *__restrict__ counts, const int *__restrict__ any_valid) {
+// Row scan of the [bucket][tile] counters (one workgroup per bucket, as row_scan_kernel) and, in the LAST workgroup to
+// arrive, what plan_finish_kernel did in a launch of its own: bucket totals -> bucket bases in reference order (pass
+// major, depth minor), pass ranges, any_valid (consumed and cleared for the next plan: no memset launch either).  The
+// totals cross workgroups as agent-scope stores / loads on both sides, the ticket is taken after they have completed.
+__global__ __launch_bounds__(256) void plan_scan_finish_kernel(u32 *__restrict__ rows, int num_tiles, u32 *__restrict__ totals,
+                                                               unsigned *__restrict__ ticket, u32 *__restrict__ bucket_base,
+                                                               PlanCounts *__restrict__ counts, int *__restrict__ any_valid) {
   __shared__ u32 tmp[4];
   __shared__ u32 sbase[257];
+  __shared__ int is_last;
+  u32 *row = rows + (size_t)blockIdx.x * num_tiles;
+  u32 carry = 0;
+  for (int base = 0; base < num_tiles; base += 256) {
+    const int i = base + threadIdx.x;
+    const u32 v = i < num_tiles ? row[i] : 0u;
+    u32 total;
+    const u32 ex = block256_exclusive_scan(v, tmp, total);
+    if (i < num_tiles) row[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&totals[blockIdx.x], carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = t == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  const u32 mine = __hip_atomic_load(&totals[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   u32 total;
-  const u32 ex = block256_exclusive_scan(totals[threadIdx.x], tmp, total);
+  const u32 ex = block256_exclusive_scan(mine, tmp, total);
   bucket_base[threadIdx.x] = ex;
   sbase[threadIdx.x] = ex;
   if (threadIdx.x == 0) { sbase[256] = total; bucket_base[256] = total; }
   __syncthreads();
   if (threadIdx.x <= 16) counts->pass_start[threadIdx.x] = (int32_t)sbase[threadIdx.x * 16];
-  if (threadIdx.x == 17) { counts->pass_start[17] = (int32_t)total; counts->total_records = (int32_t)total; counts->any_valid = *any_valid; }
+  if (threadIdx.x == 17) {
+    counts->pass_start[17] = (int32_t)total; counts->total_records = (int32_t)total;
+    counts->any_valid = *any_valid;
+    *any_valid = 0;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(256) void plan_emit_kernel(const u64 *__restrict__ skey, int n, int depth,
+__global__ __launch_bounds__(kPlanThreads) void plan_emit_kernel(const u64 *__restrict__ skey, int n, int depth,
                                                         const unsigned char *__restrict__ leaf_t,
                                                         const u32 *__restrict__ leaf_f, const u32 *__restrict__ bucket_base,
                                                         const u32 *__restrict__ row_prefix, int num_tiles,
                                                         u64 *__restrict__ rec_key, u32 *__restrict__ rec_front,
                                                         unsigned char *__restrict__ rec_pass) {
-  __shared__ u32 cnt[4][256];
+  __shared__ u32 cnt[kPlanWaves][256];
+  if (threadIdx.x < 256) {
 #pragma unroll
-  for (int w = 0; w < 4; w++) cnt[w][threadIdx.x] = 0;
+    for (int w = 0; w < kPlanWaves; w++) cnt[w][threadIdx.x] = 0;
+  }
   __syncthreads();
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.x * kPlanThreads + threadIdx.x;
   const unsigned wave = threadIdx.x >> 6;
   const unsigned long long lt = lanemask_lt();
   u64 key = 1; int c = 0, t = kNotHead, lo = 1, hi = 0; u32 f = 0;
@@ -301,10 +336,10 @@ __global__ __launch_bounds__(256) void plan_emit_kernel(const u64 *__restrict__ 
     if (valid && (peers & lt) == 0) cnt[wave][b] = (u32)__popcll(peers);
   }
   __syncthreads();
-  {
+  if (threadIdx.x < 256) {
     u32 run = 0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) { const u32 v = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = run; run += v; }
+    for (int w = 0; w < kPlanWaves; w++) { const u32 v = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = run; run += v; }
   }
   __syncthreads();
   // phase B: emit records at their reference rank
@@ -1092,7 +1127,7 @@ static int reserve_common(svoslam_workspace *ws, int n, int depth) {
   SVO_TRY(ws->vals_b.reserve(nn * 4));
   const size_t tiles = (size_t)cdiv(n, 256) + 1;
   SVO_TRY(ws->tile_hist.reserve(256 * tiles * 4));
-  SVO_TRY(ws->small.reserve(4096));
+  SVO_TRY(ws->reserve_small());  // (zeroed when created: any_valid and the plan's arrival ticket start at zero)
   SVO_TRY(ws->leaf_t.reserve(nn));
   SVO_TRY(ws->leaf_f.reserve(nn * 4));
   SVO_TRY(ws->path_nodes.reserve(nn * 4 * (size_t)(depth > 1 ? depth - 1 : 1)));
@@ -1100,12 +1135,13 @@ static int reserve_common(svoslam_workspace *ws, int n, int depth) {
   return SVOSLAM_OK;
 }
 
-// layout of ws->small (u32 words): [0,256) totals | [256,513) bucket_base | [520..) PlanCounts | [640] any_valid | [648] n0
+// layout of ws->small (u32 words): [0,256) totals | [256,513) bucket_base | [520..) PlanCounts | [640] any_valid | [648] n0 | [656] plan ticket (any_valid and the ticket start at 0 and are left at 0 by every plan)
 static inline u32 *small_totals(svoslam_workspace *ws) { return ws->small.as<u32>(); }
 static inline u32 *small_bucket_base(svoslam_workspace *ws) { return ws->small.as<u32>() + 256; }
 static inline PlanCounts *small_counts(svoslam_workspace *ws) { return reinterpret_cast<PlanCounts *>(ws->small.as<u32>() + 520); }
 static inline int *small_any(svoslam_workspace *ws) { return reinterpret_cast<int *>(ws->small.as<u32>() + 640); }
 static inline u32 *small_n0(svoslam_workspace *ws) { return ws->small.as<u32>() + 648; }  // deferred commit: first new tile
+static inline unsigned *small_ticket(svoslam_workspace *ws) { return ws->small.as<u32>() + 656; }  // plan_scan_finish_kernel's arrival count
 
 // keys of the n inputs are in ws->keys_a
 static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, const void *d_colors, bool vec4,
@@ -1118,10 +1154,10 @@ static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *poo
   unsigned char *leaf_t = ws->leaf_t.as<unsigned char>();
   u32 *leaf_f = ws->leaf_f.as<u32>();
   u32 *tile_hist = ws->tile_hist.as<u32>();
-  SVO_HIP(hipMemsetAsync(small_any(ws), 0, 4, stream));
-  plan_count_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, tiles, small_any(ws));
-  row_scan_rows(tile_hist, tiles, small_totals(ws), stream);
-  plan_finish_kernel<<<1, 256, 0, stream>>>(small_totals(ws), small_bucket_base(ws), small_counts(ws), small_any(ws));
+  const int ptiles = (int)cdiv(n, kPlanThreads);
+  plan_count_kernel<<<ptiles, kPlanThreads, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, ptiles, small_any(ws));
+  plan_scan_finish_kernel<<<256, 256, 0, stream>>>(tile_hist, ptiles, small_totals(ws), small_ticket(ws), small_bucket_base(ws),
+                                                   small_counts(ws), small_any(ws));
   SVO_LAUNCH_CHECK();
   SVO_HIP(hipMemcpyAsync(ws->h_counts, small_counts(ws), sizeof(PlanCounts), hipMemcpyDeviceToHost, stream));
   SVO_HIP(hipStreamSynchronize(stream));  // the one host round trip of a fused frame
@@ -1138,7 +1174,7 @@ static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *poo
     SVO_TRY(ws->rec_front.reserve((size_t)total * 4));
     u64 *rec_key = ws->rec_key.as<u64>();
     u32 *rec_front = ws->rec_front.as<u32>();
-    plan_emit_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, tiles, rec_key, rec_front, nullptr);
+    plan_emit_kernel<<<ptiles, kPlanThreads, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, ptiles, rec_key, rec_front, nullptr);
     for (int p = 0; p <= SVOSLAM_MAX_DEPTH; p++) {  // expandTreeAtKeys, svo.cu:278-289
       const int begin = hc.pass_start[p], end = hc.pass_start[p + 1];
       if (end > begin)
@@ -1305,17 +1341,16 @@ int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, h
     }
   }
   const u64 *skey = ws->sorted_keys;
-  const int tiles = (int)cdiv(n, 256);
+  const int tiles = (int)cdiv(n, kPlanThreads);
   unsigned char *leaf_t = ws->leaf_t.as<unsigned char>();
   u32 *leaf_f = ws->leaf_f.as<u32>();
   u32 *tile_hist = ws->tile_hist.as<u32>();
-  auto enqueue = [&]() -> int {
-    SVO_HIP(hipMemsetAsync(small_any(ws), 0, 4, stream));
-    plan_count_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, tiles, small_any(ws));
-    row_scan_rows(tile_hist, tiles, small_totals(ws), stream);
-    plan_finish_kernel<<<1, 256, 0, stream>>>(small_totals(ws), small_bucket_base(ws), small_counts(ws), small_any(ws));
-    plan_emit_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, tiles,
-                                                ws->rec_key.as<u64>(), ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>());
+  auto enqueue = [&]() -> int {  // three launches (round 1: a memset and five)
+    plan_count_kernel<<<tiles, kPlanThreads, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, tiles, small_any(ws));
+    plan_scan_finish_kernel<<<256, 256, 0, stream>>>(tile_hist, tiles, small_totals(ws), small_ticket(ws), small_bucket_base(ws),
+                                                     small_counts(ws), small_any(ws));
+    plan_emit_kernel<<<tiles, kPlanThreads, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, tiles,
+                                                         ws->rec_key.as<u64>(), ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>());
     SVO_LAUNCH_CHECK();
     return SVOSLAM_OK;
   };
@@ -1563,7 +1598,7 @@ int extract_voxel_grid(svoslam_workspace *ws, const svoslam_pool *pool, int dept
   *d_centers = nullptr; *d_colors = nullptr; *n_out = 0;
   if (pool->size == 0) return SVOSLAM_OK;
   if (pool->pending > 0) SVO_HIP(hipStreamSynchronize(stream));  // (size itself is not needed by the BFS)
-  SVO_TRY(ws->small.reserve(4096));
+  SVO_TRY(ws->reserve_small());  // (zeroed when created: any_valid and the plan's arrival ticket start at zero)
   SVO_TRY(ws->bfs_a.reserve(8));
   const u64 one = 1;
   SVO_HIP(hipMemcpyAsync(ws->bfs_a.ptr, &one, 8, hipMemcpyHostToDevice, stream));

@@ -61,6 +61,14 @@ struct svoslam_workspace {
   int planned_n = -1;
   const void *planned_pool = nullptr;                      // the pool svo_fuse_plan read (its reservation is already booked)
   svoslam::GraphCache g_sort, g_plan, g_commit;            // recorded launch sequences of the three phases
+  // `small` (4 KB of totals / bases / counters) is zeroed when it is created: the planner's any_valid word and arrival
+  // ticket must start at zero (every plan leaves them at zero).  Blocking, once per workspace.
+  int reserve_small() {
+    if (small.bytes >= 4096) return SVOSLAM_OK;
+    SVO_TRY(small.reserve(4096));
+    SVO_HIP(hipMemset(small.ptr, 0, small.bytes));
+    return SVOSLAM_OK;
+  }
   // every buffer address the recorded phases bake in (a reallocation makes a new key)
   unsigned long long layout_hash() const {
     const void *p[] = {keys_a.ptr, keys_b.ptr, vals_a.ptr, vals_b.ptr, tile_hist.ptr, small.ptr, leaf_t.ptr, leaf_f.ptr,
