@@ -172,6 +172,11 @@ int svoslam_svo_fuse_sort_frame(svoslam_workspace *ws, const uint16_t *d_depth, 
 int svoslam_svo_fuse_plan(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream);
 int svoslam_svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int32_t n, int32_t max_depth,
                             svoslam_pool *pool, void *stream);
+/* Optional, between plan and commit (same workspace, same pool, direct commit only): initialises the child tiles of the
+ * planned splits (splitNodes' tile writes, svo.cu:239-276) beyond the pool's present size -- nothing a ray march of the pool
+ * can reach -- so that it may run WHILE the previous frame is still being rendered; the commit then writes the links from
+ * its leaf kernel and runs two launches instead of three.  Same pool contents as without the call. */
+int svoslam_svo_fuse_split_early(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream);
 /* The planned commit applied to one of several BYTE-IDENTICAL replicas of a map (a plan made against any replica in
  * the state before this commit fits all of them: same tree, same tile numbering).  Each application uses its own
  * slot (0 or 1; applications with different slots may run concurrently), all but the last pass keep_plan != 0.

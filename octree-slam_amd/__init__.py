@@ -90,6 +90,7 @@ SIGNATURES = {
     "svoslam_svo_fuse_sort_frame": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _i32, _fp, _f32, _vp, _vp]),
     "svoslam_svo_fuse_plan": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_commit": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
+    "svoslam_svo_fuse_split_early": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_commit_to": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _i32, _i32, _vp]),
     "svoslam_svo_fuse_commit_deferred": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_apply": (C.c_int, [_vp, C.POINTER(_PoolStruct), _vp]),
@@ -391,6 +392,11 @@ def svo_fuse_sort_frame(ws, depth_image, pose_ptr, fx, fy, max_depth, center, ed
 def svo_fuse_plan(ws, n, max_depth, pool):
     """phase 2: split planning against the pool's current tree (reads the pool)."""
     check(lib().svoslam_svo_fuse_plan(ws._h, int(n), max_depth, C.byref(pool._p), _stream()))
+
+
+def svo_fuse_split_early(ws, n, max_depth, pool):
+    """between plan and commit: the planned splits' child tiles, written where no ray march can see them yet"""
+    check(lib().svoslam_svo_fuse_split_early(ws._h, int(n), int(max_depth), C.byref(pool._p), _stream()))
 
 
 def svo_fuse_commit(ws, colors, max_depth, pool):

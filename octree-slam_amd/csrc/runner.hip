@@ -63,6 +63,7 @@ struct svoslam_runner {
   hipStream_t last_caller = nullptr;
   int lead = 3;  // commits the host may run ahead of the device (see svoslam_runner_run)
   bool fused_front = false;  // back-projection + bounding box + keys in one launch (SVOSLAM_RUNNER_FUSED_FRONT=0: the four stand-alone calls)
+  bool early_split = true;  // SVOSLAM_RUNNER_EARLY_SPLIT=0: split_all_kernel inside the commit
   bool deferred = false;  // SVOSLAM_RUNNER_DEFERRED=1 (one replica): the commit of frame k+1 is computed during the march of frame k
   bool ran = false;
   // SVOSLAM_RUNNER_TIMELINE=1: timing events at the stage boundaries of the last call (svoslam_runner_timeline)
@@ -116,6 +117,8 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
     const char *ff = getenv("SVOSLAM_RUNNER_FUSED_FRONT"), *sp = getenv("SVOSLAM_SORT_PAIRS");
     r->fused_front = 3 * max_depth + 1 + idx_bits <= 64 && !(ff && ff[0] == '0') && !(sp && sp[0] == '1');
   }
+  const char *es = getenv("SVOSLAM_RUNNER_EARLY_SPLIT");
+  r->early_split = !(es && es[0] == '0');
   const char *ld = getenv("SVOSLAM_RUNNER_LEAD");
   if (ld) r->lead = atoi(ld) < 0 ? 0 : atoi(ld);
   *out = r;
@@ -308,6 +311,9 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
       SVO_HIP(hipDeviceSynchronize());
       SVO_TRY(svoslam_pool_reserve(other, planned->capacity, r->s_prep));
     }
+    // the child tiles of this frame's splits, beyond the pool's size, while the previous frame is still being marched:
+    // the commit on the map stream -- the stream that bounds the frame -- is then two launches instead of three
+    if (R == 1 && !r->deferred && r->early_split) SVO_TRY(svoslam_svo_fuse_split_early(ws, npts, r->depth, planned, r->s_prep));
     SVO_HIP(hipEventRecord(ev_plan[i], r->s_prep));
     mark(i, 6, r->s_prep);
     return SVOSLAM_OK;

@@ -307,7 +307,9 @@ __global__ __launch_bounds__(kPlanThreads) void plan_emit_kernel(const u64 *__re
                                                         const u32 *__restrict__ leaf_f, const u32 *__restrict__ bucket_base,
                                                         const u32 *__restrict__ row_prefix, int num_tiles,
                                                         u64 *__restrict__ rec_key, u32 *__restrict__ rec_front,
-                                                        unsigned char *__restrict__ rec_pass) {
+                                                        unsigned char *__restrict__ rec_pass, u32 *__restrict__ leaf_rec0) {
+  // leaf_rec0 (optional): for the head that owns the pass-0 record of its frontier node, that record's rank (what
+  // svo_fuse_split_early's commit needs to find the node's new child tile without a search)
   __shared__ u32 cnt[kPlanWaves][256];
   if (threadIdx.x < 256) {
 #pragma unroll
@@ -355,6 +357,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_emit_kernel(const u64 *__re
       rec_key[pos] = key >> (3 * (depth - d));  // prefix key with its leading 1
       rec_front[pos] = f;
       if (rec_pass) rec_pass[pos] = (unsigned char)(d - t);
+      if (leaf_rec0 && d == t) leaf_rec0[j] = pos;
     }
   }
 }
@@ -582,7 +585,9 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
                                                              u32 *__restrict__ strad, int num_tiles, u32 *__restrict__ grid_dirty,
                                                              unsigned long long *__restrict__ shadow, u32 epoch,
                                                              u32 *__restrict__ apply_nodes, const u64 *__restrict__ rec_key,
-                                                             const u32 *__restrict__ bucket_base, const u32 *__restrict__ n0_saved) {
+                                                             const u32 *__restrict__ bucket_base, const u32 *__restrict__ n0_saved,
+                                                             const u32 *__restrict__ leaf_rec0) {
+  const bool early_links = leaf_rec0 != nullptr;
   // shadow != nullptr: deferred commit.  Every colour word goes to shadow[node] instead of the pool, children are read
   // through average_tile_deferred, and apply_nodes[(level - 1) * n + j] names the node lane j wrote at that level
   // (level `depth` = the leaf; kNoStraddler = none) for commit_apply_kernel.  The link from the key's frontier node
@@ -607,6 +612,13 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   const u64 key_n = jn < n ? skey[jn] : 1ull, key_np = jn < n ? skey[jn - 1] : 1ull;
   const u32 point = j < n ? sidx[j] : 0u;
   const bool head = lt != kNotHead;
+  // early links: rank of the pass-0 record of this key's frontier node, known to the head that owns the record (the first
+  // under that node); requested with the other setup loads, handed to the heads that follow below
+  u32 rec0 = 0;
+  if (early_links && head && lt != kNoSplit) {
+    const int cc = (key_p == 1ull) ? 0 : common_levels(key_j, key_p, depth);
+    if (cc < (int)lt) rec0 = leaf_rec0[j];
+  }
   u64 key = 1; int c = 0;
   if (head) { key = key_j; c = (key_p == 1ull) ? 0 : common_levels(key_j, key_p, depth); }  // is_head() on the values in hand
   // level grid of the ray march (pool_grid.hpp): everything this key changes lies below its level-5 prefix; the first
@@ -643,18 +655,57 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
     next_c = (key_np == 1ull) ? 0 : common_levels(key_n, key_np, depth);
   }
   FILL_STAMP(1)
-  int frontier = 0;       // level whose link is deferred (0: none)
+  // early_links != 0: the child tiles of this commit were initialised ahead of it (svo_fuse_split_early: split_all_kernel
+  // without its links, while the previous frame was still being ray-marched); the links of the pass-0 records -- the only
+  // words of the split a ray march can see -- are written HERE, by the first head under each frontier node, and the walk
+  // below takes the frontier's child tile from the record's rank like a deferred commit does.
+  int frontier = 0;       // level whose link is not in the pool yet (0: none)
+  int link_level = 0;     // early_links: level of the frontier node whose link this lane writes (0: none)
   u32 frontier_child = 0;
-  if (shadow && head && lt != kNoSplit && (int)lt < depth) {
-    frontier = (int)lt;
-    const u64 prefix = key >> (3 * (depth - frontier));
-    const u32 b = bucket_id(0, frontier);
-    u32 lo = bucket_base[b], hi = bucket_base[b + 1];
-    while (lo < hi) {  // the record exists: every head's path is split down to depth - 1
-      const u32 mid = (lo + hi) >> 1;
-      if (rec_key[mid] < prefix) lo = mid + 1; else hi = mid;
+  // The heads under one frontier node are consecutive heads that all stop at it (the node has no children, so every key
+  // through it has the same leaf_t), and the first of them owns its record: a head's record is that of the NEAREST owner
+  // at or before it.  Within a wavefront by ballot + shuffle, across wavefronts through LDS; a run that began in an
+  // earlier workgroup falls back to the search by key.
+  bool have_rec0 = false;
+  if (early_links) {
+    __shared__ u32 wave_rec0[kFillThreads / 64];
+    __shared__ int wave_has[kFillThreads / 64];
+    const bool towner = head && lt != kNoSplit && c < (int)lt;
+    const unsigned lane = (unsigned)tid & 63u, wv = (unsigned)tid >> 6;
+    const unsigned long long om = __ballot(towner);
+    const unsigned long long upto = om & ((lane == 63u) ? ~0ull : ((2ull << lane) - 1ull));
+    const int src = upto ? 63 - __clzll((long long)upto) : -1;
+    const u32 got = (u32)__shfl((int)rec0, src >= 0 ? src : 0);
+    const int last = om ? 63 - __clzll((long long)om) : 0;
+    const u32 lastv = (u32)__shfl((int)rec0, last);
+    if (lane == 0) { wave_has[wv] = om != 0ull; wave_rec0[wv] = lastv; }
+    __syncthreads();
+    if (src >= 0) { rec0 = got; have_rec0 = true; }
+    else {
+      for (int w = (int)wv - 1; w >= 0; w--)
+        if (wave_has[w]) { rec0 = wave_rec0[w]; have_rec0 = true; break; }
+    }
+  }
+  if ((shadow || early_links) && head && lt != kNoSplit && ((int)lt < depth || early_links)) {
+    const int ft = (int)lt;
+    const u64 prefix = key >> (3 * (depth - ft));
+    u32 lo = rec0;
+    if (!have_rec0) {
+      const u32 b = bucket_id(0, ft);
+      u32 hi = bucket_base[b + 1];
+      lo = bucket_base[b];
+      while (lo < hi) {  // the record exists: every head's path is split down to depth - 1 (and an octant-7 leaf gains children, Q4)
+        const u32 mid = (lo + hi) >> 1;
+        if (rec_key[mid] < prefix) lo = mid + 1; else hi = mid;
+      }
     }
     frontier_child = *n0_saved + 8u * lo;
+    if (ft < depth) frontier = ft;
+    if (early_links && c < ft) {  // this lane is the first head under the frontier node: it owns the pass-0 record
+      link_level = ft;            // (the node's index comes out of the walk below)
+      // level grid of the ray march: a split above the block level re-labels the whole cube of its node (as split_all_kernel marks it)
+      if (grid_dirty && ft < kPoolGridBlockLevel) pool_grid_mark(grid_dirty, prefix, ft);
+    }
   }
   // walk to the leaf (fillNodes, svo.cu:291-382), remembering the owned nodes and their child tiles
   u32 node_at[SVOSLAM_MAX_DEPTH], child_at[SVOSLAM_MAX_DEPTH];
@@ -669,6 +720,7 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
     for (int lvl = 1; lvl <= SVOSLAM_MAX_DEPTH; lvl++) {
       if (lvl <= depth) {
         node = base + ((u32)(key >> (3 * (depth - lvl))) & 7u);
+        if (lvl == link_level) pool[2 * (size_t)node] = kFlag + (frontier_child & kMask);
         if (lvl < depth) {
           base = pool[2 * (size_t)node] & kMask;
           if (lvl == frontier) base = frontier_child & kMask;
@@ -1174,7 +1226,7 @@ static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *poo
     SVO_TRY(ws->rec_front.reserve((size_t)total * 4));
     u64 *rec_key = ws->rec_key.as<u64>();
     u32 *rec_front = ws->rec_front.as<u32>();
-    plan_emit_kernel<<<ptiles, kPlanThreads, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, ptiles, rec_key, rec_front, nullptr);
+    plan_emit_kernel<<<ptiles, kPlanThreads, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, ptiles, rec_key, rec_front, nullptr, nullptr);
     for (int p = 0; p <= SVOSLAM_MAX_DEPTH; p++) {  // expandTreeAtKeys, svo.cu:278-289
       const int begin = hc.pass_start[p], end = hc.pass_start[p + 1];
       if (end > begin)
@@ -1243,6 +1295,7 @@ static int fuse_sort_impl(svoslam_workspace *ws, const float *d_points, const Fr
   SVO_TRY(ws->rec_key.reserve((size_t)rmax * 8));
   SVO_TRY(ws->rec_front.reserve((size_t)rmax * 4));
   SVO_TRY(ws->rec_pass.reserve((size_t)rmax));
+  SVO_TRY(ws->leaf_rec0.reserve((size_t)n * 4));
   const int key_bits = 3 * depth + 1, idx_bits = packed_idx_bits(n);
   const bool packed = key_bits + idx_bits <= 64 && !sort_pairs_forced();
   if (!packed && fs) return SVOSLAM_ERR_INVALID_ARG;  // (callers fall back to the stand-alone kernels + svo_fuse_sort)
@@ -1350,7 +1403,8 @@ int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, h
     plan_scan_finish_kernel<<<256, 256, 0, stream>>>(tile_hist, tiles, small_totals(ws), small_ticket(ws), small_bucket_base(ws),
                                                      small_counts(ws), small_any(ws));
     plan_emit_kernel<<<tiles, kPlanThreads, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, tiles,
-                                                         ws->rec_key.as<u64>(), ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>());
+                                                         ws->rec_key.as<u64>(), ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>(),
+                                                         ws->leaf_rec0.as<u32>());
     SVO_LAUNCH_CHECK();
     return SVOSLAM_OK;
   };
@@ -1367,6 +1421,27 @@ int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, h
 // one map (the frame scheduler ray-marches one replica while the next frame is committed to the other): the same plan
 // -- made against ANY of the replicas in the state before this commit -- is applied to each of them, every
 // application with its own slot (0 or 1: the scratch list of the mip pass) and all but the last with keep_plan.
+// The part of the next commit that no ray march can see, ahead of the commit: the child tiles of the planned splits are
+// initialised beyond the pool's present size (split_all_kernel without its links and without its level-grid marks) while the
+// previous frame is still being ray-marched.  The commit that follows on this workspace and pool then runs two launches
+// instead of three -- its leaf kernel writes the links -- which takes ~20 us off the stream that bounds the frame
+// (commit + march).  Same pool contents as the plain commit.  After svo_fuse_plan, before svo_fuse_commit, same pool.
+int svo_fuse_split_early(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream) {
+  if (!ws || !pool || n < 0) return SVOSLAM_ERR_INVALID_ARG;
+  if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
+  if (ws->planned_n != n || ws->planned_pool != pool || pool_shadow_pending(pool)) return SVOSLAM_ERR_INVALID_ARG;
+  ws->early_split_pool = nullptr;
+  if (n == 0) return SVOSLAM_OK;
+  int split_blocks = (int)cdiv(max_records(n, depth), 256);
+  if (split_blocks > 2048) split_blocks = 2048;
+  split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>(),
+                                                     small_bucket_base(ws), small_counts(ws), pool->d_data, pool->d_size, depth, nullptr,
+                                                     small_n0(ws));
+  SVO_LAUNCH_CHECK();
+  ws->early_split_pool = pool;
+  return SVOSLAM_OK;
+}
+
 static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, int slot,
                        bool keep_plan, bool deferred, hipStream_t stream) {
   if (!ws || !pool || n < 0 || (n > 0 && !d_colors) || slot < 0 || slot > 1) return SVOSLAM_ERR_INVALID_ARG;
@@ -1375,6 +1450,9 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   if (ws->planned_n != n) return SVOSLAM_ERR_INVALID_ARG;  // svo_fuse_plan has not run for this batch
   if (!keep_plan) ws->planned_n = -1;
   ws->deferred_pool = nullptr;
+  const bool early = ws->early_split_pool != nullptr;
+  if (early && (ws->early_split_pool != pool || deferred || keep_plan)) return SVOSLAM_ERR_INVALID_ARG;  // one pool, direct commit
+  ws->early_split_pool = nullptr;
   if (n == 0) {
     if (deferred) { ws->deferred_pool = pool; ws->deferred_n = 0; }
     return SVOSLAM_OK;
@@ -1409,12 +1487,13 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   }
   u32 *grid_dirty = pool_accel_dirty_bitmap(pool, deferred ? (int)(epoch & 1u) : 0);  // nullptr: not a registered pool
   auto enqueue = [&]() -> int {
-    split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
-                                                       ws->rec_pass.as<unsigned char>(), small_bucket_base(ws), small_counts(ws),
-                                                       pool->d_data, pool->d_size, depth, grid_dirty, deferred ? small_n0(ws) : nullptr);
+    if (!early)
+      split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
+                                                         ws->rec_pass.as<unsigned char>(), small_bucket_base(ws), small_counts(ws),
+                                                         pool->d_data, pool->d_size, depth, grid_dirty, deferred ? small_n0(ws) : nullptr);
     fill_mip_local_kernel<<<fill_tiles, kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
                                                                    grid_dirty, shadow, epoch, apply_nodes, ws->rec_key.as<u64>(),
-                                                                   small_bucket_base(ws), small_n0(ws));
+                                                                   small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr);
     mip_straddle_kernel<<<1, kStradThreads, 0, stream>>>(pool->d_data, strad, fill_tiles, depth, small_counts(ws), pool->d_size, grid_dirty,
                                                          trk ? trk->h_size : nullptr, trk ? trk->d_slot : nullptr, shadow, epoch);
     SVO_LAUNCH_CHECK();
@@ -1427,7 +1506,8 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   }
   GraphKey key;
   key.add(skey).add(d_colors).add((unsigned long long)n).add((unsigned long long)depth).add(pool->d_data).add(pool->d_size)
-     .add((unsigned long long)slot).add(grid_dirty).add(trk ? (const void *)trk->h_size : nullptr).add(ws->layout_hash());
+     .add((unsigned long long)slot).add(grid_dirty).add(trk ? (const void *)trk->h_size : nullptr).add(ws->layout_hash())
+     .add((unsigned long long)early);
   SVO_TRY(ws->g_commit.run(key, stream, enqueue));
   pool->pending += 1;
   return tracker_push(pool, 8 * rmax, stream);

@@ -294,3 +294,36 @@ def test_deferred_commit_then_apply_matches_oracle(env, oracle, depth, n, frames
         pkg.svo_fuse_apply(ws, pool)
         opool.insert_cloud(pts, col, depth, center, edge)
         assert_pools_equal(pool, opool)
+
+
+@pytest.mark.parametrize("depth,n,frames", [(1, 300, 3), (2, 500, 3), (6, 20000, 4), (10, 40000, 4), (12, 60000, 3), (16, 20000, 2)])
+def test_early_split_then_commit_matches_oracle(env, oracle, depth, n, frames):
+    """sort -> plan -> split_early -> commit: the splits' child tiles are written ahead of the commit (beyond the pool's
+    size), the commit's leaf kernel writes the links (Q4 links of octant-7 leaves included): same pool as the oracle;
+    and between split_early and commit the pool still renders / reads as before the commit"""
+    pkg, torch = env
+    rng = np.random.default_rng(900 + depth)
+    ws, pool = pkg.Workspace(), pkg.Pool(1 << 22)
+    opool = oracle.Pool()
+    center, edge = (0.05, -0.02, 0.01), 1.0
+    for f in range(frames):
+        pts, col = (surface_cloud(rng, n) if f % 2 == 0 else random_cloud(rng, n, nan_every=53, dup_frac=0.1))
+        pts = pts + np.float32(0.003 * f)
+        if f == frames - 1:
+            pts[: n // 4] = np.abs(pts[: n // 4])        # many keys ending in octant 7 paths (Q4 leaves gain children)
+        tp, tc = torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda()
+        pkg.svo_fuse_sort(ws, tp, depth, center, edge)
+        pkg.svo_fuse_plan(ws, n, depth, pool)
+        before = pool.words().copy() if f > 0 else None
+        pkg.svo_fuse_split_early(ws, n, depth, pool)
+        if before is not None:
+            torch.cuda.synchronize()
+            assert np.array_equal(pool.words(), before)   # nothing a reader of the pool can see has changed
+        pkg.svo_fuse_commit(ws, tc, depth, pool)
+        opool.insert_cloud(pts, col, depth, center, edge)
+        assert_pools_equal(pool, opool)
+    # a plain commit on the same workspace afterwards is not affected
+    pts, col = surface_cloud(rng, n)
+    pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, pool, center, edge)
+    opool.insert_cloud(pts, col, depth, center, edge)
+    assert_pools_equal(pool, opool)
