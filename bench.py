@@ -218,8 +218,11 @@ def main():
         for i in range(K):
             k = Wm + i
             P.track(depth[k], rgb[k], k)
-            P.backproject(depth[k])
-            P.fuse(rgb[k])
+            if dist is None:
+                P.fuse_frame(depth[k], rgb[k])     # the kernels of the frame loop (fused front end), one after the other
+            else:
+                P.backproject(depth[k])
+                P.fuse(rgb[k])
             P.render(views[k])
     else:
         # four HIP streams (pipeline.run_stream); every frame still goes through

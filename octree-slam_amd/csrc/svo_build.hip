@@ -227,6 +227,14 @@ __device__ inline void record_range(int t, int c, int depth, int &lo, int &hi) {
 
 __device__ inline u32 bucket_id(int p, int d) { return (u32)(p * 16 + (d - 1)); }
 
+// Workgroup id -> tile of the sorted key array.  MEASURED AND NOT USED (round 2): an XCD-aware mapping -- tile = (id % 8) *
+// ceil(tiles / 8) + id / 8, one contiguous eighth of the Morton-ordered keys, i.e. a compact part of the tree and of the
+// colour image, per XCD and L2 -- made plan_emit_kernel 21 -> 57 us and fill_mip_local_kernel 50 -> 60 us in the frame loop
+// (plan_count_kernel unchanged): the eight XCDs then stream into eight far-apart regions of the record arrays / the pool
+// in lockstep instead of interleaving finely over the memory channels.  The plain mapping stays; the hooks are kept.
+__host__ __device__ inline int xcd_grid(int tiles) { return tiles; }
+__device__ inline int xcd_tile(int tiles) { (void)tiles; return (int)blockIdx.x; }
+
 // Plan tiles are 512 sorted keys (8 wavefronts): half the [bucket][tile] counters of 256-key tiles to write,
 // scan and read back.  (1024-thread workgroups were measured 3x slower in the frame loop -- plan_emit 17 -> 57 us: next to the
 // march and the tracker a 16-wavefront workgroup rarely finds a CU with room for all of it.)
@@ -236,9 +244,11 @@ __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(const u64 *__r
                                                                   u32 *__restrict__ leaf_f, u32 *__restrict__ tile_hist,
                                                                   int num_tiles, int *__restrict__ any_valid) {
   __shared__ u32 hist[256];
+  const int tile = xcd_tile(num_tiles);
+  if (tile >= num_tiles) return;
   if (threadIdx.x < 256) hist[threadIdx.x] = 0;
   __syncthreads();
-  const int j = blockIdx.x * kPlanThreads + threadIdx.x;
+  const int j = tile * kPlanThreads + threadIdx.x;
   if (j < n) {
     u64 key; int c = 0;
     if (is_head(skey, j, key, c, depth)) {
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(const u64 *__r
     }
   }
   __syncthreads();
-  if (threadIdx.x < 256) tile_hist[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];
+  if (threadIdx.x < 256) tile_hist[(size_t)threadIdx.x * num_tiles + tile] = hist[threadIdx.x];
 }
 
 // Row scan of the [bucket][tile] counters (one workgroup per bucket, as row_scan_kernel) and, in the LAST workgroup to
@@ -311,12 +321,14 @@ __global__ __launch_bounds__(kPlanThreads) void plan_emit_kernel(const u64 *__re
   // leaf_rec0 (optional): for the head that owns the pass-0 record of its frontier node, that record's rank (what
   // svo_fuse_split_early's commit needs to find the node's new child tile without a search)
   __shared__ u32 cnt[kPlanWaves][256];
+  const int tile = xcd_tile(num_tiles);
+  if (tile >= num_tiles) return;
   if (threadIdx.x < 256) {
 #pragma unroll
     for (int w = 0; w < kPlanWaves; w++) cnt[w][threadIdx.x] = 0;
   }
   __syncthreads();
-  const int j = blockIdx.x * kPlanThreads + threadIdx.x;
+  const int j = tile * kPlanThreads + threadIdx.x;
   const unsigned wave = threadIdx.x >> 6;
   const unsigned long long lt = lanemask_lt();
   u64 key = 1; int c = 0, t = kNotHead, lo = 1, hi = 0; u32 f = 0;
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_emit_kernel(const u64 *__re
     const u32 b = bucket_id(d - t, d) & 255u;
     const unsigned long long peers = match_digit8(valid, b);
     if (valid) {
-      const u32 pos = bucket_base[b] + row_prefix[(size_t)b * num_tiles + blockIdx.x] + cnt[wave][b] +
+      const u32 pos = bucket_base[b] + row_prefix[(size_t)b * num_tiles + tile] + cnt[wave][b] +
                       (u32)__popcll(peers & lt);
       rec_key[pos] = key >> (3 * (depth - d));  // prefix key with its leading 1
       rec_front[pos] = f;
@@ -601,7 +613,9 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   unsigned long long stamp[8];
   FILL_STAMP(0)
 #endif
-  const int j = blockIdx.x * kFillThreads + tid;
+  const int bid = xcd_tile(num_tiles);  // this workgroup's tile of the sorted keys
+  if (bid >= num_tiles) return;
+  const int j = bid * kFillThreads + tid;
   // Everything the setup needs from memory is requested at once (one round trip instead of four in sequence): this
   // lane's key pair and point index, and the key pair of the lane at the same place in the next workgroup, one of
   // which is the first head after this workgroup (normally; the loop below covers a workgroup without any head).
@@ -627,8 +641,8 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   if (tid <= SVOSLAM_MAX_DEPTH) {
     last_owner[tid] = -1;
     if (tid >= 1 && tid < depth) {  // "no straddler" unless a lane says otherwise below
-      strad[2 * ((size_t)tid * num_tiles + blockIdx.x)] = kNoStraddler;
-      strad[2 * ((size_t)tid * num_tiles + blockIdx.x) + 1] = 0u;
+      strad[2 * ((size_t)tid * num_tiles + bid)] = kNoStraddler;
+      strad[2 * ((size_t)tid * num_tiles + bid) + 1] = 0u;
     }
   }
   if (tid == 0) { next_pos = 0x7FFFFFFF; next_c = -1; }  // no later head: every run ends with the array
@@ -638,7 +652,7 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   if (ltn != kNotHead) atomicMin(&next_pos, jn);
   __syncthreads();
   if (next_pos == 0x7FFFFFFF) {  // no head in the next workgroup (all duplicates / invalid points): look further
-    for (int nb = (int)blockIdx.x + 2; nb < (int)gridDim.x; nb++) {
+    for (int nb = bid + 2; nb < num_tiles; nb++) {
       const int jj = nb * kFillThreads + tid;
       if (jj < n && leaf_t[jj] != kNotHead) atomicMin(&next_pos, jj);
       __syncthreads();
@@ -752,8 +766,8 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
             pool[2 * (size_t)node_at[d] + 1] = average_tile(pool, child_at[d]);
           }
         } else {  // the run continues in a later workgroup
-          strad[2 * ((size_t)d * num_tiles + blockIdx.x)] = node_at[d];
-          strad[2 * ((size_t)d * num_tiles + blockIdx.x) + 1] = child_at[d];
+          strad[2 * ((size_t)d * num_tiles + bid)] = node_at[d];
+          strad[2 * ((size_t)d * num_tiles + bid) + 1] = child_at[d];
         }
       }
       if (shadow && j < n) apply_nodes[(size_t)(d - 1) * n + j] = wrote;
@@ -762,8 +776,8 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   }
 #ifdef SVO_FILL_PROF
   FILL_STAMP(5)
-  if (tid == 0 && (blockIdx.x % 37) == 0)
-    printf("fillprof wg %d of %d: start %llu setup %llu descent %llu leaf %llu sync %llu mip %llu (x10 ns)\n", (int)blockIdx.x, (int)gridDim.x,
+  if (tid == 0 && (bid % 37) == 0)
+    printf("fillprof wg %d of %d: start %llu setup %llu descent %llu leaf %llu sync %llu mip %llu (x10 ns)\n", bid, num_tiles,
            stamp[0] % 100000000ull, stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4]);
 #endif
 }
@@ -1207,7 +1221,7 @@ static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *poo
   u32 *leaf_f = ws->leaf_f.as<u32>();
   u32 *tile_hist = ws->tile_hist.as<u32>();
   const int ptiles = (int)cdiv(n, kPlanThreads);
-  plan_count_kernel<<<ptiles, kPlanThreads, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, ptiles, small_any(ws));
+  plan_count_kernel<<<xcd_grid(ptiles), kPlanThreads, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, ptiles, small_any(ws));
   plan_scan_finish_kernel<<<256, 256, 0, stream>>>(tile_hist, ptiles, small_totals(ws), small_ticket(ws), small_bucket_base(ws),
                                                    small_counts(ws), small_any(ws));
   SVO_LAUNCH_CHECK();
@@ -1226,7 +1240,7 @@ static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *poo
     SVO_TRY(ws->rec_front.reserve((size_t)total * 4));
     u64 *rec_key = ws->rec_key.as<u64>();
     u32 *rec_front = ws->rec_front.as<u32>();
-    plan_emit_kernel<<<ptiles, kPlanThreads, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, ptiles, rec_key, rec_front, nullptr, nullptr);
+    plan_emit_kernel<<<xcd_grid(ptiles), kPlanThreads, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, ptiles, rec_key, rec_front, nullptr, nullptr);
     for (int p = 0; p <= SVOSLAM_MAX_DEPTH; p++) {  // expandTreeAtKeys, svo.cu:278-289
       const int begin = hc.pass_start[p], end = hc.pass_start[p + 1];
       if (end > begin)
@@ -1399,10 +1413,10 @@ int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, h
   u32 *leaf_f = ws->leaf_f.as<u32>();
   u32 *tile_hist = ws->tile_hist.as<u32>();
   auto enqueue = [&]() -> int {  // three launches (round 1: a memset and five)
-    plan_count_kernel<<<tiles, kPlanThreads, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, tiles, small_any(ws));
+    plan_count_kernel<<<xcd_grid(tiles), kPlanThreads, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, tiles, small_any(ws));
     plan_scan_finish_kernel<<<256, 256, 0, stream>>>(tile_hist, tiles, small_totals(ws), small_ticket(ws), small_bucket_base(ws),
                                                      small_counts(ws), small_any(ws));
-    plan_emit_kernel<<<tiles, kPlanThreads, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, tiles,
+    plan_emit_kernel<<<xcd_grid(tiles), kPlanThreads, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, tiles,
                                                          ws->rec_key.as<u64>(), ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>(),
                                                          ws->leaf_rec0.as<u32>());
     SVO_LAUNCH_CHECK();
@@ -1491,7 +1505,7 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
       split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
                                                          ws->rec_pass.as<unsigned char>(), small_bucket_base(ws), small_counts(ws),
                                                          pool->d_data, pool->d_size, depth, grid_dirty, deferred ? small_n0(ws) : nullptr);
-    fill_mip_local_kernel<<<fill_tiles, kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
+    fill_mip_local_kernel<<<xcd_grid(fill_tiles), kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
                                                                    grid_dirty, shadow, epoch, apply_nodes, ws->rec_key.as<u64>(),
                                                                    small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr);
     mip_straddle_kernel<<<1, kStradThreads, 0, stream>>>(pool->d_data, strad, fill_tiles, depth, small_counts(ws), pool->d_size, grid_dirty,

@@ -228,6 +228,18 @@ class SlamPipeline:
                                        self.center, self.edge)
         return None
 
+    def fuse_frame(self, depth, rgb):
+        """backproject() + fuse() as the native frame loop runs them (csrc/runner.hip): back-projection, pose transform,
+        bounding box and keys in ONE launch straight from the depth image (no point cloud in memory), sort, plan, the
+        splits' tiles ahead of the commit, commit.  Same pool and bounding box as backproject() + fuse()."""
+        assert not self.band_exchange
+        n = self.w * self.h
+        pkg.svo_fuse_sort_frame(self.ws, depth, self.cam.fusion_transform_ptr(), self.focal, self.focal, self.depth, self.center,
+                                self.edge, self.bbox)
+        pkg.svo_fuse_plan(self.ws, n, self.depth, self.pool)
+        pkg.svo_fuse_split_early(self.ws, n, self.depth, self.pool)
+        pkg.svo_fuse_commit(self.ws, rgb.view(-1, 3), self.depth, self.pool)
+
     def render(self, view):
         if not self.dist.enabled:
             pkg.cone_trace_svo(self.image, FOV, view, self.pool.data_ptr, self.center, self.edge, self.mode, self.counters)

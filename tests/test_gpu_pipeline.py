@@ -276,3 +276,22 @@ print("RESULT" + json.dumps([sha(P.image.cpu().numpy()), sha(P.pool.words()), sh
     assert run({"SVOSLAM_RUNNER_DEFERRED": "1"}) == base
     assert run({"SVOSLAM_RUNNER_DEFERRED": "1", "SVOSLAM_RUNNER_LEAD": "0"}) == base
     assert base[3] > 8
+
+
+def test_fuse_frame_equals_backproject_plus_fuse(env):
+    """the frame loop's fusion in its sequential form (fused front end from the depth image, plan, early split, commit)
+    against back-projection into a point cloud + the one-call asynchronous fusion: pool, bounding box, image"""
+    pkg, torch, synth, pl = env
+    w, h, depth, center, edge = 320, 240, 10, (0.0, 1.5, 0.0), 4.096
+    A = pl.SlamPipeline(w, h, depth, center, edge)
+    B = pl.SlamPipeline(w, h, depth, center, edge)
+    for k in range(5):
+        d, c = synth.render_frame(k, w, h, device="cuda")
+        view = pl.ground_truth_view(k, synth)
+        ia = A.frame(d, c, k, view).cpu().numpy()
+        B.track(d, c, k)
+        B.fuse_frame(d, c)
+        ib = B.render(view).cpu().numpy()
+        assert np.array_equal(ia, ib), k
+        assert A.pool.size == B.pool.size and np.array_equal(A.pool.words(), B.pool.words()), k
+        assert np.array_equal(A.bbox.cpu().numpy(), B.bbox.cpu().numpy()) and float(B.bbox[6]) == 1.0

@@ -20,7 +20,14 @@ python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | line > 
 python $R/bench.py --steps 300 --warmup 5 --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_300frames.json
 python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --include-h2d 2>/dev/null | line > ${P}_bench_cfg3_include_h2d.json
 python $R/bench.py --workload cfg4 --steps 40 --warmup 5 2>/dev/null | line > ${P}_bench_cfg4.json
-SVOSLAM_FORCE_DIST=1 python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_forced_dist_none.json
+SVOSLAM_FORCE_DIST=1 python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --exchange none 2>/dev/null | line > ${P}_bench_cfg3_forced_dist_none.json
+SVOSLAM_FORCE_DIST=1 python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --exchange deltas 2>/dev/null | line > ${P}_bench_cfg3_forced_dist_deltas.json
+for e in 0/2 1/2 0/4 2/4 0/8 3/8 7/8; do
+  python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --emulate-rank $e 2>/dev/null | line > ${P}_bench_cfg3_emulated_rank_$(echo $e | sed "s#/#_of_#").json
+done
+for e in 0/2 0/8 3/8; do
+  python $R/bench.py --workload cfg4 --steps 40 --warmup 5 --no-cpu-baseline --emulate-rank $e 2>/dev/null | line > ${P}_bench_cfg4_emulated_rank_$(echo $e | sed "s#/#_of_#").json
+done
 SVOSLAM_FORCE_DIST=1 python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --exchange allreduce 2>/dev/null | line > ${P}_bench_cfg3_forced_dist_allreduce.json
 for f in ${P}_bench_*.json; do python3 - "$f" <<'PY'
 import json, sys, os
@@ -107,5 +114,6 @@ tail -30 $CC
 echo "== march anatomy, scheduler timeline, tracker hand-off profile"
 python $R/tools/prof/ray_anatomy.py 105 2>&1 | grep -v amdgpu.ids > ${P}_ray_anatomy_cfg3_105frames.txt; tail -3 ${P}_ray_anatomy_cfg3_105frames.txt
 python $R/tools/prof/runner_timeline.py 2>&1 | grep -v amdgpu.ids > ${P}_runner_timeline_cfg3.txt; tail -4 ${P}_runner_timeline_cfg3.txt
+python $R/tools/prof/runner_timeline.py 3/8 2>&1 | grep -v -E "amdgpu.ids|RCCL|HIP version|ROCm version|Hostname|Librccl" > ${P}_runner_timeline_cfg3_emulated_rank_3_of_8.txt; tail -4 ${P}_runner_timeline_cfg3_emulated_rank_3_of_8.txt
 SVOSLAM_RUNNER_REPLICAS=2 python $R/tools/prof/runner_timeline.py 2>&1 | grep -v amdgpu.ids > ${P}_runner_timeline_cfg3_two_replicas.txt; tail -4 ${P}_runner_timeline_cfg3_two_replicas.txt
 ls -la "$OUT"

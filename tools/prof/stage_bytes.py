@@ -61,7 +61,7 @@ times = {
     "maps (vertex + normal, 3 levels)": tsum("vertex_normal_kernel"),
     "pyramid (subsample)": tsum("subsample_depth_kernel"),
     "ICP (19 iterations)": tsum("icp_accumulate_kernel", "cam_reduce_solve_kernel", "track_persistent_kernel"),
-    "fuse": tsum("compute_keys", "radix_", "row_scan", "plan_", "split_all", "fill_mip_local", "mip_straddle", "vertex_map_kernel", "transform_kernel", "bbox_"),
+    "fuse": tsum("compute_keys", "keys_packed", "packed_", "radix_", "row_scan", "plan_", "split_all", "fill_mip_local", "mip_straddle", "vertex_map_kernel", "transform_kernel", "bbox_"),
     "raycast": tsum("cone_trace_kernel", "build_accel_kernel"),
 }
 out = ["# cfg3 (640x480, depth 12), mean over frames 5..104 of the bench stream; algorithmic bytes per SURVEY.md 8d;",
