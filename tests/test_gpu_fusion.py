@@ -327,3 +327,36 @@ def test_early_split_then_commit_matches_oracle(env, oracle, depth, n, frames):
     pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, pool, center, edge)
     opool.insert_cloud(pts, col, depth, center, edge)
     assert_pools_equal(pool, opool)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 511, 512, 513, 2047, 2048, 2049, 4097, 6145])
+def test_async_fusion_sizes_around_the_sort_and_plan_tiles(env, oracle, n):
+    """the asynchronous path (packed sort: tiles of 2048 keys; plan tiles of 512; fill tiles of 512) with element counts at
+    and around every tile boundary, ragged last tiles, all-invalid batches and a single point, at depths whose packed word
+    uses few (depth 1: 4 + idx bits) and many (depth 16: 49 + idx bits, exactly 64 at n = 2^15) bits"""
+    pkg, torch = env
+    rng = np.random.default_rng(31 + n)
+    for depth in (1, 3, 9, 16):
+        ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
+        center, edge = (0.01, 0.02, -0.01), 1.0
+        for f in range(3):
+            pts, col = random_cloud(rng, n, nan_every=7 if n > 20 else 0, dup_frac=0.2)
+            if f == 2:
+                pts[:] = np.nan                      # a batch without a single valid point
+            pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, pool, center, edge)
+            opool.insert_cloud(pts, col, depth, center, edge)
+            assert_pools_equal(pool, opool)
+
+
+def test_async_fusion_packed_word_exactly_64_bits(env, oracle):
+    """3 x 16 + 1 key bits + 15 index bits = 64: the largest batch the packed sort takes at depth 16 (one more point
+    falls back to the pair sort); both must build the oracle's pool"""
+    pkg, torch = env
+    rng = np.random.default_rng(77)
+    for n in (1 << 15, (1 << 15) + 1):
+        ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
+        for f in range(2):
+            pts, col = surface_cloud(rng, n, jitter=0.002)
+            pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), 16, pool, (0, 0, 0), 1.0)
+            opool.insert_cloud(pts, col, 16, (0, 0, 0), 1.0)
+        assert_pools_equal(pool, opool)
