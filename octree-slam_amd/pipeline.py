@@ -419,9 +419,10 @@ class SlamPipeline:
         deltas, events, march, outs = [None] * n, [None] * n, [False] * n, [None] * n
         keep = []
         for (a, b, slots) in frame_shards(n, g0, world, per_rank):
-            mine = torch.zeros((per_rank, pkg.DELTA_FLOATS), dtype=torch.float32, device="cuda")
-            allr = torch.empty((world, per_rank, pkg.DELTA_FLOATS), dtype=torch.float32, device="cuda")
             with torch.cuda.stream(self._s_delta):
+                # (allocated and zeroed ON the delta stream: a fill enqueued on the caller's stream could land after the records)
+                mine = torch.zeros((per_rank, pkg.DELTA_FLOATS), dtype=torch.float32, device="cuda")
+                allr = torch.empty((world, per_rank, pkg.DELTA_FLOATS), dtype=torch.float32, device="cuda")
                 for i in range(a, b):
                     r, row = slots[i - a]
                     if r == rank and g0 + i > 0:   # (a camera's first frame has no ICP)

@@ -156,3 +156,61 @@ def test_sharded_path_over_rccl_one_rank(env):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def _two_process_worker(rank, world, port, out_dir, n, w, h, depth):
+    """one rank of a REAL two-process frame-sharded session (both processes on the one GPU there is, so the process group
+    is gloo -- RCCL refuses two ranks on one device; the schedule, the collectives' order and the library calls are those
+    of the RCCL path)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import svoslam_pkg
+    pkg = svoslam_pkg.load()
+    synth = importlib.import_module("octree_slam_amd.synth")
+    pl = importlib.import_module("octree_slam_amd.pipeline")
+    torch.cuda.set_device(0)
+    center, edge = (0.0, 1.5, 0.0), 4.096
+    dstack, cstack = synth.render_stream(n, w, h, device="cuda")
+    views = [pl.ground_truth_view(k, synth) for k in range(n)]
+    P = pl.SlamPipeline(w, h, depth, center, edge, dist=pl.DistContext(rank, world, exchange="deltas"))
+    imgs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(n)]
+    half = n // 2 + 1
+    P.run_stream_sharded(list(dstack[:half]), list(cstack[:half]), list(range(half)), views[:half], images=imgs[:half], per_rank=2)
+    P.run_stream_sharded(list(dstack[half:]), list(cstack[half:]), list(range(half, n)), views[half:], images=imgs[half:], per_rank=2)
+    torch.cuda.synchronize()
+    p, o = P.cam.pose()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), words=P.pool.words(), size=P.pool.size, pos=p, ori=o,
+             lost=P.cam.tracking_lost_count(), images=np.stack([i.cpu().numpy() for i in imgs]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_sharded_session_on_one_gpu(env, tmp_path):
+    """two processes, one process group, frames tracked and marched alternately: each rank's replica and poses equal the
+    one-GPU session's, rank r holds the images of the frames k % 2 == r"""
+    pkg, torch, synth, pl = env
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    n, w, h, depth = 11, 160, 120, 8
+    mp.get_context("spawn")
+    mp.spawn(_two_process_worker, args=(2, port, str(tmp_path), n, w, h, depth), nprocs=2, join=True)
+    center, edge = (0.0, 1.5, 0.0), 4.096
+    dstack, cstack = synth.render_stream(n, w, h, device="cuda")
+    A = pl.SlamPipeline(w, h, depth, center, edge)
+    ref = [A.frame(dstack[k], cstack[k], k, pl.ground_truth_view(k, synth)).cpu().numpy().copy() for k in range(n)]
+    pa, oa = A.cam.pose()
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert int(z["size"]) == A.pool.size and np.array_equal(z["words"], A.pool.words()), r
+        assert np.array_equal(z["pos"], pa) and np.array_equal(z["ori"], oa) and int(z["lost"]) == A.cam.tracking_lost_count()
+        for k in range(n):
+            if k % 2 == r:
+                assert np.array_equal(z["images"][k], ref[k]), (r, k)
+            else:
+                assert int(z["images"][k].max()) == 0
