@@ -227,17 +227,21 @@ __device__ inline void record_range(int t, int c, int depth, int &lo, int &hi) {
 
 __device__ inline u32 bucket_id(int p, int d) { return (u32)(p * 16 + (d - 1)); }
 
-// Workgroup id -> tile of the sorted key array.  MEASURED AND NOT USED (round 2): an XCD-aware mapping -- tile = (id % 8) *
-// ceil(tiles / 8) + id / 8, one contiguous eighth of the Morton-ordered keys, i.e. a compact part of the tree and of the
-// colour image, per XCD and L2 -- made plan_emit_kernel 21 -> 57 us and fill_mip_local_kernel 50 -> 60 us in the frame loop
-// (plan_count_kernel unchanged): the eight XCDs then stream into eight far-apart regions of the record arrays / the pool
-// in lockstep instead of interleaving finely over the memory channels.  The plain mapping stays; the hooks are kept.
+// Workgroup id -> tile of the sorted key array.  An XCD-aware order -- tile = (id % 8) * ceil(tiles / 8) + id / 8: one
+// contiguous eighth of the Morton-ordered keys, i.e. a compact part of the tree and of the colour image, per XCD and L2 --
+// was built and A/B-measured (round 2): kernel durations in the sequential form within 3 % (leaf kernel 34.0 / 33.9 us,
+// plan_emit 10.8 / 11.0, plan_count 9.5 / 10.5), frames/s within run-to-run noise.  The plain order stays the default.
+#ifdef SVO_XCD_TILES  // the measured variant (build with SVOSLAM_EXTRA_HIPCC_FLAGS=-DSVO_XCD_TILES)
+__host__ __device__ inline int xcd_grid(int tiles) { return 8 * ((tiles + 7) / 8); }
+__device__ inline int xcd_tile(int tiles) { return (int)(blockIdx.x & 7u) * ((tiles + 7) / 8) + (int)(blockIdx.x >> 3); }
+#else
 __host__ __device__ inline int xcd_grid(int tiles) { return tiles; }
 __device__ inline int xcd_tile(int tiles) { (void)tiles; return (int)blockIdx.x; }
+#endif
 
 // Plan tiles are 512 sorted keys (8 wavefronts): half the [bucket][tile] counters of 256-key tiles to write,
-// scan and read back.  (1024-thread workgroups were measured 3x slower in the frame loop -- plan_emit 17 -> 57 us: next to the
-// march and the tracker a 16-wavefront workgroup rarely finds a CU with room for all of it.)
+// scan and read back.  (1024-key tiles: same frames/s within noise, and a 16-wavefront workgroup is the hardest to place
+// next to the march and the tracker.)
 constexpr int kPlanThreads = 512, kPlanWaves = kPlanThreads / 64;
 __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(const u64 *__restrict__ skey, int n, int depth,
                                                                   const u32 *__restrict__ pool, unsigned char *__restrict__ leaf_t,
