@@ -177,6 +177,16 @@ int svoslam_svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int3
  * can reach -- so that it may run WHILE the previous frame is still being rendered; the commit then writes the links from
  * its leaf kernel and runs two launches instead of three.  Same pool contents as without the call. */
 int svoslam_svo_fuse_split_early(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream);
+/* The structure chain, for callers that do NOT render every frame (one rank of a frame-sharded session).  A plan reads only
+ * the tree's structure words, and those are final once the previous frame's splits are in (splitNodes, svo.cu:239-276); its
+ * leaf blend and mip levels (fillNodes / mipmapNodes, :291-465) write colour words only.  plan_structure = plan + all splits
+ * with their links, tiles numbered from a size that follows the plans; it waits for no commit, only for the previous
+ * plan_structure (same stream, or ordered by the caller).  The commits (svoslam_svo_fuse_commit on the same workspace: leaf
+ * kernel + straddlers) follow in frame order on another stream.  The caller must keep a render of frame k away from the
+ * structure of frame k+1: no plan_structure(k+1) before the render of frame k has finished.  pool_structure_begin: once per
+ * sequence, ordered after everything earlier on the pool.  Same pool contents as plan + commit per frame. */
+int svoslam_pool_structure_begin(svoslam_pool *pool, void *stream);
+int svoslam_svo_fuse_plan_structure(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream);
 /* The planned commit applied to one of several BYTE-IDENTICAL replicas of a map (a plan made against any replica in
  * the state before this commit fits all of them: same tree, same tile numbering).  Each application uses its own
  * slot (0 or 1; applications with different slots may run concurrently), all but the last pass keep_plan != 0.

@@ -91,6 +91,8 @@ SIGNATURES = {
     "svoslam_svo_fuse_plan": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_commit": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_split_early": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
+    "svoslam_svo_fuse_plan_structure": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
+    "svoslam_pool_structure_begin": (C.c_int, [C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_commit_to": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _i32, _i32, _vp]),
     "svoslam_svo_fuse_commit_deferred": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_apply": (C.c_int, [_vp, C.POINTER(_PoolStruct), _vp]),
@@ -392,6 +394,16 @@ def svo_fuse_sort_frame(ws, depth_image, pose_ptr, fx, fy, max_depth, center, ed
 def svo_fuse_plan(ws, n, max_depth, pool):
     """phase 2: split planning against the pool's current tree (reads the pool)."""
     check(lib().svoslam_svo_fuse_plan(ws._h, int(n), max_depth, C.byref(pool._p), _stream()))
+
+
+def pool_structure_begin(pool):
+    """before a sequence of svo_fuse_plan_structure calls: the structure-side size := the pool's size"""
+    check(lib().svoslam_pool_structure_begin(C.byref(pool._p), _stream()))
+
+
+def svo_fuse_plan_structure(ws, n, max_depth, pool):
+    """plan + every split with its links, independent of the previous frame's commit (colour words)"""
+    check(lib().svoslam_svo_fuse_plan_structure(ws._h, int(n), int(max_depth), C.byref(pool._p), _stream()))
 
 
 def svo_fuse_split_early(ws, n, max_depth, pool):

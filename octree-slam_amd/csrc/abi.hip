@@ -174,6 +174,14 @@ int svoslam_svo_fuse_plan(svoslam_workspace *ws, int32_t n, int32_t max_depth, s
   NEED_DEVICE();
   return svo_fuse_plan(ws, n, max_depth, pool, S(stream));
 }
+int svoslam_pool_structure_begin(svoslam_pool *pool, void *stream) {
+  NEED_DEVICE();
+  return pool_structure_begin(pool, S(stream));
+}
+int svoslam_svo_fuse_plan_structure(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream) {
+  NEED_DEVICE();
+  return svo_fuse_plan_structure(ws, n, max_depth, pool, S(stream));
+}
 int svoslam_svo_fuse_split_early(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream) {
   NEED_DEVICE();
   return svo_fuse_split_early(ws, n, max_depth, pool, S(stream));

@@ -232,11 +232,21 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
   const bool one_stream = r->maps_on_track_stream && !sharded;
   // frame-sharded ranks that march at most one frame in three plan on the map stream (see enqueue_commit)
   bool plan_on_map = false;
+  // ... or, by default, run the STRUCTURE CHAIN (svoslam_svo_fuse_plan_structure): a plan reads structure words only, so
+  // plan + splits of frame i+1 need the splits of frame i, not its leaf blend / mip levels.  Three chains side by side --
+  // front end + sort on the (otherwise idle) maps stream, plan + splits on S, leaf kernel + straddlers (+ this rank's
+  // marches) on M -- and a frame costs the longest of them instead of plan + commit in sequence.  A march of frame k must not
+  // see the structure of frame k+1: S waits for the rank's latest march before the next plan.
+  bool chain = false;
+  int last_march = -1;  // latest frame of this call whose march has been enqueued (chain: ev_ray[last_march] is recorded)
   if (sharded && march) {
     int marched = 0;
     for (int i = 0; i < n; i++) marched += march[i] ? 1 : 0;
     plan_on_map = 3 * marched <= n;
+    static const bool chain_on = [] { const char *e = getenv("SVOSLAM_RUNNER_STRUCTURE_CHAIN"); return !(e && e[0] == '0'); }();
+    if (plan_on_map && chain_on && R == 1 && !r->deferred) { chain = true; plan_on_map = false; }
   }
+  if (chain) SVO_TRY(svoslam_pool_structure_begin(r->pool, r->s_prep));
   hipStream_t s_maps = one_stream ? r->s_track : r->s_maps;
   auto enqueue_maps = [&](int i) -> int {  // bilateral filter + pyramids of frame i (no dependence on earlier poses)
     if (sharded) return SVOSLAM_OK;  // tracked elsewhere: this camera only composes poses
@@ -273,6 +283,13 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
   auto enqueue_prepare = [&](int i) -> int {
     svoslam_workspace *ws = r->ws[i % kRing];
     float *pts = r->points[i % kRing];
+    hipStream_t s_plan = r->s_prep;                       // where the plan runs
+    hipStream_t s_prep_saved = r->s_prep;
+    struct Restore { svoslam_runner *r; hipStream_t s; ~Restore() { r->s_prep = s; } } restore{r, s_prep_saved};
+    // chain: front end + sort of this frame on the maps stream, idle in a sharded call (restored on return).  (Alternating
+    // the sorts of consecutive frames over TWO idle streams was measured: each sort then takes 0.5 ms instead of 0.14 and
+    // a rank of 8 drops from 5450 to 3500 frames/s -- six busy streams on the runtime's hardware queues.)
+    if (chain) r->s_prep = r->s_maps;
     SVO_HIP(hipStreamWaitEvent(r->s_prep, ev_pose[i], 0));
     if (i >= kRing)  // the ring slot's previous user: both of its commits are done with workspace, points and colours
       for (int k = 0; k < R; k++) SVO_HIP(hipStreamWaitEvent(r->s_prep, ev_commit[k][i - kRing], 0));
@@ -296,6 +313,16 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
     if (plan_on_map) {  // the plan moves to the map stream (enqueue_commit): see there
       mark(i, 5, r->s_prep);
       SVO_HIP(hipEventRecord(ev_plan[i], r->s_prep));
+      return SVOSLAM_OK;
+    }
+    if (chain) {
+      SVO_HIP(hipEventRecord(ev_maps[i], r->s_prep));     // "sorted" (the maps events are free in a sharded call)
+      SVO_HIP(hipStreamWaitEvent(s_plan, ev_maps[i], 0));
+      if (last_march >= 0) SVO_HIP(hipStreamWaitEvent(s_plan, ev_ray[last_march], 0));  // no structure of frame i under that march
+      mark(i, 5, s_plan);
+      SVO_TRY(svoslam_svo_fuse_plan_structure(ws, npts, r->depth, r->pool, s_plan));
+      SVO_HIP(hipEventRecord(ev_plan[i], s_plan));
+      mark(i, 6, s_plan);
       return SVOSLAM_OK;
     }
     // the plan reads the replica that receives commit i-1 FIRST (the one frame i-1 is marched on); the march only reads
@@ -398,16 +425,18 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
       // steady state).  With a lead of 8 frames that tail was 8 of the 20 frames of a short call: 2130 -> 2580 frames/s.
       if (r->lead > 0 && i >= r->lead) SVO_HIP(hipEventSynchronize(ev_commit[a][i - r->lead]));
       SVO_TRY(enqueue_commit(i, a, R == 1));
-      if (i + 1 < n) SVO_TRY(enqueue_prepare(i + 1));  // host order: after ev_commit[a][i] has been recorded
+      if (i + 1 < n && !chain) SVO_TRY(enqueue_prepare(i + 1));  // host order: after ev_commit[a][i] has been recorded
       // one march at a time: two of them (1200 workgroups) leave no CU for the tracker's and the fusion's workgroups
       if (R == 2 && serial_marches && i > 0) SVO_HIP(hipStreamWaitEvent(r->s_map[a], ev_ray[i - 1], 0));
       if (!march || march[i]) {
         uint8_t *img = d_images ? d_images[i] : ((i == n - 1) ? d_image : r->scratch_image[a]);
         SVO_TRY(svoslam_cone_trace_svo_band(img, r->w, r->h, row_first, rows, r->fov, views + 16 * (size_t)i, replica(r, a)->d_data,
                                             r->center, r->edge, r->mode, d_steps, r->s_map[a]));
+        if (chain) { SVO_HIP(hipEventRecord(ev_ray[i], r->s_map[a])); last_march = i; }
       }
       if (R == 2) SVO_HIP(hipEventRecord(ev_ray[i], r->s_map[a]));
       mark(i, 9, r->s_map[a]);
+      if (i + 1 < n && chain) SVO_TRY(enqueue_prepare(i + 1));  // host order: after the march's event, which its plan may have to wait for
       if (R == 2) SVO_TRY(enqueue_commit(i, a ^ 1, true));  // behind the march of frame i-1 on that replica
     }
     return SVOSLAM_OK;

@@ -278,7 +278,10 @@ __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(const u64 *__r
 // totals cross workgroups as agent-scope stores / loads on both sides, the ticket is taken after they have completed.
 __global__ __launch_bounds__(256) void plan_scan_finish_kernel(u32 *__restrict__ rows, int num_tiles, u32 *__restrict__ totals,
                                                                unsigned *__restrict__ ticket, u32 *__restrict__ bucket_base,
-                                                               PlanCounts *__restrict__ counts, int *__restrict__ any_valid) {
+                                                               PlanCounts *__restrict__ counts, int *__restrict__ any_valid,
+                                                               int *__restrict__ d_struct, u32 *__restrict__ n0_out) {
+  // d_struct (optional; svo_fuse_plan_structure): the first tile index of THIS plan's splits is taken from, and its
+  // 8 x records added to, a size that follows the plans instead of the commits
   __shared__ u32 tmp[4];
   __shared__ u32 sbase[257];
   __shared__ int is_last;
@@ -312,6 +315,11 @@ __global__ __launch_bounds__(256) void plan_scan_finish_kernel(u32 *__restrict__
     counts->pass_start[17] = (int32_t)total; counts->total_records = (int32_t)total;
     counts->any_valid = *any_valid;
     *any_valid = 0;
+    if (d_struct) {
+      const int n0 = *d_struct;
+      *n0_out = (u32)n0;
+      *d_struct = n0 + 8 * (int)total;
+    }
   }
   if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -391,13 +399,15 @@ __global__ __launch_bounds__(256) void split_all_kernel(const u64 *__restrict__ 
                                                         const unsigned char *__restrict__ rec_pass,
                                                         const u32 *__restrict__ bucket_base, const PlanCounts *__restrict__ counts,
                                                         u32 *__restrict__ pool, const int *__restrict__ d_size, int depth,
-                                                        u32 *__restrict__ grid_dirty, u32 *__restrict__ n0_saved) {
+                                                        u32 *__restrict__ grid_dirty, u32 *__restrict__ n0_saved, int structure) {
   if (!n0_saved) SVO_HIGH_PRIO();  // in-place commits sit between two raycasts on the map stream; deferred ones run beside one
   const u32 total = (u32)counts->total_records;
-  const u32 n0 = (u32)*d_size;
+  // structure != 0 (svo_fuse_plan_structure): the first tile index comes from the plan (*n0_saved, set by
+  // plan_scan_finish_kernel from the structure-side size) and the links ARE written -- the next plan reads them
+  const u32 n0 = structure ? *n0_saved : (u32)*d_size;
   // n0_saved != nullptr: deferred commit -- the links of the pass-0 records (the only words of this kernel a concurrent
   // ray march could see) are left to commit_apply_kernel, which needs the first tile index
-  if (n0_saved && blockIdx.x == 0 && threadIdx.x == 0) *n0_saved = n0;
+  if (n0_saved && !structure && blockIdx.x == 0 && threadIdx.x == 0) *n0_saved = n0;
   for (u32 r = blockIdx.x * 256u + threadIdx.x; r < total; r += gridDim.x * 256u) {
     const u64 key = rec_key[r];
     const int pass = rec_pass[r];
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(256) void split_all_kernel(const u64 *__restrict__ 
     // level grid of the ray march (pool_grid.hpp): a split above the block level re-labels the whole cube of its node
     if (grid_dirty && d < kPoolGridBlockLevel) pool_grid_mark(grid_dirty, key, d);
     const u32 child = n0 + 8u * r;
-    if (pass == 0 && !n0_saved) pool[2 * (size_t)rec_front[r]] = kFlag + (child & kMask);
+    if (pass == 0 && (!n0_saved || structure)) pool[2 * (size_t)rec_front[r]] = kFlag + (child & kMask);
     u32 w0[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     if (d + 1 <= depth - 1) {  // children at depth d+1 can only be records while d+1 < D
       const u32 b = bucket_id(pass + 1, d + 1);
@@ -889,10 +899,12 @@ struct PoolTracker {
   static constexpr int kSlots = 8;  // == the modulus in mip_straddle_kernel
   int32_t *h_size = nullptr;  // pinned, device-visible [kSlots]: the commit's last kernel stores the new size itself
   int *d_slot = nullptr;      // device: slot the next commit writes (advances with `next` below, once per commit)
+  int *d_struct = nullptr;    // device: the pool's size as the STRUCTURE chain sees it (svo_fuse_plan_structure; set from d_size by pool_structure_begin)
   hipEvent_t ev[kSlots];
   struct InFlight { int slot; int64_t bound; };
   InFlight q[kSlots];  // oldest first
   int count = 0, next = 0;
+  int planned_ahead = 0;  // svo_fuse_plan_structure calls whose commit has not been enqueued yet (their reservations must survive pool_sync)
 };
 
 static PoolTracker *tracker_of(svoslam_pool *pool) { return reinterpret_cast<PoolTracker *>(pool->tracker); }
@@ -905,6 +917,7 @@ static int tracker_create(svoslam_pool *pool) {
     if (hipEventCreateWithFlags(&t->ev[i], hipEventDisableTiming) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
   }
   if (hipMalloc((void **)&t->d_slot, 4) != hipSuccess || hipMemset(t->d_slot, 0, 4) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
+  if (hipMalloc((void **)&t->d_struct, 4) != hipSuccess || hipMemset(t->d_struct, 0, 4) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
   pool->tracker = t;
   return SVOSLAM_OK;
 }
@@ -915,6 +928,7 @@ void pool_tracker_destroy(svoslam_pool *pool) {
   for (int i = 0; i < PoolTracker::kSlots; i++) (void)hipEventDestroy(t->ev[i]);
   if (t->h_size) (void)hipHostFree(t->h_size);
   if (t->d_slot) (void)hipFree(t->d_slot);
+  if (t->d_struct) (void)hipFree(t->d_struct);
   delete t;
   pool->tracker = nullptr;
 }
@@ -970,7 +984,9 @@ int pool_sync(svoslam_pool *pool, hipStream_t stream) {
     pool->size = sz;
   }
   pool->pending = 0;
-  pool->pending_bound = 0;
+  // what tracker_poll left of pending_bound is the reservation of plans that have no commit yet: zero unless the
+  // structure chain is ahead of its commits
+  if (!tracker_of(pool) || tracker_of(pool)->planned_ahead == 0) pool->pending_bound = 0;
   return SVOSLAM_OK;
 }
 
@@ -982,17 +998,19 @@ static int ensure_device_size(svoslam_pool *pool, hipStream_t stream) {
   return tracker_create(pool);
 }
 
-static int grow_pool(svoslam_pool *pool, int64_t need_nodes, hipStream_t stream) {
+static int grow_pool(svoslam_pool *pool, int64_t need_nodes, hipStream_t stream, int64_t live_nodes = 0) {
   if (need_nodes > (int64_t)kMask + 1) return SVOSLAM_ERR_POOL_LIMIT;
   if (need_nodes <= pool->capacity) return SVOSLAM_OK;
   SVO_TRY(pool_sync(pool, stream));  // the copy below needs the exact size
+  // live_nodes > size: tiles that plans of the structure chain have written ahead of their commits move along
+  const int64_t copy_nodes = live_nodes > pool->size ? (live_nodes < pool->capacity ? live_nodes : pool->capacity) : pool->size;
   int64_t cap = (int64_t)pool->capacity * 2;
   if (cap < need_nodes) cap = need_nodes;
   if (cap > (int64_t)kMask + 1) cap = (int64_t)kMask + 1;
   u32 *fresh = nullptr;
   SVO_HIP(hipMalloc((void **)&fresh, (size_t)cap * 8));
-  if (pool->d_data && pool->size > 0)
-    SVO_HIP(hipMemcpyAsync(fresh, pool->d_data, (size_t)pool->size * 8, hipMemcpyDeviceToDevice, stream));
+  if (pool->d_data && copy_nodes > 0)
+    SVO_HIP(hipMemcpyAsync(fresh, pool->d_data, (size_t)copy_nodes * 8, hipMemcpyDeviceToDevice, stream));
   SVO_HIP(hipStreamSynchronize(stream));
   pool_accel_rebind(pool->d_data, fresh);
   if (pool->d_data) SVO_HIP(hipFree(pool->d_data));
@@ -1227,7 +1245,7 @@ static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *poo
   const int ptiles = (int)cdiv(n, kPlanThreads);
   plan_count_kernel<<<xcd_grid(ptiles), kPlanThreads, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, ptiles, small_any(ws));
   plan_scan_finish_kernel<<<256, 256, 0, stream>>>(tile_hist, ptiles, small_totals(ws), small_ticket(ws), small_bucket_base(ws),
-                                                   small_counts(ws), small_any(ws));
+                                                   small_counts(ws), small_any(ws), nullptr, nullptr);
   SVO_LAUNCH_CHECK();
   SVO_HIP(hipMemcpyAsync(ws->h_counts, small_counts(ws), sizeof(PlanCounts), hipMemcpyDeviceToHost, stream));
   SVO_HIP(hipStreamSynchronize(stream));  // the one host round trip of a fused frame
@@ -1383,11 +1401,35 @@ int svo_fuse_sort_frame(svoslam_workspace *ws, const uint16_t *d_depth, const fl
   return fuse_sort_impl(ws, nullptr, &fs, w * h, depth, center, edge, d_bbox7, stream);
 }
 
-int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream) {
+__global__ void pool_structure_begin_kernel(int *__restrict__ d_struct, const int *__restrict__ d_size) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *d_struct = *d_size;
+}
+
+// The structure chain (for callers that do not render every frame: one rank of a frame-sharded session).  A plan reads
+// only the pool's STRUCTURE words (children flags and links), and those are final once the splits of the previous frame
+// are in -- its leaf blend and mip levels write colour words only.  svo_fuse_plan_structure = plan + split_all (links
+// included) in one go, numbering its tiles from a size that follows the PLANS (d_struct); it needs no commit to have
+// finished, only the previous svo_fuse_plan_structure (same stream, or ordered by the caller).  The commits -- leaf kernel +
+// straddlers, as after svo_fuse_split_early -- follow in order on another stream.  Frames then cost the longer of the two
+// chains instead of their sum.  The caller keeps a ray march of frame k away from the structure of frame k+1: no
+// svo_fuse_plan_structure(k+1) before the march of frame k is done.  pool_structure_begin: once, after everything
+// earlier on the pool has completed in stream order (d_struct := the pool's size).
+int pool_structure_begin(svoslam_pool *pool, hipStream_t stream) {
+  if (!pool) return SVOSLAM_ERR_INVALID_ARG;
+  if (pool->size == 0) SVO_TRY(pool_init(pool, 8, stream));
+  SVO_TRY(ensure_device_size(pool, stream));
+  pool_structure_begin_kernel<<<1, 64, 0, stream>>>(tracker_of(pool)->d_struct, pool->d_size);
+  SVO_LAUNCH_CHECK();
+  return SVOSLAM_OK;
+}
+
+static int fuse_plan_impl(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, bool structure, hipStream_t stream) {
   if (!ws || !pool || n < 0) return SVOSLAM_ERR_INVALID_ARG;
   if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
   if (pool->size == 0) SVO_TRY(pool_init(pool, 8, stream));
   ws->planned_n = -1;
+  ws->early_split_pool = nullptr;
+  if (structure && pool_shadow_pending(pool)) return SVOSLAM_ERR_INVALID_ARG;
   if (n == 0) { ws->planned_n = 0; return SVOSLAM_OK; }
   if (!ws->sorted_keys) return SVOSLAM_ERR_INVALID_ARG;  // svo_fuse_sort has not run on this workspace
   SVO_TRY(ensure_device_size(pool, stream));
@@ -1403,12 +1445,14 @@ int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, h
     // growing moves the pool: nothing on ANY stream may still be using it (a render of the previous frame)
     SVO_HIP(hipDeviceSynchronize());
     SVO_TRY(pool_sync(pool, stream));
-    bound = (int64_t)pool->size + 8 * rmax;
+    bound = (int64_t)pool->size + pool->pending_bound + 8 * rmax;  // (pending_bound: plans of the structure chain without a commit yet; else 0)
     if (bound > pool->capacity) {
-      int64_t want = (int64_t)pool->size + 16 * 8 * rmax;  // room for ~16 worst-case calls before the next sync
+      int64_t want = (int64_t)pool->size + pool->pending_bound + 16 * 8 * rmax;  // room for ~16 worst-case calls before the next sync
       if (want > (int64_t)kMask + 1) want = (int64_t)kMask + 1;
       if (want < bound) return SVOSLAM_ERR_POOL_LIMIT;
-      SVO_TRY(grow_pool(pool, want, stream));
+      int32_t live = 0;  // structure chain: plans may be ahead of their commits (the device is idle here: read their size)
+      if (structure) SVO_HIP(hipMemcpy(&live, tracker_of(pool)->d_struct, 4, hipMemcpyDeviceToHost));
+      SVO_TRY(grow_pool(pool, want, stream, live));
     }
   }
   const u64 *skey = ws->sorted_keys;
@@ -1416,23 +1460,39 @@ int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, h
   unsigned char *leaf_t = ws->leaf_t.as<unsigned char>();
   u32 *leaf_f = ws->leaf_f.as<u32>();
   u32 *tile_hist = ws->tile_hist.as<u32>();
+  int *d_struct = structure ? tracker_of(pool)->d_struct : nullptr;
+  int split_blocks = (int)cdiv(rmax, 256);
+  if (split_blocks > 2048) split_blocks = 2048;
   auto enqueue = [&]() -> int {  // three launches (round 1: a memset and five)
     plan_count_kernel<<<xcd_grid(tiles), kPlanThreads, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, tiles, small_any(ws));
     plan_scan_finish_kernel<<<256, 256, 0, stream>>>(tile_hist, tiles, small_totals(ws), small_ticket(ws), small_bucket_base(ws),
-                                                     small_counts(ws), small_any(ws));
+                                                     small_counts(ws), small_any(ws), d_struct, small_n0(ws));
     plan_emit_kernel<<<xcd_grid(tiles), kPlanThreads, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, tiles,
                                                          ws->rec_key.as<u64>(), ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>(),
                                                          ws->leaf_rec0.as<u32>());
+    if (structure)  // tiles AND links, numbered from the plan's own size; the level-grid marks come from the commit's leaf kernel
+      split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>(),
+                                                         small_bucket_base(ws), small_counts(ws), pool->d_data, pool->d_size, depth, nullptr,
+                                                         small_n0(ws), 1);
     SVO_LAUNCH_CHECK();
     return SVOSLAM_OK;
   };
   GraphKey key;
-  key.add(skey).add((unsigned long long)n).add((unsigned long long)depth).add(pool->d_data).add(ws->layout_hash());
+  key.add(skey).add((unsigned long long)n).add((unsigned long long)depth).add(pool->d_data).add(ws->layout_hash())
+     .add((unsigned long long)structure).add(d_struct);
   SVO_TRY(ws->g_plan.run(key, stream, enqueue));
   ws->planned_n = n;
   ws->planned_pool = pool;
+  if (structure) { ws->early_split_pool = pool; tracker_of(pool)->planned_ahead++; ws->structure_planned = true; }  // the commit: leaf kernel (links again, same values; marks) + straddlers
   pool->pending_bound += 8 * rmax;  // reserved from now on
   return SVOSLAM_OK;
+}
+
+int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream) {
+  return fuse_plan_impl(ws, n, depth, pool, false, stream);
+}
+int svo_fuse_plan_structure(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream) {
+  return fuse_plan_impl(ws, n, depth, pool, true, stream);
 }
 
 // Applies the planned commit to `pool`.  slot / keep_plan serve callers that keep several byte-identical replicas of
@@ -1454,7 +1514,7 @@ int svo_fuse_split_early(svoslam_workspace *ws, int n, int depth, svoslam_pool *
   if (split_blocks > 2048) split_blocks = 2048;
   split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>(),
                                                      small_bucket_base(ws), small_counts(ws), pool->d_data, pool->d_size, depth, nullptr,
-                                                     small_n0(ws));
+                                                     small_n0(ws), 0);
   SVO_LAUNCH_CHECK();
   ws->early_split_pool = pool;
   return SVOSLAM_OK;
@@ -1471,6 +1531,10 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   const bool early = ws->early_split_pool != nullptr;
   if (early && (ws->early_split_pool != pool || deferred || keep_plan)) return SVOSLAM_ERR_INVALID_ARG;  // one pool, direct commit
   ws->early_split_pool = nullptr;
+  if (ws->structure_planned) {
+    ws->structure_planned = false;
+    if (tracker_of(pool) && tracker_of(pool)->planned_ahead > 0) tracker_of(pool)->planned_ahead--;
+  }
   if (n == 0) {
     if (deferred) { ws->deferred_pool = pool; ws->deferred_n = 0; }
     return SVOSLAM_OK;
@@ -1508,7 +1572,7 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
     if (!early)
       split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
                                                          ws->rec_pass.as<unsigned char>(), small_bucket_base(ws), small_counts(ws),
-                                                         pool->d_data, pool->d_size, depth, grid_dirty, deferred ? small_n0(ws) : nullptr);
+                                                         pool->d_data, pool->d_size, depth, grid_dirty, deferred ? small_n0(ws) : nullptr, 0);
     fill_mip_local_kernel<<<xcd_grid(fill_tiles), kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
                                                                    grid_dirty, shadow, epoch, apply_nodes, ws->rec_key.as<u64>(),
                                                                    small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr);

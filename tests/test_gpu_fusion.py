@@ -360,3 +360,39 @@ def test_async_fusion_packed_word_exactly_64_bits(env, oracle):
             pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), 16, pool, (0, 0, 0), 1.0)
             opool.insert_cloud(pts, col, 16, (0, 0, 0), 1.0)
         assert_pools_equal(pool, opool)
+
+
+@pytest.mark.parametrize("depth,n", [(2, 500), (9, 30000), (12, 60000), (16, 20000)])
+def test_structure_chain_equals_sequential_fusion(env, oracle, depth, n):
+    """svoslam_svo_fuse_plan_structure: plans + splits of three frames run AHEAD of every commit (one stream each, the
+    commits ordered only after their own plan), then the commits in frame order: the oracle's pool"""
+    pkg, torch = env
+    rng = np.random.default_rng(1200 + depth)
+    center, edge = (0.02, -0.01, 0.03), 1.0
+    pool, opool = pkg.Pool(1 << 23), oracle.Pool()
+    wss = [pkg.Workspace() for _ in range(3)]
+    s_struct, s_col = torch.cuda.Stream(), torch.cuda.Stream()
+    for rnd in range(2):
+        clouds = []
+        for f in range(3):
+            pts, col = (surface_cloud(rng, n) if f != 1 else random_cloud(rng, n, nan_every=41, dup_frac=0.15))
+            pts = pts + np.float32(0.004 * (3 * rnd + f))
+            if f == 2:
+                pts[: n // 5] = np.abs(pts[: n // 5])
+            clouds.append((torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), pts, col))
+        torch.cuda.synchronize()
+        evs = []
+        with torch.cuda.stream(s_struct):
+            pkg.pool_structure_begin(pool)
+            for f in range(3):
+                pkg.svo_fuse_sort(wss[f], clouds[f][0], depth, center, edge)
+                pkg.svo_fuse_plan_structure(wss[f], n, depth, pool)
+                e = torch.cuda.Event(); e.record(); evs.append(e)
+        with torch.cuda.stream(s_col):
+            for f in range(3):
+                s_col.wait_event(evs[f])
+                pkg.svo_fuse_commit(wss[f], clouds[f][1], depth, pool)
+        torch.cuda.synchronize()
+        for f in range(3):
+            opool.insert_cloud(clouds[f][2], clouds[f][3], depth, center, edge)
+        assert_pools_equal(pool, opool)

@@ -76,7 +76,7 @@ def test_pair_delta_then_apply_equals_update_and_oracle(env, oracle, w, h):
         P.pair_delta(depth[0], rgb[0], depth[1], rgb[1], again[0])
 
 
-@pytest.mark.parametrize("world,per_rank,w,h,depth", [(2, 2, 320, 240, 10), (3, 1, 160, 120, 8)])
+@pytest.mark.parametrize("world,per_rank,w,h,depth", [(2, 2, 320, 240, 10), (3, 1, 160, 120, 8), (4, 2, 320, 240, 10), (8, 1, 160, 120, 9)])
 def test_sharded_session_equals_single_gpu_session(env, world, per_rank, w, h, depth):
     """every rank of a frame-sharded session: poses and map replica equal the one-GPU session's after every call, the
     frames it ray-marches equal the one-GPU images; across ranks every frame is marched exactly once.  Two calls (the
