@@ -126,6 +126,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # testing aid for one-GPU boxes: SVOSLAM_BENCH_ONE_DEVICE=1 puts every rank on device 0 and uses the gloo backend
+    # (RCCL refuses two ranks on one device) -- the multi-rank code path of this file end to end, not a measurement
+    one_device = os.environ.get("SVOSLAM_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -149,7 +154,10 @@ def main():
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        tdist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_device:
+            tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            tdist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         dist = pl.DistContext(rank, world, force=force_dist, exchange=args.exchange)
     arch = pkg.device_arch()
     assert arch and arch.startswith("gfx950"), arch

@@ -214,3 +214,27 @@ def test_two_process_sharded_session_on_one_gpu(env, tmp_path):
                 assert np.array_equal(z["images"][k], ref[k]), (r, k)
             else:
                 assert int(z["images"][k].max()) == 0
+
+
+def test_bench_multi_rank_code_path_on_one_gpu(env):
+    """bench.py launched as the driver launches it for N = 2 and N = 4 (torch.distributed.run, one process per rank), all
+    ranks on the one GPU there is over gloo (SVOSLAM_BENCH_ONE_DEVICE=1: RCCL refuses two ranks on a device): the default
+    frame-sharded exchange runs end to end -- per-rank march counts, the max-over-ranks timing, one JSON line on rank 0.
+    Not a measurement."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for nproc in (2, 4):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        envv = dict(os.environ, SVOSLAM_BENCH_ONE_DEVICE="1")
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                              "--gpus", str(nproc), "--steps", "12", "--warmup", "3", "--no-cpu-baseline"],
+                             env=envv, capture_output=True, text=True, timeout=600)
+        lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+        assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-800:], out.stderr[-1500:])
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == nproc and j["steps"] == 12 and j["value"] > 0 and j["scaling"] == "strong"
+        assert "update_trans" in j["config"]["parallelism"] and j["roofline"]["kernel_ms"] > 0
