@@ -24,6 +24,17 @@ constexpr int kWave = 64;  // gfx950 wavefront
 void set_last_error(const char *what, hipError_t e);
 int ensure_device();
 
+// hipMemset of device memory may return before the fill has run, and the fill runs on the NULL stream, which the library's
+// non-blocking streams do not wait for: a kernel enqueued right after it on one of them can see the old bytes, or have its
+// own stores wiped.  Every one-off initialisation goes through this (fill, then wait for the null stream).
+inline hipError_t memset_sync(void *p, int value, size_t bytes) {
+  const hipError_t e = hipMemset(p, value, bytes);
+#ifdef SVO_MEMSET_NOSYNC  // (to reproduce the hazard)
+  return e;
+#endif
+  return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
+
 #define SVO_HIP(expr)                                  \
   do {                                                 \
     hipError_t _e = (expr);                            \

@@ -568,8 +568,8 @@ int camera_reset(svoslam_camera *c) {
     for (int r = 0; r < 4; r++) init.fusion_ring[r][i] = 1.0f;
   }
   SVO_HIP(hipMemcpy(c->d_state, &init, sizeof(init), hipMemcpyHostToDevice));
-  SVO_HIP(hipMemset(c->d_sync, 0, sizeof(TrackSync)));
-  SVO_HIP(hipMemset(c->d_tickets, 0, track_persistent_ticket_bytes()));
+  SVO_HIP(memset_sync(c->d_sync, 0, sizeof(TrackSync)));
+  SVO_HIP(memset_sync(c->d_tickets, 0, track_persistent_ticket_bytes()));
   c->have_stamp = false; c->latest_stamp = 0;
   c->prepared = 0; c->tracked = 0;
   c->frame_has_icp = false;

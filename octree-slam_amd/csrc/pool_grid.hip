@@ -68,7 +68,7 @@ static bool ensure_dirty_states(PoolAccel *pa) {
   for (int k = 0; k < 2; k++) {
     if (pa->d_dirty[k]) continue;
     if (hipMalloc((void **)&pa->d_dirty[k], kPoolGridStateWords * 4) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (hipMemset(pa->d_dirty[k], 0, kPoolGridStateWords * 4) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (memset_sync(pa->d_dirty[k], 0, kPoolGridStateWords * 4) != hipSuccess) { (void)hipGetLastError(); return false; }
   }
   return true;
 }

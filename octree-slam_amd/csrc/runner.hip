@@ -132,7 +132,7 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
   }
   for (int k = 0; k < 2; k++) SVO_HIP(hipMalloc((void **)&r->scratch_image[k], n * 4));
   SVO_HIP(hipMalloc((void **)&r->bbox, 7 * 4));
-  SVO_HIP(hipMemset(r->bbox, 0, 7 * 4));
+  SVO_HIP(svoslam::memset_sync(r->bbox, 0, 7 * 4));
   SVO_HIP(hipMalloc((void **)&r->in_track, n * 2));
   SVO_HIP(hipMalloc((void **)&r->in_prep, n * 2));
   SVO_HIP(hipEventCreateWithFlags(&r->ev_begin, hipEventDisableTiming));
@@ -283,40 +283,38 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
   auto enqueue_prepare = [&](int i) -> int {
     svoslam_workspace *ws = r->ws[i % kRing];
     float *pts = r->points[i % kRing];
-    hipStream_t s_plan = r->s_prep;                       // where the plan runs
-    hipStream_t s_prep_saved = r->s_prep;
-    struct Restore { svoslam_runner *r; hipStream_t s; ~Restore() { r->s_prep = s; } } restore{r, s_prep_saved};
-    // chain: front end + sort of this frame on the maps stream, idle in a sharded call (restored on return).  (Alternating
-    // the sorts of consecutive frames over TWO idle streams was measured: each sort then takes 0.5 ms instead of 0.14 and
-    // a rank of 8 drops from 5450 to 3500 frames/s -- six busy streams on the runtime's hardware queues.)
-    if (chain) r->s_prep = r->s_maps;
-    SVO_HIP(hipStreamWaitEvent(r->s_prep, ev_pose[i], 0));
+    hipStream_t s_plan = r->s_prep;  // where the plan runs
+    // chain: front end + sort of this frame on the maps stream, idle in a sharded call.  (Alternating the sorts of
+    // consecutive frames over TWO idle streams was measured: each sort then takes 0.5 ms instead of 0.14 and a rank of 8
+    // drops from 5450 to 3500 frames/s -- six busy streams on the runtime's hardware queues.)
+    hipStream_t s_sort = chain ? r->s_maps : r->s_prep;
+    SVO_HIP(hipStreamWaitEvent(s_sort, ev_pose[i], 0));
     if (i >= kRing)  // the ring slot's previous user: both of its commits are done with workspace, points and colours
-      for (int k = 0; k < R; k++) SVO_HIP(hipStreamWaitEvent(r->s_prep, ev_commit[k][i - kRing], 0));
-    mark(i, 4, r->s_prep);
+      for (int k = 0; k < R; k++) SVO_HIP(hipStreamWaitEvent(s_sort, ev_commit[k][i - kRing], 0));
+    mark(i, 4, s_sort);
     if (staged) {
-      SVO_HIP(hipMemcpyAsync(r->in_prep, d_depths[i], px * 2, hipMemcpyDeviceToDevice, r->s_prep));
-      SVO_HIP(hipMemcpyAsync(r->in_rgb[i % kRing], d_rgbs[i], px * 3, hipMemcpyDeviceToDevice, r->s_prep));
+      SVO_HIP(hipMemcpyAsync(r->in_prep, d_depths[i], px * 2, hipMemcpyDeviceToDevice, s_sort));
+      SVO_HIP(hipMemcpyAsync(r->in_rgb[i % kRing], d_rgbs[i], px * 3, hipMemcpyDeviceToDevice, s_sort));
     }
     if (r->fused_front) {
       // main.cpp:39-44 + computeKeys in one launch, no point cloud in memory (svoslam_svo_fuse_sort_frame), then the sort
       SVO_TRY(svoslam_svo_fuse_sort_frame(ws, staged ? r->in_prep : d_depths[i], fusion_ptr[i], r->w, r->h, r->fx, r->fy, r->depth,
-                                          r->center, r->edge, r->bbox, r->s_prep));
-      SVO_HIP(hipEventRecord(ev_bp[i], r->s_prep));
+                                          r->center, r->edge, r->bbox, s_sort));
+      SVO_HIP(hipEventRecord(ev_bp[i], s_sort));
     } else {
-      SVO_TRY(svoslam_generate_vertex_map(staged ? r->in_prep : d_depths[i], pts, r->w, r->h, r->fx, r->fy, r->w, r->h, r->s_prep));  // main.cpp:39
-      SVO_TRY(svoslam_transform_vertex_map_dmat(pts, fusion_ptr[i], npts, r->s_prep));                         // main.cpp:40-41
-      SVO_TRY(svoslam_point_cloud_bbox_device(r->ws[0], pts, npts, r->bbox, r->s_prep));                       // main.cpp:44
-      SVO_HIP(hipEventRecord(ev_bp[i], r->s_prep));
-      SVO_TRY(svoslam_svo_fuse_sort(ws, pts, npts, r->depth, r->center, r->edge, r->s_prep));
+      SVO_TRY(svoslam_generate_vertex_map(staged ? r->in_prep : d_depths[i], pts, r->w, r->h, r->fx, r->fy, r->w, r->h, s_sort));  // main.cpp:39
+      SVO_TRY(svoslam_transform_vertex_map_dmat(pts, fusion_ptr[i], npts, s_sort));                         // main.cpp:40-41
+      SVO_TRY(svoslam_point_cloud_bbox_device(r->ws[0], pts, npts, r->bbox, s_sort));                       // main.cpp:44
+      SVO_HIP(hipEventRecord(ev_bp[i], s_sort));
+      SVO_TRY(svoslam_svo_fuse_sort(ws, pts, npts, r->depth, r->center, r->edge, s_sort));
     }
     if (plan_on_map) {  // the plan moves to the map stream (enqueue_commit): see there
-      mark(i, 5, r->s_prep);
-      SVO_HIP(hipEventRecord(ev_plan[i], r->s_prep));
+      mark(i, 5, s_sort);
+      SVO_HIP(hipEventRecord(ev_plan[i], s_sort));
       return SVOSLAM_OK;
     }
     if (chain) {
-      SVO_HIP(hipEventRecord(ev_maps[i], r->s_prep));     // "sorted" (the maps events are free in a sharded call)
+      SVO_HIP(hipEventRecord(ev_maps[i], s_sort));        // "sorted" (the maps events are free in a sharded call)
       SVO_HIP(hipStreamWaitEvent(s_plan, ev_maps[i], 0));
       if (last_march >= 0) SVO_HIP(hipStreamWaitEvent(s_plan, ev_ray[last_march], 0));  // no structure of frame i under that march
       mark(i, 5, s_plan);

@@ -916,8 +916,8 @@ static int tracker_create(svoslam_pool *pool) {
   for (int i = 0; i < PoolTracker::kSlots; i++) {
     if (hipEventCreateWithFlags(&t->ev[i], hipEventDisableTiming) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
   }
-  if (hipMalloc((void **)&t->d_slot, 4) != hipSuccess || hipMemset(t->d_slot, 0, 4) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
-  if (hipMalloc((void **)&t->d_struct, 4) != hipSuccess || hipMemset(t->d_struct, 0, 4) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
+  if (hipMalloc((void **)&t->d_slot, 4) != hipSuccess || memset_sync(t->d_slot, 0, 4) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
+  if (hipMalloc((void **)&t->d_struct, 4) != hipSuccess || memset_sync(t->d_struct, 0, 4) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
   pool->tracker = t;
   return SVOSLAM_OK;
 }
@@ -1086,7 +1086,7 @@ int pool_reset(svoslam_pool *pool, hipStream_t stream) {
   if (!pool || !pool->d_data) return SVOSLAM_ERR_INVALID_ARG;
   SVO_HIP(hipDeviceSynchronize());
   SVO_TRY(pool_sync(pool, stream));  // drains the size tracker
-  SVO_HIP(hipMemset(pool->d_data, 0, 64));
+  SVO_HIP(memset_sync(pool->d_data, 0, 64));
   pool_accel_invalidate(pool);
   pool->size = 8; pool->pending = 0; pool->pending_bound = 0;
   if (pool->d_size) SVO_HIP(hipMemcpy(pool->d_size, &pool->size, 4, hipMemcpyHostToDevice));
@@ -1345,7 +1345,7 @@ static int fuse_sort_impl(svoslam_workspace *ws, const float *d_points, const Fr
       const size_t need = (size_t)(8 + 7 * (size_t)tiles) * 4;
       if (need > ws->frame_bbox.bytes) {
         SVO_TRY(ws->frame_bbox.reserve(need));
-        SVO_HIP(hipMemset(ws->frame_bbox.ptr, 0, ws->frame_bbox.bytes));  // the ticket starts at zero (blocking; once per size)
+        SVO_HIP(memset_sync(ws->frame_bbox.ptr, 0, ws->frame_bbox.bytes));  // the ticket starts at zero (blocking; once per size)
       }
       ticket = ws->frame_bbox.as<unsigned>();
       partial = ws->frame_bbox.as<float>() + 8;

@@ -69,7 +69,7 @@ struct svoslam_workspace {
   int reserve_small() {
     if (small.bytes >= 4096) return SVOSLAM_OK;
     SVO_TRY(small.reserve(4096));
-    SVO_HIP(hipMemset(small.ptr, 0, small.bytes));
+    SVO_HIP(svoslam::memset_sync(small.ptr, 0, small.bytes));
     return SVOSLAM_OK;
   }
   // every buffer address the recorded phases bake in (a reallocation makes a new key)
