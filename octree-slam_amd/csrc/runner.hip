@@ -61,7 +61,7 @@ struct svoslam_runner {
   std::vector<hipEvent_t> events;  // pool, grown on demand
   hipEvent_t ev_begin = nullptr, ev_end[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t last_caller = nullptr;
-  int lead = 3;  // commits the host may run ahead of the device (see svoslam_runner_run)
+  int lead = 2;  // commits the host may run ahead of the device (see svoslam_runner_run)
   bool fused_front = false;  // back-projection + bounding box + keys in one launch (SVOSLAM_RUNNER_FUSED_FRONT=0: the four stand-alone calls)
   bool early_split = true;  // SVOSLAM_RUNNER_EARLY_SPLIT=0: split_all_kernel inside the commit
   bool deferred = false;  // SVOSLAM_RUNNER_DEFERRED=1 (one replica): the commit of frame k+1 is computed during the march of frame k
@@ -123,8 +123,23 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
   if (ld) r->lead = atoi(ld) < 0 ? 0 : atoi(ld);
   *out = r;
   const size_t n = (size_t)width * height;
-  for (hipStream_t *s : {&r->s_maps, &r->s_track, &r->s_prep, &r->s_map[0], &r->s_map[1]})
-    SVO_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+  {
+    // Stream priorities: the map stream -- the chain that bounds the frame -- on the highest, the tracker in the middle, maps
+    // and sort on the lowest.  Measured (means of 6 / 3 runs): cfg3 over the driver's 20 frames 2690 -> 2795 frames/s with
+    // half the run-to-run spread, 100 and 300 frames and a rank of 8 unchanged, cfg4 748 -> 733 (there the launch-chain
+    // tracker is level with the map stream and loses what the map stream gains).  Default: on for images up to 640x480-class
+    // (the one-launch tracker's domain); SVOSLAM_RUNNER_PRIO=0 / 1 overrides.
+    const char *pe = getenv("SVOSLAM_RUNNER_PRIO");
+    int least = 0, greatest = 0;
+    const bool want = pe ? pe[0] == '1' : (long long)width * height <= 400000ll;
+    const bool prio = want && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
+    hipStream_t *ss[5] = {&r->s_maps, &r->s_track, &r->s_prep, &r->s_map[0], &r->s_map[1]};
+    const int pr[5] = {least, (least + greatest) / 2, least, greatest, greatest};
+    for (int k = 0; k < 5; k++) {
+      if (prio) SVO_HIP(hipStreamCreateWithPriority(ss[k], hipStreamNonBlocking, pr[k]));
+      else SVO_HIP(hipStreamCreateWithFlags(ss[k], hipStreamNonBlocking));
+    }
+  }
   for (int k = 0; k < kRing; k++) {
     SVO_TRY(svoslam_workspace_create(&r->ws[k]));
     SVO_HIP(hipMalloc((void **)&r->points[k], n * 12));
@@ -416,7 +431,7 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
       if (i + 1 < n) SVO_TRY(enqueue_track(i + 1));
       if (i + 2 < n) SVO_TRY(enqueue_maps(i + 2));  // (one stream: behind track i+1, ahead of track i+2 -- two map sets ahead at most)
       const int a = i & (R - 1);  // the replica frame i is marched on: it gets commit i first
-      // The host stays at most `lead` commits ahead of the device (default 3; SVOSLAM_RUNNER_LEAD=0: as far as the
+      // The host stays at most `lead` commits ahead of the device (default 2; SVOSLAM_RUNNER_LEAD=0: as far as the
       // pool's size ring allows, 8).  Whatever has been enqueued when the host STOPS enqueuing drains at 0.6 ms per
       // frame instead of 0.32 (measured with HIP events per stage: the kernels themselves keep their durations and the
       // clock stays at 2.4 GHz, the gaps between them grow; AMD_DIRECT_DISPATCH=0 does not show it but costs 10 % in
