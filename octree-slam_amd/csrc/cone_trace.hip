@@ -431,10 +431,13 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
       // (axis_bits_lds), and one whose bracket is still open takes the reference's chain (march -2 %)
       uint32_t xb = (uint32_t)gx, yb = (uint32_t)gy, zb = (uint32_t)gz;
       {
-        const float ax = lds_tab[gx + 1], bx = lds_tab[gx + 2];
-        const float ay = lds_tab[kLdsStride + gy + 1], by = lds_tab[kLdsStride + gy + 2];
-        const float az = lds_tab[2 * kLdsStride + gz + 1], bz = lds_tab[2 * kLdsStride + gz + 2];
-        const bool fast = (ax < tx) && !(bx < tx) && (ay < ty) && !(by < ty) && (az < tz) && !(bz < tz);
+        float ax = lds_tab[gx + 1], bx = lds_tab[gx + 2];
+        float ay = lds_tab[kLdsStride + gy + 1], by = lds_tab[kLdsStride + gy + 2];
+        float az = lds_tab[2 * kLdsStride + gz + 1], bz = lds_tab[2 * kLdsStride + gz + 2];
+        // all six in flight together and one test (written as a short-circuit chain the compiler reads them one after
+        // the other behind branches: march +3 %)
+        asm volatile("" : "+v"(ax), "+v"(bx), "+v"(ay), "+v"(by), "+v"(az), "+v"(bz));
+        const bool fast = (((int)(ax < tx) & (int)!(bx < tx)) & ((int)(ay < ty) & (int)!(by < ty)) & ((int)(az < tz) & (int)!(bz < tz))) != 0;
         if (!fast) {
           xb = axis_bits_lds<LDSD>(tx, P.lo[0], P.inv_cell_lds, lds_tab, ok);
           yb = axis_bits_lds<LDSD>(ty, P.lo[1], P.inv_cell_lds, lds_tab + kLdsStride, ok);
@@ -453,6 +456,15 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
       // measured: it removes most loads of a lane but not the wavefront's latency, which is set by the one
       // lane per step that crosses a coarse boundary; 0.277 ms against 0.261 ms without it.)
       uint32_t w1 = 0;
+      // octants of the levels between the grid and the end of the LDS table, formed while the grid entry is on its way
+      // (the walk below is then one add, one load and a flag test per level: march -4 %)
+      uint32_t oct_l[kLdsDepth - kGridLevel];
+#pragma unroll
+      for (int q = 0; q < kLdsDepth - kGridLevel; q++) {
+        const int sh = kLdsDepth - kGridLevel - 1 - q;
+        oct_l[q] = ((xb >> sh) & 1u) | (((yb >> sh) & 1u) << 1) | (((zb >> sh) & 1u) << 2);
+        asm volatile("" : "+v"(oct_l[q]));
+      }
       if (depth >= kGridLevel) {
         const uint32_t cell = ((zb >> (kLdsDepth - kGridLevel)) << (2 * kGridLevel)) | ((yb >> (kLdsDepth - kGridLevel)) << kGridLevel) |
                               (xb >> (kLdsDepth - kGridLevel));
@@ -468,14 +480,16 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
           uint32_t child_idx = g.x & kMask;
           const int lds_end = depth < kLdsDepth ? depth : kLdsDepth;
           bool stopped = false;
-          for (int l = kGridLevel + 1; l <= lds_end; l++) {
-            const int sh = kLdsDepth - l;
-            const uint32_t oct = ((xb >> sh) & 1u) | (((yb >> sh) & 1u) << 1) | (((zb >> sh) & 1u) << 2);
-            uint2 nd = nodes[child_idx + oct];
-            asm volatile("" : "+v"(nd.y));  // keep the colour word in the same 8-byte load (not a second, dependent one)
-            w1 = nd.y;
-            if (!(nd.x & kFlag)) { depth = l; stopped = true; break; }
-            child_idx = nd.x & kMask;
+#pragma unroll
+          for (int q = 0; q < kLdsDepth - kGridLevel; q++) {
+            const int l = kGridLevel + 1 + q;
+            if (!stopped && l <= lds_end) {
+              uint2 nd = nodes[child_idx + oct_l[q]];
+              asm volatile("" : "+v"(nd.y));  // keep the colour word in the same 8-byte load (not a second, dependent one)
+              w1 = nd.y;
+              if (!(nd.x & kFlag)) { depth = l; stopped = true; }
+              else child_idx = nd.x & kMask;
+            }
           }
           if (!stopped && depth > kLdsDepth) {  // below the LDS table's levels
             if (ok) walk_deep_chain<LDSD>(nodes, lds_tab, P, tx, ty, tz, xb, yb, zb, child_idx, depth, w1);
