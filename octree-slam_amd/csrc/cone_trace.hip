@@ -81,6 +81,14 @@ __device__ __forceinline__ float div_rn_midrange(float a, float b) {
   const float e2 = fmaf(-b, q1, a);
   return fmaf(e2, r1, q1);
 }
+// the same with r1 = fma(fma(-b, rcp(b), 1), rcp(b), rcp(b)) in hand
+__device__ __forceinline__ float div_rn_midrange_r(float a, float b, float r1) {
+  const float q0 = a * r1;
+  const float e1 = fmaf(-b, q0, a);
+  const float q1 = fmaf(e1, r1, q0);
+  const float e2 = fmaf(-b, q1, a);
+  return fmaf(e2, r1, q1);
+}
 __device__ __forceinline__ float sqrt_rn_midrange(float x) {
   const float s = __builtin_amdgcn_sqrtf(x);
   const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
@@ -406,13 +414,6 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
       my_steps++;
       const float tx = P.origin[0] + rx, ty = P.origin[1] + ry, tz = P.origin[2] + rz;
       const float pix_size = ray_len * P.pix_scale;
-      // LOD depth (:69); fast form of step_lod when both operands are ordinary positive floats
-      int depth;
-      {
-        const uint32_t ub = f2bits(pix_size);
-        if (ub - P.lod_first <= P.lod_span) depth = (P.size_exp - (int)(ub >> 23)) + ((ub & 0x7FFFFFu) < P.size_man ? 1 : 0);
-        else depth = step_lod(P.size, pix_size);
-      }
       // The grid entry is requested from the GUESSED table cells before the LDS table has answered: the rank of a
       // coordinate among the split planes equals the guess unless the sample lies within rounding of a plane, so the
       // load (the first of the step's dependent round trips) overlaps the table lookups; a lane whose confirmed
@@ -424,6 +425,18 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
       constexpr int kGridShift = kLdsDepth - kGridLevel;
       const uint32_t cell_s = (((uint32_t)gz >> kGridShift) << (2 * kGridLevel)) | (((uint32_t)gy >> kGridShift) << kGridLevel) | ((uint32_t)gx >> kGridShift);
       const uint2 g_s = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(grid) + (cell_s << 3));
+      // LOD depth (:69); fast form of step_lod when both operands are ordinary positive floats.  (After the grid request:
+      // the request needs the position only.)
+      int depth;
+      {
+        const uint32_t ub = f2bits(pix_size);
+        if (ub - P.lod_first <= P.lod_span) depth = (P.size_exp - (int)(ub >> 23)) + ((ub & 0x7FFFFFu) < P.size_man ? 1 : 0);
+        else depth = step_lod(P.size, pix_size);
+      }
+      // the part of the length recurrence's division that depends on the divisor alone (div_rn_midrange: v_rcp + 2 fma)
+      float inv_len = __builtin_amdgcn_rcpf(ray_len);
+      inv_len = fmaf(fmaf(-ray_len, inv_len, 1.0f), inv_len, inv_len);
+      asm volatile("" : "+v"(inv_len));
       // octant bits of every level, per axis
       bool ok = true;
       // the guess itself is confirmed against its two neighbours, S[g-1] < t <= S[g] (one LDS access per axis: the rank IS
@@ -524,7 +537,7 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
       // oct_size / pow(2.0f, depth) (:126): division by a power of two == exact scaling
       const float new_dist = (depth >= -100 && depth <= 100) ? ldexpf(P.size, -depth) : P.size / ldexpf(1.0f, depth);
       if (midrange && depth >= -60) {  // (uniform && per-lane, no branch: both forms are a dozen instructions)
-        const float s = div_rn_midrange(ray_len + new_dist, ray_len);
+        const float s = div_rn_midrange_r(ray_len + new_dist, ray_len, inv_len);
         rx *= s; ry *= s; rz *= s;
         ray_len = sqrt_rn_midrange(dot3(rx, ry, rz, rx, ry, rz));
       } else {
