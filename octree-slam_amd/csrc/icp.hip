@@ -53,23 +53,31 @@ constexpr int kMaxIcpBlocks = SVO_ICP_BLOCKS;
 // (DPP) and across the 8 wavefronts through a 1.7 KB LDS array.  (Earlier forms: 27 x 6 ds_bpermute
 // shuffles per lane were LDS-issue bound; a [27][512] LDS transpose was fast but its 108 KB kept the
 // kernel off every CU that still held raycast workgroups with their 48 KB tables.)
+template <bool WORK>
 __device__ inline void accumulate_block(const float *__restrict__ last_v, const float *__restrict__ last_n,
-                                        const float *__restrict__ cur_v, const float *__restrict__ cur_n, int first, int end,
+                                        const float *cur_v, const float *cur_n, int first, int end,
                                         const CamState *state, int flags, int chain_len, double *__restrict__ partial,
-                                        double (*wsum)[27], float *chain_s) {
+                                        double (*wsum)[27], float *chain_s, int chain_first_arg = 0, float *work_v = nullptr,
+                                        float *work_n = nullptr) {
+  const int chain_first = WORK ? chain_first_arg : 0;
+  // chain_first > 0 (work maps): cur_v / cur_n already carry the level-start transform and chain[0 .. chain_first), as
+  // the reference's maps do after transformVertexMap / transformNormalMap (rgbd_camera.cpp:163-167); only the rest is
+  // applied here.  work_v / work_n != nullptr: the transformed values are stored for the next iteration.  Same
+  // matrices in the same order on the same floats as the replay from the raw maps, so the same bits.
   int nchain = 0;
   bool lost = false;
   if (state) {
     // iteration 0 of a level: the level-start transform is update_trans as the previous level left it
     // and the "tracking lost" flag of the previous level no longer applies
     lost = !(flags & kFlagFirstIter) && state->lost != 0;
-    if (flags & kFlagLevelStart) {
+    if ((flags & kFlagLevelStart) && chain_first == 0) {
       const float *src = (flags & kFlagFirstIter) ? state->update_trans : state->level_start;
       if (threadIdx.x < 16) chain_s[threadIdx.x] = src[threadIdx.x];
       nchain = 1;
     }
-    for (int i = threadIdx.x; i < chain_len * 16; i += kIcpThreads) chain_s[nchain * 16 + i] = (&state->chain[0][0])[i];
-    nchain += chain_len;
+    const int skip = chain_first > 0 ? chain_first - 1 : 0;  // chain_first = 1 + number of chain entries already applied
+    for (int i = threadIdx.x; i < (chain_len - skip) * 16; i += kIcpThreads) chain_s[nchain * 16 + i] = (&state->chain[0][0])[skip * 16 + i];
+    nchain += chain_len - skip;
   }
   __syncthreads();
   double acc[27];
@@ -87,6 +95,10 @@ __device__ inline void accumulate_block(const float *__restrict__ last_v, const 
         v2x = ox; v2y = oy; v2z = oz;
         mat4_mul_point(chain_s + 16 * k, n2x, n2y, n2z, 0.0f, ox, oy, oz);
         n2x = ox; n2y = oy; n2z = oz;
+      }
+      if (WORK && work_v) {
+        work_v[3 * (size_t)p] = v2x; work_v[3 * (size_t)p + 1] = v2y; work_v[3 * (size_t)p + 2] = v2z;
+        work_n[3 * (size_t)p] = n2x; work_n[3 * (size_t)p + 1] = n2y; work_n[3 * (size_t)p + 2] = n2z;
       }
       icp_pixel_terms(v1x, v1y, v1z, n1x, n1y, n1z, v2x, v2y, v2z, n2x, n2y, n2z, acc);
     }
@@ -116,7 +128,19 @@ __global__ __launch_bounds__(kIcpThreads) void icp_accumulate_kernel(
   SVO_HIGH_PRIO();
   __shared__ double wsum[kIcpWaves][27];
   __shared__ float chain_s[(kMaxChain + 1) * 16];
-  accumulate_block(last_v, last_n, cur_v, cur_n, first, end, state, flags, chain_len, partial, wsum, chain_s);
+  accumulate_block<false>(last_v, last_n, cur_v, cur_n, first, end, state, flags, chain_len, partial, wsum, chain_s);
+}
+
+// the same over work maps (launch-chain tracker of one whole camera: camera_track): iteration `it` reads what iteration
+// it - 1 stored and applies one matrix instead of replaying it + 1 (at 1920x1080 the replay is most of the kernel)
+__global__ __launch_bounds__(kIcpThreads) void icp_accumulate_work_kernel(
+    const float *__restrict__ last_v, const float *__restrict__ last_n, const float *cur_v, const float *cur_n, int first, int end,
+    const CamState *__restrict__ state, int flags, int chain_len, int chain_first, float *work_v, float *work_n,
+    double *__restrict__ partial) {
+  SVO_HIGH_PRIO();
+  __shared__ double wsum[kIcpWaves][27];
+  __shared__ float chain_s[(kMaxChain + 1) * 16];
+  accumulate_block<true>(last_v, last_n, cur_v, cur_n, first, end, state, flags, chain_len, partial, wsum, chain_s, chain_first, work_v, work_n);
 }
 
 // photometric terms of the same pixels (own specification, icp_device.hpp rgbd_pixel_terms): the current vertex goes
@@ -511,6 +535,7 @@ struct svoslam_camera {
   float *grad[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   float *tmp_inten = nullptr, *tmp_inten2 = nullptr;
   double *d_partial2 = nullptr;
+  float *work_v = nullptr, *work_n = nullptr;  // launch-chain tracker: the current level's maps as transformed so far
   // one-launch tracker (track_persistent.hip)
   svoslam::TrackSync *d_sync = nullptr;
   double *d_rows = nullptr;
@@ -600,6 +625,8 @@ int camera_destroy(svoslam_camera *c) {
   if (c->d_sync) (void)hipFree(c->d_sync);
   if (c->d_tickets) (void)hipFree(c->d_tickets);
   if (c->d_rows) (void)hipFree(c->d_rows);
+  if (c->work_v) (void)hipFree(c->work_v);
+  if (c->work_n) (void)hipFree(c->work_n);
   delete c;
   return SVOSLAM_OK;
 }
@@ -763,9 +790,18 @@ int camera_track(svoslam_camera *c, hipStream_t s) {
       return SVOSLAM_OK;
     }
   }
+  // Work maps (default; SVOSLAM_TRACK_WORKMAPS=0 replays the chain from the raw maps in every iteration): allocated on
+  // the first chain-tracked frame (cameras served by the one-launch tracker never pay for them), before any capture
+  static const bool work_maps = [] { const char *e = getenv("SVOSLAM_TRACK_WORKMAPS"); return !(e && e[0] == '0'); }();
+  if (has_icp && work_maps && !c->work_v) {
+    const size_t n = (size_t)c->width * (size_t)c->height;
+    SVO_HIP(hipMalloc((void **)&c->work_v, n * 12));
+    SVO_HIP(hipMalloc((void **)&c->work_n, n * 12));
+  }
   GraphKey key;
   key.add((unsigned long long)(c->tracked % 3u)).add((unsigned long long)has_icp)
-     .add((unsigned long long)c->band_first).add((unsigned long long)c->band_rows).add((unsigned long long)c->rgbd);
+     .add((unsigned long long)c->band_first).add((unsigned long long)c->band_rows).add((unsigned long long)c->rgbd)
+     .add((unsigned long long)work_maps);
   auto enqueue = [&]() -> int {
     if (has_icp) {
       for (int level = 2; level >= 0; level--) {  // coarse to fine, :103
@@ -777,8 +813,17 @@ int camera_track(svoslam_camera *c, hipStream_t s) {
         if (blocks2 > kMaxIcpBlocks) blocks2 = kMaxIcpBlocks;
         for (int it = 0; it < kPyramidIters[level]; it++) {
           const int flags = iter_flags(level, it);
-          icp_accumulate_kernel<<<blocks, kIcpThreads, 0, s>>>(a.lv, a.ln, a.cv, a.cn, a.first, end, c->d_state, flags, it,
-                                                               c->d_partial);
+          if (work_maps) {
+            // iteration it > 0 reads what iteration it - 1 stored (level start and chain[0 .. it - 1) applied) and applies
+            // chain[it - 1]; the last iteration of a level stores nothing
+            const bool store = it + 1 < kPyramidIters[level];
+            icp_accumulate_work_kernel<<<blocks, kIcpThreads, 0, s>>>(a.lv, a.ln, it ? c->work_v : a.cv, it ? c->work_n : a.cn, a.first, end,
+                                                                      c->d_state, flags, it, it, store ? c->work_v : nullptr,
+                                                                      store ? c->work_n : nullptr, c->d_partial);
+          } else {
+            icp_accumulate_kernel<<<blocks, kIcpThreads, 0, s>>>(a.lv, a.ln, a.cv, a.cn, a.first, end, c->d_state, flags, it,
+                                                                 c->d_partial);
+          }
           if (c->rgbd)  // rgbd_camera.cpp:126-128 (there commented out): the photometric system of the same estimate
             rgbd_accumulate_kernel<<<blocks2, kIcpThreads, 0, s>>>(c->inten[last][level], c->grad[last][level], a.lv, c->inten[cur][level],
                                                                    a.cv, 0, a.w * a.h, c->fx, c->fy, (float)(c->width / a.w),

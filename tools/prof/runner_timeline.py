@@ -8,6 +8,8 @@ synth = importlib.import_module("octree_slam_amd.synth")
 pl = importlib.import_module("octree_slam_amd.pipeline")
 W, H, D, edge = 640, 480, 12, 4.096
 K = 60
+if os.environ.get("TIMELINE_WORKLOAD") == "cfg4":  # 1920x1080, depth 14, half edge 8.192 m (bench.py --workload cfg4)
+    W, H, D, edge = 1920, 1080, 14, 8.192
 depth, rgb = synth.render_stream(K, W, H, device="cuda")
 views = [pl.ground_truth_view(k, synth) for k in range(K)]
 emu = None
