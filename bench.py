@@ -282,8 +282,10 @@ def main():
                       "frame_period_ms": float(np.diff(a[:, 9]).mean()),
                       "tracker_roofline": {"alg_bytes": icp_bytes, "achieved_GBps": icp_bytes / (trk * 1e-3) / 1e9,
                                            "frac": icp_bytes / (trk * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                           "note": "one-launch tracker keeps the pixels in registers: it READS 48 B per pixel per LEVEL, "
-                                                   "not per iteration; bound by the 19 cross-workgroup hand-offs"}}
+                                           "note": ("one-launch tracker keeps the pixels in registers: it READS 48 B per pixel per LEVEL, "
+                                                    "not per iteration; bound by the 19 cross-workgroup hand-offs") if width * height <= 640 * 480 else
+                                                   ("launch-chain tracker with work maps: 48 B read + 24 B read / 24 B written of the transformed "
+                                                    "maps per pixel per iteration; 38 dependent launches beside the march")}}
     if rank == 0:
         out = {
             "metric": "SLAM frames/sec (fuse+ICP+raycast)", "value": K / elapsed, "unit": "frames/s",

@@ -197,7 +197,10 @@ __global__ __launch_bounds__(kIcpThreads) void rgbd_accumulate_kernel(
 
 // column sums of partial[rows][27] into LDS totals[27] (exact integer-valued sums);
 // blockDim.x / 32 row groups x 32 columns, all loads of a thread independent (<= 8 rows each)
-constexpr int kReduceThreads = 1024;
+#ifndef SVO_REDUCE_THREADS
+#define SVO_REDUCE_THREADS 1024
+#endif
+constexpr int kReduceThreads = SVO_REDUCE_THREADS;  // (256: a workgroup that fits wherever one march workgroup has left -- measured below)
 __device__ inline void reduce_rows(const double *__restrict__ partial, int rows, double (*red)[27], double *totals) {
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5, ngrp = blockDim.x >> 5;
   double s = 0.0;

@@ -131,10 +131,14 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
     // (the one-launch tracker's domain); SVOSLAM_RUNNER_PRIO=0 / 1 overrides.
     const char *pe = getenv("SVOSLAM_RUNNER_PRIO");
     int least = 0, greatest = 0;
-    const bool want = pe ? pe[0] == '1' : (long long)width * height <= 400000ll;
+    const bool small = (long long)width * height <= 400000ll;
+    const bool want = pe ? pe[0] != '0' : small;
+    // '2' (experiment for large images, where the launch-chain tracker bounds the frame): tracker first, map stream second
+    const bool tracker_first = pe && pe[0] == '2';
     const bool prio = want && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
     hipStream_t *ss[5] = {&r->s_maps, &r->s_track, &r->s_prep, &r->s_map[0], &r->s_map[1]};
-    const int pr[5] = {least, (least + greatest) / 2, least, greatest, greatest};
+    const int mid = (least + greatest) / 2;
+    const int pr[5] = {least, tracker_first ? greatest : mid, least, tracker_first ? mid : greatest, tracker_first ? mid : greatest};
     for (int k = 0; k < 5; k++) {
       if (prio) SVO_HIP(hipStreamCreateWithPriority(ss[k], hipStreamNonBlocking, pr[k]));
       else SVO_HIP(hipStreamCreateWithFlags(ss[k], hipStreamNonBlocking));
