@@ -133,7 +133,8 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
     int least = 0, greatest = 0;
     const bool small = (long long)width * height <= 400000ll;
     const bool want = pe ? pe[0] != '0' : small;
-    // '2' (experiment for large images, where the launch-chain tracker bounds the frame): tracker first, map stream second
+    // '2' (large images, where the launch-chain tracker bounds the frame): tracker first, map stream second -- cfg4 769 -> 774
+    // frames/s (means of 3, within the noise), '1' there 761: left off
     const bool tracker_first = pe && pe[0] == '2';
     const bool prio = want && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
     hipStream_t *ss[5] = {&r->s_maps, &r->s_track, &r->s_prep, &r->s_map[0], &r->s_map[1]};
