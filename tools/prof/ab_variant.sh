@@ -11,6 +11,7 @@ for rep in $(seq $REPS); do
     if [ $v = base ]; then cp /tmp/base.so $L; else cp octree-slam_amd/_variants/libsvoslam_hip_$v.so $L; fi
     python tools/prof/render_only.py 100 > gpurun_out/ab/render_${v}_$rep.txt 2>&1
     python bench.py --no-cpu-baseline > gpurun_out/ab/bench_${v}_$rep.json 2>/dev/null
+    if [ -n "$AB_20" ]; then python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/ab/bench20_${v}_$rep.json 2>/dev/null; fi
     if [ -n "$AB_CFG4" ]; then python bench.py --workload cfg4 --steps 40 --no-cpu-baseline > gpurun_out/ab/bench4_${v}_$rep.json 2>/dev/null; fi
   done
 done
