@@ -272,6 +272,10 @@ print("RESULT" + json.dumps([sha(P.image.cpu().numpy()), sha(P.pool.words()), sh
     base = run({})
     assert run({"SVOSLAM_GRAPHS": "1", "SVOSLAM_TRACK_CHAIN": "1"}) == base
     assert run({"SVOSLAM_GRAPHS": "1"}) == base
+    # launch chain by direct launches: with its work maps (default: iteration it applies one matrix to what iteration
+    # it - 1 stored) and with the replay of the whole transform chain from the raw maps
+    assert run({"SVOSLAM_TRACK_CHAIN": "1"}) == base
+    assert run({"SVOSLAM_TRACK_CHAIN": "1", "SVOSLAM_TRACK_WORKMAPS": "0"}) == base
     # the scheduler with deferred commits (commit of frame k+1 computed beside the march of frame k, then applied)
     assert run({"SVOSLAM_RUNNER_DEFERRED": "1"}) == base
     assert run({"SVOSLAM_RUNNER_DEFERRED": "1", "SVOSLAM_RUNNER_LEAD": "0"}) == base
