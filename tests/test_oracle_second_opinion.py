@@ -136,3 +136,178 @@ def test_f2u8_and_lod_helpers():
     assert [f2u8(x) for x in (-1.0, float("nan"), 0.99, 255.9, 256.0, 1e20, float("inf"))] == [0, 0, 0, 255, 0, 255, 255]
     assert ceil_log2_quotient(8.0, 1.0) == 3 and ceil_log2_quotient(8.0, 1.0000001) == 3 and ceil_log2_quotient(8.0, 0.9999999) == 4
     assert ceil_log2_quotient(1.0, 8.0) == -3 and ceil_log2_quotient(3.0, 1.0) == 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# svoFromPointCloud, a second time (/root/reference/src/world/svo/svo.cu:33-66 computeKey, 68-92 key helpers, 108-143
+# splitKeys, 145-174 rightToLeftShift, 182-249 prepassCheckResize, 251-291 splitNodes / expandTreeAtKeys, 334-382 fillNodes
+# (Color256), 384-441 averageChildren, 450-465 mipmapNodes, 641-693 the driver).  Kernels are emulated one thread after the
+# other over plain Python lists; where the reference's result depends on thread order the resolutions of DESIGN.md section 2
+# apply: R1 (duplicate keys in fillNodes: every thread reads the pre-kernel word, the lowest index is the write that stays)
+# and R2 (the last mip pass averages nodes 0..7 into node 0 from the pre-pass pool).  Quirks kept literally: Q1 the
+# finiteness test looks at x, z, z; Q3 `while (r_key >= 15)`; Q5 `(v >> 24) & 0xFF == 0` is `& 0`: all eight children
+# count; Q6 a key shifted down to 1 averages the root tile into node 0; the `!a & b` test of fillNodes never fires.
+# ---------------------------------------------------------------------------------------------------------------------
+BVAL = [0, 1, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4]
+
+
+def depth_from_key(key):
+    r = 0
+    if key & 0x7FFF0000:
+        r += 16; key >>= 16
+    if key & 0x0000FF00:
+        r += 8; key >>= 8
+    if key & 0x000000F0:
+        r += 4; key >>= 4
+    return int((r + BVAL[key] - 1) / 3)      # C division truncates towards zero
+
+
+def first_value_and_shift_down(key):
+    d = depth_from_key(key)
+    value = (key >> (3 * (d - 1))) & 0x7
+    key -= (8 + value) << (3 * (d - 1))
+    key += 1 << (3 * (d - 1))
+    return value, key
+
+
+def compute_key(p, center, tree_depth, edge):
+    if not (np.isfinite(p[0]) and np.isfinite(p[2]) and np.isfinite(p[2])):
+        return 1
+    c = [F(center[0]), F(center[1]), F(center[2])]
+    edge = F(edge)
+    morton = 1
+    for _ in range(tree_depth):
+        morton <<= 3
+        x, y, z = bool(p[0] > c[0]), bool(p[1] > c[1]), bool(p[2] > c[2])
+        morton += int(x) + 2 * int(y) + 4 * int(z)
+        edge = edge / F(2.0)
+        c[0] = c[0] + edge * F(1 if x else -1)
+        c[1] = c[1] + edge * F(1 if y else -1)
+        c[2] = c[2] + edge * F(1 if z else -1)
+    return morton
+
+
+def walk(octree, key):
+    node = child = 0
+    while key != 1:
+        v, key = first_value_and_shift_down(key)
+        node = child + v
+        child = octree[2 * node] & MASK
+    return node, child
+
+
+def svo_from_point_cloud(octree, points, colors, max_depth, center, edge):
+    if not octree:
+        octree.extend([0] * 16)
+        for i in range(8):
+            octree[2 * i + 1] = 127 << 24
+    n = len(points)
+    keys = [compute_key(points[i], center, max_depth, edge) for i in range(n)]
+    # prepassCheckResize
+    left, right = [0] * n, [0] * n
+    for i in range(n):                                   # splitKeys
+        r_key, l_key, temp, node = keys[i], -1, 1, 0
+        while r_key >= 15:
+            v, r_key = first_value_and_shift_down(r_key)
+            temp = (temp << 3) + v
+            node += v
+            if not (octree[2 * node] & FLAG):
+                l_key = temp
+                break
+            node = octree[2 * node] & MASK
+        left[i], right[i] = l_key, r_key
+    codes = []
+    for _ in range(max_depth):
+        valid = sorted(set(k for k in left if k >= 0))   # remove_if(negative), sort, unique
+        if not valid:
+            break
+        codes.append(valid)
+        for i in range(n):                               # rightToLeftShift
+            if left[i] == -1 or right[i] == 1:
+                left[i] = -1
+                continue
+            moved, r_key = first_value_and_shift_down(right[i])
+            right[i] = r_key
+            if r_key == 1:
+                left[i] = -1
+                continue
+            left[i] = (left[i] << 3) + moved
+    num_nodes = len(octree) // 2
+    octree.extend([0] * (16 * sum(len(c) for c in codes)))
+    for c in codes:                                      # expandTreeAtKeys / splitNodes
+        for index, key in enumerate(c):
+            if key == 1:
+                continue
+            node, _ = walk(octree, key)
+            new = num_nodes + 8 * index
+            octree[2 * node] = (1 << 30) + (new & MASK)
+            for off in range(8):
+                octree[2 * (new + off)] = 0
+                octree[2 * (new + off) + 1] = 127 << 24
+        num_nodes += 8 * len(c)
+    # fillNodes (Color256)
+    before = list(octree)
+    for i in reversed(range(n)):                         # R1: the lowest index writes last
+        if keys[i] == 1:
+            continue
+        node, _ = walk(before, keys[i])
+        cur = before[2 * node + 1]
+        a = cur >> 24
+        f1 = F(1) - (F(a) / F(256.0))
+        f2 = F(a) / F(256.0)
+        out = 0
+        for ch in range(3):
+            v = F(int(colors[i][ch])) * f1 + F((cur >> (8 * ch)) & 0xFF) * f2
+            out += (int(v) & 0xFF) << (8 * ch)
+        octree[2 * node + 1] = out + (min(255, a + 2) << 24)
+    # mipmapNodes
+    mk = list(keys)
+    while True:
+        mk = [k for k in mk if depth_from_key(k) != 0]
+        if not mk:
+            break
+        if len(mk) > 100000:
+            mk = [k for j, k in enumerate(mk) if j == 0 or k != mk[j - 1]]   # thrust::unique: adjacent duplicates only
+        snap = list(octree)                                # every thread reads the pre-pass pool (R2)
+        for j in range(len(mk)):                           # averageChildren
+            key = mk[j] >> 3
+            mk[j] = key
+            node, child = walk(snap, key)
+            r = g = b = F(0.0)
+            al = F(0.0)
+            for i in range(8):
+                cv = snap[2 * (child + i) + 1]
+                r += F(cv & 0xFF); g += F((cv >> 8) & 0xFF); b += F((cv >> 16) & 0xFF)
+                al = max(al, F((cv >> 24) & 0xFF))
+            r, g, b = r / F(8), g / F(8), b / F(8)
+            octree[2 * node + 1] = int(r) + (int(g) << 8) + (int(b) << 16) + (int(al) << 24)
+    return octree
+
+
+@pytest.mark.parametrize("depth", [3, 6, 8])
+def test_fusion_second_opinion(oracle, depth):
+    """three insertions into one map: a shell, an overlapping shell with duplicates and rejected (NaN) points, a few points
+    outside the root cube; the whole pool -- links (node numbering), colours, alpha -- word for word"""
+    center, edge = [0.0, 1.5, 0.0], 4.096
+    rng = np.random.default_rng(100 + depth)
+    clouds = []
+    p, c = shell_cloud(700, 1.6, seed=depth)
+    clouds.append((p, c))
+    p2, c2 = shell_cloud(500, 1.55, seed=depth + 50)
+    p2[::7] = p2[3]                                       # duplicates of one point (different colours: R1)
+    p2[5::31, 0] = np.nan                                 # rejected by Q1's test
+    p2[6::41, 1] = np.nan                                 # NOT rejected by it (y is never looked at): comparisons with NaN are false
+    clouds.append((p2, c2))
+    p3 = (rng.uniform(-6, 6, size=(60, 3))).astype(np.float32)   # also outside the 8 m cube
+    clouds.append((p3, rng.integers(0, 256, size=(60, 3), dtype=np.uint8)))
+    pool = oracle.Pool()
+    mine = []
+    for pts, col in clouds:
+        pool.insert_cloud(pts, col, depth, center, edge)
+        svo_from_point_cloud(mine, pts, col, depth, center, edge)
+        ref = pool.words()
+        assert pool.size == len(mine) // 2
+        got = np.array(mine, dtype=np.uint64).astype(np.uint32)
+        bad = np.flatnonzero(got != ref)
+        assert bad.size == 0, (depth, bad[:6], got[bad[:6]], ref[bad[:6]])
+    assert pool.size > 8 * depth
