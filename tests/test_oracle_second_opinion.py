@@ -311,3 +311,116 @@ def test_fusion_second_opinion(oracle, depth):
         bad = np.flatnonzero(got != ref)
         assert bad.size == 0, (depth, bad[:6], got[bad[:6]], ref[bad[:6]])
     assert pool.size > 8 * depth
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# computeICPCost2 and solveCholesky, a second time (/root/reference/src/sensor/localization_kernels.cu:17-18 thresholds,
+# 153-228 computeICPCostsUncorrespondedKernel, 303-326 the driver; src/sensor/rgbd_camera.cpp:193-221 solveCholesky).
+# Per-pixel arithmetic in numpy binary32 scalars in the source's operation order; the reduction -- whose order thrust leaves
+# open -- by resolution R3: every binary32 product enters an exact integer sum as rint(p * 2^20) (A) or rint(p * 2^30)
+# (b), in Python integers here.  Q14 (the rotational rows of G_T are not v x n) and Q15 (floor(n / load_size) partials: the
+# tail pixels are dropped) literal.
+# ---------------------------------------------------------------------------------------------------------------------
+def icp_cost2(lv, ln, cv, cn):
+    h, w, _ = lv.shape
+    n = w * h
+    load = 20 * w // 640
+    limit = (n // load) * load if load > 0 else n
+    lv, ln, cv, cn = (a.reshape(-1, 3) for a in (lv, ln, cv, cn))
+    SA = [[0] * 6 for _ in range(6)]
+    Sb = [0] * 6
+    fin = lambda v: bool(np.isfinite(v[0]) and np.isfinite(v[1]) and np.isfinite(v[2]))
+    dot = lambda a, b: (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]
+    used = 0
+    for p in range(limit):
+        v2, n2, v1, n1 = cv[p], cn[p], lv[p], ln[p]
+        if not fin(v2) or not fin(v1) or v1[2] < F(0.1) or v2[2] < F(0.1) or v1[2] > F(10.0) or v2[2] > F(10.0):
+            continue
+        if not fin(n2) or not fin(n1):
+            continue
+        d = v2 - v1
+        if np.sqrt(dot(d, d)) > F(0.1):
+            continue
+        if dot(n2, n1) < F(0.87):
+            continue
+        z, o = F(0.0), F(1.0)
+        G = [z, -v2[0], -v2[1], -v2[2], z, v2[0], v2[1], v2[2], z, o, z, z, z, o, z, z, z, o]
+        AT = [(G[3 * i] * n1[0] + G[3 * i + 1] * n1[1]) + G[3 * i + 2] * n1[2] for i in range(6)]
+        b = dot(n1, v1 - v2)
+        for i in range(6):
+            for j in range(6):
+                SA[i][j] += round(float(AT[i] * AT[j]) * 2.0 ** 20)
+            Sb[i] += round(float(b * AT[i]) * 2.0 ** 30)
+        used += 1
+    A = np.array([[F(SA[i][j] / 2 ** 20) for j in range(6)] for i in range(6)], F)
+    bb = np.array([F(Sb[i] / 2 ** 30) for i in range(6)], F)
+    return A, bb, used
+
+
+def solve_cholesky(A, b):
+    A = [F(v) for v in np.asarray(A, F).reshape(36)]
+    b = [F(v) for v in np.asarray(b, F)]
+    n = 6
+    LU = [F(0.0)] * 36
+    with np.errstate(all="ignore"):
+        for k in range(n):
+            s = 0.0
+            for p in range(k):
+                s += float(LU[k * n + p] * LU[k * n + p])
+            t = float(A[k * n + k]) - s
+            LU[k * n + k] = F(math.sqrt(t)) if t >= 0.0 else F(np.nan)
+            for i in range(k + 1, n):
+                s = 0.0
+                for p in range(k):
+                    s += float(LU[i * n + p] * LU[k * n + p])
+                LU[i * n + k] = F(np.float64(float(A[i * n + k]) - s) / np.float64(LU[k * n + k]))
+        y = [F(0.0)] * n
+        x = [F(0.0)] * n
+        for i in range(n):
+            s = 0.0
+            for k in range(i):
+                s += float(LU[i * n + k] * y[k])
+            y[i] = F(np.float64(float(b[i]) - s) / np.float64(LU[i * n + i]))
+        for i in range(n - 1, -1, -1):
+            s = 0.0
+            for k in range(i + 1, n):
+                s += float(LU[k * n + i] * x[k])
+            x[i] = F(np.float64(float(y[i]) - s) / np.float64(LU[i * n + i]))
+    return np.array(x, F)
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (96, 40)])
+def test_icp_second_opinion(oracle, w, h):
+    """two frames of a tilted plane a few millimetres and a fraction of a degree apart, with holes, a strip beyond the depth
+    range, pixels that fail the distance and the normal test, and NaN normals; load_size = 2 (w = 64: no tail) and 3 (w = 96,
+    n = 3840 = 1280 x 3: no tail either, so the last pixels count) -- A, b and the solved x bit for bit"""
+    rng = np.random.default_rng(w)
+    fx = fy = 525.0 * w / 640.0
+
+    def frame(shift, tilt):
+        ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+        z = 1.2 + 0.3 * (xs / w) + tilt * (ys / h) + shift
+        d = (z * 1000.0).astype(np.uint16)
+        d[5:9, 7:15] = 0                       # holes
+        d[:, w - 3:] = 12000                   # beyond 10 m
+        v = oracle.vertex_map(d, fx, fy, w, h)
+        return v, oracle.normal_map(v)
+    lv, ln = frame(0.0, 0.10)
+    cv, cn = frame(0.004, 0.11)
+    cv = cv.copy(); cn = cn.copy()
+    cv[20:24, 30:34, 2] += np.float32(0.5)     # fails the distance test
+    cn[30:33, 10:20] = np.float32([0.0, 1.0, 0.0])   # fails the normal test
+    cn[12, 40:44, 1] = np.nan
+    A_ref, b_ref = oracle.icp_cost2(lv, ln, cv, cn)
+    A, b, used = icp_cost2(lv, ln, cv, cn)
+    assert used > w * h // 3
+    assert np.array_equal(A.view(np.uint32), np.asarray(A_ref, F).view(np.uint32)), (A - A_ref)
+    assert np.array_equal(b.view(np.uint32), np.asarray(b_ref, F).view(np.uint32)), (b - b_ref)
+    x_ref = oracle.solve_cholesky(A_ref, b_ref)
+    x = solve_cholesky(A_ref, b_ref)
+    assert np.array_equal(x.view(np.uint32), np.asarray(x_ref, F).view(np.uint32)), (x, x_ref)
+    # and a system that is not positive definite (tracking lost: NaN solution in both)
+    bad = A_ref.copy(); bad[2, 2] = np.float32(-1.0)
+    xb, xb_ref = solve_cholesky(bad, b_ref), oracle.solve_cholesky(bad, b_ref)
+    assert np.isnan(xb).any() and np.array_equal(np.isnan(xb), np.isnan(xb_ref))
+    del rng
