@@ -424,3 +424,73 @@ def test_icp_second_opinion(oracle, w, h):
     xb, xb_ref = solve_cholesky(bad, b_ref), oracle.solve_cholesky(bad, b_ref)
     assert np.isnan(xb).any() and np.array_equal(np.isnan(xb), np.isnan(xb_ref))
     del rng
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# generateVertexMap, generateNormalMap, transformVertexMap / transformNormalMap, a second time
+# (/root/reference/src/sensor/image_kernels.cu:24-52, 104-134, 206-229; glm 0.9.5.4 as vendored: normalize = x *
+# (1 / sqrt(dot)), cross and mat4 * vec4 = (m0 x + m1 y) + (m2 z + m3 w) per type_mat4x4.inl:676-687)
+# ---------------------------------------------------------------------------------------------------------------------
+def vertex_map(depth, fx, fy, img_w, img_h):
+    h, w = depth.shape
+    out = np.full((h, w, 3), np.inf, F)
+    for y in range(h):
+        for x in range(w):
+            d = int(depth[y, x])
+            if d == 0 or d > 15000:
+                continue
+            out[y, x, 0] = F((img_w // w) * x - img_w // 2) * F(d) / F(fx) * F(0.001)     # integer pixel arithmetic (:48)
+            out[y, x, 1] = F(img_h // 2 - (img_h // h) * y) * F(d) / F(fy) * F(0.001)
+            out[y, x, 2] = F(d) * F(0.001)
+    return out
+
+
+def normal_map(v):
+    h, w, _ = v.shape
+    out = np.full((h, w, 3), np.inf, F)
+    with np.errstate(all="ignore"):
+        for y in range(h - 1):
+            for x in range(w - 1):
+                c = v[y, x]
+                a, b = v[y, x + 1] - c, v[y + 1, x] - c
+                cr = np.array([a[1] * b[2] - b[1] * a[2], a[2] * b[0] - b[2] * a[0], a[0] * b[1] - b[0] * a[1]], F)
+                n = -cr
+                sqr = n[0] * n[0] + n[1] * n[1] + n[2] * n[2]
+                out[y, x] = n * (F(1.0) / np.sqrt(sqr))
+    return out
+
+
+def transform(v, m, wcomp):
+    m = np.asarray(m, F).reshape(4, 4)     # m[c] = column c
+    out = np.empty_like(v)
+    flat_in, flat_out = v.reshape(-1, 3), out.reshape(-1, 3)
+    with np.errstate(all="ignore"):
+        for i, p in enumerate(flat_in):
+            r = (m[0] * p[0] + m[1] * p[1]) + (m[2] * p[2] + m[3] * F(wcomp))
+            flat_out[i] = r[:3]
+    return out
+
+
+def bits_equal(a, b):
+    """bit for bit, NaN == NaN whatever its sign and payload (the parity tests' convention: a NaN's sign is not a result)"""
+    a, b = np.ascontiguousarray(a, F), np.ascontiguousarray(b, F)
+    na, nb = np.isnan(a), np.isnan(b)
+    return np.array_equal(na, nb) and np.array_equal(a.view(np.uint32)[~na], b.view(np.uint32)[~nb])
+
+
+def test_maps_second_opinion(oracle):
+    rng = np.random.default_rng(7)
+    w, h = 40, 30
+    depth = rng.integers(400, 6000, size=(h, w)).astype(np.uint16)
+    depth[3:6, 4:9] = 0
+    depth[10, 10] = 15001
+    depth[11, 11] = 15000
+    v_ref = oracle.vertex_map(depth, 525.0 / 16, 525.0 / 16, 640, 480)
+    v = vertex_map(depth, 525.0 / 16, 525.0 / 16, 640, 480)
+    assert bits_equal(v, v_ref)
+    n_ref = oracle.normal_map(v_ref)
+    n = normal_map(v_ref)
+    assert bits_equal(n, n_ref)                    # NaN / inf patterns included
+    m = oracle.mat4_translate(oracle.mat4_rotate_deg(oracle.mat4_identity(), 7.5, [0.2, 1.0, -0.3]), [0.05, -0.02, 0.3])
+    assert bits_equal(transform(v_ref, m, 1.0), oracle.transform_vertex_map(v_ref, m))
+    assert bits_equal(transform(n_ref, m, 0.0), oracle.transform_normal_map(n_ref, m))
