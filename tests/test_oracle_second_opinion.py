@@ -494,3 +494,52 @@ def test_maps_second_opinion(oracle):
     m = oracle.mat4_translate(oracle.mat4_rotate_deg(oracle.mat4_identity(), 7.5, [0.2, 1.0, -0.3]), [0.05, -0.02, 0.3])
     assert bits_equal(transform(v_ref, m, 1.0), oracle.transform_vertex_map(v_ref, m))
     assert bits_equal(transform(n_ref, m, 0.0), oracle.transform_normal_map(n_ref, m))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# subsampleDepth (uint16 and float) and subsample, a second time (/root/reference/src/sensor/image_kernels.cu:236-310):
+# the 5x5 window's exclusive upper ends min(2x + 3, 2W - 1) / min(2y + 3, 2H - 1) (the last input row and column never
+# enter), the depth gate 3 x BILATERAL_SIGMA_DEPTH = 120, float sum / count, conversion to T on the store
+# ---------------------------------------------------------------------------------------------------------------------
+def subsample_depth(img):
+    h2, w2 = img.shape
+    W, H = w2 // 2, h2 // 2
+    is_u16 = img.dtype == np.uint16
+    out = np.zeros((H, W), img.dtype)
+    sigma = F(40.0) * F(3.0)
+    for y in range(H):
+        for x in range(W):
+            center = F(img[2 * y, 2 * x])
+            tx, ty = min(2 * x - 2 + 5, 2 * W - 1), min(2 * y - 2 + 5, 2 * H - 1)
+            s, count = F(0.0), F(0.0)
+            for cy in range(max(0, 2 * y - 2), ty):
+                for cx in range(max(0, 2 * x - 2), tx):
+                    val = F(img[cy, cx])
+                    if abs(val - center) < sigma:
+                        s = s + val
+                        count = count + F(1.0)
+            r = F(0.0) if count == 0 else s / count
+            out[y, x] = f2u16(r) if is_u16 else r
+    return out
+
+
+def f2u16(x):
+    x = float(x)
+    if x != x or x <= 0.0:
+        return 0
+    return int(x) & 0xFFFF if x < 4294967295.0 else 0xFFFF
+
+
+def test_pyramid_second_opinion(oracle):
+    rng = np.random.default_rng(11)
+    w, h = 48, 36
+    d = (1500 + 400 * np.sin(np.arange(w) / 5.0)[None, :] + rng.integers(-60, 60, size=(h, w))).astype(np.uint16)
+    d[4:8, 10:14] = 0            # holes (0 is a value like any other to this kernel)
+    d[20:, 30:] += 900           # a depth edge: the gate excludes the far side
+    assert np.array_equal(subsample_depth(d), oracle.subsample_depth(d))
+    df = d.astype(np.float32) * np.float32(0.37)
+    assert bits_equal(subsample_depth(df), oracle.subsample_depth(df))
+    rgb = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    assert np.array_equal(rgb[::2, ::2][: h // 2, : w // 2], oracle.subsample(rgb))
+    f = rng.normal(size=(h, w)).astype(np.float32)
+    assert bits_equal(f[::2, ::2][: h // 2, : w // 2], oracle.subsample(f))
