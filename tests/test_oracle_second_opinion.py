@@ -543,3 +543,80 @@ def test_pyramid_second_opinion(oracle):
     assert np.array_equal(rgb[::2, ::2][: h // 2, : w // 2], oracle.subsample(rgb))
     f = rng.normal(size=(h, w)).astype(np.float32)
     assert bits_equal(f[::2, ::2][: h // 2, : w // 2], oracle.subsample(f))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RGBDCamera::update, a second time (/root/reference/src/sensor/rgbd_camera.cpp:56-168): the pyramid (filtered depth
+# subsampled in place, maps with the full image size in the pixel arithmetic), levels coarse to fine, the level's copy
+# first transformed by update_trans (levels 1, 0), per iteration computeICPCost2 + solveCholesky, the NaN test that leaves
+# the level, this_trans = Rz Ry Rx T, update_trans = this_trans * update_trans, maps transformed except after a level's last
+# iteration.  Built from the restatements above; the bilateral filter (R4: this build's own expf) and glm's rotate /
+# translate / operator* (pinned by the reference's vendored glm, tests/test_ref_glm.py) are taken from the oracle.
+# ---------------------------------------------------------------------------------------------------------------------
+def track_second_opinion(oracle, depth_prev, depth_cur, fx, fy):
+    H, W = depth_cur.shape
+
+    def pyramid(depth):
+        fd = oracle.bilateral(depth)
+        vs, ns = [], []
+        for i in range(3):
+            v = vertex_map(fd, fx, fy, W, H)
+            vs.append(v); ns.append(normal_map(v))
+            if i != 2:
+                fd = subsample_depth(fd)
+        return vs, ns
+    last_v, last_n = pyramid(depth_prev)
+    cur_v, cur_n = pyramid(depth_cur)
+    update = oracle.mat4_identity()
+    lost = 0
+    I = oracle.mat4_identity()
+    for i in (2, 1, 0):
+        v, n = cur_v[i].copy(), cur_n[i].copy()
+        if i < 2:
+            v, n = transform(v, update, 1.0), transform(n, update, 0.0)
+        iters = (10, 5, 4)[i]
+        for j in range(iters):
+            A, b, _ = icp_cost2(last_v[i], last_n[i], v, n)
+            x = solve_cholesky(A, b)
+            if np.isnan(x).any():
+                lost += 1
+                break
+            rz = oracle.mat4_rotate_deg(I, -x[2] * F(180.0) / F(3.14159), [0.0, 0.0, 1.0])
+            ry = oracle.mat4_rotate_deg(I, -x[1] * F(180.0) / F(3.14159), [0.0, 1.0, 0.0])
+            rx = oracle.mat4_rotate_deg(I, -x[0] * F(180.0) / F(3.14159), [1.0, 0.0, 0.0])
+            t = oracle.mat4_translate(I, [x[3], x[4], x[5]])
+            this = oracle.mat4_mul(oracle.mat4_mul(oracle.mat4_mul(rz, ry), rx), t)
+            update = oracle.mat4_mul(this, update)
+            if j < iters - 1:
+                v, n = transform(v, this, 1.0), transform(n, this, 0.0)
+    return update, lost
+
+
+def test_tracker_second_opinion(oracle):
+    """two 128x96 frames of a tilted, slightly curved surface a few millimetres apart: update_trans after the second frame
+    bit for bit, no level lost; then a second pair whose current frame is empty: every level lost in both"""
+    w, h = 128, 96
+    fx = fy = 525.0 * w / 640.0
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+
+    def depth(shift):
+        z = 1.3 + 0.25 * (xs / w) + 0.12 * (ys / h) + 0.05 * np.sin(xs / 9.0) * np.cos(ys / 7.0) + shift
+        d = (z * 1000.0).astype(np.uint16)
+        d[10:14, 20:30] = 0
+        return d
+    d0, d1 = depth(0.0), depth(0.003)
+    rgb = np.zeros((h, w, 3), np.uint8)
+    cam = oracle.Camera(w, h, fx, fy)
+    cam.update(d0, rgb, 1)
+    cam.update(d1, rgb, 2)
+    ref = cam.last_update()
+    mine, lost = track_second_opinion(oracle, d0, d1, fx, fy)
+    assert lost == 0 and cam.tracking_lost_count() == 0
+    assert bits_equal(mine, ref), (mine, ref)
+    assert not np.array_equal(ref, oracle.mat4_identity())
+    cam2 = oracle.Camera(w, h, fx, fy)
+    cam2.update(d0, rgb, 1)
+    cam2.update(np.zeros_like(d0), rgb, 2)
+    mine2, lost2 = track_second_opinion(oracle, d0, np.zeros_like(d0), fx, fy)
+    assert lost2 == 3 and cam2.tracking_lost_count() == 3
+    assert bits_equal(mine2, cam2.last_update())
