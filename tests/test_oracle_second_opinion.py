@@ -620,3 +620,113 @@ def test_tracker_second_opinion(oracle):
     mine2, lost2 = track_second_opinion(oracle, d0, np.zeros_like(d0), fx, fy)
     assert lost2 == 3 and cam2.tracking_lost_count() == 3
     assert bits_equal(mine2, cam2.last_update())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# svoFromVoxelGrid, a second time (svo.cu:579-639): as the point-cloud driver, except that the keys are SORTED before
+# anything else -- and the colours are not, so fillNodes pairs sorted key i with colour i of the unsorted grid (the
+# reference's own "TODO" territory, kept) -- and the vec4 fillNodes (svo.cu:293-332): value * 256, float blend, (int) of it.
+# ---------------------------------------------------------------------------------------------------------------------
+def svo_from_voxel_grid(octree, centers, colors, max_depth, center, edge):
+    if not octree:
+        octree.extend([0] * 16)
+        for i in range(8):
+            octree[2 * i + 1] = 127 << 24
+    n = len(centers)
+    keys = sorted(compute_key(centers[i], center, max_depth, edge) for i in range(n))
+    left, right = [0] * n, [0] * n
+    for i in range(n):
+        r_key, l_key, temp, node = keys[i], -1, 1, 0
+        while r_key >= 15:
+            v, r_key = first_value_and_shift_down(r_key)
+            temp = (temp << 3) + v
+            node += v
+            if not (octree[2 * node] & FLAG):
+                l_key = temp
+                break
+            node = octree[2 * node] & MASK
+        left[i], right[i] = l_key, r_key
+    codes = []
+    for _ in range(max_depth):
+        valid = sorted(set(k for k in left if k >= 0))
+        if not valid:
+            break
+        codes.append(valid)
+        for i in range(n):
+            if left[i] == -1 or right[i] == 1:
+                left[i] = -1
+                continue
+            moved, r_key = first_value_and_shift_down(right[i])
+            right[i] = r_key
+            if r_key == 1:
+                left[i] = -1
+                continue
+            left[i] = (left[i] << 3) + moved
+    num_nodes = len(octree) // 2
+    octree.extend([0] * (16 * sum(len(c) for c in codes)))
+    for c in codes:
+        for index, key in enumerate(c):
+            if key == 1:
+                continue
+            node, _ = walk(octree, key)
+            new = num_nodes + 8 * index
+            octree[2 * node] = (1 << 30) + (new & MASK)
+            for off in range(8):
+                octree[2 * (new + off)] = 0
+                octree[2 * (new + off) + 1] = 127 << 24
+        num_nodes += 8 * len(c)
+    before = list(octree)
+    for i in reversed(range(n)):
+        if keys[i] == 1:
+            continue
+        node, _ = walk(before, keys[i])
+        cur = before[2 * node + 1]
+        a = cur >> 24
+        f1 = F(1) - (F(a) / F(256.0))
+        f2 = F(a) / F(256.0)
+        out = 0
+        for ch in range(3):
+            nv = F(colors[i][ch]) * F(256.0)
+            v = nv * f1 + F((cur >> (8 * ch)) & 0xFF) * f2
+            out += (int(v) << (8 * ch))
+        octree[2 * node + 1] = (out + (min(255, a + 2) << 24)) & 0xFFFFFFFF
+    mk = list(keys)
+    while True:
+        mk = [k for k in mk if depth_from_key(k) != 0]
+        if not mk:
+            break
+        if len(mk) > 100000:
+            mk = [k for j, k in enumerate(mk) if j == 0 or k != mk[j - 1]]
+        snap = list(octree)
+        for j in range(len(mk)):
+            key = mk[j] >> 3
+            mk[j] = key
+            node, child = walk(snap, key)
+            r = g = b = F(0.0)
+            al = F(0.0)
+            for i in range(8):
+                cv = snap[2 * (child + i) + 1]
+                r += F(cv & 0xFF); g += F((cv >> 8) & 0xFF); b += F((cv >> 16) & 0xFF)
+                al = max(al, F((cv >> 24) & 0xFF))
+            r, g, b = r / F(8), g / F(8), b / F(8)
+            octree[2 * node + 1] = int(r) + (int(g) << 8) + (int(b) << 16) + (int(al) << 24)
+    return octree
+
+
+@pytest.mark.parametrize("depth", [4, 7])
+def test_voxel_grid_fusion_second_opinion(oracle, depth):
+    center, edge = [0.0, 1.5, 0.0], 4.096
+    rng = np.random.default_rng(40 + depth)
+    pool = oracle.Pool()
+    mine = []
+    for k in range(2):
+        pts, _ = shell_cloud(400, 1.2 + 0.2 * k, seed=depth + k)
+        centers = np.concatenate([pts, np.ones((len(pts), 1), np.float32)], axis=1)
+        colors = rng.uniform(0.0, 0.996, size=(len(pts), 4)).astype(np.float32)   # value * 256 stays below 256
+        pool.insert_voxel_grid(centers, colors, depth, center, edge)
+        svo_from_voxel_grid(mine, centers, colors, depth, center, edge)
+        ref = pool.words()
+        assert pool.size == len(mine) // 2
+        got = np.array(mine, dtype=np.uint64).astype(np.uint32)
+        bad = np.flatnonzero(got != ref)
+        assert bad.size == 0, (depth, k, bad[:6], got[bad[:6]], ref[bad[:6]])
