@@ -730,3 +730,56 @@ def test_voxel_grid_fusion_second_opinion(oracle, depth):
         got = np.array(mine, dtype=np.uint64).astype(np.uint32)
         bad = np.flatnonzero(got != ref)
         assert bad.size == 0, (depth, k, bad[:6], got[bad[:6]], ref[bad[:6]])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# extractVoxelGridFromSVO, a second time (svo.cu:497-577 getOccupiedChildren / voxelGridFromKeys, 699-745 the driver):
+# breadth first from the empty key, children kept when their alpha byte exceeds 127, order = the stable compaction's
+# ---------------------------------------------------------------------------------------------------------------------
+def extract_voxel_grid(octree, max_depth, center, edge):
+    nodes = [1]
+    for _ in range(max_depth):
+        nxt = []
+        for key in nodes:
+            t, pointer, has_children = key, 0, 1
+            while t != 1:
+                v, t = first_value_and_shift_down(t)
+                pointer += v
+                has_children = octree[2 * pointer] & FLAG
+                pointer = octree[2 * pointer] & MASK
+            for i in range(8):
+                if has_children and ((octree[2 * (pointer + i) + 1] >> 24) & 0xFF) > 127:
+                    nxt.append((key << 3) + i)
+        nodes = nxt
+    centers = np.zeros((len(nodes), 4), F)
+    colors = np.zeros((len(nodes), 4), F)
+    for idx, key in enumerate(nodes):
+        c = [F(center[0]), F(center[1]), F(center[2])]
+        e = F(edge)
+        node = child = 0
+        while key != 1:
+            pos, key = first_value_and_shift_down(key)
+            node = child + pos
+            child = octree[2 * node] & MASK
+            e = e / F(2.0)
+            c[0] = c[0] + e * F(1 if pos & 1 else -1)
+            c[1] = c[1] + e * F(1 if pos & 2 else -1)
+            c[2] = c[2] + e * F(1 if pos & 4 else -1)
+        val = octree[2 * node + 1]
+        centers[idx] = (c[0], c[1], c[2], F(1.0))
+        colors[idx] = [F((val >> s) & 0xFF) / F(255.0) for s in (0, 8, 16, 24)]
+    return centers, colors
+
+
+def test_extract_second_opinion(oracle):
+    depth, center, edge = 6, [0.0, 1.5, 0.0], 4.096
+    pool = oracle.Pool()
+    for k in range(3):
+        pts, col = shell_cloud(600, 1.0 + 0.3 * k, seed=20 + k)
+        pool.insert_cloud(pts, col, depth, center, edge)
+    words = [int(x) for x in pool.words()]
+    for d in (3, 6):
+        ce_ref, co_ref = pool.extract(d, center, edge)
+        ce, co = extract_voxel_grid(words, d, center, edge)
+        assert len(ce) == len(ce_ref) > 50
+        assert bits_equal(ce, ce_ref) and bits_equal(co, co_ref)
