@@ -783,3 +783,77 @@ def test_extract_second_opinion(oracle):
         ce, co = extract_voxel_grid(words, d, center, edge)
         assert len(ce) == len(ce_ref) > 50
         assert bits_equal(ce, ce_ref) and bits_equal(co, co_ref)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# computeICPCost (the correspondence variant, localization_kernels.cu:56-98 stencil, 100-150 cost kernel, 231-301 driver:
+# compaction in index order, load_size 10, floor(m / 10) partials reduced -- the last m % 10 correspondences are dropped),
+# colorToIntensity (image_kernels.cu:188-198, Q13: blue enters twice, green never) and computePointCloudBoundingBox
+# (image_kernels.cu:60-102 under resolution R10: min / max over the points that pass the x, z, z finiteness test, then merged
+# with the caller's box, whose all-zero corner means "unset")
+# ---------------------------------------------------------------------------------------------------------------------
+def icp_cost_corr(lv, ln, cv, cn):
+    lv, ln, cv, cn = (a.reshape(-1, 3) for a in (lv, ln, cv, cn))
+    fin = lambda v: bool(np.isfinite(v[0]) and np.isfinite(v[1]) and np.isfinite(v[2]))
+    dot = lambda a, b: (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]
+    keep = []
+    with np.errstate(all="ignore"):
+        for p in range(len(lv)):
+            if not (fin(cv[p]) and fin(lv[p]) and fin(cn[p]) and fin(ln[p])):
+                continue
+            d = cv[p] - lv[p]
+            if np.sqrt(dot(d, d)) > F(0.1) or dot(cn[p], ln[p]) < F(0.87):
+                continue
+            keep.append(p)
+    m = len(keep)
+    SA = [[0] * 6 for _ in range(6)]
+    Sb = [0] * 6
+    for p in keep[: (m // 10) * 10]:
+        v2, v1, n = cv[p], lv[p], ln[p]
+        z, o = F(0.0), F(1.0)
+        G = [z, -v2[0], -v2[1], -v2[2], z, v2[0], v2[1], v2[2], z, o, z, z, z, o, z, z, z, o]
+        AT = [(G[3 * i] * n[0] + G[3 * i + 1] * n[1]) + G[3 * i + 2] * n[2] for i in range(6)]
+        b = dot(n, v1 - v2)
+        for i in range(6):
+            for j in range(6):
+                SA[i][j] += round(float(AT[i] * AT[j]) * 2.0 ** 20)
+            Sb[i] += round(float(b * AT[i]) * 2.0 ** 30)
+    A = np.array([[F(SA[i][j] / 2 ** 20) for j in range(6)] for i in range(6)], F)
+    return A, np.array([F(Sb[i] / 2 ** 30) for i in range(6)], F), m
+
+
+def test_small_kernels_second_opinion(oracle):
+    rng = np.random.default_rng(5)
+    w, h = 64, 48
+    fx = fy = 525.0 * w / 640.0
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+
+    def frame(shift):
+        d = ((1.4 + 0.2 * xs / w + 0.1 * ys / h + shift) * 1000.0).astype(np.uint16)
+        d[8:12, 8:20] = 0
+        v = oracle.vertex_map(d, fx, fy, w, h)
+        return v, oracle.normal_map(v)
+    lv, ln = frame(0.0)
+    cv, cn = frame(0.005)
+    cv = cv.copy()
+    cv[30:34, 40:50, 2] += np.float32(0.3)
+    A_ref, b_ref, m_ref = oracle.icp_cost(lv, ln, cv, cn)
+    A, b, m = icp_cost_corr(lv, ln, cv, cn)
+    assert m == m_ref and m % 10 != 0 and m > 1000       # a dropped tail is part of the case
+    assert bits_equal(A, A_ref) and bits_equal(b, b_ref)
+    # colorToIntensity
+    rgb = rng.integers(0, 256, size=(500, 3), dtype=np.uint8)
+    mine = np.array([(F(int(c[0])) / F(255.0) * F(0.299) + F(int(c[2])) / F(255.0) * F(0.587)) + F(int(c[2])) / F(255.0) * F(0.114) for c in rgb], F)
+    assert bits_equal(mine, oracle.color_to_intensity(rgb))
+    # bounding box
+    pts = rng.uniform(-3, 3, size=(300, 3)).astype(np.float32)
+    pts[5] = np.inf
+    pts[17, 0] = np.nan
+    pts[40, 2] = -np.inf
+    ok = np.isfinite(pts[:, 0]) & np.isfinite(pts[:, 2])
+    lo, hi = pts[ok].min(axis=0), pts[ok].max(axis=0)
+    b0, b1 = oracle.point_cloud_bbox(pts)
+    assert bits_equal(b0, lo) and bits_equal(b1, hi)
+    c0, c1 = np.float32([-1.0, -5.0, 0.5]), np.float32([1.0, 0.25, 9.0])
+    b0, b1 = oracle.point_cloud_bbox(pts, c0, c1)
+    assert bits_equal(b0, np.minimum(lo, c0)) and bits_equal(b1, np.maximum(hi, c1))
