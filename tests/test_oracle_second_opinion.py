@@ -857,3 +857,46 @@ def test_small_kernels_second_opinion(oracle):
     c0, c1 = np.float32([-1.0, -5.0, 0.5]), np.float32([1.0, 0.25, 9.0])
     b0, b1 = oracle.point_cloud_bbox(pts, c0, c1)
     assert bits_equal(b0, np.minimum(lo, c0)) and bits_equal(b1, np.maximum(hi, c1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the pose step of RGBDCamera::update (rgbd_camera.cpp:172-173): position = vec3(vec4(position, 1) * update_trans) -- a ROW
+# vector times the matrix, glm's operator*(vec4, mat4): component c = m[c][0] v0 + m[c][1] v1 + m[c][2] v2 + m[c][3] v3 --
+# and orientation = mat3(mat4(orientation) * update_trans), glm's mat4 * mat4: column c = A0 B[c][0] + A1 B[c][1] + A2 B[c][2] +
+# A3 B[c][3], both summed left to right (type_mat4x4.inl)
+# ---------------------------------------------------------------------------------------------------------------------
+def pose_step(position, orientation, update):
+    U = np.asarray(update, F).reshape(4, 4)                 # U[c] = column c
+    v = [F(position[0]), F(position[1]), F(position[2]), F(1.0)]
+    pos = np.array([((U[c][0] * v[0] + U[c][1] * v[1]) + U[c][2] * v[2]) + U[c][3] * v[3] for c in range(3)], F)
+    O4 = np.zeros((4, 4), F)
+    O4[3, 3] = F(1.0)
+    O4[:3, :3] = np.asarray(orientation, F).reshape(3, 3)   # columns of the mat3
+    R = np.zeros((4, 4), F)
+    for c in range(4):
+        R[c] = ((O4[0] * U[c][0] + O4[1] * U[c][1]) + O4[2] * U[c][2]) + O4[3] * U[c][3]
+    return pos, R[:3, :3].reshape(9).copy()
+
+
+def test_pose_step_second_opinion(oracle):
+    w, h = 128, 96
+    fx = fy = 525.0 * w / 640.0
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+
+    def depth(shift, tilt):
+        z = 1.3 + (0.25 + tilt) * (xs / w) + 0.12 * (ys / h) + 0.05 * np.sin(xs / 9.0) * np.cos(ys / 7.0) + shift
+        return (z * 1000.0).astype(np.uint16)
+    frames = [depth(0.0, 0.0), depth(0.003, 0.002), depth(0.005, 0.004)]
+    rgb = np.zeros((h, w, 3), np.uint8)
+    cam = oracle.Camera(w, h, fx, fy)
+    pos, ori = np.zeros(3, F), np.array([1, 0, 0, 0, 1, 0, 0, 0, 1], F)
+    cam.update(frames[0], rgb, 1)
+    p_ref, o_ref = cam.pose()
+    assert bits_equal(p_ref, pos) and bits_equal(o_ref, ori)
+    for k in (1, 2):
+        cam.update(frames[k], rgb, k + 1)
+        U = cam.last_update()
+        pos, ori = pose_step(pos, ori, U)
+        p_ref, o_ref = cam.pose()
+        assert bits_equal(p_ref, pos) and bits_equal(o_ref, ori), (k, pos, p_ref, ori, o_ref)
+    assert not np.array_equal(ori, np.array([1, 0, 0, 0, 1, 0, 0, 0, 1], F))
