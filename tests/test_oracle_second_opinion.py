@@ -900,3 +900,27 @@ def test_pose_step_second_opinion(oracle):
         p_ref, o_ref = cam.pose()
         assert bits_equal(p_ref, pos) and bits_equal(o_ref, ori), (k, pos, p_ref, ori, o_ref)
     assert not np.array_equal(ori, np.array([1, 0, 0, 0, 1, 0, 0, 0, 1], F))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# createCubeMesh of voxelGridToMesh, a second time (/root/reference/src/world/voxelization/voxelization.cu:184-221): one cube
+# per voxel, vertices cube * scale + centre (one multiply, one add), the colour repeated per coordinate, indices offset by
+# idx * (number of cube INDICES), as written
+# ---------------------------------------------------------------------------------------------------------------------
+def test_cube_mesh_second_opinion(oracle):
+    rng = np.random.default_rng(3)
+    n = 37
+    centers = rng.uniform(-2, 2, size=(n, 4)).astype(np.float32)
+    colors = rng.uniform(0, 1, size=(n, 4)).astype(np.float32)
+    cube_vbo = rng.uniform(-1, 1, size=24).astype(np.float32)       # 8 vertices
+    cube_nbo = rng.uniform(-1, 1, size=24).astype(np.float32)
+    cube_ibo = rng.integers(0, 8, size=36).astype(np.int32)
+    scale = np.float32(0.0137)
+    vbo, ibo, nbo, cbo = oracle.voxel_grid_to_mesh(centers, colors, scale, cube_vbo, cube_ibo, cube_nbo)
+    comp = np.arange(24) % 3
+    my_vbo = (cube_vbo[None, :] * scale + centers[:, comp]).astype(np.float32).reshape(-1)
+    my_cbo = colors[:, comp].reshape(-1)
+    my_nbo = np.tile(cube_nbo, n)
+    my_ibo = (cube_ibo[None, :] + (np.arange(n, dtype=np.int32) * 36)[:, None]).reshape(-1)
+    assert bits_equal(vbo, my_vbo) and bits_equal(cbo, my_cbo) and bits_equal(nbo, my_nbo)
+    assert np.array_equal(ibo, my_ibo)
