@@ -310,7 +310,7 @@ def main():
                        "tracking_lost_levels": P.cam.tracking_lost_count()},
             "roofline": {"bound": "hbm", "kernel": "cone_trace_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "limiter": "dependent-load latency of the longest rays (~1.2 us per march step on the critical path; the walk "
+                         "limiter": "dependent-load latency of the longest rays (~1.0 us per march step on the critical path; the walk "
                                     "is L2-resident: counter traffic is ~0.03x the algorithmic bytes), not HBM bandwidth",
                          "alg_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                          "steps_per_launch": steps / K, "levels_per_launch": levels / K},
