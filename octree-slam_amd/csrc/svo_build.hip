@@ -605,6 +605,7 @@ constexpr int kFillThreads = SVO_FILL_THREADS;  // leaves per workgroup.  Larger
 #else
 #define FILL_STAMP(k)
 #endif
+template <int MAXD>  // levels a lane keeps in registers: 12 for pools of depth <= 12 (57 VGPRs: four workgroups per CU), 16 otherwise (65: three)
 __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 *__restrict__ skey, const u32 *__restrict__ sidx, int n,
                                                              int depth, const unsigned char *__restrict__ leaf_t,
                                                              const unsigned char *__restrict__ colors, u32 *__restrict__ pool,
@@ -736,16 +737,16 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
     }
   }
   // walk to the leaf (fillNodes, svo.cu:291-382), remembering the owned nodes and their child tiles
-  u32 node_at[SVOSLAM_MAX_DEPTH], child_at[SVOSLAM_MAX_DEPTH];
+  u32 node_at[MAXD], child_at[MAXD];
 #pragma unroll
-  for (int l = 0; l < SVOSLAM_MAX_DEPTH; l++) { node_at[l] = 0; child_at[l] = 0; }
+  for (int l = 0; l < MAXD; l++) { node_at[l] = 0; child_at[l] = 0; }
   if (head) {
     // duplicates: the head of a run of equal keys is the lowest point index (stable sort)
     const unsigned char *v = colors + 3 * (size_t)point;
     const unsigned char cr = v[0], cg = v[1], cb = v[2];  // in flight during the walk
     u32 base = 0, node = 0;
 #pragma unroll
-    for (int lvl = 1; lvl <= SVOSLAM_MAX_DEPTH; lvl++) {
+    for (int lvl = 1; lvl <= MAXD; lvl++) {
       if (lvl <= depth) {
         node = base + ((u32)(key >> (3 * (depth - lvl))) & 7u);
         if (lvl == link_level) pool[2 * (size_t)node] = kFlag + (frontier_child & kMask);
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   __syncthreads();
   FILL_STAMP(4)
 #pragma unroll
-  for (int d = SVOSLAM_MAX_DEPTH - 1; d >= 1; d--) {
+  for (int d = MAXD - 1; d >= 1; d--) {
     if (d < depth) {
       u32 wrote = kNoStraddler;
       if (head && c < d) {  // this lane owns its level-d prefix
@@ -1573,7 +1574,10 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
       split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
                                                          ws->rec_pass.as<unsigned char>(), small_bucket_base(ws), small_counts(ws),
                                                          pool->d_data, pool->d_size, depth, grid_dirty, deferred ? small_n0(ws) : nullptr, 0);
-    fill_mip_local_kernel<<<xcd_grid(fill_tiles), kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
+    if (depth <= 12) fill_mip_local_kernel<12><<<xcd_grid(fill_tiles), kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
+                                                                   grid_dirty, shadow, epoch, apply_nodes, ws->rec_key.as<u64>(),
+                                                                   small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr);
+    else fill_mip_local_kernel<16><<<xcd_grid(fill_tiles), kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
                                                                    grid_dirty, shadow, epoch, apply_nodes, ws->rec_key.as<u64>(),
                                                                    small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr);
     mip_straddle_kernel<<<1, kStradThreads, 0, stream>>>(pool->d_data, strad, fill_tiles, depth, small_counts(ws), pool->d_size, grid_dirty,
