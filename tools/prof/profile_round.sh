@@ -95,7 +95,7 @@ echo "== cache counters of the march alone (standalone renders of the 100-frame 
 CC=${P}_cone_trace_cache_counters.txt
 echo "# rocprofv3 --pmc <counters> --kernel-trace -- python tools/prof/render_only.py 100 ; cone_trace_kernel launches only; mean per launch" > $CC
 i=0
-for c in "TCP_TOTAL_CACHE_ACCESSES_sum" "TCP_TCC_READ_REQ_sum" "TCC_HIT_sum" "TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_INSTS_VALU SQ_WAVE_CYCLES" "TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum"; do   # (the UTCL1 translation counters time out under rocprofv3 on this pool: left out)
+for c in "TCP_TOTAL_CACHE_ACCESSES_sum" "TCP_TCC_READ_REQ_sum" "TCC_HIT_sum" "TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_INSTS_VALU SQ_WAVE_CYCLES" "TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum" "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum"; do   # (the last pass sometimes runs into its 100 s limit on this pool: "pass ... failed" in the file then)
   i=$((i+1)); D=$SCR/cc_$i; mkdir -p $D
   timeout 100 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $D -o p -- python $R/tools/prof/render_only.py 100 > $SCR/cc.log 2>&1 || { echo "pass $c failed" >> $CC; tail -2 $SCR/cc.log; }
   f=$(find $D -name "*counter_collection.csv" | sort | tail -1)
