@@ -43,8 +43,10 @@ namespace svoslam {
 // ----------------------------------------------------------------------------
 constexpr int kIcpThreads = 512;   // 8 wavefronts per workgroup
 constexpr int kIcpWaves = kIcpThreads / kWave;
+// workgroups of an accumulate launch (cap).  cfg4 (1080p, launch chain with work maps), frames/s on one box, means of 3:
+// 256 -> 768, 384 -> 790, 512 -> 771 (before the work maps: 256 -> 721, 512 -> 735, 1024 -> 696, 2048 -> 637)
 #ifndef SVO_ICP_BLOCKS
-#define SVO_ICP_BLOCKS 256
+#define SVO_ICP_BLOCKS 384
 #endif
 constexpr int kMaxIcpBlocks = SVO_ICP_BLOCKS;
 
