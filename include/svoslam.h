@@ -354,6 +354,20 @@ int svoslam_cone_trace_release(void *stream, int32_t all_streams);
  * _read waits for the logged launches, returns the summed kernel time and their number, and clears the log. */
 int svoslam_cone_trace_timing(int32_t enable);
 int svoslam_cone_trace_timing_read(float *h_ms_sum, int32_t *h_launches);
+/* The same for every stage of the frame (bench.py's per-stage rooflines; startTiming / stopTiming of
+ * src/utils/timing_utils.cu:11-32 applied per stage): bit s of `mask` turns stage s on -- its launches are bracketed by
+ * a pair of HIP events on the stream they run on (~2.6 us of that stream per record).  svoslam_stage_timing clears
+ * every log; _read waits for the logged pairs of one stage, returns their summed duration and number, clears that log.
+ * svoslam_cone_trace_timing(e) == turning SVOSLAM_STAGE_MARCH on / off. */
+#define SVOSLAM_STAGE_MARCH 0        /* cone_trace_kernel alone */
+#define SVOSLAM_STAGE_TRACKER 1      /* the 19 ICP iterations of a frame (one launch, or the launch chain) */
+#define SVOSLAM_STAGE_FUSE_SORT 2    /* keys (+ back-projection in the frame loop) + radix sort */
+#define SVOSLAM_STAGE_FUSE_PLAN 3    /* split planning (+ the early tile initialisation) */
+#define SVOSLAM_STAGE_FUSE_COMMIT 4  /* splits, leaf blend, mip levels */
+#define SVOSLAM_STAGE_MAPS 5         /* bilateral filter + vertex / normal pyramids */
+#define SVOSLAM_STAGE_COUNT 6
+int svoslam_stage_timing(uint32_t mask);
+int svoslam_stage_timing_read(int32_t stage, float *h_ms_sum, int32_t *h_pairs);
 
 /* ------------------------------------------------------------------------
  * Sensor image kernels (include/octree_slam/sensor/image_kernels.h:21-55,

@@ -145,6 +145,8 @@ SIGNATURES = {
     "svoslam_cone_trace_release": (C.c_int, [_vp, _i32]),
     "svoslam_cone_trace_timing": (C.c_int, [_i32]),
     "svoslam_cone_trace_timing_read": (C.c_int, [_fp, C.POINTER(_i32)]),
+    "svoslam_stage_timing": (C.c_int, [C.c_uint32]),
+    "svoslam_stage_timing_read": (C.c_int, [_i32, _fp, C.POINTER(_i32)]),
     "svoslam_generate_vertex_map": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _f32, _i32, _i32, _vp]),
     "svoslam_generate_vertex_map_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _vp]),
     "svoslam_generate_normal_map": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
@@ -691,6 +693,25 @@ def cone_trace_timing_read():
     """(summed kernel ms, launches) since the last read; blocking"""
     ms, n = C.c_float(0), C.c_int32(0)
     check(lib().svoslam_cone_trace_timing_read(C.byref(ms), C.byref(n)))
+    return float(ms.value), int(n.value)
+
+
+STAGE_MARCH, STAGE_TRACKER, STAGE_FUSE_SORT, STAGE_FUSE_PLAN, STAGE_FUSE_COMMIT, STAGE_MAPS = range(6)   # SVOSLAM_STAGE_*
+STAGE_NAMES = ("march", "tracker", "fuse_sort", "fuse_plan", "fuse_commit", "maps")
+
+
+def stage_timing(stages):
+    """HIP events around the launches of the given stages (iterable of STAGE_*) from now on; clears every log"""
+    mask = 0
+    for s in stages:
+        mask |= 1 << int(s)
+    check(lib().svoslam_stage_timing(mask))
+
+
+def stage_timing_read(stage):
+    """(summed ms, bracketed launches / launch groups) of one stage since the last read; blocking"""
+    ms, n = C.c_float(0), C.c_int32(0)
+    check(lib().svoslam_stage_timing_read(int(stage), C.byref(ms), C.byref(n)))
     return float(ms.value), int(n.value)
 
 

@@ -10,6 +10,7 @@
 #include "mesh.hpp"
 #include "frame_io.hpp"
 #include "pool_grid.hpp"
+#include "stage_timing.hpp"
 #include "svo_build.hpp"
 #include "workspace.hpp"
 
@@ -351,11 +352,21 @@ int svoslam_cone_trace_svo_band(uint8_t *d_pos, int32_t width, int32_t height, i
 }
 
 int svoslam_cone_trace_release(void *stream, int32_t all_streams) { return cone_trace_release(S(stream), all_streams != 0); }
-int svoslam_cone_trace_timing(int32_t enable) { return cone_trace_timing(enable); }
+int svoslam_cone_trace_timing(int32_t enable) {
+  const unsigned bit = 1u << kStageMarch, m = stage_timing_mask();
+  return stage_timing(enable ? (m | bit) : (m & ~bit));
+}
 int svoslam_cone_trace_timing_read(float *h_ms_sum, int32_t *h_launches) {
   int n = 0;
-  const int rc = cone_trace_timing_read(h_ms_sum, &n);
+  const int rc = stage_timing_read(kStageMarch, h_ms_sum, &n);
   if (h_launches) *h_launches = n;
+  return rc;
+}
+int svoslam_stage_timing(uint32_t mask) { return stage_timing(mask); }
+int svoslam_stage_timing_read(int32_t stage, float *h_ms_sum, int32_t *h_pairs) {
+  int n = 0;
+  const int rc = stage_timing_read(stage, h_ms_sum, &n);
+  if (h_pairs) *h_pairs = n;
   return rc;
 }
 

@@ -27,6 +27,7 @@
 
 #include "cone_trace.hpp"
 #include "pool_grid.hpp"
+#include "stage_timing.hpp"
 #include "workspace.hpp"
 
 namespace svoslam {
@@ -602,47 +603,6 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
   }
 }
 
-// ---- optional HIP-event timing of the trace kernel alone (bench.py roofline) ----
-static std::mutex g_timing_mu;        // renders may be enqueued from several host threads / on several streams
-static bool g_timing = false;
-static std::vector<hipEvent_t> g_ev;  // pairs (start, stop), one per traced launch since the last read
-static size_t g_ev_used = 0;
-
-int cone_trace_timing(int enable) {
-  std::lock_guard<std::mutex> lock(g_timing_mu);
-  g_timing = enable != 0;
-  g_ev_used = 0;
-  return SVOSLAM_OK;
-}
-
-int cone_trace_timing_read(float *ms_sum, int *launches) {
-  if (!ms_sum || !launches) return SVOSLAM_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(g_timing_mu);
-  float total = 0.0f;
-  for (size_t i = 0; i + 1 < g_ev_used; i += 2) {
-    SVO_HIP(hipEventSynchronize(g_ev[i + 1]));
-    float ms = 0.0f;
-    SVO_HIP(hipEventElapsedTime(&ms, g_ev[i], g_ev[i + 1]));
-    total += ms;
-  }
-  *ms_sum = total;
-  *launches = (int)(g_ev_used / 2);
-  g_ev_used = 0;
-  return SVOSLAM_OK;
-}
-
-static int timing_event(hipStream_t stream) {
-  std::lock_guard<std::mutex> lock(g_timing_mu);
-  if (!g_timing) return SVOSLAM_OK;
-  if (g_ev_used == g_ev.size()) {
-    hipEvent_t e;
-    SVO_HIP(hipEventCreate(&e));
-    g_ev.push_back(e);
-  }
-  SVO_HIP(hipEventRecord(g_ev[g_ev_used++], stream));
-  return SVOSLAM_OK;
-}
-
 // tile -> XCD mapping of a render of tiles_x x tiles_y workgroup tiles; returns the number of workgroups to launch
 static unsigned xcd_mapping(TraceParams &P, int tiles_x, int tiles_y) {
   constexpr int kResidentTiles = 1024;  // 256 CUs x 4 workgroups of 512 threads
@@ -676,6 +636,7 @@ static int accel_for_stream(hipStream_t stream, StreamAccel **out) {
 
 // frees the acceleration buffer of one stream (nullptr: of every stream); the caller has synchronised the stream(s)
 int cone_trace_release(hipStream_t stream, bool all) {
+  if (!all) pool_accel_forget_stream(stream);  // no pool's grid is ordered behind a stream that is going away
   std::lock_guard<std::mutex> lock(g_accel_mu);
   if (all) {
     for (auto &kv : g_accel) kv.second->buf.release();
@@ -744,7 +705,8 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   StreamAccel *sa = nullptr;
   SVO_TRY(accel_for_stream(stream, &sa));
   DeviceBuffer &accel = sa->buf;
-  PoolAccel *pa = pool_accel_find(d_octree);
+  const std::shared_ptr<PoolAccel> pa_hold = pool_accel_find(d_octree);  // held until the launches below are enqueued
+  PoolAccel *pa = pa_hold.get();
 #ifdef SVO_FORCE_GRID8
   const bool large = true;
 #else
@@ -771,7 +733,7 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   }
   sa->tables_valid = true; sa->tables_at = d_table; sa->lds_depth = P.lds_depth; sa->size = size;
   for (int k = 0; k < 3; k++) sa->center[k] = center[k];
-  SVO_TRY(timing_event(stream));
+  SVO_TRY(stage_event(kStageMarch, stream));
   uchar4 *out = reinterpret_cast<uchar4 *>(d_pos);
   const bool carry = (mode & 0xFF) == SVOSLAM_RENDER_CARRY;
   if (P.lds_depth == 11 && large) {
@@ -791,7 +753,7 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
     if (carry) cone_trace_kernel<true, 12, kTraceThreads12, kGridLevelLarge><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
     else cone_trace_kernel<false, 12, kTraceThreads12, kGridLevelLarge><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
   }
-  SVO_TRY(timing_event(stream));
+  SVO_TRY(stage_event(kStageMarch, stream));
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
 }

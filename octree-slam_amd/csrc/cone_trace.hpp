@@ -7,9 +7,6 @@ namespace svoslam {
 int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int rows, float fov, const float view[16],
                    const uint32_t *d_octree, const float center[3], float size, int mode, unsigned long long *d_steps,
                    hipStream_t stream);
-// HIP-event timing of the trace kernel alone, on the stream it is launched on (roofline measurement)
-int cone_trace_timing(int enable);
-int cone_trace_timing_read(float *ms_sum, int *launches);  // blocking; resets the log
 // frees the per-stream acceleration buffer(s); the caller has synchronised the stream(s)
 int cone_trace_release(hipStream_t stream, bool all);
 }  // namespace svoslam

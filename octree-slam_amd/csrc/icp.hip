@@ -31,6 +31,7 @@
 #include "icp_device.hpp"
 #include "image_kernels.hpp"
 #include "track_persistent.hpp"
+#include "stage_timing.hpp"
 #include "wave_rank.hpp"
 
 namespace svoslam {
@@ -483,21 +484,24 @@ __global__ void cam_frame_end_kernel(CamState *st, int apply_update) {
 // IMAGES, independent of every earlier pose.  Only :172-173 (position, orientation *= update_trans) chain the frames.
 // So frames can be tracked in any order, on any GPU: delta_export_kernel hands out a frame's update_trans (+ the number of
 // pyramid levels it abandoned), cam_apply_delta_kernel is :172-173 + main.cpp:40 for a matrix from anywhere.
-constexpr int kDeltaFloats = 20;  // update_trans[16], levels lost (int bits), 3 pad: 80 bytes per frame
-__global__ void delta_export_kernel(CamState *st, float *__restrict__ out) {
+constexpr int kDeltaFloats = 20;  // update_trans[16], levels lost (int bits), give-up code of the one-launch tracker (int bits; 0 = none), 2 pad: 80 bytes per frame
+__global__ void delta_export_kernel(CamState *st, const TrackSync *__restrict__ sy, float *__restrict__ out) {
   const int e = (int)threadIdx.x;
   if (blockIdx.x || e >= kDeltaFloats) return;
   float v = 0.0f;
   if (e < 16) v = st->update_trans[e];
   else if (e == 16) v = __int_as_float(st->tracking_lost_count);
+  else if (e == 17) v = __int_as_float((int)sy->fail);  // a timed-out hand-off travels with the record: the pose camera reports it
   out[e] = v;
   if (e == 16) st->tracking_lost_count = 0;  // a delta camera counts per frame
 }
 
-__global__ void cam_apply_delta_kernel(CamState *st, const float *__restrict__ delta) {
+__global__ void cam_apply_delta_kernel(CamState *st, TrackSync *__restrict__ sy, const float *__restrict__ delta) {
   SVO_HIGH_PRIO();
   if (threadIdx.x || blockIdx.x) return;
   if (delta) {
+    const int fail = __float_as_int(delta[17]);
+    if (fail != 0) sy->fail = (unsigned)fail;  // surfaces from this camera's next readback (check_tracker_health)
     float m[16];
     for (int i = 0; i < 16; i++) { m[i] = delta[i]; st->update_trans[i] = m[i]; }
     st->tracking_lost_count += __float_as_int(delta[16]);
@@ -676,7 +680,10 @@ int camera_prepare(svoslam_camera *c, const uint16_t *d_depth, const uint8_t *d_
   const int set = (int)(c->prepared % 3u);
   GraphKey key;
   key.add(d_depth).add((unsigned long long)set).add(c->rgbd ? d_rgb : nullptr);
-  SVO_TRY(c->g_prep.run(key, s, [&]() -> int { return enqueue_preprocess(c, d_depth, d_rgb, set, s); }));
+  {
+    StageScope timed(kStageMaps, s);
+    SVO_TRY(c->g_prep.run(key, s, [&]() -> int { return enqueue_preprocess(c, d_depth, d_rgb, set, s); }));
+  }
   c->prepared++;
   return SVOSLAM_OK;
 }
@@ -775,6 +782,7 @@ static int track_one_launch(svoslam_camera *c, hipStream_t s) {
     SVO_TRY(track_persistent_capacity(s, &c->capacity));
     c->cap_stream = s;
   }
+  if (c->capacity < 2) return 1;  // no room for a solver and a worker workgroup on this stream's CUs: the launch chain
   SVO_TRY(track_persistent_plan(A, c->capacity));
   if (A.slots[0] > kTrkSlots && !track_one_launch_forced()) return 1;  // caller falls back to the launch chain
   return track_persistent_launch(c->d_state, c->d_sync, c->d_tickets, c->d_rows, A, s);
@@ -785,6 +793,7 @@ int camera_track(svoslam_camera *c, hipStream_t s) {
   if (c->tracked >= c->prepared) return SVOSLAM_ERR_INVALID_ARG;  // nothing prepared
   const bool has_icp = c->tracked >= 1;
   const int ring_slot = (int)(c->tracked & 3u);
+  StageScope timed(has_icp ? kStageTracker : -1, s);  // (the first frame has no ICP: not a tracker sample)
   if (has_icp && !track_chain_forced() && !c->rgbd) {
     const int rc = track_one_launch(c, s);
     if (rc < 0) return rc;
@@ -881,7 +890,7 @@ int camera_pair_delta(svoslam_camera *c, const uint16_t *d_depth_prev, const uin
   const int rc = camera_track(c, s);
   c->prepared = 0; c->tracked = 0; c->frame_has_icp = false;
   SVO_TRY(rc);
-  delta_export_kernel<<<1, 64, 0, s>>>(c->d_state, d_delta);
+  delta_export_kernel<<<1, 64, 0, s>>>(c->d_state, c->d_sync, d_delta);
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
 }
@@ -902,7 +911,7 @@ int camera_apply_delta(svoslam_camera *c, const float *d_delta, long long timest
   c->have_stamp = true;
   c->latest_stamp = timestamp;
   if (processed) *processed = 1;
-  cam_apply_delta_kernel<<<1, 64, 0, s>>>(c->d_state, c->tracked >= 1 ? d_delta : nullptr);
+  cam_apply_delta_kernel<<<1, 64, 0, s>>>(c->d_state, c->d_sync, c->tracked >= 1 ? d_delta : nullptr);
   SVO_LAUNCH_CHECK();
   c->ring_slot = (int)(c->tracked & 3u);
   c->tracked++;

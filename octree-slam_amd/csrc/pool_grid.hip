@@ -11,16 +11,28 @@ namespace {
 // Keyed by the address of the node memory (not of the caller's svoslam_pool struct, which the compatibility shim
 // rebuilds on the stack for every call): that is also what a render is given.
 std::mutex g_mu;
-std::map<const uint32_t *, std::unique_ptr<PoolAccel>> g_accel;
+std::map<const uint32_t *, std::shared_ptr<PoolAccel>> g_accel;
 }  // namespace
+
+PoolAccel::~PoolAccel() {
+  grid.release();
+  shadow.release();
+  for (uint32_t *d : d_dirty) if (d) (void)hipFree(d);
+  if (ev_order) (void)hipEventDestroy(ev_order);
+}
+
+void pool_accel_forget_stream(hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  for (auto &kv : g_accel)
+    if (kv.second->last_stream == stream) kv.second->last_stream = nullptr;
+}
 
 void pool_accel_register(svoslam_pool *pool) {
   if (!pool || !pool->d_data) return;
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_accel.find(pool->d_data);
   if (it == g_accel.end()) {
-    std::unique_ptr<PoolAccel> pa(new PoolAccel());
-    g_accel.emplace(pool->d_data, std::move(pa));
+    g_accel.emplace(pool->d_data, std::make_shared<PoolAccel>());
   } else {
     it->second->valid = false;  // freshly initialised memory at a recycled address: whatever the grid holds is stale
   }
@@ -30,17 +42,12 @@ void pool_accel_rebind(const uint32_t *old_data, const uint32_t *new_data) {
   if (!new_data || old_data == new_data) return;
   std::lock_guard<std::mutex> lock(g_mu);
   auto stale = g_accel.find(new_data);
-  if (stale != g_accel.end()) {  // an entry left behind by memory freed without svoslam_pool_free
-    stale->second->grid.release();
-    stale->second->shadow.release();
-    for (uint32_t *d : stale->second->d_dirty) if (d) (void)hipFree(d);
-    g_accel.erase(stale);
-  }
+  if (stale != g_accel.end()) g_accel.erase(stale);  // an entry left behind by memory freed without svoslam_pool_free
   auto it = old_data ? g_accel.find(old_data) : g_accel.end();
   if (it == g_accel.end()) {
-    g_accel.emplace(new_data, std::unique_ptr<PoolAccel>(new PoolAccel()));
+    g_accel.emplace(new_data, std::make_shared<PoolAccel>());
   } else {  // same nodes in a larger allocation: the grid stays what it is
-    std::unique_ptr<PoolAccel> pa = std::move(it->second);
+    std::shared_ptr<PoolAccel> pa = std::move(it->second);
     g_accel.erase(it);
     g_accel.emplace(new_data, std::move(pa));
   }
@@ -51,10 +58,7 @@ void pool_accel_unregister(svoslam_pool *pool) {
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_accel.find(pool->d_data);
   if (it == g_accel.end()) return;
-  it->second->grid.release();
-  it->second->shadow.release();
-  for (uint32_t *d : it->second->d_dirty) if (d) (void)hipFree(d);
-  g_accel.erase(it);
+  g_accel.erase(it);  // (~PoolAccel releases the device buffers once no enqueue holds the entry)
 }
 
 void pool_accel_invalidate(svoslam_pool *pool) {
@@ -130,11 +134,11 @@ bool pool_shadow_pending(svoslam_pool *pool) {
   return it != g_accel.end() && it->second->deferred_pending;
 }
 
-PoolAccel *pool_accel_find(const uint32_t *d_data) {
+std::shared_ptr<PoolAccel> pool_accel_find(const uint32_t *d_data) {
   if (!d_data) return nullptr;
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_accel.find(d_data);
-  return it == g_accel.end() ? nullptr : it->second.get();
+  return it == g_accel.end() ? nullptr : it->second;
 }
 
 // outcome of the reference's walk over levels 1..G on the path of cell (xi, yi, zi) (cone_tracing_kernels.cu:76-105):
@@ -200,22 +204,29 @@ __global__ __launch_bounds__(kUpdateThreads) void pool_grid_update_kernel(const 
 int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stream, const uint2 **d_grid) {
   if (!pa || !d_octree || !d_grid) return SVOSLAM_ERR_INVALID_ARG;
   constexpr size_t kCells = (size_t)1 << (3 * kPoolGridLevel);
-  bool fresh = false;
+  // the whole enqueue under the lock: the grid's host-side state (valid, last_stream) and the launches that make it
+  // true are one step for every other host thread
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (!pa->grid.ptr) {
+    SVO_TRY(pa->grid.reserve(kCells * sizeof(uint2)));
+    pa->valid = false;
+  }
+  if (!ensure_dirty_states(pa)) return SVOSLAM_ERR_HIP;
+  if (pa->last_stream != nullptr && pa->last_stream != stream) {
+    // another stream refreshed (and may still be building / marching through) this grid: order this refresh behind
+    // everything enqueued there so far
+    if (!pa->ev_order) SVO_HIP(hipEventCreateWithFlags(&pa->ev_order, hipEventDisableTiming));
+    if (hipEventRecord(pa->ev_order, pa->last_stream) == hipSuccess) SVO_HIP(hipStreamWaitEvent(stream, pa->ev_order, 0));
+    else (void)hipGetLastError();  // (a stream destroyed without svoslam_cone_trace_release: nothing left to wait for)
+  }
+  pa->last_stream = stream;
+  const bool fresh = !pa->valid;
+  pa->valid = true;
   uint32_t *serve[2] = {nullptr, nullptr};  // the dirty states this render consumes
-  {
-    std::lock_guard<std::mutex> lock(g_mu);
-    if (!pa->grid.ptr) {
-      SVO_TRY(pa->grid.reserve(kCells * sizeof(uint2)));
-      pa->valid = false;
-    }
-    if (!ensure_dirty_states(pa)) return SVOSLAM_ERR_HIP;
-    fresh = !pa->valid;
-    pa->valid = true;
-    if (pa->deferred_pending) {  // that commit's marks (parity of its epoch) belong to the render after its apply
-      serve[0] = pa->d_dirty[(pa->epoch + 1u) & 1u];
-    } else {
-      serve[0] = pa->d_dirty[0]; serve[1] = pa->d_dirty[1];
-    }
+  if (pa->deferred_pending) {  // that commit's marks (parity of its epoch) belong to the render after its apply
+    serve[0] = pa->d_dirty[(pa->epoch + 1u) & 1u];
+  } else {
+    serve[0] = pa->d_dirty[0]; serve[1] = pa->d_dirty[1];
   }
   uint2 *grid = pa->grid.as<uint2>();
   if (fresh) {

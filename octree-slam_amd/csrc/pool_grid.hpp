@@ -18,6 +18,8 @@
 // invalidates the grid as a whole; it is rebuilt in full by the next render.  Memory written behind the library's
 // back (hipMemcpy into svoslam_pool.d_data) must be followed by svoslam_pool_touch().
 #pragma once
+#include <memory>
+
 #include "common.hpp"
 #include "workspace.hpp"
 
@@ -42,6 +44,13 @@ struct PoolAccel {
   size_t shadow_nodes = 0;
   uint32_t epoch = 0;
   bool deferred_pending = false;
+  // The grid is shared by every stream that renders the pool, and `valid` flips when a build is ENQUEUED: a render on
+  // another stream must not march through (or update) a grid the previous stream may still be building.
+  // last_stream = the stream of the latest refresh; a refresh on a different stream first waits for everything enqueued
+  // on that one so far (an event recorded there at that moment: no per-frame cost while one stream renders the pool).
+  hipStream_t last_stream = nullptr;
+  hipEvent_t ev_order = nullptr;
+  ~PoolAccel();  // device buffers live as long as the last holder of the entry (std::shared_ptr)
 };
 
 // registry (guarded by a mutex inside), keyed by the address of the node memory: pools are known from pool_init
@@ -51,7 +60,9 @@ void pool_accel_rebind(const uint32_t *old_data, const uint32_t *new_data);  // 
 void pool_accel_unregister(svoslam_pool *pool);
 void pool_accel_invalidate(svoslam_pool *pool);
 uint32_t *pool_accel_dirty_bitmap(svoslam_pool *pool, int parity);  // nullptr for memory that is not a registered pool
-PoolAccel *pool_accel_find(const uint32_t *d_data);      // the registered pool whose nodes start at d_data, or nullptr
+std::shared_ptr<PoolAccel> pool_accel_find(const uint32_t *d_data);  // the registered pool whose nodes start at d_data, or null;
+// the caller holds the entry for the duration of its enqueue (a pool_free / growth on another host thread cannot pull it away)
+void pool_accel_forget_stream(hipStream_t stream);       // the stream is about to be destroyed
 
 // shadow words of the pool (allocated and zeroed on first use / growth), the epoch of the commit that starts now
 int pool_shadow_begin(svoslam_pool *pool, hipStream_t stream, unsigned long long **d_shadow, uint32_t *epoch);

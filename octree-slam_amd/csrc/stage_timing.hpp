@@ -1,0 +1,34 @@
+// stage_timing.hpp -- optional HIP-event timing of the hot path's stages (bench.py's per-stage rooflines).
+//
+// A stage's kernels are bracketed by a pair of events recorded on the stream they are launched on (torch.cuda.Event
+// would see torch's current stream only).  Off unless svoslam_stage_timing(mask) turns a stage on: an event record costs
+// ~2.6 us of its stream's time (hardware lesson 6), so the headline run enables only the two candidates for
+// "dominant kernel" (march on the map stream, tracker on its own stream) and measures the fusion's launches in a short
+// sequential pass after the timed region.
+#pragma once
+#include "common.hpp"
+
+namespace svoslam {
+
+enum Stage {
+  kStageMarch = SVOSLAM_STAGE_MARCH,          // cone_trace_kernel alone (not the grid refresh in front of it)
+  kStageTracker = SVOSLAM_STAGE_TRACKER,      // track_persistent_kernel, or the launch chain of one frame
+  kStageFuseSort = SVOSLAM_STAGE_FUSE_SORT,   // keys (fused front end) + radix sort
+  kStageFusePlan = SVOSLAM_STAGE_FUSE_PLAN,   // plan_count + plan_scan_finish + plan_emit (+ early split_all)
+  kStageFuseCommit = SVOSLAM_STAGE_FUSE_COMMIT,  // (split_all +) leaf blend / mip kernel + straddlers
+  kStageMaps = SVOSLAM_STAGE_MAPS,            // bilateral + vertex / normal pyramids
+  kStageCount = SVOSLAM_STAGE_COUNT
+};
+
+unsigned stage_timing_mask();                                  // stages that are on
+int stage_timing(unsigned mask);                               // bit s = stage s on; clears the log of every stage
+int stage_timing_read(int stage, float *ms_sum, int *pairs);   // blocking; resets that stage's log
+int stage_event(int stage, hipStream_t stream);                // no-op unless the stage is on; call before and after
+
+struct StageScope {  // brackets a scope; tolerant of early returns
+  int stage; hipStream_t s;
+  StageScope(int st, hipStream_t stream) : stage(st), s(stream) { (void)stage_event(stage, s); }
+  ~StageScope() { (void)stage_event(stage, s); }
+};
+
+}  // namespace svoslam

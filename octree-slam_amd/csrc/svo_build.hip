@@ -34,6 +34,7 @@
 #include "image_device.hpp"
 #include "pool_grid.hpp"
 #include "svo_build.hpp"
+#include "stage_timing.hpp"
 #include "wave_rank.hpp"
 
 namespace svoslam {
@@ -1375,7 +1376,10 @@ static int fuse_sort_impl(svoslam_workspace *ws, const float *d_points, const Fr
   key.add(fs ? (const void *)fs->depth : (const void *)d_points).add((unsigned long long)n).add((unsigned long long)depth)
      .addf(center[0]).addf(center[1]).addf(center[2]).addf(edge).add(ws->layout_hash()).add(fs ? fs->pose : nullptr).add(d_bbox7)
      .add(ws->frame_bbox.ptr);
-  SVO_TRY(ws->g_sort.run(key, stream, enqueue));
+  {
+    StageScope timed(kStageFuseSort, stream);
+    SVO_TRY(ws->g_sort.run(key, stream, enqueue));
+  }
   if (!skey) {  // replayed: where the recorded sort leaves its result
     if (packed) SVO_TRY(radix_sort_packed_output(ws, key_bits, &skey, &sidx));
     else SVO_TRY(radix_sort_output(ws, n, key_bits, &skey, &sidx));
@@ -1481,7 +1485,10 @@ static int fuse_plan_impl(svoslam_workspace *ws, int n, int depth, svoslam_pool 
   GraphKey key;
   key.add(skey).add((unsigned long long)n).add((unsigned long long)depth).add(pool->d_data).add(ws->layout_hash())
      .add((unsigned long long)structure).add(d_struct);
-  SVO_TRY(ws->g_plan.run(key, stream, enqueue));
+  {
+    StageScope timed(kStageFusePlan, stream);
+    SVO_TRY(ws->g_plan.run(key, stream, enqueue));
+  }
   ws->planned_n = n;
   ws->planned_pool = pool;
   if (structure) { ws->early_split_pool = pool; tracker_of(pool)->planned_ahead++; ws->structure_planned = true; }  // the commit: leaf kernel (links again, same values; marks) + straddlers
@@ -1513,9 +1520,12 @@ int svo_fuse_split_early(svoslam_workspace *ws, int n, int depth, svoslam_pool *
   if (n == 0) return SVOSLAM_OK;
   int split_blocks = (int)cdiv(max_records(n, depth), 256);
   if (split_blocks > 2048) split_blocks = 2048;
-  split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>(),
-                                                     small_bucket_base(ws), small_counts(ws), pool->d_data, pool->d_size, depth, nullptr,
-                                                     small_n0(ws), 0);
+  {
+    StageScope timed(kStageFusePlan, stream);
+    split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>(),
+                                                       small_bucket_base(ws), small_counts(ws), pool->d_data, pool->d_size, depth, nullptr,
+                                                       small_n0(ws), 0);
+  }
   SVO_LAUNCH_CHECK();
   ws->early_split_pool = pool;
   return SVOSLAM_OK;
@@ -1586,7 +1596,10 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
     return SVOSLAM_OK;
   };
   if (deferred) {  // the epoch changes with every call: not a recorded sequence
-    SVO_TRY(enqueue());
+    {
+      StageScope timed(kStageFuseCommit, stream);
+      SVO_TRY(enqueue());
+    }
     pool->pending += 1;
     return tracker_push(pool, 8 * rmax, stream);
   }
@@ -1594,7 +1607,10 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   key.add(skey).add(d_colors).add((unsigned long long)n).add((unsigned long long)depth).add(pool->d_data).add(pool->d_size)
      .add((unsigned long long)slot).add(grid_dirty).add(trk ? (const void *)trk->h_size : nullptr).add(ws->layout_hash())
      .add((unsigned long long)early);
-  SVO_TRY(ws->g_commit.run(key, stream, enqueue));
+  {
+    StageScope timed(kStageFuseCommit, stream);
+    SVO_TRY(ws->g_commit.run(key, stream, enqueue));
+  }
   pool->pending += 1;
   return tracker_push(pool, 8 * rmax, stream);
 }

@@ -26,6 +26,9 @@
 #include <stdlib.h>
 
 #include "icp_device.hpp"
+#include <map>
+#include <mutex>
+
 #include "track_persistent.hpp"
 
 namespace svoslam {
@@ -408,15 +411,22 @@ static int env_int(const char *name, int dflt) {
 }
 
 int track_persistent_capacity(hipStream_t s, int *max_workgroups) {
-  // resident workgroups the launch may count on: occupancy x the CUs the stream may use
-  static int per_cu = -1;
-  if (per_cu < 0) {
-    int n = 0;
-    SVO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, track_persistent_kernel, kTrkThreads, 0));
-    per_cu = n;
-  }
+  // resident workgroups the launch may count on: occupancy x the CUs the stream may use (per DEVICE: ADVICE r02)
+  static std::mutex mu;
+  static std::map<int, int> per_cu_of;
   int dev = 0, cus = 0;
   SVO_HIP(hipGetDevice(&dev));
+  int per_cu = 0;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = per_cu_of.find(dev);
+    if (it == per_cu_of.end()) {
+      int n = 0;
+      SVO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, track_persistent_kernel, kTrkThreads, 0));
+      it = per_cu_of.emplace(dev, n).first;
+    }
+    per_cu = it->second;
+  }
   SVO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (s != nullptr && hipExtStreamGetCUMask(s, 8, mask) == hipSuccess) {
@@ -462,9 +472,30 @@ int track_persistent_profile(const TrackSync *d_sync, unsigned long long *out, h
 
 size_t track_persistent_ticket_bytes() { return ticket_index(2, 0, 0) * sizeof(unsigned); }
 
+// The kernel's workgroups wait for each other, and its worker count assumes an otherwise idle device.  Two such launches
+// dispatched at the same time (two cameras or sessions of one process on one device, on different streams) could each
+// become partially resident and wait for the other until the bounded spins give up.  Launches of ONE
+// process on ONE device are therefore chained: a launch on a stream other than the previous one's first waits for that
+// one to finish (an event recorded behind it; nothing is recorded while a single stream tracks, the common case).
+// Several PROCESSES sharing a device (a test arrangement: bench.py's SVOSLAM_BENCH_ONE_DEVICE) use the launch chain
+// (SVOSLAM_TRACK_CHAIN=1); a give-up still surfaces as an error from the camera's next readback, and travels with the
+// delta record of a frame-sharded session.
 int track_persistent_launch(CamState *st, TrackSync *sy, unsigned *tickets, double *rows, const TrackArgs &A, hipStream_t s) {
+  struct DevChain { hipStream_t last = nullptr; hipEvent_t ev = nullptr; bool used = false; };
+  static std::mutex mu;
+  static std::map<int, DevChain> chain_of;
+  int dev = 0;
+  SVO_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  DevChain &dc = chain_of[dev];
+  if (dc.used && dc.last != s) {
+    if (!dc.ev) SVO_HIP(hipEventCreateWithFlags(&dc.ev, hipEventDisableTiming));
+    if (hipEventRecord(dc.ev, dc.last) == hipSuccess) SVO_HIP(hipStreamWaitEvent(s, dc.ev, 0));
+    else (void)hipGetLastError();  // that stream is gone, and its launches with it
+  }
   track_persistent_kernel<<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, tickets, rows, A);
   SVO_LAUNCH_CHECK();
+  dc.last = s; dc.used = true;
   return SVOSLAM_OK;
 }
 

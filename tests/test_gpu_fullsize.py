@@ -1,0 +1,95 @@
+"""Full-size, full-length parity: BASELINE config 3 -- 640x480, depth 12, ALL 300 frames -- and
+config 4 -- 1920x1080, depth 14, 16 frames -- through the HIP frame loop (native four-stream runner, the path bench.py
+times), compared at checkpoints with SHA-256 digests of the CPU oracle's state on the same frames
+(tests/golden/fullsize_digests.json, written in the build container by tests/golden/make_fullsize_digests.py: the oracle
+needs ~2 s (cfg3) / ~10 s (cfg4) per frame on one core, so it is not re-run here).
+
+Compared at every checkpoint: the whole node pool (282 M nodes at the end of cfg3: links, colours, alpha), the tracker's
+pose, the reference-mode image of the checkpoint frame (all black until alpha saturates -- reference behaviour, Q10), a
+carry-mode image of the same map (coloured), and the running totals of march steps / levels visited over EVERY frame so
+far -- one wrong sample anywhere in any frame's march changes them.  The digest of the INPUT frames is checked first, so
+that a different random stream shows up as such.
+
+This is the regime the 300-frame config lives in at full resolution: alpha saturation (>= 64 observations), Q9
+retirements, pools beyond 100 M nodes, the pool's size tracker wrapping many times, thousands of level-grid refreshes.
+"""
+import hashlib
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "fullsize_digests.json")
+
+
+def _sha(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import svoslam_pkg
+    pkg = svoslam_pkg.load()
+    synth = importlib.import_module("octree_slam_amd.synth")
+    pl = importlib.import_module("octree_slam_amd.pipeline")
+    return pkg, torch, synth, pl
+
+
+def _run_config(env, name, last_checkpoint=None):
+    pkg, torch, synth, pl = env
+    gold = json.load(open(GOLD))[name]
+    w, h, depth, edge, center, mode = gold["width"], gold["height"], gold["depth"], gold["edge"], tuple(gold["center"]), gold["render_mode"]
+    cps = sorted(int(k) for k in gold["checkpoints"])
+    if last_checkpoint:
+        cps = [c for c in cps if c <= last_checkpoint]
+    P = pl.SlamPipeline(w, h, depth, center, edge, render_mode=mode, count_steps=True, pool_capacity_nodes=(1 << 30) - 8)
+    hin = hashlib.sha256()
+    done = 0
+    for cp in cps:
+        ds, cs, views = [], [], []
+        for k in range(done, cp):
+            d, c = synth.render_frame(k, w, h)                       # CPU generator: the frames the digests were made from
+            hin.update(d.numpy().view(np.uint16).tobytes()); hin.update(c.numpy().tobytes())
+            ds.append(d.cuda()); cs.append(c.cuda()); views.append(pl.ground_truth_view(k, synth))
+        want = gold["checkpoints"][str(cp)]
+        assert hin.copy().hexdigest() == want["inputs_sha256"], "the synthetic INPUT frames differ from the build container's (not a parity failure)"
+        P.run_stream(ds, cs, list(range(done, cp)), views)
+        torch.cuda.synchronize()
+        assert hasattr(P, "_runner")                                 # the native scheduler ran, not the scripted loop
+        done = cp
+        assert P.pool.size == want["pool_nodes"], (name, cp, P.pool.size, want["pool_nodes"])
+        assert P.counters.tolist() == [want["steps_total"], want["levels_total"]], (name, cp)
+        p, o = P.cam.pose()
+        assert _sha(p.view(np.uint32), o.view(np.uint32)) == want["pose_sha256"], (name, cp, "pose")
+        assert P.cam.tracking_lost_count() == want["tracking_lost_levels"]
+        img = P.image.cpu().numpy()
+        assert _sha(img) == want["image_sha256"], (name, cp, "reference-mode image")
+        img1 = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        pkg.cone_trace_svo(img1, 45.0, views[-1], P.pool.data_ptr, center, edge, pkg.RENDER_CARRY)
+        img1 = img1.cpu().numpy()
+        assert int((img1[..., :3].max(-1) > 0).sum()) == want["image_carry_coloured_pixels"], (name, cp)
+        assert _sha(img1) == want["image_carry_sha256"], (name, cp, "carry-mode image")
+        words = P.pool.words()
+        assert _sha(words) == want["pool_sha256"], (name, cp, "pool words")
+        del words
+    return P
+
+
+def test_cfg3_300_frames_full_size(env):
+    """BASELINE config 3, complete: 300 frames at 640x480 into a depth-12 SVO (282 M nodes); checkpoints after 4, 24, 72,
+    150 and 300 frames"""
+    _run_config(env, "cfg3")
+
+
+def test_cfg4_16_frames_full_size(env):
+    """BASELINE config 4 on one GPU: 16 frames at 1920x1080 into a depth-14 SVO; checkpoints after 2, 8 and 16 frames"""
+    _run_config(env, "cfg4")
