@@ -204,9 +204,14 @@ __device__ inline bool is_head(const u64 *__restrict__ skey, int j, u64 &key, in
 // splitKeys (svo.cu:108-142) for one key: first node on the path without the
 // children flag.  Q3: the last level is examined only when its octant is 7.
 // t in [1, D] = depth of that node, f = its index; t = kNoSplit -> f = leaf index.
-__device__ inline void walk_existing(const u32 *__restrict__ pool, u64 key, int depth, int &t, u32 &f) {
+// start (round 3): the leaf kernel of the commit resumes this walk instead of repeating it from the root.  It owns the
+// levels below c (those shared with the previous head belong to that head), so what it needs from here is the child
+// tile its first owned level lives in: `start` = base after level s = min(c, t - 1) (s = c when the whole path exists).
+// s < t, so that base is one this walk has read; below the frontier the tiles are this frame's own (n0 + 8 x rank).
+__device__ inline void walk_existing(const u32 *__restrict__ pool, u64 key, int depth, int c, int &t, u32 &f, u32 &start) {
   u32 base = 0, node = 0;
   t = kNoSplit;
+  start = 0;
   for (int lvl = 1; lvl <= depth; lvl++) {
     const u32 oct = (u32)(key >> (3 * (depth - lvl))) & 7u;
     node = base + oct;
@@ -214,6 +219,7 @@ __device__ inline void walk_existing(const u32 *__restrict__ pool, u64 key, int 
       const u32 w0 = pool[2 * (size_t)node];
       if (!(w0 & kFlag)) { t = lvl; break; }
       base = w0 & kMask;
+      if (lvl <= c) start = base;  // (the last assignment is the base after level min(c, t - 1))
     }
   }
   f = node;
@@ -246,8 +252,8 @@ __device__ inline int xcd_tile(int tiles) { (void)tiles; return (int)blockIdx.x;
 constexpr int kPlanThreads = 512, kPlanWaves = kPlanThreads / 64;
 __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(const u64 *__restrict__ skey, int n, int depth,
                                                                   const u32 *__restrict__ pool, unsigned char *__restrict__ leaf_t,
-                                                                  u32 *__restrict__ leaf_f, u32 *__restrict__ tile_hist,
-                                                                  int num_tiles, int *__restrict__ any_valid) {
+                                                                  u32 *__restrict__ leaf_f, u32 *__restrict__ leaf_start,
+                                                                  u32 *__restrict__ tile_hist, int num_tiles, int *__restrict__ any_valid) {
   __shared__ u32 hist[256];
   const int tile = xcd_tile(num_tiles);
   if (tile >= num_tiles) return;
@@ -257,10 +263,11 @@ __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(const u64 *__r
   if (j < n) {
     u64 key; int c = 0;
     if (is_head(skey, j, key, c, depth)) {
-      int t; u32 f;
-      walk_existing(pool, key, depth, t, f);
+      int t; u32 f, start;
+      walk_existing(pool, key, depth, c, t, f, start);
       leaf_t[j] = (unsigned char)t;
       leaf_f[j] = f;
+      if (leaf_start) leaf_start[j] = start;
       int lo, hi;
       record_range(t, c, depth, lo, hi);
       for (int d = lo; d <= hi; d++) atomicAdd(&hist[bucket_id(d - t, d)], 1u);
@@ -614,7 +621,8 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
                                                              unsigned long long *__restrict__ shadow, u32 epoch,
                                                              u32 *__restrict__ apply_nodes, const u64 *__restrict__ rec_key,
                                                              const u32 *__restrict__ bucket_base, const u32 *__restrict__ n0_saved,
-                                                             const u32 *__restrict__ leaf_rec0) {
+                                                             const u32 *__restrict__ leaf_rec0, const u32 *__restrict__ leaf_start,
+                                                             int *__restrict__ strad_bc) {
   const bool early_links = leaf_rec0 != nullptr;
   // shadow != nullptr: deferred commit.  Every colour word goes to shadow[node] instead of the pool, children are read
   // through average_tile_deferred, and apply_nodes[(level - 1) * n + j] names the node lane j wrote at that level
@@ -642,6 +650,9 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   const u64 key_n = jn < n ? skey[jn] : 1ull, key_np = jn < n ? skey[jn - 1] : 1ull;
   const u32 point = j < n ? sidx[j] : 0u;
   const bool head = lt != kNotHead;
+  // where the plan's walk of this key's path left off (walk_existing): the child tile of its node at level
+  // min(c, leaf_t - 1) -- the walk below starts there instead of at the root (requested with the other setup loads)
+  const u32 start_base = (leaf_start && head) ? leaf_start[j] : 0u;
   // early links: rank of the pass-0 record of this key's frontier node, known to the head that owns the record (the first
   // under that node); requested with the other setup loads, handed to the heads that follow below
   u32 rec0 = 0;
@@ -683,6 +694,12 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
     }
   } else if (jn == next_pos) {
     next_c = (key_np == 1ull) ? 0 : common_levels(key_n, key_np, depth);
+  }
+  // boundary record for the straddler pass: how many levels the first head after this tile shares with its predecessor
+  // (-1: none).  A level-d node that owns leaves at the end of tile t continues into later tiles iff bc[t] >= d.
+  if (strad_bc) {
+    __syncthreads();
+    if (tid == 0) strad_bc[bid] = next_c;
   }
   FILL_STAMP(1)
   // early_links != 0: the child tiles of this commit were initialised ahead of it (svo_fuse_split_early: split_all_kernel
@@ -745,10 +762,18 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
     // duplicates: the head of a run of equal keys is the lowest point index (stable sort)
     const unsigned char *v = colors + 3 * (size_t)point;
     const unsigned char cr = v[0], cg = v[1], cb = v[2];  // in flight during the walk
+    // levels 1 .. skip belong to an earlier head (c) or were walked by the plan (up to the frontier): resume below them
+    // (links that existed when the plan ran never change; replicas of one map have the same indices)
+    int skip = 0;
     u32 base = 0, node = 0;
+    if (leaf_start) {
+      const int tt = lt == kNoSplit ? depth : (int)lt - 1;
+      skip = c < tt ? c : tt;
+      base = start_base;
+    }
 #pragma unroll
     for (int lvl = 1; lvl <= MAXD; lvl++) {
-      if (lvl <= depth) {
+      if (lvl <= depth && lvl > skip) {
         node = base + ((u32)(key >> (3 * (depth - lvl))) & 7u);
         if (lvl == link_level) pool[2 * (size_t)node] = kFlag + (frontier_child & kMask);
         if (lvl < depth) {
@@ -862,6 +887,100 @@ __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__rest
   // last kernel of the commit: every mark of this commit is in the bitmap (kernel boundaries); list the marked blocks
   // for the next render's refresh of the level grid (pool_grid.hpp)
   if (grid_dirty) pool_grid_compact(grid_dirty, kStradThreads);
+}
+
+// ---- straddlers in two tiers (round 3; direct commits) -----------------------------------------------------------
+// mip_straddle_kernel above is ONE workgroup walking [level][tile] lists level by level: 23 us at 640x480 (600 tiles,
+// 11 levels) and 127 us at 1920x1080 (4050 tiles, 13 levels) -- every level is a dependent round trip (children tiles
+// -> average -> store -> barrier) over up to `tiles` entries.  Most straddlers are LOCAL: a deep node's run crosses one
+// or two tile boundaries.  Tier 1: one workgroup per group of kStradGroup consecutive tiles finishes, level by level,
+// every straddler whose run ends inside its group (<= kStradGroup entries per level: one lane each); a run that leaves
+// the group -- at most ONE per level and group, since it covers every later tile of the group -- becomes a "super
+// straddler".  Tier 2: the last group to arrive (agent-scope hand-off, cdna_hip_programming.md Guideline 16: tier-1 words are
+// stored write-through, every wave drains, one lane takes the ticket; the last arriver acquires) finishes the super
+// straddlers, <= groups per level, then does what the single workgroup did at its end (root quirk Q6, size, dirty
+// list of the level grid).  Same values: a node is averaged after all of its touched children, whichever tier owns them.
+constexpr int kStradGroup = 16;
+constexpr int kStrad2Threads = 256;
+__global__ __launch_bounds__(kStrad2Threads) void mip_straddle2_kernel(u32 *__restrict__ pool, const u32 *__restrict__ strad,
+                                                              const int *__restrict__ strad_bc, u32 *__restrict__ sstrad,
+                                                              unsigned *__restrict__ ticket, int num_tiles, int depth,
+                                                              const PlanCounts *__restrict__ counts, int *__restrict__ d_size,
+                                                              u32 *__restrict__ grid_dirty, int32_t *__restrict__ h_sizes,
+                                                              int *__restrict__ d_slot) {
+  SVO_HIGH_PRIO();
+  __shared__ int bc[kStradGroup];
+  __shared__ int is_last;
+  const int tid = (int)threadIdx.x, g = (int)blockIdx.x, groups = (int)gridDim.x;
+  const int t0 = g * kStradGroup, t1 = (t0 + kStradGroup < num_tiles) ? t0 + kStradGroup : num_tiles;
+  const uint2 *list = reinterpret_cast<const uint2 *>(strad);
+  uint2 *super = reinterpret_cast<uint2 *>(sstrad);  // [level][group]
+  if (tid < kStradGroup) bc[tid] = (t0 + tid < t1) ? strad_bc[t0 + tid] : -1;
+  __syncthreads();
+  // ---- tier 1 (first wavefront; lane i = tile t0 + i)
+  const int t = t0 + tid;
+  for (int d = depth - 1; d >= 1; d--) {
+    if (tid < kStradGroup) {
+      uint2 sup = make_uint2(kNoStraddler, 0u);
+      if (t < t1) {
+        const uint2 e = list[(size_t)d * num_tiles + t];
+        if (e.x != kNoStraddler) {
+          // the run leaves tile t (that made it a straddler) and ends in the first later tile whose own boundary record
+          // says the node does not continue
+          bool inside = false;
+          for (int b = tid + 1; b < t1 - t0; b++)
+            if (bc[b] < d) { inside = true; break; }
+          if (inside) __hip_atomic_store(&pool[2 * (size_t)e.x + 1], average_tile(pool, e.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else sup = e;
+        }
+      }
+      // at most one lane holds a super straddler of this level: fold it to lane 0
+      const unsigned long long m = __ballot(sup.x != kNoStraddler);
+      if (m) {
+        const int src = __ffsll((long long)m) - 1;
+        sup.x = (u32)__shfl((int)sup.x, src); sup.y = (u32)__shfl((int)sup.y, src);
+      }
+      if (tid == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(&super[(size_t)d * groups + g]),
+                           ((unsigned long long)sup.y << 32) | sup.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // the level's stores have left this CU before the next level reads them back
+  }
+  // ---- hand-off: tier-1 stores are write-through (sc1) and drained above by every wave; one lane takes the ticket
+  if (tid == 0) {
+    const unsigned k = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = k == (unsigned)groups - 1u;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's stale lines once; plain loads below
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  }
+  __syncthreads();
+  // ---- tier 2: super straddlers deepest level first (a run that leaves its group may end anywhere: no locality left)
+  for (int d = depth - 1; d >= 1; d--) {
+    for (int q = tid; q < groups; q += kStrad2Threads) {
+      const unsigned long long e = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&super[(size_t)d * groups + q]),
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u32 node = (u32)e, child = (u32)(e >> 32);
+      if (node != kNoStraddler) pool[2 * (size_t)node + 1] = average_tile(pool, child);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (counts->any_valid) pool[1] = average_tile(pool, 0u);  // Q6
+    const int size_now = *d_size + 8 * counts->total_records;
+    *d_size = size_now;
+    if (h_sizes) {  // the host learns the size from pinned memory behind the commit's event (PoolTracker)
+      const int sl = *d_slot;
+      h_sizes[sl] = size_now;
+      *d_slot = (sl + 1) % 8;
+    }
+  }
+  if (grid_dirty) pool_grid_compact(grid_dirty, kStrad2Threads);
 }
 
 // Second half of a deferred commit: everything the commit computed while the previous frame was being ray-marched
@@ -1232,6 +1351,7 @@ static inline PlanCounts *small_counts(svoslam_workspace *ws) { return reinterpr
 static inline int *small_any(svoslam_workspace *ws) { return reinterpret_cast<int *>(ws->small.as<u32>() + 640); }
 static inline u32 *small_n0(svoslam_workspace *ws) { return ws->small.as<u32>() + 648; }  // deferred commit: first new tile
 static inline unsigned *small_ticket(svoslam_workspace *ws) { return ws->small.as<u32>() + 656; }  // plan_scan_finish_kernel's arrival count
+static inline unsigned *small_strad_ticket(svoslam_workspace *ws, int slot) { return ws->small.as<u32>() + 664 + 8 * slot; }  // mip_straddle2_kernel's (zero between launches)
 
 // keys of the n inputs are in ws->keys_a
 static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, const void *d_colors, bool vec4,
@@ -1245,7 +1365,7 @@ static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *poo
   u32 *leaf_f = ws->leaf_f.as<u32>();
   u32 *tile_hist = ws->tile_hist.as<u32>();
   const int ptiles = (int)cdiv(n, kPlanThreads);
-  plan_count_kernel<<<xcd_grid(ptiles), kPlanThreads, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, ptiles, small_any(ws));
+  plan_count_kernel<<<xcd_grid(ptiles), kPlanThreads, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, nullptr, tile_hist, ptiles, small_any(ws));
   plan_scan_finish_kernel<<<256, 256, 0, stream>>>(tile_hist, ptiles, small_totals(ws), small_ticket(ws), small_bucket_base(ws),
                                                    small_counts(ws), small_any(ws), nullptr, nullptr);
   SVO_LAUNCH_CHECK();
@@ -1334,6 +1454,7 @@ static int fuse_sort_impl(svoslam_workspace *ws, const float *d_points, const Fr
   SVO_TRY(ws->rec_front.reserve((size_t)rmax * 4));
   SVO_TRY(ws->rec_pass.reserve((size_t)rmax));
   SVO_TRY(ws->leaf_rec0.reserve((size_t)n * 4));
+  SVO_TRY(ws->leaf_start.reserve((size_t)n * 4));
   const int key_bits = 3 * depth + 1, idx_bits = packed_idx_bits(n);
   const bool packed = key_bits + idx_bits <= 64 && !sort_pairs_forced();
   if (!packed && fs) return SVOSLAM_ERR_INVALID_ARG;  // (callers fall back to the stand-alone kernels + svo_fuse_sort)
@@ -1469,7 +1590,7 @@ static int fuse_plan_impl(svoslam_workspace *ws, int n, int depth, svoslam_pool 
   int split_blocks = (int)cdiv(rmax, 256);
   if (split_blocks > 2048) split_blocks = 2048;
   auto enqueue = [&]() -> int {  // three launches (round 1: a memset and five)
-    plan_count_kernel<<<xcd_grid(tiles), kPlanThreads, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, tile_hist, tiles, small_any(ws));
+    plan_count_kernel<<<xcd_grid(tiles), kPlanThreads, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, ws->leaf_start.as<u32>(), tile_hist, tiles, small_any(ws));
     plan_scan_finish_kernel<<<256, 256, 0, stream>>>(tile_hist, tiles, small_totals(ws), small_ticket(ws), small_bucket_base(ws),
                                                      small_counts(ws), small_any(ws), d_struct, small_n0(ws));
     plan_emit_kernel<<<xcd_grid(tiles), kPlanThreads, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, tiles,
@@ -1566,8 +1687,16 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   if (split_blocks > 2048) split_blocks = 2048;
   const int fill_tiles = (int)cdiv(n, kFillThreads);
   DeviceBuffer &sb = slot == 0 ? ws->strad : ws->strad_b;
-  SVO_TRY(sb.reserve((size_t)(SVOSLAM_MAX_DEPTH + 1) * (size_t)fill_tiles * 8));
+  // [level][tile] straddler entries | per-tile boundary records | [level][group] super straddlers (mip_straddle2_kernel)
+  const int strad_groups = (int)cdiv(fill_tiles, kStradGroup);
+  const size_t strad_words = (size_t)(SVOSLAM_MAX_DEPTH + 1) * (size_t)fill_tiles * 2, bc_words = ((size_t)fill_tiles + 1) & ~(size_t)1;
+  SVO_TRY(sb.reserve((strad_words + bc_words + (size_t)(SVOSLAM_MAX_DEPTH + 1) * (size_t)strad_groups * 2) * 4));
   u32 *strad = sb.as<u32>();
+  int *strad_bc = reinterpret_cast<int *>(strad + strad_words);
+  u32 *sstrad = strad + strad_words + bc_words;
+  // SVOSLAM_STRADDLE=1: the single-workgroup pass of round 2 (A/B measurements); deferred commits always use it
+  static const bool one_wg = [] { const char *e = getenv("SVOSLAM_STRADDLE"); return e && e[0] == '1'; }();
+  const bool two_tier = !deferred && !one_wg;
   SVO_TRY(ensure_device_size(pool, stream));         // (creates the size tracker)
   PoolTracker *trk = tracker_of(pool);
   unsigned long long *shadow = nullptr;
@@ -1586,12 +1715,19 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
                                                          pool->d_data, pool->d_size, depth, grid_dirty, deferred ? small_n0(ws) : nullptr, 0);
     if (depth <= 12) fill_mip_local_kernel<12><<<xcd_grid(fill_tiles), kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
                                                                    grid_dirty, shadow, epoch, apply_nodes, ws->rec_key.as<u64>(),
-                                                                   small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr);
+                                                                   small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr, ws->leaf_start.as<u32>(),
+                                                                   two_tier ? strad_bc : nullptr);
     else fill_mip_local_kernel<16><<<xcd_grid(fill_tiles), kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
                                                                    grid_dirty, shadow, epoch, apply_nodes, ws->rec_key.as<u64>(),
-                                                                   small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr);
-    mip_straddle_kernel<<<1, kStradThreads, 0, stream>>>(pool->d_data, strad, fill_tiles, depth, small_counts(ws), pool->d_size, grid_dirty,
-                                                         trk ? trk->h_size : nullptr, trk ? trk->d_slot : nullptr, shadow, epoch);
+                                                                   small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr, ws->leaf_start.as<u32>(),
+                                                                   two_tier ? strad_bc : nullptr);
+    if (two_tier)
+      mip_straddle2_kernel<<<strad_groups, kStrad2Threads, 0, stream>>>(pool->d_data, strad, strad_bc, sstrad, small_strad_ticket(ws, slot), fill_tiles,
+                                                                        depth, small_counts(ws), pool->d_size, grid_dirty,
+                                                                        trk ? trk->h_size : nullptr, trk ? trk->d_slot : nullptr);
+    else
+      mip_straddle_kernel<<<1, kStradThreads, 0, stream>>>(pool->d_data, strad, fill_tiles, depth, small_counts(ws), pool->d_size, grid_dirty,
+                                                           trk ? trk->h_size : nullptr, trk ? trk->d_slot : nullptr, shadow, epoch);
     SVO_LAUNCH_CHECK();
     return SVOSLAM_OK;
   };

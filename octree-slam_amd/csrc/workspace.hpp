@@ -44,6 +44,7 @@ struct svoslam_workspace {
   svoslam::DeviceBuffer rec_key, rec_front;               // split records in reference order
   svoslam::DeviceBuffer rec_pass;                         // async path: pass of each record
   svoslam::DeviceBuffer leaf_rec0;                        // async path: per sorted key, rank of the pass-0 record it owns (early split)
+  svoslam::DeviceBuffer leaf_start;                       // async path: per sorted key, child tile where the commit's walk resumes the plan's
   svoslam::DeviceBuffer path_nodes;                       // [(D-1)][n] node index per owned depth (mip lists)
   svoslam::DeviceBuffer strad;                            // [D][tiles][2] nodes whose leaf run crosses a workgroup (async commit)
   svoslam::DeviceBuffer strad_b;                          // the same for the commit of the plan to a second replica of the pool
@@ -75,7 +76,7 @@ struct svoslam_workspace {
   // every buffer address the recorded phases bake in (a reallocation makes a new key)
   unsigned long long layout_hash() const {
     const void *p[] = {keys_a.ptr, keys_b.ptr, vals_a.ptr, vals_b.ptr, tile_hist.ptr, small.ptr, leaf_t.ptr, leaf_f.ptr,
-                       rec_key.ptr, rec_front.ptr, rec_pass.ptr, path_nodes.ptr, strad.ptr, strad_b.ptr, apply_nodes.ptr, leaf_rec0.ptr};
+                       rec_key.ptr, rec_front.ptr, rec_pass.ptr, path_nodes.ptr, strad.ptr, strad_b.ptr, apply_nodes.ptr, leaf_rec0.ptr, leaf_start.ptr};
     unsigned long long h = 1469598103934665603ull;
     for (const void *q : p) h = (h ^ (unsigned long long)(uintptr_t)q) * 1099511628211ull;
     return h;
@@ -83,7 +84,7 @@ struct svoslam_workspace {
   void release_all() {
     keys_a.release(); keys_b.release(); vals_a.release(); vals_b.release(); tile_hist.release(); small.release();
     leaf_t.release(); leaf_f.release(); rec_key.release(); rec_front.release(); path_nodes.release(); strad.release(); strad_b.release();
-    rec_pass.release(); apply_nodes.release(); leaf_rec0.release();
+    rec_pass.release(); apply_nodes.release(); leaf_rec0.release(); leaf_start.release();
     bfs_a.release(); bfs_b.release(); bfs_mask.release(); bfs_ptr.release(); misc.release(); scan_tmp.release(); frame_bbox.release();
     if (h_counts) { (void)hipHostFree(h_counts); h_counts = nullptr; }
     g_sort.clear(); g_plan.clear(); g_commit.clear();
