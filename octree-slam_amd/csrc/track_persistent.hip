@@ -475,11 +475,12 @@ size_t track_persistent_ticket_bytes() { return ticket_index(2, 0, 0) * sizeof(u
 // The kernel's workgroups wait for each other, and its worker count assumes an otherwise idle device.  Two such launches
 // dispatched at the same time (two cameras or sessions of one process on one device, on different streams) could each
 // become partially resident and wait for the other until the bounded spins give up.  Launches of ONE
-// process on ONE device are therefore chained: a launch on a stream other than the previous one's first waits for that
-// one to finish (an event recorded behind it; nothing is recorded while a single stream tracks, the common case).
-// Several PROCESSES sharing a device (a test arrangement: bench.py's SVOSLAM_BENCH_ONE_DEVICE) use the launch chain
-// (SVOSLAM_TRACK_CHAIN=1); a give-up still surfaces as an error from the camera's next readback, and travels with the
-// delta record of a frame-sharded session.
+// process on ONE device are therefore chained: every launch is followed by an event record on its stream (~2.6 us of the
+// tracker stream, which does not bound the frame), and a launch on a stream other than the previous one's first waits
+// for that event.  (Recording on the previous stream at the time of the NEXT launch would cost nothing in the
+// single-stream case, but that stream may have been destroyed by then.)  Several PROCESSES sharing a device (a test
+// arrangement: bench.py's SVOSLAM_BENCH_ONE_DEVICE) use the launch chain (SVOSLAM_TRACK_CHAIN=1); a give-up still
+// surfaces as an error from the camera's next readback, and travels with the delta record of a frame-sharded session.
 int track_persistent_launch(CamState *st, TrackSync *sy, unsigned *tickets, double *rows, const TrackArgs &A, hipStream_t s) {
   struct DevChain { hipStream_t last = nullptr; hipEvent_t ev = nullptr; bool used = false; };
   static std::mutex mu;
@@ -488,13 +489,11 @@ int track_persistent_launch(CamState *st, TrackSync *sy, unsigned *tickets, doub
   SVO_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lock(mu);
   DevChain &dc = chain_of[dev];
-  if (dc.used && dc.last != s) {
-    if (!dc.ev) SVO_HIP(hipEventCreateWithFlags(&dc.ev, hipEventDisableTiming));
-    if (hipEventRecord(dc.ev, dc.last) == hipSuccess) SVO_HIP(hipStreamWaitEvent(s, dc.ev, 0));
-    else (void)hipGetLastError();  // that stream is gone, and its launches with it
-  }
+  if (!dc.ev) SVO_HIP(hipEventCreateWithFlags(&dc.ev, hipEventDisableTiming));
+  if (dc.used && dc.last != s) SVO_HIP(hipStreamWaitEvent(s, dc.ev, 0));  // the previous launch (any stream) has finished
   track_persistent_kernel<<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, tickets, rows, A);
   SVO_LAUNCH_CHECK();
+  SVO_HIP(hipEventRecord(dc.ev, s));
   dc.last = s; dc.used = true;
   return SVOSLAM_OK;
 }
