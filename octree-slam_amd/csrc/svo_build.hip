@@ -1697,6 +1697,9 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   // SVOSLAM_STRADDLE=1: the single-workgroup pass of round 2 (A/B measurements); deferred commits always use it
   static const bool one_wg = [] { const char *e = getenv("SVOSLAM_STRADDLE"); return e && e[0] == '1'; }();
   const bool two_tier = !deferred && !one_wg;
+  // SVOSLAM_FILL_RESUME=0: the leaf kernel walks every path from the root as in round 2 (A/B measurements)
+  static const bool resume = [] { const char *e = getenv("SVOSLAM_FILL_RESUME"); return !(e && e[0] == '0'); }();
+  const u32 *leaf_start = resume ? ws->leaf_start.as<u32>() : nullptr;
   SVO_TRY(ensure_device_size(pool, stream));         // (creates the size tracker)
   PoolTracker *trk = tracker_of(pool);
   unsigned long long *shadow = nullptr;
@@ -1715,11 +1718,11 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
                                                          pool->d_data, pool->d_size, depth, grid_dirty, deferred ? small_n0(ws) : nullptr, 0);
     if (depth <= 12) fill_mip_local_kernel<12><<<xcd_grid(fill_tiles), kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
                                                                    grid_dirty, shadow, epoch, apply_nodes, ws->rec_key.as<u64>(),
-                                                                   small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr, ws->leaf_start.as<u32>(),
+                                                                   small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr, leaf_start,
                                                                    two_tier ? strad_bc : nullptr);
     else fill_mip_local_kernel<16><<<xcd_grid(fill_tiles), kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
                                                                    grid_dirty, shadow, epoch, apply_nodes, ws->rec_key.as<u64>(),
-                                                                   small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr, ws->leaf_start.as<u32>(),
+                                                                   small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr, leaf_start,
                                                                    two_tier ? strad_bc : nullptr);
     if (two_tier)
       mip_straddle2_kernel<<<strad_groups, kStrad2Threads, 0, stream>>>(pool->d_data, strad, strad_bc, sstrad, small_strad_ticket(ws, slot), fill_tiles,
