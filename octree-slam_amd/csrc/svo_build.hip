@@ -549,6 +549,24 @@ __device__ inline u32 average_tile(const u32 *__restrict__ pool, u32 child_base)
   return (r >> 3) + ((g >> 3) << 8) + ((b >> 3) << 16) + (a << 24);
 }
 
+// the same with agent-scope (sc1) loads: children that another lane of this launch has just stored write-through
+// (mip_straddle2_kernel, tier 1) must not come from a stale line of this CU's L1
+__device__ inline u32 average_tile_agent(u32 *__restrict__ pool, u32 child_base) {
+  unsigned long long *tile = reinterpret_cast<unsigned long long *>(pool + 2 * (size_t)child_base);
+  unsigned long long v[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) v[q] = __hip_atomic_load(tile + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u32 r = 0, g = 0, b = 0, a = 0;
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const u32 w1 = (u32)(v[q] >> 32);
+    r += w1 & 0xFF; g += (w1 >> 8) & 0xFF; b += (w1 >> 16) & 0xFF;
+    const u32 aa = w1 >> 24;
+    a = a > aa ? a : aa;
+  }
+  return (r >> 3) + ((g >> 3) << 8) + ((b >> 3) << 16) + (a << 24);
+}
+
 // the same over the words a deferred commit sees: a child written by THIS commit has its word in the shadow array
 // (entry = epoch << 32 | word), every other child keeps the pool's word
 __device__ inline u32 average_tile_deferred(const u32 *__restrict__ pool, const unsigned long long *__restrict__ shadow, u32 epoch,
@@ -632,6 +650,7 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   if (!shadow) SVO_HIGH_PRIO();  // in-place commits sit between two raycasts on the map stream; deferred ones run beside one
   __shared__ int last_owner[SVOSLAM_MAX_DEPTH + 1];  // per level: last lane of this workgroup owning a node there
   __shared__ int next_pos, next_c;                   // first head lane after this workgroup and its common-prefix length
+  __shared__ int min_c;                              // smallest common-prefix length of a head of this tile (99: no head)
   const int tid = (int)threadIdx.x;
 #ifdef SVO_FILL_PROF
   unsigned long long stamp[8];
@@ -672,10 +691,12 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
       strad[2 * ((size_t)tid * num_tiles + bid) + 1] = 0u;
     }
   }
-  if (tid == 0) { next_pos = 0x7FFFFFFF; next_c = -1; }  // no later head: every run ends with the array
+  if (tid == 0) { next_pos = 0x7FFFFFFF; next_c = -1; min_c = 99; }  // no later head: every run ends with the array
   __syncthreads();
-  if (head)
+  if (head) {
     for (int d = c + 1; d < depth; d++) atomicMax(&last_owner[d], j);
+    if (strad_bc) atomicMin(&min_c, c);
+  }
   if (ltn != kNotHead) atomicMin(&next_pos, jn);
   __syncthreads();
   if (next_pos == 0x7FFFFFFF) {  // no head in the next workgroup (all duplicates / invalid points): look further
@@ -695,11 +716,13 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   } else if (jn == next_pos) {
     next_c = (key_np == 1ull) ? 0 : common_levels(key_n, key_np, depth);
   }
-  // boundary record for the straddler pass: how many levels the first head after this tile shares with its predecessor
-  // (-1: none).  A level-d node that owns leaves at the end of tile t continues into later tiles iff bc[t] >= d.
+  // boundary record for the straddler pass: {how many levels the first head after this tile shares with its predecessor
+  // (-1: none), the smallest common-prefix length of a head IN this tile (99: none)}.  A level-d node that owns leaves at
+  // the end of tile t continues into later tiles iff bc[t].x >= d, and covers the whole of a later tile b iff no level-d
+  // node starts there: bc[b].y >= d.
   if (strad_bc) {
     __syncthreads();
-    if (tid == 0) strad_bc[bid] = next_c;
+    if (tid == 0) { strad_bc[2 * bid] = next_c; strad_bc[2 * bid + 1] = min_c; }
   }
   FILL_STAMP(1)
   // early_links != 0: the child tiles of this commit were initialised ahead of it (svo_fuse_split_early: split_all_kernel
@@ -909,13 +932,16 @@ __global__ __launch_bounds__(kStrad2Threads) void mip_straddle2_kernel(u32 *__re
                                                               u32 *__restrict__ grid_dirty, int32_t *__restrict__ h_sizes,
                                                               int *__restrict__ d_slot) {
   SVO_HIGH_PRIO();
-  __shared__ int bc[kStradGroup];
+  __shared__ int bc[kStradGroup], mc[kStradGroup];
   __shared__ int is_last;
   const int tid = (int)threadIdx.x, g = (int)blockIdx.x, groups = (int)gridDim.x;
   const int t0 = g * kStradGroup, t1 = (t0 + kStradGroup < num_tiles) ? t0 + kStradGroup : num_tiles;
   const uint2 *list = reinterpret_cast<const uint2 *>(strad);
   uint2 *super = reinterpret_cast<uint2 *>(sstrad);  // [level][group]
-  if (tid < kStradGroup) bc[tid] = (t0 + tid < t1) ? strad_bc[t0 + tid] : -1;
+  if (tid < kStradGroup) {
+    bc[tid] = (t0 + tid < t1) ? strad_bc[2 * (t0 + tid)] : -1;
+    mc[tid] = (t0 + tid < t1) ? strad_bc[2 * (t0 + tid) + 1] : 99;
+  }
   __syncthreads();
   // ---- tier 1 (first wavefront; lane i = tile t0 + i)
   const int t = t0 + tid;
@@ -925,12 +951,12 @@ __global__ __launch_bounds__(kStrad2Threads) void mip_straddle2_kernel(u32 *__re
       if (t < t1) {
         const uint2 e = list[(size_t)d * num_tiles + t];
         if (e.x != kNoStraddler) {
-          // the run leaves tile t (that made it a straddler) and ends in the first later tile whose own boundary record
-          // says the node does not continue
+          // the run leaves tile t (that made it a straddler: bc[t] >= d).  It ends inside a later tile b as soon as
+          // another level-d node starts there (mc[b] < d); otherwise it covers tile b to its end and goes on iff bc[b] >= d
           bool inside = false;
           for (int b = tid + 1; b < t1 - t0; b++)
-            if (bc[b] < d) { inside = true; break; }
-          if (inside) __hip_atomic_store(&pool[2 * (size_t)e.x + 1], average_tile(pool, e.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mc[b] < d || bc[b] < d) { inside = true; break; }
+          if (inside) __hip_atomic_store(&pool[2 * (size_t)e.x + 1], average_tile_agent(pool, e.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           else sup = e;
         }
       }
@@ -1689,7 +1715,7 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   DeviceBuffer &sb = slot == 0 ? ws->strad : ws->strad_b;
   // [level][tile] straddler entries | per-tile boundary records | [level][group] super straddlers (mip_straddle2_kernel)
   const int strad_groups = (int)cdiv(fill_tiles, kStradGroup);
-  const size_t strad_words = (size_t)(SVOSLAM_MAX_DEPTH + 1) * (size_t)fill_tiles * 2, bc_words = ((size_t)fill_tiles + 1) & ~(size_t)1;
+  const size_t strad_words = (size_t)(SVOSLAM_MAX_DEPTH + 1) * (size_t)fill_tiles * 2, bc_words = 2 * (size_t)fill_tiles;
   SVO_TRY(sb.reserve((strad_words + bc_words + (size_t)(SVOSLAM_MAX_DEPTH + 1) * (size_t)strad_groups * 2) * 4));
   u32 *strad = sb.as<u32>();
   int *strad_bc = reinterpret_cast<int *>(strad + strad_words);

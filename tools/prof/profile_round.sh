@@ -1,119 +1,137 @@
 #!/bin/bash
-# Regenerates the measurement records of a round on an MI355X box:  bash tools/prof/profile_round.sh r02
+# Regenerates the measurement records of a round on an MI355X box:  bash tools/prof/profile_round.sh r03 [quick]
 # Everything lands in gpurun_out/<tag>/ (scratch); the files worth judging are then copied to profiles/.
-# Counter passes use the SEQUENTIAL form of the bench (--no-overlap, SVOSLAM_GRAPHS=0, launch-chain tracker): counter
-# collection serialises kernels, which would deadlock the multi-stream pipeline and the one-launch tracker's spins;
-# per-kernel traffic does not depend on the overlap.
-TAG=${1:-r02}
+# Counter passes use the SEQUENTIAL form of the bench (--no-overlap, launch-chain tracker): counter collection serialises
+# dispatches, which would deadlock the multi-stream pipeline; per-kernel traffic does not depend on the overlap.  Only
+# the library's kernels are counted (--kernel-include-regex svoslam: the torch kernels that generate the synthetic
+# stream made the round-2 passes run into their timeouts).  A failed pass FAILS the script (no `|| echo`).
+set -u
+TAG=${1:-r03}
+QUICK=${2:-}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT="$R/gpurun_out/$TAG"; mkdir -p "$OUT"
 SCR=/tmp/svoslam_prof; mkdir -p $SCR
 cd /tmp; export TMPDIR=/tmp
 line() { grep '^{"metric"' | tail -1; }
 P="$OUT/$TAG"
-
-echo "== bench lines"
-python $R/bench.py --steps 100 --warmup 5 2>/dev/null | line > ${P}_bench_cfg3.json
-python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --stages 2>/dev/null | line > ${P}_bench_cfg3_with_stages.json
-python $R/bench.py --workload cfg4 --steps 40 --warmup 5 --no-cpu-baseline --stages 2>/dev/null | line > ${P}_bench_cfg4_with_stages.json
-python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_driver_args_20frames.json
-python $R/bench.py --steps 300 --warmup 5 --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_300frames.json
-python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --include-h2d 2>/dev/null | line > ${P}_bench_cfg3_include_h2d.json
-python $R/bench.py --workload cfg4 --steps 40 --warmup 5 2>/dev/null | line > ${P}_bench_cfg4.json
-SVOSLAM_FORCE_DIST=1 python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --exchange none 2>/dev/null | line > ${P}_bench_cfg3_forced_dist_none.json
-SVOSLAM_FORCE_DIST=1 python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --exchange deltas 2>/dev/null | line > ${P}_bench_cfg3_forced_dist_deltas.json
-for e in 0/2 1/2 0/4 2/4 0/8 3/8 7/8; do
-  python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --emulate-rank $e 2>/dev/null | line > ${P}_bench_cfg3_emulated_rank_$(echo $e | sed "s#/#_of_#").json
-done
-for e in 0/2 0/8 3/8; do
-  python $R/bench.py --workload cfg4 --steps 40 --warmup 5 --no-cpu-baseline --emulate-rank $e 2>/dev/null | line > ${P}_bench_cfg4_emulated_rank_$(echo $e | sed "s#/#_of_#").json
-done
-SVOSLAM_FORCE_DIST=1 python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --exchange allreduce 2>/dev/null | line > ${P}_bench_cfg3_forced_dist_allreduce.json
-for f in ${P}_bench_*.json; do python3 - "$f" <<'PY'
-import json, sys, os
-try:
-    d = json.load(open(sys.argv[1]))
-    print('%-52s %8.1f fps  march %.3f ms  frac %.3f' % (os.path.basename(sys.argv[1]), d['value'], d['roofline']['kernel_ms'], d['roofline']['frac']))
-except Exception as e:
-    print(os.path.basename(sys.argv[1]), "unreadable:", e)
-PY
-done
-
-echo "== kernel stats (rocprofv3 --kernel-trace --stats) of the bench"
-for W in cfg3 cfg4; do
-  S=100; [ $W = cfg4 ] && S=40
-  D=$SCR/ks_$W; mkdir -p $D
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o k -- python $R/bench.py --workload $W --steps $S --warmup 5 --no-cpu-baseline > $SCR/ks_$W.log 2>&1
-  f=$(find $D -name "*kernel_stats.csv" | sort | tail -1)
-  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --workload $W --steps $S --warmup 5 --no-cpu-baseline"
-    echo "# bench line of this profiled run: $(grep '^{"metric"' $SCR/ks_$W.log | tail -1)"
-    head -1 $f
-    grep -v -E "at::native|rocclr|^\"Name" $f; } > ${P}_bench_${W}_kernel_stats.csv
-  grep -E "cone_trace|track_persistent|fill_mip|build_accel" ${P}_bench_${W}_kernel_stats.csv | cut -d, -f1-4 | cut -c1-170
-done
-
-echo "== per-stage algorithmic bytes"
-python $R/tools/prof/stage_bytes.py ${P}_bench_cfg3_kernel_stats.csv ${P}_stage_bytes_cfg3.txt 2>/dev/null | tail -8
+FAILED=0
+fail() { echo "FAILED: $*"; FAILED=1; }
 
 echo "== PMC FETCH_SIZE / WRITE_SIZE per kernel (separate passes)"
-echo "# rocprofv3 --pmc <counter> --kernel-trace -- python bench.py --workload W --steps S --warmup 5 --no-cpu-baseline --no-overlap (SVOSLAM_GRAPHS=0 SVOSLAM_TRACK_CHAIN=1); one counter per pass; bytes per launch" > ${P}_pmc_fetch_write_per_kernel.txt
+PM=${P}_pmc_fetch_write_per_kernel.txt
+echo "# rocprofv3 --pmc <counter> --kernel-include-regex svoslam --kernel-trace -- python bench.py --workload W --no-overlap ... (SVOSLAM_TRACK_CHAIN=1); one counter per pass; KB per dispatch, all dispatches" > $PM
+declare -A FR TI ARGS
+FR[cfg3]=300; TI[cfg3]=10; ARGS[cfg3]="--steps 10 --warmup 2 --map-frames 300"
+FR[cfg4]=20;  TI[cfg4]=10; ARGS[cfg4]="--steps 10 --warmup 10 --map-frames 0"
+SPECS=""
 for W in cfg3 cfg4; do
-  S=60; [ $W = cfg4 ] && S=20
   for c in FETCH_SIZE WRITE_SIZE; do
-    D=$SCR/pm_${W}_$c; mkdir -p $D
-    SVOSLAM_GRAPHS=0 SVOSLAM_TRACK_CHAIN=1 timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $D -o p -- python $R/bench.py --workload $W --steps $S --warmup 5 --no-cpu-baseline --no-overlap > $SCR/pm.log 2>&1 || { echo "pass $W $c failed/timeout"; tail -3 $SCR/pm.log; }
+    D=$SCR/pm_${W}_$c; rm -rf $D; mkdir -p $D
+    SVOSLAM_TRACK_CHAIN=1 timeout 900 rocprofv3 --pmc $c --kernel-include-regex svoslam --kernel-trace --output-format csv -d $D -o p -- \
+      python $R/bench.py --workload $W ${ARGS[$W]} --no-overlap --no-cpu-baseline --allow-missing-traffic > $SCR/pm_${W}_$c.log 2>&1 || fail "pmc pass $W $c (tail: $(tail -2 $SCR/pm_${W}_$c.log))"
     f=$(find $D -name "*counter_collection.csv" | sort | tail -1)
-    [ -n "$f" ] && python3 - "$f" "$c" "$W" <<'PY' >> ${P}_pmc_fetch_write_per_kernel.txt
+    [ -n "$f" ] || fail "pmc pass $W $c left no counter_collection.csv"
+    cp "$f" $SCR/${W}_$c.csv
+    python3 - "$f" "$c" "$W" <<'PY' >> $PM
 import csv, sys, collections
 f, cname, w = sys.argv[1:4]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     if r["Counter_Name"] == cname:
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if "at::native" in k or "rocclr" in k: continue
-        acc[k].append(float(r["Counter_Value"]))
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
     print("%s,%s,%s,calls=%d,mean=%.1f,total=%.1f" % (w, cname, k, len(v), sum(v) / len(v), sum(v)))
 PY
   done
+  SPEC="$W:${FR[$W]}:${TI[$W]}:$SCR/${W}_FETCH_SIZE.csv:$SCR/${W}_WRITE_SIZE.csv"
+  if [ $W = cfg3 ]; then   # the one-launch tracker, on its own (the bench pass above runs the launch chain)
+    for c in FETCH_SIZE WRITE_SIZE; do
+      D=$SCR/pt_$c; rm -rf $D; mkdir -p $D
+      timeout 300 rocprofv3 --pmc $c --kernel-include-regex track_persistent --kernel-trace --output-format csv -d $D -o p -- \
+        python $R/tools/prof/track_only.py 12 > $SCR/pt_$c.log 2>&1 || fail "pmc pass one-launch tracker $c"
+      f=$(find $D -name "*counter_collection.csv" | sort | tail -1)
+      [ -n "$f" ] || fail "tracker pass $c left no csv"
+      cp "$f" $SCR/trk_$c.csv
+      python3 -c "
+import csv,sys
+v=[float(r['Counter_Value']) for r in csv.DictReader(open('$f')) if r['Counter_Name']=='$c']
+print('cfg3,$c,svoslam::track_persistent_kernel (tools/prof/track_only.py 12),calls=%d,mean=%.1f,total=%.1f'%(len(v),sum(v)/max(1,len(v)),sum(v)))" >> $PM
+    done
+    SPEC="$SPEC:$SCR/trk_FETCH_SIZE.csv:$SCR/trk_WRITE_SIZE.csv:11"
+  fi
+  SPECS="$SPECS $SPEC"
 done
-grep cone_trace ${P}_pmc_fetch_write_per_kernel.txt
-python3 - ${P}_pmc_fetch_write_per_kernel.txt "$OUT/pmc_traffic.json" $TAG <<'PY'
-import sys, json, re
-src, dst, tag = sys.argv[1:4]
-out = {"_comment": "HBM traffic of the dominant kernel from rocprofv3 PMC passes (one counter per pass); KB per launch, mean over the launches of the pass. bench.py reports traffic = (2*fetch_kb + write_kb)*1024 bytes: FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibrated there on wide coalesced reads; this kernel issues 8-byte gathers, so the factor is an upper bound here)."}
-for line in open(src):
-    m = re.match(r"(cfg\d),(FETCH_SIZE|WRITE_SIZE),([^,]*cone_trace_kernel.*),calls=\d+,mean=([\d.]+)", line)
-    if m:
-        d = out.setdefault(m.group(1), {}).setdefault("cone_trace_kernel", {"source": "profiles/%s_pmc_fetch_write_per_kernel.txt" % tag})
-        d["fetch_kb" if m.group(2) == "FETCH_SIZE" else "write_kb"] = float(m.group(4))
-json.dump(out, open(dst, "w"), indent=1)
-print(json.dumps({k: v for k, v in out.items() if k != "_comment"}))
-PY
+python3 $R/tools/prof/pmc_to_json.py "$OUT/pmc_traffic.json" $TAG $SPECS || fail "pmc_to_json"
+# the bench lines below read the traffic from profiles/pmc_traffic.json: install the fresh one in this box's copy
+[ $FAILED = 0 ] && cp "$OUT/pmc_traffic.json" $R/profiles/pmc_traffic.json
 
-echo "== cache counters of the march alone (standalone renders of the 100-frame map)"
-CC=${P}_cone_trace_cache_counters.txt
-echo "# rocprofv3 --pmc <counters> --kernel-trace -- python tools/prof/render_only.py 100 ; cone_trace_kernel launches only; mean per launch" > $CC
-i=0
-for c in "TCP_TOTAL_CACHE_ACCESSES_sum" "TCP_TCC_READ_REQ_sum" "TCC_HIT_sum" "TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_INSTS_VALU SQ_WAVE_CYCLES" "TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum" "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum"; do   # (the last pass sometimes runs into its 100 s limit on this pool: "pass ... failed" in the file then)
-  i=$((i+1)); D=$SCR/cc_$i; mkdir -p $D
-  timeout 100 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $D -o p -- python $R/tools/prof/render_only.py 100 > $SCR/cc.log 2>&1 || { echo "pass $c failed" >> $CC; tail -2 $SCR/cc.log; }
-  f=$(find $D -name "*counter_collection.csv" | sort | tail -1)
-  [ -n "$f" ] && python3 - "$f" <<'PY' >> $CC
+echo "== bench lines"
+python $R/bench.py 2>/dev/null | line > ${P}_bench_cfg3.json
+python $R/bench.py --steps 20 --warmup 5 2>/dev/null | line > ${P}_bench_cfg3_driver_args_20frames.json
+python $R/bench.py --workload cfg4 --steps 40 --warmup 5 2>/dev/null | line > ${P}_bench_cfg4.json
+python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --stages 2>/dev/null | line > ${P}_bench_cfg3_with_stages.json
+python $R/bench.py --workload cfg4 --steps 40 --warmup 5 --no-cpu-baseline --stages 2>/dev/null | line > ${P}_bench_cfg4_with_stages.json
+if [ -z "$QUICK" ]; then
+  python $R/bench.py --steps 100 --warmup 5 --map-frames 0 --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_young_map_105frames.json
+  python $R/bench.py --steps 300 --warmup 0 --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_all_300_frames_timed.json
+  python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --include-h2d 2>/dev/null | line > ${P}_bench_cfg3_include_h2d.json
+  for e in 0/2 0/4 0/8 3/8; do
+    python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --emulate-rank $e 2>/dev/null | line > ${P}_bench_cfg3_emulated_rank_$(echo $e | sed "s#/#_of_#").json
+  done
+  for e in 0/2 3/8; do
+    python $R/bench.py --workload cfg4 --steps 40 --warmup 5 --no-cpu-baseline --emulate-rank $e 2>/dev/null | line > ${P}_bench_cfg4_emulated_rank_$(echo $e | sed "s#/#_of_#").json
+  done
+fi
+for f in ${P}_bench_*.json; do python3 - "$f" <<'PY'
+import json, sys, os
+try:
+    d = json.load(open(sys.argv[1]))
+    r = d['roofline']
+    print('%-56s %8.1f fps  dominant %s %.3f ms frac %.3f traffic %s' % (os.path.basename(sys.argv[1]), d['value'], r['kernel'].split(' ')[0], r['kernel_ms'], r['frac'],
+          ('%.1f MB' % (r['traffic'] / 1e6)) if r.get('traffic') else r.get('traffic')))
+    for s in d.get('roofline_stages', []):
+        print('      %-8s %.3f ms  alg %.1f MB  frac %.3f  traffic %s' % (s['stage'], s['kernel_ms'], s['alg_bytes_per_launch'] / 1e6, s['frac'],
+              ('%.1f MB' % (s['traffic'] / 1e6)) if s.get('traffic') else s.get('traffic')))
+except Exception as e:
+    print(os.path.basename(sys.argv[1]), "unreadable:", e); sys.exit(0)
+PY
+done
+[ -s ${P}_bench_cfg3.json ] || fail "default bench line empty"
+
+echo "== kernel stats (rocprofv3 --kernel-trace --stats) of the bench"
+for W in cfg3 cfg4; do
+  A="--steps 20 --warmup 5"; [ $W = cfg4 ] && A="--workload cfg4 --steps 40 --warmup 5"
+  D=$SCR/ks_$W; rm -rf $D; mkdir -p $D
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o k -- python $R/bench.py $A --no-cpu-baseline > $SCR/ks_$W.log 2>&1 || fail "kernel stats $W"
+  f=$(find $D -name "*kernel_stats.csv" | sort | tail -1)
+  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $A --no-cpu-baseline   (all dispatches of the run: map history + warm-up + timed + the sequential stage pass)"
+    echo "# bench line of this profiled run: $(grep '^{"metric"' $SCR/ks_$W.log | tail -1)"
+    head -1 $f
+    grep -v -E "at::native|rocclr|^\"Name" $f; } > ${P}_bench_${W}_kernel_stats.csv
+  # the timed frames alone: mean duration of each kernel's LAST dispatches, from the kernel trace
+  t=$(find $D -name "*kernel_trace.csv" | sort | tail -1)
+  [ -n "$t" ] && python3 - "$t" > ${P}_bench_${W}_kernel_trace_timed_frames.txt <<'PY'
 import csv, sys, collections
-acc = collections.defaultdict(list)
+rows = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-    if "cone_trace_kernel" in k: acc[(k[-44:], r["Counter_Name"])].append(float(r["Counter_Value"]))
-for k, v in sorted(acc.items()):
-    print("%s,%s,calls=%d,mean=%.1f" % (k[0], k[1], len(v), sum(v) / len(v)))
+    n = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    if "svoslam" not in n: continue
+    rows[n].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+print("# per kernel: dispatches, mean duration over ALL dispatches, mean over the LAST 20 % (old map: the timed frames), us")
+for n, v in sorted(rows.items(), key=lambda kv: -sum(d for _, d in kv[1])):
+    v.sort()
+    d = [x for _, x in v]
+    tail = d[-max(1, len(d) // 5):]
+    print("%-70s %7d %9.2f %9.2f" % (n[:70], len(d), sum(d) / len(d) / 1e3, sum(tail) / len(tail) / 1e3))
 PY
+  grep -E "cone_trace|track_persistent|fill_mip|mip_straddle|icp_accumulate" ${P}_bench_${W}_kernel_stats.csv | cut -d, -f1-4 | cut -c1-150
 done
-tail -30 $CC
 
-echo "== march anatomy, scheduler timeline, tracker hand-off profile"
-python $R/tools/prof/ray_anatomy.py 105 2>&1 | grep -v amdgpu.ids > ${P}_ray_anatomy_cfg3_105frames.txt; tail -3 ${P}_ray_anatomy_cfg3_105frames.txt
+if [ -z "$QUICK" ]; then
+echo "== march anatomy, scheduler timeline"
+python $R/tools/prof/ray_anatomy.py 300 2>&1 | grep -v amdgpu.ids > ${P}_ray_anatomy_cfg3_300frames.txt; tail -3 ${P}_ray_anatomy_cfg3_300frames.txt
 python $R/tools/prof/runner_timeline.py 2>&1 | grep -v amdgpu.ids > ${P}_runner_timeline_cfg3.txt; tail -4 ${P}_runner_timeline_cfg3.txt
-python $R/tools/prof/runner_timeline.py 3/8 2>&1 | grep -v -E "amdgpu.ids|RCCL|HIP version|ROCm version|Hostname|Librccl" > ${P}_runner_timeline_cfg3_emulated_rank_3_of_8.txt; tail -4 ${P}_runner_timeline_cfg3_emulated_rank_3_of_8.txt
-SVOSLAM_RUNNER_REPLICAS=2 python $R/tools/prof/runner_timeline.py 2>&1 | grep -v amdgpu.ids > ${P}_runner_timeline_cfg3_two_replicas.txt; tail -4 ${P}_runner_timeline_cfg3_two_replicas.txt
+fi
 ls -la "$OUT"
+echo "profile_round: FAILED=$FAILED"
+exit $FAILED

@@ -7,7 +7,7 @@ pkg = svoslam_pkg.load()
 synth = importlib.import_module("octree_slam_amd.synth")
 pl = importlib.import_module("octree_slam_amd.pipeline")
 W, H, D, edge = 640, 480, 12, 4.096
-K = 60
+K = int(os.environ.get('TIMELINE_FRAMES', '300'))   # the map's age matters: BASELINE config 3 is 300 frames
 if os.environ.get("TIMELINE_WORKLOAD") == "cfg4":  # 1920x1080, depth 14, half edge 8.192 m (bench.py --workload cfg4)
     W, H, D, edge = 1920, 1080, 14, 8.192
 depth, rgb = synth.render_stream(K, W, H, device="cuda")
@@ -33,10 +33,11 @@ print("ms/frame %.3f" % ((time.perf_counter() - t0) / K * 1e3))
 tl = P._runner.timeline()
 names = ["maps0", "maps1", "trk0", "pose", "prep0", "plan0", "plan1", "com0", "com1", "ray1"]
 print("frame " + " ".join("%8s" % n for n in names))
-for i in range(40, 46):
-    print("%5d " % i + " ".join("%8.3f" % (tl[i][k] - tl[40][0]) for k in range(10)))
-d = np.diff(tl[20:58, 9]); print("march-end period: mean %.3f ms" % d.mean())
-print("durations (mean, frames 20..58): maps %.3f track %.3f bp+sort %.3f plan %.3f commit %.3f commit->ray end %.3f" % (
-    (tl[20:58,1]-tl[20:58,0]).mean(), (tl[20:58,3]-tl[20:58,2]).mean(), (tl[20:58,5]-tl[20:58,4]).mean(), (tl[20:58,6]-tl[20:58,5]).mean(),
-    (tl[20:58,8]-tl[20:58,7]).mean(), (tl[20:58,9]-tl[20:58,8]).mean()))
-print("waits: pose->prep0 %.3f  plan1->com0 %.3f  ray1(prev)->com0 %.3f" % ((tl[20:58,4]-tl[20:58,3]).mean(), (tl[20:58,7]-tl[20:58,6]).mean(), (tl[21:58,7]-tl[20:57,9]).mean()))
+A, B = K - 40, K - 2
+for i in range(K - 20, K - 14):
+    print("%5d " % i + " ".join("%8.3f" % (tl[i][k] - tl[K - 20][0]) for k in range(10)))
+d = np.diff(tl[A:B, 9]); print("march-end period: mean %.3f ms" % d.mean())
+print("durations (mean, the last 38 frames): maps %.3f track %.3f bp+sort %.3f plan %.3f commit %.3f commit->ray end %.3f" % (
+    (tl[A:B,1]-tl[A:B,0]).mean(), (tl[A:B,3]-tl[A:B,2]).mean(), (tl[A:B,5]-tl[A:B,4]).mean(), (tl[A:B,6]-tl[A:B,5]).mean(),
+    (tl[A:B,8]-tl[A:B,7]).mean(), (tl[A:B,9]-tl[A:B,8]).mean()))
+print("waits: pose->prep0 %.3f  plan1->com0 %.3f  ray1(prev)->com0 %.3f" % ((tl[A:B,4]-tl[A:B,3]).mean(), (tl[A:B,7]-tl[A:B,6]).mean(), (tl[A + 1:B,7]-tl[A:B - 1,9]).mean()))
