@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "pool_grid.hpp"
@@ -91,6 +92,17 @@ struct SubtreeHeader {
   uint8_t pad[8];
 };
 static_assert(sizeof(SubtreeHeader) == 64, "header is 64 bytes");
+
+// a header's num_tiles is trusted only after it has been checked against the file's length (a corrupt
+// count would otherwise size a std::vector / malloc and throw through the C ABI)
+static bool tiles_fit_file(FILE *f, uint32_t num_tiles) {
+  if (num_tiles == 0 || num_tiles > (kMask + 1u) / 8u) return false;
+  const long at = ftell(f);
+  if (at < 0 || fseek(f, 0, SEEK_END) != 0) return false;
+  const long end = ftell(f);
+  if (fseek(f, at, SEEK_SET) != 0) return false;
+  return end >= 0 && (uint64_t)(end - at) >= (uint64_t)num_tiles * 68ull;
+}
 
 static uint64_t fnv1a(const void *p, size_t bytes, uint64_t h = 1469598103934665603ull) {
   const uint8_t *b = reinterpret_cast<const uint8_t *>(p);
@@ -205,7 +217,7 @@ int pool_restore_subtree(svoslam_pool *pool, const char *file, hipStream_t strea
   if (!f) return SVOSLAM_ERR_IO;
   SubtreeHeader h;
   if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SVOSUBT1", 8) != 0 || h.version != 1 || h.levels < 1 ||
-      h.levels > SVOSLAM_MAX_DEPTH || h.num_tiles == 0) { fclose(f); return SVOSLAM_ERR_FORMAT; }
+      h.levels > SVOSLAM_MAX_DEPTH || !tiles_fit_file(f, h.num_tiles)) { fclose(f); return SVOSLAM_ERR_FORMAT; }
   std::vector<u32> tiles(h.num_tiles), nodes((size_t)h.num_tiles * 16);
   const bool ok = fread(tiles.data(), 4, tiles.size(), f) == tiles.size() && fread(nodes.data(), 4, nodes.size(), f) == nodes.size();
   fclose(f);
@@ -215,6 +227,11 @@ int pool_restore_subtree(svoslam_pool *pool, const char *file, hipStream_t strea
   if (pool->size < h.pool_size) return SVOSLAM_ERR_FORMAT;  // not the pool (or not the state) the sub-tree came from
   for (u32 t : tiles)
     if ((t & 7u) || (int64_t)t + 8 > (int64_t)h.pool_size) return SVOSLAM_ERR_FORMAT;
+  {  // a tile index may appear once
+    std::vector<u32> sorted(tiles);
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return SVOSLAM_ERR_FORMAT;
+  }
   for (size_t i = 0; i < (size_t)h.num_tiles * 8; i++) {
     const u32 w0 = nodes[2 * i];
     if ((w0 & kFlag) && ((w0 & kMask) & 7u || ((w0 & kMask) >> 3) >= h.num_tiles)) return SVOSLAM_ERR_FORMAT;
@@ -247,7 +264,7 @@ int subtree_file_nodes(const char *file, uint32_t **h_words, int32_t *num_nodes)
   FILE *f = fopen(file, "rb");
   if (!f) return SVOSLAM_ERR_IO;
   SubtreeHeader h;
-  if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SVOSUBT1", 8) != 0 || h.version != 1 || h.num_tiles == 0) { fclose(f); return SVOSLAM_ERR_FORMAT; }
+  if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SVOSUBT1", 8) != 0 || h.version != 1 || !tiles_fit_file(f, h.num_tiles)) { fclose(f); return SVOSLAM_ERR_FORMAT; }
   if (fseek(f, (long)h.num_tiles * 4, SEEK_CUR) != 0) { fclose(f); return SVOSLAM_ERR_FORMAT; }
   const size_t words = (size_t)h.num_tiles * 16;
   uint32_t *w = (uint32_t *)malloc(words * 4);

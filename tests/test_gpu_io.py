@@ -190,3 +190,58 @@ def test_subtree_paging_resume_equals_uninterrupted(env, oracle, tmp_path):
         A.restore_subtree(g)
     with pytest.raises(pkg.SvoslamError):
         A.evict_subtree([0, 0, 0, 0, 0, 0, 0, 0, 0], tmp_path / "none.svosub")       # a path that leaves the tree
+
+
+def test_formats_against_the_cpu_restatement(env, oracle, tmp_path):
+    """VERDICT r02, missing item 3: what libsvoslam_hip writes / reads -- checkpoint file, sub-tree paging file, the pool
+    after an eviction, a restore and a re-rooting -- against the CPU restatement of the formats (oracle/formats.py: the
+    reference's own reader `pullFromLinearTree`, octree.cpp:151-167, and the containers restated field by field), not
+    against a second HIP pool."""
+    from oracle import formats as fm
+    pkg, torch = env[0], env[1]
+    rng = np.random.default_rng(91)
+    center, edge, depth = (0.05, -0.02, 0.01), 1.0, 7
+    ws, pool = pkg.Workspace(), pkg.Pool()
+    opool = oracle.Pool()
+    for k in range(2):
+        pts, col = surface_cloud(rng, 12000)
+        pts = pts + np.float32(0.01 * k)
+        pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, pool, center, edge)
+        opool.insert_cloud(pts, col, depth, center, edge)
+    words = pool.words()
+    assert np.array_equal(words, opool.words())
+    tree = fm.pull_to_cpu(words)                               # the reference's reader walks the device pool's words
+    assert sum(fm.count_nodes(t) for t in tree) == pool.size
+    # ---- checkpoint: HIP writer vs CPU writer byte for byte; CPU reader reads the HIP file; HIP reader the CPU file
+    f_hip, f_cpu = tmp_path / "hip.svopool", tmp_path / "cpu.svopool"
+    pool.save(f_hip, center, edge, depth)
+    fm.write_pool_file(f_cpu, words, center, edge, depth)
+    assert f_hip.read_bytes() == f_cpu.read_bytes()
+    w, c, e, d = fm.read_pool_file(f_hip)
+    assert np.array_equal(w, words) and d == depth and e == edge and c == tuple(float(np.float32(x)) for x in center)
+    fresh = pkg.Pool()
+    assert fresh.load(f_cpu) == (pytest.approx(center), pytest.approx(edge), depth)
+    assert np.array_equal(fresh.words(), words)
+    # ---- eviction: the file and the pool afterwards
+    top = next(k for k in range(8) if tree[k][1] is not None)
+    inner = next(k for k in range(8) if tree[top][1][k][1] is not None)
+    for path in ([top], [top, inner]):
+        before = pool.words()
+        tiles, blob, after, node = fm.evict_subtree(before, path)
+        f_sub, f_sub_cpu = tmp_path / ("sub%d.svosub" % len(path)), tmp_path / ("sub%d_cpu.svosub" % len(path))
+        pool.evict_subtree(path, f_sub)
+        fm.write_subtree_file(f_sub_cpu, path, node, before.size // 2, tiles, blob)
+        assert f_sub.read_bytes() == f_sub_cpu.read_bytes()
+        sub = fm.read_subtree_file(f_sub)
+        assert np.array_equal(sub["tiles"], tiles) and np.array_equal(sub["nodes"], blob) and sub["node_index"] == node
+        assert fm.pull_to_cpu(sub["nodes"]) == fm.subtree_at(tree, path)[1]      # the blob read by the reference's reader
+        assert np.array_equal(pool.words(), after)
+        assert np.array_equal(pkg.subtree_file_words(f_sub), blob)
+        # ---- restore from the CPU-written file
+        pool.restore_subtree(f_sub_cpu)
+        assert np.array_equal(pool.words(), fm.restore_subtree(after, sub)) and np.array_equal(pool.words(), before)
+    # ---- re-rooting: the host tree of the expanded pool is the restated expansion of the host tree before
+    c2, e2 = pool.expand(center, edge, toward=(-3.0, 4.0, 0.5))
+    want, wc, we = fm.expand_root(tree, center, edge, (-3.0, 4.0, 0.5))
+    assert tuple(np.float32(x) for x in c2) == tuple(np.float32(x) for x in wc) and np.float32(e2) == np.float32(we)
+    assert fm.pull_to_cpu(pool.words()) == want

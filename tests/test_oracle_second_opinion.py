@@ -924,3 +924,216 @@ def test_cube_mesh_second_opinion(oracle):
     my_ibo = (cube_ibo[None, :] + (np.arange(n, dtype=np.int32) * 36)[:, None]).reshape(-1)
     assert bits_equal(vbo, my_vbo) and bits_equal(cbo, my_cbo) and bits_equal(nbo, my_nbo)
     assert np.array_equal(ibo, my_ibo)
+
+
+# ------------------------------------------------------------------------------------------------ bilateral filter
+# Second reading of bilateralKernel / bilateralFilter (src/sensor/image_kernels.cu:18-20,142-186), written from the source
+# alone (this kernel had ONE reading).  What the source fixes: the window [max(x-3,0), min(x+4, W-1)) x
+# [max(y-3,0), min(y+4, H-1)) -- the last column / row never enters a window (Q12) --, the weights exp(-(d2 * 0.5/4.5^2 +
+# c2 * 0.5/40^2)) with the depth sigma term formed in DOUBLE and rounded (`float depth = 0.5 / (40.0f * 40.0f)`), row-major
+# accumulation, and __float2int_rn of the quotient stored to uint16.  What it does not fix and this build resolved
+# (DESIGN.md R4 / the oracle's header): `__expf` -> cephes expf in explicit fused multiply-adds, and `sum1 += depth *
+# weight` as ONE fused multiply-add (nvcc's default contraction of exactly this statement).  Here every binary32 operation
+# is done in exact rational arithmetic and rounded once (rn32), so an fma is exact-product-plus-addend rounded once.
+from fractions import Fraction
+
+
+def rn32(q):
+    """round a Fraction to the nearest binary32 (ties to even); returns a Fraction that is exactly representable"""
+    if q == 0:
+        return Fraction(0)
+    s = -1 if q < 0 else 1
+    a = -q if q < 0 else q
+    e = a.numerator.bit_length() - a.denominator.bit_length()       # 2^(e-1) <= a < 2^(e+1)
+    if Fraction(2) ** e > a:
+        e -= 1                                                         # now 2^e <= a < 2^(e+1)
+    e = max(e, -126)                                                   # subnormal spacing below 2^-126
+    ulp = Fraction(2) ** (e - 23)
+    m = a / ulp
+    f = m.numerator // m.denominator
+    r = m - f
+    if r > Fraction(1, 2) or (r == Fraction(1, 2) and f & 1):
+        f += 1
+    return s * f * ulp
+
+
+def F(x):
+    return Fraction(float(np.float32(x)))
+
+
+def cephes_expf(x):
+    """the R4 resolution restated from its specification: range reduction k = rint(x log2 e), r = fma(k, -0.693359375, x),
+    r = fma(k, 2.12194440e-4, r); degree-5 polynomial in Horner form with fma; e = fma(p, r*r, r) + 1; scale by 2^k; results
+    for x < -87 are 0"""
+    if x < -87:
+        return Fraction(0)
+    kf = rn32(x * F(1.44269504088896341))
+    k = int(Fraction(round(kf)))                                       # rintf: kf is within 2^23, ties to even
+    if abs(kf - k) == Fraction(1, 2):
+        k = int(2 * round(kf / 2))
+    k = Fraction(k)
+    r = rn32(k * F(-0.693359375) + x)
+    r = rn32(k * F(2.12194440e-4) + r)
+    p = F(1.9875691500E-4)
+    for c in (1.3981999507E-3, 8.3334519073E-3, 4.1665795894E-2, 1.6666665459E-1, 5.0000001201E-1):
+        p = rn32(p * r + F(c))
+    rr = rn32(r * r)
+    e = rn32(rn32(p * rr + r) + 1)
+    return e * Fraction(2) ** int(k)                                   # ldexpf: exact while the result is normal
+
+
+def bilateral_second(depth):
+    h, w = depth.shape
+    sig_spat = rn32(Fraction(1, 2) / rn32(F(4.5) * F(4.5)))           # 0.5f / (4.5f * 4.5f), :180
+    sig_dep = rn32(Fraction(1, 2) / Fraction(1600))                    # (float)(0.5 / (40.0f * 40.0f)): double, then rounded, :181
+    out = np.zeros((h, w), np.uint16)
+    d = depth.astype(np.int64)
+    for y in range(h):
+        for x in range(w):
+            value = int(d[y, x])
+            tx, ty = min(x - 3 + 7, w - 1), min(y - 3 + 7, h - 1)      # :154-155
+            s1 = s2 = Fraction(0)
+            for cy in range(max(y - 3, 0), ty):                        # :160
+                for cx in range(max(x - 3, 0), tx):                    # :162
+                    dep = int(d[cy, cx])
+                    space2 = Fraction((x - cx) ** 2 + (y - cy) ** 2)   # int products, converted: exact
+                    prod = ((value - dep) ** 2) & 0xFFFFFFFF           # `int` product: wraps beyond 2^31 (a 65535 next to a small depth)
+                    prod = prod - (1 << 32) if prod & 0x80000000 else prod
+                    color2 = rn32(Fraction(prod))                      # int -> float conversion rounds above 2^24
+                    arg = -rn32(rn32(space2 * sig_spat) + rn32(color2 * sig_dep))
+                    if arg > 88:                                       # the weight overflows to +inf: sum2 = inf, sum1 = inf or NaN,
+                        s1 = None                                      # the quotient is NaN whatever follows -> 0 below
+                        continue
+                    if s1 is None:
+                        continue
+                    wgt = cephes_expf(arg)
+                    s1 = rn32(Fraction(dep) * wgt + s1)                # one fused multiply-add
+                    s2 = rn32(s2 + wgt)
+            if s2 == 0 or s1 is None:
+                out[y, x] = 0                                          # 0/0 = NaN -> __float2int_rn gives 0
+                continue
+            q = rn32(s1 / s2)
+            f = q.numerator // q.denominator
+            r = q - f
+            if r > Fraction(1, 2) or (r == Fraction(1, 2) and f & 1):
+                f += 1
+            out[y, x] = f & 0xFFFF
+    return out
+
+
+def test_bilateral_second_opinion(oracle):
+    rng = np.random.default_rng(4)
+    h, w = 13, 17
+    yy, xx = np.mgrid[0:h, 0:w]
+    depth = (900 + 35 * xx + 11 * yy + rng.integers(0, 25, (h, w))).astype(np.uint16)
+    depth[4:8, 9:] += 600                                              # a depth edge: weights that underflow
+    depth[rng.random((h, w)) < 0.06] = 0                               # dropouts take part like any other value
+    depth[0, 0] = 65535
+    got = oracle.bilateral(depth)
+    want = bilateral_second(depth)
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+    # Q12: the last column and row are in nobody's window -> changing them changes nothing but themselves
+    d2 = depth.copy(); d2[:, -1] = 7; d2[-1, :] = 9
+    g2 = oracle.bilateral(d2)
+    assert np.array_equal(g2[:-1, :-1], got[:-1, :-1])
+
+
+# ------------------------------------------------------------------------------------------------ VoxelPipe THIN raster
+# Second reading of the mesh voxelization rule (VERDICT r02: ONE reading so far), from the VoxelPipe sources the reference
+# vendors: coarse binning and the integer triangle box (external/include/voxelpipe/coarse.h:59-102, 380-412), the
+# tile / plane test and the box clamped to the tile (fine.h:936-1000), triangle_setup / plane_setup (utils.h:185-254),
+# the per-scan-line integer u-range (fine.h:130-152, 230-262) and the one w per (u, v) (fine.h:318-341), with N cells per
+# axis over the mesh's own box and tiles of T = 8 (voxelization.cu:283-299).  Every operation in numpy binary32, in
+# source order.  Output: the SET of occupied voxels and, per voxel, the highest triangle id (R12).
+f32 = np.float32
+
+
+def thin_voxelize(vbo, bbox0, bbox1, log_n, log_t=3):
+    N, T = 1 << log_n, 1 << log_t
+    b0 = [f32(x) for x in bbox0]
+    delta = [f32(f32(bbox1[k]) - b0[k]) / f32(N) for k in range(3)]        # voxelpipe_inline.h:249-252
+    inv = [f32(N) / f32(f32(bbox1[k]) - b0[k]) for k in range(3)]           # :254-257
+    SEL = {0: (1, 2, 0), 1: (0, 2, 1), 2: (0, 1, 2)}                        # axis -> (U, V, W)  utils.h:117-176
+    out = {}
+    for tri_id, tri in enumerate(np.asarray(vbo, np.float32).reshape(-1, 3, 3)):
+        v = [[f32(c) for c in p] for p in tri]
+        lo, hi = [], []
+        for k in range(3):                                                  # coarse.h:62-92
+            vals = [f32(v[i][k] - b0[k]) * inv[k] for i in range(3)]
+            mn = min(vals[2], min(vals[1], vals[0])); mx = max(vals[2], max(vals[1], vals[0]))
+            lo.append(min(max(int(mn), 0), N - 1))
+            hi.append(min(max(int(math.ceil(mx)), 0), N - 1))
+        e0 = [v[1][k] - v[0][k] for k in range(3)]; e1 = [v[2][k] - v[1][k] for k in range(3)]; e2 = [v[0][k] - v[2][k] for k in range(3)]
+        n = [e0[2] * e2[1] - e0[1] * e2[2], e0[0] * e2[2] - e0[2] * e2[0], e0[1] * e2[0] - e0[0] * e2[1]]     # anti_cross, utils.h:97-103
+        byx, byz, bzx = abs(n[1]) > abs(n[0]), abs(n[1]) > abs(n[2]), abs(n[2]) > abs(n[0])
+        axis = (1 if byz else 2) if byx else (2 if bzx else 0)              # coarse.h:98-102
+        U, V, W = SEL[axis]
+        sgn = f32(1.0) if (n[0] > 0 if axis == 0 else n[1] < 0 if axis == 1 else n[2] > 0) else f32(-1.0)
+        nn, dd = [], []
+        for e, p in ((e0, v[0]), (e1, v[1]), (e2, v[2])):                   # triangle_setup, utils.h:204-222
+            nx, ny = f32(-e[V]) * sgn, e[U] * sgn
+            d = f32(-(f32(nx * p[U]) + f32(ny * p[V]))) + max(f32(0), delta[U] * nx) + max(f32(0), delta[V] * ny)
+            nn.append((nx, ny)); dd.append(d)
+        a = [f32(f32(nn[i][0] * b0[U]) + f32(nn[i][1] * b0[V])) + dd[i] for i in range(3)]
+        ndu = [nn[i][0] * delta[U] for i in range(3)]; ndv = [nn[i][1] * delta[V] for i in range(3)]
+        with np.errstate(divide="ignore"):
+            inv_du = [f32(1.0) / ndu[i] for i in range(3)]                   # fine.h:222-226
+        inv_n = f32(1.0) / n[W]                                             # __frcp_rn, utils.h:246
+        px, py = n[U] * inv_n, n[V] * inv_n
+        pz = f32(f32(f32(f32(f32(px * v[0][U]) + f32(py * v[0][V])) + v[0][W]) - b0[W]) - f32(px * b0[U])) - f32(py * b0[V])
+        for tz in range(lo[2] >> log_t, (hi[2] >> log_t) + 1):              # coarse.h:380-412: every tile the integer box overlaps
+            for ty in range(lo[1] >> log_t, (hi[1] >> log_t) + 1):
+                for tx in range(lo[0] >> log_t, (hi[0] >> log_t) + 1):
+                    tile = (tx << log_t, ty << log_t, tz << log_t)
+                    c = [delta[k] * f32(T) if n[k] > 0 else f32(0) for k in range(3)]   # fine.h:938-958
+                    r1 = f32(f32(n[0] * (c[0] - v[0][0])) + f32(n[1] * (c[1] - v[0][1]))) + f32(n[2] * (c[2] - v[0][2]))
+                    r2 = f32(f32(n[0] * (f32(delta[0] * f32(T) - c[0]) - v[0][0])) + f32(n[1] * (f32(delta[1] * f32(T) - c[1]) - v[0][1]))) + \
+                        f32(n[2] * (f32(delta[2] * f32(T) - c[2]) - v[0][2]))
+                    npl = f32(f32(n[0] * (b0[0] + f32(tile[0]) * delta[0])) + f32(n[1] * (b0[1] + f32(tile[1]) * delta[1]))) + \
+                        f32(n[2] * (b0[2] + f32(tile[2]) * delta[2]))
+                    if not f32(f32(npl + r1) * f32(npl + r2)) <= 0:
+                        continue
+                    bb0 = [max(lo[k], tile[k]) for k in range(3)]; bb1 = [min(hi[k], tile[k] + T - 1) for k in range(3)]   # :986-992
+                    for vv in range(bb0[V], bb1[V] + 1):                   # generate_mask, fine.h:228-262
+                        b = [a[i] + f32(vv) * ndv[i] for i in range(3)]
+                        mn_u, mx_u = bb0[U], bb1[U]
+                        for i in range(3):                                 # compute_scanline_bounds, fine.h:130-152
+                            if ndu[i] > 0:
+                                mn_u = max(mn_u, int(math.ceil(f32(-b[i]) * inv_du[i])))
+                            elif ndu[i] < 0:
+                                mx_u = min(mx_u, int(f32(-b[i]) * inv_du[i]))
+                            elif b[i] < 0:
+                                mn_u = mx_u + 1
+                        if mn_u > mx_u:
+                            continue
+                        lm, rm = (mn_u - tile[U]) & (T - 1), (mx_u - tile[U]) & (T - 1)   # packed into LOG_TILE_SIZE-bit fields, :254-262
+                        vf = f32(f32(vv) + f32(0.5)) * delta[V]
+                        for uu in range(lm + tile[U], rm + tile[U] + 1):   # rasterize_scanline, fine.h:318-341
+                            uf = f32(f32(uu) + f32(0.5)) * delta[U]
+                            wf = pz - f32(f32(px * uf) + f32(py * vf))
+                            ww = int(f32(wf * inv[W]))
+                            if tile[W] <= ww < tile[W] + T:
+                                cell = [0, 0, 0]
+                                cell[U], cell[V], cell[W] = uu, vv, ww
+                                out[tuple(cell)] = tri_id               # triangles in id order: the highest id stays (R12)
+    return out
+
+
+def test_thin_raster_second_opinion(oracle, tmp_path):
+    import meshgen
+    cases = []
+    p = str(tmp_path / "cube.obj"); meshgen.write_cube_obj(p); cases.append((p, 5))
+    p = str(tmp_path / "soup.obj"); meshgen.write_soup_obj(p, n=40, seed=3); cases.append((p, 5))
+    p = str(tmp_path / "ell.obj"); meshgen.write_sphere_obj(p, rings=6, segs=8, quads=False); cases.append((p, 4))
+    for path, log_n in cases:
+        mesh = oracle.mesh_load_obj(path)
+        ce, co, idx = oracle.mesh_to_voxel_grid(mesh, None, log_n)
+        want = thin_voxelize(mesh["vbo"], mesh["bbox0"], mesh["bbox1"], log_n)
+        # the oracle's tiled index (voxelization.cu:141-164): tile * T^3 + pix, tile = tx + M ty + M^2 tz, pix = px + T py + T^2 pz
+        T, M = 8, (1 << log_n) >> 3
+        cells = set()
+        for i in idx.tolist():
+            t, pix = divmod(i, T ** 3)
+            cells.add(((t % M) * T + pix % T, (t // M % M) * T + pix // T % T, (t // (M * M)) * T + pix // (T * T)))
+        assert cells == set(want), (path, len(cells), len(want), sorted(cells ^ set(want))[:6])
+        assert len(cells) > 20
