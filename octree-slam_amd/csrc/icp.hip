@@ -768,6 +768,15 @@ static bool track_one_launch_forced() {
 
 // > 0: the image is too large for the register-resident form (1920x1080: 16 pixels per lane at the finest level, which
 // would be re-read from HBM every iteration inside the one launch: measured 525 frames/s against 718 with the chain)
+// SVOSLAM_TRACK_HYBRID=0|1|2: coarse pyramid levels a LARGE image (whose finest level does not fit the registers) still
+// runs in the one launch before the launch chain takes over (track_persistent_plan_coarse)
+static int track_hybrid_levels() {
+  static const int v = [] { const char *e = getenv("SVOSLAM_TRACK_HYBRID"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
+  return v;
+}
+
+// returns 0: the whole frame was enqueued; 1: nothing was (caller: launch chain from level 2); 2 + l: levels 2 .. l + 1 were
+// enqueued in the one launch, the launch chain continues at level l
 static int track_one_launch(svoslam_camera *c, hipStream_t s) {
   TrackArgs A;
   for (int level = 0; level < 3; level++) {
@@ -784,7 +793,13 @@ static int track_one_launch(svoslam_camera *c, hipStream_t s) {
   }
   if (c->capacity < 2) return 1;  // no room for a solver and a worker workgroup on this stream's CUs: the launch chain
   SVO_TRY(track_persistent_plan(A, c->capacity));
-  if (A.slots[0] > kTrkSlots && !track_one_launch_forced()) return 1;  // caller falls back to the launch chain
+  if (A.slots[0] > kTrkSlots && !track_one_launch_forced()) {
+    const int hybrid = track_hybrid_levels();
+    if (hybrid == 0) return 1;  // caller: the launch chain for every level
+    SVO_TRY(track_persistent_plan_coarse(A, c->capacity, hybrid));
+    SVO_TRY(track_persistent_launch(c->d_state, c->d_sync, c->d_tickets, c->d_rows, A, s));
+    return 2 + (2 - hybrid);     // the chain continues at level 2 - hybrid
+  }
   return track_persistent_launch(c->d_state, c->d_sync, c->d_tickets, c->d_rows, A, s);
 }
 
@@ -794,6 +809,7 @@ int camera_track(svoslam_camera *c, hipStream_t s) {
   const bool has_icp = c->tracked >= 1;
   const int ring_slot = (int)(c->tracked & 3u);
   StageScope timed(has_icp ? kStageTracker : -1, s);  // (the first frame has no ICP: not a tracker sample)
+  int top_level = 2;  // coarsest level the launch chain handles
   if (has_icp && !track_chain_forced() && !c->rgbd) {
     const int rc = track_one_launch(c, s);
     if (rc < 0) return rc;
@@ -803,6 +819,7 @@ int camera_track(svoslam_camera *c, hipStream_t s) {
       c->frame_has_icp = false;
       return SVOSLAM_OK;
     }
+    if (rc >= 2) top_level = rc - 2;  // hybrid: the coarser levels are already enqueued
   }
   // Work maps (default; SVOSLAM_TRACK_WORKMAPS=0 replays the chain from the raw maps in every iteration): allocated on
   // the first chain-tracked frame (cameras served by the one-launch tracker never pay for them), before any capture
@@ -815,10 +832,10 @@ int camera_track(svoslam_camera *c, hipStream_t s) {
   GraphKey key;
   key.add((unsigned long long)(c->tracked % 3u)).add((unsigned long long)has_icp)
      .add((unsigned long long)c->band_first).add((unsigned long long)c->band_rows).add((unsigned long long)c->rgbd)
-     .add((unsigned long long)work_maps);
+     .add((unsigned long long)work_maps).add((unsigned long long)top_level);
   auto enqueue = [&]() -> int {
     if (has_icp) {
-      for (int level = 2; level >= 0; level--) {  // coarse to fine, :103
+      for (int level = top_level; level >= 0; level--) {  // coarse to fine, :103
         LevelArgs a = level_args(c, level);
         int end;
         const int blocks = accumulate_range(a.w, a.h, a.first, a.num, end);

@@ -440,6 +440,40 @@ int track_persistent_capacity(hipStream_t s, int *max_workgroups) {
   return SVOSLAM_OK;
 }
 
+// The hybrid of large images (round 3): only the `coarse_levels` coarsest pyramid levels run in the one launch (1: level 2;
+// 2: levels 2 and 1), the finer ones stay with the launch chain (icp.hip), which picks update_trans / lost up from
+// CamState exactly where the solver's iteration tail left them.  A coarse iteration costs one hand-off (~11 us) here
+// against two launches (~45 us beside the march at 1920x1080) there.  Levels that stay with the chain get no participants
+// and no iterations; the worker count follows the finest level that is included.
+int track_persistent_plan_coarse(TrackArgs &A, int capacity, int coarse_levels) {
+  if (coarse_levels < 1 || coarse_levels > 2) return SVOSLAM_ERR_INVALID_ARG;
+  const int finest = 3 - coarse_levels;  // finest level handled here (2 or 1)
+  int cap = env_int("SVOSLAM_TRACK_WORKERS", kTrkMaxWorkers);
+  if (cap > capacity - 1) cap = capacity - 1;
+  if (cap < 1) return SVOSLAM_ERR_INVALID_ARG;
+  const int slots_target = env_int("SVOSLAM_TRACK_SLOTS", kTrkSlots);
+  long long W = 1;
+  for (int l = 2; l >= 0; l--) {
+    if (l < finest) { A.participants[l] = 0; A.slots[l] = 0; A.iters[l] = 0; continue; }
+    const long long n = A.level[l].end > A.level[l].first ? (long long)A.level[l].end - A.level[l].first : 0;
+    long long P = l == finest ? (n + (long long)kTrkThreads * slots_target - 1) / ((long long)kTrkThreads * slots_target)
+                              : (n + 2 * kTrkThreads - 1) / (2 * kTrkThreads);
+    if (P < 1) P = 1;
+    if (P > cap) P = cap;
+    A.participants[l] = (int)P;
+    A.slots[l] = (int)((n + P * kTrkThreads - 1) / (P * kTrkThreads));
+    if (P > W) W = P;
+  }
+  // participation must be a suffix of the levels (a worker of a coarser level also works on every finer one)
+  if (A.participants[2] > A.participants[finest]) {
+    A.participants[2] = A.participants[finest];
+    const long long n = (long long)A.level[2].end - A.level[2].first;
+    A.slots[2] = (int)((n + (long long)A.participants[2] * kTrkThreads - 1) / ((long long)A.participants[2] * kTrkThreads));
+  }
+  A.workers = (int)W;
+  return SVOSLAM_OK;
+}
+
 int track_persistent_plan(TrackArgs &A, int capacity) {
   // workers: the finest level decides (kTrkSlots pixels per lane); coarser levels use as many of them as give a lane
   // two pixels.  All workers take part in the finest (last) level.

@@ -34,6 +34,7 @@ struct TrackArgs {
 
 int track_persistent_capacity(hipStream_t s, int *max_workgroups);
 int track_persistent_plan(TrackArgs &A, int capacity);
+int track_persistent_plan_coarse(TrackArgs &A, int capacity, int coarse_levels);  // only the coarsest 1 or 2 levels; the rest: launch chain
 int track_persistent_profile(const TrackSync *d_sync, unsigned long long *out, hipStream_t s);
 size_t track_persistent_ticket_bytes();  // arrival counters: [2 banks][32 epochs][8], zeroed with TrackSync
 int track_persistent_launch(CamState *st, TrackSync *sy, unsigned *tickets, double *rows, const TrackArgs &A, hipStream_t s);

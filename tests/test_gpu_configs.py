@@ -242,6 +242,35 @@ def test_cfg3_alpha_saturation_long_run(env, oracle, mode):
     assert np.array_equal(o.view(np.uint32), ro.view(np.uint32))
 
 
+# ------------------------------------------------------------------------------------------------ cfg1
+def test_cfg1_cube_obj(env, oracle):
+    """BASELINE config 1 on the reference's own objs/cube.obj (tests/data/cube.obj): Scene::loadObjFile ->
+    voxelizeMeshes at 2^5 -> depth-5 SVO -> one 256x256 render from the view of SURVEY 8d.1, both render modes, against the
+    digests of the oracle's host walk (tests/golden/cfg1_cube.json, tests/golden/make_cfg1_golden.py)."""
+    pkg, torch, synth, pl = env
+    gold = json.load(open(os.path.join(HERE, "golden", "cfg1_cube.json")))
+    obj = os.path.join(HERE, "data", "cube.obj")
+    scene = pkg.Scene()
+    scene.load_obj(obj)
+    scene.voxelize_meshes(octree=True, log_n=5)
+    mesh = pkg.Mesh(obj)
+    ce, co, idx, scale = pkg.mesh_to_voxel_grid(pkg.Workspace(), mesh, None, 5)
+    assert mesh.n_tris == gold["n_tris"] == 12 and len(idx) == gold["n_voxels"]
+    assert _sha(idx.astype(np.int64)) == gold["voxel_index_sha256"]
+    assert _sha(ce.cpu().numpy()) == gold["voxel_centers_sha256"] and _sha(co.cpu().numpy()) == gold["voxel_colors_sha256"]
+    svo = scene.svo()
+    assert svo["num_nodes"] == gold["num_nodes"] and svo["max_depth"] == 5
+    assert [float(v) for v in svo["center"]] == gold["center"] and svo["size"] == gold["size"]
+    assert _sha(scene.pool_words()) == gold["pool_sha256"]
+    view = oracle.look_at((0.0, 0.1, -0.6), (0.0, 0.1, 0.0), (0.0, 1.0, 0.0))
+    for mode in (0, 1):
+        img = torch.zeros((256, 256, 4), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+        pkg.cone_trace_svo(img, 45.0, view, svo["data_ptr"], svo["center"], svo["size"], mode, cnt)
+        assert cnt.tolist() == gold["image_steps_levels"][mode], mode
+        assert _sha(img.cpu().numpy()) == gold["images_sha256"][mode], mode
+
+
 # ------------------------------------------------------------------------------------------------ cfg2
 def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()

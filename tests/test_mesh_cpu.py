@@ -72,3 +72,21 @@ def test_oracle_cube_voxelization_appendix_d8(tmp_path, oracle):
         assert (c == 31).sum() < 100              # max faces: only the conservative fringe
     assert np.array_equal(np.unique(co, axis=0), [[0.0, 1.0, 0.0, 0.0]])   # no texture -> green (voxelization.cu:101-103)
     assert np.array_equal(idx, np.sort(idx)) and np.unique(idx).size == idx.size
+
+
+def test_cfg1_cube_obj_oracle_matches_committed_digests():
+    """BASELINE config 1 (the CPU-runnable case) on the reference's own objs/cube.obj (tests/data/cube.obj): 12 triangles,
+    recentred box y in [0, 0.2], 2^5 voxelization, depth-5 SVO, one 256x256 render by the oracle's host walk -- against
+    tests/golden/cfg1_cube.json (the GPU side: tests/test_gpu_configs.py::test_cfg1_cube_obj)."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_cfg1_golden", os.path.join(here, "golden", "make_cfg1_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "golden", "cfg1_cube.json")))
+    got = mod.compute()
+    assert got == want
+    assert got["n_tris"] == 12 and got["bbox0"][1] == 0.0 and abs(got["bbox1"][1] - 0.2) < 1e-6      # SURVEY 8d.1
+    assert got["size"] == got["bbox1"][0] and 129 in got["alpha_values"]                              # A = 127 + 2 after one insert
