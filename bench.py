@@ -207,10 +207,20 @@ def main():
         for k in range(1, total):
             dcam.pair_delta(depth[k - 1], rgb[k - 1], depth[k], rgb[k], table[k])
         torch.cuda.synchronize()
+        tab_k = tab_i = None
+        if P.shard_sort:   # what the owners of the other frames would all-gather after sorting them
+            tab_k = torch.empty((total, width * height), dtype=torch.int64, device="cuda")
+            tab_i = torch.empty((total, width * height), dtype=torch.int32, device="cuda")
+            scam, sws = pkg.Camera(width, height, P.focal, P.focal), pkg.Workspace()
+            for k in range(total):
+                scam.apply_delta(table[k], k)
+                pkg.svo_fuse_sort_frame(sws, depth[k], scam.fusion_transform_ptr(), P.focal, P.focal, max_depth, center, edge)
+                pkg.svo_fuse_export_sorted(sws, width * height, tab_k[k], tab_i[k])
+            torch.cuda.synchronize()
 
     def expect(lo, hi):
         if emu is not None:
-            emu.expect(table[lo:hi], lo, per_rank)
+            emu.expect(table[lo:hi], lo, per_rank, tab_k[lo:hi] if tab_k is not None else None, tab_i[lo:hi] if tab_i is not None else None)
 
     def barrier():
         if (world > 1 or force_dist) and emu is None:
@@ -341,18 +351,19 @@ def main():
     # ---- sequential per-stage pass over three MORE frames (after the timed region): the fusion's launches, the maps
     stage_seq = None
     if stage_pass:
-        fus = {"sort": [0.0, 0], "plan": [0.0, 0], "commit": [0.0, 0], "maps": [0.0, 0]}
+        fus = {"sort": [0.0, 0], "plan": [0.0, 0], "commit": [0.0, 0], "maps": [0.0, 0], "tracker": [0.0, 0]}
         alg_f, marches_seq = [], []
         lo = torch.tensor(center, device="cuda", dtype=torch.float32) - edge
         for k in range(total, total + extra):
             torch.cuda.synchronize()
-            pkg.stage_timing([pkg.STAGE_FUSE_SORT, pkg.STAGE_FUSE_PLAN, pkg.STAGE_FUSE_COMMIT, pkg.STAGE_MAPS, pkg.STAGE_MARCH])
+            pkg.stage_timing([pkg.STAGE_FUSE_SORT, pkg.STAGE_FUSE_PLAN, pkg.STAGE_FUSE_COMMIT, pkg.STAGE_MAPS, pkg.STAGE_MARCH, pkg.STAGE_TRACKER])
             P.track(depth[k], rgb[k], k)
             size0 = P.pool.size
             P.fuse_frame(depth[k], rgb[k])
             P.render(views[k])
             torch.cuda.synchronize()
-            for nm, st in (("sort", pkg.STAGE_FUSE_SORT), ("plan", pkg.STAGE_FUSE_PLAN), ("commit", pkg.STAGE_FUSE_COMMIT), ("maps", pkg.STAGE_MAPS)):
+            for nm, st in (("sort", pkg.STAGE_FUSE_SORT), ("plan", pkg.STAGE_FUSE_PLAN), ("commit", pkg.STAGE_FUSE_COMMIT), ("maps", pkg.STAGE_MAPS),
+                           ("tracker", pkg.STAGE_TRACKER)):
                 ms, n = pkg.stage_timing_read(st)
                 fus[nm][0] += ms; fus[nm][1] += 1
             marches_seq.append(pkg.stage_timing_read(pkg.STAGE_MARCH)[0])
@@ -375,7 +386,7 @@ def main():
                           "floors, not bandwidth"))
         roofs[-1]["timed"] = "sequential pass over %d frames after the timed region (sum of the event-bracketed launch groups)" % extra
         roofs[-1]["parts_ms"] = {nm: fus[nm][0] / extra for nm in ("sort", "plan", "commit")}
-        stage_seq = {"maps_ms": fus["maps"][0] / extra, "fuse_sort_ms": fus["sort"][0] / extra, "fuse_plan_ms": fus["plan"][0] / extra,
+        stage_seq = {"maps_ms": fus["maps"][0] / extra, "tracker_ms": fus["tracker"][0] / extra, "fuse_sort_ms": fus["sort"][0] / extra, "fuse_plan_ms": fus["plan"][0] / extra,
                      "fuse_commit_ms": fus["commit"][0] / extra, "march_ms": sum(marches_seq) / extra,
                      "note": "stages one after the other on an otherwise idle GPU, frames %d..%d" % (total, total + extra - 1)}
     # the dominant kernel: the larger mean duration of the two measured live

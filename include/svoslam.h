@@ -172,6 +172,14 @@ int svoslam_svo_fuse_sort_frame(svoslam_workspace *ws, const uint16_t *d_depth, 
 int svoslam_svo_fuse_plan(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream);
 int svoslam_svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int32_t n, int32_t max_depth,
                             svoslam_pool *pool, void *stream);
+/* Sorted keys from elsewhere (frame-sharded sessions, DESIGN.md section 5: the rank that owns a frame sorts it and the sorted
+ * arrays are all-gathered): _export_sorted copies the outcome of this workspace's sort phase to d_keys_out[n] (ascending
+ * Morton keys, invalid points = 1) and d_idx_out[n] (point index per key; equal keys in ascending index order: R1);
+ * _adopt_sorted makes such arrays the outcome of a workspace's sort phase -- svoslam_svo_fuse_plan / _split_early /
+ * _commit follow as after svoslam_svo_fuse_sort.  The adopted arrays stay the caller's and must stay valid until the
+ * commit has run.  Replaces nothing in the reference (svo.cu:602 sorts every cloud where it is fused). */
+int svoslam_svo_fuse_export_sorted(svoslam_workspace *ws, int32_t n, unsigned long long *d_keys_out, uint32_t *d_idx_out, void *stream);
+int svoslam_svo_fuse_adopt_sorted(svoslam_workspace *ws, const unsigned long long *d_keys, const uint32_t *d_idx, int32_t n, int32_t max_depth);
 /* Optional, between plan and commit (same workspace, same pool, direct commit only): initialises the child tiles of the
  * planned splits (splitNodes' tile writes, svo.cu:239-276) beyond the pool's present size -- nothing a ray march of the pool
  * can reach -- so that it may run WHILE the previous frame is still being rendered; the commit then writes the links from
@@ -568,6 +576,17 @@ int svoslam_runner_run_sharded(svoslam_runner *runner, const uint16_t *const *d_
                                const long long *timestamps, const float *views, int32_t n, const float *const *d_deltas,
                                void *const *delta_events, const uint8_t *march, uint8_t *const *d_images, int32_t row_first,
                                int32_t rows, unsigned long long *d_steps, void *caller_stream);
+/* The same with the SORT sharded as well (round 3): the rank that owns frame i has back-projected and sorted it
+ * (svoslam_svo_fuse_sort_frame with the pose its own chain of svoslam_camera_apply_delta gives, svoslam_svo_fuse_export_sorted)
+ * and the sorted arrays have been all-gathered: d_sorted_keys[i] / d_sorted_idx[i] (all n entries required),
+ * sorted_events[i] (optional) = what the plan waits for before it reads them.  This rank then only plans and commits every
+ * frame and ray-marches its own; the bounding box of svoslam_runner_bbox is not computed in this form. */
+int svoslam_runner_run_sharded_presorted(svoslam_runner *runner, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs,
+                                         const long long *timestamps, const float *views, int32_t n, const float *const *d_deltas,
+                                         void *const *delta_events, const uint8_t *march, uint8_t *const *d_images,
+                                         const unsigned long long *const *d_sorted_keys, const uint32_t *const *d_sorted_idx,
+                                         void *const *sorted_events, int32_t row_first, int32_t rows, unsigned long long *d_steps,
+                                         void *caller_stream);
 
 /* ------------------------------------------------------------------------
  * Timing hook: replaces startTiming/stopTiming (include/octree_slam/

@@ -92,6 +92,8 @@ SIGNATURES = {
     "svoslam_svo_fuse_commit": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_split_early": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_plan_structure": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
+    "svoslam_svo_fuse_adopt_sorted": (C.c_int, [_vp, _vp, _vp, _i32, _i32]),
+    "svoslam_svo_fuse_export_sorted": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
     "svoslam_pool_structure_begin": (C.c_int, [C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_commit_to": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _i32, _i32, _vp]),
     "svoslam_svo_fuse_commit_deferred": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
@@ -128,6 +130,9 @@ SIGNATURES = {
     "svoslam_runner_bbox": (C.c_int, [_vp, _fp]),
     "svoslam_runner_run_sharded": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_longlong), _fp, _i32, C.POINTER(_vp),
                                              C.POINTER(_vp), C.POINTER(C.c_uint8), C.POINTER(_vp), _i32, _i32, _vp, _vp]),
+    "svoslam_runner_run_sharded_presorted": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_longlong), _fp, _i32, C.POINTER(_vp),
+                                                       C.POINTER(_vp), C.POINTER(C.c_uint8), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
+                                                       C.POINTER(_vp), _i32, _i32, _vp, _vp]),
     "svoslam_scene_create": (C.c_int, [C.POINTER(_vp)]),
     "svoslam_scene_destroy": (C.c_int, [_vp]),
     "svoslam_scene_load_obj": (C.c_int, [_vp, C.c_char_p]),
@@ -393,6 +398,17 @@ def svo_fuse_sort_frame(ws, depth_image, pose_ptr, fx, fy, max_depth, center, ed
                                             int(max_depth), _fa(center, 3), float(edge_length), _ptr(bbox7), _stream()))
 
 
+def svo_fuse_export_sorted(ws, n, keys_out, idx_out):
+    """the outcome of the workspace's sort phase -> keys_out (int64 cuda tensor [n]), idx_out (int32 cuda tensor [n])"""
+    check(lib().svoslam_svo_fuse_export_sorted(ws._h, int(n), _ptr(keys_out), _ptr(idx_out), _stream()))
+
+
+def svo_fuse_adopt_sorted(ws, keys, idx, max_depth):
+    """sorted keys / point indices from elsewhere become the outcome of the workspace's sort phase (they must stay alive
+    until the commit has run)"""
+    check(lib().svoslam_svo_fuse_adopt_sorted(ws._h, _ptr(keys), _ptr(idx), int(keys.shape[0]), int(max_depth)))
+
+
 def svo_fuse_plan(ws, n, max_depth, pool):
     """phase 2: split planning against the pool's current tree (reads the pool)."""
     check(lib().svoslam_svo_fuse_plan(ws._h, int(n), max_depth, C.byref(pool._p), _stream()))
@@ -584,6 +600,26 @@ class Runner:
         self._keep = (depths, rgbs, deltas, delta_events, images)   # alive until the next call (the work is asynchronous)
         check(lib().svoslam_runner_run_sharded(self._h, dp, rp, ts, vw.ctypes.data_as(_fp), n, dl, ev, mf, im, int(row_first), int(rows),
                                                _ptr(counters), _stream()))
+
+    def run_sharded_presorted(self, depths, rgbs, timestamps, views, deltas, delta_events, march, images, sorted_keys, sorted_idx,
+                              sorted_events, row_first, rows, counters=None):
+        """run_sharded with every frame's sorted keys / point indices supplied (svoslam_runner_run_sharded_presorted):
+        sorted_keys / sorted_idx = per-frame int64 / int32 cuda tensors, sorted_events = per-frame torch.cuda.Event or None"""
+        n = len(timestamps)
+        dp = (C.c_void_p * n)(*[d.data_ptr() for d in depths])
+        rp = (C.c_void_p * n)(*[r.data_ptr() for r in rgbs])
+        ts = (C.c_longlong * n)(*[int(t) for t in timestamps])
+        vw = np.ascontiguousarray(np.stack([np.asarray(v, np.float32).reshape(16) for v in views]), np.float32)
+        dl = (C.c_void_p * n)(*[(d.data_ptr() if d is not None else None) for d in deltas])
+        ev = (C.c_void_p * n)(*[(e.cuda_event if e is not None else None) for e in delta_events]) if delta_events is not None else None
+        mf = (C.c_uint8 * n)(*[1 if m else 0 for m in march])
+        im = (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in images])
+        sk = (C.c_void_p * n)(*[k.data_ptr() for k in sorted_keys])
+        si = (C.c_void_p * n)(*[k.data_ptr() for k in sorted_idx])
+        se = (C.c_void_p * n)(*[(e.cuda_event if e is not None else None) for e in sorted_events]) if sorted_events is not None else None
+        self._keep = (depths, rgbs, deltas, delta_events, images, sorted_keys, sorted_idx, sorted_events)
+        check(lib().svoslam_runner_run_sharded_presorted(self._h, dp, rp, ts, vw.ctypes.data_as(_fp), n, dl, ev, mf, im, sk, si, se,
+                                                         int(row_first), int(rows), _ptr(counters), _stream()))
 
     def bbox(self):
         """{min xyz, max xyz, any} of the last frame's point cloud (main.cpp:43)"""

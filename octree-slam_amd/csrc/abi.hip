@@ -179,6 +179,14 @@ int svoslam_pool_structure_begin(svoslam_pool *pool, void *stream) {
   NEED_DEVICE();
   return pool_structure_begin(pool, S(stream));
 }
+int svoslam_svo_fuse_adopt_sorted(svoslam_workspace *ws, const unsigned long long *d_keys, const uint32_t *d_idx, int32_t n, int32_t max_depth) {
+  NEED_DEVICE();
+  return svo_fuse_adopt_sorted(ws, d_keys, d_idx, n, max_depth);
+}
+int svoslam_svo_fuse_export_sorted(svoslam_workspace *ws, int32_t n, unsigned long long *d_keys_out, uint32_t *d_idx_out, void *stream) {
+  NEED_DEVICE();
+  return svo_fuse_export_sorted(ws, n, d_keys_out, d_idx_out, S(stream));
+}
 int svoslam_svo_fuse_plan_structure(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream) {
   NEED_DEVICE();
   return svo_fuse_plan_structure(ws, n, max_depth, pool, S(stream));

@@ -775,6 +775,12 @@ static int track_hybrid_levels() {
   return v;
 }
 
+// SVOSLAM_TRACK_STREAM=1: large images run all 19 iterations in the streaming one-launch form (default: see camera_track)
+static bool track_stream_enabled() {
+  static const bool on = [] { const char *e = getenv("SVOSLAM_TRACK_STREAM"); return e && e[0] == '1'; }();
+  return on;
+}
+
 // returns 0: the whole frame was enqueued; 1: nothing was (caller: launch chain from level 2); 2 + l: levels 2 .. l + 1 were
 // enqueued in the one launch, the launch chain continues at level l
 static int track_one_launch(svoslam_camera *c, hipStream_t s) {
@@ -793,6 +799,21 @@ static int track_one_launch(svoslam_camera *c, hipStream_t s) {
   }
   if (c->capacity < 2) return 1;  // no room for a solver and a worker workgroup on this stream's CUs: the launch chain
   SVO_TRY(track_persistent_plan(A, c->capacity));
+  if (A.slots[0] > kTrkSlots && !track_one_launch_forced() && track_stream_enabled()) {
+    // the streaming one-launch form (track_persistent.hip): work maps allocated on first use (before any capture)
+    if (!c->work_v) {
+      const size_t n = (size_t)c->width * (size_t)c->height;
+      SVO_HIP(hipMalloc((void **)&c->work_v, n * 12));
+      SVO_HIP(hipMalloc((void **)&c->work_n, n * 12));
+    }
+    int cap1 = 0;
+    SVO_TRY(track_persistent_capacity(s, &cap1, 1));
+    if (cap1 >= 2) {
+      A.work_v = c->work_v; A.work_n = c->work_n;
+      SVO_TRY(track_persistent_plan_stream(A, cap1));
+      return track_persistent_launch(c->d_state, c->d_sync, c->d_tickets, c->d_rows, A, s);
+    }
+  }
   if (A.slots[0] > kTrkSlots && !track_one_launch_forced()) {
     const int hybrid = track_hybrid_levels();
     if (hybrid == 0) return 1;  // caller: the launch chain for every level

@@ -199,8 +199,17 @@ int svoslam_runner_destroy(svoslam_runner *r) {
 static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs, const long long *timestamps,
                            const float *views, int32_t n, uint8_t *d_image, int32_t row_first, int32_t rows,
                            unsigned long long *d_steps, void *caller_stream, const float *const *d_deltas,
-                           void *const *delta_events, const uint8_t *march, uint8_t *const *d_images) {
+                           void *const *delta_events, const uint8_t *march, uint8_t *const *d_images,
+                           const unsigned long long *const *d_sorted_keys = nullptr, const uint32_t *const *d_sorted_idx = nullptr,
+                           void *const *sorted_events = nullptr) {
   const bool sharded = d_deltas != nullptr;
+  // presorted (frame-sharded sessions with a sharded SORT): frame i's sorted keys / point indices come
+  // from whichever rank owns the frame (all-gathered); back-projection + keys + sort are skipped here, the plan adopts them
+  const bool presorted = d_sorted_keys != nullptr;
+  if (presorted && (!sharded || !d_sorted_idx)) return SVOSLAM_ERR_INVALID_ARG;
+  if (presorted)
+    for (int i = 0; i < n; i++)
+      if (!d_sorted_keys[i] || !d_sorted_idx[i]) return SVOSLAM_ERR_INVALID_ARG;
   if (!r || n < 0 || (n > 0 && (!d_depths || !d_rgbs || !timestamps || !views || (!d_image && !d_images)))) return SVOSLAM_ERR_INVALID_ARG;
   if (n == 0) return SVOSLAM_OK;
   if (row_first < 0 || rows < 0 || row_first + rows > r->h) return SVOSLAM_ERR_INVALID_ARG;
@@ -316,7 +325,11 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
       SVO_HIP(hipMemcpyAsync(r->in_prep, d_depths[i], px * 2, hipMemcpyDeviceToDevice, s_sort));
       SVO_HIP(hipMemcpyAsync(r->in_rgb[i % kRing], d_rgbs[i], px * 3, hipMemcpyDeviceToDevice, s_sort));
     }
-    if (r->fused_front) {
+    if (presorted) {
+      if (sorted_events && sorted_events[i]) SVO_HIP(hipStreamWaitEvent(s_sort, reinterpret_cast<hipEvent_t>(sorted_events[i]), 0));
+      SVO_TRY(svoslam_svo_fuse_adopt_sorted(ws, d_sorted_keys[i], d_sorted_idx[i], npts, r->depth));
+      SVO_HIP(hipEventRecord(ev_bp[i], s_sort));
+    } else if (r->fused_front) {
       // main.cpp:39-44 + computeKeys in one launch, no point cloud in memory (svoslam_svo_fuse_sort_frame), then the sort
       SVO_TRY(svoslam_svo_fuse_sort_frame(ws, staged ? r->in_prep : d_depths[i], fusion_ptr[i], r->w, r->h, r->fx, r->fy, r->depth,
                                           r->center, r->edge, r->bbox, s_sort));
@@ -483,6 +496,17 @@ int svoslam_runner_run_sharded(svoslam_runner *r, const uint16_t *const *d_depth
   if (n > 0 && (!d_deltas || !d_images)) return SVOSLAM_ERR_INVALID_ARG;
   return runner_run_impl(r, d_depths, d_rgbs, timestamps, views, n, nullptr, row_first, rows, d_steps, caller_stream, d_deltas,
                          delta_events, march, d_images);
+}
+
+int svoslam_runner_run_sharded_presorted(svoslam_runner *r, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs,
+                                         const long long *timestamps, const float *views, int32_t n, const float *const *d_deltas,
+                                         void *const *delta_events, const uint8_t *march, uint8_t *const *d_images,
+                                         const unsigned long long *const *d_sorted_keys, const uint32_t *const *d_sorted_idx,
+                                         void *const *sorted_events, int32_t row_first, int32_t rows, unsigned long long *d_steps,
+                                         void *caller_stream) {
+  if (n > 0 && (!d_deltas || !d_images || !d_sorted_keys || !d_sorted_idx)) return SVOSLAM_ERR_INVALID_ARG;
+  return runner_run_impl(r, d_depths, d_rgbs, timestamps, views, n, nullptr, row_first, rows, d_steps, caller_stream, d_deltas,
+                         delta_events, march, d_images, d_sorted_keys, d_sorted_idx, sorted_events);
 }
 
 // computePointCloudBoundingBox of the last frame enqueued (main.cpp:43): {min xyz, max xyz, any}.  Blocking.

@@ -1467,12 +1467,8 @@ static bool sort_pairs_forced() {
   return on;
 }
 
-// keys + sort of one batch: from a point array (fs == nullptr) or straight from a depth image and a device-resident pose
-static int fuse_sort_impl(svoslam_workspace *ws, const float *d_points, const FrameSource *fs, int n, int depth, const float center[3],
-                          float edge, float *d_bbox7, hipStream_t stream) {
-  if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
-  ws->sorted_keys = nullptr; ws->sorted_idx = nullptr; ws->planned_n = -1;
-  if (n == 0) return SVOSLAM_OK;
+// buffers of the asynchronous phases (plan + commit) for a batch of n sorted keys
+static int reserve_async(svoslam_workspace *ws, int n, int depth) {
   const int64_t rmax = max_records(n, depth);
   if (rmax > 0x7FFFFFFFll / 8) return SVOSLAM_ERR_POOL_LIMIT;
   SVO_TRY(reserve_common(ws, n, depth));
@@ -1481,6 +1477,42 @@ static int fuse_sort_impl(svoslam_workspace *ws, const float *d_points, const Fr
   SVO_TRY(ws->rec_pass.reserve((size_t)rmax));
   SVO_TRY(ws->leaf_rec0.reserve((size_t)n * 4));
   SVO_TRY(ws->leaf_start.reserve((size_t)n * 4));
+  return SVOSLAM_OK;
+}
+
+// Sorted keys from ELSEWHERE (round 3: another rank of a frame-sharded session sorted this frame and all-gathered the
+// result): the workspace adopts d_keys[n] (ascending depth-D Morton keys with their leading 1, invalid points = 1) and
+// d_idx[n] (the point index of each key: the colour svo_fuse_commit looks up; equal keys in ascending index order, as the
+// stable sort leaves them) as the outcome of its sort phase.  svo_fuse_plan / _commit follow as after svo_fuse_sort.  The
+// arrays stay the caller's and must stay valid until the commit has run.
+int svo_fuse_adopt_sorted(svoslam_workspace *ws, const unsigned long long *d_keys, const uint32_t *d_idx, int n, int depth) {
+  if (!ws || n < 0 || (n > 0 && (!d_keys || !d_idx))) return SVOSLAM_ERR_INVALID_ARG;
+  if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
+  ws->sorted_keys = nullptr; ws->sorted_idx = nullptr; ws->planned_n = -1;
+  if (n == 0) return SVOSLAM_OK;
+  SVO_TRY(reserve_async(ws, n, depth));
+  SVO_TRY(ws->tile_hist.reserve((size_t)256 * ((size_t)cdiv(n, kPlanThreads) + 1) * 4));
+  ws->sorted_keys = d_keys; ws->sorted_idx = d_idx;
+  return SVOSLAM_OK;
+}
+
+// the outcome of this workspace's sort phase, copied out (device to device) for an exchange: d_keys_out[n], d_idx_out[n]
+int svo_fuse_export_sorted(svoslam_workspace *ws, int n, unsigned long long *d_keys_out, uint32_t *d_idx_out, hipStream_t stream) {
+  if (!ws || n < 0 || (n > 0 && (!d_keys_out || !d_idx_out))) return SVOSLAM_ERR_INVALID_ARG;
+  if (n == 0) return SVOSLAM_OK;
+  if (!ws->sorted_keys || !ws->sorted_idx) return SVOSLAM_ERR_INVALID_ARG;  // svo_fuse_sort has not run on this workspace
+  SVO_HIP(hipMemcpyAsync(d_keys_out, ws->sorted_keys, (size_t)n * 8, hipMemcpyDeviceToDevice, stream));
+  SVO_HIP(hipMemcpyAsync(d_idx_out, ws->sorted_idx, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+  return SVOSLAM_OK;
+}
+
+// keys + sort of one batch: from a point array (fs == nullptr) or straight from a depth image and a device-resident pose
+static int fuse_sort_impl(svoslam_workspace *ws, const float *d_points, const FrameSource *fs, int n, int depth, const float center[3],
+                          float edge, float *d_bbox7, hipStream_t stream) {
+  if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
+  ws->sorted_keys = nullptr; ws->sorted_idx = nullptr; ws->planned_n = -1;
+  if (n == 0) return SVOSLAM_OK;
+  SVO_TRY(reserve_async(ws, n, depth));
   const int key_bits = 3 * depth + 1, idx_bits = packed_idx_bits(n);
   const bool packed = key_bits + idx_bits <= 64 && !sort_pairs_forced();
   if (!packed && fs) return SVOSLAM_ERR_INVALID_ARG;  // (callers fall back to the stand-alone kernels + svo_fuse_sort)

@@ -157,14 +157,26 @@ __device__ __attribute__((noinline)) TailResult solver_tail(CamState *st, const 
   return iteration_tail_wave(st, totals, it, flags, tail_sm, pre);
 }
 
+template <int SLOTS>
 struct PixelSet {  // one lane's pixels of the current level
-  float v1[kTrkSlots][3], n1[kTrkSlots][3], v2[kTrkSlots][3], n2[kTrkSlots][3];
+  float v1[SLOTS][3], n1[SLOTS][3], v2[SLOTS][3], n2[SLOTS][3];
 };
+
+// 12 floats of one pixel pair, as loaded (streaming levels: software-pipelined one pixel ahead)
+struct PixelRaw { float v1[3], n1[3], v2[3], n2[3]; };
 
 #ifndef SVO_TRK_MIN_WAVES
 #define SVO_TRK_MIN_WAVES 2
 #endif
-__global__ __launch_bounds__(kTrkThreads, SVO_TRK_MIN_WAVES) void track_persistent_kernel(CamState *st, TrackSync *sy, unsigned *tickets, double *rows, TrackArgs A) {
+// SLOTS = pixels of a level a lane may keep in registers; MINW = minimum wavefronts per SIMD the register budget allows.
+// <kTrkSlots, 2, false>: images whose finest level fits the registers (up to 640x480-class: 4 pixels per lane on <= 247 workers,
+// ~220 VGPRs: one workgroup per CU).  <2, kTrkStreamMinWaves, true> (round 3): LARGE images -- only the coarsest level is register-resident, the
+// finer ones STREAM: every iteration a lane reads its pixels' work maps (the current frame's maps as transformed so far:
+// what the reference rewrites in place, rgbd_camera.cpp:163-167), applies the one new this_trans, uses them and stores
+// them back -- a lane only ever re-reads what it wrote itself -- with the next pixel's 12 floats requested before the
+// current one is used.  <= 128 VGPRs, so its workgroups find room beside the march's instead of needing empty CUs.
+template <int SLOTS, int MINW, bool STREAM>
+__global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(CamState *st, TrackSync *sy, unsigned *tickets, double *rows, TrackArgs A) {
 #ifndef SVO_TRK_NO_PRIO
   SVO_HIGH_PRIO();
 #endif
@@ -280,12 +292,12 @@ __global__ __launch_bounds__(kTrkThreads, SVO_TRK_MIN_WAVES) void track_persiste
       if (s_fail) return;
     }
     joined = true;
-    const bool in_regs = slots <= kTrkSlots;
-    PixelSet px;
-    int nchain = 0;
+    const bool in_regs = slots <= SLOTS;
+    PixelSet<SLOTS> px;
+    int nchain = 0, applied = 0;  // chain_s entries so far; of those, already contained in this lane's work maps
     if (in_regs) {
 #pragma unroll
-      for (int k = 0; k < kTrkSlots; k++) {
+      for (int k = 0; k < SLOTS; k++) {
         const long long p = (long long)L.first + ((long long)k * P + wid) * kTrkThreads + tid;
         const bool have = k < slots && p < (long long)L.end;
         const size_t q = have ? (size_t)p : (size_t)L.first;
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(kTrkThreads, SVO_TRK_MIN_WAVES) void track_persiste
         if (!lost) {
           if (in_regs) {
 #pragma unroll
-            for (int k = 0; k < kTrkSlots; k++) {
+            for (int k = 0; k < SLOTS; k++) {
               if (k < slots) {
                 icp_pixel_row(px.v1[k][0], px.v1[k][1], px.v1[k][2], px.n1[k][0], px.n1[k][1], px.n1[k][2], px.v2[k][0],
                               px.v2[k][1], px.v2[k][2], px.n2[k][0], px.n2[k][1], px.n2[k][2], my_rows + lane * kRowFloats);
@@ -333,6 +345,46 @@ __global__ __launch_bounds__(kTrkThreads, SVO_TRK_MIN_WAVES) void track_persiste
                 __builtin_amdgcn_wave_barrier();
               }
             }
+          } else if constexpr (STREAM) {
+            // streaming level with work maps: chain_s[0 .. applied) is already in what this lane stored last iteration
+            // (iteration 0 reads the raw maps: applied = 0); only chain_s[applied .. nchain) is applied now.  One pixel ahead.
+            const bool store = it + 1 < A.iters[level];
+            const bool raw = applied == 0;
+            auto fetch = [&](int k, PixelRaw &r, bool &have) {
+              const long long p = (long long)L.first + ((long long)k * P + wid) * kTrkThreads + tid;
+              have = k < slots && p < (long long)L.end;
+              const size_t q = have ? (size_t)p : (size_t)L.first;
+              const float *cv = raw ? L.cv : A.work_v, *cn = raw ? L.cn : A.work_n;
+#pragma unroll
+              for (int c = 0; c < 3; c++) { r.v2[c] = cv[3 * q + c]; r.n2[c] = cn[3 * q + c]; r.v1[c] = L.lv[3 * q + c]; r.n1[c] = L.ln[3 * q + c]; }
+            };
+            PixelRaw cur, nxt;
+            bool have_cur, have_nxt = false;
+            fetch(0, cur, have_cur);
+            for (int k = 0; k < slots; k++) {  // uniform trip count: every lane writes a row (zeros past the end)
+              if (k + 1 < slots) fetch(k + 1, nxt, have_nxt);
+              float v2x = cur.v2[0], v2y = cur.v2[1], v2z = cur.v2[2], n2x = cur.n2[0], n2y = cur.n2[1], n2z = cur.n2[2];
+              for (int c = applied; c < nchain; c++) {  // transformVertexMap / transformNormalMap: the matrices not yet in the work maps
+                float ox, oy, oz;
+                mat4_mul_point(chain_s + 16 * c, v2x, v2y, v2z, 1.0f, ox, oy, oz);
+                v2x = ox; v2y = oy; v2z = oz;
+                mat4_mul_point(chain_s + 16 * c, n2x, n2y, n2z, 0.0f, ox, oy, oz);
+                n2x = ox; n2y = oy; n2z = oz;
+              }
+              if (store && have_cur) {
+                const size_t q = (size_t)((long long)L.first + ((long long)k * P + wid) * kTrkThreads + tid);
+                A.work_v[3 * q] = v2x; A.work_v[3 * q + 1] = v2y; A.work_v[3 * q + 2] = v2z;
+                A.work_n[3 * q] = n2x; A.work_n[3 * q + 1] = n2y; A.work_n[3 * q + 2] = n2z;
+              }
+              icp_pixel_row(have_cur ? cur.v1[0] : __builtin_nanf(""), cur.v1[1], cur.v1[2], cur.n1[0], cur.n1[1], cur.n1[2], v2x, v2y, v2z, n2x, n2y,
+                            n2z, my_rows + lane * kRowFloats);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              accumulate_rows(my_rows, T, half, acc0, acc1);
+              __builtin_amdgcn_wave_barrier();
+              cur = nxt; have_cur = have_nxt;
+            }
+            if (store) applied = nchain;  // (uniform: store and nchain are the same for every lane)
           } else {
             for (int k = 0; k < slots; k++) {  // uniform trip count: every lane writes a row (zeros past the end)
               const long long p = (long long)L.first + ((long long)k * P + wid) * kTrkThreads + tid;
@@ -386,7 +438,7 @@ __global__ __launch_bounds__(kTrkThreads, SVO_TRK_MIN_WAVES) void track_persiste
       if (fl & 2) {  // this_trans of the iteration: transformVertexMap / transformNormalMap (:163-167)
         if (in_regs) {
 #pragma unroll
-          for (int k = 0; k < kTrkSlots; k++)
+          for (int k = 0; k < SLOTS; k++)
             if (k < slots) {
               float ox, oy, oz;
               mat4_mul_point(bc, px.v2[k][0], px.v2[k][1], px.v2[k][2], 1.0f, ox, oy, oz);
@@ -410,10 +462,11 @@ static int env_int(const char *name, int dflt) {
   return (e && e[0]) ? atoi(e) : dflt;
 }
 
-int track_persistent_capacity(hipStream_t s, int *max_workgroups) {
+int track_persistent_capacity(hipStream_t s, int *max_workgroups, int variant) {
   // resident workgroups the launch may count on: occupancy x the CUs the stream may use (per DEVICE: ADVICE r02)
   static std::mutex mu;
-  static std::map<int, int> per_cu_of;
+  static std::map<int, int> per_cu_tab[2];
+  std::map<int, int> &per_cu_of = per_cu_tab[variant ? 1 : 0];
   int dev = 0, cus = 0;
   SVO_HIP(hipGetDevice(&dev));
   int per_cu = 0;
@@ -422,7 +475,8 @@ int track_persistent_capacity(hipStream_t s, int *max_workgroups) {
     auto it = per_cu_of.find(dev);
     if (it == per_cu_of.end()) {
       int n = 0;
-      SVO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, track_persistent_kernel, kTrkThreads, 0));
+      if (variant) SVO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, track_persistent_kernel<kTrkStreamSlots, kTrkStreamMinWaves, true>, kTrkThreads, 0));
+      else SVO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, track_persistent_kernel<kTrkSlots, SVO_TRK_MIN_WAVES, false>, kTrkThreads, 0));
       it = per_cu_of.emplace(dev, n).first;
     }
     per_cu = it->second;
@@ -436,7 +490,8 @@ int track_persistent_capacity(hipStream_t s, int *max_workgroups) {
   } else {
     (void)hipGetLastError();
   }
-  *max_workgroups = per_cu * cus;
+  // the workers wait for each other: one workgroup per CU is all the launch counts on, however many would fit
+  *max_workgroups = (per_cu > 0 ? 1 : 0) * cus;
   return SVOSLAM_OK;
 }
 
@@ -471,6 +526,28 @@ int track_persistent_plan_coarse(TrackArgs &A, int capacity, int coarse_levels) 
     A.slots[2] = (int)((n + (long long)A.participants[2] * kTrkThreads - 1) / ((long long)A.participants[2] * kTrkThreads));
   }
   A.workers = (int)W;
+  return SVOSLAM_OK;
+}
+
+// Large images in ONE launch (round 3): every level runs here; the coarsest keeps its pixels in registers (kTrkStreamSlots
+// per lane), the finer ones stream through the work maps (TrackArgs::work_v / work_n must be set by the caller).
+int track_persistent_plan_stream(TrackArgs &A, int capacity) {
+  int cap = env_int("SVOSLAM_TRACK_WORKERS", kTrkMaxWorkers);
+  if (cap > capacity - 1) cap = capacity - 1;
+  if (cap < 1) return SVOSLAM_ERR_INVALID_ARG;
+  long long W = 1;
+  for (int l = 0; l < 3; l++) {
+    const long long n = A.level[l].end > A.level[l].first ? (long long)A.level[l].end - A.level[l].first : 0;
+    long long P = (n + (long long)kTrkThreads * kTrkStreamSlots - 1) / ((long long)kTrkThreads * kTrkStreamSlots);
+    if (P < 1) P = 1;
+    if (P > cap) P = cap;
+    if (l > 0 && P > A.participants[l - 1]) P = A.participants[l - 1];  // participation is a suffix of the levels
+    A.participants[l] = (int)P;
+    A.slots[l] = (int)((n + P * kTrkThreads - 1) / (P * kTrkThreads));
+    if (P > W) W = P;
+  }
+  A.workers = (int)W;
+  A.variant = 1;
   return SVOSLAM_OK;
 }
 
@@ -525,7 +602,11 @@ int track_persistent_launch(CamState *st, TrackSync *sy, unsigned *tickets, doub
   DevChain &dc = chain_of[dev];
   if (!dc.ev) SVO_HIP(hipEventCreateWithFlags(&dc.ev, hipEventDisableTiming));
   if (dc.used && dc.last != s) SVO_HIP(hipStreamWaitEvent(s, dc.ev, 0));  // the previous launch (any stream) has finished
-  track_persistent_kernel<<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, tickets, rows, A);
+  // SVOSLAM_TRACK_STREAM_WAVES=2: the streaming form with the full register budget (no spills, but one workgroup per CU)
+  static const bool wide = [] { const char *e = getenv("SVOSLAM_TRACK_STREAM_WAVES"); return e && e[0] == '2'; }();
+  if (A.variant && wide) track_persistent_kernel<kTrkStreamSlots, 2, true><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, tickets, rows, A);
+  else if (A.variant) track_persistent_kernel<kTrkStreamSlots, kTrkStreamMinWaves, true><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, tickets, rows, A);
+  else track_persistent_kernel<kTrkSlots, SVO_TRK_MIN_WAVES, false><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, tickets, rows, A);
   SVO_LAUNCH_CHECK();
   SVO_HIP(hipEventRecord(dc.ev, s));
   dc.last = s; dc.used = true;

@@ -30,9 +30,17 @@ struct TrackArgs {
   int workers;           // workgroups 1..workers; workgroup 0 solves
   int participants[3];   // workers taking part at each level (a prefix)
   int slots[3];          // pixels per lane at each level
+  float *work_v = nullptr, *work_n = nullptr;  // streaming levels: the current frame's maps as transformed so far (finest-level size)
+  int variant = 0;       // 0: register-resident form <kTrkSlots, 2>; 1: streaming form for large images
 };
+constexpr int kTrkStreamSlots = 2;
+#ifndef SVO_TRK_STREAM_MIN_WAVES
+#define SVO_TRK_STREAM_MIN_WAVES 3
+#endif
+constexpr int kTrkStreamMinWaves = SVO_TRK_STREAM_MIN_WAVES;
 
-int track_persistent_capacity(hipStream_t s, int *max_workgroups);
+int track_persistent_capacity(hipStream_t s, int *max_workgroups, int variant = 0);
+int track_persistent_plan_stream(TrackArgs &A, int capacity);  // large images: coarsest level in registers, finer levels streamed through work maps
 int track_persistent_plan(TrackArgs &A, int capacity);
 int track_persistent_plan_coarse(TrackArgs &A, int capacity, int coarse_levels);  // only the coarsest 1 or 2 levels; the rest: launch chain
 int track_persistent_profile(const TrackSync *d_sync, unsigned long long *out, hipStream_t s);

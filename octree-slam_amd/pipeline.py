@@ -109,6 +109,15 @@ class DistContext:
             out.view(-1).copy_(mine.view(-1))
         return out
 
+    def all_gather_sorted(self, out, mine):
+        """out[world, m, n] <- every rank's mine[m, n] (sorted keys or point indices of the frames it owns)"""
+        if self.enabled:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(out.view(-1), mine.view(-1), group=self.group)
+        else:
+            out.view(-1).copy_(mine.view(-1))
+        return out
+
     def all_gather_rows(self, full, height):
         """`full` is [height, ...]; each rank has filled its own band; returns with all bands filled.
         Bands may differ by one row, so gather into per-rank views of padded size."""
@@ -138,10 +147,34 @@ class EmulatedRank:
     def __init__(self, rank, world):
         self.rank, self.world = rank, world
         self.table, self.first, self.per_rank, self.calls = None, 0, 1, 0
+        self.sorted, self.sorted_calls = (None, None), [0, 0]
 
-    def expect(self, table, first_index, per_rank):
-        """records [n, DELTA_FLOATS] of the frames of the next call, whose first frame has global index first_index"""
+    @property
+    def has_sorted(self):
+        """the emulation was given the other ranks' sorted arrays (else the pipeline sorts every frame itself)"""
+        return self.sorted[0] is not None
+
+    def expect(self, table, first_index, per_rank, sorted_keys=None, sorted_idx=None):
+        """records [n, DELTA_FLOATS] of the frames of the next call, whose first frame has global index first_index;
+        sorted_keys / sorted_idx [n, pixels] (optional): what the owners of those frames would all-gather after sorting them"""
         self.table, self.first, self.per_rank, self.calls = table, first_index, per_rank, 0
+        self.sorted = (sorted_keys, sorted_idx)
+        self.sorted_calls = [0, 0]
+
+    def all_gather_sorted(self, out, mine):
+        which = 0 if out.dtype == torch.int64 else 1
+        tab = self.sorted[which]
+        size = self.world * self.per_rank
+        a = self.sorted_calls[which] * size
+        rows = [0] * self.world
+        for i in range(a, min(tab.shape[0], a + size)):
+            r = (self.first + i) % self.world
+            if r != self.rank:
+                out[r, rows[r]] = tab[i]
+            rows[r] += 1
+        out[self.rank] = mine
+        self.sorted_calls[which] += 1
+        return out
 
     def all_gather_deltas(self, out, mine):
         size = self.world * self.per_rank
@@ -175,10 +208,24 @@ class SlamPipeline:
         self.image = torch.zeros((height, width, 4), dtype=torch.uint8, device=dev)
         self.counters = torch.zeros(2, dtype=torch.int64, device=dev) if count_steps else None
         self.frame_sharded = self.dist.exchange == "deltas"   # (also without a process group: world 1, or an emulated rank)
+        self.shard_sort = False
         if self.frame_sharded:
             self.first, self.rows = 0, height                    # whole images of this rank's frames
             self.delta_cam = pkg.Camera(width, height, self.focal, self.focal)   # scratch camera of pair_delta
             self.frames_seen, self._prev = 0, None
+            # the SORT can be sharded too (round 3): the owner of a frame sorts it -- with the pose a second chain of apply_delta
+            # gives -- and the sorted keys / point indices (12 bytes per pixel) are all-gathered per chunk; needs the packed key
+            # to fit 64 bits.  Measured with emulated ranks on the 300-frame map (profiles/r03_*emulated*): at 640x480 a rank
+            # of 8 is bound by commit + its marches, not by the sort (4550 frames/s either way), and ranks of 2 / 4 LOSE 14-17 %
+            # to the extra stream; at 1920x1080, where the sort is 0.25 ms, a rank of 8 gains 21 % (1556 -> 1882).  Default: on
+            # for images of a megapixel and more; SVOSLAM_SHARD_SORT=0 / 1 overrides.
+            idx_bits = max(1, (width * height - 1).bit_length())
+            want = os.environ.get("SVOSLAM_SHARD_SORT")
+            want = (width * height >= (1 << 20)) if want is None else want != "0"
+            self.shard_sort = want and 3 * max_depth + 1 + idx_bits <= 64
+            if self.shard_sort:
+                self.sort_cam = pkg.Camera(width, height, self.focal, self.focal)   # composes the poses the owner sorts with
+                self.ws_sort = pkg.Workspace()
         else:
             self.first, self.rows = band_rows(height, self.dist.rank, self.dist.world)
         self.band_exchange = self.dist.enabled and self.dist.exchange == "allreduce"
@@ -194,6 +241,8 @@ class SlamPipeline:
         self.cam.reset()
         if self.frame_sharded:
             self.delta_cam.reset()
+            if self.shard_sort:
+                self.sort_cam.reset()
             self.frames_seen, self._prev = 0, None
         if self.counters is not None:
             self.counters.zero_()
@@ -413,8 +462,13 @@ class SlamPipeline:
             self._runner = pkg.Runner(self.cam, self.pool, self.w, self.h, self.depth, self.center, self.edge, self.focal,
                                       self.focal, self.mode)
             self._s_delta = torch.cuda.Stream()
+            self._s_sort = torch.cuda.Stream()
         cur = torch.cuda.current_stream()
         self._s_delta.wait_stream(cur)
+        self._s_sort.wait_stream(cur)
+        npix = self.w * self.h
+        skeys, sidx, sevents = [None] * n, [None] * n, [None] * n
+        use_sort = self.shard_sort and getattr(self.dist, "has_sorted", True)   # (one choice per session: the sort camera sees every frame or none)
         g0 = self.frames_seen
         deltas, events, march, outs = [None] * n, [None] * n, [False] * n, [None] * n
         keep = []
@@ -439,7 +493,34 @@ class SlamPipeline:
                 if march[i]:
                     outs[i] = images[i] if images is not None else self.image
             events[a] = ev      # the pose stream is in order: the chunk's first frame waits for the gather
-        self._runner.run_sharded(depths, rgbs, timestamps, views, deltas, events, march, outs, 0, self.h, self.counters)
+            if use_sort:
+                with torch.cuda.stream(self._s_sort):
+                    self._s_sort.wait_event(ev)
+                    mine_k = torch.empty((per_rank, npix), dtype=torch.int64, device="cuda")
+                    mine_i = torch.empty((per_rank, npix), dtype=torch.int32, device="cuda")
+                    all_k = torch.empty((world, per_rank, npix), dtype=torch.int64, device="cuda")
+                    all_i = torch.empty((world, per_rank, npix), dtype=torch.int32, device="cuda")
+                    for i in range(a, b):
+                        r, row = slots[i - a]
+                        self.sort_cam.apply_delta(deltas[i], timestamps[i])     # main.cpp:40's pose of frame i, on this stream
+                        if r == rank:
+                            pkg.svo_fuse_sort_frame(self.ws_sort, depths[i], self.sort_cam.fusion_transform_ptr(), self.focal, self.focal,
+                                                    self.depth, self.center, self.edge)
+                            pkg.svo_fuse_export_sorted(self.ws_sort, npix, mine_k[row], mine_i[row])
+                    self.dist.all_gather_sorted(all_k, mine_k)
+                    self.dist.all_gather_sorted(all_i, mine_i)
+                    evs = torch.cuda.Event()
+                    evs.record()
+                keep.append((mine_k, mine_i, all_k, all_i))
+                for i in range(a, b):
+                    r, row = slots[i - a]
+                    skeys[i], sidx[i] = all_k[r, row], all_i[r, row]
+                sevents[a] = evs
+        if use_sort:
+            self._runner.run_sharded_presorted(depths, rgbs, timestamps, views, deltas, events, march, outs, skeys, sidx, sevents, 0, self.h,
+                                               self.counters)
+        else:
+            self._runner.run_sharded(depths, rgbs, timestamps, views, deltas, events, march, outs, 0, self.h, self.counters)
         self._keep_sharded = keep
         self._prev = (depths[n - 1], rgbs[n - 1])
         self.frames_seen = g0 + n

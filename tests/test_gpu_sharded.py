@@ -76,8 +76,9 @@ def test_pair_delta_then_apply_equals_update_and_oracle(env, oracle, w, h):
         P.pair_delta(depth[0], rgb[0], depth[1], rgb[1], again[0])
 
 
+@pytest.mark.parametrize("sort_sharded", [True, False])
 @pytest.mark.parametrize("world,per_rank,w,h,depth", [(2, 2, 320, 240, 10), (3, 1, 160, 120, 8), (4, 2, 320, 240, 10), (8, 1, 160, 120, 9)])
-def test_sharded_session_equals_single_gpu_session(env, world, per_rank, w, h, depth):
+def test_sharded_session_equals_single_gpu_session(env, world, per_rank, w, h, depth, sort_sharded, monkeypatch):
     """every rank of a frame-sharded session: poses and map replica equal the one-GPU session's after every call, the
     frames it ray-marches equal the one-GPU images; across ranks every frame is marched exactly once.  Two calls (the
     second starts mid-stream: its first frame is tracked against the last frame of the first call)."""
@@ -101,11 +102,26 @@ def test_sharded_session_equals_single_gpu_session(env, world, per_rank, w, h, d
     for k in range(1, n):
         D.pair_delta(dstack[k - 1], cstack[k - 1], dstack[k], cstack[k], table[k])
     torch.cuda.synchronize()
+    # sort_sharded (round 3): the owner of a frame also back-projects and SORTS it, the sorted keys / point indices are
+    # all-gathered and every other rank adopts them (svoslam_runner_run_sharded_presorted); the table holds what the owners
+    # would deliver -- sorted with the pose their own chain of apply_delta gives
+    tab_k = tab_i = None
+    if sort_sharded:
+        tab_k = torch.empty((n, w * h), dtype=torch.int64, device="cuda")
+        tab_i = torch.empty((n, w * h), dtype=torch.int32, device="cuda")
+        scam, sws = pkg.Camera(w, h, f, f), pkg.Workspace()
+        for k in range(n):
+            scam.apply_delta(table[k], k)
+            pkg.svo_fuse_sort_frame(sws, dstack[k], scam.fusion_transform_ptr(), f, f, depth, center, edge)
+            pkg.svo_fuse_export_sorted(sws, w * h, tab_k[k], tab_i[k])
+        torch.cuda.synchronize()
     marched = np.zeros(n, np.int32)
+    monkeypatch.setenv("SVOSLAM_SHARD_SORT", "1" if sort_sharded else "0")   # (the default follows the image size)
     for rank in range(world):
         B = pl.SlamPipeline(w, h, depth, center, edge, dist=pl.EmulatedRank(rank, world))
+        assert B.shard_sort == sort_sharded
         for part, (lo, hi) in enumerate(((0, n1), (n1, n))):
-            B.dist.expect(table[lo:hi], lo, per_rank)
+            B.dist.expect(table[lo:hi], lo, per_rank, tab_k[lo:hi] if sort_sharded else None, tab_i[lo:hi] if sort_sharded else None)
             imgs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(lo, hi)]
             B.run_stream_sharded(list(dstack[lo:hi]), list(cstack[lo:hi]), list(range(lo, hi)), views[lo:hi], images=imgs,
                                  per_rank=per_rank)
