@@ -178,6 +178,16 @@ int svoslam_svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int3
  * _adopt_sorted makes such arrays the outcome of a workspace's sort phase -- svoslam_svo_fuse_plan / _split_early /
  * _commit follow as after svoslam_svo_fuse_sort.  The adopted arrays stay the caller's and must stay valid until the
  * commit has run.  Replaces nothing in the reference (svo.cu:602 sorts every cloud where it is fused). */
+/* Row bands ("each GPU computes keys for its band ... all-gather of the sorted lists, merge -> identical global
+ * list on every rank -> identical newNode = num_nodes + 8 x rank"): _sort_frame_band is svoslam_svo_fuse_sort_frame for rows
+ * [first_row, first_row + rows) of the image, with whole-image point indices; _merge_sorted merges `lists` (<= 16) sorted
+ * (key, index) lists with ascending, disjoint index ranges (bands in order) into d_keys_out / d_idx_out, which then hold
+ * exactly what one sort of the whole frame produces: adopt them (below), plan, commit. */
+int svoslam_svo_fuse_sort_frame_band(svoslam_workspace *ws, const uint16_t *d_depth, const float *d_pose, int32_t width, int32_t height,
+                                     float fx, float fy, int32_t max_depth, const float center[3], float edge_length, int32_t first_row,
+                                     int32_t rows, void *stream);
+int svoslam_svo_fuse_merge_sorted(const unsigned long long *const *d_keys, const uint32_t *const *d_idx, const int32_t *counts, int32_t lists,
+                                  unsigned long long *d_keys_out, uint32_t *d_idx_out, void *stream);
 int svoslam_svo_fuse_export_sorted(svoslam_workspace *ws, int32_t n, unsigned long long *d_keys_out, uint32_t *d_idx_out, void *stream);
 int svoslam_svo_fuse_adopt_sorted(svoslam_workspace *ws, const unsigned long long *d_keys, const uint32_t *d_idx, int32_t n, int32_t max_depth);
 /* Optional, between plan and commit (same workspace, same pool, direct commit only): initialises the child tiles of the

@@ -93,6 +93,8 @@ SIGNATURES = {
     "svoslam_svo_fuse_split_early": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_plan_structure": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_adopt_sorted": (C.c_int, [_vp, _vp, _vp, _i32, _i32]),
+    "svoslam_svo_fuse_sort_frame_band": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _i32, _fp, _f32, _i32, _i32, _vp]),
+    "svoslam_svo_fuse_merge_sorted": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp, _vp, _vp]),
     "svoslam_svo_fuse_export_sorted": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
     "svoslam_pool_structure_begin": (C.c_int, [C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_commit_to": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _i32, _i32, _vp]),
@@ -396,6 +398,22 @@ def svo_fuse_sort_frame(ws, depth_image, pose_ptr, fx, fy, max_depth, center, ed
     h, w = depth_image.shape[-2], depth_image.shape[-1]
     check(lib().svoslam_svo_fuse_sort_frame(ws._h, _ptr(depth_image), C.c_void_p(int(pose_ptr)), w, h, float(fx), float(fy),
                                             int(max_depth), _fa(center, 3), float(edge_length), _ptr(bbox7), _stream()))
+
+
+def svo_fuse_sort_frame_band(ws, depth_image, pose_ptr, fx, fy, max_depth, center, edge_length, first_row, rows):
+    """svo_fuse_sort_frame for one row band of the frame; the sorted point indices are whole-image indices"""
+    h, w = depth_image.shape[-2], depth_image.shape[-1]
+    check(lib().svoslam_svo_fuse_sort_frame_band(ws._h, _ptr(depth_image), C.c_void_p(int(pose_ptr)), w, h, float(fx), float(fy),
+                                                 int(max_depth), _fa(center, 3), float(edge_length), int(first_row), int(rows), _stream()))
+
+
+def svo_fuse_merge_sorted(keys_lists, idx_lists, keys_out, idx_out):
+    """merge sorted (key, index) lists with ascending, disjoint index ranges (row bands in order) -> keys_out, idx_out"""
+    n = len(keys_lists)
+    kp = (C.c_void_p * n)(*[k.data_ptr() for k in keys_lists])
+    ip = (C.c_void_p * n)(*[k.data_ptr() for k in idx_lists])
+    cn = (C.c_int32 * n)(*[int(k.shape[0]) for k in keys_lists])
+    check(lib().svoslam_svo_fuse_merge_sorted(kp, ip, cn, n, _ptr(keys_out), _ptr(idx_out), _stream()))
 
 
 def svo_fuse_export_sorted(ws, n, keys_out, idx_out):

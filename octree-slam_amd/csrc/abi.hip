@@ -179,6 +179,18 @@ int svoslam_pool_structure_begin(svoslam_pool *pool, void *stream) {
   NEED_DEVICE();
   return pool_structure_begin(pool, S(stream));
 }
+int svoslam_svo_fuse_sort_frame_band(svoslam_workspace *ws, const uint16_t *d_depth, const float *d_pose, int32_t width, int32_t height,
+                                     float fx, float fy, int32_t max_depth, const float center[3], float edge_length, int32_t first_row,
+                                     int32_t rows, void *stream) {
+  NEED_DEVICE();
+  if (!center) return SVOSLAM_ERR_INVALID_ARG;
+  return svo_fuse_sort_frame_band(ws, d_depth, d_pose, width, height, fx, fy, max_depth, center, edge_length, first_row, rows, S(stream));
+}
+int svoslam_svo_fuse_merge_sorted(const unsigned long long *const *d_keys, const uint32_t *const *d_idx, const int32_t *counts, int32_t lists,
+                                  unsigned long long *d_keys_out, uint32_t *d_idx_out, void *stream) {
+  NEED_DEVICE();
+  return svo_fuse_merge_sorted(d_keys, d_idx, counts, lists, d_keys_out, d_idx_out, S(stream));
+}
 int svoslam_svo_fuse_adopt_sorted(svoslam_workspace *ws, const unsigned long long *d_keys, const uint32_t *d_idx, int32_t n, int32_t max_depth) {
   NEED_DEVICE();
   return svo_fuse_adopt_sorted(ws, d_keys, d_idx, n, max_depth);

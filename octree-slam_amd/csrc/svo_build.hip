@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void compute_keys_kernel(const float *__restri
 // transformVertexMap by a device-resident pose, computePointCloudBoundingBox (main.cpp:39-44) and computeKeys, every
 // expression as in the stand-alone kernels (vertex_map_kernel, transform_kernel, bbox_partial_kernel, compute_keys_kernel)
 // -- without a point cloud in memory: 1.2 MB of depth in, 2.4 MB of keys out instead of 3 x 3.6 MB of points.
-struct FrameSource { const uint16_t *depth; const float *pose; int w, h; float fx, fy; };
+struct FrameSource { const uint16_t *depth; const float *pose; int w, h; float fx, fy; int first = 0; };  // first: pixel offset of a row band (its n pixels follow it)
 
 constexpr int kKeysThreads = 512, kKeysIPT = 4;  // == the packed sort's tile (radix_packed_tile(): checked by the host)
 template <bool FROM_DEPTH>
@@ -104,7 +104,8 @@ __global__ __launch_bounds__(kKeysThreads) void keys_packed_kernel(const float *
     float px, py, pz;
     if (FROM_DEPTH) {
       float vx, vy, vz;
-      vertex_from_depth(fs.depth[i], i % fs.w, i / fs.w, fs.w, fs.h, fs.fx, fs.fy, fs.w, fs.h, vx, vy, vz);
+      const int g = fs.first + i;  // pixel of the whole image (a row band starts at fs.first)
+      vertex_from_depth(fs.depth[g], g % fs.w, g / fs.w, fs.w, fs.h, fs.fx, fs.fy, fs.w, fs.h, vx, vy, vz);
       mat4_mul_point(m, vx, vy, vz, 1.0f, px, py, pz);
       if (finitef_(px) && finitef_(pz)) {  // computePointCloudBoundingBox (image_kernels.cu:60-102, Q1)
         lo[0] = fminf(px, lo[0]); lo[1] = fminf(py, lo[1]); lo[2] = fminf(pz, lo[2]);
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(kKeysThreads) void keys_packed_kernel(const float *
         cz += edge * (z ? 1 : -1);
       }
     }
-    packed[i] = (morton << idx_bits) | (u64)(unsigned)i;
+    packed[i] = (morton << idx_bits) | (u64)(unsigned)(FROM_DEPTH ? fs.first + i : i);
     atomicAdd(&hist[(u32)morton & ((u32)bins - 1u)], 1u);
   }
   __syncthreads();
@@ -1513,7 +1514,7 @@ static int fuse_sort_impl(svoslam_workspace *ws, const float *d_points, const Fr
   ws->sorted_keys = nullptr; ws->sorted_idx = nullptr; ws->planned_n = -1;
   if (n == 0) return SVOSLAM_OK;
   SVO_TRY(reserve_async(ws, n, depth));
-  const int key_bits = 3 * depth + 1, idx_bits = packed_idx_bits(n);
+  const int key_bits = 3 * depth + 1, idx_bits = packed_idx_bits(fs ? fs->w * fs->h : n);  // (a row band carries whole-image pixel indices)
   const bool packed = key_bits + idx_bits <= 64 && !sort_pairs_forced();
   if (!packed && fs) return SVOSLAM_ERR_INVALID_ARG;  // (callers fall back to the stand-alone kernels + svo_fuse_sort)
   const int tiles = radix_packed_tiles(n);
@@ -1554,7 +1555,7 @@ static int fuse_sort_impl(svoslam_workspace *ws, const float *d_points, const Fr
   GraphKey key;
   key.add(fs ? (const void *)fs->depth : (const void *)d_points).add((unsigned long long)n).add((unsigned long long)depth)
      .addf(center[0]).addf(center[1]).addf(center[2]).addf(edge).add(ws->layout_hash()).add(fs ? fs->pose : nullptr).add(d_bbox7)
-     .add(ws->frame_bbox.ptr);
+     .add(ws->frame_bbox.ptr).add((unsigned long long)(fs ? fs->first : 0));
   {
     StageScope timed(kStageFuseSort, stream);
     SVO_TRY(ws->g_sort.run(key, stream, enqueue));
@@ -1583,6 +1584,61 @@ int svo_fuse_sort_frame(svoslam_workspace *ws, const uint16_t *d_depth, const fl
   FrameSource fs;
   fs.depth = d_depth; fs.pose = d_pose; fs.w = w; fs.h = h; fs.fx = fx; fs.fy = fy;
   return fuse_sort_impl(ws, nullptr, &fs, w * h, depth, center, edge, d_bbox7, stream);
+}
+
+// The same for ONE ROW BAND of the frame ("each GPU computes keys for its band"): rows [first_row, first_row + rows);
+// the sorted point indices are those of the WHOLE image, so that bands merge into the order the one-GPU sort produces.
+int svo_fuse_sort_frame_band(svoslam_workspace *ws, const uint16_t *d_depth, const float *d_pose, int w, int h, float fx, float fy, int depth,
+                             const float center[3], float edge, int first_row, int rows, hipStream_t stream) {
+  if (!ws || !d_depth || !d_pose || w <= 0 || h <= 0 || (long long)w * h > 0x7FFFFFFFll) return SVOSLAM_ERR_INVALID_ARG;
+  if (first_row < 0 || rows < 0 || first_row + rows > h) return SVOSLAM_ERR_INVALID_ARG;
+  FrameSource fs;
+  fs.depth = d_depth; fs.pose = d_pose; fs.w = w; fs.h = h; fs.fx = fx; fs.fy = fy; fs.first = first_row * w;
+  return fuse_sort_impl(ws, nullptr, &fs, rows * w, depth, center, edge, nullptr, stream);
+}
+
+// k-way merge of sorted (key, point index) lists whose index ranges are disjoint and ascending with the list number (row
+// bands): element e of list a lands at (its place in a) + sum over b < a of #{keys of b <= e.key} + sum over b > a of
+// #{keys of b < e.key} -- equal keys stay in ascending index order, i.e. exactly the order one stable sort of the whole
+// image leaves them in (R1: the lowest point index of a run of equal keys is its head).  One thread per element, binary
+// searches in L2-resident lists.
+constexpr int kMergeMaxLists = 16;
+struct MergeArgs { const u64 *keys[kMergeMaxLists]; const u32 *idx[kMergeMaxLists]; int offset[kMergeMaxLists + 1]; int lists; };
+__global__ __launch_bounds__(256) void merge_sorted_kernel(MergeArgs A, u64 *__restrict__ out_keys, u32 *__restrict__ out_idx) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= A.offset[A.lists]) return;
+  int a = 0;
+  while (g >= A.offset[a + 1]) a++;
+  const int p = g - A.offset[a];
+  const u64 key = A.keys[a][p];
+  int rank = p;
+  for (int b = 0; b < A.lists; b++) {
+    if (b == a) continue;
+    const u64 *kb = A.keys[b];
+    int lo = 0, hi = A.offset[b + 1] - A.offset[b];
+    if (b < a) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (kb[mid] <= key) lo = mid + 1; else hi = mid; } }  // upper bound
+    else       { while (lo < hi) { const int mid = (lo + hi) >> 1; if (kb[mid] < key) lo = mid + 1; else hi = mid; } }   // lower bound
+    rank += lo;
+  }
+  out_keys[rank] = key;
+  out_idx[rank] = A.idx[a][p];
+}
+
+int svo_fuse_merge_sorted(const unsigned long long *const *d_keys, const uint32_t *const *d_idx, const int32_t *counts, int lists,
+                          unsigned long long *d_keys_out, uint32_t *d_idx_out, hipStream_t stream) {
+  if (!d_keys || !d_idx || !counts || lists < 1 || lists > kMergeMaxLists || !d_keys_out || !d_idx_out) return SVOSLAM_ERR_INVALID_ARG;
+  MergeArgs A;
+  A.lists = lists; A.offset[0] = 0;
+  for (int b = 0; b < lists; b++) {
+    if (counts[b] < 0 || (counts[b] > 0 && (!d_keys[b] || !d_idx[b]))) return SVOSLAM_ERR_INVALID_ARG;
+    A.keys[b] = d_keys[b]; A.idx[b] = d_idx[b];
+    if ((long long)A.offset[b] + counts[b] > 0x7FFFFFFFll) return SVOSLAM_ERR_INVALID_ARG;
+    A.offset[b + 1] = A.offset[b] + counts[b];
+  }
+  if (A.offset[lists] == 0) return SVOSLAM_OK;
+  merge_sorted_kernel<<<cdiv(A.offset[lists], 256), 256, 0, stream>>>(A, d_keys_out, d_idx_out);
+  SVO_LAUNCH_CHECK();
+  return SVOSLAM_OK;
 }
 
 __global__ void pool_structure_begin_kernel(int *__restrict__ d_struct, const int *__restrict__ d_size) {

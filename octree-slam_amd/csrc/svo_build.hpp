@@ -26,6 +26,10 @@ int svo_fuse_sort_frame(svoslam_workspace *ws, const uint16_t *d_depth, const fl
                         const float center[3], float edge, float *d_bbox7, hipStream_t stream);
 int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream);
 int pool_structure_begin(svoslam_pool *pool, hipStream_t stream);
+int svo_fuse_sort_frame_band(svoslam_workspace *ws, const uint16_t *d_depth, const float *d_pose, int w, int h, float fx, float fy, int depth,
+                             const float center[3], float edge, int first_row, int rows, hipStream_t stream);
+int svo_fuse_merge_sorted(const unsigned long long *const *d_keys, const uint32_t *const *d_idx, const int32_t *counts, int lists,
+                          unsigned long long *d_keys_out, uint32_t *d_idx_out, hipStream_t stream);
 int svo_fuse_adopt_sorted(svoslam_workspace *ws, const unsigned long long *d_keys, const uint32_t *d_idx, int n, int depth);
 int svo_fuse_export_sorted(svoslam_workspace *ws, int n, unsigned long long *d_keys_out, uint32_t *d_idx_out, hipStream_t stream);
 int svo_fuse_plan_structure(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream);

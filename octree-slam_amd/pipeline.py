@@ -233,6 +233,15 @@ class SlamPipeline:
             self.acc = torch.zeros(27, dtype=torch.float64, device=dev)
             self.cam.set_acc(self.acc)
             self.cam.set_band(self.first, self.rows)
+            # SURVEY 8e's sharded fusion (round 3): each rank computes and SORTS the keys of its band, the sorted (key, pixel)
+            # lists are all-gathered and merged (identical global list on every rank -> identical node numbering), instead
+            # of all-gathering the band's points and sorting the whole frame everywhere.  SVOSLAM_BAND_FUSION=points: round 2.
+            idx_bits = max(1, (width * height - 1).bit_length())
+            self.band_keys = os.environ.get("SVOSLAM_BAND_FUSION", "keys") != "points" and 3 * max_depth + 1 + idx_bits <= 64
+            if self.band_keys:
+                self.ws_band = pkg.Workspace()
+                base, rem = divmod(height, self.dist.world)
+                self._band_pad = (base + (1 if rem else 0)) * width
         self.last_stats = None
 
     def reset(self):
@@ -277,6 +286,37 @@ class SlamPipeline:
                                        self.center, self.edge)
         return None
 
+    def sort_bands(self, depth, ws, pose_ptr=None):
+        """SURVEY 8e: keys + sort of THIS rank's row band, all-gather of the bands' sorted (key, pixel) lists, k-way merge;
+        `ws` adopts the merged list as the outcome of its sort phase (plan / commit follow).  Same list as one sort of the
+        whole frame, on every rank."""
+        w, world = self.w, self.dist.world
+        nb = self.rows * w
+        pkg.svo_fuse_sort_frame_band(self.ws_band, depth, pose_ptr if pose_ptr is not None else self.cam.fusion_transform_ptr(), self.focal,
+                                     self.focal, self.depth, self.center, self.edge, self.first, self.rows)
+        pad = self._band_pad
+        mine_k = torch.zeros(pad, dtype=torch.int64, device="cuda")
+        mine_i = torch.zeros(pad, dtype=torch.int32, device="cuda")
+        pkg.svo_fuse_export_sorted(self.ws_band, nb, mine_k, mine_i)
+        all_k = torch.empty((world, pad), dtype=torch.int64, device="cuda")
+        all_i = torch.empty((world, pad), dtype=torch.int32, device="cuda")
+        self.dist.all_gather_sorted(all_k, mine_k)
+        self.dist.all_gather_sorted(all_i, mine_i)
+        counts = [band_rows(self.h, r, world)[1] * w for r in range(world)]
+        merged_k = torch.empty(w * self.h, dtype=torch.int64, device="cuda")
+        merged_i = torch.empty(w * self.h, dtype=torch.int32, device="cuda")
+        pkg.svo_fuse_merge_sorted([all_k[r, :counts[r]] for r in range(world)], [all_i[r, :counts[r]] for r in range(world)], merged_k, merged_i)
+        pkg.svo_fuse_adopt_sorted(ws, merged_k, merged_i, self.depth)
+        self._merged = getattr(self, "_merged", [])[-3:] + [(merged_k, merged_i, all_k, all_i)]   # alive until the commits have run
+        return merged_k, merged_i
+
+    def fuse_bands(self, depth, rgb):
+        """one frame's fusion in band mode: sort_bands + plan + commit (the pool of the one-GPU loop, byte for byte)"""
+        n = self.w * self.h
+        self.sort_bands(depth, self.ws)
+        pkg.svo_fuse_plan(self.ws, n, self.depth, self.pool)
+        pkg.svo_fuse_commit(self.ws, rgb.view(-1, 3), self.depth, self.pool)
+
     def fuse_frame(self, depth, rgb):
         """backproject() + fuse() as the native frame loop runs them (csrc/runner.hip): back-projection, pose transform,
         bounding box and keys in ONE launch straight from the depth image (no point cloud in memory), sort, plan, the
@@ -299,8 +339,11 @@ class SlamPipeline:
 
     def frame(self, depth, rgb, timestamp, view):
         self.track(depth, rgb, timestamp)
-        self.backproject(depth)
-        self.fuse(rgb)
+        if self.band_exchange and self.band_keys:
+            self.fuse_bands(depth, rgb)
+        else:
+            self.backproject(depth)
+            self.fuse(rgb)
         return self.render(view)
 
     # -- software-pipelined stream of frames ------------------------------------------------
@@ -398,9 +441,13 @@ class SlamPipeline:
                 mark("prep0", i)
                 self.points = pts
                 self._in_prep.copy_(depths[i])
-                self._backproject_with(self._in_prep, fusion_ptr[i])
-                ev_bp[i].record()
-                pkg.svo_fuse_sort(ws, pts.view(-1, 3), self.depth, self.center, self.edge)
+                if self.band_exchange and self.band_keys:
+                    self.sort_bands(self._in_prep, ws, fusion_ptr[i])
+                    ev_bp[i].record()
+                else:
+                    self._backproject_with(self._in_prep, fusion_ptr[i])
+                    ev_bp[i].record()
+                    pkg.svo_fuse_sort(ws, pts.view(-1, 3), self.depth, self.center, self.edge)
                 if i > 0:
                     self._s_prep.wait_event(ev_commit[i - 1])    # the tree the plan reads
                 mark("plan0", i)

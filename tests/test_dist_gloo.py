@@ -77,6 +77,72 @@ def test_two_rank_bands_gloo(tmp_path, h, w):
     assert covered == h
 
 
+def merge_rule(keys_lists, idx_lists):
+    """the rank formula of merge_sorted_kernel (csrc/svo_build.hip), restated with numpy searches: element e of list a goes
+    to (its place in a) + sum_{b<a} #{keys of b <= e.key} + sum_{b>a} #{keys of b < e.key}"""
+    total = sum(len(k) for k in keys_lists)
+    out_k, out_i = np.zeros(total, np.int64), np.zeros(total, np.int64)
+    for a, (ka, ia) in enumerate(zip(keys_lists, idx_lists)):
+        rank = np.arange(len(ka))
+        for b, kb in enumerate(keys_lists):
+            if b != a:
+                rank = rank + np.searchsorted(kb, ka, side="right" if b < a else "left")
+        out_k[rank], out_i[rank] = ka, ia
+    return out_k, out_i
+
+
+def _worker_keys(rank, world, port, h, w, out_dir):
+    """SURVEY 8e's sharded fusion on the CPU: every rank computes and sorts the keys of its row band (oracle keys, a stable
+    sort by (key, pixel)), the sorted lists are all-gathered through pipeline.DistContext.all_gather_sorted (padded bands,
+    as the GPU path sends them), merged by the device kernel's rank rule, and must equal the one-rank stable sort of the
+    whole frame on EVERY rank -- the list every replica numbers its new nodes from (num_nodes + 8 x rank in that list)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import svoslam_pkg
+    svoslam_pkg.load()
+    pl = importlib.import_module("octree_slam_amd.pipeline")
+    from oracle import oracle as ora
+    ctx = pl.DistContext(rank, world)
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:h, 0:w]
+    d = (1400 + 150 * np.sin(xx / 6.0) + 90 * np.cos(yy / 5.0) + rng.normal(scale=1.0, size=(h, w))).astype(np.uint16)
+    d[rng.random((h, w)) < 0.05] = 0                       # dropouts: invalid points (key 1), sorted first
+    d[10:14] = d[10]                                       # equal rows -> many duplicate keys ACROSS bands
+    f = 570.3 * w / 640
+    v = ora.vertex_map(d, f, f, w, h).reshape(-1, 3)
+    depth, center, edge = 5, (0.0, 0.0, 1.5), 2.0
+    keys = ora.compute_keys(v, depth, center, edge).astype(np.int64)
+    n = h * w
+    want = np.lexsort((np.arange(n), keys))                # one stable sort of the whole frame
+    first, rows = pl.band_rows(h, rank, world)
+    lo, nb = first * w, rows * w
+    order = np.lexsort((np.arange(lo, lo + nb), keys[lo:lo + nb]))
+    base, rem = divmod(h, world)
+    pad = (base + (1 if rem else 0)) * w
+    mine_k, mine_i = torch.zeros(pad, dtype=torch.int64), torch.zeros(pad, dtype=torch.int32)
+    mine_k[:nb] = torch.from_numpy(keys[lo:lo + nb][order]); mine_i[:nb] = torch.from_numpy((order + lo).astype(np.int32))
+    all_k, all_i = torch.empty((world, pad), dtype=torch.int64), torch.empty((world, pad), dtype=torch.int32)
+    ctx.all_gather_sorted(all_k, mine_k); ctx.all_gather_sorted(all_i, mine_i)
+    counts = [pl.band_rows(h, r, world)[1] * w for r in range(world)]
+    mk, mi = merge_rule([all_k[r, :counts[r]].numpy() for r in range(world)], [all_i[r, :counts[r]].numpy() for r in range(world)])
+    ok = bool(np.array_equal(mk, keys[want])) and bool(np.array_equal(mi, want))
+    dup = int((np.diff(mk) == 0).sum())
+    np.save(os.path.join(out_dir, "keys_rank%d.npy" % rank), np.array([ok, dup, int((mk == 1).sum())]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("h,w,world", [(48, 64, 2), (45, 64, 2), (50, 32, 3)])
+def test_band_key_lists_merge_gloo(tmp_path, h, w, world):
+    port = _free_port()
+    mp.spawn(_worker_keys, args=(world, port, h, w, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        ok, dup, invalid = np.load(os.path.join(str(tmp_path), "keys_rank%d.npy" % r))
+        assert ok, r
+        assert dup > 0 and invalid > 0          # the case had duplicate keys and invalid points to get right
+
+
 def test_band_rows_partition():
     import sys
     sys.path.insert(0, ROOT)

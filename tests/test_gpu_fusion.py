@@ -396,3 +396,48 @@ def test_structure_chain_equals_sequential_fusion(env, oracle, depth, n):
         for f in range(3):
             opool.insert_cloud(clouds[f][2], clouds[f][3], depth, center, edge)
         assert_pools_equal(pool, opool)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_band_sort_merge_equals_whole_frame_sort(env, oracle, world):
+    """SURVEY 8e's sharded fusion on the device: every band's keys are computed and sorted on their own
+    (svoslam_svo_fuse_sort_frame_band, whole-image pixel indices), the lists are merged (svoslam_svo_fuse_merge_sorted) and
+    adopted: the merged list equals the whole-frame sort bit for bit, and plan + commit on it build the oracle's pool."""
+    import importlib
+    pkg, torch = env
+    synth = importlib.import_module("octree_slam_amd.synth")
+    pl = importlib.import_module("octree_slam_amd.pipeline")
+    w, h, depth, center, edge = 320, 240 + (1 if world == 3 else 0), 10, (0.0, 1.5, 0.0), 4.096
+    f = synth.focal_length(w)
+    cam = pkg.Camera(w, h, f, f)
+    opool, pool = oracle.Pool(), pkg.Pool()
+    ocam = oracle.Camera(w, h, f, f)
+    for k in range(3):
+        d, c = synth.render_frame(k, w, h)
+        dn, cn = d.numpy().view(np.uint16), c.numpy()
+        dd, cc = d.cuda(), c.cuda()
+        cam.update(dd, cc, k); ocam.update(dn, cn, k)
+        pose = cam.fusion_transform_ptr()
+        ws_full = pkg.Workspace()
+        pkg.svo_fuse_sort_frame(ws_full, dd, pose, f, f, depth, center, edge)
+        fk = torch.empty(w * h, dtype=torch.int64, device="cuda"); fi = torch.empty(w * h, dtype=torch.int32, device="cuda")
+        pkg.svo_fuse_export_sorted(ws_full, w * h, fk, fi)
+        ks, is_ = [], []
+        for r in range(world):
+            first, rows = pl.band_rows(h, r, world)
+            wsb = pkg.Workspace()
+            pkg.svo_fuse_sort_frame_band(wsb, dd, pose, f, f, depth, center, edge, first, rows)
+            bk = torch.empty(rows * w, dtype=torch.int64, device="cuda"); bi = torch.empty(rows * w, dtype=torch.int32, device="cuda")
+            pkg.svo_fuse_export_sorted(wsb, rows * w, bk, bi)
+            ks.append(bk); is_.append(bi)
+        mk = torch.empty(w * h, dtype=torch.int64, device="cuda"); mi = torch.empty(w * h, dtype=torch.int32, device="cuda")
+        pkg.svo_fuse_merge_sorted(ks, is_, mk, mi)
+        torch.cuda.synchronize()
+        assert torch.equal(mk, fk) and torch.equal(mi, fi), k
+        ws = pkg.Workspace()
+        pkg.svo_fuse_adopt_sorted(ws, mk, mi, depth)
+        pkg.svo_fuse_plan(ws, w * h, depth, pool)
+        pkg.svo_fuse_commit(ws, cc.view(-1, 3), depth, pool)
+        v = oracle.transform_vertex_map(oracle.vertex_map(dn, f, f, w, h), ocam.fusion_transform())
+        opool.insert_cloud(v.reshape(-1, 3), cn.reshape(-1, 3), depth, center, edge)
+        assert_pools_equal(pool, opool)
