@@ -152,6 +152,9 @@ def main():
         # several PROCESSES on one device: the one-launch tracker's workgroups wait for each other and assume an idle
         # device (csrc/track_persistent.hip); the launch chain has no such assumption
         os.environ.setdefault("SVOSLAM_TRACK_CHAIN", "1")
+        # likewise the peer-to-peer mailbox: its collect kernel polls until the peers have posted, and processes that share ONE
+        # device are time-sliced by the hardware scheduler (milliseconds per exchange instead of microseconds)
+        os.environ.setdefault("SVOSLAM_MAILBOX", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))

@@ -605,6 +605,28 @@ int svoslam_runner_run_sharded_presorted(svoslam_runner *runner, const uint16_t 
 int svoslam_timer_start(void *stream);
 int svoslam_timer_stop(void *stream, float *h_ms); /* blocking */
 
+/* ------------------------------------------------------------------------
+ * One-shot peer-to-peer exchange of small records between the ranks of one node (csrc/mailbox.hip; SURVEY 5 "comm
+ * backend" / 8e).  Replaces the per-iteration 168-byte device-to-host copy of the reference's ICP reduction
+ * (src/sensor/localization_kernels.cu:318-325) across GPUs: every rank stores its record into each peer's inbox (device
+ * memory mapped by the peers: hipIpc handles between processes, plain pointers inside one) and polls its own; sums are
+ * formed in rank order, so every rank gets the same bits.  Two short launches on the caller's stream per collective, no
+ * host round trip, no communication library.  All ranks must issue the collectives of a mailbox in the same order.
+ * ---------------------------------------------------------------------- */
+typedef struct svoslam_mailbox svoslam_mailbox;
+int svoslam_mailbox_create(svoslam_mailbox **mailbox, int32_t rank, int32_t world);
+int svoslam_mailbox_destroy(svoslam_mailbox *mailbox);
+int svoslam_mailbox_handle(svoslam_mailbox *mailbox, void *handle64);                 /* 64 bytes for the other processes */
+int svoslam_mailbox_connect(svoslam_mailbox *mailbox, const void *handles);           /* world x 64 bytes, any order of arrival */
+int svoslam_mailbox_connect_local(svoslam_mailbox *mailbox, svoslam_mailbox *const *all);  /* peers inside this process */
+int svoslam_mailbox_all_gather(svoslam_mailbox *mailbox, const void *d_src, int32_t bytes, void *d_dst, void *stream);
+int svoslam_mailbox_all_reduce_f64(svoslam_mailbox *mailbox, double *d_values, int32_t count, void *stream);
+/* the two halves of a collective, for callers that drive several mailboxes from one stream (post them all, then collect):
+ * _post stages d_src and stores it into every inbox (next epoch), _collect waits for every rank's record of that epoch */
+int svoslam_mailbox_post(svoslam_mailbox *mailbox, const void *d_src, int32_t bytes, void *stream);
+int svoslam_mailbox_collect(svoslam_mailbox *mailbox, void *d_dst, int32_t bytes, int32_t reduce_f64, void *stream);
+int svoslam_mailbox_failed(svoslam_mailbox *mailbox, int32_t *failed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,6 +135,16 @@ SIGNATURES = {
     "svoslam_runner_run_sharded_presorted": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_longlong), _fp, _i32, C.POINTER(_vp),
                                                        C.POINTER(_vp), C.POINTER(C.c_uint8), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                                        C.POINTER(_vp), _i32, _i32, _vp, _vp]),
+    "svoslam_mailbox_create": (C.c_int, [C.POINTER(_vp), _i32, _i32]),
+    "svoslam_mailbox_destroy": (C.c_int, [_vp]),
+    "svoslam_mailbox_handle": (C.c_int, [_vp, _vp]),
+    "svoslam_mailbox_connect": (C.c_int, [_vp, _vp]),
+    "svoslam_mailbox_connect_local": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "svoslam_mailbox_all_gather": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
+    "svoslam_mailbox_all_reduce_f64": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "svoslam_mailbox_failed": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "svoslam_mailbox_post": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "svoslam_mailbox_collect": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "svoslam_scene_create": (C.c_int, [C.POINTER(_vp)]),
     "svoslam_scene_destroy": (C.c_int, [_vp]),
     "svoslam_scene_load_obj": (C.c_int, [_vp, C.c_char_p]),
@@ -655,6 +665,67 @@ class Runner:
     def close(self):
         if self._h:
             lib().svoslam_runner_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Mailbox:
+    """One-shot peer-to-peer exchange of small records between the ranks of a node (csrc/mailbox.hip): all_gather of up to
+    2 KB per rank, all_reduce of up to 256 float64 added in rank order; enqueued on the current stream, no host round trip."""
+
+    def __init__(self, rank, world):
+        self._h = C.c_void_p()
+        self.rank, self.world = int(rank), int(world)
+        check(lib().svoslam_mailbox_create(C.byref(self._h), self.rank, self.world))
+
+    def handle(self):
+        """64 bytes (numpy uint8) that the other PROCESSES need to map this rank's inbox"""
+        buf = (C.c_uint8 * 64)()
+        check(lib().svoslam_mailbox_handle(self._h, buf))
+        return np.frombuffer(bytes(buf), dtype=np.uint8).copy()
+
+    def connect(self, handles):
+        """handles: uint8 array [world, 64], row r from rank r (this rank's own row is ignored)"""
+        h = np.ascontiguousarray(handles, dtype=np.uint8)
+        assert h.shape == (self.world, 64)
+        check(lib().svoslam_mailbox_connect(self._h, h.ctypes.data_as(C.c_void_p)))
+
+    def connect_local(self, boxes):
+        """all mailboxes of the session live in this process (tests; one process driving several devices)"""
+        arr = (C.c_void_p * self.world)(*[b._h for b in boxes])
+        check(lib().svoslam_mailbox_connect_local(self._h, arr))
+
+    def all_gather(self, src, dst):
+        """dst[world, ...] <- every rank's src (same byte count on every rank, a multiple of 4, <= 2048)"""
+        nbytes = src.numel() * src.element_size()
+        assert dst.numel() * dst.element_size() == nbytes * self.world
+        check(lib().svoslam_mailbox_all_gather(self._h, _ptr(src), nbytes, _ptr(dst), _stream()))
+
+    def all_reduce_f64(self, values):
+        """values (float64 cuda tensor, <= 256 entries) <- sum over ranks, added in rank order: the same bits everywhere"""
+        check(lib().svoslam_mailbox_all_reduce_f64(self._h, _ptr(values), int(values.numel()), _stream()))
+
+    def post(self, src):
+        """first half of a collective: this rank's record into every inbox"""
+        check(lib().svoslam_mailbox_post(self._h, _ptr(src), src.numel() * src.element_size(), _stream()))
+
+    def collect(self, dst, nbytes, reduce_f64=False):
+        """second half: every rank's record of the epoch just posted -> dst[world, ...] (or their rank-ordered float64 sum)"""
+        check(lib().svoslam_mailbox_collect(self._h, _ptr(dst), int(nbytes), 1 if reduce_f64 else 0, _stream()))
+
+    def failed(self):
+        f = _i32(0)
+        check(lib().svoslam_mailbox_failed(self._h, C.byref(f)))
+        return bool(f.value)
+
+    def close(self):
+        if self._h:
+            lib().svoslam_mailbox_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -200,8 +200,10 @@ def _two_process_worker(rank, world, port, out_dir, n, w, h, depth):
     P.run_stream_sharded(list(dstack[half:]), list(cstack[half:]), list(range(half, n)), views[half:], images=imgs[half:], per_rank=2)
     torch.cuda.synchronize()
     p, o = P.cam.pose()
+    mb = P.dist.mailbox      # the pose records travelled through the peer-to-peer mailbox (hipIpc between the two processes)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), words=P.pool.words(), size=P.pool.size, pos=p, ori=o,
-             lost=P.cam.tracking_lost_count(), images=np.stack([i.cpu().numpy() for i in imgs]))
+             lost=P.cam.tracking_lost_count(), images=np.stack([i.cpu().numpy() for i in imgs]),
+             mailbox=np.array([mb is not None, bool(mb.failed()) if mb is not None else False]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -223,6 +225,7 @@ def test_two_process_sharded_session_on_one_gpu(env, tmp_path):
     pa, oa = A.cam.pose()
     for r in range(2):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert bool(z["mailbox"][0]) and not bool(z["mailbox"][1]), (r, z["mailbox"])     # used, and no wait gave up
         assert int(z["size"]) == A.pool.size and np.array_equal(z["words"], A.pool.words()), r
         assert np.array_equal(z["pos"], pa) and np.array_equal(z["ori"], oa) and int(z["lost"]) == A.cam.tracking_lost_count()
         for k in range(n):
@@ -247,7 +250,7 @@ def test_bench_multi_rank_code_path_on_one_gpu(env):
         envv = dict(os.environ, SVOSLAM_BENCH_ONE_DEVICE="1")
         out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                              "--gpus", str(nproc), "--steps", "12", "--warmup", "3", "--no-cpu-baseline"],
+                              "--gpus", str(nproc), "--steps", "12", "--warmup", "3", "--map-frames", "0", "--no-cpu-baseline"],
                              env=envv, capture_output=True, text=True, timeout=600)
         lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
         assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-800:], out.stderr[-1500:])
