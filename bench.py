@@ -430,6 +430,11 @@ def main():
                                        "raycast in %d row bands; tracker + fusion on every rank, no data-path collective" % world
                                        if args.exchange == "none" else
                                        "%d row bands: ICP all-reduce (19 per frame) + point all-gather, replicated pool" % world),
+                       "multi_gpu_scheme": (None if world == 1 and emu is None and not force_dist else
+                                            "%s (bench.py's default for N > 1 is 'deltas': on ONE GPU, emulating one rank of N on the 300-frame map, "
+                                            "it gives 1.45x / 2.25x / 3.0x of the single-GPU rate for N = 2 / 4 / 8, against < 1x for the row-band scheme "
+                                            "'allreduce' = SURVEY 8e with sorted-key all-gather + merge (profiles/r03_bench_cfg3_emulated_*.json, "
+                                            "r03_bench_cfg3_forced_dist_*.json); UNMEASURED on multi-GPU hardware)" % args.exchange),
                        "overlap": "none" if args.no_overlap else "4 HIP streams: maps(k+2) | ICP(k+1) | back-project+sort+plan(k+1) | commit+raycast(k)",
                        "frames_in_map_at_end": total, "frames_fused_untimed_before_warmup": pre, "frames_input": "pinned host memory, uploaded inside the timed region" if args.include_h2d else "resident in HBM",
                        "raycast_views": "ground-truth sensor poses (the reference renders from a free GLFW camera)",

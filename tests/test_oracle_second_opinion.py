@@ -957,7 +957,7 @@ def rn32(q):
     return s * f * ulp
 
 
-def F(x):
+def FR(x):
     return Fraction(float(np.float32(x)))
 
 
@@ -967,16 +967,16 @@ def cephes_expf(x):
     for x < -87 are 0"""
     if x < -87:
         return Fraction(0)
-    kf = rn32(x * F(1.44269504088896341))
+    kf = rn32(x * FR(1.44269504088896341))
     k = int(Fraction(round(kf)))                                       # rintf: kf is within 2^23, ties to even
     if abs(kf - k) == Fraction(1, 2):
         k = int(2 * round(kf / 2))
     k = Fraction(k)
-    r = rn32(k * F(-0.693359375) + x)
-    r = rn32(k * F(2.12194440e-4) + r)
-    p = F(1.9875691500E-4)
+    r = rn32(k * FR(-0.693359375) + x)
+    r = rn32(k * FR(2.12194440e-4) + r)
+    p = FR(1.9875691500E-4)
     for c in (1.3981999507E-3, 8.3334519073E-3, 4.1665795894E-2, 1.6666665459E-1, 5.0000001201E-1):
-        p = rn32(p * r + F(c))
+        p = rn32(p * r + FR(c))
     rr = rn32(r * r)
     e = rn32(rn32(p * rr + r) + 1)
     return e * Fraction(2) ** int(k)                                   # ldexpf: exact while the result is normal
@@ -984,7 +984,7 @@ def cephes_expf(x):
 
 def bilateral_second(depth):
     h, w = depth.shape
-    sig_spat = rn32(Fraction(1, 2) / rn32(F(4.5) * F(4.5)))           # 0.5f / (4.5f * 4.5f), :180
+    sig_spat = rn32(Fraction(1, 2) / rn32(FR(4.5) * FR(4.5)))           # 0.5f / (4.5f * 4.5f), :180
     sig_dep = rn32(Fraction(1, 2) / Fraction(1600))                    # (float)(0.5 / (40.0f * 40.0f)): double, then rounded, :181
     out = np.zeros((h, w), np.uint16)
     d = depth.astype(np.int64)
