@@ -1060,20 +1060,24 @@ static PoolTracker *tracker_of(svoslam_pool *pool) { return reinterpret_cast<Poo
 static int tracker_create(svoslam_pool *pool) {
   if (pool->tracker) return SVOSLAM_OK;
   PoolTracker *t = new PoolTracker();
-  if (hipHostMalloc((void **)&t->h_size, PoolTracker::kSlots * 4, hipHostMallocDefault) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
-  for (int i = 0; i < PoolTracker::kSlots; i++) {
-    if (hipEventCreateWithFlags(&t->ev[i], hipEventDisableTiming) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
-  }
-  if (hipMalloc((void **)&t->d_slot, 4) != hipSuccess || memset_sync(t->d_slot, 0, 4) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
-  if (hipMalloc((void **)&t->d_struct, 4) != hipSuccess || memset_sync(t->d_struct, 0, 4) != hipSuccess) { delete t; return SVOSLAM_ERR_HIP; }
+  for (int i = 0; i < PoolTracker::kSlots; i++) t->ev[i] = nullptr;
+  bool ok = hipHostMalloc((void **)&t->h_size, PoolTracker::kSlots * 4, hipHostMallocDefault) == hipSuccess;
+  for (int i = 0; ok && i < PoolTracker::kSlots; i++) ok = hipEventCreateWithFlags(&t->ev[i], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipMalloc((void **)&t->d_slot, 4) == hipSuccess && memset_sync(t->d_slot, 0, 4) == hipSuccess;
+  ok = ok && hipMalloc((void **)&t->d_struct, 4) == hipSuccess && memset_sync(t->d_struct, 0, 4) == hipSuccess;
   pool->tracker = t;
+  if (!ok) {  // whatever was created goes away again (events and pinned memory leaked on these paths)
+    (void)hipGetLastError();
+    pool_tracker_destroy(pool);
+    return SVOSLAM_ERR_HIP;
+  }
   return SVOSLAM_OK;
 }
 
 void pool_tracker_destroy(svoslam_pool *pool) {
   PoolTracker *t = pool ? tracker_of(pool) : nullptr;
   if (!t) return;
-  for (int i = 0; i < PoolTracker::kSlots; i++) (void)hipEventDestroy(t->ev[i]);
+  for (int i = 0; i < PoolTracker::kSlots; i++) if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
   if (t->h_size) (void)hipHostFree(t->h_size);
   if (t->d_slot) (void)hipFree(t->d_slot);
   if (t->d_struct) (void)hipFree(t->d_struct);
@@ -1101,6 +1105,16 @@ static int tracker_poll(svoslam_pool *pool, bool wait_all) {
     t->count--;
   }
   return SVOSLAM_OK;
+}
+
+// before a commit is enqueued: its last kernel stores the new size into h_size[next], which must not be the slot of a
+// readback the host has not retired yet (with 8 readbacks in flight the 9th commit overwrote the oldest
+// un-polled entry and pool->size jumped ahead and stepped back until the next drain)
+static int tracker_make_room(svoslam_pool *pool) {
+  PoolTracker *t = tracker_of(pool);
+  if (!t || t->count < PoolTracker::kSlots) return SVOSLAM_OK;
+  SVO_HIP(hipEventSynchronize(t->ev[t->q[0].slot]));  // the oldest readback is long done in practice
+  return tracker_poll(pool, false);
 }
 
 // after a commit has been enqueued on `stream`
@@ -1237,6 +1251,7 @@ int pool_reset(svoslam_pool *pool, hipStream_t stream) {
   SVO_HIP(memset_sync(pool->d_data, 0, 64));
   pool_accel_invalidate(pool);
   pool->size = 8; pool->pending = 0; pool->pending_bound = 0;
+  if (tracker_of(pool)) tracker_of(pool)->planned_ahead = 0;  // plans of the structure chain whose commit never came (an error mid-run) hold no reservation any more
   if (pool->d_size) SVO_HIP(hipMemcpy(pool->d_size, &pool->size, 4, hipMemcpyHostToDevice));
   return SVOSLAM_OK;
 }
@@ -1307,6 +1322,7 @@ int pool_set_nodes(svoslam_pool *pool, const uint32_t *h_words, int32_t num_node
   pool_accel_invalidate(pool);
   pool->size = num_nodes;
   pool->pending = 0; pool->pending_bound = 0;
+  if (tracker_of(pool)) tracker_of(pool)->planned_ahead = 0;
   if (pool->d_size) SVO_HIP(hipMemcpy(pool->d_size, &pool->size, 4, hipMemcpyHostToDevice));
   return SVOSLAM_OK;
 }
@@ -1824,6 +1840,7 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
     SVO_TRY(pool_shadow_begin(pool, stream, &shadow, &epoch));
     ws->deferred_pool = pool; ws->deferred_n = n; ws->deferred_depth = depth; ws->deferred_tiles = fill_tiles;
   }
+  SVO_TRY(tracker_make_room(pool));
   u32 *grid_dirty = pool_accel_dirty_bitmap(pool, deferred ? (int)(epoch & 1u) : 0);  // nullptr: not a registered pool
   auto enqueue = [&]() -> int {
     if (!early)

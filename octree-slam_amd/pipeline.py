@@ -344,6 +344,11 @@ class SlamPipeline:
         splits' tiles ahead of the commit, commit.  Same pool and bounding box as backproject() + fuse()."""
         assert not self.band_exchange
         n = self.w * self.h
+        idx_bits = max(1, (n - 1).bit_length())
+        if 3 * self.depth + 1 + idx_bits > 64:      # the packed key does not fit one word (e.g. depth 16 at 640x480): the stand-alone kernels
+            self.backproject(depth)
+            self.fuse(rgb)
+            return
         pkg.svo_fuse_sort_frame(self.ws, depth, self.cam.fusion_transform_ptr(), self.focal, self.focal, self.depth, self.center,
                                 self.edge, self.bbox)
         pkg.svo_fuse_plan(self.ws, n, self.depth, self.pool)

@@ -57,6 +57,24 @@ def test_bilateral_constant_and_extremes(env, oracle):
         assert np.array_equal(u16(out), oracle.bilateral(d))
 
 
+def test_bilateral_int_wrap_and_overflowed_weights(env, oracle):
+    """`(value - depth) * (value - depth)` is an `int` product (image_kernels.cu:168): a 65535 next to a small depth wraps it
+    negative, the weight overflows to +inf and the quotient is NaN -> 0 (found by the second reading of the filter,
+    tests/test_oracle_second_opinion.py); the device must do the same"""
+    pkg, torch, _ = env
+    rng = np.random.default_rng(8)
+    d = (900 + rng.integers(0, 400, (40, 56))).astype(np.uint16)
+    d[rng.random(d.shape) < 0.03] = 65535
+    d[rng.random(d.shape) < 0.03] = 0
+    d[5, 5], d[5, 6] = 65535, 19195            # difference 46340: the largest whose square still fits; 46341 next to it
+    d[20, 20], d[20, 21] = 65535, 19194
+    out = torch.zeros(d.shape, dtype=torch.int16, device="cuda")
+    pkg.bilateral_filter(dev16(torch, d), out)
+    ref = oracle.bilateral(d)
+    assert np.array_equal(u16(out), ref), describe_mismatch(u16(out), ref)
+    assert (ref == 0).sum() > (d == 0).sum() // 4      # the NaN -> 0 case occurs
+
+
 @pytest.mark.parametrize("h,w,iw,ih", [(480, 640, 640, 480), (240, 320, 640, 480), (120, 160, 640, 480), (61, 97, 97, 61)])
 def test_vertex_normal_maps(env, oracle, h, w, iw, ih):
     pkg, torch, _ = env
