@@ -603,6 +603,304 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
   }
 }
 
+
+// ---- the march over occupancy bricks (SVOSLAM_RENDER_REFERENCE; pool_grid.hpp "occupancy bricks") --------------------------
+// the reference's walk for one sample (:76-105) through the level grid and the tree, as cone_trace_kernel performs it:
+// returns the colour word of the node it ends on, `depth` = its level
+template <int LDSD, int GRID>
+__device__ __forceinline__ uint32_t walk_sample(const uint2 *__restrict__ nodes, const uint32_t *__restrict__ octree, const uint2 *__restrict__ grid,
+                                             const float *__restrict__ table, const float *lds_tab, const TraceParams &P, float tx, float ty, float tz,
+                                             uint32_t xb, uint32_t yb, uint32_t zb, bool ok, int &depth) {
+  uint32_t w1 = 0;
+  if (depth >= GRID) {
+    const uint32_t cell = ((zb >> (LDSD - GRID)) << (2 * GRID)) | ((yb >> (LDSD - GRID)) << GRID) | (xb >> (LDSD - GRID));
+    const uint2 g = grid[cell];
+    w1 = g.y;
+    if (!(g.x & kFlag)) {
+      depth = (int)g.x;
+    } else if (depth > GRID) {
+      uint32_t child_idx = g.x & kMask;
+      const int lds_end = depth < LDSD ? depth : LDSD;
+      bool stopped = false;
+      for (int l = GRID + 1; l <= lds_end; l++) {
+        const int sh = LDSD - l;
+        const uint32_t oct = ((xb >> sh) & 1u) | (((yb >> sh) & 1u) << 1) | (((zb >> sh) & 1u) << 2);
+        const uint2 nd = nodes[child_idx + oct];
+        w1 = nd.y;
+        if (!(nd.x & kFlag)) { depth = l; stopped = true; break; }
+        child_idx = nd.x & kMask;
+      }
+      if (!stopped && depth > LDSD) {
+        if (ok) walk_deep_chain<LDSD>(nodes, lds_tab, P, tx, ty, tz, xb, yb, zb, child_idx, depth, w1);
+        else walk_deep(nodes, table, P, tx, ty, tz, LDSD + 1, child_idx, depth, w1);
+      }
+    }
+  } else if (depth >= 1) {
+    walk_shallow<LDSD>(nodes, xb, yb, zb, depth, w1);
+  } else {
+    w1 = octree[1];
+  }
+  return w1;
+}
+
+// Same rays, same samples, same pixel as cone_trace_kernel<false, ...>.  Every sample requests TWO entries from the guessed
+// table cells, side by side: its brick entry (2 bytes) and its level-grid entry (8 bytes).  A sample whose LOD lies in
+// 9..12 and whose level-8 node has children is answered by the brick; one whose walk stops at or above level 8 (empty
+// space: first childless node at level <= 8, or an LOD of exactly 8) by the grid entry; so a step is ONE round trip to
+// memory whatever the depth of the tree.  What remains -- an LOD coarser than 8 or deeper than a level-12 node with
+// children, a sample whose table bracket is not confirmed -- and the LAST sample of a ray that ended on a brick (whose
+// node's colour word forms the pixel, Q9) take walk_sample().  The rare cases sit behind wavefront-uniform branches.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
+                                                                   const uint2 *__restrict__ grid, const uint16_t *__restrict__ bricks,
+                                                                   const float *__restrict__ table, const float *__restrict__ alpha_lut_g,
+                                                                   TraceParams P, unsigned long long *__restrict__ counters) {
+  constexpr int LDSD = 11, GRID = kPoolGridLevel;
+  constexpr int kLdsStride = lds_stride(LDSD);
+  __shared__ float alpha_lut[256];
+  __shared__ float lds_tab[3 * kLdsStride];
+  if (threadIdx.x < 256) alpha_lut[threadIdx.x] = alpha_lut_g[threadIdx.x];
+  {
+    const float *src = table + 3 * kTabStride;
+    for (int i = threadIdx.x; i < 3 * kLdsStride; i += THREADS) lds_tab[i] = src[i];
+  }
+  __syncthreads();
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  int tile_x, tile_y;  // (tile -> XCD mapping: see cone_trace_kernel)
+  if (P.xcd_w > 0) {
+    const int xcd = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);
+    const int slot_y = slot / P.xcd_w;
+    tile_x = (xcd & 3) * P.xcd_w + (slot - slot_y * P.xcd_w);
+    tile_y = (xcd >> 2) * P.xcd_h + slot_y;
+  } else {
+    tile_y = (int)blockIdx.x / P.xcd_h;
+    tile_x = (int)blockIdx.x - tile_y * P.xcd_h;
+  }
+  const int px = tile_x * 32 + (int)(wave & 3u) * 8 + (int)(lane & 7u);
+  const int py = P.row_first + tile_y * (THREADS / 32) + (int)(wave >> 2) * 8 + (int)(lane >> 3);
+  uint32_t my_steps = 0, my_levels = 0;
+  if (px < P.width && py < P.row_end) {
+    const int idx = py * P.width + px;
+    const float res_x = (float)P.width, res_y = (float)P.height;
+    const float magx = ((float)px - res_x / 2.0f) / 532.57f;
+    const float magy = ((float)py - res_y / 2.0f) / 531.54f;
+    const float nyx = -P.y_dir[0], nyy = -P.y_dir[1], nyz = -P.y_dir[2];
+    const float fx = P.x_dir[1] * nyz - nyy * P.x_dir[2];
+    const float fy = P.x_dir[2] * nyx - nyz * P.x_dir[0];
+    const float fz = P.x_dir[0] * nyy - nyx * P.x_dir[1];
+    const float dx = ((magx * P.x_dir[0]) + (magy * P.y_dir[0])) + fx;
+    const float dy = ((magx * P.x_dir[1]) + (magy * P.y_dir[1])) + fy;
+    const float dz = ((magx * P.x_dir[2]) + (magy * P.y_dir[2])) + fz;
+    const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+    float rx = kStartDist * (dx * inv), ry = kStartDist * (dy * inv), rz = kStartDist * (dz * inv);
+    const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
+    float ray_len = length3(rx, ry, rz);
+    // (a root cube outside the ordinary range of sizes never gets here: the host launches cone_trace_kernel for it)
+    const float ts11 = ldexpf(P.size, -LDSD);  // size / 2^11: what the level-11 decision adds to the centre (walk_deep_chain)
+    // The loop carries the ray (rx, ry, rz, ray_len) and the counters, nothing else: which of its two exits a ray took is
+    // read off ray_len afterwards, and the last sample's node is looked up again for the pixel (once per ray).
+    float tx = 0.0f, ty = 0.0f, tz = 0.0f;  // the sample of the current step (the last one, after the loop)
+    int lod = 0;
+    // the answers of a sample's two entries: `depth` / `retired` when one of them decides (return value), given the level-12
+    // octant where a brick needs it (oct12 < 0: not known -- such a sample is left undecided)
+    auto decode = [&](uint32_t e, uint2 gq, int lod_, int oct12, int &depth, bool &retired) -> bool {
+      // the brick: the path stops at level st = 9 / 10 / 11, or goes on to level 12 (code 4); code 0 (no brick) gives st = 8
+      // and never qualifies.  The walk ends at min(LOD, st); levels 9..11 carry their own bit, level 12 one per octant.
+      // (An LOD beyond 12 over a level-12 node with children -- bit 3 -- ends deeper: not the brick's to answer.)
+      const int st = 8 + (int)(e & 7u);
+      const int depth_b = lod_ < st ? lod_ : st;
+      const bool deep = depth_b == 12 && oct12 >= 0 && !(lod_ > 12 && (e & 8u));
+      const bool by_brick = (uint32_t)(depth_b - kBrickNodeLevel) < 3u || deep;
+      const uint32_t bit = deep ? 8u + (uint32_t)oct12 : (uint32_t)(depth_b - 5);
+      // the grid: a first childless node at level gq.x <= 8 ends every walk whose LOD reaches it; a level-8 node with
+      // children ends the walk of LOD 8 only
+      const bool g_children = (gq.x & kFlag) != 0u;
+      const int depth_g = g_children ? GRID : (int)gq.x;
+      const bool by_grid = lod_ >= depth_g && (!g_children || lod_ == GRID);
+      depth = by_brick ? depth_b : depth_g;
+      retired = by_brick ? ((e >> bit) & 1u) != 0u : gq.y >= 0xFE000000u;
+      return by_brick || by_grid;
+    };
+#ifdef SVO_BRICK_DIAG
+    uint32_t diag[4] = {0, 0, 0, 0};
+    long long clk[3] = {0, 0, 0};
+#endif
+    for (int step = 0; step < kMaxSteps; step++) {
+#ifdef SVO_BRICK_DIAG
+      const long long c0 = clock64();
+#endif
+      my_steps++;
+      tx = P.origin[0] + rx; ty = P.origin[1] + ry; tz = P.origin[2] + rz;
+      const float pix_size = ray_len * P.pix_scale;
+      int gx = (int)((tx - P.lo[0]) * P.inv_cell_lds), gy = (int)((ty - P.lo[1]) * P.inv_cell_lds), gz = (int)((tz - P.lo[2]) * P.inv_cell_lds);
+      gx = gx < 0 ? 0 : (gx > lds_cells(LDSD) - 1 ? lds_cells(LDSD) - 1 : gx);
+      gy = gy < 0 ? 0 : (gy > lds_cells(LDSD) - 1 ? lds_cells(LDSD) - 1 : gy);
+      gz = gz < 0 ? 0 : (gz > lds_cells(LDSD) - 1 ? lds_cells(LDSD) - 1 : gz);
+      // both entries requested from the GUESSED cells (see cone_trace_kernel)
+      const uint32_t e = bricks[brick_entry_index((uint32_t)gx, (uint32_t)gy, (uint32_t)gz)];
+      const uint2 gq = grid[(((uint32_t)gz >> (LDSD - GRID)) << (2 * GRID)) | (((uint32_t)gy >> (LDSD - GRID)) << GRID) | ((uint32_t)gx >> (LDSD - GRID))];
+      const uint32_t ub = f2bits(pix_size);
+      lod = (P.size_exp - (int)(ub >> 23)) + ((ub & 0x7FFFFFu) < P.size_man ? 1 : 0);
+      const bool lod_ok = ub - P.lod_first <= P.lod_span;
+      float inv_len = __builtin_amdgcn_rcpf(ray_len);
+      inv_len = fmaf(fmaf(-ray_len, inv_len, 1.0f), inv_len, inv_len);
+      // confirmation of the guessed ranks: S[g-1] < t <= S[g] on every axis
+      const float ax = lds_tab[gx + 1], bx = lds_tab[gx + 2];
+      const float ay = lds_tab[kLdsStride + gy + 1], by = lds_tab[kLdsStride + gy + 2];
+      const float az = lds_tab[2 * kLdsStride + gz + 1], bz = lds_tab[2 * kLdsStride + gz + 2];
+      const bool conf = (((int)(ax < tx) & (int)!(bx < tx)) & ((int)(ay < ty) & (int)!(by < ty)) & ((int)(az < tz) & (int)!(bz < tz))) != 0;
+      int depth;
+      bool retired;
+#ifdef SVO_BRICK_DIAG
+      asm volatile("" :: "v"(conf), "v"(inv_len));
+      const long long c1 = clock64();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const long long c2 = clock64();
+#endif
+      const bool decided = decode(e, gq, lod, -1, depth, retired);
+      float new_dist = ldexpf(P.size, -depth);  // (decided: depth in 1..12)
+      bool full_form = false;
+#ifdef SVO_BRICK_DIAG
+      if (decided && conf && lod_ok) diag[0]++;
+#endif
+      if (__builtin_expect(__any(!(decided && conf && lod_ok)), 0)) {
+        if (!(decided && conf && lod_ok)) {
+          // the rare sample: an LOD outside the fast form's range, a guess that is not the rank (within rounding of a split
+          // plane), a brick that needs the level-12 octant, or a walk neither entry decides
+          if (!lod_ok) lod = step_lod(P.size, pix_size);
+          bool ok = true;
+          uint32_t xb = (uint32_t)gx, yb = (uint32_t)gy, zb = (uint32_t)gz;
+          uint32_t e2 = e;
+          uint2 g2 = gq;
+          if (!conf) {
+            xb = axis_bits_lds<LDSD>(tx, P.lo[0], P.inv_cell_lds, lds_tab, ok);
+            yb = axis_bits_lds<LDSD>(ty, P.lo[1], P.inv_cell_lds, lds_tab + kLdsStride, ok);
+            zb = axis_bits_lds<LDSD>(tz, P.lo[2], P.inv_cell_lds, lds_tab + 2 * kLdsStride, ok);
+            if (!ok) {
+              xb = axis_bits_chain(tx, P.center[0], P.size, LDSD);
+              yb = axis_bits_chain(ty, P.center[1], P.size, LDSD);
+              zb = axis_bits_chain(tz, P.center[2], P.size, LDSD);
+            }
+            e2 = bricks[brick_entry_index(xb, yb, zb)];
+            g2 = grid[((zb >> (LDSD - GRID)) << (2 * GRID)) | ((yb >> (LDSD - GRID)) << GRID) | (xb >> (LDSD - GRID))];
+          }
+          // the level-12 octant: the level-11 decision's plane is the table entry at the even rank (walk_deep_chain)
+          float cx = lds_tab[(xb & ~1u) + 2u], cy = lds_tab[kLdsStride + (yb & ~1u) + 2u], cz = lds_tab[2 * kLdsStride + (zb & ~1u) + 2u];
+          cx += ts11 * ((xb & 1u) ? 1.0f : -1.0f);
+          cy += ts11 * ((yb & 1u) ? 1.0f : -1.0f);
+          cz += ts11 * ((zb & 1u) ? 1.0f : -1.0f);
+          const int oct12 = (int)((uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2));
+          const bool decided2 = ok && decode(e2, g2, lod, oct12, depth, retired);
+          if (!decided2) {
+            depth = lod;
+            const uint32_t w = walk_sample<LDSD, GRID>(nodes, octree, grid, table, lds_tab, P, tx, ty, tz, xb, yb, zb, ok, depth);
+            retired = (w >> 24) >= 254u;  // == !((int)(A - 127u) < 127), :108-119 with value.w == 0
+#ifdef SVO_BRICK_DIAG
+            diag[3]++;
+#endif
+          }
+          new_dist = (depth >= -100 && depth <= 100) ? ldexpf(P.size, -depth) : P.size / ldexpf(1.0f, depth);
+          full_form = depth < -60;
+#ifdef SVO_BRICK_DIAG
+          diag[1]++;
+          if (!conf) diag[2]++;
+#endif
+        }
+      }
+      my_levels += (uint32_t)(depth > 0 ? depth : 0);
+#ifdef SVO_BRICK_DIAG
+      clk[0] += c1 - c0; clk[1] += c2 - c1;
+#endif
+      if (retired) break;
+      float s = div_rn_midrange_r(ray_len + new_dist, ray_len, inv_len);
+      if (__builtin_expect(__any(full_form), 0)) {
+        if (full_form) s = (ray_len + new_dist) / ray_len;
+      }
+      rx *= s; ry *= s; rz *= s;
+      ray_len = sqrt_rn_midrange(dot3(rx, ry, rz, rx, ry, rz));
+      if (__builtin_expect(__any(full_form), 0)) {
+        if (full_form) ray_len = length3(rx, ry, rz);
+      }
+#ifdef SVO_BRICK_DIAG
+      asm volatile("" :: "v"(ray_len));
+      clk[2] += clock64() - c2;
+#endif
+      if (ray_len > kMaxRange) break;
+    }
+#ifdef SVO_BRICK_DIAG
+    if (counters) {
+      // cycles of the lane that stayed longest = of its wavefront: before the entries are needed / waiting for them / after
+      atomicAdd(&counters[2], (unsigned long long)diag[0]);
+      atomicAdd(&counters[3], (unsigned long long)diag[1]);
+      uint32_t mx = my_steps;
+      for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)mx, o); mx = v > mx ? v : mx; }
+      const unsigned long long top = __ballot(my_steps == mx);
+      if ((int)lane == __ffsll((long long)top) - 1) {
+        atomicAdd(&counters[4], (unsigned long long)clk[0]);
+        atomicAdd(&counters[5], (unsigned long long)clk[1]);
+        atomicAdd(&counters[6], (unsigned long long)clk[2]);
+        atomicAdd(&counters[7], (unsigned long long)mx);
+      }
+    }
+#endif
+    // the range exit (:131) leaves the advanced length behind; a retired ray (or the step guard) the last sample's, <= 10
+    const bool range_exit = ray_len > kMaxRange;
+    // the pixel of the last sample, formed from an all-zero pos[index] (Q9): its node's colour word
+    uint32_t w_last;
+    {
+      bool ok = true;
+      uint32_t xb = axis_bits_lds<LDSD>(tx, P.lo[0], P.inv_cell_lds, lds_tab, ok);
+      uint32_t yb = axis_bits_lds<LDSD>(ty, P.lo[1], P.inv_cell_lds, lds_tab + kLdsStride, ok);
+      uint32_t zb = axis_bits_lds<LDSD>(tz, P.lo[2], P.inv_cell_lds, lds_tab + 2 * kLdsStride, ok);
+      if (!ok) {
+        xb = axis_bits_chain(tx, P.center[0], P.size, LDSD);
+        yb = axis_bits_chain(ty, P.center[1], P.size, LDSD);
+        zb = axis_bits_chain(tz, P.center[2], P.size, LDSD);
+      }
+      int d2 = lod;
+      w_last = walk_sample<LDSD, GRID>(nodes, octree, grid, table, lds_tab, P, tx, ty, tz, xb, yb, zb, ok, d2);
+    }
+    const int alpha = (int)((w_last >> 24) - 127u);
+    const float af = alpha_lut[alpha + 127];
+    uint32_t vx = f2u8(af * (float)(w_last & 0xFF));
+    uint32_t vy = f2u8(af * (float)((w_last >> 8) & 0xFF));
+    uint32_t vz = f2u8(af * (float)((w_last >> 16) & 0xFF));
+    const uint32_t vw = (uint32_t)alpha & 0xFFu;
+    if (range_exit) {
+      const float sc = 127.0f / (float)vw;
+      vx = f2u8((float)vx * sc);
+      vy = f2u8((float)vy * sc);
+      vz = f2u8((float)vz * sc);
+    }
+    uint32_t out = vx | (vy << 8) | (vz << 16) | (255u << 24);
+    if (P.mode & 0x100) out = my_steps;
+    uchar4 o;
+    o.x = (unsigned char)(out & 0xFF); o.y = (unsigned char)((out >> 8) & 0xFF);
+    o.z = (unsigned char)((out >> 16) & 0xFF); o.w = (unsigned char)(out >> 24);
+    pos[idx] = o;
+  }
+  if (counters) {
+    __shared__ unsigned long long wg_sum[2];
+    if (threadIdx.x == 0) { wg_sum[0] = 0ull; wg_sum[1] = 0ull; }
+    __syncthreads();
+    unsigned long long s64 = my_steps, l64 = my_levels;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s64 += __shfl_down(s64, o);
+      l64 += __shfl_down(l64, o);
+    }
+    if (lane == 0) {
+      atomicAdd(&wg_sum[0], s64);
+      atomicAdd(&wg_sum[1], l64);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(&counters[0], wg_sum[0]);
+      atomicAdd(&counters[1], wg_sum[1]);
+    }
+  }
+}
+
 // tile -> XCD mapping of a render of tiles_x x tiles_y workgroup tiles; returns the number of workgroups to launch
 static unsigned xcd_mapping(TraceParams &P, int tiles_x, int tiles_y) {
   constexpr int kResidentTiles = 1024;  // 256 CUs x 4 workgroups of 512 threads
@@ -721,10 +1019,12 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   float *d_table = reinterpret_cast<float *>(own_grid + own_cells);
   float *alpha_lut = d_table + 3 * (kTabStride + kLdsStrideMax);
   const uint2 *d_grid = own_grid;
+  const uint16_t *d_bricks = nullptr;
   const bool tables_match = sa->tables_valid && sa->tables_at == d_table && sa->lds_depth == P.lds_depth && sa->size == size &&
                             sa->center[0] == center[0] && sa->center[1] == center[1] && sa->center[2] == center[2];
   if (pa) {
-    SVO_TRY(pool_accel_refresh(pa, d_octree, stream, &d_grid));
+    // (the brick march is compiled for the 11-level LDS table: SVOSLAM_MARCH_LDS_DEPTH=12 keeps the tree march)
+    SVO_TRY(pool_accel_refresh(pa, d_octree, stream, &d_grid, (mode & 0xFF) == SVOSLAM_RENDER_REFERENCE && P.lds_depth == 11, &d_bricks));
     if (!tables_match) build_tables_kernel<<<(int)cdiv(3 * (kTabStride + kLdsStrideMax) + 256, 256), 256, 0, stream>>>(d_table, alpha_lut, P);
   } else {
     const int build_blocks = (int)cdiv(own_cells + 3 * (kTabStride + kLdsStrideMax) + 256, 256);
@@ -736,7 +1036,11 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   SVO_TRY(stage_event(kStageMarch, stream));
   uchar4 *out = reinterpret_cast<uchar4 *>(d_pos);
   const bool carry = (mode & 0xFF) == SVOSLAM_RENDER_CARRY;
-  if (P.lds_depth == 11 && large) {
+  const bool midrange_size = size >= 9.5367431640625e-07f && size <= 1048576.0f;  // (see cone_trace_kernel: the length recurrence's short forms)
+  if (d_bricks && !carry && P.lds_depth == 11 && midrange_size) {  // a pool of this library in reference mode: the march over occupancy bricks
+    const dim3 grid(xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads / 32)));
+    cone_trace_brick_kernel<kTraceThreads><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps);
+  } else if (P.lds_depth == 11 && large) {
     const dim3 grid(xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads / 32)));
     if (carry) cone_trace_kernel<true, 11, kTraceThreads, kGridLevelLarge><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
     else cone_trace_kernel<false, 11, kTraceThreads, kGridLevelLarge><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);

@@ -18,6 +18,8 @@ PoolAccel::~PoolAccel() {
   grid.release();
   shadow.release();
   for (uint32_t *d : d_dirty) if (d) (void)hipFree(d);
+  if (bricks) (void)hipFree(bricks);
+  if (d_brick_touched) (void)hipFree(d_brick_touched);
   if (ev_order) (void)hipEventDestroy(ev_order);
 }
 
@@ -35,6 +37,7 @@ void pool_accel_register(svoslam_pool *pool) {
     g_accel.emplace(pool->d_data, std::make_shared<PoolAccel>());
   } else {
     it->second->valid = false;  // freshly initialised memory at a recycled address: whatever the grid holds is stale
+    it->second->bricks_valid = false;
   }
 }
 
@@ -65,7 +68,7 @@ void pool_accel_invalidate(svoslam_pool *pool) {
   if (!pool || !pool->d_data) return;
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_accel.find(pool->d_data);
-  if (it != g_accel.end()) it->second->valid = false;
+  if (it != g_accel.end()) { it->second->valid = false; it->second->bricks_valid = false; }
 }
 
 static bool ensure_dirty_states(PoolAccel *pa) {
@@ -170,6 +173,103 @@ __global__ __launch_bounds__(256) void pool_grid_build_kernel(const uint32_t *__
   if (e == 0) { dirty_a[kPoolGridCountOffset] = 0u; if (dirty_b) dirty_b[kPoolGridCountOffset] = 0u; }
 }
 
+// ---- occupancy bricks (pool_grid.hpp) ----------------------------------------------------------------------------------
+// the 64 entries of the brick of level-9 node (x9, y9, z9), one per lane of ONE wavefront: lane = octant at level 10 (bits
+// 5..3) and at level 11 (bits 2..0) of the cell's path below the node
+__device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint2 *__restrict__ grid, uint16_t *__restrict__ bricks,
+                                     uint32_t *__restrict__ touched, uint32_t x9, uint32_t y9, uint32_t z9, unsigned lane) {
+  constexpr int G = kPoolGridLevel;
+  const uint2 g = grid[((z9 >> 1) << (2 * G)) | ((y9 >> 1) << G) | (x9 >> 1)];
+  if (!(g.x & kFlag)) return;  // the level-8 node has no children (cannot happen for a listed node: listed = below a key's path)
+  const uint2 w9 = nodes[(g.x & kMask) + ((x9 & 1u) | ((y9 & 1u) << 1) | ((z9 & 1u) << 2))];
+  uint32_t v = ((w9.y >> 24) >= 254u) ? 0x10u : 0u;
+  if (!(w9.x & kFlag)) v |= 1u;
+  else {
+    const uint2 w10 = nodes[(w9.x & kMask) + (lane >> 3)];
+    v |= ((w10.y >> 24) >= 254u) ? 0x20u : 0u;
+    if (!(w10.x & kFlag)) v |= 2u;
+    else {
+      const uint2 w11 = nodes[(w10.x & kMask) + (lane & 7u)];
+      v |= ((w11.y >> 24) >= 254u) ? 0x40u : 0u;
+      if (!(w11.x & kFlag)) v |= 3u;
+      else {
+        v |= 4u;
+        const uint2 *tile = nodes + (w11.x & kMask);  // the eight level-12 children
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint2 c = tile[q];
+          v |= ((c.y >> 24) >= 254u) ? (0x100u << q) : 0u;
+          v |= (c.x & kFlag) ? 8u : 0u;
+        }
+      }
+    }
+  }
+  // cell of this lane: x bit 1 = level-10 octant bit, x bit 0 = level-11 octant bit (likewise y, z)
+  const uint32_t cx = (x9 << 2) | (((lane >> 3) & 1u) << 1) | (lane & 1u);
+  const uint32_t cy = (y9 << 2) | (((lane >> 4) & 1u) << 1) | ((lane >> 1) & 1u);
+  const uint32_t cz = (z9 << 2) | (((lane >> 5) & 1u) << 1) | ((lane >> 2) & 1u);
+  bricks[brick_entry_index(cx, cy, cz)] = (uint16_t)v;
+  if (lane == 0) {
+    const uint32_t grp = ((z9 >> 3) << (2 * kBrickGroupLevel)) | ((y9 >> 3) << kBrickGroupLevel) | (x9 >> 3);
+    if (!((touched[grp >> 5] >> (grp & 31u)) & 1u)) atomicOr(&touched[grp >> 5], 1u << (grp & 31u));
+  }
+}
+
+constexpr int kBrickThreads = 256, kBrickBlocks = 2048;
+// One wavefront per stale brick.  `all` (or a ring that was lapped): every level-8 cell with children instead -- a
+// wavefront reads 64 cells of the level grid and rebuilds the eight bricks of each one that has children.
+__global__ __launch_bounds__(kBrickThreads) void brick_rebuild_kernel(const uint32_t *__restrict__ octree, const uint2 *__restrict__ grid,
+                                                                      uint16_t *__restrict__ bricks, uint32_t *__restrict__ touched,
+                                                                      uint32_t *__restrict__ dirty_a, uint32_t *__restrict__ dirty_b, int all) {
+  const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  constexpr unsigned kWaves = kBrickThreads / 64;
+  // (nothing appends to a served ring while this launch runs: commits of the served states are ordered around the render)
+  const uint32_t count_a = dirty_a ? dirty_a[kBrickCountOffset] : 0u, count_b = dirty_b ? dirty_b[kBrickCountOffset] : 0u;
+  const uint32_t first_a = dirty_a ? dirty_a[kBrickConsumedOffset] : 0u, first_b = dirty_b ? dirty_b[kBrickConsumedOffset] : 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // what this launch serves; the next refresh moves the consumed mark here
+    if (dirty_a) dirty_a[kBrickSeenOffset] = count_a;
+    if (dirty_b) dirty_b[kBrickSeenOffset] = count_b;
+  }
+  if (all || count_a - first_a > (uint32_t)kBrickListCap || count_b - first_b > (uint32_t)kBrickListCap) {
+    constexpr int G = kPoolGridLevel;
+    constexpr uint32_t kCells = 1u << (3 * G);
+    for (uint32_t c0 = (blockIdx.x * kWaves + wave) * 64u; c0 < kCells; c0 += kBrickBlocks * kWaves * 64u) {
+      const uint32_t cell = c0 + lane;
+      unsigned long long m = __ballot((grid[cell].x & kFlag) != 0u);
+      while (m) {
+        const uint32_t hit = c0 + (uint32_t)(__ffsll((long long)m) - 1);
+        m &= m - 1ull;
+        const uint32_t x8 = hit & ((1u << G) - 1u), y8 = (hit >> G) & ((1u << G) - 1u), z8 = hit >> (2 * G);
+        for (uint32_t o = 0; o < 8u; o++)
+          brick_rebuild(nodes, grid, bricks, touched, (x8 << 1) | (o & 1u), (y8 << 1) | ((o >> 1) & 1u), (z8 << 1) | (o >> 2), lane);
+      }
+    }
+  } else {
+    for (int state = 0; state < 2; state++) {
+      const uint32_t *dirty = state ? dirty_b : dirty_a;
+      const uint32_t pending = state ? count_b - first_b : count_a - first_a, first = state ? first_b : first_a;
+      for (uint32_t i = blockIdx.x * kWaves + wave; i < pending; i += kBrickBlocks * kWaves) {
+        const uint32_t e = dirty[kBrickListOffset + ((first + i) & (uint32_t)(kBrickListCap - 1))];
+        brick_rebuild(nodes, grid, bricks, touched, e & 511u, (e >> 9) & 511u, e >> 18, lane);
+      }
+    }
+  }
+}
+
+// zero the 64 KB groups that hold bricks (before every brick is rebuilt: what the field says about a pool that has been
+// reset / reloaded / re-rooted since is stale) and clear their bits
+__global__ __launch_bounds__(256) void brick_clear_kernel(uint16_t *__restrict__ bricks, uint32_t *__restrict__ touched) {
+  for (uint32_t grp = blockIdx.x; grp < (uint32_t)kBrickGroups; grp += gridDim.x) {
+    const bool set = (touched[grp >> 5] >> (grp & 31u)) & 1u;
+    __syncthreads();
+    if (!set) continue;
+    uint4 *p = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(bricks) + (size_t)grp * kBrickGroupBytes);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(kBrickGroupBytes / 16); i += 256u) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x == 0) atomicAnd(&touched[grp >> 5], ~(1u << (grp & 31u)));
+  }
+}
+
 // one WORKGROUP per listed block (the list is compacted from the bitmap at the end of every commit), one cell per lane:
 // rebuild its 8^3 cells if its bit is still set, then clear the bit -- a second render without a commit in between
 // finds them clear.  (One wavefront per block with 8 cells per lane took 15-17 us per frame at 640x480: eight walks
@@ -179,13 +279,16 @@ constexpr int kUpdateThreads = 1 << (3 * (kPoolGridLevel - kPoolGridBlockLevel))
 // use; as a launch of its own it showed as 6 us per frame in the kernel statistics -- frames/s are the same either way:
 // 2804 against 2804 over 100 frames, A/B on one box).
 __global__ __launch_bounds__(kUpdateThreads) void pool_grid_update_kernel(const uint32_t *__restrict__ octree, uint2 *__restrict__ grid,
-                                                                          uint32_t *__restrict__ dirty_a, uint32_t *__restrict__ dirty_b) {
+                                                                          uint32_t *__restrict__ dirty_a, uint32_t *__restrict__ dirty_b,
+                                                                          int bricks_on) {
   constexpr int G = kPoolGridLevel, B = kPoolGridBlockLevel, S = G - B;  // 2^S cells per block and axis
   const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
   const uint32_t c = threadIdx.x;
   for (int state = 0; state < 2; state++) {
     uint32_t *dirty = state ? dirty_b : dirty_a;
     if (!dirty) continue;
+    // the stale-brick ring: what the previous refresh's rebuild saw has been served
+    if (blockIdx.x == 0 && c == 0) dirty[kBrickConsumedOffset] = dirty[kBrickSeenOffset];
     const uint32_t count = dirty[kPoolGridCountOffset];
     const uint32_t *list = dirty + kPoolGridListOffset;
     for (uint32_t i = blockIdx.x; i < count; i += kUpdateBlocks) {
@@ -195,13 +298,46 @@ __global__ __launch_bounds__(kUpdateThreads) void pool_grid_update_kernel(const 
       if (!set) continue;
       const uint32_t bx = b & ((1u << B) - 1u), by = (b >> B) & ((1u << B) - 1u), bz = b >> (2 * B);
       const uint32_t xi = (bx << S) | (c & ((1u << S) - 1u)), yi = (by << S) | ((c >> S) & ((1u << S) - 1u)), zi = (bz << S) | (c >> (2 * S));
-      grid[(zi << (2 * G)) | (yi << G) | xi] = grid_entry(nodes, xi, yi, zi);
+      const uint32_t cell = (zi << (2 * G)) | (yi << G) | xi;
+      const uint2 fresh = grid_entry(nodes, xi, yi, zi);
+      if (bricks_on && (fresh.x & kFlag) && !(grid[cell].x & kFlag)) {
+        // the level-8 node has just been split: the bricks of its eight children say "ask the level grid" so far
+        const uint32_t pos = atomicAdd(&dirty[kBrickCountOffset], 8u);
+        for (uint32_t o = 0; o < 8u; o++)
+          dirty[kBrickListOffset + ((pos + o) & (uint32_t)(kBrickListCap - 1))] =
+              brick_list_entry((xi << 1) | (o & 1u), (yi << 1) | ((o >> 1) & 1u), (zi << 1) | (o >> 2));
+      }
+      grid[cell] = fresh;
       if (c == 0) atomicAnd(&dirty[b >> 5], ~(1u << (b & 31u)));
     }
   }
 }
 
-int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stream, const uint2 **d_grid) {
+// SVOSLAM_MARCH_BRICKS=0: no occupancy bricks (the march walks the tree below the level grid, as in round 2)
+static bool bricks_enabled() {
+  static const bool on = [] { const char *e = getenv("SVOSLAM_MARCH_BRICKS"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+static void ensure_bricks(PoolAccel *pa, hipStream_t stream) {
+  if (pa->bricks || pa->bricks_failed) return;
+  void *field = nullptr, *touched = nullptr;
+  if (hipMalloc(&field, kBrickFieldBytes) != hipSuccess || hipMalloc(&touched, kBrickGroupWords * 4) != hipSuccess ||
+      hipMemsetAsync(field, 0, kBrickFieldBytes, stream) != hipSuccess ||
+      hipMemsetAsync(touched, 0, kBrickGroupWords * 4, stream) != hipSuccess) {
+    (void)hipGetLastError();  // no room for the field on this device: the pool is marched through the tree
+    if (field) (void)hipFree(field);
+    if (touched) (void)hipFree(touched);
+    pa->bricks_failed = true;
+    return;
+  }
+  pa->bricks = reinterpret_cast<uint16_t *>(field);
+  pa->d_brick_touched = reinterpret_cast<uint32_t *>(touched);
+  pa->bricks_valid = false;
+}
+
+int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stream, const uint2 **d_grid, bool want_bricks,
+                       const uint16_t **d_bricks) {
   if (!pa || !d_octree || !d_grid) return SVOSLAM_ERR_INVALID_ARG;
   constexpr size_t kCells = (size_t)1 << (3 * kPoolGridLevel);
   // the whole enqueue under the lock: the grid's host-side state (valid, last_stream) and the launches that make it
@@ -220,6 +356,7 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
     else (void)hipGetLastError();  // (a stream destroyed without svoslam_cone_trace_release: nothing left to wait for)
   }
   pa->last_stream = stream;
+  if (want_bricks && bricks_enabled()) ensure_bricks(pa, stream);  // (behind the ordering above: the first fill runs on `stream`)
   const bool fresh = !pa->valid;
   pa->valid = true;
   uint32_t *serve[2] = {nullptr, nullptr};  // the dirty states this render consumes
@@ -229,13 +366,21 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
     serve[0] = pa->d_dirty[0]; serve[1] = pa->d_dirty[1];
   }
   uint2 *grid = pa->grid.as<uint2>();
+  // once a pool has bricks every refresh keeps them current, whatever the mode of the render that asks
+  const bool bricks_all = pa->bricks && (fresh || !pa->bricks_valid);
   if (fresh) {
     pool_grid_build_kernel<<<(unsigned)(kCells / 256), 256, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
   } else {
-    pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
+    pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1], pa->bricks && !bricks_all);
+  }
+  if (pa->bricks) {
+    if (bricks_all) brick_clear_kernel<<<2048, 256, 0, stream>>>(pa->bricks, pa->d_brick_touched);
+    brick_rebuild_kernel<<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], bricks_all ? 1 : 0);
+    pa->bricks_valid = true;
   }
   SVO_LAUNCH_CHECK();
   *d_grid = grid;
+  if (d_bricks) *d_bricks = pa->bricks;
   return SVOSLAM_OK;
 }
 

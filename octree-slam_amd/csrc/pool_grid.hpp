@@ -50,6 +50,12 @@ struct PoolAccel {
   // on that one so far (an event recorded there at that moment: no per-frame cost while one stream renders the pool).
   hipStream_t last_stream = nullptr;
   hipEvent_t ev_order = nullptr;
+  // occupancy bricks (below): the dense field and the bitmap of the 64 KB groups that hold anything.  Allocated by the
+  // first reference-mode render of the pool; bricks_valid = false: rebuild all.
+  uint16_t *bricks = nullptr;
+  uint32_t *d_brick_touched = nullptr;  // [kBrickGroupWords]
+  bool bricks_valid = false;
+  bool bricks_failed = false;           // the field could not be allocated: this pool is marched through the tree
   ~PoolAccel();  // device buffers live as long as the last holder of the entry (std::shared_ptr)
 };
 
@@ -71,11 +77,45 @@ void pool_shadow_end(svoslam_pool *pool);
 bool pool_shadow_pending(svoslam_pool *pool);
 
 // enqueue on `stream`: bring the grid of `pa` up to date with its pool (full build or dirty blocks only); returns the grid
-int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stream, const uint2 **d_grid);
+// want_bricks: also bring the occupancy bricks up to date (allocating them on first use); *d_bricks = the field, or
+// nullptr when the pool has none (not wanted so far, SVOSLAM_MARCH_BRICKS=0, or no memory for them)
+int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stream, const uint2 **d_grid, bool want_bricks,
+                       const uint16_t **d_bricks);
 
 constexpr int kPoolGridListOffset = kPoolGridDirtyWords;                     // words
 constexpr int kPoolGridCountOffset = kPoolGridDirtyWords + kPoolGridBlocks;  // words
-constexpr int kPoolGridStateWords = kPoolGridCountOffset + 4;
+// behind them, the ring of the level-9 nodes whose occupancy brick is stale (see "occupancy bricks"): three words -- entries
+// appended so far (commits, the grid's refresh), entries consumed, and the appended count the latest rebuild saw (which the
+// next refresh makes the consumed one: no launch has to wait for its last workgroup to reset anything) -- then the entries
+constexpr int kBrickCountOffset = kPoolGridCountOffset + 4, kBrickConsumedOffset = kBrickCountOffset + 1, kBrickSeenOffset = kBrickCountOffset + 2;
+constexpr int kBrickListOffset = kBrickCountOffset + 4;
+constexpr int kBrickListCap = 1 << 20;  // more than this pending = "rebuild every brick" (a commit appends <= its distinct level-9 prefixes)
+constexpr int kPoolGridStateWords = kBrickListOffset + kBrickListCap;
+
+// ---- occupancy bricks (round 3; north_star's "4^3 bricks") -------------------------------------------------
+// In SVOSLAM_RENDER_REFERENCE mode a sample of the march needs two facts about the node the reference's walk ends on
+// (cone_tracing_kernels.cu:76-105): its level (the step is size / 2^level, :126) and whether its alpha saturates the ray
+// (A - 127 >= 127, :108-119) -- the colour matters on the retiring step only (Q9).  Below the level-8 grid the walk is a
+// chain of dependent 8-byte loads from a multi-GB pool; the long rays of a mature map spend nearly all their steps there.
+// A brick holds those two facts for the 4^3 level-11 cells of ONE level-9 node as 64 x 16 bits = one 128-byte line:
+//   bits 0-2  where the path through the cell stops: 0 = the level-8 node has no children (ask the level grid),
+//             1 / 2 / 3 = first childless node at level 9 / 10 / 11, 4 = the level-11 node has children
+//   bit  3    a level-12 node below this cell has children itself (an LOD deeper than 12 takes the tree walk)
+//   bits 4-6  A >= 254 of the path's nodes at levels 9 / 10 / 11
+//   bits 8-15 A >= 254 of the eight level-12 children (octant order)
+// so a step whose LOD lies in 9..12 costs ONE 2-byte load, whatever the depth of the tree.  Bricks are addressed, not
+// allocated: brick (x9, y9, z9) lives at a fixed place of a dense 2 x 2048^3-byte field (16 GiB of the 288 GB; bricks of
+// one level-6 cube are 64 KB contiguous), zero = "ask the level grid", so nothing is built for space the map never
+// reaches.  Upkeep rides on the level grid's: the leaf kernel of a commit appends the level-9 prefix of every run of keys
+// to a list (each change of a commit lies on the path of one of its keys), the refresh of the level grid adds the eight
+// children of level-8 nodes that have just been split, and one wavefront per listed node rewrites its line before the
+// march.  Anything that invalidates the level grid clears the touched 64 KB groups and rebuilds every brick.
+constexpr int kBrickNodeLevel = 9, kBrickCellLevel = 11, kBrickGroupLevel = 6;
+constexpr size_t kBrickFieldEntries = (size_t)1 << (3 * kBrickCellLevel);
+constexpr size_t kBrickFieldBytes = 2 * kBrickFieldEntries;
+constexpr int kBrickGroups = 1 << (3 * kBrickGroupLevel);
+constexpr int kBrickGroupWords = kBrickGroups / 32;  // "touched" bitmap: 32 KB
+constexpr size_t kBrickGroupBytes = kBrickFieldBytes / kBrickGroups;  // 64 KB
 
 #ifdef __HIPCC__
 // called by ALL threads of ONE workgroup of `threads` (a multiple of 64, <= 1024) lanes after the commit's marks are
@@ -136,6 +176,39 @@ __device__ inline void pool_grid_mark(uint32_t *dirty, unsigned long long key, i
         const uint32_t b = ((((z << sh) | dz) << (2 * B)) | (((y << sh) | dy) << B)) | ((x << sh) | dx);
         atomicOr(&dirty[b >> 5], 1u << (b & 31u));
       }
+}
+
+// entry index of level-11 cell (x, y, z) (11 bits each) in the brick field: [z>>5 | y>>5 | x>>5] group (level 6, linear),
+// [z y x bits 4..2] brick in the group, [z y x bits 1..0] cell in the brick
+__host__ __device__ inline unsigned long long brick_entry_index(uint32_t x, uint32_t y, uint32_t z) {
+  const uint32_t lo = ((y >> 5) << 21) | ((x >> 5) << 15) | (((z >> 2) & 7u) << 12) | (((y >> 2) & 7u) << 9) | (((x >> 2) & 7u) << 6) |
+                      ((z & 3u) << 4) | ((y & 3u) << 2) | (x & 3u);
+  return ((unsigned long long)(z >> 5) << 27) | lo;
+}
+
+// list entry of the level-9 node (x9, y9, z9): 9 bits each
+__host__ __device__ inline uint32_t brick_list_entry(uint32_t x9, uint32_t y9, uint32_t z9) { return (z9 << 18) | (y9 << 9) | x9; }
+
+// Called by ALL lanes of a wavefront (convergent): the lanes with `pred` append the level-9 prefix of their key (depth
+// >= 9 levels) to the stale-brick ring; one atomic per wavefront.  Lapping the consumer is allowed: more than the
+// capacity pending tells the refresh to rebuild every brick.
+__device__ inline void brick_mark(uint32_t *dirty, bool pred, unsigned long long key, int depth) {
+  const unsigned long long m = __ballot(pred);
+  if (!m) return;
+  const unsigned lane = threadIdx.x & 63u;
+  const int leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if ((int)lane == leader) base = atomicAdd(&dirty[kBrickCountOffset], (uint32_t)__popcll(m));
+  base = (uint32_t)__shfl((int)base, leader);
+  if (pred) {
+    const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    uint32_t x = 0, y = 0, z = 0;
+    for (int k = 1; k <= kBrickNodeLevel; k++) {
+      const uint32_t oct = (uint32_t)(key >> (3 * (depth - k))) & 7u;
+      x = (x << 1) | (oct & 1u); y = (y << 1) | ((oct >> 1) & 1u); z = (z << 1) | (oct >> 2);
+    }
+    dirty[kBrickListOffset + (pos & (uint32_t)(kBrickListCap - 1))] = brick_list_entry(x, y, z);
+  }
 }
 #endif
 

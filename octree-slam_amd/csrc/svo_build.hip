@@ -685,6 +685,8 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   // level grid of the ray march (pool_grid.hpp): everything this key changes lies below its level-5 prefix; the first
   // head of a run of keys sharing that prefix marks the block
   if (grid_dirty && head && c < kPoolGridBlockLevel) pool_grid_mark(grid_dirty, key, depth);
+  // occupancy bricks: likewise everything below level 9 lies under the key's level-9 prefix; the first head of a run lists it
+  if (grid_dirty && depth >= kBrickNodeLevel) brick_mark(grid_dirty, head && c < kBrickNodeLevel, key, depth);
   if (tid <= SVOSLAM_MAX_DEPTH) {
     last_owner[tid] = -1;
     if (tid >= 1 && tid < depth) {  // "no straddler" unless a lane says otherwise below
