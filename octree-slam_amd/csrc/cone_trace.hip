@@ -156,6 +156,7 @@ struct TraceParams {
   float lo[3], inv_cell, inv_cell_lds;   // guess of the table cell: (t - lo) * inv_cell
   int lds_depth;                          // levels of the LDS table of this render (11 or 12)
   int xcd_w, xcd_h;                       // tile -> XCD mapping (see cone_trace_kernel)
+  int xcd_rows;                           // brick march: 1 = the two XCD groups take alternate tile rows (see cone_trace_brick_kernel)
   uint32_t lod_first, lod_span, size_man;  // fast LOD: valid when bits(pix_size) - lod_first <= lod_span
   int size_exp;
 };
@@ -330,6 +331,43 @@ __device__ __forceinline__ void walk_shallow(const uint2 *__restrict__ nodes, ui
   }
 }
 
+// ---- step / level counters ---------------------------------------------------------------------------------------------
+// Every wavefront adds its sums to one of kCountSlots slots (64 bytes apart), a one-workgroup launch behind the march folds
+// the slots into the caller's two counters and leaves them zero.  (One atomic pair per WORKGROUP on the caller's two words
+// was 16 200 same-address atomics for a 1920x1080 render: ~0.5 ms of L2 serialisation, more than the march itself.)
+constexpr int kCountSlots = 1024, kCountSlotWords = 8;
+__device__ inline void count_steps(unsigned long long *__restrict__ slots, uint32_t my_steps, uint32_t my_levels, unsigned lane) {
+  unsigned long long s64 = my_steps, l64 = my_levels;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s64 += __shfl_down(s64, o);
+    l64 += __shfl_down(l64, o);
+  }
+  if (lane == 0) {
+    const unsigned slot = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (unsigned)(kCountSlots - 1);
+    atomicAdd(&slots[slot * kCountSlotWords], s64);
+    atomicAdd(&slots[slot * kCountSlotWords + 1], l64);
+  }
+}
+__global__ __launch_bounds__(kCountSlots) void count_reduce_kernel(unsigned long long *__restrict__ slots, unsigned long long *__restrict__ counters) {
+  __shared__ unsigned long long part[kCountSlots / 64][2];
+  unsigned long long s64 = slots[threadIdx.x * kCountSlotWords], l64 = slots[threadIdx.x * kCountSlotWords + 1];
+  slots[threadIdx.x * kCountSlotWords] = 0ull; slots[threadIdx.x * kCountSlotWords + 1] = 0ull;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s64 += __shfl_down(s64, o);
+    l64 += __shfl_down(l64, o);
+  }
+  if ((threadIdx.x & 63u) == 0) { part[threadIdx.x >> 6][0] = s64; part[threadIdx.x >> 6][1] = l64; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long a = 0, b = 0;
+    for (int w = 0; w < kCountSlots / 64; w++) { a += part[w][0]; b += part[w][1]; }
+    atomicAdd(&counters[0], a);
+    atomicAdd(&counters[1], b);
+  }
+}
+
 // CARRY = false: SVOSLAM_RENDER_REFERENCE.  The reference re-reads pos[index] every step and that
 // pixel stays 0 until the ray retires (Q9), so a sample's colour matters only on the step that
 // retires the ray: the march needs alpha alone and the colour is formed once, after the loop.
@@ -338,7 +376,7 @@ template <bool CARRY, int LDSD, int THREADS, int GRID>
 __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
                                                          const uint2 *__restrict__ grid, const float *__restrict__ table,
                                                          const float *__restrict__ alpha_lut_g, TraceParams P,
-                                                         unsigned long long *__restrict__ counters) {
+                                                         unsigned long long *__restrict__ counters, unsigned long long *__restrict__ slots) {
 #ifdef SVO_MARCH_PRIO
   __builtin_amdgcn_s_setprio(SVO_MARCH_PRIO);
 #endif
@@ -579,28 +617,7 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
     o.z = (unsigned char)((out >> 16) & 0xFF); o.w = (unsigned char)(out >> 24);
     pos[idx] = o;
   }
-  if (counters) {
-    // wave sums -> workgroup sums in LDS -> one atomic pair per workgroup (9600 same-address atomics,
-    // one pair per wavefront, cost 60 us of L2 serialisation per frame)
-    __shared__ unsigned long long wg_sum[2];
-    if (threadIdx.x == 0) { wg_sum[0] = 0ull; wg_sum[1] = 0ull; }
-    __syncthreads();
-    unsigned long long s64 = my_steps, l64 = my_levels;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      s64 += __shfl_down(s64, o);
-      l64 += __shfl_down(l64, o);
-    }
-    if (lane == 0) {
-      atomicAdd(&wg_sum[0], s64);
-      atomicAdd(&wg_sum[1], l64);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      atomicAdd(&counters[0], wg_sum[0]);
-      atomicAdd(&counters[1], wg_sum[1]);
-    }
-  }
+  if (slots) count_steps(slots, my_steps, my_levels, lane);
 }
 
 
@@ -643,26 +660,42 @@ __device__ __forceinline__ uint32_t walk_sample(const uint2 *__restrict__ nodes,
   return w1;
 }
 
-// Same rays, same samples, same pixel as cone_trace_kernel<false, ...>.  Every sample requests TWO entries from the guessed
-// table cells, side by side: its brick entry (2 bytes) and its level-grid entry (8 bytes).  A sample whose LOD lies in
-// 9..12 and whose level-8 node has children is answered by the brick; one whose walk stops at or above level 8 (empty
-// space: first childless node at level <= 8, or an LOD of exactly 8) by the grid entry; so a step is ONE round trip to
-// memory whatever the depth of the tree.  What remains -- an LOD coarser than 8 or deeper than a level-12 node with
-// children, a sample whose table bracket is not confirmed -- and the LAST sample of a ray that ended on a brick (whose
-// node's colour word forms the pixel, Q9) take walk_sample().  The rare cases sit behind wavefront-uniform branches.
+// Same rays, same samples, same pixel as cone_trace_kernel<false, ...>.  A sample requests its level-grid entry (8 bytes)
+// and -- while the ray is among nodes, i.e. the previous sample's level-8 node had children -- its brick entry (2
+// bytes) side by side, both from the guessed table cells.  A sample whose LOD lies in 9..12 and whose level-8 node has
+// children is answered by the brick; one whose walk stops at or above level 8 (empty space: first childless node at level
+// <= 8, or an LOD of exactly 8) by the grid entry; so a step is ONE round trip to memory whatever the depth of the
+// tree (two on the step that enters a level-8 node with children).  What remains -- an LOD coarser than the stop level
+// or deeper than a level-12 node with children, a sample whose table bracket is not confirmed -- and the LAST sample
+// of every ray (whose node's colour word forms the pixel, Q9) take walk_sample().  The rare cases sit behind
+// wavefront-uniform branches: the loop is bound by the instructions it issues (profiles/r03_brick_march_anatomy.txt).
 template <int THREADS>
 __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
                                                                    const uint2 *__restrict__ grid, const uint16_t *__restrict__ bricks,
                                                                    const float *__restrict__ table, const float *__restrict__ alpha_lut_g,
-                                                                   TraceParams P, unsigned long long *__restrict__ counters) {
+                                                                   TraceParams P, unsigned long long *__restrict__ counters,
+                                                                   unsigned long long *__restrict__ slots) {
   constexpr int LDSD = 11, GRID = kPoolGridLevel;
   constexpr int kLdsStride = lds_stride(LDSD);
+  constexpr int kCells = lds_cells(LDSD);
+#ifdef SVO_BRICK_DIAG
+  const long long c_entry = clock64();
+#endif
   __shared__ float alpha_lut[256];
-  __shared__ float lds_tab[3 * kLdsStride];
+  // split planes of the three axes, then what each axis' rank contributes to the DWORD index of its brick entry
+  // (brick_entry_index() >> 1: the field has 2^33 entries; bit 0 of the x rank picks the half)
+  __shared__ float lds_tab[3 * kLdsStride + 3 * kCells];
+  uint32_t *spread = reinterpret_cast<uint32_t *>(lds_tab + 3 * kLdsStride);
   if (threadIdx.x < 256) alpha_lut[threadIdx.x] = alpha_lut_g[threadIdx.x];
   {
     const float *src = table + 3 * kTabStride;
     for (int i = threadIdx.x; i < 3 * kLdsStride; i += THREADS) lds_tab[i] = src[i];
+    for (int i = threadIdx.x; i < kCells; i += THREADS) {
+      const uint32_t r = (uint32_t)i;
+      spread[i] = (uint32_t)(brick_entry_index(r, 0u, 0u) >> 1);
+      spread[kCells + i] = (uint32_t)(brick_entry_index(0u, r, 0u) >> 1);
+      spread[2 * kCells + i] = (uint32_t)(brick_entry_index(0u, 0u, r) >> 1);
+    }
   }
   __syncthreads();
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -671,8 +704,12 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
     const int xcd = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);
     const int slot_y = slot / P.xcd_w;
     tile_x = (xcd & 3) * P.xcd_w + (slot - slot_y * P.xcd_w);
-    tile_y = (xcd >> 2) * P.xcd_h + slot_y;
+    tile_y = P.xcd_rows ? 2 * slot_y + (xcd >> 2) : (xcd >> 2) * P.xcd_h + slot_y;
   } else {
+    // Row-major order (the default here): the march is bound by instruction issue, not by its loads, and the long rays
+    // of a frame come in bands of rows (grazing views of the floor, a silhouette) -- with one image region per XCD the
+    // SIMDs of the other regions idle through the tail; dealing consecutive tiles to the eight XCDs spreads it
+    // (640x480, 300-frame map: 0.388 ms with regions, 0.333 with alternate rows per XCD group, 0.324 row-major).
     tile_y = (int)blockIdx.x / P.xcd_h;
     tile_x = (int)blockIdx.x - tile_y * P.xcd_h;
   }
@@ -697,35 +734,46 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
     float ray_len = length3(rx, ry, rz);
     // (a root cube outside the ordinary range of sizes never gets here: the host launches cone_trace_kernel for it)
     const float ts11 = ldexpf(P.size, -LDSD);  // size / 2^11: what the level-11 decision adds to the centre (walk_deep_chain)
-    // The loop carries the ray (rx, ry, rz, ray_len) and the counters, nothing else: which of its two exits a ray took is
-    // read off ray_len afterwards, and the last sample's node is looked up again for the pixel (once per ray).
+    // The loop carries the ray (rx, ry, rz, ray_len), the previous grid word and the counters, nothing else: which of its
+    // two exits a ray took is read off afterwards, and the last sample's node is looked up again for the pixel (once per ray).
     float tx = 0.0f, ty = 0.0f, tz = 0.0f;  // the sample of the current step (the last one, after the loop)
     int lod = 0;
-    // the answers of a sample's two entries: `depth` / `retired` when one of them decides (return value), given the level-12
-    // octant where a brick needs it (oct12 < 0: not known -- such a sample is left undecided)
-    auto decode = [&](uint32_t e, uint2 gq, int lod_, int oct12, int &depth, bool &retired) -> bool {
+    bool retired = false;
+    uint32_t prev_gx = 0;  // the previous sample's grid word: its children flag = "this ray is among nodes"
+    auto brick_entry = [&](uint32_t x, uint32_t y, uint32_t z) -> uint32_t {  // through the LDS spread tables
+      const uint32_t d = spread[x] | spread[kCells + y] | spread[2 * kCells + z];
+      return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(bricks) + (((size_t)d << 2) | ((x & 1u) << 1)));
+    };
+    auto brick_deep = [&](uint32_t e, int lod_) -> bool {  // the walk ends on a level-12 node the brick describes
+      const int st = (int)((e & 7u) | 8u);
+      return (lod_ < st ? lod_ : st) == 12 && (lod_ == 12 || !(e & 8u));
+    };
+    // the answers of a sample's two entries: `depth` / `retired` when one of them decides (return value); oct12 = the
+    // sample's level-12 octant (only read when the brick's walk ends at level 12)
+    auto decode = [&](uint32_t e, uint2 gq, int lod_, uint32_t oct12, int &depth, bool &ret) -> bool {
       // the brick: the path stops at level st = 9 / 10 / 11, or goes on to level 12 (code 4); code 0 (no brick) gives st = 8
       // and never qualifies.  The walk ends at min(LOD, st); levels 9..11 carry their own bit, level 12 one per octant.
       // (An LOD beyond 12 over a level-12 node with children -- bit 3 -- ends deeper: not the brick's to answer.)
-      const int st = 8 + (int)(e & 7u);
+      const int st = (int)((e & 7u) | 8u);
       const int depth_b = lod_ < st ? lod_ : st;
-      const bool deep = depth_b == 12 && oct12 >= 0 && !(lod_ > 12 && (e & 8u));
+      const bool deep = depth_b == 12 && (lod_ == 12 || !(e & 8u));
       const bool by_brick = (uint32_t)(depth_b - kBrickNodeLevel) < 3u || deep;
-      const uint32_t bit = deep ? 8u + (uint32_t)oct12 : (uint32_t)(depth_b - 5);
+      const uint32_t bit = deep ? 8u + oct12 : (uint32_t)(depth_b - 5);
       // the grid: a first childless node at level gq.x <= 8 ends every walk whose LOD reaches it; a level-8 node with
       // children ends the walk of LOD 8 only
       const bool g_children = (gq.x & kFlag) != 0u;
       const int depth_g = g_children ? GRID : (int)gq.x;
       const bool by_grid = lod_ >= depth_g && (!g_children || lod_ == GRID);
       depth = by_brick ? depth_b : depth_g;
-      retired = by_brick ? ((e >> bit) & 1u) != 0u : gq.y >= 0xFE000000u;
+      ret = by_brick ? ((e >> bit) & 1u) != 0u : gq.y >= 0xFE000000u;
       return by_brick || by_grid;
     };
 #ifdef SVO_BRICK_DIAG
     uint32_t diag[4] = {0, 0, 0, 0};
     long long clk[3] = {0, 0, 0};
+    const long long c_loop = clock64();
 #endif
-    for (int step = 0; step < kMaxSteps; step++) {
+    for (;;) {
 #ifdef SVO_BRICK_DIAG
       const long long c0 = clock64();
 #endif
@@ -733,12 +781,14 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       tx = P.origin[0] + rx; ty = P.origin[1] + ry; tz = P.origin[2] + rz;
       const float pix_size = ray_len * P.pix_scale;
       int gx = (int)((tx - P.lo[0]) * P.inv_cell_lds), gy = (int)((ty - P.lo[1]) * P.inv_cell_lds), gz = (int)((tz - P.lo[2]) * P.inv_cell_lds);
-      gx = gx < 0 ? 0 : (gx > lds_cells(LDSD) - 1 ? lds_cells(LDSD) - 1 : gx);
-      gy = gy < 0 ? 0 : (gy > lds_cells(LDSD) - 1 ? lds_cells(LDSD) - 1 : gy);
-      gz = gz < 0 ? 0 : (gz > lds_cells(LDSD) - 1 ? lds_cells(LDSD) - 1 : gz);
-      // both entries requested from the GUESSED cells (see cone_trace_kernel)
-      const uint32_t e = bricks[brick_entry_index((uint32_t)gx, (uint32_t)gy, (uint32_t)gz)];
+      gx = gx < 0 ? 0 : (gx > kCells - 1 ? kCells - 1 : gx);
+      gy = gy < 0 ? 0 : (gy > kCells - 1 ? kCells - 1 : gy);
+      gz = gz < 0 ? 0 : (gz > kCells - 1 ? kCells - 1 : gz);
+      // entries requested from the GUESSED cells (see cone_trace_kernel)
       const uint2 gq = grid[(((uint32_t)gz >> (LDSD - GRID)) << (2 * GRID)) | (((uint32_t)gy >> (LDSD - GRID)) << GRID) | ((uint32_t)gx >> (LDSD - GRID))];
+      const bool with_brick = __any((prev_gx & kFlag) != 0u);  // (uniform: some ray of this wavefront is among nodes)
+      uint32_t e = 0;
+      if (with_brick) e = brick_entry((uint32_t)gx, (uint32_t)gy, (uint32_t)gz);
       const uint32_t ub = f2bits(pix_size);
       lod = (P.size_exp - (int)(ub >> 23)) + ((ub & 0x7FFFFFu) < P.size_man ? 1 : 0);
       const bool lod_ok = ub - P.lod_first <= P.lod_span;
@@ -749,24 +799,38 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       const float ay = lds_tab[kLdsStride + gy + 1], by = lds_tab[kLdsStride + gy + 2];
       const float az = lds_tab[2 * kLdsStride + gz + 1], bz = lds_tab[2 * kLdsStride + gz + 2];
       const bool conf = (((int)(ax < tx) & (int)!(bx < tx)) & ((int)(ay < ty) & (int)!(by < ty)) & ((int)(az < tz) & (int)!(bz < tz))) != 0;
-      int depth;
-      bool retired;
 #ifdef SVO_BRICK_DIAG
       asm volatile("" :: "v"(conf), "v"(inv_len));
       const long long c1 = clock64();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const long long c2 = clock64();
 #endif
-      const bool decided = decode(e, gq, lod, -1, depth, retired);
+      prev_gx = gq.x;
+      // the step that enters a level-8 node with children: its brick entry has not been requested yet
+      if (!with_brick && __any((gq.x & kFlag) != 0u && lod >= kBrickNodeLevel)) e = brick_entry((uint32_t)gx, (uint32_t)gy, (uint32_t)gz);
+      // the level-12 octant, where some lane's walk ends at level 12: the level-11 decision's plane is the table entry at
+      // the even rank (walk_deep_chain), i.e. S[g-1] for an odd rank and S[g] for an even one -- one of the two entries
+      // the confirmation has read (valid for confirmed guesses; the others are redone below)
+      uint32_t oct12 = 0;
+      if (__any(brick_deep(e, lod))) {
+        float cx = (gx & 1) ? ax : bx, cy = (gy & 1) ? ay : by, cz = (gz & 1) ? az : bz;
+        cx += ts11 * ((gx & 1) ? 1.0f : -1.0f);
+        cy += ts11 * ((gy & 1) ? 1.0f : -1.0f);
+        cz += ts11 * ((gz & 1) ? 1.0f : -1.0f);
+        oct12 = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
+      }
+      int depth;
+      const bool decided = decode(e, gq, lod, oct12, depth, retired);
       float new_dist = ldexpf(P.size, -depth);  // (decided: depth in 1..12)
       bool full_form = false;
 #ifdef SVO_BRICK_DIAG
       if (decided && conf && lod_ok) diag[0]++;
+      if (with_brick) diag[2]++;
 #endif
       if (__builtin_expect(__any(!(decided && conf && lod_ok)), 0)) {
         if (!(decided && conf && lod_ok)) {
           // the rare sample: an LOD outside the fast form's range, a guess that is not the rank (within rounding of a split
-          // plane), a brick that needs the level-12 octant, or a walk neither entry decides
+          // plane), or a walk neither entry decides
           if (!lod_ok) lod = step_lod(P.size, pix_size);
           bool ok = true;
           uint32_t xb = (uint32_t)gx, yb = (uint32_t)gy, zb = (uint32_t)gz;
@@ -783,14 +847,14 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
             }
             e2 = bricks[brick_entry_index(xb, yb, zb)];
             g2 = grid[((zb >> (LDSD - GRID)) << (2 * GRID)) | ((yb >> (LDSD - GRID)) << GRID) | (xb >> (LDSD - GRID))];
+            prev_gx = g2.x;
           }
-          // the level-12 octant: the level-11 decision's plane is the table entry at the even rank (walk_deep_chain)
           float cx = lds_tab[(xb & ~1u) + 2u], cy = lds_tab[kLdsStride + (yb & ~1u) + 2u], cz = lds_tab[2 * kLdsStride + (zb & ~1u) + 2u];
           cx += ts11 * ((xb & 1u) ? 1.0f : -1.0f);
           cy += ts11 * ((yb & 1u) ? 1.0f : -1.0f);
           cz += ts11 * ((zb & 1u) ? 1.0f : -1.0f);
-          const int oct12 = (int)((uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2));
-          const bool decided2 = ok && decode(e2, g2, lod, oct12, depth, retired);
+          const uint32_t oct12r = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
+          const bool decided2 = ok && decode(e2, g2, lod, oct12r, depth, retired);
           if (!decided2) {
             depth = lod;
             const uint32_t w = walk_sample<LDSD, GRID>(nodes, octree, grid, table, lds_tab, P, tx, ty, tz, xb, yb, zb, ok, depth);
@@ -801,37 +865,44 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
           }
           new_dist = (depth >= -100 && depth <= 100) ? ldexpf(P.size, -depth) : P.size / ldexpf(1.0f, depth);
           full_form = depth < -60;
+          if (depth < 0) depth = 0;  // (levels the reference visits: none)
 #ifdef SVO_BRICK_DIAG
           diag[1]++;
-          if (!conf) diag[2]++;
 #endif
         }
       }
-      my_levels += (uint32_t)(depth > 0 ? depth : 0);
+      my_levels += (uint32_t)depth;
 #ifdef SVO_BRICK_DIAG
       clk[0] += c1 - c0; clk[1] += c2 - c1;
 #endif
-      if (retired) break;
+      // advance (:126-131); a retired ray leaves before its advance counts: its ray_len stays the last sample's
       float s = div_rn_midrange_r(ray_len + new_dist, ray_len, inv_len);
       if (__builtin_expect(__any(full_form), 0)) {
         if (full_form) s = (ray_len + new_dist) / ray_len;
       }
-      rx *= s; ry *= s; rz *= s;
-      ray_len = sqrt_rn_midrange(dot3(rx, ry, rz, rx, ry, rz));
+      const float nx = rx * s, ny = ry * s, nz = rz * s;
+      float nlen = sqrt_rn_midrange(dot3(nx, ny, nz, nx, ny, nz));
       if (__builtin_expect(__any(full_form), 0)) {
-        if (full_form) ray_len = length3(rx, ry, rz);
+        if (full_form) nlen = length3(nx, ny, nz);
       }
 #ifdef SVO_BRICK_DIAG
-      asm volatile("" :: "v"(ray_len));
+      asm volatile("" :: "v"(nlen));
       clk[2] += clock64() - c2;
 #endif
-      if (ray_len > kMaxRange) break;
+      if (retired || my_steps >= (uint32_t)kMaxSteps) break;
+      rx = nx; ry = ny; rz = nz; ray_len = nlen;
+      if (nlen > kMaxRange) break;
     }
 #ifdef SVO_BRICK_DIAG
     if (counters) {
       // cycles of the lane that stayed longest = of its wavefront: before the entries are needed / waiting for them / after
+      if (P.mode & 0x200) {  // prologue and whole loop instead of the step classes
+        const long long c_end = clock64();
+        if (lane == 0) { atomicAdd(&counters[2], (unsigned long long)(c_loop - c_entry)); atomicAdd(&counters[3], (unsigned long long)(c_end - c_loop)); }
+      } else {
       atomicAdd(&counters[2], (unsigned long long)diag[0]);
       atomicAdd(&counters[3], (unsigned long long)diag[1]);
+      }
       uint32_t mx = my_steps;
       for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)mx, o); mx = v > mx ? v : mx; }
       const unsigned long long top = __ballot(my_steps == mx);
@@ -879,26 +950,7 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
     o.z = (unsigned char)((out >> 16) & 0xFF); o.w = (unsigned char)(out >> 24);
     pos[idx] = o;
   }
-  if (counters) {
-    __shared__ unsigned long long wg_sum[2];
-    if (threadIdx.x == 0) { wg_sum[0] = 0ull; wg_sum[1] = 0ull; }
-    __syncthreads();
-    unsigned long long s64 = my_steps, l64 = my_levels;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      s64 += __shfl_down(s64, o);
-      l64 += __shfl_down(l64, o);
-    }
-    if (lane == 0) {
-      atomicAdd(&wg_sum[0], s64);
-      atomicAdd(&wg_sum[1], l64);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      atomicAdd(&counters[0], wg_sum[0]);
-      atomicAdd(&counters[1], wg_sum[1]);
-    }
-  }
+  if (slots) count_steps(slots, my_steps, my_levels, lane);
 }
 
 // tile -> XCD mapping of a render of tiles_x x tiles_y workgroup tiles; returns the number of workgroups to launch
@@ -915,6 +967,7 @@ static unsigned xcd_mapping(TraceParams &P, int tiles_x, int tiles_y) {
 // ---- per-stream acceleration buffers ----
 struct StreamAccel {
   DeviceBuffer buf;
+  unsigned long long *count_slots = nullptr;  // [kCountSlots][kCountSlotWords], zero between renders (count_reduce_kernel)
   // what the tables in `buf` were built for (they depend on the root cube only, not on the tree)
   bool tables_valid = false;
   const float *tables_at = nullptr;
@@ -937,11 +990,11 @@ int cone_trace_release(hipStream_t stream, bool all) {
   if (!all) pool_accel_forget_stream(stream);  // no pool's grid is ordered behind a stream that is going away
   std::lock_guard<std::mutex> lock(g_accel_mu);
   if (all) {
-    for (auto &kv : g_accel) kv.second->buf.release();
+    for (auto &kv : g_accel) { kv.second->buf.release(); if (kv.second->count_slots) (void)hipFree(kv.second->count_slots); }
     g_accel.clear();
   } else {
     auto it = g_accel.find(stream);
-    if (it != g_accel.end()) { it->second->buf.release(); g_accel.erase(it); }
+    if (it != g_accel.end()) { it->second->buf.release(); if (it->second->count_slots) (void)hipFree(it->second->count_slots); g_accel.erase(it); }
   }
   return SVOSLAM_OK;
 }
@@ -967,6 +1020,7 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   P.pix_scale = tanf(fov * 3.14159f / 180.0f) / (float)height;
   P.width = width; P.height = height; P.mode = mode;
   P.row_first = row_first; P.row_end = row_first + rows;
+  P.xcd_rows = 0;
   // lookup helpers: the table-cell guess and the operand range of the fast LOD form
   for (int k = 0; k < 3; k++) P.lo[k] = center[k] - size;
   P.inv_cell = (float)kTabCells / (2.0f * size);
@@ -1033,31 +1087,46 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   }
   sa->tables_valid = true; sa->tables_at = d_table; sa->lds_depth = P.lds_depth; sa->size = size;
   for (int k = 0; k < 3; k++) sa->center[k] = center[k];
+  unsigned long long *slots = nullptr;
+  if (d_steps) {
+    if (!sa->count_slots) {
+      SVO_HIP(hipMalloc((void **)&sa->count_slots, (size_t)kCountSlots * kCountSlotWords * 8));
+      SVO_HIP(hipMemsetAsync(sa->count_slots, 0, (size_t)kCountSlots * kCountSlotWords * 8, stream));
+    }
+    slots = sa->count_slots;
+  }
   SVO_TRY(stage_event(kStageMarch, stream));
   uchar4 *out = reinterpret_cast<uchar4 *>(d_pos);
   const bool carry = (mode & 0xFF) == SVOSLAM_RENDER_CARRY;
   const bool midrange_size = size >= 9.5367431640625e-07f && size <= 1048576.0f;  // (see cone_trace_kernel: the length recurrence's short forms)
   if (d_bricks && !carry && P.lds_depth == 11 && midrange_size) {  // a pool of this library in reference mode: the march over occupancy bricks
-    const dim3 grid(xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads / 32)));
-    cone_trace_brick_kernel<kTraceThreads><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps);
+    unsigned blocks = xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads / 32));
+    // SVOSLAM_MARCH_XCD: 0 = one image region per XCD, 1 = the two XCD groups take alternate tile rows, 2 (default) = row-major
+    // order (A/B measurements: see the kernel)
+    static const int xcd_mode = [] { const char *e = getenv("SVOSLAM_MARCH_XCD"); return e ? atoi(e) : 2; }();
+    P.xcd_rows = xcd_mode == 1;
+    if (xcd_mode == 2 && P.xcd_w > 0) { P.xcd_w = 0; P.xcd_h = (int)cdiv(width, 32); blocks = cdiv(width, 32) * cdiv(rows, kTraceThreads / 32); }
+    const dim3 grid(blocks);
+    cone_trace_brick_kernel<kTraceThreads><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps, slots);
   } else if (P.lds_depth == 11 && large) {
     const dim3 grid(xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads / 32)));
-    if (carry) cone_trace_kernel<true, 11, kTraceThreads, kGridLevelLarge><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
-    else cone_trace_kernel<false, 11, kTraceThreads, kGridLevelLarge><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    if (carry) cone_trace_kernel<true, 11, kTraceThreads, kGridLevelLarge><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
+    else cone_trace_kernel<false, 11, kTraceThreads, kGridLevelLarge><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
   } else if (P.lds_depth == 11) {
     const dim3 grid(xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads / 32)));
-    if (carry) cone_trace_kernel<true, 11, kTraceThreads, kGridLevelSmall><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
-    else cone_trace_kernel<false, 11, kTraceThreads, kGridLevelSmall><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    if (carry) cone_trace_kernel<true, 11, kTraceThreads, kGridLevelSmall><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
+    else cone_trace_kernel<false, 11, kTraceThreads, kGridLevelSmall><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
   } else if (!large) {
     const dim3 grid(xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads12 / 32)));
-    if (carry) cone_trace_kernel<true, 12, kTraceThreads12, kGridLevelSmall><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
-    else cone_trace_kernel<false, 12, kTraceThreads12, kGridLevelSmall><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    if (carry) cone_trace_kernel<true, 12, kTraceThreads12, kGridLevelSmall><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
+    else cone_trace_kernel<false, 12, kTraceThreads12, kGridLevelSmall><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
   } else {
     const dim3 grid(xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads12 / 32)));
-    if (carry) cone_trace_kernel<true, 12, kTraceThreads12, kGridLevelLarge><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
-    else cone_trace_kernel<false, 12, kTraceThreads12, kGridLevelLarge><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps);
+    if (carry) cone_trace_kernel<true, 12, kTraceThreads12, kGridLevelLarge><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
+    else cone_trace_kernel<false, 12, kTraceThreads12, kGridLevelLarge><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
   }
   SVO_TRY(stage_event(kStageMarch, stream));
+  if (slots) count_reduce_kernel<<<1, kCountSlots, 0, stream>>>(slots, d_steps);
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
 }

@@ -124,7 +124,11 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const uint16_t *__restri
     for (int cx = cx0; cx < tx; ++cx) {
       const int depth = tile[cy - y0][cx - x0];
       const float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
-      const float color2 = (float)((value - depth) * (value - depth));
+      // the reference's product is a 32-bit `int` one (:168, mul.lo.s32): a difference beyond 46340 wraps it, negative for
+      // 65535 next to an ordinary depth.  Written as an unsigned product converted back, so that the wrap is defined
+      // behaviour here (the compiler had turned the signed form into an unsigned convert: no wrap, 60 % of a test image off)
+      const unsigned diff = (unsigned)(value - depth);
+      const float color2 = (float)(int)(diff * diff);
       const float weight = det_expf(-(space2 * sig_spat + color2 * sig_dep));
       sum1 = fmaf((float)depth, weight, sum1);
       sum2 += weight;

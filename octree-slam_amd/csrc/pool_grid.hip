@@ -38,6 +38,7 @@ void pool_accel_register(svoslam_pool *pool) {
   } else {
     it->second->valid = false;  // freshly initialised memory at a recycled address: whatever the grid holds is stale
     it->second->bricks_valid = false;
+    it->second->max_depth = 0;
   }
 }
 
@@ -64,11 +65,14 @@ void pool_accel_unregister(svoslam_pool *pool) {
   g_accel.erase(it);  // (~PoolAccel releases the device buffers once no enqueue holds the entry)
 }
 
-void pool_accel_invalidate(svoslam_pool *pool) {
+void pool_accel_invalidate(svoslam_pool *pool, int depth) {
   if (!pool || !pool->d_data) return;
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_accel.find(pool->d_data);
-  if (it != g_accel.end()) { it->second->valid = false; it->second->bricks_valid = false; }
+  if (it == g_accel.end()) return;
+  it->second->valid = false; it->second->bricks_valid = false;
+  if (depth < 0) it->second->max_depth = 0;
+  else if (depth > it->second->max_depth) it->second->max_depth = depth;
 }
 
 static bool ensure_dirty_states(PoolAccel *pa) {
@@ -83,11 +87,12 @@ static bool ensure_dirty_states(PoolAccel *pa) {
 // Commits mark from the first one on, whether or not a grid exists yet: whether the NEXT render builds the grid in full
 // is decided when that render is enqueued, which may be after the commit was (the scheduler enqueues the deferred
 // commit of frame k+1 before the render of frame k).
-uint32_t *pool_accel_dirty_bitmap(svoslam_pool *pool, int parity) {
+uint32_t *pool_accel_dirty_bitmap(svoslam_pool *pool, int parity, int commit_depth) {
   if (!pool || !pool->d_data) return nullptr;
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_accel.find(pool->d_data);
   if (it == g_accel.end() || !ensure_dirty_states(it->second.get())) return nullptr;
+  if (commit_depth > it->second->max_depth) it->second->max_depth = commit_depth;
   return it->second->d_dirty[parity & 1];
 }
 
@@ -356,7 +361,7 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
     else (void)hipGetLastError();  // (a stream destroyed without svoslam_cone_trace_release: nothing left to wait for)
   }
   pa->last_stream = stream;
-  if (want_bricks && bricks_enabled()) ensure_bricks(pa, stream);  // (behind the ordering above: the first fill runs on `stream`)
+  if (want_bricks && bricks_enabled() && pa->max_depth <= 12) ensure_bricks(pa, stream);  // (behind the ordering above: the first fill runs on `stream`)
   const bool fresh = !pa->valid;
   pa->valid = true;
   uint32_t *serve[2] = {nullptr, nullptr};  // the dirty states this render consumes
@@ -380,7 +385,7 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
   }
   SVO_LAUNCH_CHECK();
   *d_grid = grid;
-  if (d_bricks) *d_bricks = pa->bricks;
+  if (d_bricks) *d_bricks = pa->max_depth <= 12 ? pa->bricks : nullptr;
   return SVOSLAM_OK;
 }
 

@@ -1251,7 +1251,7 @@ int pool_reset(svoslam_pool *pool, hipStream_t stream) {
   SVO_HIP(hipDeviceSynchronize());
   SVO_TRY(pool_sync(pool, stream));  // drains the size tracker
   SVO_HIP(memset_sync(pool->d_data, 0, 64));
-  pool_accel_invalidate(pool);
+  pool_accel_invalidate(pool, -1);
   pool->size = 8; pool->pending = 0; pool->pending_bound = 0;
   if (tracker_of(pool)) tracker_of(pool)->planned_ahead = 0;  // plans of the structure chain whose commit never came (an error mid-run) hold no reservation any more
   if (pool->d_size) SVO_HIP(hipMemcpy(pool->d_size, &pool->size, 4, hipMemcpyHostToDevice));
@@ -1401,7 +1401,7 @@ static inline unsigned *small_strad_ticket(svoslam_workspace *ws, int slot) { re
 // keys of the n inputs are in ws->keys_a
 static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, const void *d_colors, bool vec4,
                       bool color_by_position, svoslam_fuse_stats *stats, hipStream_t stream) {
-  pool_accel_invalidate(pool);  // the blocking path does not track what it touches: the next render rebuilds the level grid
+  pool_accel_invalidate(pool, depth);  // the blocking path does not track what it touches: the next render rebuilds the level grid
   SVO_TRY(pool_sync(pool, stream));
   u64 *skey = nullptr; u32 *sidx = nullptr;
   SVO_TRY(radix_sort_pairs(ws, n, 3 * depth + 1, stream, &skey, &sidx));
@@ -1843,7 +1843,7 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
     ws->deferred_pool = pool; ws->deferred_n = n; ws->deferred_depth = depth; ws->deferred_tiles = fill_tiles;
   }
   SVO_TRY(tracker_make_room(pool));
-  u32 *grid_dirty = pool_accel_dirty_bitmap(pool, deferred ? (int)(epoch & 1u) : 0);  // nullptr: not a registered pool
+  u32 *grid_dirty = pool_accel_dirty_bitmap(pool, deferred ? (int)(epoch & 1u) : 0, depth);  // nullptr: not a registered pool
   auto enqueue = [&]() -> int {
     if (!early)
       split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),

@@ -783,7 +783,9 @@ void ora_bilateral_filter(const uint16_t *in, uint16_t *out, int width, int heig
         for (int cx = x0; cx < tx; ++cx) {
           int depth = in[cy * width + cx];
           float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
-          float color2 = (float)((value - depth) * (value - depth));
+          /* a 32-bit int product that wraps (mul.lo.s32): written unsigned so that the wrap is defined behaviour in C */
+          unsigned diff = (unsigned)(value - depth);
+          float color2 = (float)(int)(diff * diff);
           float weight = det_expf(-(space2 * sig_spat + color2 * sig_dep));
           sum1 = fmaf((float)depth, weight, sum1);
           sum2 += weight;

@@ -6,6 +6,8 @@ import importlib
 synth = importlib.import_module("octree_slam_amd.synth")
 pl = importlib.import_module("octree_slam_amd.pipeline")
 W, H, D, edge = 640, 480, 12, 4.096
+if os.environ.get("DIAG_CFG4"):
+    W, H, D = 1920, 1080, 14
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 depth, rgb = synth.render_stream(K, W, H, device="cuda")
 P = pl.SlamPipeline(W, H, D, (0, 1.5, 0), edge)
