@@ -64,7 +64,11 @@ struct svoslam_runner {
   int lead = 2;  // commits the host may run ahead of the device (see svoslam_runner_run)
   bool fused_front = false;  // back-projection + bounding box + keys in one launch (SVOSLAM_RUNNER_FUSED_FRONT=0: the four stand-alone calls)
   bool early_split = true;  // SVOSLAM_RUNNER_EARLY_SPLIT=0: split_all_kernel inside the commit
-  bool deferred = false;  // SVOSLAM_RUNNER_DEFERRED=1 (one replica): the commit of frame k+1 is computed during the march of frame k
+  // one replica: the commit of frame k+1 is computed during the march of frame k (svoslam_svo_fuse_commit_deferred).  Default
+  // since round 3 for images up to 640x480-class: the march over occupancy bricks is bound by instruction issue and no
+  // longer by the loads the commit competes for (cfg3, 300-frame map: 1862 -> 2055 frames/s; the driver's 20 frames 1565 ->
+  // 1707; cfg4, where the launch-chain tracker bounds the frame, 815 -> 694: off there).  SVOSLAM_RUNNER_DEFERRED=0 / 1 overrides.
+  bool deferred = false, deferred_explicit = false;
   bool ran = false;
   // SVOSLAM_RUNNER_TIMELINE=1: timing events at the stage boundaries of the last call (svoslam_runner_timeline)
   bool maps_on_track_stream = false;  // SVOSLAM_RUNNER_MAPS_STREAM=0: maps of a frame right before its ICP on stream T (saves an
@@ -110,7 +114,8 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
   const char *tl = getenv("SVOSLAM_RUNNER_TIMELINE");
   r->timeline = tl && tl[0] == '1';
   const char *df = getenv("SVOSLAM_RUNNER_DEFERRED");
-  r->deferred = df && df[0] == '1';
+  r->deferred_explicit = df != nullptr;
+  r->deferred = df ? df[0] == '1' : ((long long)width * height <= 400000ll && r->replicas == 1);
   {
     int idx_bits = 1;
     while ((1ll << idx_bits) < (long long)width * height) idx_bits++;
@@ -213,7 +218,8 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
   if (!r || n < 0 || (n > 0 && (!d_depths || !d_rgbs || !timestamps || !views || (!d_image && !d_images)))) return SVOSLAM_ERR_INVALID_ARG;
   if (n == 0) return SVOSLAM_OK;
   if (row_first < 0 || rows < 0 || row_first + rows > r->h) return SVOSLAM_ERR_INVALID_ARG;
-  if (sharded && (r->replicas != 1 || r->deferred)) return SVOSLAM_ERR_INVALID_ARG;
+  if (sharded && (r->replicas != 1 || (r->deferred && r->deferred_explicit))) return SVOSLAM_ERR_INVALID_ARG;
+  const bool deferred = r->deferred && !sharded;  // (frame-sharded sessions keep the in-place commit)
   if (d_images)
     for (int i = 0; i < n; i++)
       if ((!march || march[i]) && !d_images[i]) return SVOSLAM_ERR_INVALID_ARG;
@@ -273,7 +279,7 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
     for (int i = 0; i < n; i++) marched += march[i] ? 1 : 0;
     plan_on_map = 3 * marched <= n;
     static const bool chain_on = [] { const char *e = getenv("SVOSLAM_RUNNER_STRUCTURE_CHAIN"); return !(e && e[0] == '0'); }();
-    if (plan_on_map && chain_on && R == 1 && !r->deferred) { chain = true; plan_on_map = false; }
+    if (plan_on_map && chain_on && R == 1 && !deferred) { chain = true; plan_on_map = false; }
   }
   if (chain) SVO_TRY(svoslam_pool_structure_begin(r->pool, r->s_prep));
   hipStream_t s_maps = one_stream ? r->s_track : r->s_maps;
@@ -371,7 +377,7 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
     }
     // the child tiles of this frame's splits, beyond the pool's size, while the previous frame is still being marched:
     // the commit on the map stream -- the stream that bounds the frame -- is then two launches instead of three
-    if (R == 1 && !r->deferred && r->early_split) SVO_TRY(svoslam_svo_fuse_split_early(ws, npts, r->depth, planned, r->s_prep));
+    if (R == 1 && !deferred && r->early_split) SVO_TRY(svoslam_svo_fuse_split_early(ws, npts, r->depth, planned, r->s_prep));
     SVO_HIP(hipEventRecord(ev_plan[i], r->s_prep));
     mark(i, 6, r->s_prep);
     return SVOSLAM_OK;
@@ -440,7 +446,7 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
     return SVOSLAM_OK;
   };
   auto enqueue_all = [&]() -> int {
-    if (R == 1 && r->deferred) return enqueue_all_deferred();
+    if (R == 1 && deferred) return enqueue_all_deferred();
     SVO_TRY(enqueue_maps(0));
     SVO_TRY(enqueue_track(0));
     if (n > 1) SVO_TRY(enqueue_maps(1));

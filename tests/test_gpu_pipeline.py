@@ -276,9 +276,13 @@ print("RESULT" + json.dumps([sha(P.image.cpu().numpy()), sha(P.pool.words()), sh
     # it - 1 stored) and with the replay of the whole transform chain from the raw maps
     assert run({"SVOSLAM_TRACK_CHAIN": "1"}) == base
     assert run({"SVOSLAM_TRACK_CHAIN": "1", "SVOSLAM_TRACK_WORKMAPS": "0"}) == base
-    # the scheduler with deferred commits (commit of frame k+1 computed beside the march of frame k, then applied)
+    # the scheduler with deferred commits (commit of frame k+1 computed beside the march of frame k, then applied: the
+    # default at this image size since round 3) and with in-place commits; with and without the occupancy bricks
     assert run({"SVOSLAM_RUNNER_DEFERRED": "1"}) == base
     assert run({"SVOSLAM_RUNNER_DEFERRED": "1", "SVOSLAM_RUNNER_LEAD": "0"}) == base
+    assert run({"SVOSLAM_RUNNER_DEFERRED": "0"}) == base
+    assert run({"SVOSLAM_RUNNER_DEFERRED": "0", "SVOSLAM_MARCH_BRICKS": "0"}) == base
+    assert run({"SVOSLAM_MARCH_BRICKS": "0"}) == base
     assert base[3] > 8
 
 
