@@ -1,0 +1,152 @@
+"""GPU parity of the reference-mode march over occupancy bricks (csrc/pool_grid.hpp "occupancy bricks",
+csrc/cone_trace.hip cone_trace_brick_kernel) against the CPU oracle's coneTrace (cone_tracing_kernels.cu:53-146):
+images and step / level counters byte for byte while the map is fused incrementally (stale-brick ring), through alpha
+saturation (A >= 254: the bricks' retire bits), at LODs on both sides of the bricks' levels 9..12, after a reset, for
+pools deeper than the bricks describe, and -- in child processes -- with the ring lapped and the bricks switched off."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from util import describe_mismatch, surface_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import svoslam_pkg
+    return svoslam_pkg.load(), torch
+
+
+def render_check(pkg, torch, oracle, pool, opool, w, h, view, center, size, what):
+    img = torch.full((h, w, 4), 9, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+    pkg.cone_trace_svo(img, 45.0, view, pool.data_ptr, center, size, 0, counters=cnt)
+    words = opool.words()
+    if len(words) == 0:
+        words = np.zeros(16, np.uint32)  # (an oracle pool that has seen no insertion holds no nodes: the empty root tile)
+    ref, steps, levels = oracle.cone_trace(words, w, h, 45.0, view, center, size, 0)
+    got = img.cpu().numpy()
+    assert np.array_equal(got, ref), (what, describe_mismatch(got, ref))
+    assert cnt.cpu().tolist() == [steps, levels], what
+    return got
+
+
+# the LOD of a sample is ceil(log2(size / (ray length x tan(45 deg) / image height))): tall narrow images reach the fine LODs
+VIEWS = (((0.1, 0.2, -2.6), (0, 0, 0), (96, 72)),            # far, coarse pixels: LOD ~5 at the surfaces (walks above the level grid)
+         ((0.1, 0.2, -1.2), (0, 0, 0), (24, 480)),           # one metre away: LOD 9..10 (bricks, levels 9..10)
+         ((0.3, 0.1, 0.62), (0.28, 0.05, 0.2), (32, 480)),   # a hand's breadth from the sheet: LOD 11..12 (level-12 octant bits)
+         ((0.12, -0.18, 0.14), (0.1, -0.2, -0.3), (24, 480)))  # centimetres outside the sphere, grazing: LOD 13+ (below the bricks)
+
+
+@pytest.mark.parametrize("depth", [10, 12])
+def test_bricks_follow_incremental_fusion_through_saturation(env, oracle, depth):
+    """the same surface observed 131 times with a few new points each time (asynchronous fusion: the commit lists the
+    stale bricks, the render rebuilds them): leaves pass A = 254 at observation 127 and rays begin to retire on them"""
+    pkg, torch = env
+    rng = np.random.default_rng(depth)
+    ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
+    center, edge = (0.0, 0.0, 0.0), 1.0
+    base, bcol = surface_cloud(rng, 5000, jitter=0.002)
+    checks = {0, 1, 2, 64, 125, 126, 127, 128, 130}
+    retired_seen = False
+    for it in range(131):
+        extra, ecol = surface_cloud(rng, 300, jitter=0.004)
+        pts, col = np.concatenate([base, extra]), np.concatenate([bcol, ecol])
+        pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, pool, center, edge)
+        opool.insert_cloud(pts, col, depth, center, edge)
+        if it in checks:
+            for eye, tgt, (w, h) in VIEWS:
+                got = render_check(pkg, torch, oracle, pool, opool, w, h, oracle.look_at(eye, tgt, (0, 1, 0)), center, edge, (it, eye))
+                retired_seen |= bool((got[..., :3] != 0).any())
+    assert np.array_equal(pool.words()[:2 * pool.size], opool.words()[:2 * pool.size])
+    assert retired_seen  # saturated leaves were reached: some pixel carries a colour
+
+
+def test_bricks_deferred_commits_and_reset(env, oracle):
+    """deferred commit + apply (marks go to the other dirty state), a render between the two halves (old map), a reset
+    followed by a different cloud (every brick of the old map must be gone)"""
+    pkg, torch = env
+    rng = np.random.default_rng(77)
+    ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
+    center, edge, depth = (0.0, 0.0, 0.0), 1.0, 11
+    view = oracle.look_at(VIEWS[2][0], VIEWS[2][1], (0, 1, 0))
+    w, h = VIEWS[2][2]
+    for it in range(4):
+        pts, col = surface_cloud(rng, 4000, jitter=0.003)
+        tp, tc = torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda()
+        pkg.svo_fuse_sort(ws, tp, depth, center, edge)
+        pkg.svo_fuse_plan(ws, len(pts), depth, pool)
+        pkg.svo_fuse_commit_deferred(ws, tc, depth, pool)
+        render_check(pkg, torch, oracle, pool, opool, w, h, view, center, edge, ("between", it))  # still the old map
+        pkg.svo_fuse_apply(ws, pool)
+        opool.insert_cloud(pts, col, depth, center, edge)
+        render_check(pkg, torch, oracle, pool, opool, w, h, view, center, edge, ("applied", it))
+    pool.reset()
+    opool = oracle.Pool()
+    pts, col = surface_cloud(rng, 3000, jitter=0.003)
+    pts = (pts * np.float32(0.5) + np.float32(0.3)).astype(np.float32)
+    pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, pool, center, edge)
+    opool.insert_cloud(pts, col, depth, center, edge)
+    for eye, tgt, (w2, h2) in VIEWS:
+        render_check(pkg, torch, oracle, pool, opool, w2, h2, oracle.look_at(eye, tgt, (0, 1, 0)), center, edge, ("after reset", eye))
+
+
+def test_pool_deeper_than_the_bricks(env, oracle):
+    """depth 14: the bricks stop at level 12, such a pool is marched through the tree (no bricks are kept for it); a
+    depth-12 pool that is then fused at depth 14 switches over"""
+    pkg, torch = env
+    rng = np.random.default_rng(5)
+    ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
+    center, edge = (0.0, 0.0, 0.0), 1.0
+    pts, col = surface_cloud(rng, 4000, jitter=0.002)
+    for depth in (12, 12, 14, 14):
+        pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, pool, center, edge)
+        opool.insert_cloud(pts, col, depth, center, edge)
+        for eye, tgt, (w, h) in VIEWS[1:]:
+            render_check(pkg, torch, oracle, pool, opool, w, h, oracle.look_at(eye, tgt, (0, 1, 0)), center, edge, (depth, eye))
+
+
+def test_bricks_ring_lapped_and_bricks_off_in_child_processes():
+    """60 fusions of 320x240 frames without a render in between append more stale-brick entries than the ring holds (the
+    refresh must rebuild every brick), then renders interleave with further fusions; the same with the bricks switched off
+    (the tree march of round 2) and with in-place commits: identical images, counters and pools"""
+    code = r'''
+import sys, json, hashlib, importlib, os
+sys.path.insert(0, %r)
+import numpy as np, torch
+import svoslam_pkg
+pkg = svoslam_pkg.load()
+synth = importlib.import_module("octree_slam_amd.synth")
+pl = importlib.import_module("octree_slam_amd.pipeline")
+w, h, depth, center, edge = 320, 240, 12, (0.0, 1.5, 0.0), 4.096
+P = pl.SlamPipeline(w, h, depth, center, edge, count_steps=True)
+sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+out = []
+n_quiet = 60
+for k in range(n_quiet + 6):
+    d, c = synth.render_frame(k, w, h, device="cuda")
+    P.track(d, c, k)
+    P.fuse_frame(d, c)
+    if k >= n_quiet:
+        img = P.render(pl.ground_truth_view(k, synth)).cpu().numpy()
+        out.append([sha(img), P.counters.cpu().tolist()])
+torch.cuda.synchronize()
+out.append([sha(P.pool.words()), int(P.pool.size)])
+print("RESULT" + json.dumps(out))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        e = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0][6:])
+    base = run({})
+    assert run({"SVOSLAM_MARCH_BRICKS": "0"}) == base
+    assert base[-1][1] > 8 and base[0][1][0] > 0
