@@ -156,6 +156,7 @@ struct TraceParams {
   float lo[3], inv_cell, inv_cell_lds;   // guess of the table cell: (t - lo) * inv_cell
   int lds_depth;                          // levels of the LDS table of this render (11 or 12)
   int xcd_w, xcd_h;                       // tile -> XCD mapping (see cone_trace_kernel)
+  int lod_always;                         // brick march: pix_scale x [0.001, 11 + size] lies inside the fast LOD form's range
   int xcd_rows;                           // brick march: 1 = the two XCD groups take alternate tile rows (see cone_trace_brick_kernel)
   uint32_t lod_first, lod_span, size_man;  // fast LOD: valid when bits(pix_size) - lod_first <= lod_span
   int size_exp;
@@ -739,33 +740,36 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
     float tx = 0.0f, ty = 0.0f, tz = 0.0f;  // the sample of the current step (the last one, after the loop)
     int lod = 0;
     bool retired = false;
+    const bool lod_always = P.lod_always != 0;  // (uniform) every pixel size this render can form is in the fast LOD form's range
     uint32_t prev_gx = 0;  // the previous sample's grid word: its children flag = "this ray is among nodes"
     auto brick_entry = [&](uint32_t x, uint32_t y, uint32_t z) -> uint32_t {  // through the LDS spread tables
       const uint32_t d = spread[x] | spread[kCells + y] | spread[2 * kCells + z];
       return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(bricks) + (((size_t)d << 2) | ((x & 1u) << 1)));
     };
-    auto brick_deep = [&](uint32_t e, int lod_) -> bool {  // the walk ends on a level-12 node the brick describes
-      const int st = (int)((e & 7u) | 8u);
-      return (lod_ < st ? lod_ : st) == 12 && (lod_ == 12 || !(e & 8u));
-    };
     // the answers of a sample's two entries: `depth` / `retired` when one of them decides (return value); oct12 = the
-    // sample's level-12 octant (only read when the brick's walk ends at level 12)
+    // sample's level-12 octant (read only when the brick's walk ends at level 12; 0 unless some lane's LOD reaches 12).
+    // Written in integers: as booleans every condition is a 64-bit lane mask and the loop is bound by what it issues.
     auto decode = [&](uint32_t e, uint2 gq, int lod_, uint32_t oct12, int &depth, bool &ret) -> bool {
       // the brick: the path stops at level st = 9 / 10 / 11, or goes on to level 12 (code 4); code 0 (no brick) gives st = 8
-      // and never qualifies.  The walk ends at min(LOD, st); levels 9..11 carry their own bit, level 12 one per octant.
-      // (An LOD beyond 12 over a level-12 node with children -- bit 3 -- ends deeper: not the brick's to answer.)
+      // and never qualifies.  The walk ends at min(LOD, st); levels 9..11 carry their own bit (4..6), level 12 one per
+      // octant (8..15).  An LOD beyond 12 over a level-12 node with children (bit 3) ends deeper: not the brick's to answer.
       const int st = (int)((e & 7u) | 8u);
       const int depth_b = lod_ < st ? lod_ : st;
-      const bool deep = depth_b == 12 && (lod_ == 12 || !(e & 8u));
-      const bool by_brick = (uint32_t)(depth_b - kBrickNodeLevel) < 3u || deep;
-      const uint32_t bit = deep ? 8u + oct12 : (uint32_t)(depth_b - 5);
+      uint32_t bit = (uint32_t)(depth_b - 5);                       // 4..6 for levels 9..11, 7 for level 12
+      bool by_brick = (uint32_t)(depth_b - kBrickNodeLevel) < 3u;
+      if (lod_ >= 12) {  // (per lane; rare except at close range)
+        const bool deep = depth_b == 12 && (lod_ == 12 || !(e & 8u));
+        by_brick = by_brick || deep;
+        bit = deep ? 8u + oct12 : bit;
+      }
       // the grid: a first childless node at level gq.x <= 8 ends every walk whose LOD reaches it; a level-8 node with
-      // children ends the walk of LOD 8 only
-      const bool g_children = (gq.x & kFlag) != 0u;
-      const int depth_g = g_children ? GRID : (int)gq.x;
-      const bool by_grid = lod_ >= depth_g && (!g_children || lod_ == GRID);
-      depth = by_brick ? depth_b : depth_g;
-      ret = by_brick ? ((e >> bit) & 1u) != 0u : gq.y >= 0xFE000000u;
+      // children (gq.x = flag | tile >= 2^30) ends the walk of LOD 8 only
+      const uint32_t depth_g = gq.x < (uint32_t)GRID ? gq.x : (uint32_t)GRID;
+      const uint32_t top_g = gq.x < kFlag ? 127u : (uint32_t)GRID;   // the LODs it answers: depth_g .. top_g
+      const bool by_grid = (uint32_t)lod_ - depth_g <= top_g - depth_g;
+      depth = by_brick ? depth_b : (int)depth_g;
+      const uint32_t rbit = by_brick ? (e >> bit) & 1u : (uint32_t)(gq.y >= 0xFE000000u);
+      ret = rbit != 0u;
       return by_brick || by_grid;
     };
 #ifdef SVO_BRICK_DIAG
@@ -791,7 +795,7 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       if (with_brick) e = brick_entry((uint32_t)gx, (uint32_t)gy, (uint32_t)gz);
       const uint32_t ub = f2bits(pix_size);
       lod = (P.size_exp - (int)(ub >> 23)) + ((ub & 0x7FFFFFu) < P.size_man ? 1 : 0);
-      const bool lod_ok = ub - P.lod_first <= P.lod_span;
+      const bool lod_ok = lod_always || ub - P.lod_first <= P.lod_span;
       float inv_len = __builtin_amdgcn_rcpf(ray_len);
       inv_len = fmaf(fmaf(-ray_len, inv_len, 1.0f), inv_len, inv_len);
       // confirmation of the guessed ranks: S[g-1] < t <= S[g] on every axis
@@ -812,7 +816,7 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       // the even rank (walk_deep_chain), i.e. S[g-1] for an odd rank and S[g] for an even one -- one of the two entries
       // the confirmation has read (valid for confirmed guesses; the others are redone below)
       uint32_t oct12 = 0;
-      if (__any(brick_deep(e, lod))) {
+      if (__any(lod >= 12)) {
         float cx = (gx & 1) ? ax : bx, cy = (gy & 1) ? ay : by, cz = (gz & 1) ? az : bz;
         cx += ts11 * ((gx & 1) ? 1.0f : -1.0f);
         cy += ts11 * ((gy & 1) ? 1.0f : -1.0f);
@@ -1020,7 +1024,7 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   P.pix_scale = tanf(fov * 3.14159f / 180.0f) / (float)height;
   P.width = width; P.height = height; P.mode = mode;
   P.row_first = row_first; P.row_end = row_first + rows;
-  P.xcd_rows = 0;
+  P.xcd_rows = 0; P.lod_always = 0;
   // lookup helpers: the table-cell guess and the operand range of the fast LOD form
   for (int k = 0; k < 3; k++) P.lo[k] = center[k] - size;
   P.inv_cell = (float)kTabCells / (2.0f * size);
@@ -1045,6 +1049,12 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
       P.lod_first = 0xFFFFFFFFu;
       P.lod_span = 0u;
     }
+  }
+  {  // ray lengths run from kStartDist to the range exit (<= 10 + one step of at most `size`): is every pixel size ordinary?
+    const float lo_pix = 0.001f * P.pix_scale, hi_pix = (11.0f + size) * P.pix_scale;
+    uint32_t ul, uh;
+    memcpy(&ul, &lo_pix, 4); memcpy(&uh, &hi_pix, 4);
+    P.lod_always = (lo_pix > 0.0f && hi_pix >= lo_pix && ul - P.lod_first <= P.lod_span && uh - P.lod_first <= P.lod_span) ? 1 : 0;
   }
   // Acceleration data of the render.
   //  * Level grid: pools the library knows (anything it allocated: svoslam_pool_init / fusion / scene) carry a level-8

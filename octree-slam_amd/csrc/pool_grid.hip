@@ -179,48 +179,70 @@ __global__ __launch_bounds__(256) void pool_grid_build_kernel(const uint32_t *__
 }
 
 // ---- occupancy bricks (pool_grid.hpp) ----------------------------------------------------------------------------------
-// the 64 entries of the brick of level-9 node (x9, y9, z9), one per lane of ONE wavefront: lane = octant at level 10 (bits
-// 5..3) and at level 11 (bits 2..0) of the cell's path below the node
+// the 64 entries of the bricks of N level-9 nodes (x9, y9, z9)[k], one entry per lane of ONE wavefront and brick: lane =
+// octant at level 10 (bits 5..3) and at level 11 (bits 2..0) of the cell's path below the node.  A brick is a chain of
+// five dependent loads (grid entry, level-9 / -10 / -11 nodes, the level-12 tile); N chains are walked side by side.
+template <int N>
 __device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint2 *__restrict__ grid, uint16_t *__restrict__ bricks,
-                                     uint32_t *__restrict__ touched, uint32_t x9, uint32_t y9, uint32_t z9, unsigned lane) {
+                                     uint32_t *__restrict__ touched, const uint32_t (&x9)[N], const uint32_t (&y9)[N], const uint32_t (&z9)[N],
+                                     const bool (&live)[N], unsigned lane) {
   constexpr int G = kPoolGridLevel;
-  const uint2 g = grid[((z9 >> 1) << (2 * G)) | ((y9 >> 1) << G) | (x9 >> 1)];
-  if (!(g.x & kFlag)) return;  // the level-8 node has no children (cannot happen for a listed node: listed = below a key's path)
-  const uint2 w9 = nodes[(g.x & kMask) + ((x9 & 1u) | ((y9 & 1u) << 1) | ((z9 & 1u) << 2))];
-  uint32_t v = ((w9.y >> 24) >= 254u) ? 0x10u : 0u;
-  if (!(w9.x & kFlag)) v |= 1u;
-  else {
-    const uint2 w10 = nodes[(w9.x & kMask) + (lane >> 3)];
-    v |= ((w10.y >> 24) >= 254u) ? 0x20u : 0u;
-    if (!(w10.x & kFlag)) v |= 2u;
-    else {
-      const uint2 w11 = nodes[(w10.x & kMask) + (lane & 7u)];
-      v |= ((w11.y >> 24) >= 254u) ? 0x40u : 0u;
-      if (!(w11.x & kFlag)) v |= 3u;
-      else {
-        v |= 4u;
-        const uint2 *tile = nodes + (w11.x & kMask);  // the eight level-12 children
+  uint2 g[N], w9[N], w10[N], w11[N];
+  uint32_t v[N];
+  bool on[N], on10[N], on11[N], on12[N];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const uint2 c = tile[q];
-          v |= ((c.y >> 24) >= 254u) ? (0x100u << q) : 0u;
-          v |= (c.x & kFlag) ? 8u : 0u;
-        }
+  for (int k = 0; k < N; k++) g[k] = live[k] ? grid[((z9[k] >> 1) << (2 * G)) | ((y9[k] >> 1) << G) | (x9[k] >> 1)] : make_uint2(0u, 0u);
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    on[k] = (g[k].x & kFlag) != 0u;  // (no children: cannot happen for a listed node -- listed = below a key's path)
+    w9[k] = on[k] ? nodes[(g[k].x & kMask) + ((x9[k] & 1u) | ((y9[k] & 1u) << 1) | ((z9[k] & 1u) << 2))] : make_uint2(0u, 0u);
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    v[k] = ((w9[k].y >> 24) >= 254u) ? 0x10u : 0u;
+    on10[k] = on[k] && (w9[k].x & kFlag);
+    if (on[k] && !on10[k]) v[k] |= 1u;
+    w10[k] = on10[k] ? nodes[(w9[k].x & kMask) + (lane >> 3)] : make_uint2(0u, 0u);
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    v[k] |= ((w10[k].y >> 24) >= 254u) ? 0x20u : 0u;
+    on11[k] = on10[k] && (w10[k].x & kFlag);
+    if (on10[k] && !on11[k]) v[k] |= 2u;
+    w11[k] = on11[k] ? nodes[(w10[k].x & kMask) + (lane & 7u)] : make_uint2(0u, 0u);
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    v[k] |= ((w11[k].y >> 24) >= 254u) ? 0x40u : 0u;
+    on12[k] = on11[k] && (w11[k].x & kFlag);
+    if (on11[k] && !on12[k]) v[k] |= 3u;
+    if (on12[k]) {
+      v[k] |= 4u;
+      const uint2 *tile = nodes + (w11[k].x & kMask);  // the eight level-12 children
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint2 c = tile[q];
+        v[k] |= ((c.y >> 24) >= 254u) ? (0x100u << q) : 0u;
+        v[k] |= (c.x & kFlag) ? 8u : 0u;
       }
     }
   }
-  // cell of this lane: x bit 1 = level-10 octant bit, x bit 0 = level-11 octant bit (likewise y, z)
-  const uint32_t cx = (x9 << 2) | (((lane >> 3) & 1u) << 1) | (lane & 1u);
-  const uint32_t cy = (y9 << 2) | (((lane >> 4) & 1u) << 1) | ((lane >> 1) & 1u);
-  const uint32_t cz = (z9 << 2) | (((lane >> 5) & 1u) << 1) | ((lane >> 2) & 1u);
-  bricks[brick_entry_index(cx, cy, cz)] = (uint16_t)v;
-  if (lane == 0) {
-    const uint32_t grp = ((z9 >> 3) << (2 * kBrickGroupLevel)) | ((y9 >> 3) << kBrickGroupLevel) | (x9 >> 3);
-    if (!((touched[grp >> 5] >> (grp & 31u)) & 1u)) atomicOr(&touched[grp >> 5], 1u << (grp & 31u));
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    if (!on[k]) continue;
+    // cell of this lane: x bit 1 = level-10 octant bit, x bit 0 = level-11 octant bit (likewise y, z)
+    const uint32_t cx = (x9[k] << 2) | (((lane >> 3) & 1u) << 1) | (lane & 1u);
+    const uint32_t cy = (y9[k] << 2) | (((lane >> 4) & 1u) << 1) | ((lane >> 1) & 1u);
+    const uint32_t cz = (z9[k] << 2) | (((lane >> 5) & 1u) << 1) | ((lane >> 2) & 1u);
+    bricks[brick_entry_index(cx, cy, cz)] = (uint16_t)v[k];
+    if (lane == 0) {
+      const uint32_t grp = ((z9[k] >> 3) << (2 * kBrickGroupLevel)) | ((y9[k] >> 3) << kBrickGroupLevel) | (x9[k] >> 3);
+      if (!((touched[grp >> 5] >> (grp & 31u)) & 1u)) atomicOr(&touched[grp >> 5], 1u << (grp & 31u));
+    }
   }
 }
 
-constexpr int kBrickThreads = 256, kBrickBlocks = 2048;
+constexpr int kBrickThreads = 256, kBrickBlocks = 2048, kBrickChains = 4;
 // One wavefront per stale brick.  `all` (or a ring that was lapped): every level-8 cell with children instead -- a
 // wavefront reads 64 cells of the level grid and rebuilds the eight bricks of each one that has children.
 __global__ __launch_bounds__(kBrickThreads) void brick_rebuild_kernel(const uint32_t *__restrict__ octree, const uint2 *__restrict__ grid,
@@ -246,17 +268,28 @@ __global__ __launch_bounds__(kBrickThreads) void brick_rebuild_kernel(const uint
         const uint32_t hit = c0 + (uint32_t)(__ffsll((long long)m) - 1);
         m &= m - 1ull;
         const uint32_t x8 = hit & ((1u << G) - 1u), y8 = (hit >> G) & ((1u << G) - 1u), z8 = hit >> (2 * G);
-        for (uint32_t o = 0; o < 8u; o++)
-          brick_rebuild(nodes, grid, bricks, touched, (x8 << 1) | (o & 1u), (y8 << 1) | ((o >> 1) & 1u), (z8 << 1) | (o >> 2), lane);
+        uint32_t xs[8], ys[8], zs[8];
+        bool live[8];
+#pragma unroll
+        for (uint32_t o = 0; o < 8u; o++) { xs[o] = (x8 << 1) | (o & 1u); ys[o] = (y8 << 1) | ((o >> 1) & 1u); zs[o] = (z8 << 1) | (o >> 2); live[o] = true; }
+        brick_rebuild<8>(nodes, grid, bricks, touched, xs, ys, zs, live, lane);
       }
     }
   } else {
     for (int state = 0; state < 2; state++) {
       const uint32_t *dirty = state ? dirty_b : dirty_a;
       const uint32_t pending = state ? count_b - first_b : count_a - first_a, first = state ? first_b : first_a;
-      for (uint32_t i = blockIdx.x * kWaves + wave; i < pending; i += kBrickBlocks * kWaves) {
-        const uint32_t e = dirty[kBrickListOffset + ((first + i) & (uint32_t)(kBrickListCap - 1))];
-        brick_rebuild(nodes, grid, bricks, touched, e & 511u, (e >> 9) & 511u, e >> 18, lane);
+      // kBrickChains listed bricks per wavefront and round, their load chains side by side
+      for (uint32_t i0 = (blockIdx.x * kWaves + wave) * kBrickChains; i0 < pending; i0 += kBrickBlocks * kWaves * kBrickChains) {
+        uint32_t xs[kBrickChains], ys[kBrickChains], zs[kBrickChains];
+        bool live[kBrickChains];
+#pragma unroll
+        for (int k = 0; k < kBrickChains; k++) {
+          live[k] = i0 + k < pending;
+          const uint32_t e = live[k] ? dirty[kBrickListOffset + ((first + i0 + k) & (uint32_t)(kBrickListCap - 1))] : 0u;
+          xs[k] = e & 511u; ys[k] = (e >> 9) & 511u; zs[k] = e >> 18;
+        }
+        brick_rebuild<kBrickChains>(nodes, grid, bricks, touched, xs, ys, zs, live, lane);
       }
     }
   }
