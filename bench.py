@@ -340,9 +340,14 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src, "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms": ms, "launches_per_frame": launches_per_frame, "limiter": note}
 
-    roofs = [roof("march", "cone_trace_kernel", march_alg, kern_ms, 1,
-                  "dependent chain of the longest rays (~1.0 us per march step on the critical path; the walk is L2-resident: "
-                  "counter traffic is a few percent of the algorithmic bytes), not HBM bandwidth")]
+    # which march runs: pools fused to depth <= 12 are marched over occupancy bricks in reference mode (csrc/pool_grid.hpp)
+    bricks = max_depth <= 12 and args.render_mode == "reference" and os.environ.get("SVOSLAM_MARCH_BRICKS") != "0"
+    roofs = [roof("march", "cone_trace_brick_kernel" if bricks else "cone_trace_kernel", march_alg, kern_ms, 1,
+                  ("instruction issue: a step is ONE memory round trip (brick entry + level-grid entry requested together, mostly L1 / L2 "
+                   "hits: counter traffic is a few percent of the algorithmic bytes) and ~160 instructions; a lone wavefront of the tail "
+                   "issues them in ~0.5 us, the full chip is VALU-bound (profiles/r03_brick_march_anatomy.txt); not HBM bandwidth") if bricks else
+                  ("dependent chain of the longest rays (~1.0 us per march step on the critical path; the walk is L2-resident: "
+                   "counter traffic is a few percent of the algorithmic bytes), not HBM bandwidth"))]
     roofs[0].update({"steps_per_launch": steps / marches, "levels_per_launch": levels / marches, "timed": "live, timed region"})
     if trk_ms:
         roofs.append(roof("tracker", trk_kernel, icp_alg, trk_ms, 1 if one_launch else 38,
@@ -435,7 +440,10 @@ def main():
                                             "it gives 1.45x / 2.25x / 3.0x of the single-GPU rate for N = 2 / 4 / 8, against < 1x for the row-band scheme "
                                             "'allreduce' = SURVEY 8e with sorted-key all-gather + merge (profiles/r03_bench_cfg3_emulated_*.json, "
                                             "r03_bench_cfg3_forced_dist_*.json); UNMEASURED on multi-GPU hardware)" % args.exchange),
-                       "overlap": "none" if args.no_overlap else "4 HIP streams: maps(k+2) | ICP(k+1) | back-project+sort+plan(k+1) | commit+raycast(k)",
+                       "overlap": "none" if args.no_overlap else
+                                  ("5 HIP streams: maps(k+2) | ICP(k+1) | back-project+sort+plan(k+1) | deferred commit(k+1) beside | apply+bricks+raycast(k)"
+                                   if width * height <= 400000 and os.environ.get("SVOSLAM_RUNNER_DEFERRED") != "0" and world == 1 and emu is None and not force_dist
+                                   else "4 HIP streams: maps(k+2) | ICP(k+1) | back-project+sort+plan(k+1) | commit+raycast(k)"),
                        "frames_in_map_at_end": total, "frames_fused_untimed_before_warmup": pre, "frames_input": "pinned host memory, uploaded inside the timed region" if args.include_h2d else "resident in HBM",
                        "raycast_views": "ground-truth sensor poses (the reference renders from a free GLFW camera)",
                        "pool_nodes_end": P.pool.size, "mrays_per_s": width * rows / (kern_ms * 1e-3) / 1e6,

@@ -128,6 +128,23 @@ PY
 done
 
 if [ -z "$QUICK" ]; then
+echo "== A/B records of the round's switches (same box): occupancy bricks, deferred commits, tile order of the brick march"
+SVOSLAM_MARCH_BRICKS=0 python $R/bench.py --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_ab_bricks_off.json
+SVOSLAM_RUNNER_DEFERRED=0 python $R/bench.py --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_ab_inplace_commits.json
+SVOSLAM_MARCH_BRICKS=0 SVOSLAM_RUNNER_DEFERRED=0 python $R/bench.py --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_ab_round2_march_and_schedule.json
+SVOSLAM_MARCH_XCD=0 python $R/bench.py --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_ab_march_xcd_regions.json
+for f in ${P}_bench_cfg3_ab_*.json; do python3 -c "import json,sys,os; d=json.load(open('$f')); print('%-60s %8.1f fps  march %.3f ms' % (os.path.basename('$f'), d['value'], d['roofline_stages'][0]['kernel_ms']))"; done
+echo "== brick march anatomy (diag variant of the library: -DSVO_BRICK_DIAG, built by tools/prof/build_diag_variant.sh)"
+if [ -f $R/octree-slam_amd/_variants/libsvoslam_hip_diag.so ]; then
+  cp $R/octree-slam_amd/libsvoslam_hip.so /tmp/base.so
+  cp $R/octree-slam_amd/_variants/libsvoslam_hip_diag.so $R/octree-slam_amd/libsvoslam_hip.so
+  { echo "# tools/prof/band_diag.py 300 with the -DSVO_BRICK_DIAG library: cycles (clock64) per wavefront-step of cone_trace_brick_kernel on the 300-frame cfg3 map,"
+    echo "# before the entries are needed / waiting for them (forced s_waitcnt) / after; 'full' = whole image (the waits of a full chip are other wavefronts'"
+    echo "# issue slots, and the per-lane diagnostic atomics), 'band N' = rows N..N+15 alone (a lone wavefront per SIMD: the tail's regime)"
+    python $R/tools/prof/band_diag.py 300 2>&1 | grep -v amdgpu.ids; } > ${P}_brick_march_anatomy.txt
+  cp /tmp/base.so $R/octree-slam_amd/libsvoslam_hip.so
+  tail -9 ${P}_brick_march_anatomy.txt
+fi
 echo "== march anatomy, scheduler timeline"
 python $R/tools/prof/ray_anatomy.py 300 2>&1 | grep -v amdgpu.ids > ${P}_ray_anatomy_cfg3_300frames.txt; tail -3 ${P}_ray_anatomy_cfg3_300frames.txt
 python $R/tools/prof/runner_timeline.py 2>&1 | grep -v amdgpu.ids > ${P}_runner_timeline_cfg3.txt; tail -4 ${P}_runner_timeline_cfg3.txt
