@@ -261,6 +261,11 @@ __global__ __launch_bounds__(kBrickThreads) void brick_rebuild_kernel(const uint
   if (all || count_a - first_a > (uint32_t)kBrickListCap || count_b - first_b > (uint32_t)kBrickListCap) {
     constexpr int G = kPoolGridLevel;
     constexpr uint32_t kCells = 1u << (3 * G);
+    // everything listed so far is served by this pass: no brick is "in the ring" any more
+    for (uint32_t w = blockIdx.x * kBrickThreads + threadIdx.x; w < (uint32_t)kBrickBitsWords; w += kBrickBlocks * kBrickThreads) {
+      if (dirty_a) dirty_a[kBrickBitsOffset + w] = 0u;
+      if (dirty_b) dirty_b[kBrickBitsOffset + w] = 0u;
+    }
     for (uint32_t c0 = (blockIdx.x * kWaves + wave) * 64u; c0 < kCells; c0 += kBrickBlocks * kWaves * 64u) {
       const uint32_t cell = c0 + lane;
       unsigned long long m = __ballot((grid[cell].x & kFlag) != 0u);
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_rebuild_kernel(const uint
     }
   } else {
     for (int state = 0; state < 2; state++) {
-      const uint32_t *dirty = state ? dirty_b : dirty_a;
+      uint32_t *dirty = state ? dirty_b : dirty_a;
       const uint32_t pending = state ? count_b - first_b : count_a - first_a, first = state ? first_b : first_a;
       // kBrickChains listed bricks per wavefront and round, their load chains side by side
       for (uint32_t i0 = (blockIdx.x * kWaves + wave) * kBrickChains; i0 < pending; i0 += kBrickBlocks * kWaves * kBrickChains) {
@@ -288,6 +293,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_rebuild_kernel(const uint
           live[k] = i0 + k < pending;
           const uint32_t e = live[k] ? dirty[kBrickListOffset + ((first + i0 + k) & (uint32_t)(kBrickListCap - 1))] : 0u;
           xs[k] = e & 511u; ys[k] = (e >> 9) & 511u; zs[k] = e >> 18;
+          if (live[k] && lane == 0) atomicAnd(&dirty[kBrickBitsOffset + (e >> 5)], ~(1u << (e & 31u)));  // served: may be listed again
         }
         brick_rebuild<kBrickChains>(nodes, grid, bricks, touched, xs, ys, zs, live, lane);
       }
@@ -340,10 +346,13 @@ __global__ __launch_bounds__(kUpdateThreads) void pool_grid_update_kernel(const 
       const uint2 fresh = grid_entry(nodes, xi, yi, zi);
       if (bricks_on && (fresh.x & kFlag) && !(grid[cell].x & kFlag)) {
         // the level-8 node has just been split: the bricks of its eight children say "ask the level grid" so far
-        const uint32_t pos = atomicAdd(&dirty[kBrickCountOffset], 8u);
-        for (uint32_t o = 0; o < 8u; o++)
-          dirty[kBrickListOffset + ((pos + o) & (uint32_t)(kBrickListCap - 1))] =
-              brick_list_entry((xi << 1) | (o & 1u), (yi << 1) | ((o >> 1) & 1u), (zi << 1) | (o >> 2));
+        for (uint32_t o = 0; o < 8u; o++) {
+          const uint32_t entry = brick_list_entry((xi << 1) | (o & 1u), (yi << 1) | ((o >> 1) & 1u), (zi << 1) | (o >> 2));
+          const uint32_t bit = 1u << (entry & 31u);
+          if (atomicOr(&dirty[kBrickBitsOffset + (entry >> 5)], bit) & bit) continue;  // (the commit listed it)
+          const uint32_t pos = atomicAdd(&dirty[kBrickCountOffset], 1u);
+          dirty[kBrickListOffset + (pos & (uint32_t)(kBrickListCap - 1))] = entry;
+        }
       }
       grid[cell] = fresh;
       if (c == 0) atomicAnd(&dirty[b >> 5], ~(1u << (b & 31u)));

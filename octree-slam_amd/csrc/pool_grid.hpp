@@ -95,7 +95,12 @@ constexpr int kPoolGridCountOffset = kPoolGridDirtyWords + kPoolGridBlocks;  // 
 constexpr int kBrickCountOffset = kPoolGridCountOffset + 4, kBrickConsumedOffset = kBrickCountOffset + 1, kBrickSeenOffset = kBrickCountOffset + 2;
 constexpr int kBrickListOffset = kBrickCountOffset + 4;
 constexpr int kBrickListCap = 1 << 20;  // more than this pending = "rebuild every brick" (a commit appends <= its distinct level-9 prefixes)
-constexpr int kPoolGridStateWords = kBrickListOffset + kBrickListCap;
+// ... and one bit per level-9 node: "in this state's ring" (set by whoever appends it, cleared by the rebuild that serves it), so
+// that a brick is listed ONCE however many commits touch it before the next render -- a rank of a frame-sharded session fuses
+// N frames per march, and the bricks of consecutive frames are mostly the same ones (16 MB per state)
+constexpr int kBrickBitsOffset = kBrickListOffset + kBrickListCap;
+constexpr int kBrickBitsWords = 1 << (3 * 9 - 5);
+constexpr int kPoolGridStateWords = kBrickBitsOffset + kBrickBitsWords;
 
 // ---- occupancy bricks (round 3; north_star's "4^3 bricks") -------------------------------------------------
 // In SVOSLAM_RENDER_REFERENCE mode a sample of the march needs two facts about the node the reference's walk ends on
@@ -195,9 +200,21 @@ __host__ __device__ inline unsigned long long brick_entry_index(uint32_t x, uint
 __host__ __device__ inline uint32_t brick_list_entry(uint32_t x9, uint32_t y9, uint32_t z9) { return (z9 << 18) | (y9 << 9) | x9; }
 
 // Called by ALL lanes of a wavefront (convergent): the lanes with `pred` append the level-9 prefix of their key (depth
-// >= 9 levels) to the stale-brick ring; one atomic per wavefront.  Lapping the consumer is allowed: more than the
-// capacity pending tells the refresh to rebuild every brick.
+// >= 9 levels) to the stale-brick ring unless it is in the ring already; one ring atomic per wavefront.  Lapping the
+// consumer is allowed: more than the capacity pending tells the refresh to rebuild every brick.
 __device__ inline void brick_mark(uint32_t *dirty, bool pred, unsigned long long key, int depth) {
+  uint32_t entry = 0;
+  if (pred) {
+    uint32_t x = 0, y = 0, z = 0;
+    for (int k = 1; k <= kBrickNodeLevel; k++) {
+      const uint32_t oct = (uint32_t)(key >> (3 * (depth - k))) & 7u;
+      x = (x << 1) | (oct & 1u); y = (y << 1) | ((oct >> 1) & 1u); z = (z << 1) | (oct >> 2);
+    }
+    entry = brick_list_entry(x, y, z);
+    // listed already (by an earlier commit, or by another run of this one that ends in the same node)?
+    const uint32_t bit = 1u << (entry & 31u);
+    pred = !(atomicOr(&dirty[kBrickBitsOffset + (entry >> 5)], bit) & bit);
+  }
   const unsigned long long m = __ballot(pred);
   if (!m) return;
   const unsigned lane = threadIdx.x & 63u;
@@ -207,12 +224,7 @@ __device__ inline void brick_mark(uint32_t *dirty, bool pred, unsigned long long
   base = (uint32_t)__shfl((int)base, leader);
   if (pred) {
     const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    uint32_t x = 0, y = 0, z = 0;
-    for (int k = 1; k <= kBrickNodeLevel; k++) {
-      const uint32_t oct = (uint32_t)(key >> (3 * (depth - k))) & 7u;
-      x = (x << 1) | (oct & 1u); y = (y << 1) | ((oct >> 1) & 1u); z = (z << 1) | (oct >> 2);
-    }
-    dirty[kBrickListOffset + (pos & (uint32_t)(kBrickListCap - 1))] = brick_list_entry(x, y, z);
+    dirty[kBrickListOffset + (pos & (uint32_t)(kBrickListCap - 1))] = entry;
   }
 }
 #endif
