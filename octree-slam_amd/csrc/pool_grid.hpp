@@ -199,33 +199,28 @@ __host__ __device__ inline unsigned long long brick_entry_index(uint32_t x, uint
 // list entry of the level-9 node (x9, y9, z9): 9 bits each
 __host__ __device__ inline uint32_t brick_list_entry(uint32_t x9, uint32_t y9, uint32_t z9) { return (z9 << 18) | (y9 << 9) | x9; }
 
-// Called by ALL lanes of a wavefront (convergent): the lanes with `pred` append the level-9 prefix of their key (depth
-// >= 9 levels) to the stale-brick ring unless it is in the ring already; one ring atomic per wavefront.  Lapping the
-// consumer is allowed: more than the capacity pending tells the refresh to rebuild every brick.
-__device__ inline void brick_mark(uint32_t *dirty, bool pred, unsigned long long key, int depth) {
-  uint32_t entry = 0;
-  if (pred) {
-    uint32_t x = 0, y = 0, z = 0;
-    for (int k = 1; k <= kBrickNodeLevel; k++) {
-      const uint32_t oct = (uint32_t)(key >> (3 * (depth - k))) & 7u;
-      x = (x << 1) | (oct & 1u); y = (y << 1) | ((oct >> 1) & 1u); z = (z << 1) | (oct >> 2);
-    }
-    entry = brick_list_entry(x, y, z);
-    // listed already (by an earlier commit, or by another run of this one that ends in the same node)?
-    const uint32_t bit = 1u << (entry & 31u);
-    pred = !(atomicOr(&dirty[kBrickBitsOffset + (entry >> 5)], bit) & bit);
+// Listing a stale brick, in the three steps the leaf kernel spreads over its barriers (one ring atomic per WORKGROUP: one per
+// wavefront -- 4800 same-address atomics with a return value per 640x480 commit -- cost the kernel 30 us):
+//  1. brick_mark_test: the lane's level-9 prefix (key of `depth` >= 9 levels) as a ring entry; true when this lane is the one
+//     that lists it (the brick was not in the ring: test-and-set of its bit);
+//  2. the workgroup counts its true lanes in LDS and reserves that many ring slots with ONE atomic (brick_ring_reserve);
+//  3. brick_ring_store: the lane's entry into its slot.  Lapping the consumer is allowed: more than the capacity pending tells
+//     the refresh to rebuild every brick.
+__device__ inline bool brick_mark_test(uint32_t *dirty, bool pred, unsigned long long key, int depth, uint32_t &entry) {
+  entry = 0;
+  if (!pred) return false;
+  uint32_t x = 0, y = 0, z = 0;
+  for (int k = 1; k <= kBrickNodeLevel; k++) {
+    const uint32_t oct = (uint32_t)(key >> (3 * (depth - k))) & 7u;
+    x = (x << 1) | (oct & 1u); y = (y << 1) | ((oct >> 1) & 1u); z = (z << 1) | (oct >> 2);
   }
-  const unsigned long long m = __ballot(pred);
-  if (!m) return;
-  const unsigned lane = threadIdx.x & 63u;
-  const int leader = __ffsll((long long)m) - 1;
-  uint32_t base = 0;
-  if ((int)lane == leader) base = atomicAdd(&dirty[kBrickCountOffset], (uint32_t)__popcll(m));
-  base = (uint32_t)__shfl((int)base, leader);
-  if (pred) {
-    const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    dirty[kBrickListOffset + (pos & (uint32_t)(kBrickListCap - 1))] = entry;
-  }
+  entry = brick_list_entry(x, y, z);
+  const uint32_t bit = 1u << (entry & 31u);
+  return !(atomicOr(&dirty[kBrickBitsOffset + (entry >> 5)], bit) & bit);
+}
+__device__ inline uint32_t brick_ring_reserve(uint32_t *dirty, uint32_t count) { return atomicAdd(&dirty[kBrickCountOffset], count); }
+__device__ inline void brick_ring_store(uint32_t *dirty, uint32_t pos, uint32_t entry) {
+  dirty[kBrickListOffset + (pos & (uint32_t)(kBrickListCap - 1))] = entry;
 }
 #endif
 

@@ -686,7 +686,11 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   // head of a run of keys sharing that prefix marks the block
   if (grid_dirty && head && c < kPoolGridBlockLevel) pool_grid_mark(grid_dirty, key, depth);
   // occupancy bricks: likewise everything below level 9 lies under the key's level-9 prefix; the first head of a run lists it
-  if (grid_dirty && depth >= kBrickNodeLevel) brick_mark(grid_dirty, head && c < kBrickNodeLevel, key, depth);
+  // (pool_grid.hpp: test-and-set here, the workgroup's ring slots behind the two barriers below, the store behind the walk)
+  __shared__ u32 brick_cnt, brick_base;
+  const bool bricks_on = grid_dirty != nullptr && depth >= kBrickNodeLevel;
+  u32 brick_entry = 0, brick_off = 0;
+  const bool brick_mine = bricks_on && brick_mark_test(grid_dirty, head && c < kBrickNodeLevel, key, depth, brick_entry);
   if (tid <= SVOSLAM_MAX_DEPTH) {
     last_owner[tid] = -1;
     if (tid >= 1 && tid < depth) {  // "no straddler" unless a lane says otherwise below
@@ -694,14 +698,24 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
       strad[2 * ((size_t)tid * num_tiles + bid) + 1] = 0u;
     }
   }
-  if (tid == 0) { next_pos = 0x7FFFFFFF; next_c = -1; min_c = 99; }  // no later head: every run ends with the array
+  if (tid == 0) { next_pos = 0x7FFFFFFF; next_c = -1; min_c = 99; brick_cnt = 0u; }  // no later head: every run ends with the array
   __syncthreads();
   if (head) {
     for (int d = c + 1; d < depth; d++) atomicMax(&last_owner[d], j);
     if (strad_bc) atomicMin(&min_c, c);
   }
   if (ltn != kNotHead) atomicMin(&next_pos, jn);
+  if (bricks_on) {
+    const unsigned long long bm = __ballot(brick_mine);
+    if (bm) {
+      const int leader = __ffsll((long long)bm) - 1;
+      u32 woff = 0;
+      if ((tid & 63) == leader) woff = atomicAdd(&brick_cnt, (u32)__popcll(bm));
+      brick_off = (u32)__shfl((int)woff, leader) + (u32)__popcll(bm & ((1ull << (tid & 63)) - 1ull));
+    }
+  }
   __syncthreads();
+  if (bricks_on && tid == 0 && brick_cnt) brick_base = brick_ring_reserve(grid_dirty, brick_cnt);
   if (next_pos == 0x7FFFFFFF) {  // no head in the next workgroup (all duplicates / invalid points): look further
     for (int nb = bid + 2; nb < num_tiles; nb++) {
       const int jj = nb * kFillThreads + tid;
@@ -819,6 +833,7 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   if (shadow && j < n) apply_nodes[(size_t)(depth - 1) * n + j] = head ? node_at[0] : kNoStraddler;
   FILL_STAMP(3)
   __syncthreads();
+  if (brick_mine) brick_ring_store(grid_dirty, brick_base + brick_off, brick_entry);
   FILL_STAMP(4)
 #pragma unroll
   for (int d = MAXD - 1; d >= 1; d--) {
