@@ -2,7 +2,8 @@
 csrc/cone_trace.hip cone_trace_brick_kernel) against the CPU oracle's coneTrace (cone_tracing_kernels.cu:53-146):
 images and step / level counters byte for byte while the map is fused incrementally (stale-brick ring), through alpha
 saturation (A >= 254: the bricks' retire bits), at LODs on both sides of the bricks' levels 9..12, after a reset, for
-pools deeper than the bricks describe, and -- in child processes -- with the ring lapped and the bricks switched off."""
+pools deeper than the bricks describe, and -- in child processes -- with sixty commits between renders (every brick
+listed once however often it is touched) and the bricks switched off."""
 import hashlib
 import json
 import os
@@ -113,10 +114,10 @@ def test_pool_deeper_than_the_bricks(env, oracle):
             render_check(pkg, torch, oracle, pool, opool, w, h, oracle.look_at(eye, tgt, (0, 1, 0)), center, edge, (depth, eye))
 
 
-def test_bricks_ring_lapped_and_bricks_off_in_child_processes():
-    """60 fusions of 320x240 frames without a render in between append more stale-brick entries than the ring holds (the
-    refresh must rebuild every brick), then renders interleave with further fusions; the same with the bricks switched off
-    (the tree march of round 2) and with in-place commits: identical images, counters and pools"""
+def test_bricks_many_commits_between_renders_and_bricks_off_in_child_processes():
+    """60 fusions of 320x240 frames without a render in between (the stale-brick ring lists a brick once, its bit keeps
+    later commits from listing it again until a refresh has served it), then renders interleave with further fusions;
+    the same with the bricks switched off (the tree march of round 2): identical images, counters and pools"""
     code = r'''
 import sys, json, hashlib, importlib, os
 sys.path.insert(0, %r)
