@@ -679,6 +679,9 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
   constexpr int LDSD = 11, GRID = kPoolGridLevel;
   constexpr int kLdsStride = lds_stride(LDSD);
   constexpr int kCells = lds_cells(LDSD);
+#ifdef SVO_BRICK_PRIO
+  __builtin_amdgcn_s_setprio(SVO_BRICK_PRIO);
+#endif
 #ifdef SVO_BRICK_DIAG
   const long long c_entry = clock64();
 #endif

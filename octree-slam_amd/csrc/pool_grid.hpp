@@ -56,6 +56,14 @@ struct PoolAccel {
   uint32_t *d_brick_touched = nullptr;  // [kBrickGroupWords]
   bool bricks_valid = false;
   bool bricks_failed = false;           // the field could not be allocated: this pool is marched through the tree
+  // SVOSLAM_BRICK_ASYNC=1 (opt-in; measured slower, see pool_accel_refresh): the rebuild of the stale bricks runs BESIDE the
+  // march: the refresh zeroes the listed bricks' lines on the render's stream (zero = "ask the level grid", which says "has children": such a sample walks the tree -- correct, slower),
+  // hands the rebuild to this stream and lets the march start at once; a ray that reaches a brick before its rebuild does
+  // pays a tree walk for that sample.  ev_ready: grid updated + lines zeroed (the rebuild waits for it); ev_rebuilt: the
+  // rebuild's end (the next refresh, and everything that writes the pool, waits for it).
+  hipStream_t s_rebuild = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_rebuilt = nullptr;
+  bool rebuild_in_flight = false;
   // deepest commit so far.  Bricks describe levels 9..12: a sample whose LOD reaches below a level-12 node with children
   // walks the tree, so a pool fused deeper than 12 (1920x1080 at depth 14: LOD 13 at two metres) gets no bricks at all
   // -- its march is the tree march (measured: 0.67 ms against 0.90 with bricks that defer most of their samples)
@@ -71,6 +79,9 @@ void pool_accel_unregister(svoslam_pool *pool);
 void pool_accel_invalidate(svoslam_pool *pool, int depth = 0);  // depth > 0: of the fusion that changed the pool; < 0: the pool is empty again
 uint32_t *pool_accel_dirty_bitmap(svoslam_pool *pool, int parity, int commit_depth = 0);  // nullptr for memory that is not a registered pool;
 // commit_depth: the depth of the commit that is about to mark (the pool remembers the deepest one: see PoolAccel::max_depth)
+// `stream` is about to WRITE the pool's nodes (in-place commit, apply of a deferred one): order it behind a brick rebuild
+// that may still be reading them
+int pool_accel_order_writer(svoslam_pool *pool, hipStream_t stream);
 std::shared_ptr<PoolAccel> pool_accel_find(const uint32_t *d_data);  // the registered pool whose nodes start at d_data, or null;
 // the caller holds the entry for the duration of its enqueue (a pool_free / growth on another host thread cannot pull it away)
 void pool_accel_forget_stream(hipStream_t stream);       // the stream is about to be destroyed

@@ -1417,6 +1417,7 @@ static inline unsigned *small_strad_ticket(svoslam_workspace *ws, int slot) { re
 static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, const void *d_colors, bool vec4,
                       bool color_by_position, svoslam_fuse_stats *stats, hipStream_t stream) {
   pool_accel_invalidate(pool, depth);  // the blocking path does not track what it touches: the next render rebuilds the level grid
+  SVO_TRY(pool_accel_order_writer(pool, stream));  // (a brick rebuild of the previous render may still be reading the nodes)
   SVO_TRY(pool_sync(pool, stream));
   u64 *skey = nullptr; u32 *sidx = nullptr;
   SVO_TRY(radix_sort_pairs(ws, n, 3 * depth + 1, stream, &skey, &sidx));
@@ -1858,6 +1859,7 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
     ws->deferred_pool = pool; ws->deferred_n = n; ws->deferred_depth = depth; ws->deferred_tiles = fill_tiles;
   }
   SVO_TRY(tracker_make_room(pool));
+  if (!deferred) SVO_TRY(pool_accel_order_writer(pool, stream));  // (a deferred commit stores nothing a brick rebuild reads)
   u32 *grid_dirty = pool_accel_dirty_bitmap(pool, deferred ? (int)(epoch & 1u) : 0, depth);  // nullptr: not a registered pool
   auto enqueue = [&]() -> int {
     if (!early)
@@ -1929,6 +1931,7 @@ int svo_fuse_apply(svoslam_workspace *ws, svoslam_pool *pool, hipStream_t stream
   unsigned long long *shadow = nullptr;
   u32 epoch = 0;
   SVO_TRY(pool_shadow_current(pool, &shadow, &epoch));
+  SVO_TRY(pool_accel_order_writer(pool, stream));
   const long long slots = (long long)n * depth;
   int blocks = (int)cdiv(slots, 256 * 4);
   if (blocks > 4096) blocks = 4096;
