@@ -1,4 +1,5 @@
 // pool_grid.hip -- see pool_grid.hpp
+#include <cstdio>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -246,6 +247,13 @@ __device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint
     const uint32_t cx = (x9[k] << 2) | (((lane >> 3) & 1u) << 1) | (lane & 1u);
     const uint32_t cy = (y9[k] << 2) | (((lane >> 4) & 1u) << 1) | ((lane >> 1) & 1u);
     const uint32_t cz = (z9[k] << 2) | (((lane >> 5) & 1u) << 1) | ((lane >> 2) & 1u);
+#ifdef SVO_BRICK_DIAG
+    {  // how many rebuilt bricks actually change (diagnostic build)
+      const bool diff = bricks[brick_entry_index(cx, cy, cz)] != (uint16_t)v[k];
+      const unsigned long long dm = __ballot(diff);
+      if (lane == 0) { atomicAdd(&touched[kBrickGroupWords], 1u); if (dm) atomicAdd(&touched[kBrickGroupWords + 1], 1u); atomicAdd(&touched[kBrickGroupWords + 2], (uint32_t)__popcll(dm)); }
+    }
+#endif
     bricks[brick_entry_index(cx, cy, cz)] = (uint16_t)v[k];
     if (lane == 0) {
       const uint32_t grp = ((z9[k] >> 3) << (2 * kBrickGroupLevel)) | ((y9[k] >> 3) << kBrickGroupLevel) | (x9[k] >> 3);
@@ -404,12 +412,18 @@ static bool bricks_enabled() {
   return on;
 }
 
+// deepest fusion a pool may have seen and still be marched over bricks (PoolAccel::max_depth); SVOSLAM_BRICK_MAX_DEPTH overrides
+static int brick_max_depth() {
+  static const int d = [] { const char *e = getenv("SVOSLAM_BRICK_MAX_DEPTH"); return e ? atoi(e) : 12; }();
+  return d;
+}
+
 static void ensure_bricks(PoolAccel *pa, hipStream_t stream) {
   if (pa->bricks || pa->bricks_failed) return;
   void *field = nullptr, *touched = nullptr;
-  if (hipMalloc(&field, kBrickFieldBytes) != hipSuccess || hipMalloc(&touched, kBrickGroupWords * 4) != hipSuccess ||
+  if (hipMalloc(&field, kBrickFieldBytes) != hipSuccess || hipMalloc(&touched, (kBrickGroupWords + 8) * 4) != hipSuccess ||
       hipMemsetAsync(field, 0, kBrickFieldBytes, stream) != hipSuccess ||
-      hipMemsetAsync(touched, 0, kBrickGroupWords * 4, stream) != hipSuccess) {
+      hipMemsetAsync(touched, 0, (kBrickGroupWords + 8) * 4, stream) != hipSuccess) {
     (void)hipGetLastError();  // no room for the field on this device: the pool is marched through the tree
     if (field) (void)hipFree(field);
     if (touched) (void)hipFree(touched);
@@ -443,7 +457,7 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
   pa->last_stream = stream;
   // a rebuild handed to the pool's own stream by the previous refresh: this refresh (its ring marks, the grid it reads) comes after it
   if (pa->rebuild_in_flight) SVO_HIP(hipStreamWaitEvent(stream, pa->ev_rebuilt, 0));
-  if (want_bricks && bricks_enabled() && pa->max_depth <= 12) ensure_bricks(pa, stream);  // (behind the ordering above: the first fill runs on `stream`)
+  if (want_bricks && bricks_enabled() && pa->max_depth <= brick_max_depth()) ensure_bricks(pa, stream);  // (behind the ordering above: the first fill runs on `stream`)
   const bool fresh = !pa->valid;
   pa->valid = true;
   uint32_t *serve[2] = {nullptr, nullptr};  // the dirty states this render consumes
@@ -482,10 +496,22 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
       pa->rebuild_in_flight = true;
     }
     pa->bricks_valid = true;
+#ifdef SVO_BRICK_DIAG
+    {
+      static int calls = 0;
+      if (++calls % 50 == 0) {
+        uint32_t c[3];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(c, pa->d_brick_touched + kBrickGroupWords, 12, hipMemcpyDeviceToHost);
+        fprintf(stderr, "brick diag after %d refreshes: rebuilt %u bricks, %u of them changed, %u entries changed\n", calls, c[0], c[1], c[2]);
+        (void)hipMemset(pa->d_brick_touched + kBrickGroupWords, 0, 12);
+      }
+    }
+#endif
   }
   SVO_LAUNCH_CHECK();
   *d_grid = grid;
-  if (d_bricks) *d_bricks = pa->max_depth <= 12 ? pa->bricks : nullptr;
+  if (d_bricks) *d_bricks = pa->max_depth <= brick_max_depth() ? pa->bricks : nullptr;
   return SVOSLAM_OK;
 }
 

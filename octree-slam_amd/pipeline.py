@@ -93,19 +93,61 @@ class DistContext:
         # (csrc/mailbox.hip): a rank stores its record straight into every peer's inbox and polls its own -- no host-issued
         # collective, no ~25 us of RCCL latency per 216 bytes.  SVOSLAM_MAILBOX=0: torch.distributed for everything (the
         # required baseline: ncclAllReduce / ncclAllGather).  The inbox handles travel once, through the process group.
+        # The mailbox has only ever run between processes on ONE device (no multi-GPU node was available to this build): its
+        # set-up is therefore guarded -- every rank reports whether it could map its peers' inboxes, a first all-gather of
+        # rank-stamped records is checked against the collective's, and unless EVERY rank succeeded the session falls back
+        # to torch.distributed for these records too (a note on stderr says so).
         self.mailbox = None
         if self.enabled and torch.cuda.is_available() and os.environ.get("SVOSLAM_MAILBOX", "1") != "0":
+            import sys
             import torch.distributed as dist
-            mb = pkg.Mailbox(self.rank, self.world)
-            mine = torch.from_numpy(mb.handle())
             backend = dist.get_backend(self.group)
-            if backend == "nccl":
-                mine = mine.cuda()
-            allh = torch.empty((self.world, 64), dtype=torch.uint8, device=mine.device)
+            dev = "cuda" if backend == "nccl" else "cpu"
+
+            def all_agree(ok):
+                f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(f, op=dist.ReduceOp.MIN, group=self.group)
+                return int(f.item()) == 1
+
+            mb, why = None, ""
+            try:
+                mb = pkg.Mailbox(self.rank, self.world)
+                mine = torch.from_numpy(mb.handle()).to(dev)
+                have = True
+            except Exception as e:                      # (e.g. hipIpcGetMemHandle refused)
+                mine, have, why = torch.zeros(64, dtype=torch.uint8, device=dev), False, repr(e)
+            allh = torch.empty((self.world, 64), dtype=torch.uint8, device=dev)
             dist.all_gather_into_tensor(allh.view(-1), mine, group=self.group)
-            mb.connect(allh.cpu().numpy())
-            dist.barrier(group=self.group)       # every inbox is mapped before anyone posts
-            self.mailbox = mb
+            if all_agree(have):
+                try:
+                    mb.connect(allh.cpu().numpy())
+                    connected = True
+                except Exception as e:                  # (e.g. no peer access between the two devices)
+                    connected, why = False, repr(e)
+                if all_agree(connected):
+                    dist.barrier(group=self.group)   # every inbox is mapped before anyone posts
+                    try:                              # first use, checked against the collective
+                        rec = torch.full((1, pkg.DELTA_FLOATS), float(self.rank + 1), dtype=torch.float32, device="cuda")
+                        got = torch.zeros((self.world, 1, pkg.DELTA_FLOATS), dtype=torch.float32, device="cuda")
+                        mb.all_gather(rec, got)
+                        torch.cuda.synchronize()
+                        want = torch.arange(1, self.world + 1, dtype=torch.float32, device="cuda").view(-1, 1, 1).expand_as(got)
+                        good = bool(torch.equal(got, want)) and not mb.failed()
+                    except Exception as e:
+                        good, why = False, repr(e)
+                    if all_agree(good):
+                        self.mailbox = mb
+                    else:
+                        why = why or "first all-gather through the mailbox differs from the expected records"
+            if self.mailbox is None:
+                if self.rank == 0:
+                    print("svoslam: peer-to-peer mailbox unavailable (%s): small records go through torch.distributed" % (why or "a peer failed"),
+                          file=sys.stderr, flush=True)
+                if mb is not None:
+                    try:
+                        mb.close()
+                    except Exception:
+                        pass
 
     @property
     def enabled(self):

@@ -9,7 +9,7 @@ synth = importlib.import_module("octree_slam_amd.synth")
 pl = importlib.import_module("octree_slam_amd.pipeline")
 W, H, D, edge = 640, 480, 12, 4.096
 if os.environ.get("DIAG_CFG4"):
-    W, H, D = 1920, 1080, 14
+    W, H, D, edge = 1920, 1080, 14, 8.192
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 depth, rgb = synth.render_stream(K, W, H, device="cuda")
 views = [pl.ground_truth_view(k, synth) for k in range(K)]
