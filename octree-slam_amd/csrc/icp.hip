@@ -56,7 +56,7 @@ constexpr int kMaxIcpBlocks = SVO_ICP_BLOCKS;
 // (DPP) and across the 8 wavefronts through a 1.7 KB LDS array.  (Earlier forms: 27 x 6 ds_bpermute
 // shuffles per lane were LDS-issue bound; a [27][512] LDS transpose was fast but its 108 KB kept the
 // kernel off every CU that still held raycast workgroups with their 48 KB tables.)
-template <bool WORK>
+template <bool WORK, bool COHERENT = false>
 __device__ inline void accumulate_block(const float *__restrict__ last_v, const float *__restrict__ last_n,
                                         const float *cur_v, const float *cur_n, int first, int end,
                                         const CamState *state, int flags, int chain_len, double *__restrict__ partial,
@@ -120,7 +120,10 @@ __device__ inline void accumulate_block(const float *__restrict__ last_v, const 
     double v = 0.0;
 #pragma unroll
     for (int w = 0; w < kIcpWaves; w++) v += wsum[w][threadIdx.x];
-    partial[(size_t)blockIdx.x * 27 + threadIdx.x] = v;
+    // COHERENT: the rows are summed by the LAST workgroup of this very launch (icp_accumulate_work_solve_kernel): written
+    // through to where another XCD's CU will find them
+    if (COHERENT) __hip_atomic_store(&partial[(size_t)blockIdx.x * 27 + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else partial[(size_t)blockIdx.x * 27 + threadIdx.x] = v;
   }
 }
 
@@ -452,6 +455,53 @@ __global__ __launch_bounds__(kReduceThreads) void cam_reduce_solve_kernel(CamSta
   iteration_tail_wave(st, totals, slot, flags, tail_sm, pre, partial2 ? totals2 : nullptr);
 }
 
+// The launch chain's iteration in ONE launch (round 3): accumulate over work maps, and the workgroup that finishes LAST sums
+// the rows, solves and composes (what cam_reduce_solve_kernel does in a launch of its own: 14 us + a launch boundary, fifteen
+// times per 1920x1080 frame).  Hand-off as in mip_straddle2_kernel (cdna_hip_programming.md Guideline 16): rows stored
+// write-through at agent scope, every wave drains, one lane takes the ticket; the last arriver acquires and reads the rows with
+// agent-scope loads.  CamState is read by every workgroup at its start and written by the tail only after all of them have
+// taken their ticket; the next launch sees it behind the kernel boundary.  Same sums (integer-valued, order-free), same tail.
+__global__ __launch_bounds__(kIcpThreads) void icp_accumulate_work_solve_kernel(
+    const float *__restrict__ last_v, const float *__restrict__ last_n, const float *cur_v, const float *cur_n, int first, int end,
+    CamState *st, int flags, int chain_len, int chain_first, float *work_v, float *work_n, double *partial, int slot,
+    unsigned *__restrict__ ticket) {
+  SVO_HIGH_PRIO();
+  __shared__ double wsum[kIcpWaves][27];
+  __shared__ float chain_s[(kMaxChain + 1) * 16];
+  __shared__ double red[kIcpThreads / 32][27];
+  __shared__ double totals[27];
+  __shared__ float tail_sm[kTailScratch];
+  __shared__ int is_last;
+  accumulate_block<true, true>(last_v, last_n, cur_v, cur_n, first, end, st, flags, chain_len, partial, wsum, chain_s, chain_first, work_v, work_n);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // this workgroup's row (and its work-map stores) have left the CU
+  if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+  __syncthreads();
+  if (!is_last) return;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  }
+  __syncthreads();
+  const TailPrefetch pre = tail_prefetch(st, flags);  // written by the previous launch
+  {  // reduce_rows() with agent-scope loads
+    const int rows = (int)gridDim.x, col = threadIdx.x & 31, grp = threadIdx.x >> 5, ngrp = kIcpThreads >> 5;
+    double sacc = 0.0;
+    if (col < 27)
+      for (int r = grp; r < rows; r += ngrp) sacc += __hip_atomic_load(&partial[(size_t)r * 27 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (col < 27) red[grp][col] = sacc;
+    __syncthreads();
+    if (threadIdx.x < 27) {
+      double t = 0.0;
+      for (int g = 0; g < ngrp; g++) t += red[g][threadIdx.x];
+      totals[threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x >= 64) return;  // the tail runs on the first wavefront
+  iteration_tail_wave(st, totals, slot, flags, tail_sm, pre, nullptr);
+}
+
 // multi-GPU iteration tail: acc[] holds the all-reduced sums
 __global__ void cam_solve_kernel(CamState *st, double *acc, int slot, int flags) {
   SVO_HIGH_PRIO();
@@ -549,6 +599,7 @@ struct svoslam_camera {
   svoslam::TrackSync *d_sync = nullptr;
   double *d_rows = nullptr;
   unsigned *d_tickets = nullptr;
+  unsigned *d_chain_ticket = nullptr;  // arrival count of icp_accumulate_work_solve_kernel (zero between launches)
   hipStream_t cap_stream = nullptr;  // stream whose resident-workgroup capacity is cached below
   int capacity = 0;
   bool delta_fed = false;  // poses come from camera_apply_delta: there are no maps of the previous frame to track against
@@ -581,6 +632,7 @@ int camera_create(svoslam_camera **out, int w, int h, float fx, float fy) {
   SVO_HIP(hipMalloc((void **)&c->d_partial, (size_t)kMaxIcpBlocks * 27 * sizeof(double)));
   SVO_HIP(hipMalloc((void **)&c->d_sync, sizeof(TrackSync)));
   SVO_HIP(hipMalloc((void **)&c->d_tickets, track_persistent_ticket_bytes()));
+  SVO_HIP(hipMalloc((void **)&c->d_chain_ticket, 64));
   SVO_HIP(hipMalloc((void **)&c->d_rows, (size_t)(kTrkMaxWorkers + 1) * 27 * sizeof(double)));
   c->d_acc = c->d_state->acc;
   const int rc = camera_reset(c);
@@ -604,6 +656,7 @@ int camera_reset(svoslam_camera *c) {
   SVO_HIP(hipMemcpy(c->d_state, &init, sizeof(init), hipMemcpyHostToDevice));
   SVO_HIP(memset_sync(c->d_sync, 0, sizeof(TrackSync)));
   SVO_HIP(memset_sync(c->d_tickets, 0, track_persistent_ticket_bytes()));
+  SVO_HIP(memset_sync(c->d_chain_ticket, 0, 64));
   c->have_stamp = false; c->latest_stamp = 0;
   c->prepared = 0; c->tracked = 0;
   c->frame_has_icp = false;
@@ -633,6 +686,7 @@ int camera_destroy(svoslam_camera *c) {
   if (c->d_partial2) (void)hipFree(c->d_partial2);
   if (c->d_sync) (void)hipFree(c->d_sync);
   if (c->d_tickets) (void)hipFree(c->d_tickets);
+  if (c->d_chain_ticket) (void)hipFree(c->d_chain_ticket);
   if (c->d_rows) (void)hipFree(c->d_rows);
   if (c->work_v) (void)hipFree(c->work_v);
   if (c->work_n) (void)hipFree(c->work_n);
@@ -850,6 +904,10 @@ int camera_track(svoslam_camera *c, hipStream_t s) {
     SVO_HIP(hipMalloc((void **)&c->work_v, n * 12));
     SVO_HIP(hipMalloc((void **)&c->work_n, n * 12));
   }
+  // SVOSLAM_TRACK_FUSED_TAIL=1: accumulate + reduce + solve in ONE launch per iteration (icp_accumulate_work_solve_kernel).  Built,
+  // bit-exact, and no better: cfg4 815-819 frames/s against 809-811 in the loop, and the tracker ALONE 0.666 ms against 0.620 --
+  // the last arriver's acquire + agent-scope row loads cost what the launch boundary did.  Opt-in.
+  static const bool fused_tail = [] { const char *e = getenv("SVOSLAM_TRACK_FUSED_TAIL"); return e && e[0] == '1'; }();
   GraphKey key;
   key.add((unsigned long long)(c->tracked % 3u)).add((unsigned long long)has_icp)
      .add((unsigned long long)c->band_first).add((unsigned long long)c->band_rows).add((unsigned long long)c->rgbd)
@@ -869,6 +927,12 @@ int camera_track(svoslam_camera *c, hipStream_t s) {
             // iteration it > 0 reads what iteration it - 1 stored (level start and chain[0 .. it - 1) applied) and applies
             // chain[it - 1]; the last iteration of a level stores nothing
             const bool store = it + 1 < kPyramidIters[level];
+            if (fused_tail && !c->rgbd) {  // accumulate + reduce + solve in one launch
+              icp_accumulate_work_solve_kernel<<<blocks, kIcpThreads, 0, s>>>(a.lv, a.ln, it ? c->work_v : a.cv, it ? c->work_n : a.cn, a.first, end,
+                                                                              c->d_state, flags, it, it, store ? c->work_v : nullptr,
+                                                                              store ? c->work_n : nullptr, c->d_partial, it, c->d_chain_ticket);
+              continue;
+            }
             icp_accumulate_work_kernel<<<blocks, kIcpThreads, 0, s>>>(a.lv, a.ln, it ? c->work_v : a.cv, it ? c->work_n : a.cn, a.first, end,
                                                                       c->d_state, flags, it, it, store ? c->work_v : nullptr,
                                                                       store ? c->work_n : nullptr, c->d_partial);
