@@ -670,7 +670,7 @@ __device__ __forceinline__ uint32_t walk_sample(const uint2 *__restrict__ nodes,
 // or deeper than a level-12 node with children, a sample whose table bracket is not confirmed -- and the LAST sample
 // of every ray (whose node's colour word forms the pixel, Q9) take walk_sample().  The rare cases sit behind
 // wavefront-uniform branches: the loop is bound by the instructions it issues (profiles/r03_brick_march_anatomy.txt).
-template <int THREADS>
+template <int THREADS, bool LOD_ALWAYS>  // LOD_ALWAYS: every pixel size this render can form is in the fast LOD form's range (checked by the host)
 __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
                                                                    const uint2 *__restrict__ grid, const uint16_t *__restrict__ bricks,
                                                                    const float *__restrict__ table, const float *__restrict__ alpha_lut_g,
@@ -742,8 +742,7 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
     // two exits a ray took is read off afterwards, and the last sample's node is looked up again for the pixel (once per ray).
     float tx = 0.0f, ty = 0.0f, tz = 0.0f;  // the sample of the current step (the last one, after the loop)
     int lod = 0;
-    bool retired = false;
-    const bool lod_always = P.lod_always != 0;  // (uniform) every pixel size this render can form is in the fast LOD form's range
+    uint32_t retired = 0;  // (an integer, not a bool: a loop-carried bool is a lane mask the compiler re-blends every iteration)
     uint32_t prev_gx = 0;  // the previous sample's grid word: its children flag = "this ray is among nodes"
     auto brick_entry = [&](uint32_t x, uint32_t y, uint32_t z) -> uint32_t {  // through the LDS spread tables
       const uint32_t d = spread[x] | spread[kCells + y] | spread[2 * kCells + z];
@@ -752,7 +751,7 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
     // the answers of a sample's two entries: `depth` / `retired` when one of them decides (return value); oct12 = the
     // sample's level-12 octant (read only when the brick's walk ends at level 12; 0 unless some lane's LOD reaches 12).
     // Written in integers: as booleans every condition is a 64-bit lane mask and the loop is bound by what it issues.
-    auto decode = [&](uint32_t e, uint2 gq, int lod_, uint32_t oct12, int &depth, bool &ret) -> bool {
+    auto decode = [&](uint32_t e, uint2 gq, int lod_, uint32_t oct12, int &depth, uint32_t &ret) -> bool {
       // the brick: the path stops at level st = 9 / 10 / 11, or goes on to level 12 (code 4); code 0 (no brick) gives st = 8
       // and never qualifies.  The walk ends at min(LOD, st); levels 9..11 carry their own bit (4..6), level 12 one per
       // octant (8..15).  An LOD beyond 12 over a level-12 node with children (bit 3) ends deeper: not the brick's to answer.
@@ -771,8 +770,7 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       const uint32_t top_g = gq.x < kFlag ? 127u : (uint32_t)GRID;   // the LODs it answers: depth_g .. top_g
       const bool by_grid = (uint32_t)lod_ - depth_g <= top_g - depth_g;
       depth = by_brick ? depth_b : (int)depth_g;
-      const uint32_t rbit = by_brick ? (e >> bit) & 1u : (uint32_t)(gq.y >= 0xFE000000u);
-      ret = rbit != 0u;
+      ret = by_brick ? (e >> bit) & 1u : (uint32_t)(gq.y >= 0xFE000000u);
       return by_brick || by_grid;
     };
 #ifdef SVO_BRICK_DIAG
@@ -798,7 +796,7 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       if (with_brick) e = brick_entry((uint32_t)gx, (uint32_t)gy, (uint32_t)gz);
       const uint32_t ub = f2bits(pix_size);
       lod = (P.size_exp - (int)(ub >> 23)) + ((ub & 0x7FFFFFu) < P.size_man ? 1 : 0);
-      const bool lod_ok = lod_always || ub - P.lod_first <= P.lod_span;
+      const bool lod_ok = LOD_ALWAYS || ub - P.lod_first <= P.lod_span;
       float inv_len = __builtin_amdgcn_rcpf(ray_len);
       inv_len = fmaf(fmaf(-ray_len, inv_len, 1.0f), inv_len, inv_len);
       // confirmation of the guessed ranks: S[g-1] < t <= S[g] on every axis
@@ -865,7 +863,7 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
           if (!decided2) {
             depth = lod;
             const uint32_t w = walk_sample<LDSD, GRID>(nodes, octree, grid, table, lds_tab, P, tx, ty, tz, xb, yb, zb, ok, depth);
-            retired = (w >> 24) >= 254u;  // == !((int)(A - 127u) < 127), :108-119 with value.w == 0
+            retired = (w >> 24) >= 254u ? 1u : 0u;  // == !((int)(A - 127u) < 127), :108-119 with value.w == 0
 #ifdef SVO_BRICK_DIAG
             diag[3]++;
 #endif
@@ -896,9 +894,10 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       asm volatile("" :: "v"(nlen));
       clk[2] += clock64() - c2;
 #endif
-      if (retired || my_steps >= (uint32_t)kMaxSteps) break;
+      // one exit: a retired ray, the range exit (:131), the step guard.  The advance is committed either way (the pixel is formed
+      // from tx, ty, tz and the LOD of the last sample; which exit it was is read off `retired` below)
       rx = nx; ry = ny; rz = nz; ray_len = nlen;
-      if (nlen > kMaxRange) break;
+      if (retired != 0u || nlen > kMaxRange || my_steps >= (uint32_t)kMaxSteps) break;
     }
 #ifdef SVO_BRICK_DIAG
     if (counters) {
@@ -921,8 +920,8 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       }
     }
 #endif
-    // the range exit (:131) leaves the advanced length behind; a retired ray (or the step guard) the last sample's, <= 10
-    const bool range_exit = ray_len > kMaxRange;
+    // the range exit (:131): a ray that did not retire on its last sample and whose advanced length passed the range
+    const bool range_exit = retired == 0u && ray_len > kMaxRange;
     // the pixel of the last sample, formed from an all-zero pos[index] (Q9): its node's colour word
     uint32_t w_last;
     {
@@ -1120,7 +1119,8 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
     P.xcd_rows = xcd_mode == 1;
     if (xcd_mode == 2 && P.xcd_w > 0) { P.xcd_w = 0; P.xcd_h = (int)cdiv(width, 32); blocks = cdiv(width, 32) * cdiv(rows, kTraceThreads / 32); }
     const dim3 grid(blocks);
-    cone_trace_brick_kernel<kTraceThreads><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps, slots);
+    if (P.lod_always) cone_trace_brick_kernel<kTraceThreads, true><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps, slots);
+    else cone_trace_brick_kernel<kTraceThreads, false><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps, slots);
   } else if (P.lds_depth == 11 && large) {
     const dim3 grid(xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads / 32)));
     if (carry) cone_trace_kernel<true, 11, kTraceThreads, kGridLevelLarge><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
