@@ -333,11 +333,13 @@ __device__ __forceinline__ void walk_shallow(const uint2 *__restrict__ nodes, ui
 }
 
 // ---- step / level counters ---------------------------------------------------------------------------------------------
-// Every wavefront adds its sums to one of kCountSlots slots (64 bytes apart), a one-workgroup launch behind the march folds
-// the slots into the caller's two counters and leaves them zero.  (One atomic pair per WORKGROUP on the caller's two words
-// was 16 200 same-address atomics for a 1920x1080 render: ~0.5 ms of L2 serialisation, more than the march itself.)
+// Every wavefront adds its sums to one of kCountSlots slots (64 bytes apart); the LAST workgroup of the launch to get here
+// (ticket in the word behind the slots) folds the slots into the caller's two counters and leaves them zero.  (One atomic pair
+// per WORKGROUP on the caller's two words was 16 200 same-address atomics for a 1920x1080 render: ~0.5 ms of L2 serialisation,
+// more than the march itself; a fold launch of its own behind the march cost the map stream 11 us per frame.)
 constexpr int kCountSlots = 1024, kCountSlotWords = 8;
-__device__ inline void count_steps(unsigned long long *__restrict__ slots, uint32_t my_steps, uint32_t my_levels, unsigned lane) {
+__device__ inline void count_steps(unsigned long long *__restrict__ slots, unsigned long long *__restrict__ counters, uint32_t my_steps,
+                                   uint32_t my_levels, unsigned lane) {
   unsigned long long s64 = my_steps, l64 = my_levels;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -346,29 +348,33 @@ __device__ inline void count_steps(unsigned long long *__restrict__ slots, uint3
   }
   if (lane == 0) {
     const unsigned slot = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (unsigned)(kCountSlots - 1);
-    atomicAdd(&slots[slot * kCountSlotWords], s64);
-    atomicAdd(&slots[slot * kCountSlotWords + 1], l64);
+    __hip_atomic_fetch_add(&slots[slot * kCountSlotWords], s64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&slots[slot * kCountSlotWords + 1], l64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-}
-__global__ __launch_bounds__(kCountSlots) void count_reduce_kernel(unsigned long long *__restrict__ slots, unsigned long long *__restrict__ counters) {
-  __shared__ unsigned long long part[kCountSlots / 64][2];
-  unsigned long long s64 = slots[threadIdx.x * kCountSlotWords], l64 = slots[threadIdx.x * kCountSlotWords + 1];
-  slots[threadIdx.x * kCountSlotWords] = 0ull; slots[threadIdx.x * kCountSlotWords + 1] = 0ull;
+  // hand-off (cdna_hip_programming.md Guideline 16): the adds have been performed at the L2 they share before the ticket is taken
+  __shared__ int count_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned *ticket = reinterpret_cast<unsigned *>(slots + (size_t)kCountSlots * kCountSlotWords);
+  if (threadIdx.x == 0) count_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+  __syncthreads();
+  if (!count_last) return;
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long a = 0, b = 0;
+  for (unsigned i = threadIdx.x; i < (unsigned)kCountSlots; i += blockDim.x) {  // (atomic exchanges: read at the L2, and zeroed)
+    a += __hip_atomic_exchange(&slots[i * kCountSlotWords], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b += __hip_atomic_exchange(&slots[i * kCountSlotWords + 1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    s64 += __shfl_down(s64, o);
-    l64 += __shfl_down(l64, o);
+    a += __shfl_down(a, o);
+    b += __shfl_down(b, o);
   }
-  if ((threadIdx.x & 63u) == 0) { part[threadIdx.x >> 6][0] = s64; part[threadIdx.x >> 6][1] = l64; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long a = 0, b = 0;
-    for (int w = 0; w < kCountSlots / 64; w++) { a += part[w][0]; b += part[w][1]; }
+  if (lane == 0 && (a | b)) {
     atomicAdd(&counters[0], a);
     atomicAdd(&counters[1], b);
   }
 }
-
 // CARRY = false: SVOSLAM_RENDER_REFERENCE.  The reference re-reads pos[index] every step and that
 // pixel stays 0 until the ray retires (Q9), so a sample's colour matters only on the step that
 // retires the ray: the march needs alpha alone and the colour is formed once, after the loop.
@@ -618,7 +624,7 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
     o.z = (unsigned char)((out >> 16) & 0xFF); o.w = (unsigned char)(out >> 24);
     pos[idx] = o;
   }
-  if (slots) count_steps(slots, my_steps, my_levels, lane);
+  if (slots) count_steps(slots, counters, my_steps, my_levels, lane);
 }
 
 
@@ -956,7 +962,7 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
     o.z = (unsigned char)((out >> 16) & 0xFF); o.w = (unsigned char)(out >> 24);
     pos[idx] = o;
   }
-  if (slots) count_steps(slots, my_steps, my_levels, lane);
+  if (slots) count_steps(slots, counters, my_steps, my_levels, lane);
 }
 
 // tile -> XCD mapping of a render of tiles_x x tiles_y workgroup tiles; returns the number of workgroups to launch
@@ -973,7 +979,7 @@ static unsigned xcd_mapping(TraceParams &P, int tiles_x, int tiles_y) {
 // ---- per-stream acceleration buffers ----
 struct StreamAccel {
   DeviceBuffer buf;
-  unsigned long long *count_slots = nullptr;  // [kCountSlots][kCountSlotWords], zero between renders (count_reduce_kernel)
+  unsigned long long *count_slots = nullptr;  // [kCountSlots][kCountSlotWords] + ticket, zero between renders (count_steps)
   // what the tables in `buf` were built for (they depend on the root cube only, not on the tree)
   bool tables_valid = false;
   const float *tables_at = nullptr;
@@ -1102,8 +1108,8 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   unsigned long long *slots = nullptr;
   if (d_steps) {
     if (!sa->count_slots) {
-      SVO_HIP(hipMalloc((void **)&sa->count_slots, (size_t)kCountSlots * kCountSlotWords * 8));
-      SVO_HIP(hipMemsetAsync(sa->count_slots, 0, (size_t)kCountSlots * kCountSlotWords * 8, stream));
+      SVO_HIP(hipMalloc((void **)&sa->count_slots, ((size_t)kCountSlots * kCountSlotWords + 8) * 8));  // (+ the ticket)
+      SVO_HIP(hipMemsetAsync(sa->count_slots, 0, ((size_t)kCountSlots * kCountSlotWords + 8) * 8, stream));
     }
     slots = sa->count_slots;
   }
@@ -1139,7 +1145,6 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
     else cone_trace_kernel<false, 12, kTraceThreads12, kGridLevelLarge><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
   }
   SVO_TRY(stage_event(kStageMarch, stream));
-  if (slots) count_reduce_kernel<<<1, kCountSlots, 0, stream>>>(slots, d_steps);
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
 }
