@@ -43,6 +43,7 @@ void pool_accel_register(svoslam_pool *pool) {
     it->second->valid = false;  // freshly initialised memory at a recycled address: whatever the grid holds is stale
     it->second->bricks_valid = false;
     it->second->max_depth = 0;
+    it->second->mip_consistent = true;
   }
 }
 
@@ -69,14 +70,17 @@ void pool_accel_unregister(svoslam_pool *pool) {
   g_accel.erase(it);  // (~PoolAccel releases the device buffers once no enqueue holds the entry)
 }
 
-void pool_accel_invalidate(svoslam_pool *pool, int depth) {
+void pool_accel_invalidate(svoslam_pool *pool, int depth, bool foreign_words) {
   if (!pool || !pool->d_data) return;
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_accel.find(pool->d_data);
   if (it == g_accel.end()) return;
   it->second->valid = false; it->second->bricks_valid = false;
-  if (depth < 0) it->second->max_depth = 0;
-  else if (depth > it->second->max_depth) it->second->max_depth = depth;
+  if (depth < 0) { it->second->max_depth = 0; it->second->mip_consistent = true; }  // an empty pool
+  else {
+    if (depth > it->second->max_depth) it->second->max_depth = depth;
+    if (foreign_words) it->second->mip_consistent = false;
+  }
 }
 
 static bool ensure_dirty_states(PoolAccel *pa) {
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void pool_grid_build_kernel(const uint32_t *__
 template <int N>
 __device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint2 *__restrict__ grid, uint16_t *__restrict__ bricks,
                                      uint32_t *__restrict__ touched, const uint32_t (&x9)[N], const uint32_t (&y9)[N], const uint32_t (&z9)[N],
-                                     const bool (&live)[N], unsigned lane) {
+                                     const bool (&live)[N], unsigned lane, bool trust_mip) {
   constexpr int G = kPoolGridLevel;
   uint2 g[N], w9[N], w10[N], w11[N];
   uint32_t v[N];
@@ -229,8 +233,16 @@ __device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint
     v[k] |= ((w11[k].y >> 24) >= 254u) ? 0x40u : 0u;
     on12[k] = on11[k] && (w11[k].x & kFlag);
     if (on11[k] && !on12[k]) v[k] |= 3u;
+#ifdef SVO_BRICK_DIAG
+    {  // level-11 nodes with children, and how many of them are saturated (would their level-12 tiles have to be read?)
+      const unsigned long long m12 = __ballot(on12[k]), msat = __ballot(on12[k] && (w11[k].y >> 24) >= 254u);
+      if (lane == 0) { atomicAdd(&touched[kBrickGroupWords + 3], (uint32_t)__popcll(m12)); atomicAdd(&touched[kBrickGroupWords + 4], (uint32_t)__popcll(msat)); }
+    }
+#endif
+    if (on12[k]) v[k] |= 4u;
+    // PoolAccel::mip_consistent: an unsaturated level-11 node has no saturated child; whether a child has children is left open
+    if (on12[k] && trust_mip && (w11[k].y >> 24) < 254u) { v[k] |= 8u; on12[k] = false; }
     if (on12[k]) {
-      v[k] |= 4u;
       const uint2 *tile = nodes + (w11[k].x & kMask);  // the eight level-12 children
 #pragma unroll
       for (int q = 0; q < 8; q++) {
@@ -267,7 +279,8 @@ constexpr int kBrickThreads = 256, kBrickBlocks = 2048, kBrickChains = 4;
 // wavefront reads 64 cells of the level grid and rebuilds the eight bricks of each one that has children.
 __global__ __launch_bounds__(kBrickThreads) void brick_rebuild_kernel(const uint32_t *__restrict__ octree, const uint2 *__restrict__ grid,
                                                                       uint16_t *__restrict__ bricks, uint32_t *__restrict__ touched,
-                                                                      uint32_t *__restrict__ dirty_a, uint32_t *__restrict__ dirty_b, int all) {
+                                                                      uint32_t *__restrict__ dirty_a, uint32_t *__restrict__ dirty_b, int all,
+                                                                      int trust_mip) {
   const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   constexpr unsigned kWaves = kBrickThreads / 64;
@@ -297,7 +310,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_rebuild_kernel(const uint
         bool live[8];
 #pragma unroll
         for (uint32_t o = 0; o < 8u; o++) { xs[o] = (x8 << 1) | (o & 1u); ys[o] = (y8 << 1) | ((o >> 1) & 1u); zs[o] = (z8 << 1) | (o >> 2); live[o] = true; }
-        brick_rebuild<8>(nodes, grid, bricks, touched, xs, ys, zs, live, lane);
+        brick_rebuild<8>(nodes, grid, bricks, touched, xs, ys, zs, live, lane, trust_mip != 0);
       }
     }
   } else {
@@ -315,7 +328,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_rebuild_kernel(const uint
           xs[k] = e & 511u; ys[k] = (e >> 9) & 511u; zs[k] = e >> 18;
           if (live[k] && lane == 0) atomicAnd(&dirty[kBrickBitsOffset + (e >> 5)], ~(1u << (e & 31u)));  // served: may be listed again
         }
-        brick_rebuild<kBrickChains>(nodes, grid, bricks, touched, xs, ys, zs, live, lane);
+        brick_rebuild<kBrickChains>(nodes, grid, bricks, touched, xs, ys, zs, live, lane, trust_mip != 0);
       }
     }
   }
@@ -475,13 +488,16 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
     pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1], pa->bricks && !bricks_all);
   }
   if (pa->bricks) {
+    // SVOSLAM_BRICK_TRUST_MIP=0: the rebuild reads every level-12 tile whatever the pool's history (A/B measurements)
+    static const bool trust_on = [] { const char *e = getenv("SVOSLAM_BRICK_TRUST_MIP"); return !(e && e[0] == '0'); }();
+    const int trust = trust_on && pa->mip_consistent ? 1 : 0;
     // SVOSLAM_BRICK_ASYNC=1: the rebuild beside the march (PoolAccel::s_rebuild).  Built, bit-exact, measured, and LOST: the rays
     // reach the surfaces before the rebuild does and pay tree walks in the rare-sample path -- march 0.325 -> 0.395 ms, cfg3 2140 ->
     // 1990 frames/s, the driver's 20 frames 1785 -> 1674 -- so the rebuild stays in line, 65 us on the map stream
     static const bool async = [] { const char *e = getenv("SVOSLAM_BRICK_ASYNC"); return e && e[0] == '1'; }();
     if (bricks_all || !async) {
       if (bricks_all) brick_clear_kernel<<<2048, 256, 0, stream>>>(pa->bricks, pa->d_brick_touched);
-      brick_rebuild_kernel<<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], bricks_all ? 1 : 0);
+      brick_rebuild_kernel<<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], bricks_all ? 1 : 0, trust);
     } else {
       if (!pa->s_rebuild) {
         SVO_HIP(hipStreamCreateWithFlags(&pa->s_rebuild, hipStreamNonBlocking));
@@ -491,7 +507,7 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
       brick_invalidate_kernel<<<kBrickBlocks, kBrickThreads, 0, stream>>>(pa->bricks, pa->d_brick_touched, serve[0], serve[1]);
       SVO_HIP(hipEventRecord(pa->ev_ready, stream));
       SVO_HIP(hipStreamWaitEvent(pa->s_rebuild, pa->ev_ready, 0));
-      brick_rebuild_kernel<<<kBrickBlocks, kBrickThreads, 0, pa->s_rebuild>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], 0);
+      brick_rebuild_kernel<<<kBrickBlocks, kBrickThreads, 0, pa->s_rebuild>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], 0, trust);
       SVO_HIP(hipEventRecord(pa->ev_rebuilt, pa->s_rebuild));
       pa->rebuild_in_flight = true;
     }
@@ -500,11 +516,12 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
     {
       static int calls = 0;
       if (++calls % 50 == 0) {
-        uint32_t c[3];
+        uint32_t c[5];
         (void)hipStreamSynchronize(stream);
-        (void)hipMemcpy(c, pa->d_brick_touched + kBrickGroupWords, 12, hipMemcpyDeviceToHost);
-        fprintf(stderr, "brick diag after %d refreshes: rebuilt %u bricks, %u of them changed, %u entries changed\n", calls, c[0], c[1], c[2]);
-        (void)hipMemset(pa->d_brick_touched + kBrickGroupWords, 0, 12);
+        (void)hipMemcpy(c, pa->d_brick_touched + kBrickGroupWords, 20, hipMemcpyDeviceToHost);
+        fprintf(stderr, "brick diag after %d refreshes: rebuilt %u bricks, %u of them changed, %u entries changed; %u level-11 nodes with children, %u of them saturated\n",
+                calls, c[0], c[1], c[2], c[3], c[4]);
+        (void)hipMemset(pa->d_brick_touched + kBrickGroupWords, 0, 20);
       }
     }
 #endif

@@ -64,6 +64,13 @@ struct PoolAccel {
   hipStream_t s_rebuild = nullptr;
   hipEvent_t ev_ready = nullptr, ev_rebuilt = nullptr;
   bool rebuild_in_flight = false;
+  // Every colour word of the pool was computed by this library's fusion from an empty pool (any path: blocking, phased,
+  // deferred): then a node with children carries the MAXIMUM of its children's alphas (averageChildren, svo.cu:384-447,
+  // re-run for every ancestor of a touched leaf), so a level-11 node with A < 254 has no saturated child and the brick
+  // rebuild need not read its level-12 tile (it then reports "a level-12 node may have children": an LOD beyond 12 walks the
+  // tree).  On the 300-frame cfg3 map that is every one of the 1.5 M tiles a refresh used to read (no 2 mm leaf collects
+  // its 127 observations).  Foreign words (set_nodes / load / copy / paging / touch) clear the flag until the next reset.
+  bool mip_consistent = true;
   // deepest commit so far.  Bricks describe levels 9..12: a sample whose LOD reaches below a level-12 node with children
   // walks the tree, so a pool fused deeper than 12 (1920x1080 at depth 14: LOD 13 at two metres) gets no bricks at all
   // -- its march is the tree march (measured: 0.67 ms against 0.90 with bricks that defer most of their samples)
@@ -76,7 +83,9 @@ struct PoolAccel {
 void pool_accel_register(svoslam_pool *pool);
 void pool_accel_rebind(const uint32_t *old_data, const uint32_t *new_data);  // the nodes moved to a larger allocation
 void pool_accel_unregister(svoslam_pool *pool);
-void pool_accel_invalidate(svoslam_pool *pool, int depth = 0);  // depth > 0: of the fusion that changed the pool; < 0: the pool is empty again
+// depth > 0: of the fusion that changed the pool; < 0: the pool is empty again.  foreign_words: the nodes now hold words this
+// library's fusion did not compute (set_nodes / load / copy / paging / svoslam_pool_touch): see PoolAccel::mip_consistent
+void pool_accel_invalidate(svoslam_pool *pool, int depth = 0, bool foreign_words = true);
 uint32_t *pool_accel_dirty_bitmap(svoslam_pool *pool, int parity, int commit_depth = 0);  // nullptr for memory that is not a registered pool;
 // commit_depth: the depth of the commit that is about to mark (the pool remembers the deepest one: see PoolAccel::max_depth)
 // `stream` is about to WRITE the pool's nodes (in-place commit, apply of a deferred one): order it behind a brick rebuild

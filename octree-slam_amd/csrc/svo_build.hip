@@ -1252,7 +1252,7 @@ int pool_expand(svoslam_pool *pool, float center[3], float *edge, const float to
   }
   reroot_kernel<<<1, 64, 0, stream>>>(pool->d_data, pool->d_size, pool->size, octant);
   SVO_LAUNCH_CHECK();
-  pool_accel_invalidate(pool);  // every cell of the level grid now lies one level deeper
+  pool_accel_invalidate(pool, 0, false);  // every cell of the level grid now lies one level deeper (the words are the same ones)
   SVO_HIP(hipStreamSynchronize(stream));
   pool->size += 8;
   for (int k = 0; k < 3; k++) center[k] = nc[k];
@@ -1416,7 +1416,7 @@ static inline unsigned *small_strad_ticket(svoslam_workspace *ws, int slot) { re
 // keys of the n inputs are in ws->keys_a
 static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, const void *d_colors, bool vec4,
                       bool color_by_position, svoslam_fuse_stats *stats, hipStream_t stream) {
-  pool_accel_invalidate(pool, depth);  // the blocking path does not track what it touches: the next render rebuilds the level grid
+  pool_accel_invalidate(pool, depth, false);  // the blocking path does not track what it touches: the next render rebuilds the level grid
   SVO_TRY(pool_accel_order_writer(pool, stream));  // (a brick rebuild of the previous render may still be reading the nodes)
   SVO_TRY(pool_sync(pool, stream));
   u64 *skey = nullptr; u32 *sidx = nullptr;
