@@ -99,6 +99,38 @@ def test_bricks_deferred_commits_and_reset(env, oracle):
         render_check(pkg, torch, oracle, pool, opool, w2, h2, oracle.look_at(eye, tgt, (0, 1, 0)), center, edge, ("after reset", eye))
 
 
+def test_foreign_words_are_not_trusted(env, oracle):
+    """the brick rebuild skips the level-12 tile of an unsaturated level-11 node only for pools this library fused from empty
+    (averageChildren keeps a parent's alpha at the maximum of its children's); words uploaded by the caller may break that:
+    leaves saturated by hand under unsaturated parents must still retire their rays"""
+    pkg, torch = env
+    rng = np.random.default_rng(21)
+    ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
+    center, edge, depth = (0.0, 0.0, 0.0), 1.0, 12
+    # a densely sampled patch of a plane 0.2 m in front of the eye (which looks along +z): LOD 12 there, about one point per 0.5 mm leaf
+    pts = np.stack([rng.uniform(0.27, 0.33, 40000), rng.uniform(0.0, 0.2, 40000), 0.4 + rng.normal(scale=0.0003, size=40000)], 1).astype(np.float32)
+    col = rng.integers(1, 256, (40000, 3), dtype=np.uint8)
+    for _ in range(3):
+        pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, pool, center, edge)
+        opool.insert_cloud(pts, col, depth, center, edge)
+    eye, tgt, (w, h) = (0.3, 0.1, 0.2), (0.3, 0.1, 0.4), (32, 480)
+    view = oracle.look_at(eye, tgt, (0, 1, 0))
+    render_check(pkg, torch, oracle, pool, opool, w, h, view, center, edge, "fused")
+    words = opool.words().copy()
+    n = len(words) // 2
+    leaves = np.flatnonzero(((words[0::2] & 0x40000000) == 0) & ((words[1::2] >> 24) > 127))   # observed leaves
+    pick = leaves[rng.random(len(leaves)) < 0.3]
+    words[2 * pick + 1] = (words[2 * pick + 1] & np.uint32(0x00FFFFFF)) | np.uint32(0xFF000000)   # A = 255, parents untouched
+    pool.set_words(words)
+
+    class Edited:
+        def words(self):
+            return words
+    got = render_check(pkg, torch, oracle, pool, Edited(), w, h, view, center, edge, "edited")
+    assert (got[..., :3] != 0).any()      # rays retire on the hand-saturated leaves
+    assert n > 8
+
+
 def test_pool_deeper_than_the_bricks(env, oracle):
     """depth 14: the bricks stop at level 12, such a pool is marched through the tree (no bricks are kept for it); a
     depth-12 pool that is then fused at depth 14 switches over"""
