@@ -211,7 +211,20 @@ __device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint
   for (int k = 0; k < N; k++) g[k] = live[k] ? grid[((z9[k] >> 1) << (2 * G)) | ((y9[k] >> 1) << G) | (x9[k] >> 1)] : make_uint2(0u, 0u);
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    on[k] = (g[k].x & kFlag) != 0u;  // (no children: cannot happen for a listed node -- listed = below a key's path)
+    // no children in the grid's entry: the level-8 node has just been split and the grid (refreshed by the same launch) may
+    // not say so yet -- the walk from the root decides (rare: a few hundred nodes per frame at the map's frontier)
+    if (live[k] && !(g[k].x & kFlag)) {
+      uint32_t base = 0;
+      bool has = true;
+      for (int l = 1; l <= G && has; l++) {
+        const int sh = G + 1 - l;  // level-9 coordinates: bit sh is level l's octant bit
+        const uint2 nd = nodes[base + (((x9[k] >> sh) & 1u) | (((y9[k] >> sh) & 1u) << 1) | (((z9[k] >> sh) & 1u) << 2))];
+        has = (nd.x & kFlag) != 0u;
+        base = nd.x & kMask;
+      }
+      if (has) g[k].x = kFlag | base;
+    }
+    on[k] = (g[k].x & kFlag) != 0u;
     w9[k] = on[k] ? nodes[(g[k].x & kMask) + ((x9[k] & 1u) | ((y9[k] & 1u) << 1) | ((z9[k] & 1u) << 2))] : make_uint2(0u, 0u);
   }
 #pragma unroll
@@ -275,23 +288,58 @@ __device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint
 }
 
 constexpr int kBrickThreads = 256, kBrickBlocks = 2048, kBrickChains = 4;
+// the rings of the served states: entries [mark of the previous refresh, appended count), and this refresh's mark
+struct BrickRings {
+  uint32_t count[2], first[2];
+};
+__device__ inline BrickRings brick_rings(uint32_t *dirty_a, uint32_t *dirty_b, int par_a, int par_b, bool writer) {
+  BrickRings r;
+  // (nothing appends to a served ring while this launch runs: commits of the served states are ordered around the render)
+  r.count[0] = dirty_a ? dirty_a[kBrickCountOffset] : 0u; r.count[1] = dirty_b ? dirty_b[kBrickCountOffset] : 0u;
+  r.first[0] = dirty_a ? dirty_a[kBrickMarkOffset + (par_a ^ 1)] : 0u; r.first[1] = dirty_b ? dirty_b[kBrickMarkOffset + (par_b ^ 1)] : 0u;
+  if (writer) {  // what this refresh serves (nobody reads this word before the next refresh)
+    if (dirty_a) dirty_a[kBrickMarkOffset + par_a] = r.count[0];
+    if (dirty_b) dirty_b[kBrickMarkOffset + par_b] = r.count[1];
+  }
+  return r;
+}
+__device__ inline bool brick_rings_lapped(const BrickRings &r) {
+  return r.count[0] - r.first[0] > (uint32_t)kBrickListCap || r.count[1] - r.first[1] > (uint32_t)kBrickListCap;
+}
+
+// one wavefront per listed brick, kBrickChains of them side by side; `part` of `parts` wavefronts
+__device__ inline void brick_rebuild_listed(const uint2 *__restrict__ nodes, const uint2 *__restrict__ grid, uint16_t *__restrict__ bricks,
+                                            uint32_t *__restrict__ touched, uint32_t *dirty_a, uint32_t *dirty_b, const BrickRings &r,
+                                            uint32_t part, uint32_t parts, unsigned lane, bool trust_mip) {
+  for (int state = 0; state < 2; state++) {
+    uint32_t *dirty = state ? dirty_b : dirty_a;
+    const uint32_t pending = r.count[state] - r.first[state], first = r.first[state];
+    for (uint32_t i0 = part * kBrickChains; i0 < pending; i0 += parts * kBrickChains) {
+      uint32_t xs[kBrickChains], ys[kBrickChains], zs[kBrickChains];
+      bool live[kBrickChains];
+#pragma unroll
+      for (int k = 0; k < kBrickChains; k++) {
+        live[k] = i0 + k < pending;
+        const uint32_t e = live[k] ? dirty[kBrickListOffset + ((first + i0 + k) & (uint32_t)(kBrickListCap - 1))] : 0u;
+        xs[k] = e & 511u; ys[k] = (e >> 9) & 511u; zs[k] = e >> 18;
+        if (live[k] && lane == 0) atomicAnd(&dirty[kBrickBitsOffset + (e >> 5)], ~(1u << (e & 31u)));  // served: may be listed again
+      }
+      brick_rebuild<kBrickChains>(nodes, grid, bricks, touched, xs, ys, zs, live, lane, trust_mip);
+    }
+  }
+}
+
 // One wavefront per stale brick.  `all` (or a ring that was lapped): every level-8 cell with children instead -- a
 // wavefront reads 64 cells of the level grid and rebuilds the eight bricks of each one that has children.
 __global__ __launch_bounds__(kBrickThreads) void brick_rebuild_kernel(const uint32_t *__restrict__ octree, const uint2 *__restrict__ grid,
                                                                       uint16_t *__restrict__ bricks, uint32_t *__restrict__ touched,
                                                                       uint32_t *__restrict__ dirty_a, uint32_t *__restrict__ dirty_b, int all,
-                                                                      int trust_mip) {
+                                                                      int trust_mip, int par_a, int par_b) {
   const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   constexpr unsigned kWaves = kBrickThreads / 64;
-  // (nothing appends to a served ring while this launch runs: commits of the served states are ordered around the render)
-  const uint32_t count_a = dirty_a ? dirty_a[kBrickCountOffset] : 0u, count_b = dirty_b ? dirty_b[kBrickCountOffset] : 0u;
-  const uint32_t first_a = dirty_a ? dirty_a[kBrickConsumedOffset] : 0u, first_b = dirty_b ? dirty_b[kBrickConsumedOffset] : 0u;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // what this launch serves; the next refresh moves the consumed mark here
-    if (dirty_a) dirty_a[kBrickSeenOffset] = count_a;
-    if (dirty_b) dirty_b[kBrickSeenOffset] = count_b;
-  }
-  if (all || count_a - first_a > (uint32_t)kBrickListCap || count_b - first_b > (uint32_t)kBrickListCap) {
+  const BrickRings r = brick_rings(dirty_a, dirty_b, par_a, par_b, blockIdx.x == 0 && threadIdx.x == 0);
+  if (all || brick_rings_lapped(r)) {
     constexpr int G = kPoolGridLevel;
     constexpr uint32_t kCells = 1u << (3 * G);
     // everything listed so far is served by this pass: no brick is "in the ring" any more
@@ -314,35 +362,20 @@ __global__ __launch_bounds__(kBrickThreads) void brick_rebuild_kernel(const uint
       }
     }
   } else {
-    for (int state = 0; state < 2; state++) {
-      uint32_t *dirty = state ? dirty_b : dirty_a;
-      const uint32_t pending = state ? count_b - first_b : count_a - first_a, first = state ? first_b : first_a;
-      // kBrickChains listed bricks per wavefront and round, their load chains side by side
-      for (uint32_t i0 = (blockIdx.x * kWaves + wave) * kBrickChains; i0 < pending; i0 += kBrickBlocks * kWaves * kBrickChains) {
-        uint32_t xs[kBrickChains], ys[kBrickChains], zs[kBrickChains];
-        bool live[kBrickChains];
-#pragma unroll
-        for (int k = 0; k < kBrickChains; k++) {
-          live[k] = i0 + k < pending;
-          const uint32_t e = live[k] ? dirty[kBrickListOffset + ((first + i0 + k) & (uint32_t)(kBrickListCap - 1))] : 0u;
-          xs[k] = e & 511u; ys[k] = (e >> 9) & 511u; zs[k] = e >> 18;
-          if (live[k] && lane == 0) atomicAnd(&dirty[kBrickBitsOffset + (e >> 5)], ~(1u << (e & 31u)));  // served: may be listed again
-        }
-        brick_rebuild<kBrickChains>(nodes, grid, bricks, touched, xs, ys, zs, live, lane, trust_mip != 0);
-      }
-    }
+    brick_rebuild_listed(nodes, grid, bricks, touched, dirty_a, dirty_b, r, blockIdx.x * kWaves + wave, kBrickBlocks * kWaves, lane, trust_mip != 0);
   }
 }
 
 // the lines of the listed bricks become "ask the level grid" (zero) until the rebuild, which now runs beside the march, has
 // rewritten them; a lapped ring zeroes every group that holds bricks (the rebuild will then redo them all)
 __global__ __launch_bounds__(kBrickThreads) void brick_invalidate_kernel(uint16_t *__restrict__ bricks, const uint32_t *__restrict__ touched,
-                                                                         const uint32_t *__restrict__ dirty_a, const uint32_t *__restrict__ dirty_b) {
+                                                                         uint32_t *__restrict__ dirty_a, uint32_t *__restrict__ dirty_b, int par_a,
+                                                                         int par_b) {
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   constexpr unsigned kWaves = kBrickThreads / 64;
-  const uint32_t count_a = dirty_a ? dirty_a[kBrickCountOffset] : 0u, count_b = dirty_b ? dirty_b[kBrickCountOffset] : 0u;
-  const uint32_t first_a = dirty_a ? dirty_a[kBrickConsumedOffset] : 0u, first_b = dirty_b ? dirty_b[kBrickConsumedOffset] : 0u;
-  if (count_a - first_a > (uint32_t)kBrickListCap || count_b - first_b > (uint32_t)kBrickListCap) {
+  const BrickRings r = brick_rings(dirty_a, dirty_b, par_a, par_b, false);  // (the rebuild that follows writes the mark)
+  const uint32_t count_a = r.count[0], count_b = r.count[1], first_a = r.first[0], first_b = r.first[1];
+  if (brick_rings_lapped(r)) {
     for (uint32_t grp = blockIdx.x; grp < (uint32_t)kBrickGroups; grp += gridDim.x) {
       if (!((touched[grp >> 5] >> (grp & 31u)) & 1u)) continue;
       uint4 *p = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(bricks) + (size_t)grp * kBrickGroupBytes);
@@ -381,42 +414,66 @@ constexpr int kUpdateThreads = 1 << (3 * (kPoolGridLevel - kPoolGridBlockLevel))
 // Both dirty states the render serves are consumed by ONE launch (the second is empty unless deferred commits are in
 // use; as a launch of its own it showed as 6 us per frame in the kernel statistics -- frames/s are the same either way:
 // 2804 against 2804 over 100 frames, A/B on one box).
-__global__ __launch_bounds__(kUpdateThreads) void pool_grid_update_kernel(const uint32_t *__restrict__ octree, uint2 *__restrict__ grid,
-                                                                          uint32_t *__restrict__ dirty_a, uint32_t *__restrict__ dirty_b,
-                                                                          int bricks_on) {
+__device__ inline void pool_grid_update_blocks(const uint2 *__restrict__ nodes, uint2 *__restrict__ grid, uint32_t *dirty_a, uint32_t *dirty_b,
+                                               uint32_t part, uint32_t parts) {
   constexpr int G = kPoolGridLevel, B = kPoolGridBlockLevel, S = G - B;  // 2^S cells per block and axis
-  const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
   const uint32_t c = threadIdx.x;
   for (int state = 0; state < 2; state++) {
     uint32_t *dirty = state ? dirty_b : dirty_a;
     if (!dirty) continue;
-    // the stale-brick ring: what the previous refresh's rebuild saw has been served
-    if (blockIdx.x == 0 && c == 0) dirty[kBrickConsumedOffset] = dirty[kBrickSeenOffset];
     const uint32_t count = dirty[kPoolGridCountOffset];
     const uint32_t *list = dirty + kPoolGridListOffset;
-    for (uint32_t i = blockIdx.x; i < count; i += kUpdateBlocks) {
+    for (uint32_t i = part; i < count; i += parts) {
       const uint32_t b = list[i];
       const bool set = (dirty[b >> 5] >> (b & 31u)) & 1u;
       __syncthreads();  // every lane has read the bit before lane 0 clears it
       if (!set) continue;
       const uint32_t bx = b & ((1u << B) - 1u), by = (b >> B) & ((1u << B) - 1u), bz = b >> (2 * B);
       const uint32_t xi = (bx << S) | (c & ((1u << S) - 1u)), yi = (by << S) | ((c >> S) & ((1u << S) - 1u)), zi = (bz << S) | (c >> (2 * S));
-      const uint32_t cell = (zi << (2 * G)) | (yi << G) | xi;
-      const uint2 fresh = grid_entry(nodes, xi, yi, zi);
-      if (bricks_on && (fresh.x & kFlag) && !(grid[cell].x & kFlag)) {
-        // the level-8 node has just been split: the bricks of its eight children say "ask the level grid" so far
-        for (uint32_t o = 0; o < 8u; o++) {
-          const uint32_t entry = brick_list_entry((xi << 1) | (o & 1u), (yi << 1) | ((o >> 1) & 1u), (zi << 1) | (o >> 2));
-          const uint32_t bit = 1u << (entry & 31u);
-          if (atomicOr(&dirty[kBrickBitsOffset + (entry >> 5)], bit) & bit) continue;  // (the commit listed it)
-          const uint32_t pos = atomicAdd(&dirty[kBrickCountOffset], 1u);
-          dirty[kBrickListOffset + (pos & (uint32_t)(kBrickListCap - 1))] = entry;
-        }
-      }
-      grid[cell] = fresh;
+      grid[(zi << (2 * G)) | (yi << G) | xi] = grid_entry(nodes, xi, yi, zi);
       if (c == 0) atomicAnd(&dirty[b >> 5], ~(1u << (b & 31u)));
     }
   }
+}
+
+__global__ __launch_bounds__(kUpdateThreads) void pool_grid_update_kernel(const uint32_t *__restrict__ octree, uint2 *__restrict__ grid,
+                                                                          uint32_t *__restrict__ dirty_a, uint32_t *__restrict__ dirty_b) {
+  pool_grid_update_blocks(reinterpret_cast<const uint2 *>(octree), grid, dirty_a, dirty_b, blockIdx.x, kUpdateBlocks);
+}
+
+// The refresh before a march in ONE launch (round 3): workgroups [0, kUpdateBlocks) rebuild the listed blocks of the level
+// grid, the rest rebuild the listed bricks -- neither needs the other's result (a brick whose grid entry does not show the
+// level-8 node's children yet walks down from the root; the bricks of a freshly split level-8 node's eight children are
+// listed by the commit that split it, svo_build.hip), so the 14 us of the grid's update and a launch boundary leave the map stream.
+constexpr int kRefreshBrickBlocks = 1024;  // x 8 wavefronts
+__global__ __launch_bounds__(kUpdateThreads) void pool_refresh_kernel(const uint32_t *__restrict__ octree, uint2 *grid, uint16_t *__restrict__ bricks,
+                                                                      uint32_t *__restrict__ touched, uint32_t *dirty_a, uint32_t *dirty_b,
+                                                                      int trust_mip, int par_a, int par_b) {
+  const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
+  if (blockIdx.x < (unsigned)kUpdateBlocks) {
+    pool_grid_update_blocks(nodes, grid, dirty_a, dirty_b, blockIdx.x, kUpdateBlocks);
+    return;
+  }
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  constexpr unsigned kWaves = kUpdateThreads / 64;
+  const unsigned bb = blockIdx.x - (unsigned)kUpdateBlocks;
+  const BrickRings r = brick_rings(dirty_a, dirty_b, par_a, par_b, bb == 0 && threadIdx.x == 0);
+  if (brick_rings_lapped(r)) {
+    // more than a million distinct bricks listed since the last refresh (never seen): the ring has lost entries.  Every group
+    // that holds bricks is zeroed ("ask the level grid": such samples walk the tree, correctly) and every brick may be listed
+    // again; the bricks come back as commits touch them.
+    for (uint32_t w = bb * kUpdateThreads + threadIdx.x; w < (uint32_t)kBrickBitsWords; w += kRefreshBrickBlocks * kUpdateThreads) {
+      if (dirty_a) dirty_a[kBrickBitsOffset + w] = 0u;
+      if (dirty_b) dirty_b[kBrickBitsOffset + w] = 0u;
+    }
+    for (uint32_t grp = bb; grp < (uint32_t)kBrickGroups; grp += kRefreshBrickBlocks) {
+      if (!((touched[grp >> 5] >> (grp & 31u)) & 1u)) continue;
+      uint4 *p = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(bricks) + (size_t)grp * kBrickGroupBytes);
+      for (uint32_t i = threadIdx.x; i < (uint32_t)(kBrickGroupBytes / 16); i += kUpdateThreads) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    return;
+  }
+  brick_rebuild_listed(nodes, grid, bricks, touched, dirty_a, dirty_b, r, bb * kWaves + wave, kRefreshBrickBlocks * kWaves, lane, trust_mip != 0);
 }
 
 // SVOSLAM_MARCH_BRICKS=0: no occupancy bricks (the march walks the tree below the level grid, as in round 2)
@@ -474,43 +531,55 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
   const bool fresh = !pa->valid;
   pa->valid = true;
   uint32_t *serve[2] = {nullptr, nullptr};  // the dirty states this render consumes
+  int serve_idx[2] = {-1, -1};
   if (pa->deferred_pending) {  // that commit's marks (parity of its epoch) belong to the render after its apply
-    serve[0] = pa->d_dirty[(pa->epoch + 1u) & 1u];
+    serve_idx[0] = (int)((pa->epoch + 1u) & 1u);
   } else {
-    serve[0] = pa->d_dirty[0]; serve[1] = pa->d_dirty[1];
+    serve_idx[0] = 0; serve_idx[1] = 1;
   }
+  for (int k = 0; k < 2; k++) serve[k] = serve_idx[k] >= 0 ? pa->d_dirty[serve_idx[k]] : nullptr;
   uint2 *grid = pa->grid.as<uint2>();
   // once a pool has bricks every refresh keeps them current, whatever the mode of the render that asks
   const bool bricks_all = pa->bricks && (fresh || !pa->bricks_valid);
-  if (fresh) {
-    pool_grid_build_kernel<<<(unsigned)(kCells / 256), 256, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
-  } else {
-    pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1], pa->bricks && !bricks_all);
-  }
+  // the rings' marks alternate per state and refresh (kBrickMarkOffset)
+  const int par_a = serve_idx[0] >= 0 ? (int)(pa->brick_served[serve_idx[0]] & 1u) : 0, par_b = serve_idx[1] >= 0 ? (int)(pa->brick_served[serve_idx[1]] & 1u) : 0;
   if (pa->bricks) {
     // SVOSLAM_BRICK_TRUST_MIP=0: the rebuild reads every level-12 tile whatever the pool's history (A/B measurements)
     static const bool trust_on = [] { const char *e = getenv("SVOSLAM_BRICK_TRUST_MIP"); return !(e && e[0] == '0'); }();
     const int trust = trust_on && pa->mip_consistent ? 1 : 0;
     // SVOSLAM_BRICK_ASYNC=1: the rebuild beside the march (PoolAccel::s_rebuild).  Built, bit-exact, measured, and LOST: the rays
     // reach the surfaces before the rebuild does and pay tree walks in the rare-sample path -- march 0.325 -> 0.395 ms, cfg3 2140 ->
-    // 1990 frames/s, the driver's 20 frames 1785 -> 1674 -- so the rebuild stays in line, 65 us on the map stream
+    // 1990 frames/s, the driver's 20 frames 1785 -> 1674 -- so the rebuild stays in line on the map stream
     static const bool async = [] { const char *e = getenv("SVOSLAM_BRICK_ASYNC"); return e && e[0] == '1'; }();
-    if (bricks_all || !async) {
-      if (bricks_all) brick_clear_kernel<<<2048, 256, 0, stream>>>(pa->bricks, pa->d_brick_touched);
-      brick_rebuild_kernel<<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], bricks_all ? 1 : 0, trust);
-    } else {
+    // SVOSLAM_BRICK_FUSED_REFRESH=0: grid update and brick rebuild as two launches (A/B measurements)
+    static const bool fused = [] { const char *e = getenv("SVOSLAM_BRICK_FUSED_REFRESH"); return !(e && e[0] == '0'); }();
+    if (bricks_all) {
+      if (fresh) pool_grid_build_kernel<<<(unsigned)(kCells / 256), 256, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
+      else pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
+      brick_clear_kernel<<<2048, 256, 0, stream>>>(pa->bricks, pa->d_brick_touched);
+      brick_rebuild_kernel<<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], 1, trust, par_a, par_b);
+    } else if (async) {
+      pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
       if (!pa->s_rebuild) {
         SVO_HIP(hipStreamCreateWithFlags(&pa->s_rebuild, hipStreamNonBlocking));
         SVO_HIP(hipEventCreateWithFlags(&pa->ev_ready, hipEventDisableTiming));
         SVO_HIP(hipEventCreateWithFlags(&pa->ev_rebuilt, hipEventDisableTiming));
       }
-      brick_invalidate_kernel<<<kBrickBlocks, kBrickThreads, 0, stream>>>(pa->bricks, pa->d_brick_touched, serve[0], serve[1]);
+      brick_invalidate_kernel<<<kBrickBlocks, kBrickThreads, 0, stream>>>(pa->bricks, pa->d_brick_touched, serve[0], serve[1], par_a, par_b);
       SVO_HIP(hipEventRecord(pa->ev_ready, stream));
       SVO_HIP(hipStreamWaitEvent(pa->s_rebuild, pa->ev_ready, 0));
-      brick_rebuild_kernel<<<kBrickBlocks, kBrickThreads, 0, pa->s_rebuild>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], 0, trust);
+      brick_rebuild_kernel<<<kBrickBlocks, kBrickThreads, 0, pa->s_rebuild>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], 0, trust, par_a, par_b);
       SVO_HIP(hipEventRecord(pa->ev_rebuilt, pa->s_rebuild));
       pa->rebuild_in_flight = true;
+    } else if (fused) {
+      pool_refresh_kernel<<<kUpdateBlocks + kRefreshBrickBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1],
+                                                                                              trust, par_a, par_b);
+    } else {
+      pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
+      brick_rebuild_kernel<<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], 0, trust, par_a, par_b);
     }
+    for (int k = 0; k < 2; k++)
+      if (serve_idx[k] >= 0) pa->brick_served[serve_idx[k]]++;
     pa->bricks_valid = true;
 #ifdef SVO_BRICK_DIAG
     {
@@ -525,6 +594,10 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
       }
     }
 #endif
+  } else if (fresh) {
+    pool_grid_build_kernel<<<(unsigned)(kCells / 256), 256, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
+  } else {
+    pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
   }
   SVO_LAUNCH_CHECK();
   *d_grid = grid;

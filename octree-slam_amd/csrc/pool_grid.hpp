@@ -55,6 +55,7 @@ struct PoolAccel {
   uint16_t *bricks = nullptr;
   uint32_t *d_brick_touched = nullptr;  // [kBrickGroupWords]
   bool bricks_valid = false;
+  unsigned brick_served[2] = {0u, 0u};  // how often each dirty state's ring has been served (its parity picks the mark: kBrickMarkOffset)
   bool bricks_failed = false;           // the field could not be allocated: this pool is marched through the tree
   // SVOSLAM_BRICK_ASYNC=1 (opt-in; measured slower, see pool_accel_refresh): the rebuild of the stale bricks runs BESIDE the
   // march: the refresh zeroes the listed bricks' lines on the render's stream (zero = "ask the level grid", which says "has children": such a sample walks the tree -- correct, slower),
@@ -109,10 +110,11 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
 
 constexpr int kPoolGridListOffset = kPoolGridDirtyWords;                     // words
 constexpr int kPoolGridCountOffset = kPoolGridDirtyWords + kPoolGridBlocks;  // words
-// behind them, the ring of the level-9 nodes whose occupancy brick is stale (see "occupancy bricks"): three words -- entries
-// appended so far (commits, the grid's refresh), entries consumed, and the appended count the latest rebuild saw (which the
-// next refresh makes the consumed one: no launch has to wait for its last workgroup to reset anything) -- then the entries
-constexpr int kBrickCountOffset = kPoolGridCountOffset + 4, kBrickConsumedOffset = kBrickCountOffset + 1, kBrickSeenOffset = kBrickCountOffset + 2;
+// behind them, the ring of the level-9 nodes whose occupancy brick is stale (see "occupancy bricks"): the number of entries
+// appended so far (commits), and two marks "served up to here" that the refreshes write in turn -- refresh n of a state reads
+// mark[(n + 1) & 1] (what refresh n - 1 served) and writes mark[n & 1]: no launch has to wait for its last workgroup to reset
+// anything, and the grid's update and the bricks' rebuild can share ONE launch -- then the entries
+constexpr int kBrickCountOffset = kPoolGridCountOffset + 4, kBrickMarkOffset = kBrickCountOffset + 1;
 constexpr int kBrickListOffset = kBrickCountOffset + 4;
 constexpr int kBrickListCap = 1 << 20;  // more than this pending = "rebuild every brick" (a commit appends <= its distinct level-9 prefixes)
 // ... and one bit per level-9 node: "in this state's ring" (set by whoever appends it, cleared by the rebuild that serves it), so

@@ -716,6 +716,18 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   }
   __syncthreads();
   if (bricks_on && tid == 0 && brick_cnt) brick_base = brick_ring_reserve(grid_dirty, brick_cnt);
+  // a key whose path had no node below level 8 so far gives its level-8 node eight children: the seven siblings of the key's
+  // own level-9 node are new, childless nodes whose bricks nobody else would list (rare: the map's frontier)
+  if (bricks_on && head && c < kBrickNodeLevel && lt != kNoSplit && (int)lt <= kPoolGridLevel) {
+    const u32 x9 = brick_entry & 511u, y9 = (brick_entry >> 9) & 511u, z9 = brick_entry >> 18;
+    for (u32 o = 0; o < 8u; o++) {
+      const u32 sib = brick_list_entry((x9 & ~1u) | (o & 1u), (y9 & ~1u) | ((o >> 1) & 1u), (z9 & ~1u) | (o >> 2));
+      if (sib == brick_entry) continue;
+      const u32 bit = 1u << (sib & 31u);
+      if (atomicOr(&grid_dirty[kBrickBitsOffset + (sib >> 5)], bit) & bit) continue;
+      brick_ring_store(grid_dirty, brick_ring_reserve(grid_dirty, 1u), sib);
+    }
+  }
   if (next_pos == 0x7FFFFFFF) {  // no head in the next workgroup (all duplicates / invalid points): look further
     for (int nb = bid + 2; nb < num_tiles; nb++) {
       const int jj = nb * kFillThreads + tid;
