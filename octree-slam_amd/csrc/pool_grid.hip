@@ -417,7 +417,6 @@ constexpr int kUpdateThreads = 1 << (3 * (kPoolGridLevel - kPoolGridBlockLevel))
 __device__ inline void pool_grid_update_blocks(const uint2 *__restrict__ nodes, uint2 *__restrict__ grid, uint32_t *dirty_a, uint32_t *dirty_b,
                                                uint32_t part, uint32_t parts) {
   constexpr int G = kPoolGridLevel, B = kPoolGridBlockLevel, S = G - B;  // 2^S cells per block and axis
-  const uint32_t c = threadIdx.x;
   for (int state = 0; state < 2; state++) {
     uint32_t *dirty = state ? dirty_b : dirty_a;
     if (!dirty) continue;
@@ -429,9 +428,11 @@ __device__ inline void pool_grid_update_blocks(const uint2 *__restrict__ nodes, 
       __syncthreads();  // every lane has read the bit before lane 0 clears it
       if (!set) continue;
       const uint32_t bx = b & ((1u << B) - 1u), by = (b >> B) & ((1u << B) - 1u), bz = b >> (2 * B);
-      const uint32_t xi = (bx << S) | (c & ((1u << S) - 1u)), yi = (by << S) | ((c >> S) & ((1u << S) - 1u)), zi = (bz << S) | (c >> (2 * S));
-      grid[(zi << (2 * G)) | (yi << G) | xi] = grid_entry(nodes, xi, yi, zi);
-      if (c == 0) atomicAnd(&dirty[b >> 5], ~(1u << (b & 31u)));
+      for (uint32_t c = threadIdx.x; c < (uint32_t)kUpdateThreads; c += blockDim.x) {  // (one cell per lane of a 512-lane workgroup)
+        const uint32_t xi = (bx << S) | (c & ((1u << S) - 1u)), yi = (by << S) | ((c >> S) & ((1u << S) - 1u)), zi = (bz << S) | (c >> (2 * S));
+        grid[(zi << (2 * G)) | (yi << G) | xi] = grid_entry(nodes, xi, yi, zi);
+      }
+      if (threadIdx.x == 0) atomicAnd(&dirty[b >> 5], ~(1u << (b & 31u)));
     }
   }
 }
@@ -441,35 +442,36 @@ __global__ __launch_bounds__(kUpdateThreads) void pool_grid_update_kernel(const 
   pool_grid_update_blocks(reinterpret_cast<const uint2 *>(octree), grid, dirty_a, dirty_b, blockIdx.x, kUpdateBlocks);
 }
 
-// The refresh before a march in ONE launch (round 3): workgroups [0, kUpdateBlocks) rebuild the listed blocks of the level
-// grid, the rest rebuild the listed bricks -- neither needs the other's result (a brick whose grid entry does not show the
+// The refresh before a march in ONE launch (round 3): workgroups [0, kRefreshBrickBlocks) rebuild the listed bricks, the rest
+// the listed blocks of the level grid -- neither needs the other's result (a brick whose grid entry does not show the
 // level-8 node's children yet walks down from the root; the bricks of a freshly split level-8 node's eight children are
 // listed by the commit that split it, svo_build.hip), so the 14 us of the grid's update and a launch boundary leave the map stream.
-constexpr int kRefreshBrickBlocks = 1024;  // x 8 wavefronts
-__global__ __launch_bounds__(kUpdateThreads) void pool_refresh_kernel(const uint32_t *__restrict__ octree, uint2 *grid, uint16_t *__restrict__ bricks,
+constexpr int kRefreshBrickBlocks = kBrickBlocks, kRefreshGridBlocks = 1024;  // (workgroups of kBrickThreads; a frame marks a few hundred level-5 blocks)
+__global__ __launch_bounds__(kBrickThreads) void pool_refresh_kernel(const uint32_t *__restrict__ octree, uint2 *grid, uint16_t *__restrict__ bricks,
                                                                       uint32_t *__restrict__ touched, uint32_t *dirty_a, uint32_t *dirty_b,
                                                                       int trust_mip, int par_a, int par_b) {
   const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
-  if (blockIdx.x < (unsigned)kUpdateBlocks) {
-    pool_grid_update_blocks(nodes, grid, dirty_a, dirty_b, blockIdx.x, kUpdateBlocks);
+  // (the bricks' workgroups first: they are the long ones; 2048 nearly empty grid workgroups ahead of them cost the launch 20 us)
+  if (blockIdx.x >= (unsigned)kRefreshBrickBlocks) {
+    pool_grid_update_blocks(nodes, grid, dirty_a, dirty_b, blockIdx.x - (unsigned)kRefreshBrickBlocks, kRefreshGridBlocks);
     return;
   }
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  constexpr unsigned kWaves = kUpdateThreads / 64;
-  const unsigned bb = blockIdx.x - (unsigned)kUpdateBlocks;
+  constexpr unsigned kWaves = kBrickThreads / 64;
+  const unsigned bb = blockIdx.x;
   const BrickRings r = brick_rings(dirty_a, dirty_b, par_a, par_b, bb == 0 && threadIdx.x == 0);
   if (brick_rings_lapped(r)) {
     // more than a million distinct bricks listed since the last refresh (never seen): the ring has lost entries.  Every group
     // that holds bricks is zeroed ("ask the level grid": such samples walk the tree, correctly) and every brick may be listed
     // again; the bricks come back as commits touch them.
-    for (uint32_t w = bb * kUpdateThreads + threadIdx.x; w < (uint32_t)kBrickBitsWords; w += kRefreshBrickBlocks * kUpdateThreads) {
+    for (uint32_t w = bb * kBrickThreads + threadIdx.x; w < (uint32_t)kBrickBitsWords; w += kRefreshBrickBlocks * kBrickThreads) {
       if (dirty_a) dirty_a[kBrickBitsOffset + w] = 0u;
       if (dirty_b) dirty_b[kBrickBitsOffset + w] = 0u;
     }
     for (uint32_t grp = bb; grp < (uint32_t)kBrickGroups; grp += kRefreshBrickBlocks) {
       if (!((touched[grp >> 5] >> (grp & 31u)) & 1u)) continue;
       uint4 *p = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(bricks) + (size_t)grp * kBrickGroupBytes);
-      for (uint32_t i = threadIdx.x; i < (uint32_t)(kBrickGroupBytes / 16); i += kUpdateThreads) p[i] = make_uint4(0u, 0u, 0u, 0u);
+      for (uint32_t i = threadIdx.x; i < (uint32_t)(kBrickGroupBytes / 16); i += kBrickThreads) p[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     return;
   }
@@ -572,7 +574,7 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
       SVO_HIP(hipEventRecord(pa->ev_rebuilt, pa->s_rebuild));
       pa->rebuild_in_flight = true;
     } else if (fused) {
-      pool_refresh_kernel<<<kUpdateBlocks + kRefreshBrickBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1],
+      pool_refresh_kernel<<<kRefreshBrickBlocks + kRefreshGridBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1],
                                                                                               trust, par_a, par_b);
     } else {
       pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
