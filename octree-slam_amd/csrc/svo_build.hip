@@ -700,12 +700,7 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   }
   if (tid == 0) { next_pos = 0x7FFFFFFF; next_c = -1; min_c = 99; brick_cnt = 0u; }  // no later head: every run ends with the array
   __syncthreads();
-  if (head) {
-    for (int d = c + 1; d < depth; d++) atomicMax(&last_owner[d], j);
-    if (strad_bc) atomicMin(&min_c, c);
-  }
-  if (ltn != kNotHead) atomicMin(&next_pos, jn);
-  if (bricks_on) {
+  if (bricks_on) {  // (straight behind the barrier: every lane of the wavefront takes part in the ballot)
     const unsigned long long bm = __ballot(brick_mine);
     if (bm) {
       const int leader = __ffsll((long long)bm) - 1;
@@ -714,20 +709,13 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
       brick_off = (u32)__shfl((int)woff, leader) + (u32)__popcll(bm & ((1ull << (tid & 63)) - 1ull));
     }
   }
+  if (head) {
+    for (int d = c + 1; d < depth; d++) atomicMax(&last_owner[d], j);
+    if (strad_bc) atomicMin(&min_c, c);
+  }
+  if (ltn != kNotHead) atomicMin(&next_pos, jn);
   __syncthreads();
   if (bricks_on && tid == 0 && brick_cnt) brick_base = brick_ring_reserve(grid_dirty, brick_cnt);
-  // a key whose path had no node below level 8 so far gives its level-8 node eight children: the seven siblings of the key's
-  // own level-9 node are new, childless nodes whose bricks nobody else would list (rare: the map's frontier)
-  if (bricks_on && head && c < kBrickNodeLevel && lt != kNoSplit && (int)lt <= kPoolGridLevel) {
-    const u32 x9 = brick_entry & 511u, y9 = (brick_entry >> 9) & 511u, z9 = brick_entry >> 18;
-    for (u32 o = 0; o < 8u; o++) {
-      const u32 sib = brick_list_entry((x9 & ~1u) | (o & 1u), (y9 & ~1u) | ((o >> 1) & 1u), (z9 & ~1u) | (o >> 2));
-      if (sib == brick_entry) continue;
-      const u32 bit = 1u << (sib & 31u);
-      if (atomicOr(&grid_dirty[kBrickBitsOffset + (sib >> 5)], bit) & bit) continue;
-      brick_ring_store(grid_dirty, brick_ring_reserve(grid_dirty, 1u), sib);
-    }
-  }
   if (next_pos == 0x7FFFFFFF) {  // no head in the next workgroup (all duplicates / invalid points): look further
     for (int nb = bid + 2; nb < num_tiles; nb++) {
       const int jj = nb * kFillThreads + tid;
@@ -868,6 +856,22 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
       __syncthreads();
     }
   }
+  // a key whose path had no node below level 8 so far gives its level-8 node eight children: the seven siblings of the key's
+  // own level-9 node are new, childless nodes whose bricks nobody else would list (rare: the map's frontier).  At the END of
+  // the kernel: this divergent loop of atomics, placed between the barriers of the set-up, left the wavefront's lanes apart at
+  // the ballots that follow there (test_async_fusion_long_runs_of_duplicates_and_invalid_points caught it)
+#ifndef SVO_NO_SIBLINGS
+  if (bricks_on && head && c < kBrickNodeLevel && lt != kNoSplit && (int)lt <= kPoolGridLevel) {
+    const u32 x9 = brick_entry & 511u, y9 = (brick_entry >> 9) & 511u, z9 = brick_entry >> 18;
+    for (u32 o = 0; o < 8u; o++) {
+      const u32 sib = brick_list_entry((x9 & ~1u) | (o & 1u), (y9 & ~1u) | ((o >> 1) & 1u), (z9 & ~1u) | (o >> 2));
+      if (sib == brick_entry) continue;
+      const u32 bit = 1u << (sib & 31u);
+      if (atomicOr(&grid_dirty[kBrickBitsOffset + (sib >> 5)], bit) & bit) continue;
+      brick_ring_store(grid_dirty, brick_ring_reserve(grid_dirty, 1u), sib);
+    }
+  }
+#endif
 #ifdef SVO_FILL_PROF
   FILL_STAMP(5)
   if (tid == 0 && (bid % 37) == 0)

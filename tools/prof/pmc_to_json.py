@@ -15,8 +15,8 @@ import sys
 
 STAGES = {
     "march": ("cone_trace_brick_kernel", "cone_trace_kernel"),
-    "march_accel": ("pool_grid_update_kernel", "pool_grid_build_kernel", "build_tables_kernel", "build_accel_kernel", "brick_rebuild_kernel",
-                    "brick_clear_kernel"),
+    "march_accel": ("pool_refresh_kernel", "pool_grid_update_kernel", "pool_grid_build_kernel", "build_tables_kernel", "build_accel_kernel",
+                    "brick_rebuild_kernel", "brick_clear_kernel"),
     "tracker": ("track_persistent_kernel", "icp_accumulate_work_kernel", "icp_accumulate_kernel", "cam_reduce_solve_kernel", "cam_frame_end_kernel"),
     "fusion": ("keys_packed_kernel", "packed_upsweep_kernel", "packed_column_scan_kernel", "packed_downsweep_kernel", "plan_count_kernel",
                "plan_scan_finish_kernel", "plan_emit_kernel", "split_all_kernel", "fill_mip_local_kernel", "mip_straddle_kernel",
