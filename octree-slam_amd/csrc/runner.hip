@@ -144,7 +144,10 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
     const bool prio = want && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
     hipStream_t *ss[5] = {&r->s_maps, &r->s_track, &r->s_prep, &r->s_map[0], &r->s_map[1]};
     const int mid = (least + greatest) / 2;
-    const int pr[5] = {least, tracker_first ? greatest : mid, least, tracker_first ? mid : greatest, tracker_first ? mid : greatest};
+    // '3' / '4': the front end + sort + plan stream on the highest / the middle priority as well (round 3: with the brick march
+    // that stream's 15 short launches are the chain the frame period follows; A/B in DESIGN.md section 4)
+    const int prep_pr = (pe && pe[0] == '3') ? greatest : (pe && pe[0] == '4') ? mid : least;
+    const int pr[5] = {least, tracker_first ? greatest : mid, prep_pr, tracker_first ? mid : greatest, tracker_first ? mid : greatest};
     for (int k = 0; k < 5; k++) {
       if (prio) SVO_HIP(hipStreamCreateWithPriority(ss[k], hipStreamNonBlocking, pr[k]));
       else SVO_HIP(hipStreamCreateWithFlags(ss[k], hipStreamNonBlocking));
