@@ -457,7 +457,7 @@ def main():
                                        "%d row bands: ICP all-reduce (19 per frame) + point all-gather, replicated pool" % world),
                        "multi_gpu_scheme": (None if world == 1 and emu is None and not force_dist else
                                             "%s (bench.py's default for N > 1 is 'deltas': on ONE GPU, emulating one rank of N on the 300-frame map, "
-                                            "it gives 1.25x / 1.75x / 2.3x of the single-GPU rate for N = 2 / 4 / 8, against < 1x for the row-band scheme "
+                                            "it gives 1.2x / 1.7x / 2.1x of the single-GPU rate for N = 2 / 4 / 8, against < 1x for the row-band scheme "
                                             "'allreduce' = SURVEY 8e with sorted-key all-gather + merge (profiles/r03_bench_cfg3_emulated_*.json, "
                                             "r03_bench_cfg3_forced_dist_*.json); UNMEASURED on multi-GPU hardware)" % args.exchange),
                        "overlap": "none" if args.no_overlap else
