@@ -1,4 +1,5 @@
-// pool_grid.hpp -- the level grid of the ray march as a PROPERTY OF THE POOL, maintained incrementally.
+// pool_grid.hpp -- the acceleration data of the ray march as PROPERTIES OF THE POOL, maintained incrementally: the level-8
+// grid (round 2) and the occupancy bricks below it (round 3; further down in this file).
 //
 // Round 1 rebuilt a dense level-7 grid (16.8 MB, 9-12 us) from the pool at the start of every render and used the
 // level-8 one (134 MB, 30 us to rebuild, 14 % less march time) only for megapixel renders.  A fusion changes the

@@ -402,13 +402,13 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
     if (k == (i & (R - 1))) mark(i, 8, r->s_map[k]);
     return SVOSLAM_OK;
   };
-  // One replica, deferred commits (SVOSLAM_RUNNER_DEFERRED=1): stream C computes the commit of frame k+1 -- splits, leaf
+  // One replica, deferred commits (the default for images up to 640x480-class, svoslam_runner::deferred): stream C computes the commit of frame k+1 -- splits, leaf
   // blends, mip levels, into memory the march cannot see (svoslam_svo_fuse_commit_deferred) -- WHILE stream M ray-marches
   // frame k; M then publishes it with one short launch (svoslam_svo_fuse_apply) and marches frame k+1.  The map stream
-  // carries apply + grid refresh + march instead of commit + grid refresh + march.  Measured: the march beside a commit
-  // takes 0.32 ms instead of 0.28 and the commit 0.27 instead of 0.11 (both are latency chains through the same L2 /
-  // HBM), so the period barely moves: cfg3 100 frames 2430 -> 2560 frames/s, 20 frames 2550 -> 2290, cfg4 742 -> 634.
-  // Off by default.
+  // carries apply + grid / brick refresh + march instead of commit + refresh + march.  Round 2, beside the tree march (a
+  // latency chain through the same L2 / HBM as the commit): the march took 0.32 ms instead of 0.28, the commit 0.27 instead of
+  // 0.11, the period barely moved.  Round 3, beside the issue-bound brick march: cfg3 1862 -> 2055 frames/s; the period is
+  // now apply(k) -> plan(k+1) -> this commit -> apply(k+1) (0.42 ms) level with the map stream (0.40).
   hipStream_t s_compute = r->s_map[1];
   auto enqueue_compute = [&](int i) -> int {
     SVO_HIP(hipStreamWaitEvent(s_compute, ev_plan[i], 0));
