@@ -61,7 +61,7 @@ struct svoslam_runner {
   std::vector<hipEvent_t> events;  // pool, grown on demand
   hipEvent_t ev_begin = nullptr, ev_end[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t last_caller = nullptr;
-  int lead = 2;  // commits the host may run ahead of the device (see svoslam_runner_run)
+  int lead = -1;  // commits the host may run ahead of the device (see svoslam_runner_run); < 0: the schedule's default (1 deferred, 2 in place)
   bool fused_front = false;  // back-projection + bounding box + keys in one launch (SVOSLAM_RUNNER_FUSED_FRONT=0: the four stand-alone calls)
   bool early_split = true;  // SVOSLAM_RUNNER_EARLY_SPLIT=0: split_all_kernel inside the commit
   // one replica: the commit of frame k+1 is computed during the march of frame k (svoslam_svo_fuse_commit_deferred).  Default
@@ -433,7 +433,12 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
     for (int i = 0; i < n; i++) {
       if (i + 1 < n) SVO_TRY(enqueue_track(i + 1));
       if (i + 2 < n) SVO_TRY(enqueue_maps(i + 2));
-      if (r->lead > 0 && i >= r->lead) SVO_HIP(hipEventSynchronize(ev_commit[0][i - r->lead]));  // (see the other schedule)
+      // (see the other schedule.)  ev_commit[k] here is the DEFERRED commit of frame k, enqueued one iteration earlier than the
+      // in-place commit is there: a lead of 1 is the same distance as 2 there.  Measured, lead 1 / 2 / 3 / 4: cfg3 100 frames
+      // 2380 / 2350 / 2310 / 2035 frames/s, the driver's 20 frames 2085 / 2000 / 1860 / 1770 -- the further the host runs ahead,
+      // the more often (lead 4: always) the streams settle in the slower of their two steady states.
+      const int lead = r->lead < 0 ? 1 : r->lead;
+      if (lead > 0 && i >= lead) SVO_HIP(hipEventSynchronize(ev_commit[0][i - lead]));
       SVO_TRY(enqueue_apply(i));
       if (i + 1 < n) {
         SVO_TRY(enqueue_prepare(i + 1));  // its plan waits for apply i
@@ -463,7 +468,9 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
       // frame instead of 0.32 (measured with HIP events per stage: the kernels themselves keep their durations and the
       // clock stays at 2.4 GHz, the gaps between them grow; AMD_DIRECT_DISPATCH=0 does not show it but costs 10 % in
       // steady state).  With a lead of 8 frames that tail was 8 of the 20 frames of a short call: 2130 -> 2580 frames/s.
-      if (r->lead > 0 && i >= r->lead) SVO_HIP(hipEventSynchronize(ev_commit[a][i - r->lead]));
+      // (a rank of 8, lead 1 / 2: 4480 / 5030 frames/s)
+      const int lead = r->lead < 0 ? 2 : r->lead;
+      if (lead > 0 && i >= lead) SVO_HIP(hipEventSynchronize(ev_commit[a][i - lead]));
       SVO_TRY(enqueue_commit(i, a, R == 1));
       if (i + 1 < n && !chain) SVO_TRY(enqueue_prepare(i + 1));  // host order: after ev_commit[a][i] has been recorded
       // one march at a time: two of them (1200 workgroups) leave no CU for the tracker's and the fusion's workgroups
