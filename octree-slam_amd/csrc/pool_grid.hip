@@ -307,24 +307,25 @@ __device__ inline bool brick_rings_lapped(const BrickRings &r) {
   return r.count[0] - r.first[0] > (uint32_t)kBrickListCap || r.count[1] - r.first[1] > (uint32_t)kBrickListCap;
 }
 
-// one wavefront per listed brick, kBrickChains of them side by side; `part` of `parts` wavefronts
+// one wavefront per listed brick, C of them side by side; `part` of `parts` wavefronts
+template <int C = kBrickChains>
 __device__ inline void brick_rebuild_listed(const uint2 *__restrict__ nodes, const uint2 *__restrict__ grid, uint16_t *__restrict__ bricks,
                                             uint32_t *__restrict__ touched, uint32_t *dirty_a, uint32_t *dirty_b, const BrickRings &r,
                                             uint32_t part, uint32_t parts, unsigned lane, bool trust_mip) {
   for (int state = 0; state < 2; state++) {
     uint32_t *dirty = state ? dirty_b : dirty_a;
     const uint32_t pending = r.count[state] - r.first[state], first = r.first[state];
-    for (uint32_t i0 = part * kBrickChains; i0 < pending; i0 += parts * kBrickChains) {
-      uint32_t xs[kBrickChains], ys[kBrickChains], zs[kBrickChains];
-      bool live[kBrickChains];
+    for (uint32_t i0 = part * C; i0 < pending; i0 += parts * C) {
+      uint32_t xs[C], ys[C], zs[C];
+      bool live[C];
 #pragma unroll
-      for (int k = 0; k < kBrickChains; k++) {
+      for (int k = 0; k < C; k++) {
         live[k] = i0 + k < pending;
         const uint32_t e = live[k] ? dirty[kBrickListOffset + ((first + i0 + k) & (uint32_t)(kBrickListCap - 1))] : 0u;
         xs[k] = e & 511u; ys[k] = (e >> 9) & 511u; zs[k] = e >> 18;
         if (live[k] && lane == 0) atomicAnd(&dirty[kBrickBitsOffset + (e >> 5)], ~(1u << (e & 31u)));  // served: may be listed again
       }
-      brick_rebuild<kBrickChains>(nodes, grid, bricks, touched, xs, ys, zs, live, lane, trust_mip);
+      brick_rebuild<C>(nodes, grid, bricks, touched, xs, ys, zs, live, lane, trust_mip);
     }
   }
 }
@@ -446,14 +447,19 @@ __global__ __launch_bounds__(kUpdateThreads) void pool_grid_update_kernel(const 
 // the listed blocks of the level grid -- neither needs the other's result (a brick whose grid entry does not show the
 // level-8 node's children yet walks down from the root; the bricks of a freshly split level-8 node's eight children are
 // listed by the commit that split it, svo_build.hip), so the 14 us of the grid's update and a launch boundary leave the map stream.
-constexpr int kRefreshBrickBlocks = kBrickBlocks, kRefreshGridBlocks = 1024;  // (workgroups of kBrickThreads; a frame marks a few hundred level-5 blocks)
+// (workgroups of kBrickThreads; a frame marks a few hundred level-5 blocks and lists ~45 k bricks.)  The bricks' part: 4096 workgroups with
+// TWO bricks side by side per wavefront -- kernel-trace means over 100 frames of cfg3, three runs each: 2048 x 4 chains 53-59 us,
+// 2048 x 2 43-44, 4096 x 2 34-44, 4096 x 1 39-45, 2048 x 8 95 (tools/prof/refresh_ab.sh).  Frames/s do not move (2360 either way): the
+// period follows the sum of what runs beside the march, and this is 1 % of it.
+constexpr int kRefreshBrickBlocks = 4096, kRefreshGridBlocks = 1024, kRefreshChains = 2;
+template <int C>
 __global__ __launch_bounds__(kBrickThreads) void pool_refresh_kernel(const uint32_t *__restrict__ octree, uint2 *grid, uint16_t *__restrict__ bricks,
                                                                       uint32_t *__restrict__ touched, uint32_t *dirty_a, uint32_t *dirty_b,
-                                                                      int trust_mip, int par_a, int par_b) {
+                                                                      int trust_mip, int par_a, int par_b, unsigned brick_blocks) {
   const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
   // (the bricks' workgroups first: they are the long ones; 2048 nearly empty grid workgroups ahead of them cost the launch 20 us)
-  if (blockIdx.x >= (unsigned)kRefreshBrickBlocks) {
-    pool_grid_update_blocks(nodes, grid, dirty_a, dirty_b, blockIdx.x - (unsigned)kRefreshBrickBlocks, kRefreshGridBlocks);
+  if (blockIdx.x >= brick_blocks) {
+    pool_grid_update_blocks(nodes, grid, dirty_a, dirty_b, blockIdx.x - brick_blocks, kRefreshGridBlocks);
     return;
   }
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -464,18 +470,18 @@ __global__ __launch_bounds__(kBrickThreads) void pool_refresh_kernel(const uint3
     // more than a million distinct bricks listed since the last refresh (never seen): the ring has lost entries.  Every group
     // that holds bricks is zeroed ("ask the level grid": such samples walk the tree, correctly) and every brick may be listed
     // again; the bricks come back as commits touch them.
-    for (uint32_t w = bb * kBrickThreads + threadIdx.x; w < (uint32_t)kBrickBitsWords; w += kRefreshBrickBlocks * kBrickThreads) {
+    for (uint32_t w = bb * kBrickThreads + threadIdx.x; w < (uint32_t)kBrickBitsWords; w += brick_blocks * kBrickThreads) {
       if (dirty_a) dirty_a[kBrickBitsOffset + w] = 0u;
       if (dirty_b) dirty_b[kBrickBitsOffset + w] = 0u;
     }
-    for (uint32_t grp = bb; grp < (uint32_t)kBrickGroups; grp += kRefreshBrickBlocks) {
+    for (uint32_t grp = bb; grp < (uint32_t)kBrickGroups; grp += brick_blocks) {
       if (!((touched[grp >> 5] >> (grp & 31u)) & 1u)) continue;
       uint4 *p = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(bricks) + (size_t)grp * kBrickGroupBytes);
       for (uint32_t i = threadIdx.x; i < (uint32_t)(kBrickGroupBytes / 16); i += kBrickThreads) p[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     return;
   }
-  brick_rebuild_listed(nodes, grid, bricks, touched, dirty_a, dirty_b, r, bb * kWaves + wave, kRefreshBrickBlocks * kWaves, lane, trust_mip != 0);
+  brick_rebuild_listed<C>(nodes, grid, bricks, touched, dirty_a, dirty_b, r, bb * kWaves + wave, brick_blocks * kWaves, lane, trust_mip != 0);
 }
 
 // SVOSLAM_MARCH_BRICKS=0: no occupancy bricks (the march walks the tree below the level grid, as in round 2)
@@ -574,8 +580,16 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
       SVO_HIP(hipEventRecord(pa->ev_rebuilt, pa->s_rebuild));
       pa->rebuild_in_flight = true;
     } else if (fused) {
-      pool_refresh_kernel<<<kRefreshBrickBlocks + kRefreshGridBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1],
-                                                                                              trust, par_a, par_b);
+      // (A/B: SVOSLAM_REFRESH_BLOCKS = workgroups of the bricks' part, SVOSLAM_REFRESH_CHAINS = 1 / 2 / 4 / 8 bricks per wavefront side by side)
+      static const unsigned bblocks = [] { const char *e = getenv("SVOSLAM_REFRESH_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : (unsigned)kRefreshBrickBlocks; }();
+      static const int chains = [] { const char *e = getenv("SVOSLAM_REFRESH_CHAINS"); return e ? atoi(e) : kRefreshChains; }();
+      auto launch = [&](auto kernel) {
+        kernel<<<bblocks + kRefreshGridBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], trust, par_a, par_b, bblocks);
+      };
+      if (chains == 1) launch(pool_refresh_kernel<1>);
+      else if (chains == 4) launch(pool_refresh_kernel<4>);
+      else if (chains == 8) launch(pool_refresh_kernel<8>);
+      else launch(pool_refresh_kernel<2>);
     } else {
       pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
       brick_rebuild_kernel<<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], 0, trust, par_a, par_b);
