@@ -447,11 +447,12 @@ __global__ __launch_bounds__(kUpdateThreads) void pool_grid_update_kernel(const 
 // the listed blocks of the level grid -- neither needs the other's result (a brick whose grid entry does not show the
 // level-8 node's children yet walks down from the root; the bricks of a freshly split level-8 node's eight children are
 // listed by the commit that split it, svo_build.hip), so the 14 us of the grid's update and a launch boundary leave the map stream.
-// (workgroups of kBrickThreads; a frame marks a few hundred level-5 blocks and lists ~45 k bricks.)  The bricks' part: 4096 workgroups with
-// TWO bricks side by side per wavefront -- kernel-trace means over 100 frames of cfg3, three runs each: 2048 x 4 chains 53-59 us,
-// 2048 x 2 43-44, 4096 x 2 34-44, 4096 x 1 39-45, 2048 x 8 95 (tools/prof/refresh_ab.sh).  Frames/s do not move (2360 either way): the
-// period follows the sum of what runs beside the march, and this is 1 % of it.
-constexpr int kRefreshBrickBlocks = 4096, kRefreshGridBlocks = 1024, kRefreshChains = 2;
+// (workgroups of kBrickThreads; a frame marks a few hundred level-5 blocks and lists ~45 k bricks.)  The bricks' part in other shapes --
+// kernel-trace means over 100 frames of cfg3, three runs each (tools/prof/refresh_ab.sh): 2048 workgroups x 4 bricks per wavefront 53-59 us,
+// 2048 x 2 43-44, 4096 x 2 34-44, 4096 x 1 39-45, 2048 x 8 95.  The FRAME RATE does not follow: 4096 x 2 against 2048 x 4, eleven runs each on
+// two boxes: 2028-2372 (median 2236) against 2019-2401 (median 2362) -- a march that starts 15 us earlier meets the other streams' launches
+// at a worse moment (the schedule's steady states).  The slower shape stays.
+constexpr int kRefreshBrickBlocks = kBrickBlocks, kRefreshGridBlocks = 1024, kRefreshChains = kBrickChains;
 template <int C>
 __global__ __launch_bounds__(kBrickThreads) void pool_refresh_kernel(const uint32_t *__restrict__ octree, uint2 *grid, uint16_t *__restrict__ bricks,
                                                                       uint32_t *__restrict__ touched, uint32_t *dirty_a, uint32_t *dirty_b,
@@ -587,9 +588,9 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
         kernel<<<bblocks + kRefreshGridBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], trust, par_a, par_b, bblocks);
       };
       if (chains == 1) launch(pool_refresh_kernel<1>);
-      else if (chains == 4) launch(pool_refresh_kernel<4>);
+      else if (chains == 2) launch(pool_refresh_kernel<2>);
       else if (chains == 8) launch(pool_refresh_kernel<8>);
-      else launch(pool_refresh_kernel<2>);
+      else launch(pool_refresh_kernel<4>);
     } else {
       pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
       brick_rebuild_kernel<<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], 0, trust, par_a, par_b);
