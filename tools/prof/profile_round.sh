@@ -145,6 +145,10 @@ if [ -f $R/octree-slam_amd/_variants/libsvoslam_hip_diag.so ]; then
   cp /tmp/base.so $R/octree-slam_amd/libsvoslam_hip.so
   tail -9 ${P}_brick_march_anatomy.txt
 fi
+echo "== the schedule's two steady states under the kernel trace (host 1 / 4 commits ahead)"
+bash $R/tools/prof/state_trace.sh > /dev/null 2>&1
+for l in 1 4; do [ -s $R/gpurun_out/state/frames_lead$l.txt ] && cp $R/gpurun_out/state/frames_lead$l.txt ${P}_steady_states_kernel_trace_lead$l.txt; done
+cd /tmp
 echo "== march anatomy, scheduler timeline"
 python $R/tools/prof/ray_anatomy.py 300 2>&1 | grep -v amdgpu.ids > ${P}_ray_anatomy_cfg3_300frames.txt; tail -3 ${P}_ray_anatomy_cfg3_300frames.txt
 python $R/tools/prof/runner_timeline.py 2>&1 | grep -v amdgpu.ids > ${P}_runner_timeline_cfg3.txt; tail -4 ${P}_runner_timeline_cfg3.txt
