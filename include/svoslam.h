@@ -527,6 +527,27 @@ int svoslam_camera_set_acc(svoslam_camera *cam, double *d_acc);
 int svoslam_camera_tracking_lost_count(svoslam_camera *cam, int32_t *count, void *stream);
 /* switches the photometric RGB-D term on (see svoslam_rgbd_cost above); only before the first frame */
 int svoslam_camera_set_rgbd(svoslam_camera *cam, int32_t enable);
+/* Frame-to-model tracking (second half).  OWN SPECIFICATION: the reference tracks every frame against the
+ * previous FRAME's maps and leaves the rest as a TODO (src/sensor/rgbd_camera.cpp:185: "ICP should not swap, as
+ * last_frame should be updated by a different function"); these three entry points are that different function.
+ *   svoslam_raycast_model_depth   the map ray-cast into a depth image in the SENSOR's pixel grid and unit: pixel (x, y)
+ *       looks along ((x - w/2)/fx, (h/2 - y)/fy, 1) (the direction generateVertexMap gives it, image_kernels.cu:24-58)
+ *       carried into the map by cam_to_world (the fusion transform of main.cpp:40; exactly one of the host matrix /
+ *       the device pointer -- e.g. svoslam_camera_fusion_transform_device -- is given); marched as coneTrace marches
+ *       (cone_tracing_kernels.cu:53-146, pixel scale 1/fy) to the first sample whose node has A >= 254; the pixel is
+ *       rint(1000 z) as uint16, 0 = nothing met.  d_steps (optional): 1 x uint64 device counter of march steps.
+ *   svoslam_camera_set_model_depth   such an image goes through the front end of a sensor frame (bilateral filter,
+ *       pyramid, vertex + normal maps: rgbd_camera.cpp:62-93) into a map set of its own.  Non-blocking, stream-ordered.
+ *       d_depth == NULL: no model -- the following frames are tracked against the previous frame, until the next one.
+ *   svoslam_camera_set_frame_to_model(cam, 1)   every ICP iteration associates the incoming frame with that set (once one
+ *       has been given) instead of the previous frame's maps; everything else -- gates, sums, solve, pose composition
+ *       -- is RGBDCamera::update unchanged.  Not combined with the photometric term (SVOSLAM_ERR_INVALID_ARG).
+ * Restated on the CPU as ora_raycast_model_depth / ora_camera_set_model_depth / ora_camera_set_frame_to_model. */
+int svoslam_raycast_model_depth(uint16_t *d_depth, int32_t width, int32_t height, float fx, float fy, const float *cam_to_world,
+                                const float *d_cam_to_world, const uint32_t *d_octree, const float center[3], float size,
+                                unsigned long long *d_steps, void *stream);
+int svoslam_camera_set_model_depth(svoslam_camera *cam, const uint16_t *d_depth, void *stream);
+int svoslam_camera_set_frame_to_model(svoslam_camera *cam, int32_t enable);
 /* the newest timestamp the camera has accepted (rgbd_camera.cpp:55-59 skips frames that are not newer); *have = 0
  * before the first frame.  Host state, no device access. */
 int svoslam_camera_latest_timestamp(svoslam_camera *cam, int32_t *have, long long *timestamp);

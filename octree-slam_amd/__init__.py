@@ -182,6 +182,9 @@ SIGNATURES = {
     "svoslam_difference": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "svoslam_rgbd_cost": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _i32, _i32, _fp, _fp, _vp]),
     "svoslam_camera_set_rgbd": (C.c_int, [_vp, _i32]),
+    "svoslam_raycast_model_depth": (C.c_int, [_vp, _i32, _i32, _f32, _f32, _fp, _vp, _vp, _fp, _f32, _vp, _vp]),
+    "svoslam_camera_set_model_depth": (C.c_int, [_vp, _vp, _vp]),
+    "svoslam_camera_set_frame_to_model": (C.c_int, [_vp, _i32]),
     "svoslam_icp_cost2": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _fp, _fp, _vp]),
     "svoslam_icp_cost": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _fp, _fp, C.POINTER(_i32), _vp]),
     "svoslam_icp_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -800,6 +803,20 @@ def cone_trace_svo(out, fov, view, pool_ptr, center, size, mode=RENDER_REFERENCE
     return out
 
 
+def raycast_model_depth(out, fx, fy, pool_ptr, center, size, cam_to_world=None, cam_to_world_ptr=None, counters=None):
+    """the map ray-cast into a depth image in the sensor's pixel grid (`out`: cuda uint16 [h, w]); the pose as a host matrix
+    (16 floats, column-major: the fusion transform) or as a device pointer (Camera.fusion_transform_ptr()).  Own
+    specification: include/svoslam.h, svoslam_raycast_model_depth."""
+    h, w = int(out.shape[0]), int(out.shape[1])
+    if (cam_to_world is None) == (cam_to_world_ptr is None):
+        raise ValueError("exactly one of cam_to_world / cam_to_world_ptr")
+    host = _fa(cam_to_world, 16) if cam_to_world is not None else None
+    check(lib().svoslam_raycast_model_depth(_ptr(out), w, h, float(fx), float(fy), host,
+                                            C.c_void_p(int(cam_to_world_ptr)) if cam_to_world_ptr is not None else C.c_void_p(0),
+                                            C.c_void_p(int(pool_ptr)), _fa(center, 3), float(size), _ptr(counters), _stream()))
+    return out
+
+
 def cone_trace_svo_band(out, row_first, rows, fov, view, pool_ptr, center, size, mode=RENDER_REFERENCE, counters=None):
     """rows [row_first, row_first+rows) of the same render into the full-frame buffer `out`."""
     h, w = int(out.shape[0]), int(out.shape[1])
@@ -1033,6 +1050,14 @@ class Camera:
     def set_rgbd(self, enable=True):
         """photometric RGB-D term in every ICP iteration (rgbd_camera.cpp:126-141 switched on); before the first frame"""
         check(lib().svoslam_camera_set_rgbd(self._h, 1 if enable else 0))
+
+    def set_model_depth(self, depth):
+        """frame-to-model tracking: `depth` (cuda uint16 [h, w], e.g. raycast_model_depth from the pose of the frame just
+        tracked) becomes the map set the ICP tracks against (own specification: include/svoslam.h)"""
+        check(lib().svoslam_camera_set_model_depth(self._h, _ptr(depth), _stream()))   # (None: no model, frame to frame until the next one)
+
+    def set_frame_to_model(self, enable=True):
+        check(lib().svoslam_camera_set_frame_to_model(self._h, 1 if enable else 0))
 
     def reset(self):
         """identity pose, no frame seen; buffers and recorded graphs kept"""

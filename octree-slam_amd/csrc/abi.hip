@@ -8,6 +8,7 @@
 #include "icp.hpp"
 #include "image_kernels.hpp"
 #include "mesh.hpp"
+#include "model_depth.hpp"
 #include "frame_io.hpp"
 #include "pool_grid.hpp"
 #include "stage_timing.hpp"
@@ -479,6 +480,21 @@ int svoslam_rgbd_cost(const float *d_last_intensity, const float *d_last_gradien
 int svoslam_camera_set_rgbd(svoslam_camera *cam, int32_t enable) {
   NEED_DEVICE();
   return camera_set_rgbd(cam, enable);
+}
+
+int svoslam_raycast_model_depth(uint16_t *d_depth, int32_t width, int32_t height, float fx, float fy, const float *cam_to_world,
+                                const float *d_cam_to_world, const uint32_t *d_octree, const float center[3], float size,
+                                unsigned long long *d_steps, void *stream) {
+  NEED_DEVICE();
+  return raycast_model_depth(d_depth, width, height, fx, fy, cam_to_world, d_cam_to_world, d_octree, center, size, d_steps, S(stream));
+}
+int svoslam_camera_set_model_depth(svoslam_camera *cam, const uint16_t *d_depth, void *stream) {
+  NEED_DEVICE();
+  return camera_set_model_depth(cam, d_depth, S(stream));
+}
+int svoslam_camera_set_frame_to_model(svoslam_camera *cam, int32_t enable) {
+  NEED_DEVICE();
+  return camera_set_frame_to_model(cam, enable);
 }
 
 int svoslam_icp_cost(const float *d_last_vertex, const float *d_last_normal, const float *d_cur_vertex,

@@ -603,6 +603,11 @@ struct svoslam_camera {
   hipStream_t cap_stream = nullptr;  // stream whose resident-workgroup capacity is cached below
   int capacity = 0;
   bool delta_fed = false;  // poses come from camera_apply_delta: there are no maps of the previous frame to track against
+  // frame-to-model tracking (off by default): a map set of its own, filled by camera_set_model_depth, that the
+  // ICP associates the incoming frame with instead of the previous frame's maps (the TODO of rgbd_camera.cpp:185)
+  bool to_model = false, have_model = false;
+  uint16_t *model_filt[3] = {nullptr, nullptr, nullptr};
+  float *model_v[3] = {nullptr, nullptr, nullptr}, *model_n[3] = {nullptr, nullptr, nullptr};
 };
 
 namespace svoslam {
@@ -662,6 +667,7 @@ int camera_reset(svoslam_camera *c) {
   c->frame_has_icp = false;
   c->ring_slot = 0;
   c->delta_fed = false;
+  c->have_model = false;  // (the mode itself is a setting and stays)
   return SVOSLAM_OK;
 }
 
@@ -690,6 +696,11 @@ int camera_destroy(svoslam_camera *c) {
   if (c->d_rows) (void)hipFree(c->d_rows);
   if (c->work_v) (void)hipFree(c->work_v);
   if (c->work_n) (void)hipFree(c->work_n);
+  for (int i = 0; i < 3; i++) {
+    if (c->model_filt[i]) (void)hipFree(c->model_filt[i]);
+    if (c->model_v[i]) (void)hipFree(c->model_v[i]);
+    if (c->model_n[i]) (void)hipFree(c->model_n[i]);
+  }
   delete c;
   return SVOSLAM_OK;
 }
@@ -771,6 +782,7 @@ static LevelArgs level_args(const svoslam_camera *c, int level) {
   const int r0 = c->band_first >> level, r1 = (c->band_first + c->band_rows) >> level;
   const int cur = (int)(c->tracked % 3u), last = (int)((c->tracked + 2u) % 3u);  // frames f and f-1
   a.lv = c->vert[last][level]; a.ln = c->norm[last][level];
+  if (c->to_model && c->have_model) { a.lv = c->model_v[level]; a.ln = c->model_n[level]; }
   a.cv = c->vert[cur][level]; a.cn = c->norm[cur][level];
   a.first = r0 * a.w; a.num = (r1 - r0) * a.w;
   return a;
@@ -911,7 +923,7 @@ int camera_track(svoslam_camera *c, hipStream_t s) {
   GraphKey key;
   key.add((unsigned long long)(c->tracked % 3u)).add((unsigned long long)has_icp)
      .add((unsigned long long)c->band_first).add((unsigned long long)c->band_rows).add((unsigned long long)c->rgbd)
-     .add((unsigned long long)work_maps).add((unsigned long long)top_level);
+     .add((unsigned long long)work_maps).add((unsigned long long)top_level).add((unsigned long long)(c->to_model && c->have_model));
   auto enqueue = [&]() -> int {
     if (has_icp) {
       for (int level = top_level; level >= 0; level--) {  // coarse to fine, :103
@@ -1026,6 +1038,7 @@ int camera_apply_delta(svoslam_camera *c, const float *d_delta, long long timest
 int camera_set_rgbd(svoslam_camera *c, int enable) {
   if (!c) return SVOSLAM_ERR_INVALID_ARG;
   if (c->prepared != 0 && (enable != 0) != c->rgbd) return SVOSLAM_ERR_INVALID_ARG;
+  if (enable && c->to_model) return SVOSLAM_ERR_INVALID_ARG;  // (not combined with frame-to-model tracking)
   if (enable && !c->tmp_inten) {
     const size_t n0 = (size_t)c->width * c->height;
     SVO_HIP(hipMalloc((void **)&c->tmp_inten, n0 * 4));
@@ -1040,6 +1053,41 @@ int camera_set_rgbd(svoslam_camera *c, int enable) {
     }
   }
   c->rgbd = enable != 0;
+  return SVOSLAM_OK;
+}
+
+// Frame-to-model tracking (own specification; oracle: ora_camera_set_model_depth / ora_camera_set_frame_to_model).  d_depth
+// -- a depth image in the sensor's pixel grid and unit, e.g. raycast_model_depth from the pose of the frame just tracked --
+// goes through the front end of a sensor frame (bilateral filter, three pyramid levels, vertex and normal maps:
+// rgbd_camera.cpp:62-93) into a map set of its own.  Stream-ordered: the caller orders it behind the tracker launch that
+// still reads the previous model and ahead of the next one.
+int camera_set_model_depth(svoslam_camera *c, const uint16_t *d_depth, hipStream_t s) {
+  if (!c) return SVOSLAM_ERR_INVALID_ARG;
+  if (!d_depth) { c->have_model = false; return SVOSLAM_OK; }  // no model: the following frames are tracked against the previous frame again
+  const int W = c->width, H = c->height;
+  for (int i = 0; i < 3; i++)
+    if (!c->model_v[i]) {
+      const size_t n = (size_t)(W >> i) * (size_t)(H >> i);
+      SVO_HIP(hipMalloc((void **)&c->model_filt[i], n * 2));
+      SVO_HIP(hipMalloc((void **)&c->model_v[i], n * 12));
+      SVO_HIP(hipMalloc((void **)&c->model_n[i], n * 12));
+    }
+  SVO_TRY(bilateral_filter(d_depth, c->model_filt[0], W, H, s));
+  for (int i = 0; i < 3; i++) {
+    const int w = W >> i, h = H >> i;
+    SVO_TRY(generate_vertex_normal_maps(c->model_filt[i], c->model_v[i], c->model_n[i], w, h, c->fx, c->fy, W, H, s));
+    if (i != 2) SVO_TRY(subsample_depth_u16_to(c->model_filt[i], c->model_filt[i + 1], w, h, s));
+  }
+  c->have_model = true;
+  return SVOSLAM_OK;
+}
+
+// every ICP iteration associates the incoming frame with the model set (once one has been given) instead of the
+// previous frame's maps; not combined with the photometric term (the model has no intensity image)
+int camera_set_frame_to_model(svoslam_camera *c, int enable) {
+  if (!c) return SVOSLAM_ERR_INVALID_ARG;
+  if (enable && c->rgbd) return SVOSLAM_ERR_INVALID_ARG;
+  c->to_model = enable != 0;
   return SVOSLAM_OK;
 }
 

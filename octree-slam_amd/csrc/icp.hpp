@@ -27,6 +27,8 @@ int camera_pair_delta(svoslam_camera *c, const uint16_t *d_depth_prev, const uin
                       const uint8_t *d_rgb_cur, float *d_delta, hipStream_t s);
 int camera_apply_delta(svoslam_camera *c, const float *d_delta, long long timestamp, int32_t *processed, hipStream_t s);
 int camera_set_rgbd(svoslam_camera *c, int enable);
+int camera_set_model_depth(svoslam_camera *c, const uint16_t *d_depth, hipStream_t s);
+int camera_set_frame_to_model(svoslam_camera *c, int enable);
 int rgbd_cost(svoslam::DeviceBuffer &scratch, const float *last_i, const float *last_g, const float *last_v, const float *cur_i,
               const float *cur_v, int w, int h, float fx, float fy, int img_w, int img_h, float A[36], float b[6], hipStream_t s);
 int camera_set_band(svoslam_camera *c, int first_row, int rows);

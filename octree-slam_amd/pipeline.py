@@ -256,7 +256,7 @@ class EmulatedRank:
 
 class SlamPipeline:
     def __init__(self, width, height, max_depth, center, half_edge, render_mode=pkg.RENDER_REFERENCE, dist=None,
-                 pool_capacity_nodes=1 << 20, count_steps=False):
+                 pool_capacity_nodes=1 << 20, count_steps=False, frame_to_model=False, model_min_coverage=0.5):
         self.w, self.h, self.depth = width, height, max_depth
         self.center, self.edge = tuple(float(c) for c in center), float(half_edge)
         self.mode = render_mode
@@ -306,6 +306,32 @@ class SlamPipeline:
                 base, rem = divmod(height, self.dist.world)
                 self._band_pad = (base + (1 if rem else 0)) * width
         self.last_stats = None
+        # frame-to-model tracking (own specification: include/svoslam.h): after a frame has been fused, the map is
+        # ray-cast into a depth image from that frame's pose and the next frame is tracked against it instead of against
+        # the previous frame's maps.  frame() only (one GPU, stage by stage); the native frame loop does not carry it.
+        # A node answers a model ray only once it has been observed ~64 times (A >= 254, what retires a ray in coneTrace): a
+        # young map has no model.  The model is used for the next frame when at least model_min_coverage of its pixels are
+        # valid, otherwise that frame is tracked against the previous frame (one host read of a pixel count per frame).
+        self.frame_to_model = bool(frame_to_model)
+        self.model_min_coverage = float(model_min_coverage)
+        self.model_used = 0        # frames whose model was accepted
+        if self.frame_to_model:
+            assert not self.dist.enabled and not self.frame_sharded
+            self.model_depth = torch.zeros((height, width), dtype=torch.int16, device=dev)   # (uint16 bit pattern, as the sensor frames)
+            self.model_steps = torch.zeros(1, dtype=torch.int64, device=dev) if count_steps else None
+            self.cam.set_frame_to_model(True)
+
+    def refresh_model(self):
+        """the map as a depth image from the pose of the frame just tracked -> the maps the next frame is tracked against"""
+        pkg.raycast_model_depth(self.model_depth, self.focal, self.focal, self.pool.data_ptr, self.center, self.edge,
+                                cam_to_world_ptr=self.cam.fusion_transform_ptr(), counters=self.model_steps)
+        covered = int((self.model_depth != 0).sum().item())
+        if covered >= self.model_min_coverage * self.w * self.h:
+            self.cam.set_model_depth(self.model_depth)
+            self.model_used += 1
+        else:
+            self.cam.set_model_depth(None)
+        return self.model_depth
 
     def reset(self):
         """empty map and a fresh tracker; allocations, streams and the launch graphs recorded so far are kept"""
@@ -412,6 +438,8 @@ class SlamPipeline:
         else:
             self.backproject(depth)
             self.fuse(rgb)
+        if self.frame_to_model:
+            self.refresh_model()
         return self.render(view)
 
     # -- software-pipelined stream of frames ------------------------------------------------
@@ -433,6 +461,7 @@ class SlamPipeline:
         n = len(timestamps)
         if n == 0:
             return
+        assert not self.frame_to_model, "frame-to-model tracking runs through frame()"
         if self.frame_sharded:
             assert on_render is None
             return self.run_stream_sharded(depths, rgbs, timestamps, views)

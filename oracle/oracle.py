@@ -79,6 +79,12 @@ def lib(native=False):
     L.ora_difference.argtypes = [f32p, f32p, f32p, C.c_int]
     L.ora_rgbd_cost.argtypes = [f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, f32p, f32p]
     L.ora_camera_set_rgbd.argtypes = [C.c_void_p, C.c_int]
+    L.ora_raycast_model_depth.restype = C.c_int64
+    L.ora_raycast_model_depth.argtypes = [u16p, C.c_int, C.c_int, C.c_float, C.c_float, f32p, u32p, f32p, C.c_float]
+    L.ora_camera_set_model_depth.restype = C.c_int
+    L.ora_camera_set_model_depth.argtypes = [C.c_void_p, u16p]
+    L.ora_camera_set_frame_to_model.restype = C.c_int
+    L.ora_camera_set_frame_to_model.argtypes = [C.c_void_p, C.c_int]
     L.ora_icp_cost.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p]
     L.ora_icp_cost.restype = C.c_int
     L.ora_icp_cost2_raw.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, i64p]
@@ -238,6 +244,22 @@ def cone_trace(words, w, h, fov, view, center, size, mode=RENDER_REFERENCE, L=No
     steps = L.ora_cone_trace_svo(_p(pos, C.c_uint8), w, h, fov, _p(view, C.c_float), wptr,
                                  _p(c, C.c_float), size, mode, C.byref(lv))
     return pos, int(steps), int(lv.value)
+
+
+def raycast_model_depth(words, w, h, fx, fy, cam_to_world, center, size, L=None):
+    """the map ray-cast into a depth image in the sensor's pixel grid and unit (own specification: svoslam_oracle.c,
+    ora_raycast_model_depth) -> (uint16 [h, w], march steps)"""
+    L = L or lib()
+    if isinstance(words, Pool):
+        wptr = words._p.data
+    else:
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        wptr = _p(words, C.c_uint32)
+    m = _f32(cam_to_world).reshape(16)
+    c = _f32(center)
+    out = np.zeros((h, w), dtype=np.uint16)
+    steps = L.ora_raycast_model_depth(_p(out, C.c_uint16), w, h, fx, fy, _p(m, C.c_float), wptr, _p(c, C.c_float), size)
+    return out, int(steps)
 
 
 # ------------------------------------------------------------------ sensor
@@ -458,6 +480,16 @@ class Camera:
 
     def set_rgbd(self, enable=True):
         self._L.ora_camera_set_rgbd(self._c, 1 if enable else 0)
+
+    def set_model_depth(self, depth):
+        if depth is None:       # no model: frame to frame until the next one
+            return self._L.ora_camera_set_model_depth(self._c, None)
+        d = np.ascontiguousarray(depth, dtype=np.uint16)
+        assert d.shape == (self.h, self.w)
+        return self._L.ora_camera_set_model_depth(self._c, _p(d, C.c_uint16))
+
+    def set_frame_to_model(self, enable=True):
+        return self._L.ora_camera_set_frame_to_model(self._c, 1 if enable else 0)
 
     def tracking_lost_count(self):
         return int(self._L.ora_camera_tracking_lost_count(self._c))

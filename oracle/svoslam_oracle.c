@@ -707,6 +707,74 @@ int64_t ora_cone_trace_svo(uint8_t *pos, int w, int h, float fov, const float vi
   return total_steps;
 }
 
+/* SURVEY 8f.3, second half: the map ray-cast into a DEPTH image, the model a frame-to-model ICP tracks against.
+ * OWN SPECIFICATION -- the reference has no such function; rgbd_camera.cpp:185 only leaves the TODO ("ICP should not
+ * swap, as last_frame should be updated by a different function").  Stated in the terms of the functions it sits
+ * between: pixel (x, y) looks along d = ((x - w/2) / fx, (h/2 - y) / fy, 1) of the sensor frame (the direction
+ * generateVertexMap gives that pixel, image_kernels.cu:24-58), carried into the map by cam_to_world (the matrix
+ * main.cpp:40 applies to the vertex map, operator*(mat4, vec4)); the ray is marched exactly as coneTrace marches
+ * (cone_tracing_kernels.cu:53-146: START_DIST, LOD = ceil(log2(size / (ray length x pixel scale))) with the pixel
+ * scale 1 / fy, descent to the first childless node or the LOD, step = size / 2^level, MAX_RANGE) and stops at the
+ * first sample whose node carries A >= 254 -- what retires a ray there.  Its distance along the optical axis,
+ * ray length / |d|, becomes the pixel: rint(1000 z) as uint16 (the sensor's unit), 0 = nothing met / out of range.
+ * Returns the number of march steps. */
+int64_t ora_raycast_model_depth(uint16_t *depth_out, int w, int h, float fx, float fy, const float cam_to_world[16],
+                                const uint32_t *octree, const float center[3], float size) {
+  int64_t total_steps = 0;
+  const float zero4[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+  float o4[4];
+  mat4_mul_vec4(cam_to_world, zero4, o4);
+  const float origin[3] = {o4[0], o4[1], o4[2]};
+  const float pix_scale = 1.0f / fy;
+  for (int idx = 0; idx < w * h; idx++) {
+    const int px = idx % w, py = idx / w;
+    const float dc[4] = {(float)(px - w / 2) / fx, (float)(h / 2 - py) / fy, 1.0f, 1.0f};
+    float p4[4];
+    mat4_mul_vec4(cam_to_world, dc, p4);
+    const float dir[3] = {p4[0] - origin[0], p4[1] - origin[1], p4[2] - origin[2]};
+    const float len_d = length3(dir);
+    uint16_t out = 0;
+    if (finitef_(len_d) && len_d > 0.0f) {
+      float ray[3];
+      normalize3(dir, ray);
+      for (int k = 0; k < 3; k++) ray[k] = ORA_START_DIST * ray[k];
+      for (int step = 0; step < ORA_MAX_STEPS; step++) {
+        total_steps++;
+        const float target[3] = {origin[0] + ray[0], origin[1] + ray[1], origin[2] + ray[2]};
+        const float ray_len = length3(ray);
+        const float pix_size = ray_len * pix_scale;
+        int depth = ceil_log2_pos((float)(size / pix_size));
+        int node_idx = 0, child_idx = 0;
+        float temp_size = size;
+        float c[3] = {center[0], center[1], center[2]};
+        for (int i = 0; i < depth; i++) {
+          const int x = target[0] > c[0], y = target[1] > c[1], z = target[2] > c[2];
+          node_idx = child_idx + (x + 2 * y + 4 * z);
+          const uint32_t w0 = octree[2 * (size_t)node_idx];
+          if (!(w0 & ORA_FLAG_CHILDREN)) { depth = i + 1; break; }
+          child_idx = (int)(w0 & ORA_CHILD_MASK);
+          temp_size /= 2.0f;
+          c[0] += temp_size * (x ? 1 : -1);
+          c[1] += temp_size * (y ? 1 : -1);
+          c[2] += temp_size * (z ? 1 : -1);
+        }
+        const uint32_t oct_val = octree[2 * (size_t)node_idx + 1];
+        if ((oct_val >> 24) >= 254u) {
+          const float mm = (ray_len / len_d) * 1000.0f;
+          if (mm < 65535.0f) out = (uint16_t)rintf(mm);
+          break;
+        }
+        const float new_dist = size / ldexpf(1.0f, depth);
+        const float s = (ray_len + new_dist) / ray_len;
+        ray[0] *= s; ray[1] *= s; ray[2] *= s;
+        if (length3(ray) > ORA_MAX_RANGE) break;
+      }
+    }
+    depth_out[idx] = out;
+  }
+  return total_steps;
+}
+
 /* ======================================================================== */
 /* sensor (src/sensor/image_kernels.cu)                                      */
 /* ======================================================================== */
@@ -1174,6 +1242,9 @@ struct ora_camera {
   /* photometric RGB-D term (off by default = the reference, which ships it commented out) */
   int rgbd;
   float *last_i[PYR], *cur_i[PYR], *last_g[PYR], *cur_g[PYR]; /* intensity and its Sobel gradient per level */
+  /* frame-to-model tracking (off by default): maps the ICP tracks against instead of the previous frame's */
+  int to_model, have_model;
+  float *model_v[PYR], *model_n[PYR];
 };
 
 ora_camera *ora_camera_create(int w, int h, float fx, float fy) {
@@ -1195,6 +1266,7 @@ void ora_camera_destroy(ora_camera *c) {
   if (!c) return;
   for (int i = 0; i < PYR; i++) { free(c->last_v[i]); free(c->last_n[i]); free(c->cur_v[i]); free(c->cur_n[i]); }
   for (int i = 0; i < PYR; i++) { free(c->last_i[i]); free(c->cur_i[i]); free(c->last_g[i]); free(c->cur_g[i]); }
+  for (int i = 0; i < PYR; i++) { free(c->model_v[i]); free(c->model_n[i]); }
   free(c);
 }
 
@@ -1272,7 +1344,8 @@ int ora_camera_update(ora_camera *c, const uint16_t *depth, const uint8_t *rgb, 
       }
       for (int j = 0; j < PYRAMID_ITERS[i]; j++) {
         float A1[36], b1[6], x[6];
-        ora_icp_cost2(c->last_v[i], c->last_n[i], fv, fn, w, h, A1, b1);
+        const int model = c->to_model && c->have_model; /* the TODO of rgbd_camera.cpp:185: the maps tracked against come from elsewhere */
+        ora_icp_cost2(model ? c->model_v[i] : c->last_v[i], model ? c->model_n[i] : c->last_n[i], fv, fn, w, h, A1, b1);
         if (c->rgbd) { /* rgbd_camera.cpp:126-141 with W_RGBD (:20) applied to the photometric system */
           float A2[36], b2[6];
           ora_rgbd_cost(c->last_i[i], c->last_g[i], c->last_v[i], c->cur_i[i], fv, w, h, c->fx, c->fy, W, H, A2, b2);
@@ -1309,6 +1382,7 @@ int ora_camera_update(ora_camera *c, const uint16_t *depth, const uint8_t *rgb, 
 }
 
 void ora_camera_set_rgbd(ora_camera *c, int enable) {
+  if (enable && c->to_model) return; /* (not combined with frame-to-model tracking) */
   c->rgbd = enable != 0;
   for (int i = 0; i < PYR && enable; i++) {
     size_t n = (size_t)(c->width >> i) * (size_t)(c->height >> i);
@@ -1317,6 +1391,41 @@ void ora_camera_set_rgbd(ora_camera *c, int enable) {
       c->last_g[i] = (float *)calloc(2 * n, sizeof(float)); c->cur_g[i] = (float *)calloc(2 * n, sizeof(float));
     }
   }
+}
+
+/* Frame-to-model tracking (own specification, see ora_raycast_model_depth).  set_model_depth: `depth` -- a depth image
+ * in the sensor's pixel grid and unit, e.g. the map ray-cast from the pose of the frame just tracked -- goes through the
+ * front end of a sensor frame (bilateral filter, three pyramid levels, vertex and normal maps: rgbd_camera.cpp:62-93)
+ * into a map set of its own.  With set_frame_to_model(1) every ICP iteration associates the incoming frame with THAT set
+ * instead of the previous frame's maps, until the next set_model_depth replaces it; frames tracked before any model was
+ * given, and the pose composition, are the reference's.  Not combined with the photometric term (the model has no
+ * intensity image): returns -1. */
+int ora_camera_set_model_depth(ora_camera *c, const uint16_t *depth) {
+  if (!depth) { c->have_model = 0; return 0; } /* no model: the following frames are tracked against the previous frame again */
+  const int W = c->width, H = c->height;
+  for (int i = 0; i < PYR; i++)
+    if (!c->model_v[i]) {
+      size_t n = (size_t)(W >> i) * (size_t)(H >> i) * 3;
+      c->model_v[i] = (float *)malloc(sizeof(float) * n);
+      c->model_n[i] = (float *)malloc(sizeof(float) * n);
+    }
+  uint16_t *filtered = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)W * H);
+  ora_bilateral_filter(depth, filtered, W, H);
+  for (int i = 0; i < PYR; i++) {
+    int w = W >> i, h = H >> i;
+    ora_generate_vertex_map(filtered, c->model_v[i], w, h, c->fx, c->fy, W, H);
+    ora_generate_normal_map(c->model_v[i], c->model_n[i], w, h);
+    if (i != PYR - 1) ora_subsample_depth_u16(filtered, w, h);
+  }
+  free(filtered);
+  c->have_model = 1;
+  return 0;
+}
+
+int ora_camera_set_frame_to_model(ora_camera *c, int enable) {
+  if (enable && c->rgbd) return -1;
+  c->to_model = enable != 0;
+  return 0;
 }
 
 int ora_camera_tracking_lost_count(const ora_camera *c) { return c->lost_count; }

@@ -142,6 +142,11 @@ void ora_camera_last_update(const ora_camera *c, float out[16]);
 int ora_camera_apply_delta(ora_camera *c, const float *update_trans, int levels_lost, long long timestamp);
 int ora_camera_tracking_lost_count(const ora_camera *c);
 void ora_camera_set_rgbd(ora_camera *c, int enable); /* adds W_RGBD x the photometric system to every ICP iteration */
+/* frame-to-model tracking (own specification: see svoslam_oracle.c) */
+int64_t ora_raycast_model_depth(uint16_t *depth_out, int w, int h, float fx, float fy, const float cam_to_world[16],
+                                const uint32_t *octree, const float center[3], float size);
+int ora_camera_set_model_depth(ora_camera *c, const uint16_t *depth);
+int ora_camera_set_frame_to_model(ora_camera *c, int enable);
 /* model matrix used by main.cpp:40 : mat4(orientation) * translate(I, position) */
 void ora_camera_fusion_transform(const ora_camera *c, float out[16]);
 /* last A,b,x of the last processed frame, for tests */
