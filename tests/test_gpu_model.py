@@ -201,3 +201,38 @@ def test_young_map_has_no_model_and_tracks_frame_to_frame(env, oracle):
             cam.set_model_depth(None)
         cam.update(d, c, k); ref.update(d, c, k)
     assert np.array_equal(cam.pose()[1], ref.pose()[1])
+
+
+def test_model_depth_full_size_cfg3_geometry(env, oracle):
+    """BASELINE config 3's geometry (640x480, depth-12 map, half-edge 4.096 m about (0, 1.5, 0)): the first frame observed 64
+    times, the model image from its pose and from the pose three frames on, against the oracle bit for bit"""
+    pkg, torch, synth, pl = env
+    w, h, depth, center, edge = 640, 480, 12, (0.0, 1.5, 0.0), 4.096
+    P = pl.SlamPipeline(w, h, depth, center, edge, frame_to_model=True, count_steps=True, pool_capacity_nodes=1 << 24)
+    f = P.focal
+    ocam, opool = oracle.Camera(w, h, f, f), oracle.Pool()
+    ocam.set_frame_to_model(True)
+    d, c = synth.render_frame(0, w, h)
+    dn, cn = d.numpy().view(np.uint16), c.numpy()
+    P.track(d.cuda(), c.cuda(), 0); ocam.update(dn, cn, 0)
+    P.backproject(d.cuda())
+    v = oracle.transform_vertex_map(oracle.vertex_map(dn, f, f, w, h), ocam.fusion_transform())
+    for _ in range(64):
+        P.fuse(c.cuda())
+        opool.insert_cloud(v.reshape(-1, 3), cn.reshape(-1, 3), depth, center, edge)
+    assert P.pool.size == opool.size and np.array_equal(P.pool.words(), opool.words())
+    total = 0
+    for k in (0, 3):
+        if k:
+            d, c = synth.render_frame(k, w, h)
+            P.track(d.cuda(), c.cuda(), k); ocam.update(d.numpy().view(np.uint16), c.numpy(), k)
+            p, o = P.cam.pose(); rp, ro = ocam.pose()      # (tracked against the model of frame 0 on both sides)
+            assert np.array_equal(o.view(np.uint32), ro.view(np.uint32)) and np.array_equal(p.view(np.uint32), rp.view(np.uint32))
+        model = u16(P.refresh_model())
+        omodel, steps = oracle.raycast_model_depth(opool, w, h, f, f, ocam.fusion_transform(), center, edge)
+        total += steps
+        assert np.array_equal(model, omodel), (k, describe_mismatch(model, omodel))
+        assert int(P.model_steps.item()) == total
+        ocam.set_model_depth(omodel if (omodel > 0).sum() >= 0.5 * w * h else None)
+    valid = (omodel > 0)
+    assert valid.mean() > 0.5
