@@ -8,8 +8,10 @@
 //   LOD = ceil(log2(size / (ray length x pixel scale))), pixel scale 1 / fy, descent to the first childless node or the
 //   LOD, step = size / 2^level, MAX_RANGE) and stops at the first sample whose node carries A >= 254 -- what retires a ray
 //   there; rint(1000 x ray length / |d|) is the pixel (uint16 millimetres along the optical axis), 0 = nothing met.
-// One ray per lane, the descent from the root with the reference's own centre arithmetic (no level grid, no bricks): a
-// few march-times per image; the mode is opt-in and this kernel is its first, plain form.
+// One ray per lane, the descent from the root with the reference's own centre arithmetic (no level grid, no bricks): 0.19 ms
+// for a 640x480 image of the saturated first frame of config 3 (5.5 M steps).  Resuming a step's descent at the level-8 node of
+// the previous step (faces kept as lo < t <= hi per axis; exact, bit-equal) was built and measured: 0.21 ms -- the upper levels
+// are L1 / L2 hits whose loads overlap, the twelve extra registers and six compares cost more.  The mode is opt-in.
 #include "model_depth.hpp"
 
 namespace svoslam {
