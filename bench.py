@@ -39,7 +39,9 @@ fusion; the fusion's 18 launches are timed in a short SEQUENTIAL pass over three
 (event pairs on the map stream would cost the timed region ~1.5 %).  `traffic` = HBM bytes per frame from the committed
 rocprofv3 PMC passes (profiles/pmc_traffic.json, written by tools/prof/profile_round.sh; counters cannot be sampled
 from inside the process) -- missing entries for the chosen workload are an ERROR, not a null.
-`cpu_baseline` times the single-thread CPU oracle (kind "port") on the first frames of the same stream.
+`cpu_baseline` times the single-thread CPU oracle (kind "port") on the TIMED frames of the same stream, continued from the
+GPU's map and pose before them.  `value` is the median of --repeats windows (each from an empty map); `runs` lists them all,
+`pipeline_fill` states the share of the cold five-stream pipeline's fill inside the window.
 """
 import argparse
 import importlib
@@ -62,11 +64,14 @@ WORKLOADS = {
     "cfg3": (640, 480, 12, (0.0, 1.5, 0.0), 4.096),
     "cfg4": (1920, 1080, 14, (0.0, 1.5, 0.0), 8.192),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_MEASURED_COPY_GBS = 6290.0  # the same guide's measured copy ceiling; quoted beside the spec peak
 
 
-def cpu_baseline(depth_frames, rgb_frames, views, width, height, max_depth, center, edge, budget_s=20.0):
-    """Single-thread CPU oracle on the first frames of the same stream (reported baseline only)."""
+def cpu_baseline(depth_frames, rgb_frames, views, first, width, height, max_depth, center, edge, seed_words, seed_pose, budget_s=20.0):
+    """Single-thread CPU oracle on the TIMED frames of the same stream (reported baseline only): its pool starts from the
+    words of the GPU's map after frame first - 1 (bit-identical to the oracle's own, tests/test_gpu_fullsize.py), its tracker
+    from the GPU's pose and the maps of frame first - 1 (built untimed), then frames first, first + 1, ... until the budget."""
     import numpy as np
     from oracle import oracle as ora
     try:
@@ -80,8 +85,13 @@ def cpu_baseline(depth_frames, rgb_frames, views, width, height, max_depth, cent
     focal = 570.3 * width / 640.0
     cam = ora.Camera(width, height, focal, focal, L=L)
     pool = ora.Pool(L=L)
+    if first > 0:
+        pool.load_words(seed_words)
+        k0 = first - 1
+        cam.update(depth_frames[k0].cpu().numpy().view(np.uint16), rgb_frames[k0].cpu().numpy(), k0)   # the "last frame" maps
+        cam.set_pose(*seed_pose)
     n_done, t_total = 0, 0.0
-    for k in range(len(depth_frames)):
+    for k in range(first, len(depth_frames)):
         d = depth_frames[k].cpu().numpy().view(np.uint16)
         c = rgb_frames[k].cpu().numpy()
         t0 = time.perf_counter()
@@ -101,8 +111,9 @@ def cpu_baseline(depth_frames, rgb_frames, views, width, height, max_depth, cent
         if t_total > budget_s:
             break
     return {"value": n_done / t_total, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "first %d frames of the same %dx%d depth-%d stream, CPU oracle (gcc %s, single thread), %.1f s"
-                      % (n_done, width, height, max_depth, flags, t_total)}
+            "sample": "frames %d..%d of the same %dx%d depth-%d stream = the first %d of the GPU's timed frames, from the map and pose the GPU "
+                      "had before them (%d nodes); CPU oracle (gcc %s, single thread), %.1f s"
+                      % (first + 1, first + n_done, width, height, max_depth, n_done, pool.size, flags, t_total)}
 
 
 def main():
@@ -127,6 +138,12 @@ def main():
     ap.add_argument("--map-frames", type=int, default=None,
                     help="frames in the map when the timed region ENDS (default: 300 for cfg3 = BASELINE config 3, K + W for "
                          "cfg4); the frames before the warm-up are fused untimed; 0 = K + W")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-frame window is measured this many times, each from an empty map (reset + history + warm-up + K timed "
+                         "frames); `value` is the median run, `runs` lists them all")
+    ap.add_argument("--no-other-partition", action="store_true",
+                    help="N > 1: do not also measure the other partition (by default the line carries both north_star's row-band "
+                         "'allreduce' scheme and the frame-sharded 'deltas' scheme: `value` is --exchange's, `other_partition` the other's)")
     ap.add_argument("--no-stage-pass", action="store_true", help="skip the sequential per-stage pass after the timed region")
     ap.add_argument("--allow-missing-traffic", action="store_true",
                     help="profiles/pmc_traffic.json incomplete for this workload: report traffic null instead of failing "
@@ -158,11 +175,27 @@ def main():
         # likewise the peer-to-peer mailbox: its collect kernel polls until the peers have posted, and processes that share ONE
         # device are time-sliced by the hardware scheduler (milliseconds per exchange instead of microseconds)
         os.environ.setdefault("SVOSLAM_MAILBOX", "0")
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libsvoslam_hip has no CPU fallback")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks HERE (one process per GPU under torch.distributed.run)
+        # -- never measure one GPU and print it under --gpus N (VERDICT r03 missing 3)
+        if args.emulate_rank:
+            raise SystemExit("--emulate-rank runs ONE rank on one GPU: use --gpus 1")
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and not one_device:
+            raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s); refusing to run fewer ranks than asked for" % (args.gpus, ndev))
+        import socket
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("bench.py: --gpus %d without WORLD_SIZE: launching %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        raise SystemExit(subprocess.call(cmd))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1 and not one_device and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but %d visible GPU(s)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     force_dist = os.environ.get("SVOSLAM_FORCE_DIST") == "1"   # exercise the row-band/RCCL code path on one GPU
@@ -185,6 +218,8 @@ def main():
             tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             tdist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if tdist.get_world_size() != world:
+            raise SystemExit("bench.py: the process group has %d ranks, --gpus says %d" % (tdist.get_world_size(), world))
         dist = pl.DistContext(rank, world, force=force_dist, exchange=args.exchange)
     arch = pkg.device_arch()
     assert arch and arch.startswith("gfx950"), arch
@@ -244,63 +279,134 @@ def main():
         P.run_stream(depth[:ninit], rgb[:ninit], list(range(ninit)), views[:ninit])
         barrier()
         P.reset()
-    # the map's history (untimed) and the warm-up, through the same streamed path as the timed region
-    t0w = pre + Wm                                # first timed frame
-    if args.no_overlap:
-        for k in range(t0w):
-            P.frame(depth[k], rgb[k], k, views[k])
-    else:
-        if pre:
-            expect(0, pre)
-            P.run_stream(depth[:pre], rgb[:pre], list(range(pre)), views[:pre])
-            barrier()
-        if Wm:
-            expect(pre, t0w)
-            P.run_stream(depth[pre:t0w], rgb[pre:t0w], list(range(pre, t0w)), views[pre:t0w])
-    barrier()
-    P.counters.zero_()
-    barrier()
-    # HIP events around each trace kernel and each tracker launch (group), recorded by the library on the launch streams
-    pkg.stage_timing([pkg.STAGE_MARCH, pkg.STAGE_TRACKER])
-    h_depth = h_rgb = None
-    if args.include_h2d:     # the timed frames leave the device; what stays are pinned host copies
-        h_depth, h_rgb = depth[t0w:total].cpu().pin_memory(), rgb[t0w:total].cpu().pin_memory()
-        depth[t0w:total].zero_(); rgb[t0w:total].zero_()
+
+    cur = {"P": P}
+
+    def history(upto):
+        """the map's history (untimed) and the warm-up through the same streamed path as the timed region: frames [0, upto)
+        from an EMPTY map and a fresh tracker (allocations, streams and recorded launch graphs are kept)"""
+        P = cur["P"]
+        P.reset()
+        if args.no_overlap:
+            for k in range(upto):
+                P.frame(depth[k], rgb[k], k, views[k])
+        else:
+            a = min(pre, upto)
+            if a:
+                expect(0, a)
+                P.run_stream(depth[:a], rgb[:a], list(range(a)), views[:a])
+                barrier()
+            if upto > a:
+                expect(a, upto)
+                P.run_stream(depth[a:upto], rgb[a:upto], list(range(a, upto)), views[a:upto])
         barrier()
-    t0 = time.perf_counter()
-    if args.include_h2d:     # enqueued ahead of the frame loop on the same stream (not overlapped: an upper bound of its cost)
-        depth[t0w:total].copy_(h_depth, non_blocking=True)
-        rgb[t0w:total].copy_(h_rgb, non_blocking=True)
-    if args.no_overlap:
-        for i in range(K):
-            k = t0w + i
-            P.track(depth[k], rgb[k], k)
-            if dist is None:
-                P.fuse_frame(depth[k], rgb[k])     # the kernels of the frame loop (fused front end), one after the other
-            else:
-                P.backproject(depth[k])
-                P.fuse(rgb[k])
-            P.render(views[k])
-    else:
-        # four HIP streams (pipeline.run_stream); every frame still goes through
-        # track -> back-project -> fuse -> render with the same results
-        expect(t0w, total)
-        P.run_stream(depth[t0w:total], rgb[t0w:total], list(range(t0w, total)), views[t0w:total])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        import torch.distributed as tdist
-        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-    elapsed = float(t.item())
+
+    def timed_window(first, include_h2d=False):
+        """frames [first, total) timed between barrier + synchronize on both sides; the state before it is history(first)"""
+        P = cur["P"]
+        history(first)
+        P.counters.zero_()
+        barrier()
+        # HIP events around each trace kernel and each tracker launch (group), recorded by the library on the launch streams
+        pkg.stage_timing([pkg.STAGE_MARCH, pkg.STAGE_TRACKER])
+        h_depth = h_rgb = None
+        if include_h2d:     # the timed frames leave the device; what stays are pinned host copies
+            h_depth, h_rgb = depth[first:total].cpu().pin_memory(), rgb[first:total].cpu().pin_memory()
+            depth[first:total].zero_(); rgb[first:total].zero_()
+            barrier()
+        t0 = time.perf_counter()
+        if include_h2d:     # enqueued ahead of the frame loop on the same stream (not overlapped: an upper bound of its cost)
+            depth[first:total].copy_(h_depth, non_blocking=True)
+            rgb[first:total].copy_(h_rgb, non_blocking=True)
+        if args.no_overlap:
+            for k in range(first, total):
+                P.track(depth[k], rgb[k], k)
+                if dist is None:
+                    P.fuse_frame(depth[k], rgb[k])     # the kernels of the frame loop (fused front end), one after the other
+                else:
+                    P.backproject(depth[k])
+                    P.fuse(rgb[k])
+                P.render(views[k])
+        else:
+            # the HIP streams of the frame loop (pipeline.run_stream); every frame still goes through
+            # track -> back-project -> fuse -> render with the same results
+            expect(first, total)
+            P.run_stream(depth[first:total], rgb[first:total], list(range(first, total)), views[first:total])
+        barrier()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        if world > 1:
+            import torch.distributed as tdist
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        st, lv = (int(x) for x in P.counters.cpu().tolist())
+        rec = {"elapsed": float(t.item()), "steps": st, "levels": lv, "march": pkg.stage_timing_read(pkg.STAGE_MARCH),
+               "tracker": pkg.stage_timing_read(pkg.STAGE_TRACKER),
+               "marches": P.marched_last_call if getattr(P, "frame_sharded", False) else total - first}
+        pkg.stage_timing([])
+        return rec
+
+    # The K-frame window is measured R times, each time from an EMPTY map: reset, the 300 - K - W frames of history, the W
+    # warm-up frames, barrier, K timed frames (the whole stream is ~0.15 s of GPU time).  `value` is the MEDIAN run (VERDICT
+    # r03: the schedule has two steady states and one window is a coin flip); every run is listed in `runs`.
+    t0w = pre + Wm                                # first timed frame
+    R = max(1, args.repeats)
+    runs = [timed_window(t0w, args.include_h2d) for _ in range(R)]
+    order = sorted(range(R), key=lambda i: runs[i]["elapsed"])
+    med = runs[order[(R - 1) // 2]]               # (an actual run: its kernel timings go with it)
+    elapsed = med["elapsed"]
+    # the cold pipeline's fill: the window starts on an idle device (the contract's barrier), so its first frames pay the
+    # latency of the five-stream schedule.  T(K) = fill + K x period, measured with a second window over the last K / 2
+    # frames of the same stream (same map at the end): period = (T(K) - T(K/2)) / (K - K/2), fill = T(K) - K x period.
+    fill = None
+    if R > 1 and K >= 8 and not args.no_overlap and not args.include_h2d:
+        half = sorted(timed_window(t0w + K // 2)["elapsed"] for _ in range(3))[1]
+        period = (elapsed - half) / (K // 2)
+        if period > 0:
+            fill = {"pipeline_fill_ms": (elapsed - K * period) * 1e3, "steady_period_ms": period * 1e3,
+                    "steady_frames_per_s": 1.0 / period,
+                    "how": "T(K) = fill + K x period from the median window of K = %d frames and the median of three windows over its last "
+                           "%d frames; the contract's barrier before the timed frames empties the pipeline, so the fill is INSIDE `value`" % (K, K - K // 2)}
+
+    # ---- what the map and the tracker look like when the timed region ends (VERDICT r03 weak 6: say what the tracker does)
+    def pool_i32():
+        """the pool's node words as a device tensor (int32 view of the uint32 words; no copy)"""
+        class _Words:
+            __cuda_array_interface__ = {"shape": (2 * P.pool.size,), "typestr": "<i4", "data": (P.pool.data_ptr, False), "version": 2}
+        return torch.as_tensor(_Words(), device="cuda")
+
+    def pose_error(frame):
+        """estimated sensor pose of `frame` against the generator's ground truth, both in the map frame (= camera frame of
+        frame 0): main.cpp:40 maps a camera point x to orientation * (x + position)"""
+        p, o = P.cam.pose()
+        M = o.reshape(3, 3).T.astype(np.float64)                       # column-major mat3 -> M[row][col]
+        (p0, yaw0), (pk, yawk) = synth.camera_pose(0), synth.camera_pose(frame)
+        th = yawk - yaw0
+        Rgt = np.array([[np.cos(th), 0.0, np.sin(th)], [0.0, 1.0, 0.0], [-np.sin(th), 0.0, np.cos(th)]])
+        c0, s0 = np.cos(yaw0), np.sin(yaw0)
+        d = np.array(pk) - np.array(p0)
+        eye = np.array([c0 * d[0] - s0 * d[2], d[1], s0 * d[0] + c0 * d[2]])
+        E = M @ Rgt.T
+        ang = float(np.degrees(np.arccos(np.clip((np.trace(E) - 1.0) / 2.0, -1.0, 1.0))))
+        return ang, float(np.linalg.norm(M @ p.astype(np.float64) - eye))
+
+    end_state = None
+    if rank == 0:
+        words = pool_i32()
+        alpha = (words[1::2] >> 24) & 0xFF
+        err_deg, err_m = pose_error(total - 1)
+        end_state = {"pool_nodes_end": P.pool.size, "saturated_nodes_end": int((alpha >= 254).sum().item()),
+                     "pose_error_deg_end": err_deg, "pose_error_m_end": err_m,
+                     "pose_error_note": "against the generator's ground truth after %d frames.  The tracker reproduces the reference's rotational "
+                                        "Jacobian (Q14, localization_kernels.cu:207-213: not v x n), which drifts by degrees per frame on clean data; "
+                                        "tracking_lost_levels counts abandoned ICP levels and is NOT a health indicator" % total,
+                     "tracking_lost_levels": P.cam.tracking_lost_count()}
+        del words, alpha
 
     # ---- live kernel timings of the timed region: march and tracker (HIP events on their launch streams)
-    steps, levels = (int(x) for x in P.counters.cpu().tolist())
-    march_total_ms, march_launches = pkg.stage_timing_read(pkg.STAGE_MARCH)
-    trk_total_ms, trk_launches = pkg.stage_timing_read(pkg.STAGE_TRACKER)
-    pkg.stage_timing([])
-    sharded = getattr(P, "frame_sharded", False)
-    marches = P.marched_last_call if sharded else K      # frame-sharded: this rank ray-marches its own frames only
+    steps, levels = med["steps"], med["levels"]
+    march_total_ms, march_launches = med["march"]
+    trk_total_ms, trk_launches = med["tracker"]
+    marches = med["marches"]                              # frame-sharded: this rank ray-marches its own frames only
     assert march_launches == marches and marches > 0, (march_launches, marches)
     kern_ms = march_total_ms / marches
     rows = P.rows
@@ -340,11 +446,11 @@ def main():
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         tr, src = stage_traffic(stage)
         return {"stage": stage, "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src, "alg_bytes_per_launch": alg_bytes,
+                "frac": achieved / HBM_PEAK_GBS, "peak_measured": HBM_MEASURED_COPY_GBS, "frac_of_measured": achieved / HBM_MEASURED_COPY_GBS, "traffic": tr, "traffic_source": src, "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms": ms, "launches_per_frame": launches_per_frame, "limiter": note}
 
-    # which march runs: pools fused to depth <= 12 are marched over occupancy bricks in reference mode (csrc/pool_grid.hpp)
-    bricks = max_depth <= 12 and args.render_mode == "reference" and os.environ.get("SVOSLAM_MARCH_BRICKS") != "0"
+    # which march runs: pools fused to depth <= 14 are marched over occupancy bricks in reference mode (csrc/pool_grid.hpp)
+    bricks = max_depth <= 14 and args.render_mode == "reference" and os.environ.get("SVOSLAM_MARCH_BRICKS") != "0"
     roofs = [roof("march", "cone_trace_brick_kernel" if bricks else "cone_trace_kernel", march_alg, kern_ms, 1,
                   ("instruction issue: a step is ONE memory round trip (brick entry + level-grid entry requested together, mostly L1 / L2 "
                    "hits: counter traffic is a few percent of the algorithmic bytes) and ~160 instructions; a lone wavefront of the tail "
@@ -410,7 +516,7 @@ def main():
     tie_note = "ALWAYS"
     roofline = None
     def make_roofline(dom, how):
-        r = {k: dom[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "limiter",
+        r = {k: dom[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "peak_measured", "frac_of_measured", "traffic", "traffic_source", "limiter",
                                  "alg_bytes_per_launch", "kernel_ms")}
         r["chosen_by"] = how + ": " + ", ".join("%s %.3f ms" % (q["kernel"].split(" ")[0], q["kernel_ms"]) for q in roofs[:2])
         return r
@@ -438,10 +544,33 @@ def main():
                       "commit_ms": float((a[:, 8] - a[:, 7]).mean()), "accel_build_plus_march_ms": float((a[:, 9] - a[:, 8]).mean()),
                       "frame_period_ms": float(np.diff(a[:, 9]).mean()),
                       "frame_latency_ms_maps_begin_to_march_end": float((a[:, 9] - a[:, 0]).mean())}
+    # ---- N > 1: the OTHER partition as well, same windows (a SCALE run then measures both what north_star
+    # describes -- row bands, ICP all-reduce, all-gather of sorted band key lists -- and the frame-sharded scheme recommended here)
+    other = None
+    if world > 1 and emu is None and not args.no_other_partition and args.exchange in ("deltas", "allreduce") and not args.no_overlap:
+        oex = "allreduce" if args.exchange == "deltas" else "deltas"
+        try:
+            d2 = pl.DistContext(rank, world, force=force_dist, exchange=oex)
+            cur["P"] = pl.SlamPipeline(width, height, max_depth, center, edge, render_mode=mode, dist=d2, count_steps=True,
+                                       pool_capacity_nodes=(1 << 30) - 8)
+            r2 = [timed_window(t0w) for _ in range(min(R, 3))]
+            e2 = sorted(r["elapsed"] for r in r2)[(len(r2) - 1) // 2]
+            other = {"exchange": oex, "value": K / e2, "unit": "frames/s", "ms_per_step": e2 / K * 1e3, "runs": [K / r["elapsed"] for r in r2],
+                     "what": ("SURVEY 8e / north_star: image rows in %d bands, ICP sums all-reduced (19 per frame), sorted band key lists all-gathered "
+                              "and merged, replicated pool" % world) if oex == "allreduce" else
+                             "frames tracked + ray-marched by rank k %% %d, update_trans records all-gathered, every rank applies every fusion" % world}
+        except Exception as e:   # the line still carries the primary scheme; the failure is IN the record, not swallowed
+            other = {"exchange": oex, "value": None, "error": repr(e)}
+        cur["P"] = P
     if rank == 0:
         out = {
             "metric": "SLAM frames/sec (fuse+ICP+raycast)", "value": K / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
+            "value_is": "median of %d windows of K = %d timed frames, each from an empty map (reset, %d frames of history, %d of warm-up)" % (R, K, pre, Wm),
+            "runs": [K / r["elapsed"] for r in runs], "value_min": K / max(r["elapsed"] for r in runs),
+            "value_max": K / min(r["elapsed"] for r in runs),
+            # the schedule's two steady states: a run more than 7 % under the best one of this process fell into the slow one
+            "runs_steady_state": ["fast" if min(q["elapsed"] for q in runs) / r["elapsed"] >= 0.93 else "slow" for r in runs],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32/f32 (ICP sums exact fixed-point in f64)", "data": "synthetic",
             "config": {"workload": "%s: synthetic %dx%d RGB-D stream, depth-%d SVO, half-edge %.3f m, bilateral+ICP(19 it)+fuse+raycast(%s mode)"
@@ -466,8 +595,7 @@ def main():
                                    else "4 HIP streams: maps(k+2) | ICP(k+1) | back-project+sort+plan(k+1) | commit+raycast(k)"),
                        "frames_in_map_at_end": total, "frames_fused_untimed_before_warmup": pre, "frames_input": "pinned host memory, uploaded inside the timed region" if args.include_h2d else "resident in HBM",
                        "raycast_views": "ground-truth sensor poses (the reference renders from a free GLFW camera)",
-                       "pool_nodes_end": P.pool.size, "mrays_per_s": width * rows / (kern_ms * 1e-3) / 1e6,
-                       "tracking_lost_levels": P.cam.tracking_lost_count()},
+                       "mrays_per_s": width * rows / (kern_ms * 1e-3) / 1e6, **(end_state or {})},
             "roofline": roofline,
             "roofline_stages": roofs,
         }
@@ -475,8 +603,14 @@ def main():
             out["stages_sequential"] = stage_seq
         if stages:
             out["stages"] = stages
+        if fill:
+            out["pipeline_fill"] = fill
+        if other:
+            out["other_partition"] = other
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(depth, rgb, views, width, height, max_depth, center, edge)
+            history(t0w)          # the map and the pose the timed frames started from
+            seed_words = pool_i32().cpu().numpy().view(np.uint32) if t0w > 0 else None
+            out["cpu_baseline"] = cpu_baseline(depth[:total], rgb[:total], views, t0w, width, height, max_depth, center, edge, seed_words, P.cam.pose())
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         import torch.distributed as tdist

@@ -647,6 +647,9 @@ int svoslam_mailbox_all_reduce_f64(svoslam_mailbox *mailbox, double *d_values, i
 int svoslam_mailbox_post(svoslam_mailbox *mailbox, const void *d_src, int32_t bytes, void *stream);
 int svoslam_mailbox_collect(svoslam_mailbox *mailbox, void *d_dst, int32_t bytes, int32_t reduce_f64, void *stream);
 int svoslam_mailbox_failed(svoslam_mailbox *mailbox, int32_t *failed);
+/* polls per granule before a wait gives up (default 2^24, about a second).  A wait that gives up writes all-ones granules (NaN
+ * as binary32 / binary64) in place of the missing record and sets the sticky flag svoslam_mailbox_failed() reports. */
+int svoslam_mailbox_set_wait_limit(svoslam_mailbox *mailbox, uint32_t polls);
 
 #ifdef __cplusplus
 }

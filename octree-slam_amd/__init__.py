@@ -143,6 +143,7 @@ SIGNATURES = {
     "svoslam_mailbox_all_gather": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "svoslam_mailbox_all_reduce_f64": (C.c_int, [_vp, _vp, _i32, _vp]),
     "svoslam_mailbox_failed": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "svoslam_mailbox_set_wait_limit": (C.c_int, [_vp, C.c_uint32]),
     "svoslam_mailbox_post": (C.c_int, [_vp, _vp, _i32, _vp]),
     "svoslam_mailbox_collect": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "svoslam_scene_create": (C.c_int, [C.POINTER(_vp)]),
@@ -720,6 +721,9 @@ class Mailbox:
     def collect(self, dst, nbytes, reduce_f64=False):
         """second half: every rank's record of the epoch just posted -> dst[world, ...] (or their rank-ordered float64 sum)"""
         check(lib().svoslam_mailbox_collect(self._h, _ptr(dst), int(nbytes), 1 if reduce_f64 else 0, _stream()))
+
+    def set_wait_limit(self, polls):
+        check(lib().svoslam_mailbox_set_wait_limit(self._h, int(polls)))
 
     def failed(self):
         f = _i32(0)

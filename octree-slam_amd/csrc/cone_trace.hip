@@ -676,7 +676,12 @@ __device__ __forceinline__ uint32_t walk_sample(const uint2 *__restrict__ nodes,
 // or deeper than a level-12 node with children, a sample whose table bracket is not confirmed -- and the LAST sample
 // of every ray (whose node's colour word forms the pixel, Q9) take walk_sample().  The rare cases sit behind
 // wavefront-uniform branches: the loop is bound by the instructions it issues (profiles/r03_brick_march_anatomy.txt).
-template <int THREADS, bool LOD_ALWAYS>  // LOD_ALWAYS: every pixel size this render can form is in the fast LOD form's range (checked by the host)
+// Shape S (pool_grid.hpp "Shapes"): S = 0 is the above; S = 1 (pools fused to depth 13 / 14) answers LODs 9..13 from bricks of
+// level-10 nodes with level-12 cells inside the 2048^3-cell window.  The cell of a sample is then one level finer than the LDS
+// table's ranks: it is GUESSED by the same float multiply at the finer pitch, its upper 11 bits are confirmed against the table
+// as before and its last bit against the reference's own next centre (c_11 = table entry +- size / 2^11: the level-12 decision of
+// walk_deep_chain), which the S = 0 kernel forms anyway whenever an LOD reaches 12.
+template <int THREADS, bool LOD_ALWAYS, int S>  // LOD_ALWAYS: every pixel size this render can form is in the fast LOD form's range (checked by the host)
 __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
                                                                    const uint2 *__restrict__ grid, const uint16_t *__restrict__ bricks,
                                                                    const float *__restrict__ table, const float *__restrict__ alpha_lut_g,
@@ -685,6 +690,9 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
   constexpr int LDSD = 11, GRID = kPoolGridLevel;
   constexpr int kLdsStride = lds_stride(LDSD);
   constexpr int kCells = lds_cells(LDSD);
+  constexpr int BL = brick_bits_level(S);                               // level of the per-octant bits
+  constexpr int kFine = kCells << S;                                   // cells per axis at the bricks' cell level
+  constexpr uint32_t kOrg = brick_window_origin(S);                    // first cell of the window
 #ifdef SVO_BRICK_PRIO
   __builtin_amdgcn_s_setprio(SVO_BRICK_PRIO);
 #endif
@@ -744,13 +752,19 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
     float ray_len = length3(rx, ry, rz);
     // (a root cube outside the ordinary range of sizes never gets here: the host launches cone_trace_kernel for it)
     const float ts11 = ldexpf(P.size, -LDSD);  // size / 2^11: what the level-11 decision adds to the centre (walk_deep_chain)
+    const float ts12 = ldexpf(P.size, -LDSD - 1);
+    const float inv_cell_fine = S == 0 ? P.inv_cell_lds : P.inv_cell_lds * 2.0f;  // (a power of two times it: the same guess one bit finer)
     // The loop carries the ray (rx, ry, rz, ray_len), the previous grid word and the counters, nothing else: which of its
     // two exits a ray took is read off afterwards, and the last sample's node is looked up again for the pixel (once per ray).
     float tx = 0.0f, ty = 0.0f, tz = 0.0f;  // the sample of the current step (the last one, after the loop)
     int lod = 0;
     uint32_t retired = 0;  // (an integer, not a bool: a loop-carried bool is a lane mask the compiler re-blends every iteration)
     uint32_t prev_gx = 0;  // the previous sample's grid word: its children flag = "this ray is among nodes"
-    auto brick_entry = [&](uint32_t x, uint32_t y, uint32_t z) -> uint32_t {  // through the LDS spread tables
+    auto brick_entry = [&](uint32_t x, uint32_t y, uint32_t z) -> uint32_t {  // cell (x, y, z) at the bricks' cell level, through the LDS spread tables
+      if (S > 0) {  // the window: cells outside it have no entry (0 = "ask the level grid")
+        x -= kOrg; y -= kOrg; z -= kOrg;
+        if ((x | y | z) >= kBrickWindowCells) return 0u;
+      }
       const uint32_t d = spread[x] | spread[kCells + y] | spread[2 * kCells + z];
       return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(bricks) + (((size_t)d << 2) | ((x & 1u) << 1)));
     };
@@ -758,15 +772,22 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
     // sample's level-12 octant (read only when the brick's walk ends at level 12; 0 unless some lane's LOD reaches 12).
     // Written in integers: as booleans every condition is a 64-bit lane mask and the loop is bound by what it issues.
     auto decode = [&](uint32_t e, uint2 gq, int lod_, uint32_t oct12, int &depth, uint32_t &ret) -> bool {
-      // the brick: the path stops at level st = 9 / 10 / 11, or goes on to level 12 (code 4); code 0 (no brick) gives st = 8
-      // and never qualifies.  The walk ends at min(LOD, st); levels 9..11 carry their own bit (4..6), level 12 one per
-      // octant (8..15).  An LOD beyond 12 over a level-12 node with children (bit 3) ends deeper: not the brick's to answer.
-      const int st = (int)((e & 7u) | 8u);
+      // the brick: the path stops at level st, or goes on to the bits level BL (code 4); code 0 (no brick) gives st = 8 and never
+      // qualifies.  S = 0: st = 8 | code (9 / 10 / 11 / 12).  S = 1: codes 1..4 = 10..13, code 5 = the level-9 node is childless.
+      // The walk ends at min(LOD, st); levels 9.. carry their own bit (4..), the bits level one per octant (8..15).  An LOD beyond
+      // BL over a node with children there (bit 3) ends deeper: not the brick's to answer.
+      const int st = S == 0 ? (int)((e & 7u) | 8u) : (int)((0x009DCBA8u >> ((e & 7u) << 2)) & 15u);
       const int depth_b = lod_ < st ? lod_ : st;
-      uint32_t bit = (uint32_t)(depth_b - 5);                       // 4..6 for levels 9..11, 7 for level 12
-      bool by_brick = (uint32_t)(depth_b - kBrickNodeLevel) < 3u;
-      if (lod_ >= 12) {  // (per lane; rare except at close range)
-        const bool deep = depth_b == 12 && (lod_ == 12 || !(e & 8u));
+      uint32_t bit = (uint32_t)(depth_b - 5);                       // 4.. for levels 9..
+      // levels NL .. BL - 1 are the brick's own (its node, the two levels of its cells).  S = 1: a level ABOVE the brick node (9)
+      // is answered only where the path STOPS there (a childless node's word never changes); the alpha of a level-9 node with
+      // children changes whenever anything below it does, and the seven sibling bricks that also carry its bit are not rebuilt
+      // then -- such a sample (LOD 9 among nodes: a ray length of tens of metres at the depths this shape serves) walks the tree
+      constexpr int NLv = brick_node_level(S);
+      bool by_brick = (uint32_t)(depth_b - NLv) < 3u;
+      if (S > 0) by_brick = by_brick || (st > GRID && st < NLv && depth_b == st);   // (st = GRID: no brick entry)
+      if (lod_ >= BL) {  // (per lane; rare except at close range)
+        const bool deep = depth_b == BL && (lod_ == BL || !(e & 8u));
         by_brick = by_brick || deep;
         bit = deep ? 8u + oct12 : bit;
       }
@@ -791,15 +812,17 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       my_steps++;
       tx = P.origin[0] + rx; ty = P.origin[1] + ry; tz = P.origin[2] + rz;
       const float pix_size = ray_len * P.pix_scale;
-      int gx = (int)((tx - P.lo[0]) * P.inv_cell_lds), gy = (int)((ty - P.lo[1]) * P.inv_cell_lds), gz = (int)((tz - P.lo[2]) * P.inv_cell_lds);
-      gx = gx < 0 ? 0 : (gx > kCells - 1 ? kCells - 1 : gx);
-      gy = gy < 0 ? 0 : (gy > kCells - 1 ? kCells - 1 : gy);
-      gz = gz < 0 ? 0 : (gz > kCells - 1 ? kCells - 1 : gz);
+      // the guessed cell at the bricks' cell level (fx..); its upper 11 bits are the guessed table ranks (gx..)
+      int fx_ = (int)((tx - P.lo[0]) * inv_cell_fine), fy_ = (int)((ty - P.lo[1]) * inv_cell_fine), fz_ = (int)((tz - P.lo[2]) * inv_cell_fine);
+      fx_ = fx_ < 0 ? 0 : (fx_ > kFine - 1 ? kFine - 1 : fx_);
+      fy_ = fy_ < 0 ? 0 : (fy_ > kFine - 1 ? kFine - 1 : fy_);
+      fz_ = fz_ < 0 ? 0 : (fz_ > kFine - 1 ? kFine - 1 : fz_);
+      const int gx = fx_ >> S, gy = fy_ >> S, gz = fz_ >> S;
       // entries requested from the GUESSED cells (see cone_trace_kernel)
       const uint2 gq = grid[(((uint32_t)gz >> (LDSD - GRID)) << (2 * GRID)) | (((uint32_t)gy >> (LDSD - GRID)) << GRID) | ((uint32_t)gx >> (LDSD - GRID))];
       const bool with_brick = __any((prev_gx & kFlag) != 0u);  // (uniform: some ray of this wavefront is among nodes)
       uint32_t e = 0;
-      if (with_brick) e = brick_entry((uint32_t)gx, (uint32_t)gy, (uint32_t)gz);
+      if (with_brick) e = brick_entry((uint32_t)fx_, (uint32_t)fy_, (uint32_t)fz_);
       const uint32_t ub = f2bits(pix_size);
       lod = (P.size_exp - (int)(ub >> 23)) + ((ub & 0x7FFFFFu) < P.size_man ? 1 : 0);
       const bool lod_ok = LOD_ALWAYS || ub - P.lod_first <= P.lod_span;
@@ -809,7 +832,7 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       const float ax = lds_tab[gx + 1], bx = lds_tab[gx + 2];
       const float ay = lds_tab[kLdsStride + gy + 1], by = lds_tab[kLdsStride + gy + 2];
       const float az = lds_tab[2 * kLdsStride + gz + 1], bz = lds_tab[2 * kLdsStride + gz + 2];
-      const bool conf = (((int)(ax < tx) & (int)!(bx < tx)) & ((int)(ay < ty) & (int)!(by < ty)) & ((int)(az < tz) & (int)!(bz < tz))) != 0;
+      bool conf = (((int)(ax < tx) & (int)!(bx < tx)) & ((int)(ay < ty) & (int)!(by < ty)) & ((int)(az < tz) & (int)!(bz < tz))) != 0;
 #ifdef SVO_BRICK_DIAG
       asm volatile("" :: "v"(conf), "v"(inv_len));
       const long long c1 = clock64();
@@ -818,17 +841,29 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
 #endif
       prev_gx = gq.x;
       // the step that enters a level-8 node with children: its brick entry has not been requested yet
-      if (!with_brick && __any((gq.x & kFlag) != 0u && lod >= kBrickNodeLevel)) e = brick_entry((uint32_t)gx, (uint32_t)gy, (uint32_t)gz);
-      // the level-12 octant, where some lane's walk ends at level 12: the level-11 decision's plane is the table entry at
+      if (!with_brick && __any((gq.x & kFlag) != 0u && lod > GRID)) e = brick_entry((uint32_t)fx_, (uint32_t)fy_, (uint32_t)fz_);
+      // the octant at the bits level, where some lane's walk ends there: the level-11 decision's plane is the table entry at
       // the even rank (walk_deep_chain), i.e. S[g-1] for an odd rank and S[g] for an even one -- one of the two entries
-      // the confirmation has read (valid for confirmed guesses; the others are redone below)
+      // the confirmation has read (valid for confirmed guesses; the others are redone below).  S = 1: the level-12 bit of the
+      // guessed cell is confirmed the same way (always), and the octant one level further follows the chain.
       uint32_t oct12 = 0;
-      if (__any(lod >= 12)) {
+      if (S > 0 || __any(lod >= BL)) {
         float cx = (gx & 1) ? ax : bx, cy = (gy & 1) ? ay : by, cz = (gz & 1) ? az : bz;
         cx += ts11 * ((gx & 1) ? 1.0f : -1.0f);
         cy += ts11 * ((gy & 1) ? 1.0f : -1.0f);
         cz += ts11 * ((gz & 1) ? 1.0f : -1.0f);
-        oct12 = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
+        const uint32_t hx = (uint32_t)(tx > cx), hy = (uint32_t)(ty > cy), hz = (uint32_t)(tz > cz);
+        if (S == 0) {
+          oct12 = hx | (hy << 1) | (hz << 2);
+        } else {
+          conf = conf && (((hx ^ (uint32_t)fx_) | (hy ^ (uint32_t)fy_) | (hz ^ (uint32_t)fz_)) & 1u) == 0u;
+          if (__any(lod >= BL)) {
+            cx += ts12 * (hx ? 1.0f : -1.0f);
+            cy += ts12 * (hy ? 1.0f : -1.0f);
+            cz += ts12 * (hz ? 1.0f : -1.0f);
+            oct12 = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
+          }
+        }
       }
       int depth;
       const bool decided = decode(e, gq, lod, oct12, depth, retired);
@@ -856,15 +891,25 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
               yb = axis_bits_chain(ty, P.center[1], P.size, LDSD);
               zb = axis_bits_chain(tz, P.center[2], P.size, LDSD);
             }
-            e2 = bricks[brick_entry_index(xb, yb, zb)];
             g2 = grid[((zb >> (LDSD - GRID)) << (2 * GRID)) | ((yb >> (LDSD - GRID)) << GRID) | (xb >> (LDSD - GRID))];
             prev_gx = g2.x;
           }
+          // the reference's centres below the table (walk_deep_chain): the level-12 octant, and for S = 1 the level-13 one
           float cx = lds_tab[(xb & ~1u) + 2u], cy = lds_tab[kLdsStride + (yb & ~1u) + 2u], cz = lds_tab[2 * kLdsStride + (zb & ~1u) + 2u];
           cx += ts11 * ((xb & 1u) ? 1.0f : -1.0f);
           cy += ts11 * ((yb & 1u) ? 1.0f : -1.0f);
           cz += ts11 * ((zb & 1u) ? 1.0f : -1.0f);
-          const uint32_t oct12r = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
+          uint32_t oct12r = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
+          if (S > 0) {
+            const uint32_t cxf = (xb << 1) | (oct12r & 1u), cyf = (yb << 1) | ((oct12r >> 1) & 1u), czf = (zb << 1) | (oct12r >> 2);
+            if (!conf) e2 = ok ? brick_entry(cxf, cyf, czf) : 0u;
+            cx += ts12 * ((oct12r & 1u) ? 1.0f : -1.0f);
+            cy += ts12 * ((oct12r & 2u) ? 1.0f : -1.0f);
+            cz += ts12 * ((oct12r & 4u) ? 1.0f : -1.0f);
+            oct12r = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
+          } else if (!conf) {
+            e2 = ok ? brick_entry(xb, yb, zb) : 0u;
+          }
           const bool decided2 = ok && decode(e2, g2, lod, oct12r, depth, retired);
           if (!decided2) {
             depth = lod;
@@ -1092,11 +1137,12 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   float *alpha_lut = d_table + 3 * (kTabStride + kLdsStrideMax);
   const uint2 *d_grid = own_grid;
   const uint16_t *d_bricks = nullptr;
+  int brick_shift = -1;
   const bool tables_match = sa->tables_valid && sa->tables_at == d_table && sa->lds_depth == P.lds_depth && sa->size == size &&
                             sa->center[0] == center[0] && sa->center[1] == center[1] && sa->center[2] == center[2];
   if (pa) {
     // (the brick march is compiled for the 11-level LDS table: SVOSLAM_MARCH_LDS_DEPTH=12 keeps the tree march)
-    SVO_TRY(pool_accel_refresh(pa, d_octree, stream, &d_grid, (mode & 0xFF) == SVOSLAM_RENDER_REFERENCE && P.lds_depth == 11, &d_bricks));
+    SVO_TRY(pool_accel_refresh(pa, d_octree, stream, &d_grid, (mode & 0xFF) == SVOSLAM_RENDER_REFERENCE && P.lds_depth == 11, &d_bricks, &brick_shift));
     if (!tables_match) build_tables_kernel<<<(int)cdiv(3 * (kTabStride + kLdsStrideMax) + 256, 256), 256, 0, stream>>>(d_table, alpha_lut, P);
   } else {
     const int build_blocks = (int)cdiv(own_cells + 3 * (kTabStride + kLdsStrideMax) + 256, 256);
@@ -1113,7 +1159,8 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
     }
     slots = sa->count_slots;
   }
-  SVO_TRY(stage_event(kStageMarch, stream));
+  long long stage_token = -1;
+  SVO_TRY(stage_begin(kStageMarch, stream, &stage_token));
   uchar4 *out = reinterpret_cast<uchar4 *>(d_pos);
   const bool carry = (mode & 0xFF) == SVOSLAM_RENDER_CARRY;
   const bool midrange_size = size >= 9.5367431640625e-07f && size <= 1048576.0f;  // (see cone_trace_kernel: the length recurrence's short forms)
@@ -1125,8 +1172,14 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
     P.xcd_rows = xcd_mode == 1;
     if (xcd_mode == 2 && P.xcd_w > 0) { P.xcd_w = 0; P.xcd_h = (int)cdiv(width, 32); blocks = cdiv(width, 32) * cdiv(rows, kTraceThreads / 32); }
     const dim3 grid(blocks);
-    if (P.lod_always) cone_trace_brick_kernel<kTraceThreads, true><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps, slots);
-    else cone_trace_brick_kernel<kTraceThreads, false><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps, slots);
+    auto launch = [&](auto kernel) { kernel<<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps, slots); };
+    if (brick_shift == 0) {
+      if (P.lod_always) launch(cone_trace_brick_kernel<kTraceThreads, true, 0>);
+      else launch(cone_trace_brick_kernel<kTraceThreads, false, 0>);
+    } else {
+      if (P.lod_always) launch(cone_trace_brick_kernel<kTraceThreads, true, 1>);
+      else launch(cone_trace_brick_kernel<kTraceThreads, false, 1>);
+    }
   } else if (P.lds_depth == 11 && large) {
     const dim3 grid(xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads / 32)));
     if (carry) cone_trace_kernel<true, 11, kTraceThreads, kGridLevelLarge><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
@@ -1144,7 +1197,7 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
     if (carry) cone_trace_kernel<true, 12, kTraceThreads12, kGridLevelLarge><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
     else cone_trace_kernel<false, 12, kTraceThreads12, kGridLevelLarge><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
   }
-  SVO_TRY(stage_event(kStageMarch, stream));
+  SVO_TRY(stage_end(kStageMarch, stage_token, stream));
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
 }

@@ -26,7 +26,7 @@ namespace svoslam {
 
 constexpr int kMbSlots = 4;
 constexpr int kMbMaxGranules = 512;      // 2 KB of payload per rank and collective
-constexpr unsigned kMbSpinLimit = 1u << 24;
+constexpr unsigned kMbSpinLimit = 1u << 24;  // default polls per granule before a wait gives up (svoslam_mailbox_set_wait_limit)
 
 __global__ void mailbox_post_kernel(unsigned long long *const *__restrict__ inboxes, int world, int rank, int slot, unsigned epoch,
                                     const unsigned *__restrict__ src, int granules) {
@@ -41,7 +41,8 @@ __global__ void mailbox_post_kernel(unsigned long long *const *__restrict__ inbo
 // waits until every rank's record of this epoch has arrived in the OWN inbox, then copies the payloads out in rank order;
 // reduce_f64 != 0: out[k] = sum over ranks (in rank order) of the k-th double instead
 __global__ void mailbox_collect_kernel(const unsigned long long *__restrict__ inbox, int world, int slot, unsigned epoch,
-                                       unsigned *__restrict__ out, int granules, int reduce_f64, unsigned *__restrict__ fail) {
+                                       unsigned *__restrict__ out, int granules, int reduce_f64, unsigned *__restrict__ fail,
+                                       unsigned spin_limit) {
   __shared__ unsigned vals[kMbMaxGranules];
   __shared__ int bad;
   if (threadIdx.x == 0) bad = 0;
@@ -55,7 +56,10 @@ __global__ void mailbox_collect_kernel(const unsigned long long *__restrict__ in
       for (;;) {
         x = __hip_atomic_load(src + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((unsigned)(x >> 32) == epoch) break;
-        if (++spins > kMbSpinLimit) { bad = 1; break; }
+        // a peer that never posted (about a second of polling): the wait gives up LOUDLY -- the granule is poisoned (all ones: a NaN
+        // as binary32 and as either half of a binary64, so a pose record or an ICP sum built from it cannot pass for data) and
+        // the mailbox's sticky fail word is set, which DistContext checks at the end of every stream call
+        if (++spins > spin_limit) { bad = 1; x = 0xFFFFFFFFull; break; }
         __builtin_amdgcn_s_sleep(2);
       }
       if (reduce_f64) vals[g] = (unsigned)x;
@@ -90,6 +94,7 @@ struct svoslam_mailbox {
   unsigned *d_stage = nullptr;                  // reduce: staging of the local record (so that src may alias dst)
   unsigned *d_fail = nullptr;
   unsigned epoch = 0;
+  unsigned spin_limit = svoslam::kMbSpinLimit;
   bool connected = false;
 };
 
@@ -109,13 +114,17 @@ int svoslam_mailbox_create(svoslam_mailbox **out, int32_t rank, int32_t world) {
     (void)hipGetLastError();
     if (hipMalloc((void **)&m->inbox, bytes) != hipSuccess) { delete m; return SVOSLAM_ERR_OOM; }
   }
-  SVO_HIP(memset_sync(m->inbox, 0, bytes));     // tag 0 is never an epoch
-  SVO_HIP(hipMalloc((void **)&m->d_peers, (size_t)world * sizeof(void *)));
-  SVO_HIP(hipMalloc((void **)&m->d_stage, kMbMaxGranules * 4));
-  SVO_HIP(hipMalloc((void **)&m->d_fail, 4));
-  SVO_HIP(memset_sync(m->d_fail, 0, 4));
   m->peers.assign((size_t)world, nullptr);
   m->opened.assign((size_t)world, false);
+  // (a failure below releases what exists so far: svoslam_mailbox_destroy takes the half-built object)
+  if (memset_sync(m->inbox, 0, bytes) != hipSuccess ||                                  // tag 0 is never an epoch
+      hipMalloc((void **)&m->d_peers, (size_t)world * sizeof(void *)) != hipSuccess ||
+      hipMalloc((void **)&m->d_stage, kMbMaxGranules * 4) != hipSuccess || hipMalloc((void **)&m->d_fail, 4) != hipSuccess ||
+      memset_sync(m->d_fail, 0, 4) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)svoslam_mailbox_destroy(m);
+    return SVOSLAM_ERR_HIP;
+  }
   m->peers[(size_t)rank] = m->inbox;
   *out = m;
   return SVOSLAM_OK;
@@ -160,7 +169,12 @@ int svoslam_mailbox_connect(svoslam_mailbox *m, const void *handles) {
     hipIpcMemHandle_t h;
     memcpy(&h, (const char *)handles + 64 * (size_t)p, 64);
     void *ptr = nullptr;
-    SVO_HIP(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+    if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+      (void)hipGetLastError();
+      for (int q = 0; q < m->world; q++)  // no half-registered mappings: close what this call opened
+        if (m->opened[(size_t)q] && m->peers[(size_t)q]) { (void)hipIpcCloseMemHandle(m->peers[(size_t)q]); m->peers[(size_t)q] = nullptr; m->opened[(size_t)q] = false; }
+      return SVOSLAM_ERR_HIP;
+    }
     m->peers[(size_t)p] = (unsigned long long *)ptr;
     m->opened[(size_t)p] = true;
   }
@@ -199,7 +213,7 @@ static int collect(svoslam_mailbox *m, void *d_dst, int bytes, int reduce, hipSt
   if (!m || !m->connected || !d_dst || bytes <= 0 || (bytes & 3) || bytes > kMbMaxGranules * 4 || m->epoch == 0) return SVOSLAM_ERR_INVALID_ARG;
   if (reduce && (bytes & 7)) return SVOSLAM_ERR_INVALID_ARG;
   const int slot = (int)(m->epoch % kMbSlots);
-  mailbox_collect_kernel<<<1, 256, 0, s>>>(m->inbox, m->world, slot, m->epoch, reinterpret_cast<unsigned *>(d_dst), bytes / 4, reduce, m->d_fail);
+  mailbox_collect_kernel<<<1, 256, 0, s>>>(m->inbox, m->world, slot, m->epoch, reinterpret_cast<unsigned *>(d_dst), bytes / 4, reduce, m->d_fail, m->spin_limit);
   SVO_LAUNCH_CHECK();
   return SVOSLAM_OK;
 }
@@ -223,6 +237,13 @@ int svoslam_mailbox_all_reduce_f64(svoslam_mailbox *m, double *d_values, int32_t
   if (count <= 0 || count > kMbMaxGranules / 2) return SVOSLAM_ERR_INVALID_ARG;
   SVO_TRY(post(m, d_values, count * 8, true, reinterpret_cast<hipStream_t>(stream)));
   return collect(m, d_values, count * 8, 1, reinterpret_cast<hipStream_t>(stream));
+}
+
+// polls per granule before a wait gives up (default 2^24, about a second); tests shorten it
+int svoslam_mailbox_set_wait_limit(svoslam_mailbox *m, uint32_t polls) {
+  if (!m || polls == 0) return SVOSLAM_ERR_INVALID_ARG;
+  m->spin_limit = polls;
+  return SVOSLAM_OK;
 }
 
 // 1 if a wait of this mailbox has ever given up (a peer that never posted).  Blocking.

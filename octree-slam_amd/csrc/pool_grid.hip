@@ -19,9 +19,6 @@ PoolAccel::~PoolAccel() {
   grid.release();
   shadow.release();
   for (uint32_t *d : d_dirty) if (d) (void)hipFree(d);
-  if (s_rebuild) { (void)hipStreamSynchronize(s_rebuild); (void)hipStreamDestroy(s_rebuild); }
-  if (ev_ready) (void)hipEventDestroy(ev_ready);
-  if (ev_rebuilt) (void)hipEventDestroy(ev_rebuilt);
   if (bricks) (void)hipFree(bricks);
   if (d_brick_touched) (void)hipFree(d_brick_touched);
   if (ev_order) (void)hipEventDestroy(ev_order);
@@ -95,12 +92,18 @@ static bool ensure_dirty_states(PoolAccel *pa) {
 // Commits mark from the first one on, whether or not a grid exists yet: whether the NEXT render builds the grid in full
 // is decided when that render is enqueued, which may be after the commit was (the scheduler enqueues the deferred
 // commit of frame k+1 before the render of frame k).
-uint32_t *pool_accel_dirty_bitmap(svoslam_pool *pool, int parity, int commit_depth) {
+uint32_t *pool_accel_dirty_bitmap(svoslam_pool *pool, int parity, int commit_depth, int *brick_shift) {
+  if (brick_shift) *brick_shift = -1;
   if (!pool || !pool->d_data) return nullptr;
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_accel.find(pool->d_data);
   if (it == g_accel.end() || !ensure_dirty_states(it->second.get())) return nullptr;
   if (commit_depth > it->second->max_depth) it->second->max_depth = commit_depth;
+  const int shift = brick_shift_for_depth(it->second->max_depth);
+  // a commit SHALLOWER than the brick node's level (a pool fused at mixed depths) changes nodes between the level grid and the
+  // brick nodes that no key of it lists a brick for: every brick is rebuilt by the next refresh
+  if (shift > 0 && commit_depth > kPoolGridLevel && commit_depth < brick_node_level(shift)) it->second->bricks_valid = false;
+  if (brick_shift) *brick_shift = shift;  // the shape the next refresh will hold the bricks in
   return it->second->d_dirty[parity & 1];
 }
 
@@ -150,15 +153,6 @@ bool pool_shadow_pending(svoslam_pool *pool) {
   return it != g_accel.end() && it->second->deferred_pending;
 }
 
-int pool_accel_order_writer(svoslam_pool *pool, hipStream_t stream) {
-  if (!pool || !pool->d_data) return SVOSLAM_OK;
-  std::lock_guard<std::mutex> lock(g_mu);
-  auto it = g_accel.find(pool->d_data);
-  if (it == g_accel.end() || !it->second->rebuild_in_flight) return SVOSLAM_OK;
-  SVO_HIP(hipStreamWaitEvent(stream, it->second->ev_rebuilt, 0));
-  return SVOSLAM_OK;
-}
-
 std::shared_ptr<PoolAccel> pool_accel_find(const uint32_t *d_data) {
   if (!d_data) return nullptr;
   std::lock_guard<std::mutex> lock(g_mu);
@@ -196,70 +190,157 @@ __global__ __launch_bounds__(256) void pool_grid_build_kernel(const uint32_t *__
 }
 
 // ---- occupancy bricks (pool_grid.hpp) ----------------------------------------------------------------------------------
-// the 64 entries of the bricks of N level-9 nodes (x9, y9, z9)[k], one entry per lane of ONE wavefront and brick: lane =
-// octant at level 10 (bits 5..3) and at level 11 (bits 2..0) of the cell's path below the node.  A brick is a chain of
-// five dependent loads (grid entry, level-9 / -10 / -11 nodes, the level-12 tile); N chains are walked side by side.
-template <int N>
-__device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint2 *__restrict__ grid, uint16_t *__restrict__ bricks,
-                                     uint32_t *__restrict__ touched, const uint32_t (&x9)[N], const uint32_t (&y9)[N], const uint32_t (&z9)[N],
-                                     const bool (&live)[N], unsigned lane, bool trust_mip) {
+// the 64 entries of the bricks of N brick nodes -- window-relative brick coordinates (xr, yr, zr)[k], shape S -- one entry per
+// lane of ONE wavefront and brick: lane = octant at level NL + 1 (bits 5..3) and at level NL + 2 = the cell level (bits 2..0)
+// of the cell's path below the brick node (level NL = 9 + S).  A brick is a chain of 5 + S dependent loads (grid entry, the
+// nodes of levels 9 .. NL on the path -- the same for every lane --, the two per-lane levels, the tile of the bits level); N
+// chains are walked side by side.
+// the level-8 node above brick node (xa, ya, za) (level-NL coordinates): its grid entry, or -- when the entry does not show
+// children: the node has just been split and the grid (refreshed by the same launch) may not say so yet -- the walk from the
+// root (rare: a few hundred nodes per frame at the map's frontier).  Returns flag | children tile, or 0.
+template <int NL>
+__device__ inline uint32_t brick_level8(const uint2 *__restrict__ nodes, uint2 g, uint32_t xa, uint32_t ya, uint32_t za) {
   constexpr int G = kPoolGridLevel;
-  uint2 g[N], w9[N], w10[N], w11[N];
-  uint32_t v[N];
-  bool on[N], on10[N], on11[N], on12[N];
-#pragma unroll
-  for (int k = 0; k < N; k++) g[k] = live[k] ? grid[((z9[k] >> 1) << (2 * G)) | ((y9[k] >> 1) << G) | (x9[k] >> 1)] : make_uint2(0u, 0u);
-#pragma unroll
-  for (int k = 0; k < N; k++) {
-    // no children in the grid's entry: the level-8 node has just been split and the grid (refreshed by the same launch) may
-    // not say so yet -- the walk from the root decides (rare: a few hundred nodes per frame at the map's frontier)
-    if (live[k] && !(g[k].x & kFlag)) {
-      uint32_t base = 0;
-      bool has = true;
-      for (int l = 1; l <= G && has; l++) {
-        const int sh = G + 1 - l;  // level-9 coordinates: bit sh is level l's octant bit
-        const uint2 nd = nodes[base + (((x9[k] >> sh) & 1u) | (((y9[k] >> sh) & 1u) << 1) | (((z9[k] >> sh) & 1u) << 2))];
-        has = (nd.x & kFlag) != 0u;
-        base = nd.x & kMask;
+  if (g.x & kFlag) return g.x;
+  uint32_t base = 0;
+  bool has = true;
+  for (int l = 1; l <= G && has; l++) {
+    const int sh = NL - l;  // level-NL coordinates: bit sh is level l's octant bit
+    const uint2 nd = nodes[base + (((xa >> sh) & 1u) | (((ya >> sh) & 1u) << 1) | (((za >> sh) & 1u) << 2))];
+    has = (nd.x & kFlag) != 0u;
+    base = nd.x & kMask;
+  }
+  return has ? (kFlag | base) : 0u;
+}
+
+// SIBLINGS of a brick in the sibling ring (the commit that listed it created nodes at or above the brick node's level on
+// its path).  A split that gives a node its first children creates seven childless siblings per level
+// beside the key's path; nobody lists them (their content follows from the parent's tile alone), and without their lines a
+// ray through them would find "no entry" under a level-8 node with children and walk the tree.  Here the children tile of every
+// node on the wavefront-uniform part of the path (levels 9 .. NL) is read whole, and a sibling of the path's node that is
+// CHILDLESS gets its lines -- 8^(NL - l) bricks whose 64 entries all say "the path stops at level l" -- unless its first entry
+// already says so.  A sibling WITH children has been listed by the commit that gave it its children.  A routine of its own,
+// called after the brick's rebuild for the few flagged entries (the tiles are cached by then): woven into the rebuild's load
+// chains it cost the refresh 23 us per frame on the map stream (51 -> 74 us, cfg3 2390 -> 2290 frames/s); round 3 listed the
+// seven level-9 siblings from the leaf kernel instead, a divergent loop of atomics at that kernel's end.
+template <int S>
+__device__ inline void brick_siblings(const uint2 *__restrict__ nodes, const uint2 *__restrict__ grid, uint16_t *__restrict__ bricks,
+                                            uint32_t *__restrict__ touched, uint32_t xr, uint32_t yr, uint32_t zr, unsigned lane) {
+  constexpr int G = kPoolGridLevel, NL = brick_node_level(S);
+  constexpr uint32_t kOrg = brick_window_origin(S) >> 2;
+  const uint32_t xa = xr + kOrg, ya = yr + kOrg, za = zr + kOrg;
+  const uint32_t g8 = brick_level8<NL>(nodes, grid[((za >> (NL - G)) << (2 * G)) | ((ya >> (NL - G)) << G) | (xa >> (NL - G))], xa, ya, za);
+  if (!(g8 & kFlag)) return;
+  uint32_t tile = g8 & kMask, v = 0u;
+  for (int l = G + 1; l <= NL; l++) {
+    const int sh = NL - l;
+    const uint32_t oct = ((xa >> sh) & 1u) | (((ya >> sh) & 1u) << 1) | (((za >> sh) & 1u) << 2);
+    const uint32_t q = lane & 7u;
+    const uint2 sib = nodes[tile + q];  // lane q < 8: sibling q (the path's own node at q == oct)
+    const uint32_t code = l == NL ? 1u : 4u + (uint32_t)(l - G);
+    const uint32_t want = v | code | (((sib.y >> 24) >= 254u) ? (1u << (l - 5)) : 0u);
+    // first brick of sibling q (window-relative brick coordinates): the parent's prefix, q's octant bit at sh, zeros below
+    const uint32_t m = ~((2u << sh) - 1u);
+    const uint32_t sx = (xr & m) | ((q & 1u) << sh), sy = (yr & m) | (((q >> 1) & 1u) << sh), sz = (zr & m) | ((q >> 2) << sh);
+    bool need = lane < 8u && q != oct && !(sib.x & kFlag);
+    if (need) need = bricks[brick_entry_index(sx << 2, sy << 2, sz << 2)] != (uint16_t)want;
+    unsigned long long todo = __ballot(need);
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      const uint32_t bx = (uint32_t)__shfl((int)sx, src), by = (uint32_t)__shfl((int)sy, src), bz = (uint32_t)__shfl((int)sz, src);
+      const uint32_t val = (uint32_t)__shfl((int)want, src);
+      const uint32_t span = 1u << sh;  // bricks per axis under the sibling
+      for (uint32_t dz = 0; dz < span; dz++)
+        for (uint32_t dy = 0; dy < span; dy++)
+          for (uint32_t dx = 0; dx < span; dx++)
+            bricks[brick_entry_index(((bx + dx) << 2) | (lane & 3u), ((by + dy) << 2) | ((lane >> 2) & 3u), ((bz + dz) << 2) | (lane >> 4))] = (uint16_t)val;
+      if (lane == 0) {
+        const uint32_t grp = ((bz >> 3) << (2 * kBrickGroupLevel)) | ((by >> 3) << kBrickGroupLevel) | (bx >> 3);
+        if (!((touched[grp >> 5] >> (grp & 31u)) & 1u)) atomicOr(&touched[grp >> 5], 1u << (grp & 31u));
       }
-      if (has) g[k].x = kFlag | base;
     }
-    on[k] = (g[k].x & kFlag) != 0u;
-    w9[k] = on[k] ? nodes[(g[k].x & kMask) + ((x9[k] & 1u) | ((y9[k] & 1u) << 1) | ((z9[k] & 1u) << 2))] : make_uint2(0u, 0u);
+    // on along the path
+    const uint2 w = make_uint2((uint32_t)__shfl((int)sib.x, (int)oct), (uint32_t)__shfl((int)sib.y, (int)oct));
+    v |= ((w.y >> 24) >= 254u) ? (1u << (l - 5)) : 0u;
+    if (!(w.x & kFlag)) return;
+    tile = w.x & kMask;
+  }
+}
+
+template <int N, int S>
+__device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint2 *__restrict__ grid, uint16_t *__restrict__ bricks,
+                                     uint32_t *__restrict__ touched, const uint32_t (&xr)[N], const uint32_t (&yr)[N], const uint32_t (&zr)[N],
+                                     const bool (&live)[N], unsigned lane, bool trust_mip) {
+  constexpr int G = kPoolGridLevel, NL = brick_node_level(S);
+  constexpr uint32_t kOrg = brick_window_origin(S) >> 2;  // in bricks
+  uint32_t xa[N], ya[N], za[N];  // the brick nodes' coordinates at level NL
+  uint2 g[N];
+  uint32_t v[N], tile[N];
+  bool on[N], write[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    xa[k] = xr[k] + kOrg; ya[k] = yr[k] + kOrg; za[k] = zr[k] + kOrg;
+    g[k] = live[k] ? grid[((za[k] >> (NL - G)) << (2 * G)) | ((ya[k] >> (NL - G)) << G) | (xa[k] >> (NL - G))] : make_uint2(0u, 0u);
   }
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    v[k] = ((w9[k].y >> 24) >= 254u) ? 0x10u : 0u;
-    on10[k] = on[k] && (w9[k].x & kFlag);
-    if (on[k] && !on10[k]) v[k] |= 1u;
-    w10[k] = on10[k] ? nodes[(w9[k].x & kMask) + (lane >> 3)] : make_uint2(0u, 0u);
+    if (live[k]) g[k].x = brick_level8<NL>(nodes, g[k], xa[k], ya[k], za[k]);
+    on[k] = (g[k].x & kFlag) != 0u;   // the path is alive: its node at the level above has children
+    write[k] = on[k];                 // a line is written iff the level-8 node has children
+    tile[k] = g[k].x & kMask;
+    v[k] = 0u;
   }
+  // the wavefront-uniform levels 9 .. NL
+#pragma unroll
+  for (int l = G + 1; l <= NL; l++) {
+    uint2 w[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      const int sh = NL - l;
+      const uint32_t oct = ((xa[k] >> sh) & 1u) | (((ya[k] >> sh) & 1u) << 1) | (((za[k] >> sh) & 1u) << 2);
+      w[k] = on[k] ? nodes[tile[k] + oct] : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      if (on[k]) {
+        v[k] |= ((w[k].y >> 24) >= 254u) ? (1u << (l - 5)) : 0u;
+        if (!(w[k].x & kFlag)) { v[k] |= l == NL ? 1u : 4u + (uint32_t)(l - G); on[k] = false; }  // the path stops here for every cell of the brick
+        tile[k] = w[k].x & kMask;
+      }
+    }
+  }
+  // the two per-lane levels and the tile of the bits level
+  uint2 w10[N], w11[N];
+  bool on11[N], on12[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) w10[k] = on[k] ? nodes[tile[k] + (lane >> 3)] : make_uint2(0u, 0u);
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    v[k] |= ((w10[k].y >> 24) >= 254u) ? 0x20u : 0u;
-    on11[k] = on10[k] && (w10[k].x & kFlag);
-    if (on10[k] && !on11[k]) v[k] |= 2u;
+    v[k] |= ((w10[k].y >> 24) >= 254u) ? (1u << (NL + 1 - 5)) : 0u;
+    on11[k] = on[k] && (w10[k].x & kFlag);
+    if (on[k] && !on11[k]) v[k] |= 2u;
     w11[k] = on11[k] ? nodes[(w10[k].x & kMask) + (lane & 7u)] : make_uint2(0u, 0u);
   }
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    v[k] |= ((w11[k].y >> 24) >= 254u) ? 0x40u : 0u;
+    v[k] |= ((w11[k].y >> 24) >= 254u) ? (1u << (NL + 2 - 5)) : 0u;
     on12[k] = on11[k] && (w11[k].x & kFlag);
     if (on11[k] && !on12[k]) v[k] |= 3u;
 #ifdef SVO_BRICK_DIAG
-    {  // level-11 nodes with children, and how many of them are saturated (would their level-12 tiles have to be read?)
+    {  // cell-level nodes with children, and how many of them are saturated (would their tiles have to be read?)
       const unsigned long long m12 = __ballot(on12[k]), msat = __ballot(on12[k] && (w11[k].y >> 24) >= 254u);
       if (lane == 0) { atomicAdd(&touched[kBrickGroupWords + 3], (uint32_t)__popcll(m12)); atomicAdd(&touched[kBrickGroupWords + 4], (uint32_t)__popcll(msat)); }
     }
 #endif
     if (on12[k]) v[k] |= 4u;
-    // PoolAccel::mip_consistent: an unsaturated level-11 node has no saturated child; whether a child has children is left open
+    // PoolAccel::mip_consistent: an unsaturated cell-level node has no saturated child; whether a child has children is left open
     if (on12[k] && trust_mip && (w11[k].y >> 24) < 254u) { v[k] |= 8u; on12[k] = false; }
     if (on12[k]) {
-      const uint2 *tile = nodes + (w11[k].x & kMask);  // the eight level-12 children
+      const uint2 *t12 = nodes + (w11[k].x & kMask);  // the eight children at the bits level
 #pragma unroll
       for (int q = 0; q < 8; q++) {
-        const uint2 c = tile[q];
+        const uint2 c = t12[q];
         v[k] |= ((c.y >> 24) >= 254u) ? (0x100u << q) : 0u;
         v[k] |= (c.x & kFlag) ? 8u : 0u;
       }
@@ -267,11 +348,11 @@ __device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint
   }
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    if (!on[k]) continue;
-    // cell of this lane: x bit 1 = level-10 octant bit, x bit 0 = level-11 octant bit (likewise y, z)
-    const uint32_t cx = (x9[k] << 2) | (((lane >> 3) & 1u) << 1) | (lane & 1u);
-    const uint32_t cy = (y9[k] << 2) | (((lane >> 4) & 1u) << 1) | ((lane >> 1) & 1u);
-    const uint32_t cz = (z9[k] << 2) | (((lane >> 5) & 1u) << 1) | ((lane >> 2) & 1u);
+    if (!write[k]) continue;
+    // cell of this lane (window-relative): x bit 1 = the octant bit at level NL + 1, x bit 0 = at level NL + 2 (likewise y, z)
+    const uint32_t cx = (xr[k] << 2) | (((lane >> 3) & 1u) << 1) | (lane & 1u);
+    const uint32_t cy = (yr[k] << 2) | (((lane >> 4) & 1u) << 1) | ((lane >> 1) & 1u);
+    const uint32_t cz = (zr[k] << 2) | (((lane >> 5) & 1u) << 1) | ((lane >> 2) & 1u);
 #ifdef SVO_BRICK_DIAG
     {  // how many rebuilt bricks actually change (diagnostic build)
       const bool diff = bricks[brick_entry_index(cx, cy, cz)] != (uint16_t)v[k];
@@ -281,7 +362,7 @@ __device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint
 #endif
     bricks[brick_entry_index(cx, cy, cz)] = (uint16_t)v[k];
     if (lane == 0) {
-      const uint32_t grp = ((z9[k] >> 3) << (2 * kBrickGroupLevel)) | ((y9[k] >> 3) << kBrickGroupLevel) | (x9[k] >> 3);
+      const uint32_t grp = ((zr[k] >> 3) << (2 * kBrickGroupLevel)) | ((yr[k] >> 3) << kBrickGroupLevel) | (xr[k] >> 3);
       if (!((touched[grp >> 5] >> (grp & 31u)) & 1u)) atomicOr(&touched[grp >> 5], 1u << (grp & 31u));
     }
   }
@@ -289,17 +370,19 @@ __device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint
 
 constexpr int kBrickThreads = 256, kBrickBlocks = 2048, kBrickChains = 4;
 // the rings of the served states: entries [mark of the previous refresh, appended count), and this refresh's mark
+// (count_off = kBrickCountOffset: the stale bricks; kSibCountOffset: the sibling ring; the marks follow the count)
 struct BrickRings {
   uint32_t count[2], first[2];
 };
-__device__ inline BrickRings brick_rings(uint32_t *dirty_a, uint32_t *dirty_b, int par_a, int par_b, bool writer) {
+__device__ inline BrickRings brick_rings(uint32_t *dirty_a, uint32_t *dirty_b, int par_a, int par_b, bool writer, int count_off = kBrickCountOffset) {
   BrickRings r;
+  const int mark_off = count_off + 1;
   // (nothing appends to a served ring while this launch runs: commits of the served states are ordered around the render)
-  r.count[0] = dirty_a ? dirty_a[kBrickCountOffset] : 0u; r.count[1] = dirty_b ? dirty_b[kBrickCountOffset] : 0u;
-  r.first[0] = dirty_a ? dirty_a[kBrickMarkOffset + (par_a ^ 1)] : 0u; r.first[1] = dirty_b ? dirty_b[kBrickMarkOffset + (par_b ^ 1)] : 0u;
+  r.count[0] = dirty_a ? dirty_a[count_off] : 0u; r.count[1] = dirty_b ? dirty_b[count_off] : 0u;
+  r.first[0] = dirty_a ? dirty_a[mark_off + (par_a ^ 1)] : 0u; r.first[1] = dirty_b ? dirty_b[mark_off + (par_b ^ 1)] : 0u;
   if (writer) {  // what this refresh serves (nobody reads this word before the next refresh)
-    if (dirty_a) dirty_a[kBrickMarkOffset + par_a] = r.count[0];
-    if (dirty_b) dirty_b[kBrickMarkOffset + par_b] = r.count[1];
+    if (dirty_a) dirty_a[mark_off + par_a] = r.count[0];
+    if (dirty_b) dirty_b[mark_off + par_b] = r.count[1];
   }
   return r;
 }
@@ -308,7 +391,7 @@ __device__ inline bool brick_rings_lapped(const BrickRings &r) {
 }
 
 // one wavefront per listed brick, C of them side by side; `part` of `parts` wavefronts
-template <int C = kBrickChains>
+template <int C, int S>
 __device__ inline void brick_rebuild_listed(const uint2 *__restrict__ nodes, const uint2 *__restrict__ grid, uint16_t *__restrict__ bricks,
                                             uint32_t *__restrict__ touched, uint32_t *dirty_a, uint32_t *dirty_b, const BrickRings &r,
                                             uint32_t part, uint32_t parts, unsigned lane, bool trust_mip) {
@@ -325,71 +408,70 @@ __device__ inline void brick_rebuild_listed(const uint2 *__restrict__ nodes, con
         xs[k] = e & 511u; ys[k] = (e >> 9) & 511u; zs[k] = e >> 18;
         if (live[k] && lane == 0) atomicAnd(&dirty[kBrickBitsOffset + (e >> 5)], ~(1u << (e & 31u)));  // served: may be listed again
       }
-      brick_rebuild<C>(nodes, grid, bricks, touched, xs, ys, zs, live, lane, trust_mip);
+      brick_rebuild<C, S>(nodes, grid, bricks, touched, xs, ys, zs, live, lane, trust_mip);
     }
   }
 }
 
-// One wavefront per stale brick.  `all` (or a ring that was lapped): every level-8 cell with children instead -- a
-// wavefront reads 64 cells of the level grid and rebuilds the eight bricks of each one that has children.
+// the sibling ring: one wavefront per entry, `part` of `parts` wavefronts -- run by the workgroups of the refresh that update
+// the level grid (they have little to do), so that the rebuild's wavefronts carry none of this (woven into their load chains it
+// cost the refresh 10-23 us per frame; as a flag in the bricks' ring, found by scanning it, 18 us)
+template <int S>
+__device__ inline void brick_siblings_listed(const uint2 *__restrict__ nodes, const uint2 *__restrict__ grid, uint16_t *__restrict__ bricks,
+                                             uint32_t *__restrict__ touched, const uint32_t *dirty_a, const uint32_t *dirty_b, const BrickRings &r,
+                                             uint32_t part, uint32_t parts, unsigned lane) {
+  for (int state = 0; state < 2; state++) {
+    const uint32_t *dirty = state ? dirty_b : dirty_a;
+    uint32_t pending = r.count[state] - r.first[state];
+    const uint32_t first = r.first[state];
+    if (pending > (uint32_t)kSibListCap) pending = (uint32_t)kSibListCap;  // lapped: the newest entries (the others' siblings walk the tree)
+    for (uint32_t i = part; i < pending; i += parts) {
+      const uint32_t f = dirty[kSibListOffset + ((first + i) & (uint32_t)(kSibListCap - 1))] & 0x07FFFFFFu;
+      brick_siblings<S>(nodes, grid, bricks, touched, f & 511u, (f >> 9) & 511u, f >> 18, lane);
+    }
+  }
+}
+
+// Every brick of the pool (a fresh field, a pool changed by anything but this library's commits, a change of shape): a
+// wavefront reads 64 cells of the level grid and rebuilds the 8^(S + 1) bricks below each one that has children (those inside
+// the window).  Everything listed so far in the served states is served by this pass.
+template <int S>
 __global__ __launch_bounds__(kBrickThreads) void brick_rebuild_kernel(const uint32_t *__restrict__ octree, const uint2 *__restrict__ grid,
                                                                       uint16_t *__restrict__ bricks, uint32_t *__restrict__ touched,
-                                                                      uint32_t *__restrict__ dirty_a, uint32_t *__restrict__ dirty_b, int all,
+                                                                      uint32_t *__restrict__ dirty_a, uint32_t *__restrict__ dirty_b,
                                                                       int trust_mip, int par_a, int par_b) {
   const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   constexpr unsigned kWaves = kBrickThreads / 64;
-  const BrickRings r = brick_rings(dirty_a, dirty_b, par_a, par_b, blockIdx.x == 0 && threadIdx.x == 0);
-  if (all || brick_rings_lapped(r)) {
-    constexpr int G = kPoolGridLevel;
-    constexpr uint32_t kCells = 1u << (3 * G);
-    // everything listed so far is served by this pass: no brick is "in the ring" any more
-    for (uint32_t w = blockIdx.x * kBrickThreads + threadIdx.x; w < (uint32_t)kBrickBitsWords; w += kBrickBlocks * kBrickThreads) {
-      if (dirty_a) dirty_a[kBrickBitsOffset + w] = 0u;
-      if (dirty_b) dirty_b[kBrickBitsOffset + w] = 0u;
-    }
-    for (uint32_t c0 = (blockIdx.x * kWaves + wave) * 64u; c0 < kCells; c0 += kBrickBlocks * kWaves * 64u) {
-      const uint32_t cell = c0 + lane;
-      unsigned long long m = __ballot((grid[cell].x & kFlag) != 0u);
-      while (m) {
-        const uint32_t hit = c0 + (uint32_t)(__ffsll((long long)m) - 1);
-        m &= m - 1ull;
-        const uint32_t x8 = hit & ((1u << G) - 1u), y8 = (hit >> G) & ((1u << G) - 1u), z8 = hit >> (2 * G);
+  (void)brick_rings(dirty_a, dirty_b, par_a, par_b, blockIdx.x == 0 && threadIdx.x == 0);  // (writes this refresh's marks)
+  (void)brick_rings(dirty_a, dirty_b, par_a, par_b, blockIdx.x == 0 && threadIdx.x == 0, kSibCountOffset);
+  constexpr int G = kPoolGridLevel;
+  constexpr uint32_t kCells = 1u << (3 * G);
+  constexpr uint32_t kOrg = brick_window_origin(S) >> 2, kSpan = kBrickWindowCells >> 2;  // the window, in bricks
+  for (uint32_t w = blockIdx.x * kBrickThreads + threadIdx.x; w < (uint32_t)kBrickBitsWords; w += kBrickBlocks * kBrickThreads) {  // no brick is "in the ring" any more
+    if (dirty_a) dirty_a[kBrickBitsOffset + w] = 0u;
+    if (dirty_b) dirty_b[kBrickBitsOffset + w] = 0u;
+  }
+  for (uint32_t c0 = (blockIdx.x * kWaves + wave) * 64u; c0 < kCells; c0 += kBrickBlocks * kWaves * 64u) {
+    const uint32_t cell = c0 + lane;
+    unsigned long long m = __ballot((grid[cell].x & kFlag) != 0u);
+    while (m) {
+      const uint32_t hit = c0 + (uint32_t)(__ffsll((long long)m) - 1);
+      m &= m - 1ull;
+      const uint32_t x8 = hit & ((1u << G) - 1u), y8 = (hit >> G) & ((1u << G) - 1u), z8 = hit >> (2 * G);
+      // the bricks below the cell, eight at a time: `up` = the octants of the levels between the cell and the brick node's parent
+      for (uint32_t up = 0; up < (1u << (3 * S)); up++) {
+        uint32_t px = x8, py = y8, pz = z8;
+        for (int q = S - 1; q >= 0; q--) { const uint32_t o = (up >> (3 * q)) & 7u; px = (px << 1) | (o & 1u); py = (py << 1) | ((o >> 1) & 1u); pz = (pz << 1) | (o >> 2); }
         uint32_t xs[8], ys[8], zs[8];
         bool live[8];
 #pragma unroll
-        for (uint32_t o = 0; o < 8u; o++) { xs[o] = (x8 << 1) | (o & 1u); ys[o] = (y8 << 1) | ((o >> 1) & 1u); zs[o] = (z8 << 1) | (o >> 2); live[o] = true; }
-        brick_rebuild<8>(nodes, grid, bricks, touched, xs, ys, zs, live, lane, trust_mip != 0);
+        for (uint32_t o = 0; o < 8u; o++) {
+          xs[o] = ((px << 1) | (o & 1u)) - kOrg; ys[o] = ((py << 1) | ((o >> 1) & 1u)) - kOrg; zs[o] = ((pz << 1) | (o >> 2)) - kOrg;
+          live[o] = (xs[o] | ys[o] | zs[o]) < kSpan;
+        }
+        if (live[0]) brick_rebuild<8, S>(nodes, grid, bricks, touched, xs, ys, zs, live, lane, trust_mip != 0);  // (aligned groups: all eight in or out; this pass visits the siblings itself)
       }
-    }
-  } else {
-    brick_rebuild_listed(nodes, grid, bricks, touched, dirty_a, dirty_b, r, blockIdx.x * kWaves + wave, kBrickBlocks * kWaves, lane, trust_mip != 0);
-  }
-}
-
-// the lines of the listed bricks become "ask the level grid" (zero) until the rebuild, which now runs beside the march, has
-// rewritten them; a lapped ring zeroes every group that holds bricks (the rebuild will then redo them all)
-__global__ __launch_bounds__(kBrickThreads) void brick_invalidate_kernel(uint16_t *__restrict__ bricks, const uint32_t *__restrict__ touched,
-                                                                         uint32_t *__restrict__ dirty_a, uint32_t *__restrict__ dirty_b, int par_a,
-                                                                         int par_b) {
-  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  constexpr unsigned kWaves = kBrickThreads / 64;
-  const BrickRings r = brick_rings(dirty_a, dirty_b, par_a, par_b, false);  // (the rebuild that follows writes the mark)
-  const uint32_t count_a = r.count[0], count_b = r.count[1], first_a = r.first[0], first_b = r.first[1];
-  if (brick_rings_lapped(r)) {
-    for (uint32_t grp = blockIdx.x; grp < (uint32_t)kBrickGroups; grp += gridDim.x) {
-      if (!((touched[grp >> 5] >> (grp & 31u)) & 1u)) continue;
-      uint4 *p = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(bricks) + (size_t)grp * kBrickGroupBytes);
-      for (uint32_t i = threadIdx.x; i < (uint32_t)(kBrickGroupBytes / 16); i += kBrickThreads) p[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    return;
-  }
-  for (int state = 0; state < 2; state++) {
-    const uint32_t *dirty = state ? dirty_b : dirty_a;
-    const uint32_t pending = state ? count_b - first_b : count_a - first_a, first = state ? first_b : first_a;
-    for (uint32_t i = blockIdx.x * kWaves + wave; i < pending; i += gridDim.x * kWaves) {
-      const uint32_t e = dirty[kBrickListOffset + ((first + i) & (uint32_t)(kBrickListCap - 1))];
-      bricks[brick_entry_index((e & 511u) << 2, ((e >> 9) & 511u) << 2, (e >> 18) << 2) + lane] = (uint16_t)0;
     }
   }
 }
@@ -453,19 +535,23 @@ __global__ __launch_bounds__(kUpdateThreads) void pool_grid_update_kernel(const 
 // two boxes: 2028-2372 (median 2236) against 2019-2401 (median 2362) -- a march that starts 15 us earlier meets the other streams' launches
 // at a worse moment (the schedule's steady states).  The slower shape stays.
 constexpr int kRefreshBrickBlocks = kBrickBlocks, kRefreshGridBlocks = 1024, kRefreshChains = kBrickChains;
-template <int C>
+template <int C, int S>
 __global__ __launch_bounds__(kBrickThreads) void pool_refresh_kernel(const uint32_t *__restrict__ octree, uint2 *grid, uint16_t *__restrict__ bricks,
                                                                       uint32_t *__restrict__ touched, uint32_t *dirty_a, uint32_t *dirty_b,
                                                                       int trust_mip, int par_a, int par_b, unsigned brick_blocks) {
   const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
   // (the bricks' workgroups first: they are the long ones; 2048 nearly empty grid workgroups ahead of them cost the launch 20 us)
-  if (blockIdx.x >= brick_blocks) {
-    pool_grid_update_blocks(nodes, grid, dirty_a, dirty_b, blockIdx.x - brick_blocks, kRefreshGridBlocks);
-    return;
-  }
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   constexpr unsigned kWaves = kBrickThreads / 64;
   const unsigned bb = blockIdx.x;
+  if (bb >= brick_blocks) {
+    pool_grid_update_blocks(nodes, grid, dirty_a, dirty_b, bb - brick_blocks, kRefreshGridBlocks);
+    // ... and the childless siblings of the listed bricks whose commit created them (brick_siblings_listed)
+    const BrickRings rs = brick_rings(dirty_a, dirty_b, par_a, par_b, bb == brick_blocks && threadIdx.x == 0, kSibCountOffset);
+    if (!brick_rings_lapped(brick_rings(dirty_a, dirty_b, par_a, par_b, false)))  // (a lapped brick ring zeroes every group: nothing to complete)
+      brick_siblings_listed<S>(nodes, grid, bricks, touched, dirty_a, dirty_b, rs, (bb - brick_blocks) * kWaves + wave, kRefreshGridBlocks * kWaves, lane);
+    return;
+  }
   const BrickRings r = brick_rings(dirty_a, dirty_b, par_a, par_b, bb == 0 && threadIdx.x == 0);
   if (brick_rings_lapped(r)) {
     // more than a million distinct bricks listed since the last refresh (never seen): the ring has lost entries.  Every group
@@ -482,7 +568,7 @@ __global__ __launch_bounds__(kBrickThreads) void pool_refresh_kernel(const uint3
     }
     return;
   }
-  brick_rebuild_listed<C>(nodes, grid, bricks, touched, dirty_a, dirty_b, r, bb * kWaves + wave, brick_blocks * kWaves, lane, trust_mip != 0);
+  brick_rebuild_listed<C, S>(nodes, grid, bricks, touched, dirty_a, dirty_b, r, bb * kWaves + wave, brick_blocks * kWaves, lane, trust_mip != 0);
 }
 
 // SVOSLAM_MARCH_BRICKS=0: no occupancy bricks (the march walks the tree below the level grid, as in round 2)
@@ -491,14 +577,15 @@ static bool bricks_enabled() {
   return on;
 }
 
-// deepest fusion a pool may have seen and still be marched over bricks (PoolAccel::max_depth); SVOSLAM_BRICK_MAX_DEPTH overrides
-static int brick_max_depth() {
-  static const int d = [] { const char *e = getenv("SVOSLAM_BRICK_MAX_DEPTH"); return e ? atoi(e) : 12; }();
-  return d;
-}
-
+// The field is 16 GiB of the 288 GB, allocated by the first reference-mode render of a pool.  It is only taken when it leaves
+// room: after it, at least twice its size must stay free for pool growth, shadow words and the caller's own
+// tensors -- several live pools, or ranks / test processes sharing one device, otherwise end in an out-of-memory error far from
+// here; a pool that does not get its field is marched through the tree (correct, slower).
 static void ensure_bricks(PoolAccel *pa, hipStream_t stream) {
   if (pa->bricks || pa->bricks_failed) return;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); pa->bricks_failed = true; return; }
+  if (free_b < 3 * kBrickFieldBytes) { pa->bricks_failed = true; return; }
   void *field = nullptr, *touched = nullptr;
   if (hipMalloc(&field, kBrickFieldBytes) != hipSuccess || hipMalloc(&touched, (kBrickGroupWords + 8) * 4) != hipSuccess ||
       hipMemsetAsync(field, 0, kBrickFieldBytes, stream) != hipSuccess ||
@@ -515,7 +602,7 @@ static void ensure_bricks(PoolAccel *pa, hipStream_t stream) {
 }
 
 int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stream, const uint2 **d_grid, bool want_bricks,
-                       const uint16_t **d_bricks) {
+                       const uint16_t **d_bricks, int *brick_shift) {
   if (!pa || !d_octree || !d_grid) return SVOSLAM_ERR_INVALID_ARG;
   constexpr size_t kCells = (size_t)1 << (3 * kPoolGridLevel);
   // the whole enqueue under the lock: the grid's host-side state (valid, last_stream) and the launches that make it
@@ -534,9 +621,11 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
     else (void)hipGetLastError();  // (a stream destroyed without svoslam_cone_trace_release: nothing left to wait for)
   }
   pa->last_stream = stream;
-  // a rebuild handed to the pool's own stream by the previous refresh: this refresh (its ring marks, the grid it reads) comes after it
-  if (pa->rebuild_in_flight) SVO_HIP(hipStreamWaitEvent(stream, pa->ev_rebuilt, 0));
-  if (want_bricks && bricks_enabled() && pa->max_depth <= brick_max_depth()) ensure_bricks(pa, stream);  // (behind the ordering above: the first fill runs on `stream`)
+  // the brick shape follows the deepest fusion the pool has seen (commits enqueued so far list stale bricks in that shape: they
+  // asked pool_accel_dirty_bitmap, which raised max_depth first); a change of shape rebuilds every brick
+  const int shift = brick_shift_for_depth(pa->max_depth);
+  if (want_bricks && bricks_enabled() && shift >= 0) ensure_bricks(pa, stream);  // (behind the ordering above: the first fill runs on `stream`)
+  if (pa->bricks && shift != pa->brick_shift) { pa->brick_shift = shift; pa->bricks_valid = false; }
   const bool fresh = !pa->valid;
   pa->valid = true;
   uint32_t *serve[2] = {nullptr, nullptr};  // the dirty states this render consumes
@@ -548,52 +637,27 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
   }
   for (int k = 0; k < 2; k++) serve[k] = serve_idx[k] >= 0 ? pa->d_dirty[serve_idx[k]] : nullptr;
   uint2 *grid = pa->grid.as<uint2>();
+  const bool use_bricks = pa->bricks && shift >= 0;
   // once a pool has bricks every refresh keeps them current, whatever the mode of the render that asks
-  const bool bricks_all = pa->bricks && (fresh || !pa->bricks_valid);
+  const bool bricks_all = use_bricks && (fresh || !pa->bricks_valid);
   // the rings' marks alternate per state and refresh (kBrickMarkOffset)
   const int par_a = serve_idx[0] >= 0 ? (int)(pa->brick_served[serve_idx[0]] & 1u) : 0, par_b = serve_idx[1] >= 0 ? (int)(pa->brick_served[serve_idx[1]] & 1u) : 0;
-  if (pa->bricks) {
-    // SVOSLAM_BRICK_TRUST_MIP=0: the rebuild reads every level-12 tile whatever the pool's history (A/B measurements)
+  if (use_bricks) {
+    // SVOSLAM_BRICK_TRUST_MIP=0: the rebuild reads every tile of the bits level whatever the pool's history (A/B measurements)
     static const bool trust_on = [] { const char *e = getenv("SVOSLAM_BRICK_TRUST_MIP"); return !(e && e[0] == '0'); }();
     const int trust = trust_on && pa->mip_consistent ? 1 : 0;
-    // SVOSLAM_BRICK_ASYNC=1: the rebuild beside the march (PoolAccel::s_rebuild).  Built, bit-exact, measured, and LOST: the rays
-    // reach the surfaces before the rebuild does and pay tree walks in the rare-sample path -- march 0.325 -> 0.395 ms, cfg3 2140 ->
-    // 1990 frames/s, the driver's 20 frames 1785 -> 1674 -- so the rebuild stays in line on the map stream
-    static const bool async = [] { const char *e = getenv("SVOSLAM_BRICK_ASYNC"); return e && e[0] == '1'; }();
-    // SVOSLAM_BRICK_FUSED_REFRESH=0: grid update and brick rebuild as two launches (A/B measurements)
-    static const bool fused = [] { const char *e = getenv("SVOSLAM_BRICK_FUSED_REFRESH"); return !(e && e[0] == '0'); }();
     if (bricks_all) {
       if (fresh) pool_grid_build_kernel<<<(unsigned)(kCells / 256), 256, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
       else pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
       brick_clear_kernel<<<2048, 256, 0, stream>>>(pa->bricks, pa->d_brick_touched);
-      brick_rebuild_kernel<<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], 1, trust, par_a, par_b);
-    } else if (async) {
-      pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
-      if (!pa->s_rebuild) {
-        SVO_HIP(hipStreamCreateWithFlags(&pa->s_rebuild, hipStreamNonBlocking));
-        SVO_HIP(hipEventCreateWithFlags(&pa->ev_ready, hipEventDisableTiming));
-        SVO_HIP(hipEventCreateWithFlags(&pa->ev_rebuilt, hipEventDisableTiming));
-      }
-      brick_invalidate_kernel<<<kBrickBlocks, kBrickThreads, 0, stream>>>(pa->bricks, pa->d_brick_touched, serve[0], serve[1], par_a, par_b);
-      SVO_HIP(hipEventRecord(pa->ev_ready, stream));
-      SVO_HIP(hipStreamWaitEvent(pa->s_rebuild, pa->ev_ready, 0));
-      brick_rebuild_kernel<<<kBrickBlocks, kBrickThreads, 0, pa->s_rebuild>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], 0, trust, par_a, par_b);
-      SVO_HIP(hipEventRecord(pa->ev_rebuilt, pa->s_rebuild));
-      pa->rebuild_in_flight = true;
-    } else if (fused) {
-      // (A/B: SVOSLAM_REFRESH_BLOCKS = workgroups of the bricks' part, SVOSLAM_REFRESH_CHAINS = 1 / 2 / 4 / 8 bricks per wavefront side by side)
-      static const unsigned bblocks = [] { const char *e = getenv("SVOSLAM_REFRESH_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : (unsigned)kRefreshBrickBlocks; }();
-      static const int chains = [] { const char *e = getenv("SVOSLAM_REFRESH_CHAINS"); return e ? atoi(e) : kRefreshChains; }();
-      auto launch = [&](auto kernel) {
-        kernel<<<bblocks + kRefreshGridBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], trust, par_a, par_b, bblocks);
-      };
-      if (chains == 1) launch(pool_refresh_kernel<1>);
-      else if (chains == 2) launch(pool_refresh_kernel<2>);
-      else if (chains == 8) launch(pool_refresh_kernel<8>);
-      else launch(pool_refresh_kernel<4>);
+      if (shift == 0) brick_rebuild_kernel<0><<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], trust, par_a, par_b);
+      else brick_rebuild_kernel<1><<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], trust, par_a, par_b);
     } else {
-      pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
-      brick_rebuild_kernel<<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], 0, trust, par_a, par_b);
+      // grid update and brick rebuild in ONE launch.  (Measured and not kept, round 3: the rebuild on a stream of its own beside
+      // the march -- rays reach the surfaces before the rebuild does and pay tree walks: march 0.325 -> 0.395 ms; two launches;
+      // 4096 workgroups x 2 bricks per wavefront -- kernel 55 -> 40 us, frame rate lower: DESIGN.md section 4.)
+      if (shift == 0) pool_refresh_kernel<kRefreshChains, 0><<<kRefreshBrickBlocks + kRefreshGridBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], trust, par_a, par_b, kRefreshBrickBlocks);
+      else pool_refresh_kernel<kRefreshChains, 1><<<kRefreshBrickBlocks + kRefreshGridBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], trust, par_a, par_b, kRefreshBrickBlocks);
     }
     for (int k = 0; k < 2; k++)
       if (serve_idx[k] >= 0) pa->brick_served[serve_idx[k]]++;
@@ -605,20 +669,21 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
         uint32_t c[5];
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(c, pa->d_brick_touched + kBrickGroupWords, 20, hipMemcpyDeviceToHost);
-        fprintf(stderr, "brick diag after %d refreshes: rebuilt %u bricks, %u of them changed, %u entries changed; %u level-11 nodes with children, %u of them saturated\n",
+        fprintf(stderr, "brick diag after %d refreshes: rebuilt %u bricks, %u of them changed, %u entries changed; %u cell-level nodes with children, %u of them saturated\n",
                 calls, c[0], c[1], c[2], c[3], c[4]);
         (void)hipMemset(pa->d_brick_touched + kBrickGroupWords, 0, 20);
       }
     }
 #endif
-  } else if (fresh) {
-    pool_grid_build_kernel<<<(unsigned)(kCells / 256), 256, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
   } else {
-    pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
+    pa->bricks_valid = false;  // (a field that exists but is not kept current -- a pool deeper than any shape -- is stale from here on)
+    if (fresh) pool_grid_build_kernel<<<(unsigned)(kCells / 256), 256, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
+    else pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
   }
   SVO_LAUNCH_CHECK();
   *d_grid = grid;
-  if (d_bricks) *d_bricks = pa->max_depth <= brick_max_depth() ? pa->bricks : nullptr;
+  if (d_bricks) *d_bricks = use_bricks ? pa->bricks : nullptr;
+  if (brick_shift) *brick_shift = use_bricks ? shift : -1;
   return SVOSLAM_OK;
 }
 

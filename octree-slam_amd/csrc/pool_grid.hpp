@@ -58,14 +58,6 @@ struct PoolAccel {
   bool bricks_valid = false;
   unsigned brick_served[2] = {0u, 0u};  // how often each dirty state's ring has been served (its parity picks the mark: kBrickMarkOffset)
   bool bricks_failed = false;           // the field could not be allocated: this pool is marched through the tree
-  // SVOSLAM_BRICK_ASYNC=1 (opt-in; measured slower, see pool_accel_refresh): the rebuild of the stale bricks runs BESIDE the
-  // march: the refresh zeroes the listed bricks' lines on the render's stream (zero = "ask the level grid", which says "has children": such a sample walks the tree -- correct, slower),
-  // hands the rebuild to this stream and lets the march start at once; a ray that reaches a brick before its rebuild does
-  // pays a tree walk for that sample.  ev_ready: grid updated + lines zeroed (the rebuild waits for it); ev_rebuilt: the
-  // rebuild's end (the next refresh, and everything that writes the pool, waits for it).
-  hipStream_t s_rebuild = nullptr;
-  hipEvent_t ev_ready = nullptr, ev_rebuilt = nullptr;
-  bool rebuild_in_flight = false;
   // Every colour word of the pool was computed by this library's fusion from an empty pool (any path: blocking, phased,
   // deferred): then a node with children carries the MAXIMUM of its children's alphas (averageChildren, svo.cu:384-447,
   // re-run for every ancestor of a touched leaf), so a level-11 node with A < 254 has no saturated child and the brick
@@ -73,10 +65,12 @@ struct PoolAccel {
   // tree).  On the 300-frame cfg3 map that is every one of the 1.5 M tiles a refresh used to read (no 2 mm leaf collects
   // its 127 observations).  Foreign words (set_nodes / load / copy / paging / touch) clear the flag until the next reset.
   bool mip_consistent = true;
-  // deepest commit so far.  Bricks describe levels 9..12: a sample whose LOD reaches below a level-12 node with children
-  // walks the tree, so a pool fused deeper than 12 (1920x1080 at depth 14: LOD 13 at two metres) gets no bricks at all
-  // -- its march is the tree march (measured: 0.67 ms against 0.90 with bricks that defer most of their samples)
+  // deepest commit so far, and the brick shape that follows from it (brick_shift_for_depth): bricks describe levels 9 + s .. 12 + s,
+  // a sample whose LOD reaches below a level-(12 + s) node with children walks the tree.  Pools fused to depth <= 12 (640x480
+  // at a 4 m half edge: LODs 9..12) take s = 0, depth 13 / 14 (1920x1080 into a depth-14 SVO: LOD 13 between one and two
+  // metres) s = 1; deeper pools get no bricks.  brick_shift = the shape the field currently holds (-1: none built yet).
   int max_depth = 0;
+  int brick_shift = -1;
   ~PoolAccel();  // device buffers live as long as the last holder of the entry (std::shared_ptr)
 };
 
@@ -88,11 +82,9 @@ void pool_accel_unregister(svoslam_pool *pool);
 // depth > 0: of the fusion that changed the pool; < 0: the pool is empty again.  foreign_words: the nodes now hold words this
 // library's fusion did not compute (set_nodes / load / copy / paging / svoslam_pool_touch): see PoolAccel::mip_consistent
 void pool_accel_invalidate(svoslam_pool *pool, int depth = 0, bool foreign_words = true);
-uint32_t *pool_accel_dirty_bitmap(svoslam_pool *pool, int parity, int commit_depth = 0);  // nullptr for memory that is not a registered pool;
-// commit_depth: the depth of the commit that is about to mark (the pool remembers the deepest one: see PoolAccel::max_depth)
-// `stream` is about to WRITE the pool's nodes (in-place commit, apply of a deferred one): order it behind a brick rebuild
-// that may still be reading them
-int pool_accel_order_writer(svoslam_pool *pool, hipStream_t stream);
+uint32_t *pool_accel_dirty_bitmap(svoslam_pool *pool, int parity, int commit_depth = 0, int *brick_shift = nullptr);  // nullptr for memory that is not a registered pool;
+// commit_depth: the depth of the commit that is about to mark (the pool remembers the deepest one: see PoolAccel::max_depth);
+// *brick_shift: the brick shape the commit lists stale bricks in (-1: the pool gets no bricks)
 std::shared_ptr<PoolAccel> pool_accel_find(const uint32_t *d_data);  // the registered pool whose nodes start at d_data, or null;
 // the caller holds the entry for the duration of its enqueue (a pool_free / growth on another host thread cannot pull it away)
 void pool_accel_forget_stream(hipStream_t stream);       // the stream is about to be destroyed
@@ -107,7 +99,7 @@ bool pool_shadow_pending(svoslam_pool *pool);
 // want_bricks: also bring the occupancy bricks up to date (allocating them on first use); *d_bricks = the field, or
 // nullptr when the pool has none (not wanted so far, SVOSLAM_MARCH_BRICKS=0, or no memory for them)
 int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stream, const uint2 **d_grid, bool want_bricks,
-                       const uint16_t **d_bricks);
+                       const uint16_t **d_bricks, int *brick_shift);  // *brick_shift: the shape of *d_bricks (pool_grid.hpp "Shapes")
 
 constexpr int kPoolGridListOffset = kPoolGridDirtyWords;                     // words
 constexpr int kPoolGridCountOffset = kPoolGridDirtyWords + kPoolGridBlocks;  // words
@@ -123,7 +115,13 @@ constexpr int kBrickListCap = 1 << 20;  // more than this pending = "rebuild eve
 // N frames per march, and the bricks of consecutive frames are mostly the same ones (16 MB per state)
 constexpr int kBrickBitsOffset = kBrickListOffset + kBrickListCap;
 constexpr int kBrickBitsWords = 1 << (3 * 9 - 5);
-constexpr int kPoolGridStateWords = kBrickBitsOffset + kBrickBitsWords;
+// ... and a second, small ring of the same kind (count, two marks, entries): the listed bricks whose commit created nodes at or
+// above the brick node's level on the key's path -- the refresh writes the lines of the childless siblings those splits created
+// (pool_grid.hip, brick_siblings).  Lapping it loses nothing but speed: a sibling without its lines is marched through the tree.
+constexpr int kSibCountOffset = kBrickBitsOffset + kBrickBitsWords, kSibMarkOffset = kSibCountOffset + 1;
+constexpr int kSibListOffset = kSibCountOffset + 4;
+constexpr int kSibListCap = 1 << 16;
+constexpr int kPoolGridStateWords = kSibListOffset + kSibListCap;
 
 // ---- occupancy bricks (round 3; north_star's "4^3 bricks") -------------------------------------------------
 // In SVOSLAM_RENDER_REFERENCE mode a sample of the march needs two facts about the node the reference's walk ends on
@@ -143,8 +141,26 @@ constexpr int kPoolGridStateWords = kBrickBitsOffset + kBrickBitsWords;
 // to a list (each change of a commit lies on the path of one of its keys), the refresh of the level grid adds the eight
 // children of level-8 nodes that have just been split, and one wavefront per listed node rewrites its line before the
 // march.  Anything that invalidates the level grid clears the touched 64 KB groups and rebuilds every brick.
-constexpr int kBrickNodeLevel = 9, kBrickCellLevel = 11, kBrickGroupLevel = 6;
-constexpr size_t kBrickFieldEntries = (size_t)1 << (3 * kBrickCellLevel);
+// Shapes (round 4): shift s = 0 is the shape above; s = 1 moves every level down by one (bricks of level-10 nodes, level-12
+// cells, bits for the level-13 children) for pools fused to depth 13 / 14, and adds what the gap between the level-8 grid
+// and the brick node needs: stop code 5 = "the level-9 node on the path is childless", and bit 7 = A >= 254 of the level-(11 + s)
+// = cell-level node for s = 1 -- the saturation bits of the path are bits 4.. for levels 9.., so `bit = level - 5` in both
+// shapes.  The field stays 2 x 2048^3 bytes: for s = 1 it is a WINDOW of 2048^3 level-12 cells in the middle of the root cube
+// (half its edge: 8.2 m of the 16.4 m root of BASELINE config 4); a sample outside the window has no brick entry and takes the
+// level grid / the tree walk as before.  Ring entries and the dedupe bitmap hold window-relative brick coordinates (9 bits per
+// axis) in every shape.
+constexpr int kBrickGroupLevel = 6;  // (of the window: 64 KB groups of 8^3 bricks)
+constexpr int kBrickWindowBits = 11;
+constexpr uint32_t kBrickWindowCells = 1u << kBrickWindowBits;
+constexpr int kBrickMaxShift = 1;
+__host__ __device__ constexpr int brick_node_level(int s) { return 9 + s; }
+__host__ __device__ constexpr int brick_cell_level(int s) { return 11 + s; }
+__host__ __device__ constexpr int brick_bits_level(int s) { return 12 + s; }
+// first cell of the window on every axis, in cells of level 11 + s (a multiple of 32: whole groups)
+__host__ __device__ constexpr uint32_t brick_window_origin(int s) { return ((1u << (11 + s)) - kBrickWindowCells) >> 1; }
+// the shape for a pool whose deepest fusion was `depth` levels (-1: no bricks)
+inline int brick_shift_for_depth(int depth) { return depth <= 12 ? 0 : (depth <= 14 ? 1 : -1); }
+constexpr size_t kBrickFieldEntries = (size_t)1 << (3 * kBrickWindowBits);
 constexpr size_t kBrickFieldBytes = 2 * kBrickFieldEntries;
 constexpr int kBrickGroups = 1 << (3 * kBrickGroupLevel);
 constexpr int kBrickGroupWords = kBrickGroups / 32;  // "touched" bitmap: 32 KB
@@ -211,7 +227,7 @@ __device__ inline void pool_grid_mark(uint32_t *dirty, unsigned long long key, i
       }
 }
 
-// entry index of level-11 cell (x, y, z) (11 bits each) in the brick field: [z>>5 | y>>5 | x>>5] group (level 6, linear),
+// entry index of window cell (x, y, z) (11 bits each, relative to brick_window_origin) in the brick field: [z>>5 | y>>5 | x>>5] group (level 6, linear),
 // [z y x bits 4..2] brick in the group, [z y x bits 1..0] cell in the brick
 __host__ __device__ inline unsigned long long brick_entry_index(uint32_t x, uint32_t y, uint32_t z) {
   const uint32_t lo = ((y >> 5) << 21) | ((x >> 5) << 15) | (((z >> 2) & 7u) << 12) | (((y >> 2) & 7u) << 9) | (((x >> 2) & 7u) << 6) |
@@ -219,7 +235,7 @@ __host__ __device__ inline unsigned long long brick_entry_index(uint32_t x, uint
   return ((unsigned long long)(z >> 5) << 27) | lo;
 }
 
-// list entry of the level-9 node (x9, y9, z9): 9 bits each
+// list entry of the brick at window-relative brick coordinates (x9, y9, z9): 9 bits each
 __host__ __device__ inline uint32_t brick_list_entry(uint32_t x9, uint32_t y9, uint32_t z9) { return (z9 << 18) | (y9 << 9) | x9; }
 
 // Listing a stale brick, in the three steps the leaf kernel spreads over its barriers (one ring atomic per WORKGROUP: one per
@@ -229,14 +245,18 @@ __host__ __device__ inline uint32_t brick_list_entry(uint32_t x9, uint32_t y9, u
 //  2. the workgroup counts its true lanes in LDS and reserves that many ring slots with ONE atomic (brick_ring_reserve);
 //  3. brick_ring_store: the lane's entry into its slot.  Lapping the consumer is allowed: more than the capacity pending tells
 //     the refresh to rebuild every brick.
-__device__ inline bool brick_mark_test(uint32_t *dirty, bool pred, unsigned long long key, int depth, uint32_t &entry) {
+__device__ inline bool brick_mark_test(uint32_t *dirty, bool pred, unsigned long long key, int depth, int shift, uint32_t &entry) {
   entry = 0;
   if (!pred) return false;
+  const int nl = brick_node_level(shift);
   uint32_t x = 0, y = 0, z = 0;
-  for (int k = 1; k <= kBrickNodeLevel; k++) {
+  for (int k = 1; k <= nl; k++) {
     const uint32_t oct = (uint32_t)(key >> (3 * (depth - k))) & 7u;
     x = (x << 1) | (oct & 1u); y = (y << 1) | ((oct >> 1) & 1u); z = (z << 1) | (oct >> 2);
   }
+  const uint32_t org = brick_window_origin(shift) >> 2;  // in bricks
+  x -= org; y -= org; z -= org;
+  if ((x | y | z) >= (kBrickWindowCells >> 2)) return false;  // outside the window: no brick to rebuild
   entry = brick_list_entry(x, y, z);
   const uint32_t bit = 1u << (entry & 31u);
   return !(atomicOr(&dirty[kBrickBitsOffset + (entry >> 5)], bit) & bit);
@@ -244,6 +264,11 @@ __device__ inline bool brick_mark_test(uint32_t *dirty, bool pred, unsigned long
 __device__ inline uint32_t brick_ring_reserve(uint32_t *dirty, uint32_t count) { return atomicAdd(&dirty[kBrickCountOffset], count); }
 __device__ inline void brick_ring_store(uint32_t *dirty, uint32_t pos, uint32_t entry) {
   dirty[kBrickListOffset + (pos & (uint32_t)(kBrickListCap - 1))] = entry;
+}
+// the sibling ring (one returning atomic per entry: a few hundred per frame, at the end of the leaf kernel)
+__device__ inline void brick_sibling_list(uint32_t *dirty, uint32_t entry) {
+  const uint32_t pos = atomicAdd(&dirty[kSibCountOffset], 1u);
+  dirty[kSibListOffset + (pos & (uint32_t)(kSibListCap - 1))] = entry;
 }
 #endif
 

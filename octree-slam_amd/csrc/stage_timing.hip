@@ -9,7 +9,9 @@ namespace svoslam {
 namespace {
 std::mutex g_mu;  // stages are enqueued from several host threads / on several streams
 unsigned g_mask = 0;
-struct Log { std::vector<hipEvent_t> ev; size_t used = 0; };  // pairs (start, stop) since the last read
+unsigned g_generation = 1;  // advanced whenever a log is cleared: a bracket that began before does not end into the new log
+struct Entry { hipEvent_t start = nullptr, stop = nullptr; bool done = false; };
+struct Log { std::vector<Entry> e; size_t used = 0; };  // entries since the last read
 Log g_log[kStageCount];
 }  // namespace
 
@@ -21,6 +23,7 @@ unsigned stage_timing_mask() {
 int stage_timing(unsigned mask) {
   std::lock_guard<std::mutex> lock(g_mu);
   g_mask = mask;
+  g_generation++;
   for (Log &l : g_log) l.used = 0;
   return SVOSLAM_OK;
 }
@@ -30,29 +33,52 @@ int stage_timing_read(int stage, float *ms_sum, int *pairs) {
   std::lock_guard<std::mutex> lock(g_mu);
   Log &l = g_log[stage];
   float total = 0.0f;
-  for (size_t i = 0; i + 1 < l.used; i += 2) {
-    SVO_HIP(hipEventSynchronize(l.ev[i + 1]));
+  int n = 0;
+  for (size_t i = 0; i < l.used; i++) {
+    if (!l.e[i].done) continue;  // (a bracket still open, or one whose second record failed)
+    SVO_HIP(hipEventSynchronize(l.e[i].stop));
     float ms = 0.0f;
-    SVO_HIP(hipEventElapsedTime(&ms, l.ev[i], l.ev[i + 1]));
+    SVO_HIP(hipEventElapsedTime(&ms, l.e[i].start, l.e[i].stop));
     total += ms;
+    n++;
   }
   *ms_sum = total;
-  *pairs = (int)(l.used / 2);
+  *pairs = n;
   l.used = 0;
+  g_generation++;
   return SVOSLAM_OK;
 }
 
-int stage_event(int stage, hipStream_t stream) {
-  if (stage < 0 || stage >= kStageCount) return SVOSLAM_ERR_INVALID_ARG;
+int stage_begin(int stage, hipStream_t stream, long long *token) {
+  if (token) *token = -1;
+  if (stage < 0 || stage >= kStageCount || !token) return SVOSLAM_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lock(g_mu);
   if (!(g_mask & (1u << stage))) return SVOSLAM_OK;
   Log &l = g_log[stage];
-  if (l.used == l.ev.size()) {
-    hipEvent_t e;
-    SVO_HIP(hipEventCreate(&e));
-    l.ev.push_back(e);
+  if (l.used == l.e.size()) {
+    Entry en;
+    SVO_HIP(hipEventCreate(&en.start));
+    if (hipEventCreate(&en.stop) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(en.start); return SVOSLAM_ERR_HIP; }
+    l.e.push_back(en);
   }
-  SVO_HIP(hipEventRecord(l.ev[l.used++], stream));
+  Entry &en = l.e[l.used];
+  en.done = false;
+  SVO_HIP(hipEventRecord(en.start, stream));  // (on failure the entry is not taken)
+  *token = ((long long)g_generation << 32) | (long long)l.used;
+  l.used++;
+  return SVOSLAM_OK;
+}
+
+int stage_end(int stage, long long token, hipStream_t stream) {
+  if (token < 0) return SVOSLAM_OK;
+  if (stage < 0 || stage >= kStageCount) return SVOSLAM_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(g_mu);
+  if ((unsigned)(token >> 32) != g_generation) return SVOSLAM_OK;  // the log was cleared in between: the bracket is dropped
+  Log &l = g_log[stage];
+  const size_t i = (size_t)(token & 0xFFFFFFFFll);
+  if (i >= l.used) return SVOSLAM_OK;
+  SVO_HIP(hipEventRecord(l.e[i].stop, stream));
+  l.e[i].done = true;
   return SVOSLAM_OK;
 }
 

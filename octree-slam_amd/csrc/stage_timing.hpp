@@ -23,12 +23,17 @@ enum Stage {
 unsigned stage_timing_mask();                                  // stages that are on
 int stage_timing(unsigned mask);                               // bit s = stage s on; clears the log of every stage
 int stage_timing_read(int stage, float *ms_sum, int *pairs);   // blocking; resets that stage's log
-int stage_event(int stage, hipStream_t stream);                // no-op unless the stage is on; call before and after
+// A bracket is ONE entry of its stage's log: stage_begin reserves the entry's two events under the lock and records the
+// first, stage_end records the second into the SAME entry -- brackets of several streams / host threads that are open at the
+// same time cannot mis-pair, a change of the mask or a read between the two halves drops the entry, and so does
+// a failed record.  token < 0: the stage is off (stage_end is then a no-op).
+int stage_begin(int stage, hipStream_t stream, long long *token);
+int stage_end(int stage, long long token, hipStream_t stream);
 
 struct StageScope {  // brackets a scope; tolerant of early returns
-  int stage; hipStream_t s;
-  StageScope(int st, hipStream_t stream) : stage(st), s(stream) { (void)stage_event(stage, s); }
-  ~StageScope() { (void)stage_event(stage, s); }
+  int stage; hipStream_t s; long long token = -1;
+  StageScope(int st, hipStream_t stream) : stage(st), s(stream) { (void)stage_begin(stage, s, &token); }
+  ~StageScope() { (void)stage_end(stage, token, s); }
 };
 
 }  // namespace svoslam

@@ -641,7 +641,7 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
                                                              u32 *__restrict__ apply_nodes, const u64 *__restrict__ rec_key,
                                                              const u32 *__restrict__ bucket_base, const u32 *__restrict__ n0_saved,
                                                              const u32 *__restrict__ leaf_rec0, const u32 *__restrict__ leaf_start,
-                                                             int *__restrict__ strad_bc) {
+                                                             int *__restrict__ strad_bc, int brick_shift) {
   const bool early_links = leaf_rec0 != nullptr;
   // shadow != nullptr: deferred commit.  Every colour word goes to shadow[node] instead of the pool, children are read
   // through average_tile_deferred, and apply_nodes[(level - 1) * n + j] names the node lane j wrote at that level
@@ -685,12 +685,15 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   // level grid of the ray march (pool_grid.hpp): everything this key changes lies below its level-5 prefix; the first
   // head of a run of keys sharing that prefix marks the block
   if (grid_dirty && head && c < kPoolGridBlockLevel) pool_grid_mark(grid_dirty, key, depth);
-  // occupancy bricks: likewise everything below level 9 lies under the key's level-9 prefix; the first head of a run lists it
-  // (pool_grid.hpp: test-and-set here, the workgroup's ring slots behind the two barriers below, the store behind the walk)
+  // occupancy bricks: likewise everything below the brick node's level (9 + brick_shift) lies under the key's prefix of that
+  // level; the first head of a run lists it (pool_grid.hpp: test-and-set here, the workgroup's ring slots behind the two
+  // barriers below, the store behind the walk).  Childless siblings that a split creates beside the key's path are not listed
+  // as bricks: a key whose frontier lies above the brick node (new tiles at or above its level) puts its brick into the sibling
+  // ring at the end of this kernel, and the refresh writes the siblings' (uniform) lines (pool_grid.hip, brick_siblings).
   __shared__ u32 brick_cnt, brick_base;
-  const bool bricks_on = grid_dirty != nullptr && depth >= kBrickNodeLevel;
+  const bool bricks_on = grid_dirty != nullptr && brick_shift >= 0 && depth >= brick_node_level(brick_shift);
   u32 brick_entry = 0, brick_off = 0;
-  const bool brick_mine = bricks_on && brick_mark_test(grid_dirty, head && c < kBrickNodeLevel, key, depth, brick_entry);
+  const bool brick_mine = bricks_on && brick_mark_test(grid_dirty, head && c < brick_node_level(brick_shift), key, depth, brick_shift, brick_entry);
   if (tid <= SVOSLAM_MAX_DEPTH) {
     last_owner[tid] = -1;
     if (tid >= 1 && tid < depth) {  // "no straddler" unless a lane says otherwise below
@@ -856,22 +859,9 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
       __syncthreads();
     }
   }
-  // a key whose path had no node below level 8 so far gives its level-8 node eight children: the seven siblings of the key's
-  // own level-9 node are new, childless nodes whose bricks nobody else would list (rare: the map's frontier).  At the END of
-  // the kernel: this divergent loop of atomics, placed between the barriers of the set-up, left the wavefront's lanes apart at
-  // the ballots that follow there (test_async_fusion_long_runs_of_duplicates_and_invalid_points caught it)
-#ifndef SVO_NO_SIBLINGS
-  if (bricks_on && head && c < kBrickNodeLevel && lt != kNoSplit && (int)lt <= kPoolGridLevel) {
-    const u32 x9 = brick_entry & 511u, y9 = (brick_entry >> 9) & 511u, z9 = brick_entry >> 18;
-    for (u32 o = 0; o < 8u; o++) {
-      const u32 sib = brick_list_entry((x9 & ~1u) | (o & 1u), (y9 & ~1u) | ((o >> 1) & 1u), (z9 & ~1u) | (o >> 2));
-      if (sib == brick_entry) continue;
-      const u32 bit = 1u << (sib & 31u);
-      if (atomicOr(&grid_dirty[kBrickBitsOffset + (sib >> 5)], bit) & bit) continue;
-      brick_ring_store(grid_dirty, brick_ring_reserve(grid_dirty, 1u), sib);
-    }
-  }
-#endif
+  // the sibling ring (see above).  At the END of the kernel: a divergent returning atomic between the barriers of the set-up left
+  // the wavefront's lanes apart at the ballots that follow there (test_async_fusion_long_runs_of_duplicates_and_invalid_points)
+  if (brick_mine && lt != kNoSplit && (int)lt < brick_node_level(brick_shift)) brick_sibling_list(grid_dirty, brick_entry);
 #ifdef SVO_FILL_PROF
   FILL_STAMP(5)
   if (tid == 0 && (bid % 37) == 0)
@@ -1433,7 +1423,6 @@ static inline unsigned *small_strad_ticket(svoslam_workspace *ws, int slot) { re
 static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, const void *d_colors, bool vec4,
                       bool color_by_position, svoslam_fuse_stats *stats, hipStream_t stream) {
   pool_accel_invalidate(pool, depth, false);  // the blocking path does not track what it touches: the next render rebuilds the level grid
-  SVO_TRY(pool_accel_order_writer(pool, stream));  // (a brick rebuild of the previous render may still be reading the nodes)
   SVO_TRY(pool_sync(pool, stream));
   u64 *skey = nullptr; u32 *sidx = nullptr;
   SVO_TRY(radix_sort_pairs(ws, n, 3 * depth + 1, stream, &skey, &sidx));
@@ -1875,8 +1864,8 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
     ws->deferred_pool = pool; ws->deferred_n = n; ws->deferred_depth = depth; ws->deferred_tiles = fill_tiles;
   }
   SVO_TRY(tracker_make_room(pool));
-  if (!deferred) SVO_TRY(pool_accel_order_writer(pool, stream));  // (a deferred commit stores nothing a brick rebuild reads)
-  u32 *grid_dirty = pool_accel_dirty_bitmap(pool, deferred ? (int)(epoch & 1u) : 0, depth);  // nullptr: not a registered pool
+  int brick_shift = -1;
+  u32 *grid_dirty = pool_accel_dirty_bitmap(pool, deferred ? (int)(epoch & 1u) : 0, depth, &brick_shift);  // nullptr: not a registered pool
   auto enqueue = [&]() -> int {
     if (!early)
       split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
@@ -1885,11 +1874,11 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
     if (depth <= 12) fill_mip_local_kernel<12><<<xcd_grid(fill_tiles), kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
                                                                    grid_dirty, shadow, epoch, apply_nodes, ws->rec_key.as<u64>(),
                                                                    small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr, leaf_start,
-                                                                   two_tier ? strad_bc : nullptr);
+                                                                   two_tier ? strad_bc : nullptr, brick_shift);
     else fill_mip_local_kernel<16><<<xcd_grid(fill_tiles), kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
                                                                    grid_dirty, shadow, epoch, apply_nodes, ws->rec_key.as<u64>(),
                                                                    small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr, leaf_start,
-                                                                   two_tier ? strad_bc : nullptr);
+                                                                   two_tier ? strad_bc : nullptr, brick_shift);
     if (two_tier)
       mip_straddle2_kernel<<<strad_groups, kStrad2Threads, 0, stream>>>(pool->d_data, strad, strad_bc, sstrad, small_strad_ticket(ws, slot), fill_tiles,
                                                                         depth, small_counts(ws), pool->d_size, grid_dirty,
@@ -1911,7 +1900,7 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   GraphKey key;
   key.add(skey).add(d_colors).add((unsigned long long)n).add((unsigned long long)depth).add(pool->d_data).add(pool->d_size)
      .add((unsigned long long)slot).add(grid_dirty).add(trk ? (const void *)trk->h_size : nullptr).add(ws->layout_hash())
-     .add((unsigned long long)early);
+     .add((unsigned long long)early).add((unsigned long long)(brick_shift + 1));
   {
     StageScope timed(kStageFuseCommit, stream);
     SVO_TRY(ws->g_commit.run(key, stream, enqueue));
@@ -1947,7 +1936,6 @@ int svo_fuse_apply(svoslam_workspace *ws, svoslam_pool *pool, hipStream_t stream
   unsigned long long *shadow = nullptr;
   u32 epoch = 0;
   SVO_TRY(pool_shadow_current(pool, &shadow, &epoch));
-  SVO_TRY(pool_accel_order_writer(pool, stream));
   const long long slots = (long long)n * depth;
   int blocks = (int)cdiv(slots, 256 * 4);
   if (blocks > 4096) blocks = 4096;

@@ -91,14 +91,17 @@ class DistContext:
                 torch.cuda.synchronize()
         # Small records (the 27 ICP sums, the 80-byte pose records) go through the peer-to-peer mailbox instead of a collective
         # (csrc/mailbox.hip): a rank stores its record straight into every peer's inbox and polls its own -- no host-issued
-        # collective, no ~25 us of RCCL latency per 216 bytes.  SVOSLAM_MAILBOX=0: torch.distributed for everything (the
-        # required baseline: ncclAllReduce / ncclAllGather).  The inbox handles travel once, through the process group.
+        # collective, no ~25 us of RCCL latency per 216 bytes.  OPT-IN (SVOSLAM_MAILBOX=1) since round 4: it has only ever run
+        # between processes on one device, so the default is torch.distributed for everything (the required baseline:
+        # ncclAllReduce / ncclAllGather) until it has been validated across real devices.  A wait that gives up
+        # poisons its output and sets a sticky flag that check_mailbox() turns into an exception at the end of every stream
+        # call.  The inbox handles travel once, through the process group.
         # The mailbox has only ever run between processes on ONE device (no multi-GPU node was available to this build): its
         # set-up is therefore guarded -- every rank reports whether it could map its peers' inboxes, a first all-gather of
         # rank-stamped records is checked against the collective's, and unless EVERY rank succeeded the session falls back
         # to torch.distributed for these records too (a note on stderr says so).
         self.mailbox = None
-        if self.enabled and torch.cuda.is_available() and os.environ.get("SVOSLAM_MAILBOX", "1") != "0":
+        if self.enabled and torch.cuda.is_available() and os.environ.get("SVOSLAM_MAILBOX", "0") == "1":
             import sys
             import torch.distributed as dist
             backend = dist.get_backend(self.group)
@@ -152,6 +155,13 @@ class DistContext:
     @property
     def enabled(self):
         return self.world > 1 or self.force
+
+    def check_mailbox(self):
+        """raises when a wait of the peer-to-peer mailbox has given up (a peer that posted late or never): the records built
+        from it are poisoned, the session must not go on silently (blocks until the device is idle)"""
+        if self.mailbox is not None and self.mailbox.failed():
+            raise pkg.SvoslamError("peer-to-peer mailbox: a wait for a peer's record timed out (rank %d of %d); the session's "
+                                   "ICP sums / pose records are invalid from that exchange on" % (self.rank, self.world))
 
     def all_reduce_sum(self, t):
         if self.mailbox is not None and t.is_cuda and t.dtype == torch.float64 and t.numel() <= 256:
@@ -300,7 +310,9 @@ class SlamPipeline:
             # lists are all-gathered and merged (identical global list on every rank -> identical node numbering), instead
             # of all-gathering the band's points and sorting the whole frame everywhere.  SVOSLAM_BAND_FUSION=points: round 2.
             idx_bits = max(1, (width * height - 1).bit_length())
-            self.band_keys = os.environ.get("SVOSLAM_BAND_FUSION", "keys") != "points" and 3 * max_depth + 1 + idx_bits <= 64
+            # (the merge kernel takes at most 16 lists, svoslam_svo_fuse_merge_sorted; a forced pair sort has no packed word to export)
+            self.band_keys = (os.environ.get("SVOSLAM_BAND_FUSION", "keys") != "points" and 3 * max_depth + 1 + idx_bits <= 64
+                              and self.dist.world <= 16 and os.environ.get("SVOSLAM_SORT_PAIRS") != "1")
             if self.band_keys:
                 self.ws_band = pkg.Workspace()
                 base, rem = divmod(height, self.dist.world)
@@ -581,6 +593,8 @@ class SlamPipeline:
                     on_render(i, self.image)
         for st in (self._s_maps, self._s_track, self._s_prep, self._s_map):
             cur.wait_stream(st)
+        if self.band_exchange:
+            self.dist.check_mailbox()
         if tl is not None:
             torch.cuda.synchronize()
             base = tl[("commit0", 0)]
@@ -669,6 +683,8 @@ class SlamPipeline:
         self._prev = (depths[n - 1], rgbs[n - 1])
         self.frames_seen = g0 + n
         self.marched_last_call = sum(march)
+        if getattr(self.dist, "mailbox", None) is not None:
+            self.dist.check_mailbox()
 
     def _backproject_with(self, depth, fusion_ptr):
         if not self.band_exchange:

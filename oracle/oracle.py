@@ -61,6 +61,8 @@ def lib(native=False):
     L.ora_extract_voxel_grid.restype = C.c_int
     L.ora_extract_voxel_grid.argtypes = [C.POINTER(_Pool), C.c_int, f32p, C.c_float, C.POINTER(f32p), C.POINTER(f32p)]
     L.ora_pool_free.argtypes = [C.POINTER(_Pool)]
+    L.ora_pool_load_words.restype = C.c_int
+    L.ora_pool_load_words.argtypes = [C.POINTER(_Pool), u32p, C.c_int]
     L.ora_cone_trace_svo.restype = C.c_int64
     L.ora_cone_trace_svo.argtypes = [u8p, C.c_int, C.c_int, C.c_float, f32p, u32p, f32p, C.c_float, C.c_int, i64p]
     L.ora_generate_vertex_map.argtypes = [u16p, f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int]
@@ -105,6 +107,7 @@ def lib(native=False):
     L.ora_camera_update.restype = C.c_int
     L.ora_camera_update.argtypes = [C.c_void_p, u16p, u8p, C.c_longlong]
     L.ora_camera_pose.argtypes = [C.c_void_p, f32p, f32p]
+    L.ora_camera_set_pose.argtypes = [C.c_void_p, f32p, f32p]
     L.ora_camera_last_update.argtypes = [C.c_void_p, f32p]
     L.ora_camera_apply_delta.restype = C.c_int
     L.ora_camera_apply_delta.argtypes = [C.c_void_p, f32p, C.c_int, C.c_longlong]
@@ -179,6 +182,12 @@ class Pool:
         words = np.ascontiguousarray(words, dtype=np.uint32)
         assert words.size == 2 * self._p.size
         C.memmove(self._p.data, words.ctypes.data, words.nbytes)
+
+    def load_words(self, words):
+        """the pool becomes a copy of these nodes (any size: a map fused elsewhere, continued here)"""
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        assert words.size % 2 == 0 and words.size >= 16
+        assert self._L.ora_pool_load_words(C.byref(self._p), _p(words, C.c_uint32), words.size // 2) == 0
 
     def insert_cloud(self, points, colors, depth, center, edge):
         pts = _f32(points).reshape(-1, 3)
@@ -464,6 +473,10 @@ class Camera:
         p = np.empty(3, np.float32); o = np.empty(9, np.float32)
         self._L.ora_camera_pose(self._c, _p(p, C.c_float), _p(o, C.c_float))
         return p, o
+
+    def set_pose(self, position, orientation):
+        p, o = _f32(position).reshape(3), _f32(orientation).reshape(9)
+        self._L.ora_camera_set_pose(self._c, _p(p, C.c_float), _p(o, C.c_float))
 
     def last_update(self):
         """update_trans of the frame most recently tracked (identity for a first frame)"""

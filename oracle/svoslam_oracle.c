@@ -197,6 +197,18 @@ void ora_pool_free(ora_pool *p) {
   p->size = 0;
 }
 
+/* the pool becomes a copy of `num_nodes` nodes given as words (a map fused elsewhere: bench.py's cpu_baseline continues
+ * the GPU's map, whose words equal this oracle's own -- tests/test_gpu_fullsize.py); not a reference function */
+int ora_pool_load_words(ora_pool *p, const uint32_t *words, int num_nodes) {
+  if (num_nodes < 8 || !words) return -1;
+  uint32_t *d = (uint32_t *)realloc(p->data, sizeof(uint32_t) * 2 * (size_t)num_nodes);
+  if (!d) return -1;
+  memcpy(d, words, sizeof(uint32_t) * 2 * (size_t)num_nodes);
+  p->data = d;
+  p->size = num_nodes;
+  return 0;
+}
+
 /* the blend of svo.cu:366-381 (Color256) : values are exact in binary32, so the
  * result is floor((new*(256-a) + cur*a)/256) regardless of FMA contraction. */
 static uint32_t blend_color256(uint32_t current_value, const uint8_t rgb[3]) {
@@ -1433,6 +1445,12 @@ int ora_camera_tracking_lost_count(const ora_camera *c) { return c->lost_count; 
 void ora_camera_pose(const ora_camera *c, float position[3], float orientation[9]) {
   memcpy(position, c->position, sizeof(float) * 3);
   memcpy(orientation, c->orientation, sizeof(float) * 9);
+}
+
+/* overwrite position_ / orientation_ (a session continued from a pose tracked elsewhere; not a reference function) */
+void ora_camera_set_pose(ora_camera *c, const float position[3], const float orientation[9]) {
+  memcpy(c->position, position, sizeof(float) * 3);
+  memcpy(c->orientation, orientation, sizeof(float) * 9);
 }
 
 /* main.cpp:40 : glm::mat4(orientation) * glm::translate(glm::mat4(1.0f), position) */

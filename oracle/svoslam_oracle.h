@@ -55,6 +55,7 @@ typedef struct {
 } ora_pool;
 
 void ora_pool_free(ora_pool *p);
+int ora_pool_load_words(ora_pool *p, const uint32_t *words, int num_nodes);
 
 /* split planning, exposed for tests: returns number of split nodes, fills
  * pass_sizes[max_depth] and (if codes_out != NULL) the concatenated sorted
@@ -137,6 +138,7 @@ void ora_camera_destroy(ora_camera *c);
 /* returns 1 if the frame was processed, 0 if skipped (stale timestamp) */
 int ora_camera_update(ora_camera *c, const uint16_t *depth, const uint8_t *rgb, long long timestamp);
 void ora_camera_pose(const ora_camera *c, float position[3], float orientation[9]);
+void ora_camera_set_pose(ora_camera *c, const float position[3], const float orientation[9]);
 /* frame-parallel tracking: a tracked frame's update_trans, and the pose step for an update_trans from anywhere */
 void ora_camera_last_update(const ora_camera *c, float out[16]);
 int ora_camera_apply_delta(ora_camera *c, const float *update_trans, int levels_lost, long long timestamp);

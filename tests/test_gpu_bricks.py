@@ -2,7 +2,8 @@
 csrc/cone_trace.hip cone_trace_brick_kernel) against the CPU oracle's coneTrace (cone_tracing_kernels.cu:53-146):
 images and step / level counters byte for byte while the map is fused incrementally (stale-brick ring), through alpha
 saturation (A >= 254: the bricks' retire bits), at LODs on both sides of the bricks' levels 9..12, after a reset, for
-pools deeper than the bricks describe, and -- in child processes -- with sixty commits between renders (every brick
+pools of depth 13 / 14 (the second brick shape: level-10 nodes, level-12 cells, level-13 bits inside the field's window; the
+test cloud reaches beyond the window), through a change of shape, and -- in child processes -- with sixty commits between renders (every brick
 listed once however often it is touched) and the bricks switched off."""
 import hashlib
 import json
@@ -36,6 +37,7 @@ def render_check(pkg, torch, oracle, pool, opool, w, h, view, center, size, what
     got = img.cpu().numpy()
     assert np.array_equal(got, ref), (what, describe_mismatch(got, ref))
     assert cnt.cpu().tolist() == [steps, levels], what
+    render_check.last_steps = steps
     return got
 
 
@@ -46,7 +48,7 @@ VIEWS = (((0.1, 0.2, -2.6), (0, 0, 0), (96, 72)),            # far, coarse pixel
          ((0.12, -0.18, 0.14), (0.1, -0.2, -0.3), (24, 480)))  # centimetres outside the sphere, grazing: LOD 13+ (below the bricks)
 
 
-@pytest.mark.parametrize("depth", [10, 12])
+@pytest.mark.parametrize("depth", [10, 12, 13, 14])
 def test_bricks_follow_incremental_fusion_through_saturation(env, oracle, depth):
     """the same surface observed 131 times with a few new points each time (asynchronous fusion: the commit lists the
     stale bricks, the render rebuilds them): leaves pass A = 254 at observation 127 and rays begin to retire on them"""
@@ -57,6 +59,7 @@ def test_bricks_follow_incremental_fusion_through_saturation(env, oracle, depth)
     base, bcol = surface_cloud(rng, 5000, jitter=0.002)
     checks = {0, 1, 2, 64, 125, 126, 127, 128, 130}
     retired_seen = False
+    steps_at = {}
     for it in range(131):
         extra, ecol = surface_cloud(rng, 300, jitter=0.004)
         pts, col = np.concatenate([base, extra]), np.concatenate([bcol, ecol])
@@ -66,17 +69,23 @@ def test_bricks_follow_incremental_fusion_through_saturation(env, oracle, depth)
             for eye, tgt, (w, h) in VIEWS:
                 got = render_check(pkg, torch, oracle, pool, opool, w, h, oracle.look_at(eye, tgt, (0, 1, 0)), center, edge, (it, eye))
                 retired_seen |= bool((got[..., :3] != 0).any())
+                steps_at[(it, eye)] = render_check.last_steps
     assert np.array_equal(pool.words()[:2 * pool.size], opool.words()[:2 * pool.size])
-    assert retired_seen  # saturated leaves were reached: some pixel carries a colour
+    # saturated leaves were reached: rays retire on them (fewer march steps than through the young map), and up to depth 12 some
+    # pixel carries a colour (deeper trees dilute the mip colour of a lone leaf to zero at the LOD's level: averageChildren
+    # divides by 8 per level, Q5)
+    assert any(steps_at[(130, eye)] < steps_at[(2, eye)] for eye, _, _ in VIEWS)
+    assert retired_seen or depth > 12
 
 
-def test_bricks_deferred_commits_and_reset(env, oracle):
+@pytest.mark.parametrize("depth", [11, 14])
+def test_bricks_deferred_commits_and_reset(env, oracle, depth):
     """deferred commit + apply (marks go to the other dirty state), a render between the two halves (old map), a reset
     followed by a different cloud (every brick of the old map must be gone)"""
     pkg, torch = env
     rng = np.random.default_rng(77)
     ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
-    center, edge, depth = (0.0, 0.0, 0.0), 1.0, 11
+    center, edge = (0.0, 0.0, 0.0), 1.0
     view = oracle.look_at(VIEWS[2][0], VIEWS[2][1], (0, 1, 0))
     w, h = VIEWS[2][2]
     for it in range(4):
@@ -131,15 +140,15 @@ def test_foreign_words_are_not_trusted(env, oracle):
     assert n > 8
 
 
-def test_pool_deeper_than_the_bricks(env, oracle):
-    """depth 14: the bricks stop at level 12, such a pool is marched through the tree (no bricks are kept for it); a
-    depth-12 pool that is then fused at depth 14 switches over"""
+def test_pool_changes_brick_shape_and_outgrows_the_bricks(env, oracle):
+    """a depth-12 pool (bricks of level-9 nodes) that is then fused at depth 14 switches to the second shape (every brick
+    rebuilt), and at depth 16 to no bricks at all (the tree march)"""
     pkg, torch = env
     rng = np.random.default_rng(5)
     ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
     center, edge = (0.0, 0.0, 0.0), 1.0
     pts, col = surface_cloud(rng, 4000, jitter=0.002)
-    for depth in (12, 12, 14, 14):
+    for depth in (12, 12, 14, 14, 13, 16, 12):
         pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, pool, center, edge)
         opool.insert_cloud(pts, col, depth, center, edge)
         for eye, tgt, (w, h) in VIEWS[1:]:

@@ -61,3 +61,32 @@ def test_mailbox_rejects_bad_sizes(env):
     fresh = pkg.Mailbox(0, 2)
     with pytest.raises(pkg.SvoslamError):
         fresh.all_reduce_f64(torch.zeros(4, dtype=torch.float64, device="cuda"))                                              # not connected
+
+
+def test_mailbox_timeout_is_loud(env):
+    """a peer that never posts: the wait gives up, the missing record arrives as all-ones granules (NaN), the sum is NaN, the
+    sticky flag is set and DistContext.check_mailbox() raises (a silent stale granule let the maps diverge)"""
+    pkg, torch = env
+    import importlib
+    pl = importlib.import_module("octree_slam_amd.pipeline")
+    boxes = [pkg.Mailbox(r, 2) for r in range(2)]
+    for b in boxes:
+        b.connect_local(boxes)
+        b.set_wait_limit(2000)
+    rec = torch.arange(20, dtype=torch.int32, device="cuda")
+    out = torch.zeros((2, 20), dtype=torch.int32, device="cuda")
+    boxes[0].post(rec)                 # rank 1 never posts
+    boxes[0].collect(out, 80)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert np.array_equal(o[0], np.arange(20)) and np.all(o[1].view(np.uint32) == 0xFFFFFFFF)
+    assert boxes[0].failed() and not boxes[1].failed()
+    acc = torch.ones(27, dtype=torch.float64, device="cuda")
+    boxes[0].post(acc)
+    boxes[0].collect(acc, 27 * 8, reduce_f64=True)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(acc).all())
+    ctx = pl.DistContext(0, 1)
+    ctx.mailbox = boxes[0]
+    with pytest.raises(pkg.SvoslamError):
+        ctx.check_mailbox()

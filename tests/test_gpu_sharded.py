@@ -182,6 +182,7 @@ def _two_process_worker(rank, world, port, out_dir, n, w, h, depth):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ["SVOSLAM_MAILBOX"] = "1"     # (opt-in since round 4)
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
