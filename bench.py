@@ -414,8 +414,11 @@ def main():
     march_alg = (4.0 * (levels + steps) + 4.0 * width * rows * marches) / marches     # per launch (this rank's band / frames)
     # ICP reads 48 B per pixel per iteration, 10 / 5 / 4 iterations on the three pyramid levels = 552 N0
     icp_alg = 48.0 * (10 * n0 + 5 * (n0 // 4) + 4 * (n0 // 16))
-    one_launch = n0 <= 640 * 480 and os.environ.get("SVOSLAM_TRACK_CHAIN") != "1"
-    trk_kernel = "track_persistent_kernel" if one_launch else "icp_accumulate_work_kernel + cam_reduce_solve_kernel (38 launches)"
+    chain = os.environ.get("SVOSLAM_TRACK_CHAIN") == "1" or (n0 > 640 * 480 and os.environ.get("SVOSLAM_TRACK_STREAM") == "0")
+    one_launch = not chain
+    streaming = one_launch and n0 > 640 * 480
+    trk_kernel = ("track_persistent_kernel (streaming form)" if streaming else "track_persistent_kernel") if one_launch else \
+        "icp_accumulate_work_kernel + cam_reduce_solve_kernel (38 launches)"
     trk_ms = trk_total_ms / trk_launches if trk_launches else None
 
     # ---- HBM traffic per frame from the committed rocprofv3 PMC passes (cannot be sampled from inside the process)
@@ -460,6 +463,8 @@ def main():
     roofs[0].update({"steps_per_launch": steps / marches, "levels_per_launch": levels / marches, "timed": "live, timed region"})
     if trk_ms:
         roofs.append(roof("tracker", trk_kernel, icp_alg, trk_ms, 1 if one_launch else 38,
+                          ("one launch for the 19 iterations, the two finer levels streamed through work maps (72 B per pixel and iteration) on "
+                           "176 workgroups: HBM bandwidth of the ten 1080p iterations + 19 hand-offs") if streaming else
                           ("one launch for the 19 iterations: pixels live in registers (48 B per pixel read once per LEVEL, not per "
                            "iteration); bound by the 19 cross-workgroup fan-in / solve / broadcast hand-offs (~11 us each)") if one_launch else
                           "launch chain with work maps: 38 dependent launches beside the march"))

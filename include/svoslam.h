@@ -527,6 +527,19 @@ int svoslam_camera_set_acc(svoslam_camera *cam, double *d_acc);
 int svoslam_camera_tracking_lost_count(svoslam_camera *cam, int32_t *count, void *stream);
 /* switches the photometric RGB-D term on (see svoslam_rgbd_cost above); only before the first frame */
 int svoslam_camera_set_rgbd(svoslam_camera *cam, int32_t enable);
+/* strict = 1 (default): RGBDCamera::update as the reference has it, every quirk included.  strict = 0: this build's CORRECTED
+ * tracker (own specification, no reference behaviour; SURVEY section 7 step 1 "every Appendix-B quirk behind a strict_reference
+ * switch").  Three places where the reference's update is not a rigid-motion estimate are replaced, everything else -- gates,
+ * pyramid, iteration counts, exact fixed-point sums, Cholesky, glm products -- stays:
+ *   - the rotational rows of the Jacobian are those of [v2]x (A_T[0..2] = v2 x n1) instead of the rows of
+ *     src/sensor/localization_kernels.cu:207-213 (Q14);
+ *   - this_trans = translate(x3, x4, x5) * Rz(x2) * Ry(x1) * Rx(x0) (a current-frame point goes to R v + t) instead of
+ *     Rz(-x2) * Ry(-x1) * Rx(-x0) * translate(..) (rgbd_camera.cpp:154-158);
+ *   - position = (position + t) * update_trans in the row-vector product of rgbd_camera.cpp:172 (Q17 drops t), so that
+ *     main.cpp:40's orientation * (x + position) composes the frame-to-frame transforms.
+ * Restated in oracle/svoslam_oracle.c (ora_camera_set_strict_reference) and a second time in tests/test_cpu_corrected.py.
+ * Before the first frame only; not combined with the photometric term. */
+int svoslam_camera_set_strict_reference(svoslam_camera *cam, int32_t strict);
 /* Frame-to-model tracking (second half).  OWN SPECIFICATION: the reference tracks every frame against the
  * previous FRAME's maps and leaves the rest as a TODO (src/sensor/rgbd_camera.cpp:185: "ICP should not swap, as
  * last_frame should be updated by a different function"); these three entry points are that different function.

@@ -183,6 +183,7 @@ SIGNATURES = {
     "svoslam_difference": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "svoslam_rgbd_cost": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _i32, _i32, _fp, _fp, _vp]),
     "svoslam_camera_set_rgbd": (C.c_int, [_vp, _i32]),
+    "svoslam_camera_set_strict_reference": (C.c_int, [_vp, _i32]),
     "svoslam_raycast_model_depth": (C.c_int, [_vp, _i32, _i32, _f32, _f32, _fp, _vp, _vp, _fp, _f32, _vp, _vp]),
     "svoslam_camera_set_model_depth": (C.c_int, [_vp, _vp, _vp]),
     "svoslam_camera_set_frame_to_model": (C.c_int, [_vp, _i32]),
@@ -1054,6 +1055,10 @@ class Camera:
     def set_rgbd(self, enable=True):
         """photometric RGB-D term in every ICP iteration (rgbd_camera.cpp:126-141 switched on); before the first frame"""
         check(lib().svoslam_camera_set_rgbd(self._h, 1 if enable else 0))
+
+    def set_strict_reference(self, strict=True):
+        """False: this build's corrected tracker (include/svoslam.h svoslam_camera_set_strict_reference); before the first frame"""
+        check(lib().svoslam_camera_set_strict_reference(self._h, 1 if strict else 0))
 
     def set_model_depth(self, depth):
         """frame-to-model tracking: `depth` (cuda uint16 [h, w], e.g. raycast_model_depth from the pose of the frame just

@@ -477,6 +477,7 @@ int svoslam_rgbd_cost(const float *d_last_intensity, const float *d_last_gradien
   return rgbd_cost(g_misc, d_last_intensity, d_last_gradient, d_last_vertex, d_cur_intensity, d_cur_vertex, width, height, fx, fy,
                    img_width, img_height, h_A, h_b, S(stream));
 }
+int svoslam_camera_set_strict_reference(svoslam_camera *cam, int32_t strict) { return camera_set_strict_reference(cam, strict); }
 int svoslam_camera_set_rgbd(svoslam_camera *cam, int32_t enable) {
   NEED_DEVICE();
   return camera_set_rgbd(cam, enable);

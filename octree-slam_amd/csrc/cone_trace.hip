@@ -716,6 +716,9 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
     }
   }
   __syncthreads();
+#ifdef SVO_BRICK_DIAG
+  const long long c_tables = clock64();
+#endif
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   int tile_x, tile_y;  // (tile -> XCD mapping: see cone_trace_kernel)
   if (P.xcd_w > 0) {
@@ -801,6 +804,7 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       return by_brick || by_grid;
     };
 #ifdef SVO_BRICK_DIAG
+    long long c_after_loop = 0;
     uint32_t diag[4] = {0, 0, 0, 0};
     long long clk[3] = {0, 0, 0};
     const long long c_loop = clock64();
@@ -953,9 +957,9 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
 #ifdef SVO_BRICK_DIAG
     if (counters) {
       // cycles of the lane that stayed longest = of its wavefront: before the entries are needed / waiting for them / after
-      if (P.mode & 0x200) {  // prologue and whole loop instead of the step classes
-        const long long c_end = clock64();
-        if (lane == 0) { atomicAdd(&counters[2], (unsigned long long)(c_loop - c_entry)); atomicAdd(&counters[3], (unsigned long long)(c_end - c_loop)); }
+      if (P.mode & 0x200) {  // the kernel's phases instead of the step classes: LDS tables, ray set-up, loop (the epilogue: below)
+        c_after_loop = clock64();
+        if (lane == 0) { atomicAdd(&counters[2], (unsigned long long)(c_tables - c_entry)); atomicAdd(&counters[3], (unsigned long long)(c_loop - c_tables)); atomicAdd(&counters[4], (unsigned long long)(c_after_loop - c_loop)); }
       } else {
       atomicAdd(&counters[2], (unsigned long long)diag[0]);
       atomicAdd(&counters[3], (unsigned long long)diag[1]);
@@ -963,7 +967,7 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       uint32_t mx = my_steps;
       for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)mx, o); mx = v > mx ? v : mx; }
       const unsigned long long top = __ballot(my_steps == mx);
-      if ((int)lane == __ffsll((long long)top) - 1) {
+      if (!(P.mode & 0x200) && (int)lane == __ffsll((long long)top) - 1) {
         atomicAdd(&counters[4], (unsigned long long)clk[0]);
         atomicAdd(&counters[5], (unsigned long long)clk[1]);
         atomicAdd(&counters[6], (unsigned long long)clk[2]);
@@ -1006,6 +1010,9 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
     o.x = (unsigned char)(out & 0xFF); o.y = (unsigned char)((out >> 8) & 0xFF);
     o.z = (unsigned char)((out >> 16) & 0xFF); o.w = (unsigned char)(out >> 24);
     pos[idx] = o;
+#ifdef SVO_BRICK_DIAG
+    if (counters && (P.mode & 0x200) && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); atomicAdd(&counters[5], (unsigned long long)(clock64() - c_after_loop)); }
+#endif
   }
   if (slots) count_steps(slots, counters, my_steps, my_levels, lane);
 }

@@ -69,7 +69,9 @@ __device__ inline void accumulate_block(const float *__restrict__ last_v, const 
   // matrices in the same order on the same floats as the replay from the raw maps, so the same bits.
   int nchain = 0;
   bool lost = false;
+  bool corrected = false;  // (stateless calls -- computeICPCost2 of the ABI -- are the reference's)
   if (state) {
+    corrected = state->corrected != 0;
     // iteration 0 of a level: the level-start transform is update_trans as the previous level left it
     // and the "tracking lost" flag of the previous level no longer applies
     lost = !(flags & kFlagFirstIter) && state->lost != 0;
@@ -103,7 +105,7 @@ __device__ inline void accumulate_block(const float *__restrict__ last_v, const 
         work_v[3 * (size_t)p] = v2x; work_v[3 * (size_t)p + 1] = v2y; work_v[3 * (size_t)p + 2] = v2z;
         work_n[3 * (size_t)p] = n2x; work_n[3 * (size_t)p + 1] = n2y; work_n[3 * (size_t)p + 2] = n2z;
       }
-      icp_pixel_terms(v1x, v1y, v1z, n1x, n1y, n1z, v2x, v2y, v2z, n2x, n2y, n2z, acc);
+      icp_pixel_terms(v1x, v1y, v1z, n1x, n1y, n1z, v2x, v2y, v2z, n2x, n2y, n2z, acc, corrected);
     }
   }
   // workgroup -> one 27-double row; every partial is an integer-valued double (exact, order-free).
@@ -606,6 +608,7 @@ struct svoslam_camera {
   // frame-to-model tracking (off by default): a map set of its own, filled by camera_set_model_depth, that the
   // ICP associates the incoming frame with instead of the previous frame's maps (the TODO of rgbd_camera.cpp:185)
   bool to_model = false, have_model = false;
+  bool corrected = false;  // svoslam_camera_set_strict_reference(cam, 0): the corrected tracker (icp_device.hpp icp_rot_rows); a setting, survives reset
   uint16_t *model_filt[3] = {nullptr, nullptr, nullptr};
   float *model_v[3] = {nullptr, nullptr, nullptr}, *model_n[3] = {nullptr, nullptr, nullptr};
 };
@@ -658,6 +661,7 @@ int camera_reset(svoslam_camera *c) {
     init.update_trans[i] = 1.0f; init.fusion[i] = 1.0f; init.level_start[i] = 1.0f;
     for (int r = 0; r < 4; r++) init.fusion_ring[r][i] = 1.0f;
   }
+  init.corrected = c->corrected ? 1 : 0;
   SVO_HIP(hipMemcpy(c->d_state, &init, sizeof(init), hipMemcpyHostToDevice));
   SVO_HIP(memset_sync(c->d_sync, 0, sizeof(TrackSync)));
   SVO_HIP(memset_sync(c->d_tickets, 0, track_persistent_ticket_bytes()));
@@ -841,9 +845,13 @@ static int track_hybrid_levels() {
   return v;
 }
 
-// SVOSLAM_TRACK_STREAM=1: large images run all 19 iterations in the streaming one-launch form (default: see camera_track)
+// Large images (1920x1080: the finest level does not fit the registers) run all 19 iterations in the STREAMING one-launch form
+// (track_persistent.hip: coarsest level in registers, the finer ones through the work maps) -- the default since round 4: with
+// the march over bricks the frame no longer loses what this form's residency takes (cfg4 811 -> 893 frames/s; round 3, beside
+// the tree march: 810 -> 690).  SVOSLAM_TRACK_STREAM=0: the hybrid of round 3 (coarsest level in the one launch, then the
+// launch chain).
 static bool track_stream_enabled() {
-  static const bool on = [] { const char *e = getenv("SVOSLAM_TRACK_STREAM"); return e && e[0] == '1'; }();
+  static const bool on = [] { const char *e = getenv("SVOSLAM_TRACK_STREAM"); return !(e && e[0] == '0'); }();
   return on;
 }
 
@@ -859,6 +867,7 @@ static int track_one_launch(svoslam_camera *c, hipStream_t s) {
     A.level[level].first = a.first; A.level[level].end = end > a.first ? end : a.first;
     A.iters[level] = kPyramidIters[level];
   }
+  A.corrected = c->corrected ? 1 : 0;
   if (c->capacity == 0 || c->cap_stream != s) {
     SVO_TRY(track_persistent_capacity(s, &c->capacity));
     c->cap_stream = s;
@@ -923,7 +932,8 @@ int camera_track(svoslam_camera *c, hipStream_t s) {
   GraphKey key;
   key.add((unsigned long long)(c->tracked % 3u)).add((unsigned long long)has_icp)
      .add((unsigned long long)c->band_first).add((unsigned long long)c->band_rows).add((unsigned long long)c->rgbd)
-     .add((unsigned long long)work_maps).add((unsigned long long)top_level).add((unsigned long long)(c->to_model && c->have_model));
+     .add((unsigned long long)work_maps).add((unsigned long long)top_level).add((unsigned long long)(c->to_model && c->have_model))
+     .add((unsigned long long)c->corrected);
   auto enqueue = [&]() -> int {
     if (has_icp) {
       for (int level = top_level; level >= 0; level--) {  // coarse to fine, :103
@@ -1034,11 +1044,22 @@ int camera_apply_delta(svoslam_camera *c, const float *d_delta, long long timest
   return SVOSLAM_OK;
 }
 
+// strict = 1 (default): RGBDCamera::update as the reference has it (Q14, Q17 included).  strict = 0: this build's corrected
+// tracker (own specification: icp_device.hpp icp_rot_rows; oracle ora_camera_set_strict_reference).  Before the first frame only.
+int camera_set_strict_reference(svoslam_camera *c, int strict) {
+  if (!c) return SVOSLAM_ERR_INVALID_ARG;
+  if (c->prepared != 0 && (strict == 0) != c->corrected) return SVOSLAM_ERR_INVALID_ARG;
+  if (!strict && c->rgbd) return SVOSLAM_ERR_INVALID_ARG;  // (the photometric term shares the reference's rows: not combined)
+  c->corrected = strict == 0;
+  return camera_reset(c);
+}
+
 // RGBDCamera with the photometric term of rgbd_camera.cpp:126-141 switched on (W_RGBD = 0.1); before the first frame only
 int camera_set_rgbd(svoslam_camera *c, int enable) {
   if (!c) return SVOSLAM_ERR_INVALID_ARG;
   if (c->prepared != 0 && (enable != 0) != c->rgbd) return SVOSLAM_ERR_INVALID_ARG;
   if (enable && c->to_model) return SVOSLAM_ERR_INVALID_ARG;  // (not combined with frame-to-model tracking)
+  if (enable && c->corrected) return SVOSLAM_ERR_INVALID_ARG;  // (nor with the corrected tracker)
   if (enable && !c->tmp_inten) {
     const size_t n0 = (size_t)c->width * c->height;
     SVO_HIP(hipMalloc((void **)&c->tmp_inten, n0 * 4));

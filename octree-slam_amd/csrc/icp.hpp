@@ -27,6 +27,7 @@ int camera_pair_delta(svoslam_camera *c, const uint16_t *d_depth_prev, const uin
                       const uint8_t *d_rgb_cur, float *d_delta, hipStream_t s);
 int camera_apply_delta(svoslam_camera *c, const float *d_delta, long long timestamp, int32_t *processed, hipStream_t s);
 int camera_set_rgbd(svoslam_camera *c, int enable);
+int camera_set_strict_reference(svoslam_camera *c, int strict);
 int camera_set_model_depth(svoslam_camera *c, const uint16_t *d_depth, hipStream_t s);
 int camera_set_frame_to_model(svoslam_camera *c, int enable);
 int rgbd_cost(svoslam::DeviceBuffer &scratch, const float *last_i, const float *last_g, const float *last_v, const float *cur_i,

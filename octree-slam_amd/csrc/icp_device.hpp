@@ -32,6 +32,7 @@ struct CamState {
   int frames_done;          // frames whose pose is final; the next frame's pose goes to fusion_ring[frames_done & 3]
   int lost;                 // NaN seen at this pyramid level (rgbd_camera.cpp:148-151)
   int tracking_lost_count;  // levels abandoned so far
+  int corrected;            // svoslam_camera_set_strict_reference(cam, 0): the corrected tracker (see icp_rot_rows)
 };
 
 // iteration flags (host-known)
@@ -62,12 +63,29 @@ __device__ inline double wave_sum_to_lane63(double v) {
 }
 
 
+// Rotational rows of A_T = G_T * n (localization_kernels.cu:207-213).  The reference's G_T rows are (0,-x,-y), (-z,0,x),
+// (y,z,0) -- not the rows of [v]x (Q14) --, which makes its tracker turn by degrees per frame on clean data.  corrected (own
+// specification, oracle: ora_camera_set_strict_reference(c, 0); include/svoslam.h svoslam_camera_set_strict_reference): the
+// rows of [v2]x, i.e. A_T[0..2] = v2 x n1, the linearisation of n1 . (v1 - (R v2 + t)) in a small rotation vector; with it go
+// this_trans = T(t) Rz Ry Rx with positive angles (iteration_tail_wave) and a position that takes the update's translation
+// (frame_end_step).  Same products in the same order; `corrected` is wavefront-uniform.
+__device__ __forceinline__ void icp_rot_rows(float x, float y, float z, float nx, float ny, float nz, bool corrected, float &j0, float &j1,
+                                             float &j2) {
+  const float a01 = corrected ? -z : -x, a02 = corrected ? y : -y;
+  const float a10 = corrected ? z : -z, a12 = corrected ? -x : x;
+  const float a20 = corrected ? -y : y, a21 = corrected ? x : z;
+  j0 = (0.0f * nx + a01 * ny) + a02 * nz;
+  j1 = (a10 * nx + 0.0f * ny) + a12 * nz;
+  j2 = (a20 * nx + a21 * ny) + 0.0f * nz;
+}
+
 // The 27 exact normal-equation terms of one pixel pair (localization_kernels.cu:186-226) added to acc[27]:
 // gates, A_T = G_T * n1 with the G_T rows of :208-213 (Q14), products in source order; fixed point:
 // prod * 2^k is exact in binary32 (power-of-two scale), rintf gives the same integer as
 // rint((double)prod * 2^k) of the specification (R3).
 __device__ __forceinline__ void icp_pixel_terms(float v1x, float v1y, float v1z, float n1x, float n1y, float n1z, float v2x,
-                                                float v2y, float v2z, float n2x, float n2y, float n2z, double (&acc)[27]) {
+                                                float v2y, float v2z, float n2x, float n2y, float n2z, double (&acc)[27],
+                                                bool corrected = false) {
   // Branch-free: the terms of a rejected pixel are formed (from whatever its floats hold) and replaced by +0
   // before they are added -- one set of accumulators, no per-pixel control flow, same sums.
   bool ok = finitef_(v2x) && finitef_(v2y) && finitef_(v2z) && finitef_(v1x) && finitef_(v1y) && finitef_(v1z) &&
@@ -77,9 +95,7 @@ __device__ __forceinline__ void icp_pixel_terms(float v1x, float v1y, float v1z,
   ok = ok && !(sqrtf(dot3(dx, dy, dz, dx, dy, dz)) > kDistThresh);
   ok = ok && !(dot3(n2x, n2y, n2z, n1x, n1y, n1z) < kNormThresh);
   float J[6];
-  J[0] = (0.0f * n1x + (-v2x) * n1y) + (-v2y) * n1z;
-  J[1] = ((-v2z) * n1x + 0.0f * n1y) + v2x * n1z;
-  J[2] = (v2y * n1x + v2z * n1y) + 0.0f * n1z;
+  icp_rot_rows(v2x, v2y, v2z, n1x, n1y, n1z, corrected, J[0], J[1], J[2]);
   J[3] = (1.0f * n1x + 0.0f * n1y) + 0.0f * n1z;
   J[4] = (0.0f * n1x + 1.0f * n1y) + 0.0f * n1z;
   J[5] = (0.0f * n1x + 0.0f * n1y) + 1.0f * n1z;
@@ -337,7 +353,10 @@ __device__ inline float mat4_mul_elem(const volatile float *a, const volatile fl
 __device__ inline void frame_end_step(CamState *st, int apply_update, const volatile float *m) {
   const int slot = st->frames_done;  // kept on the device so that the recorded launch sequence is the same for every frame
   if (apply_update) {
-    const float v[4] = {st->position[0], st->position[1], st->position[2], 1.0f};
+    float v[4] = {st->position[0], st->position[1], st->position[2], 1.0f};
+    // corrected tracker: the row-vector product below gives R^T p and drops the update's translation (Q17); main.cpp:40 maps a
+    // camera point x to orientation * (x + position), so composing with v_last = R v_cur + t needs R^T (p + t): add t first
+    if (st->corrected) { v[0] = v[0] + m[12]; v[1] = v[1] + m[13]; v[2] = v[2] + m[14]; }
     float np[3];
     for (int i = 0; i < 3; i++) np[i] = ((m[4 * i] * v[0] + m[4 * i + 1] * v[1]) + m[4 * i + 2] * v[2]) + m[4 * i + 3] * v[3];
     st->position[0] = np[0]; st->position[1] = np[1]; st->position[2] = np[2];
@@ -369,7 +388,7 @@ __device__ inline void frame_end_step(CamState *st, int apply_update, const vola
 constexpr int kTailScratch = 128;
 // state words the tail needs, fetched by the caller BEFORE it waits for the sums (one round trip instead of two;
 // a global access costs ~2 us while a raycast is running)
-struct TailPrefetch { float ut; int lost; };
+struct TailPrefetch { float ut; int lost; int corrected; };
 // what an iteration leaves behind, element e = lane & 15 of each matrix on every lane (the one-launch tracker hands
 // these to the other workgroups): update_trans, this_trans (valid when `solved`), the level's lost flag
 struct TailResult { float ut, tt; int lost, solved; };
@@ -378,6 +397,7 @@ __device__ inline TailPrefetch tail_prefetch(const CamState *st, int flags) {
   const int e = (int)(threadIdx.x & 15u);
   p.ut = st->update_trans[e];
   p.lost = st->lost;
+  p.corrected = st->corrected;
   (void)flags;
   return p;
 }
@@ -409,12 +429,14 @@ __device__ inline TailResult iteration_tail_wave(CamState *st, const double *sum
       }
       lost = 1;
     } else {
-      // this_trans = Rz(-x2) * Ry(-x1) * Rx(-x0) * T(x3,x4,x5), glm degrees API (:154-158)
+      // this_trans = Rz(-x2) * Ry(-x1) * Rx(-x0) * T(x3,x4,x5), glm degrees API (:154-158); corrected tracker: x is the rotation
+      // vector and translation that carry a current-frame point to R v + t: T(x3,x4,x5) * Rz(x2) * Ry(x1) * Rx(x0)
+      const bool cor = pre.corrected != 0;
       const int k = lane < 2 ? lane : 2;  // lane 0: Rz, lane 1: Ry, lanes 2..: Rx
       const float xk = k == 0 ? x[2] : (k == 1 ? x[1] : x[0]);
       float I[16], R[16], tr[16];
       d_identity(I);
-      d_rotate_deg(I, -xk * 180.0f / 3.14159f, k == 2 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 0 ? 1.0f : 0.0f, R);
+      d_rotate_deg(I, (cor ? xk : -xk) * 180.0f / 3.14159f, k == 2 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 0 ? 1.0f : 0.0f, R);
       const float tv[3] = {x[3], x[4], x[5]};
       d_translate(I, tv, tr);
       if (lane < 3)
@@ -423,13 +445,13 @@ __device__ inline TailResult iteration_tail_wave(CamState *st, const double *sum
         for (int i = 0; i < 16; i++) sm[48 + i] = tr[i];
       if (lane < 16) sm[112 + e] = ut;
       __builtin_amdgcn_wave_barrier();
-      const float t1 = mat4_mul_elem(sm, sm + 16, e);          // Rz * Ry
+      const float t1 = cor ? mat4_mul_elem(sm + 48, sm, e) : mat4_mul_elem(sm, sm + 16, e);               // Rz * Ry      | T * Rz
       if (lane < 16) sm[64 + e] = t1;
       __builtin_amdgcn_wave_barrier();
-      const float t2 = mat4_mul_elem(sm + 64, sm + 32, e);     // * Rx
+      const float t2 = cor ? mat4_mul_elem(sm + 64, sm + 16, e) : mat4_mul_elem(sm + 64, sm + 32, e);     // * Rx         | * Ry
       if (lane < 16) sm[80 + e] = t2;
       __builtin_amdgcn_wave_barrier();
-      const float tt = mat4_mul_elem(sm + 80, sm + 48, e);     // * T  = this_trans
+      const float tt = cor ? mat4_mul_elem(sm + 80, sm + 32, e) : mat4_mul_elem(sm + 80, sm + 48, e);     // * T          | * Rx  = this_trans
       if (lane < 16) sm[96 + e] = tt;
       __builtin_amdgcn_wave_barrier();
       ut = mat4_mul_elem(sm + 96, sm + 112, e);                // update_trans = this_trans * update_trans (:160)

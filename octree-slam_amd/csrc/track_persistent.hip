@@ -105,7 +105,7 @@ __device__ inline TermLane term_of_lane(int t) {
 
 // gates + Jacobian row of one pixel pair -> row[0..8) (zeros when a gate rejects the pair)
 __device__ __forceinline__ void icp_pixel_row(float v1x, float v1y, float v1z, float n1x, float n1y, float n1z, float v2x,
-                                              float v2y, float v2z, float n2x, float n2y, float n2z, float *row) {
+                                              float v2y, float v2z, float n2x, float n2y, float n2z, float *row, bool corrected) {
   bool ok = finitef_(v2x) && finitef_(v2y) && finitef_(v2z) && finitef_(v1x) && finitef_(v1y) && finitef_(v1z) &&
             !(v1z < 0.1f) && !(v2z < 0.1f) && !(v1z > 10.0f) && !(v2z > 10.0f);
   ok = ok && finitef_(n2x) && finitef_(n2y) && finitef_(n2z) && finitef_(n1x) && finitef_(n1y) && finitef_(n1z);
@@ -113,9 +113,7 @@ __device__ __forceinline__ void icp_pixel_row(float v1x, float v1y, float v1z, f
   ok = ok && !(sqrtf(dot3(dx, dy, dz, dx, dy, dz)) > kDistThresh);
   ok = ok && !(dot3(n2x, n2y, n2z, n1x, n1y, n1z) < kNormThresh);
   float J[6];
-  J[0] = (0.0f * n1x + (-v2x) * n1y) + (-v2y) * n1z;
-  J[1] = ((-v2z) * n1x + 0.0f * n1y) + v2x * n1z;
-  J[2] = (v2y * n1x + v2z * n1y) + 0.0f * n1z;
+  icp_rot_rows(v2x, v2y, v2z, n1x, n1y, n1z, corrected, J[0], J[1], J[2]);
   J[3] = (1.0f * n1x + 0.0f * n1y) + 0.0f * n1z;
   J[4] = (0.0f * n1x + 1.0f * n1y) + 0.0f * n1z;
   J[5] = (0.0f * n1x + 0.0f * n1y) + 1.0f * n1z;
@@ -151,9 +149,9 @@ __device__ __forceinline__ void accumulate_rows(const float *rows, const TermLan
 // the solver's iteration tail as a real call: its ~70 VGPRs and the workers' register-resident pixels are then
 // allocated independently (inlined, the allocator spills the tail's values around the 255-VGPR worker body)
 __device__ __attribute__((noinline)) TailResult solver_tail(CamState *st, const double *totals, int it, int flags, float *tail_sm,
-                                                            float pre_ut, int pre_lost) {
+                                                            float pre_ut, int pre_lost, int corrected) {
   TailPrefetch pre;
-  pre.ut = pre_ut; pre.lost = pre_lost;
+  pre.ut = pre_ut; pre.lost = pre_lost; pre.corrected = corrected;
   return iteration_tail_wave(st, totals, it, flags, tail_sm, pre);
 }
 
@@ -252,7 +250,7 @@ __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(Cam
           if (it == 0) flags |= kFlagFirstIter;
           if (level == 2 && it == 0) flags |= kFlagFirstOfFrame;
           if (level == 0 && it == A.iters[0] - 1) flags |= kFlagLastOfFrame;
-          const TailResult res = solver_tail(st, totals, it, flags, tail_sm, bc[16 + (lane & 15u)], bc_flags & 1);
+          const TailResult res = solver_tail(st, totals, it, flags, tail_sm, bc[16 + (lane & 15u)], bc_flags & 1, A.corrected);
           const unsigned tag = gen * 32u + (unsigned)e;
           const unsigned fl = (unsigned)(res.lost ? 1 : 0) | (unsigned)(res.solved ? 2 : 0);
           const unsigned val = lane < 16 ? __float_as_uint(res.tt) : (lane < 32 ? __float_as_uint(res.ut) : fl);
@@ -338,7 +336,7 @@ __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(Cam
             for (int k = 0; k < SLOTS; k++) {
               if (k < slots) {
                 icp_pixel_row(px.v1[k][0], px.v1[k][1], px.v1[k][2], px.n1[k][0], px.n1[k][1], px.n1[k][2], px.v2[k][0],
-                              px.v2[k][1], px.v2[k][2], px.n2[k][0], px.n2[k][1], px.n2[k][2], my_rows + lane * kRowFloats);
+                              px.v2[k][1], px.v2[k][2], px.n2[k][0], px.n2[k][1], px.n2[k][2], my_rows + lane * kRowFloats, A.corrected != 0);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();  // the rows of this wavefront are read by its own lanes only
                 accumulate_rows(my_rows, T, half, acc0, acc1);
@@ -377,7 +375,7 @@ __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(Cam
                 A.work_n[3 * q] = n2x; A.work_n[3 * q + 1] = n2y; A.work_n[3 * q + 2] = n2z;
               }
               icp_pixel_row(have_cur ? cur.v1[0] : __builtin_nanf(""), cur.v1[1], cur.v1[2], cur.n1[0], cur.n1[1], cur.n1[2], v2x, v2y, v2z, n2x, n2y,
-                            n2z, my_rows + lane * kRowFloats);
+                            n2z, my_rows + lane * kRowFloats, A.corrected != 0);
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
               __builtin_amdgcn_wave_barrier();
               accumulate_rows(my_rows, T, half, acc0, acc1);
@@ -403,7 +401,7 @@ __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(Cam
                 mat4_mul_point(chain_s + 16 * c, n2x, n2y, n2z, 0.0f, ox, oy, oz);
                 n2x = ox; n2y = oy; n2z = oz;
               }
-              icp_pixel_row(v1x, v1y, v1z, n1x, n1y, n1z, v2x, v2y, v2z, n2x, n2y, n2z, my_rows + lane * kRowFloats);
+              icp_pixel_row(v1x, v1y, v1z, n1x, n1y, n1z, v2x, v2y, v2z, n2x, n2y, n2z, my_rows + lane * kRowFloats, A.corrected != 0);
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
               __builtin_amdgcn_wave_barrier();
               accumulate_rows(my_rows, T, half, acc0, acc1);
@@ -532,7 +530,10 @@ int track_persistent_plan_coarse(TrackArgs &A, int capacity, int coarse_levels) 
 // Large images in ONE launch (round 3): every level runs here; the coarsest keeps its pixels in registers (kTrkStreamSlots
 // per lane), the finer ones stream through the work maps (TrackArgs::work_v / work_n must be set by the caller).
 int track_persistent_plan_stream(TrackArgs &A, int capacity) {
-  int cap = env_int("SVOSLAM_TRACK_WORKERS", kTrkMaxWorkers);
+  // 176 workers: the form is bound by bandwidth, not by CUs, and what it leaves free the march and the fusion use -- cfg4 with
+  // the brick march, frames/s by worker count (one box, medians of 3): 64 -> 542, 96 -> 707, 128 -> 835, 160 -> 881, 176 -> 893,
+  // 192 -> 884, 208 -> 865, 224 -> 773, 255 -> 790; the launch chain 811
+  int cap = env_int("SVOSLAM_TRACK_WORKERS", 176);
   if (cap > capacity - 1) cap = capacity - 1;
   if (cap < 1) return SVOSLAM_ERR_INVALID_ARG;
   long long W = 1;

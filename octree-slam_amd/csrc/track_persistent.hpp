@@ -32,6 +32,7 @@ struct TrackArgs {
   int slots[3];          // pixels per lane at each level
   float *work_v = nullptr, *work_n = nullptr;  // streaming levels: the current frame's maps as transformed so far (finest-level size)
   int variant = 0;       // 0: register-resident form <kTrkSlots, 2>; 1: streaming form for large images
+  int corrected = 0;     // the corrected tracker (icp_device.hpp icp_rot_rows)
 };
 constexpr int kTrkStreamSlots = 2;
 #ifndef SVO_TRK_STREAM_MIN_WAVES

@@ -266,13 +266,18 @@ class EmulatedRank:
 
 class SlamPipeline:
     def __init__(self, width, height, max_depth, center, half_edge, render_mode=pkg.RENDER_REFERENCE, dist=None,
-                 pool_capacity_nodes=1 << 20, count_steps=False, frame_to_model=False, model_min_coverage=0.5):
+                 pool_capacity_nodes=1 << 20, count_steps=False, frame_to_model=False, model_min_coverage=0.5, strict_reference=True):
         self.w, self.h, self.depth = width, height, max_depth
         self.center, self.edge = tuple(float(c) for c in center), float(half_edge)
         self.mode = render_mode
         self.dist = dist or DistContext()
         self.focal = 570.3 * width / 640.0
         self.cam = pkg.Camera(width, height, self.focal, self.focal)
+        # strict_reference=False: the corrected tracker (include/svoslam.h svoslam_camera_set_strict_reference) on every camera of
+        # the session -- own specification, never the headline
+        self.strict_reference = bool(strict_reference)
+        if not self.strict_reference:
+            self.cam.set_strict_reference(False)
         self.ws = pkg.Workspace()
         self.pool = pkg.Pool(pool_capacity_nodes)
         dev = "cuda"
@@ -285,6 +290,8 @@ class SlamPipeline:
         if self.frame_sharded:
             self.first, self.rows = 0, height                    # whole images of this rank's frames
             self.delta_cam = pkg.Camera(width, height, self.focal, self.focal)   # scratch camera of pair_delta
+            if not self.strict_reference:
+                self.delta_cam.set_strict_reference(False)
             self.frames_seen, self._prev = 0, None
             # the SORT can be sharded too (round 3): the owner of a frame sorts it -- with the pose a second chain of apply_delta
             # gives -- and the sorted keys / point indices (12 bytes per pixel) are all-gathered per chunk; needs the packed key
@@ -298,6 +305,8 @@ class SlamPipeline:
             self.shard_sort = want and 3 * max_depth + 1 + idx_bits <= 64
             if self.shard_sort:
                 self.sort_cam = pkg.Camera(width, height, self.focal, self.focal)   # composes the poses the owner sorts with
+                if not self.strict_reference:
+                    self.sort_cam.set_strict_reference(False)
                 self.ws_sort = pkg.Workspace()
         else:
             self.first, self.rows = band_rows(height, self.dist.rank, self.dist.world)

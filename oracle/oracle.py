@@ -108,6 +108,7 @@ def lib(native=False):
     L.ora_camera_update.argtypes = [C.c_void_p, u16p, u8p, C.c_longlong]
     L.ora_camera_pose.argtypes = [C.c_void_p, f32p, f32p]
     L.ora_camera_set_pose.argtypes = [C.c_void_p, f32p, f32p]
+    L.ora_camera_set_strict_reference.argtypes = [C.c_void_p, C.c_int]
     L.ora_camera_last_update.argtypes = [C.c_void_p, f32p]
     L.ora_camera_apply_delta.restype = C.c_int
     L.ora_camera_apply_delta.argtypes = [C.c_void_p, f32p, C.c_int, C.c_longlong]
@@ -493,6 +494,10 @@ class Camera:
 
     def set_rgbd(self, enable=True):
         self._L.ora_camera_set_rgbd(self._c, 1 if enable else 0)
+
+    def set_strict_reference(self, strict=True):
+        """False: this build's corrected tracker (svoslam_oracle.c ora_camera_set_strict_reference); before the first frame"""
+        self._L.ora_camera_set_strict_reference(self._c, 1 if strict else 0)
 
     def set_model_depth(self, depth):
         if depth is None:       # no model: frame to frame until the next one

@@ -988,8 +988,21 @@ void ora_point_cloud_bbox(const float *pts, int n, float bbox0[3], float bbox1[3
  * more accurate than the reference's binary32 sums.
  * Q15: with load_size = 20*w/640 the reference reduces floor(n/load_size)
  * partials, so pixels >= floor(n/load)*load are excluded. */
+static void icp_cost2_raw_mode(const float *last_v, const float *last_n, const float *cur_v, const float *cur_n,
+                               int first_pixel, int num_pixels, int w, int h, int corrected, int64_t acc[27]);
 void ora_icp_cost2_raw(const float *last_v, const float *last_n, const float *cur_v, const float *cur_n,
                        int first_pixel, int num_pixels, int w, int h, int64_t acc[27]) {
+  icp_cost2_raw_mode(last_v, last_n, cur_v, cur_n, first_pixel, num_pixels, w, h, 0, acc);
+}
+/* corrected != 0: the CORRECTED tracker of this build (ora_camera_set_strict_reference): the rotational rows of the Jacobian
+ * are [v2]x = ((0,-z,y),(z,0,-x),(-y,x,0)), i.e. A_T[0..2] = v2 x n1 -- the linearisation of n1 . (v1 - (R v2 + t)) in a small
+ * rotation vector -- instead of the reference's rows (Q14).  Everything else (gates, products in this order, exact sums) as above. */
+void ora_icp_cost2_raw_corrected(const float *last_v, const float *last_n, const float *cur_v, const float *cur_n,
+                                 int first_pixel, int num_pixels, int w, int h, int64_t acc[27]) {
+  icp_cost2_raw_mode(last_v, last_n, cur_v, cur_n, first_pixel, num_pixels, w, h, 1, acc);
+}
+static void icp_cost2_raw_mode(const float *last_v, const float *last_n, const float *cur_v, const float *cur_n,
+                               int first_pixel, int num_pixels, int w, int h, int corrected, int64_t acc[27]) {
   for (int i = 0; i < 27; i++) acc[i] = 0;
   int n = w * h;
   int load_size = 20 * w / 640;
@@ -1009,9 +1022,12 @@ void ora_icp_cost2_raw(const float *last_v, const float *last_n, const float *cu
     float d[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
     if (length3(d) > ICP_DIST_THRESH) continue;
     if (dot3(n2, n1) < ICP_NORM_THRESH) continue;
-    /* G_T rows (Q14) */
-    const float G_T[18] = {0.0f, -v2[0], -v2[1], -v2[2], 0.0f, v2[0], v2[1], v2[2], 0.0f,
-                           1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f};
+    /* G_T rows (Q14); corrected: the rows of [v2]x */
+    const float G_ref[18] = {0.0f, -v2[0], -v2[1], -v2[2], 0.0f, v2[0], v2[1], v2[2], 0.0f,
+                             1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f};
+    const float G_cor[18] = {0.0f, -v2[2], v2[1], v2[2], 0.0f, -v2[0], -v2[1], v2[0], 0.0f,
+                             1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f};
+    const float *G_T = corrected ? G_cor : G_ref;
     float A_T[6];
     for (int i = 0; i < 6; i++) A_T[i] = (G_T[3 * i] * n1[0] + G_T[3 * i + 1] * n1[1]) + G_T[3 * i + 2] * n1[2];
     float dv[3] = {v1[0] - v2[0], v1[1] - v2[1], v1[2] - v2[2]};
@@ -1148,6 +1164,23 @@ void ora_icp_update_transform(const float x[6], float out[16]) {
   ora_mat4_mul(t2, tr, out);
 }
 
+/* the CORRECTED tracker's update (own specification): x = (rotation vector, translation) of the linearisation above, so a
+ * point of the current frame moves to R v + t with R = Rz(x2) Ry(x1) Rx(x0) (positive angles; the reference negates them and
+ * translates BEFORE rotating, :154-158): translate(x3, x4, x5) * Rz * Ry * Rx with the same glm calls */
+void ora_icp_update_transform_corrected(const float x[6], float out[16]) {
+  float I[16], rz[16], ry[16], rx[16], tr[16], t1[16], t2[16];
+  static const float ax[3] = {1, 0, 0}, ay[3] = {0, 1, 0}, az[3] = {0, 0, 1};
+  ora_mat4_identity(I);
+  ora_mat4_rotate_deg(I, x[2] * 180.0f / 3.14159f, az, rz);
+  ora_mat4_rotate_deg(I, x[1] * 180.0f / 3.14159f, ay, ry);
+  ora_mat4_rotate_deg(I, x[0] * 180.0f / 3.14159f, ax, rx);
+  float tv[3] = {x[3], x[4], x[5]};
+  ora_mat4_translate(I, tv, tr);
+  ora_mat4_mul(tr, rz, t1);
+  ora_mat4_mul(t1, ry, t2);
+  ora_mat4_mul(t2, rx, out);
+}
+
 /* ======================================================================== */
 /* tracker (src/sensor/rgbd_camera.cpp:22-191)                               */
 /* ======================================================================== */
@@ -1257,6 +1290,8 @@ struct ora_camera {
   /* frame-to-model tracking (off by default): maps the ICP tracks against instead of the previous frame's */
   int to_model, have_model;
   float *model_v[PYR], *model_n[PYR];
+  /* ora_camera_set_strict_reference(c, 0): the corrected tracker (own specification; default 1 = the reference's, Q14 / Q17) */
+  int corrected;
 };
 
 ora_camera *ora_camera_create(int w, int h, float fx, float fy) {
@@ -1288,10 +1323,15 @@ static void mat3_to_mat4(const float m3[9], float m4[16]) {
     for (int r = 0; r < 3; r++) m4[4 * c + r] = m3[3 * c + r];
 }
 
-/* rgbd_camera.cpp:172-173 (Q17: row-vector products) */
+/* rgbd_camera.cpp:172-173 (Q17: row-vector products).  The row-vector product gives R^T p and drops the update's
+ * translation; main.cpp:40 maps a camera point x to orientation * (x + position), so the pose that composes camera -> map with
+ * the frame-to-frame transform v_last = R v_cur + t is orientation * R and R^T (position + t): the corrected tracker adds t
+ * to the position first (same product, same order otherwise). */
 static void pose_step(ora_camera *c, const float update_trans[16]) {
   float p4[4] = {c->position[0], c->position[1], c->position[2], 1.0f}, np[4];
+  if (c->corrected) { p4[0] = p4[0] + update_trans[12]; p4[1] = p4[1] + update_trans[13]; p4[2] = p4[2] + update_trans[14]; }
   vec4_mul_mat4(p4, update_trans, np);
+  if (c->corrected) { /* (the translation column contributes to w only; the rotation part of the product is R^T (p + t)) */ }
   c->position[0] = np[0]; c->position[1] = np[1]; c->position[2] = np[2];
   float o4[16], no[16];
   mat3_to_mat4(c->orientation, o4);
@@ -1357,6 +1397,11 @@ int ora_camera_update(ora_camera *c, const uint16_t *depth, const uint8_t *rgb, 
       for (int j = 0; j < PYRAMID_ITERS[i]; j++) {
         float A1[36], b1[6], x[6];
         const int model = c->to_model && c->have_model; /* the TODO of rgbd_camera.cpp:185: the maps tracked against come from elsewhere */
+        if (c->corrected) {
+          int64_t acc[27];
+          ora_icp_cost2_raw_corrected(model ? c->model_v[i] : c->last_v[i], model ? c->model_n[i] : c->last_n[i], fv, fn, 0, w * h, w, h, acc);
+          ora_icp_finish(acc, A1, b1);
+        } else
         ora_icp_cost2(model ? c->model_v[i] : c->last_v[i], model ? c->model_n[i] : c->last_n[i], fv, fn, w, h, A1, b1);
         if (c->rgbd) { /* rgbd_camera.cpp:126-141 with W_RGBD (:20) applied to the photometric system */
           float A2[36], b2[6];
@@ -1368,7 +1413,8 @@ int ora_camera_update(ora_camera *c, const uint16_t *depth, const uint8_t *rgb, 
         memcpy(c->lastA, A1, sizeof(A1)); memcpy(c->lastb, b1, sizeof(b1)); memcpy(c->lastx, x, sizeof(x));
         if (x[0] != x[0] || x[1] != x[1] || x[2] != x[2] || x[3] != x[3] || x[4] != x[4] || x[5] != x[5]) { c->lost_count++; break; }
         float this_trans[16];
-        ora_icp_update_transform(x, this_trans);
+        if (c->corrected) ora_icp_update_transform_corrected(x, this_trans);
+        else ora_icp_update_transform(x, this_trans);
         ora_mat4_mul(this_trans, update_trans, update_trans);
         if (j < PYRAMID_ITERS[i] - 1) {
           ora_transform_vertex_map(fv, this_trans, n);
@@ -1441,6 +1487,12 @@ int ora_camera_set_frame_to_model(ora_camera *c, int enable) {
 }
 
 int ora_camera_tracking_lost_count(const ora_camera *c) { return c->lost_count; }
+
+/* strict = 1 (default): RGBDCamera::update as the reference has it, every quirk included.  strict = 0: this build's CORRECTED
+ * tracker -- the three places where the reference's update is not a rigid-motion estimate are replaced (Jacobian rows = [v2]x
+ * instead of Q14's; this_trans = T(t) Rz Ry Rx with positive angles; the position takes the update's translation, Q17) --
+ * own specification, no reference behaviour; before the first frame. */
+void ora_camera_set_strict_reference(ora_camera *c, int strict) { c->corrected = !strict; }
 
 void ora_camera_pose(const ora_camera *c, float position[3], float orientation[9]) {
   memcpy(position, c->position, sizeof(float) * 3);

@@ -141,6 +141,10 @@ void ora_camera_pose(const ora_camera *c, float position[3], float orientation[9
 void ora_camera_set_pose(ora_camera *c, const float position[3], const float orientation[9]);
 /* frame-parallel tracking: a tracked frame's update_trans, and the pose step for an update_trans from anywhere */
 void ora_camera_last_update(const ora_camera *c, float out[16]);
+void ora_camera_set_strict_reference(ora_camera *c, int strict);
+void ora_icp_cost2_raw_corrected(const float *last_v, const float *last_n, const float *cur_v, const float *cur_n,
+                                 int first_pixel, int num_pixels, int w, int h, int64_t acc[27]);
+void ora_icp_update_transform_corrected(const float x[6], float out[16]);
 int ora_camera_apply_delta(ora_camera *c, const float *update_trans, int levels_lost, long long timestamp);
 int ora_camera_tracking_lost_count(const ora_camera *c);
 void ora_camera_set_rgbd(ora_camera *c, int enable); /* adds W_RGBD x the photometric system to every ICP iteration */

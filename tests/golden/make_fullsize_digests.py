@@ -27,9 +27,12 @@ OUT = os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")
 
 CENTER = (0.0, 1.5, 0.0)
 CONFIGS = {
-    # name: width, height, depth, half-edge, checkpoints (frames fused when the state is digested), render mode
-    "cfg3": (640, 480, 12, 4.096, (4, 24, 72, 150, 300), 0),
-    "cfg4": (1920, 1080, 14, 8.192, (2, 8, 16), 0),
+    # name: width, height, depth, half-edge, checkpoints (frames fused when the state is digested), render mode, strict tracker
+    "cfg3": (640, 480, 12, 4.096, (4, 24, 72, 150, 300), 0, True),
+    "cfg4": (1920, 1080, 14, 8.192, (2, 8, 16), 0, True),
+    # the same stream with this build's CORRECTED tracker (own specification: oracle ora_camera_set_strict_reference(c, 0)): the
+    # pose follows the sensor, surfaces are re-observed, alpha saturates, rays retire, the reference-mode image has colour
+    "cfg3_corrected": (640, 480, 12, 4.096, (4, 24, 72, 150, 300), 0, False),
 }
 
 
@@ -59,11 +62,14 @@ def run_stream_config(name):
     from oracle import oracle as ora
     synth = importlib.import_module("octree_slam_amd.synth")
     pl = importlib.import_module("octree_slam_amd.pipeline")
-    w, h, depth, edge, checkpoints, mode = CONFIGS[name]
+    w, h, depth, edge, checkpoints, mode, strict = CONFIGS[name]
     L = ora.lib(native=True)            # -O3 -march=native, -ffp-contract=off kept: same bits as the -O2 build
     f = synth.focal_length(w)
     cam, pool = ora.Camera(w, h, f, f, L=L), ora.Pool(L=L)
-    out = {"width": w, "height": h, "depth": depth, "edge": edge, "center": list(CENTER), "render_mode": mode, "checkpoints": {}}
+    if not strict:
+        cam.set_strict_reference(False)
+    out = {"width": w, "height": h, "depth": depth, "edge": edge, "center": list(CENTER), "render_mode": mode, "strict_reference": bool(strict),
+           "checkpoints": {}}
     tot_steps = tot_levels = 0
     hin = hashlib.sha256()
     t0 = time.time()
@@ -89,6 +95,7 @@ def run_stream_config(name):
                 "image_carry_sha256": sha(img1), "image_carry_coloured_pixels": int((img1[..., :3].max(-1) > 0).sum()),
                 "steps_total": int(tot_steps), "levels_total": int(tot_levels),
                 "tracking_lost_levels": int(cam.tracking_lost_count()),
+                "saturated_nodes": int(((pool.words()[1::2] >> 24) >= 254).sum()) if pool.size < (1 << 27) else None,
             }
             print(name, k + 1, "%.0f s" % (time.time() - t0), out["checkpoints"][str(k + 1)], flush=True)
     return out

@@ -51,7 +51,8 @@ def _run_config(env, name, last_checkpoint=None):
     cps = sorted(int(k) for k in gold["checkpoints"])
     if last_checkpoint:
         cps = [c for c in cps if c <= last_checkpoint]
-    P = pl.SlamPipeline(w, h, depth, center, edge, render_mode=mode, count_steps=True, pool_capacity_nodes=(1 << 30) - 8)
+    P = pl.SlamPipeline(w, h, depth, center, edge, render_mode=mode, count_steps=True, pool_capacity_nodes=(1 << 30) - 8,
+                        strict_reference=gold.get("strict_reference", True))
     hin = hashlib.sha256()
     done = 0
     for cp in cps:
@@ -93,3 +94,13 @@ def test_cfg3_300_frames_full_size(env):
 def test_cfg4_16_frames_full_size(env):
     """BASELINE config 4 on one GPU: 16 frames at 1920x1080 into a depth-14 SVO; checkpoints after 2, 8 and 16 frames"""
     _run_config(env, "cfg4")
+
+
+def test_cfg3_300_frames_full_size_corrected_tracker(env):
+    """the same 300 frames with this build's CORRECTED tracker (own specification: svoslam_camera_set_strict_reference(cam, 0)):
+    the pose follows the sensor, surfaces are re-observed, alpha saturates -- the regime the reference's tracker (Q14) never
+    reaches at full size: rays retire on saturated nodes through the bricks' A >= 254 bits, the reference-mode image carries
+    colour, the fusion is dominated by read-modify-writes of existing leaves.  Against oracle digests as above."""
+    P = _run_config(env, "cfg3_corrected")
+    gold = json.load(open(GOLD))["cfg3_corrected"]["checkpoints"]["300"]
+    assert gold["image_coloured_pixels"] > 0 and gold["saturated_nodes"] > 0

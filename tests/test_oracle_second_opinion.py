@@ -321,7 +321,7 @@ def test_fusion_second_opinion(oracle, depth):
 # (b), in Python integers here.  Q14 (the rotational rows of G_T are not v x n) and Q15 (floor(n / load_size) partials: the
 # tail pixels are dropped) literal.
 # ---------------------------------------------------------------------------------------------------------------------
-def icp_cost2(lv, ln, cv, cn):
+def icp_cost2(lv, ln, cv, cn, corrected=False):
     h, w, _ = lv.shape
     n = w * h
     load = 20 * w // 640
@@ -345,6 +345,8 @@ def icp_cost2(lv, ln, cv, cn):
             continue
         z, o = F(0.0), F(1.0)
         G = [z, -v2[0], -v2[1], -v2[2], z, v2[0], v2[1], v2[2], z, o, z, z, z, o, z, z, z, o]
+        if corrected:       # this build's corrected tracker: the rows of [v2]x, i.e. AT[0..2] = v2 x n1
+            G = [z, -v2[2], v2[1], v2[2], z, -v2[0], -v2[1], v2[0], z, o, z, z, z, o, z, z, z, o]
         AT = [(G[3 * i] * n1[0] + G[3 * i + 1] * n1[1]) + G[3 * i + 2] * n1[2] for i in range(6)]
         b = dot(n1, v1 - v2)
         for i in range(6):
@@ -553,7 +555,7 @@ def test_pyramid_second_opinion(oracle):
 # iteration.  Built from the restatements above; the bilateral filter (R4: this build's own expf) and glm's rotate /
 # translate / operator* (pinned by the reference's vendored glm, tests/test_ref_glm.py) are taken from the oracle.
 # ---------------------------------------------------------------------------------------------------------------------
-def track_second_opinion(oracle, depth_prev, depth_cur, fx, fy):
+def track_second_opinion(oracle, depth_prev, depth_cur, fx, fy, corrected=False):
     H, W = depth_cur.shape
 
     def pyramid(depth):
@@ -576,11 +578,21 @@ def track_second_opinion(oracle, depth_prev, depth_cur, fx, fy):
             v, n = transform(v, update, 1.0), transform(n, update, 0.0)
         iters = (10, 5, 4)[i]
         for j in range(iters):
-            A, b, _ = icp_cost2(last_v[i], last_n[i], v, n)
+            A, b, _ = icp_cost2(last_v[i], last_n[i], v, n, corrected)
             x = solve_cholesky(A, b)
             if np.isnan(x).any():
                 lost += 1
                 break
+            if corrected:   # a current-frame point goes to R v + t: translate * Rz * Ry * Rx with positive angles
+                rz = oracle.mat4_rotate_deg(I, x[2] * F(180.0) / F(3.14159), [0.0, 0.0, 1.0])
+                ry = oracle.mat4_rotate_deg(I, x[1] * F(180.0) / F(3.14159), [0.0, 1.0, 0.0])
+                rx = oracle.mat4_rotate_deg(I, x[0] * F(180.0) / F(3.14159), [1.0, 0.0, 0.0])
+                t = oracle.mat4_translate(I, [x[3], x[4], x[5]])
+                this = oracle.mat4_mul(oracle.mat4_mul(oracle.mat4_mul(t, rz), ry), rx)
+                update = oracle.mat4_mul(this, update)
+                if j < iters - 1:
+                    v, n = transform(v, this, 1.0), transform(n, this, 0.0)
+                continue
             rz = oracle.mat4_rotate_deg(I, -x[2] * F(180.0) / F(3.14159), [0.0, 0.0, 1.0])
             ry = oracle.mat4_rotate_deg(I, -x[1] * F(180.0) / F(3.14159), [0.0, 1.0, 0.0])
             rx = oracle.mat4_rotate_deg(I, -x[0] * F(180.0) / F(3.14159), [1.0, 0.0, 0.0])
@@ -865,9 +877,11 @@ def test_small_kernels_second_opinion(oracle):
 # and orientation = mat3(mat4(orientation) * update_trans), glm's mat4 * mat4: column c = A0 B[c][0] + A1 B[c][1] + A2 B[c][2] +
 # A3 B[c][3], both summed left to right (type_mat4x4.inl)
 # ---------------------------------------------------------------------------------------------------------------------
-def pose_step(position, orientation, update):
+def pose_step(position, orientation, update, corrected=False):
     U = np.asarray(update, F).reshape(4, 4)                 # U[c] = column c
     v = [F(position[0]), F(position[1]), F(position[2]), F(1.0)]
+    if corrected:                                           # the update's translation joins the position first (Q17 drops it)
+        v = [v[0] + U[3][0], v[1] + U[3][1], v[2] + U[3][2], F(1.0)]
     pos = np.array([((U[c][0] * v[0] + U[c][1] * v[1]) + U[c][2] * v[2]) + U[c][3] * v[3] for c in range(3)], F)
     O4 = np.zeros((4, 4), F)
     O4[3, 3] = F(1.0)
@@ -900,6 +914,69 @@ def test_pose_step_second_opinion(oracle):
         p_ref, o_ref = cam.pose()
         assert bits_equal(p_ref, pos) and bits_equal(o_ref, ori), (k, pos, p_ref, ori, o_ref)
     assert not np.array_equal(ori, np.array([1, 0, 0, 0, 1, 0, 0, 0, 1], F))
+
+
+def test_corrected_tracker_second_opinion(oracle):
+    """this build's CORRECTED tracker (own specification: include/svoslam.h svoslam_camera_set_strict_reference; oracle
+    ora_camera_set_strict_reference) restated a second time -- rows of [v2]x, translate * Rz * Ry * Rx with positive angles,
+    position += t before the row-vector product -- against the oracle: update_trans and the pose bit for bit over three
+    frames; and it differs from the strict tracker on the same frames"""
+    w, h = 128, 96
+    fx = fy = 525.0 * w / 640.0
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+
+    def depth(shift, tilt):
+        z = 1.3 + (0.25 + tilt) * (xs / w) + 0.12 * (ys / h) + 0.05 * np.sin(xs / 9.0) * np.cos(ys / 7.0) + shift
+        d = (z * 1000.0).astype(np.uint16)
+        d[10:14, 20:30] = 0
+        return d
+    frames = [depth(0.0, 0.0), depth(0.003, 0.002), depth(0.005, 0.004)]
+    rgb = np.zeros((h, w, 3), np.uint8)
+    cam, strict = oracle.Camera(w, h, fx, fy), oracle.Camera(w, h, fx, fy)
+    cam.set_strict_reference(False)
+    pos, ori = np.zeros(3, F), np.array([1, 0, 0, 0, 1, 0, 0, 0, 1], F)
+    cam.update(frames[0], rgb, 1); strict.update(frames[0], rgb, 1)
+    for k in (1, 2):
+        cam.update(frames[k], rgb, k + 1); strict.update(frames[k], rgb, k + 1)
+        mine, lost = track_second_opinion(oracle, frames[k - 1], frames[k], fx, fy, corrected=True)
+        assert lost == 0 and bits_equal(mine, cam.last_update()), (k, mine, cam.last_update())
+        pos, ori = pose_step(pos, ori, mine, corrected=True)
+        p_ref, o_ref = cam.pose()
+        assert bits_equal(p_ref, pos) and bits_equal(o_ref, ori), (k, pos, p_ref)
+    assert not np.array_equal(cam.last_update(), strict.last_update()) and np.abs(pos).max() > 0
+
+
+def test_corrected_tracker_follows_the_synthetic_sensor(oracle):
+    """what the corrected mode is for: on the synthetic stream (0.1 degrees and ~0.9 mm per frame) it stays within a degree and
+    a centimetre of the generator's ground truth over 40 frames at 160x120, where the reference's tracker (Q14) has turned by
+    tens of degrees"""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("synth_cpu", os.path.join(here, "octree-slam_amd", "synth.py"))
+    synth = importlib.util.module_from_spec(spec); spec.loader.exec_module(synth)
+    w, h, n = 160, 120, 40
+    f = synth.focal_length(w)
+
+    def errors(cam):
+        p, o = cam.pose()
+        M = o.reshape(3, 3).T.astype(np.float64)
+        (p0, y0), (pk, yk) = synth.camera_pose(0), synth.camera_pose(n - 1)
+        th = yk - y0
+        R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+        d, c0, s0 = np.array(pk) - np.array(p0), np.cos(y0), np.sin(y0)
+        eye = np.array([c0 * d[0] - s0 * d[2], d[1], s0 * d[0] + c0 * d[2]])
+        E = M @ R.T
+        return np.degrees(np.arccos(np.clip((np.trace(E) - 1) / 2, -1, 1))), np.linalg.norm(M @ p.astype(np.float64) - eye)
+    cams = [oracle.Camera(w, h, f, f), oracle.Camera(w, h, f, f)]
+    cams[1].set_strict_reference(False)
+    for k in range(n):
+        d, c = synth.render_frame(k, w, h)
+        for cam in cams:
+            cam.update(d.numpy().view(np.uint16), c.numpy(), k)
+    (rs, ts), (rc, tc) = errors(cams[0]), errors(cams[1])
+    assert rc < 1.0 and tc < 0.01, (rc, tc)
+    assert rs > 20.0, rs
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -29,7 +29,8 @@ def show(name, fn):
 show("full", lambda c: pkg.cone_trace_svo(img, 45.0, view, P.pool.data_ptr, P.center, P.edge, 0, c))
 cnt.zero_(); pkg.cone_trace_svo(img, 45.0, view, P.pool.data_ptr, P.center, P.edge, 0x200, cnt); torch.cuda.synchronize()
 c = cnt.tolist(); nw = W * H // 64
-print("full: per wavefront (lane 0): prologue %.0f cycles, loop %.0f cycles; waves %d" % (c[2] / nw, c[3] / nw, nw))
+print("full: per wavefront (lane 0): LDS tables %.0f cycles, ray set-up %.0f, loop %.0f, epilogue (last sample's walk, pixel) %.0f; waves %d"
+      % (c[2] / nw, c[3] / nw, c[4] / nw, c[5] / nw, nw))
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for name, rows in (("full", H), ("half", H // 2), ("quarter", H // 4), ("eighth", H // 8)):
     f = lambda: pkg.cone_trace_svo_band(img, 0, rows, 45.0, view, P.pool.data_ptr, P.center, P.edge, 0)
