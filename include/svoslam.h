@@ -49,6 +49,30 @@ typedef enum {
 
 int svoslam_abi_version(void);
 const char *svoslam_status_string(int status);
+
+/* Library-wide settings (SURVEY section 5 "config / flags": the reference has compile-time constants and one #define,
+ * include/octree_slam/world/svo/svo.h:8).  One struct through the ABI; a process may also preset it with the environment
+ * variable SVOSLAM_CONFIG = "name=value,name=value" (field names below; tools and child-process tests), read once when the
+ * library first needs a setting.  svoslam_config_set takes effect for objects created afterwards (cameras, runners) and for
+ * the next render / fusion call.  -1 = automatic where noted. */
+typedef struct svoslam_config {
+  int32_t march_bricks;     /* 1: reference-mode renders of this library's pools march over occupancy bricks (0: the tree march) */
+  int32_t track_mode;       /* 0: automatic (one launch per frame; its streaming form for large images); 1: the launch chain (two
+                               launches per ICP iteration: several PROCESSES sharing one device); 2: the register-resident one-launch
+                               form forced whatever the image size (tests) */
+  int32_t track_workers;    /* 0: automatic; > 0: cap on the worker workgroups of the one-launch tracker */
+  int32_t track_stream;     /* 1: large images use the streaming one-launch form; 0: coarsest level in one launch, then the chain */
+  int32_t runner_deferred;  /* frame scheduler: deferred commits -1 automatic (on up to 640x480-class images), 0, 1 */
+  int32_t runner_lead;      /* commits the host may run ahead of the device: -1 automatic */
+  int32_t runner_prio;      /* stream priorities (map stream highest): -1 automatic, 0, 1 */
+  int32_t runner_replicas;  /* 1, or 2 map replicas marched alternately (measured slower on one GPU: DESIGN.md) */
+  int32_t runner_timeline;  /* 1: HIP-event marks at the stage boundaries (svoslam_runner_timeline); costs ~6 % */
+  int32_t sort_pairs;       /* 1: force the (key, index) pair sort instead of the packed one-word sort */
+  int32_t graphs;           /* 1: launch sequences recorded and replayed as HIP graphs (0: direct launches, the default) */
+  int32_t reserved[5];
+} svoslam_config;
+int svoslam_config_get(svoslam_config *out);
+int svoslam_config_set(const svoslam_config *in);
 /* last HIP error text seen by the calling thread (empty string if none) */
 const char *svoslam_last_error(void);
 /* name of the device the library runs on, e.g. "gfx950:..."; NULL if none */

@@ -67,6 +67,8 @@ _fp = C.POINTER(C.c_float)
 # name -> (restype, argtypes); this table is also what tests/test_abi_symbols.py checks against include/svoslam.h
 SIGNATURES = {
     "svoslam_abi_version": (C.c_int, []),
+    "svoslam_config_get": (C.c_int, [C.c_void_p]),
+    "svoslam_config_set": (C.c_int, [C.c_void_p]),
     "svoslam_status_string": (C.c_char_p, [C.c_int]),
     "svoslam_last_error": (C.c_char_p, []),
     "svoslam_device_arch": (C.c_char_p, []),
@@ -263,6 +265,38 @@ def _ptr(t):
 def _fa(values, n):
     a = (C.c_float * n)(*[float(v) for v in np.asarray(values, dtype=np.float32).reshape(-1)])
     return a
+
+
+class ConfigStruct(C.Structure):
+    """include/svoslam.h svoslam_config"""
+    _fields_ = [(n, C.c_int32) for n in ("march_bricks", "track_mode", "track_workers", "track_stream", "runner_deferred", "runner_lead",
+                                         "runner_prio", "runner_replicas", "runner_timeline", "sort_pairs", "graphs")] + [("reserved", C.c_int32 * 5)]
+
+
+def get_config():
+    """the library's settings as a dict (include/svoslam.h svoslam_config)"""
+    c = ConfigStruct()
+    check(lib().svoslam_config_get(C.byref(c)))
+    return {n: int(getattr(c, n)) for n, _ in ConfigStruct._fields_ if n != "reserved"}
+
+
+def configure(**settings):
+    """svoslam_config_set: e.g. configure(track_mode=1, graphs=1); takes effect for cameras / runners created afterwards and
+    for the next render / fusion call.  Returns the settings as they were."""
+    c = ConfigStruct()
+    check(lib().svoslam_config_get(C.byref(c)))
+    before = {n: int(getattr(c, n)) for n, _ in ConfigStruct._fields_ if n != "reserved"}
+    for k, v in settings.items():
+        if k not in before:
+            raise KeyError("svoslam_config has no field %r" % (k,))
+        setattr(c, k, int(v))
+    check(lib().svoslam_config_set(C.byref(c)))
+    return before
+
+
+def config_env(**settings):
+    """{"SVOSLAM_CONFIG": "name=value,..."}: the same settings for a child process (read once when its library starts)"""
+    return {"SVOSLAM_CONFIG": ",".join("%s=%d" % (k, int(v)) for k, v in settings.items())}
 
 
 def device_arch():
@@ -661,7 +695,7 @@ class Runner:
         return np.array(list(b), np.float32)
 
     def timeline(self, max_frames=4096):
-        """[frames, 10] stage times in ms of the last run (SVOSLAM_RUNNER_TIMELINE=1)"""
+        """[frames, 10] stage times in ms of the last run (svoslam_config.runner_timeline = 1 when the runner was created)"""
         out = np.full((max_frames, 10), -1.0, np.float32)
         n = _i32(0)
         check(lib().svoslam_runner_timeline(self._h, out.ctypes.data_as(_fp), max_frames, C.byref(n)))

@@ -29,9 +29,6 @@ int ensure_device();
 // own stores wiped.  Every one-off initialisation goes through this (fill, then wait for the null stream).
 inline hipError_t memset_sync(void *p, int value, size_t bytes) {
   const hipError_t e = hipMemset(p, value, bytes);
-#ifdef SVO_MEMSET_NOSYNC  // (to reproduce the hazard)
-  return e;
-#endif
   return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
 }
 

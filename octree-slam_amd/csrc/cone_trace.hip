@@ -112,24 +112,18 @@ __device__ __forceinline__ float sqrt_rn_midrange(float x) {
 // bracket S[bits-1] < t <= S[bits] is CHECKED; a lane whose bracket is not confirmed
 // (extreme centre/size ratios, NaN) falls back to the reference's own chain.  The table
 // holds exactly the floats the chain produces, so the bits are the reference's bits.
-// Two tables: the first 11 or 12 levels live in LDS (25 / 49 KB per workgroup, copied at kernel start) and are
-// consulted every step; the levels below them, down to kTabDepth, come from a global (L2-resident) table only
-// when a walk actually goes that deep.
+// Two tables: the first 11 levels live in LDS (25 KB per workgroup, copied at kernel start) and are consulted every step;
+// the levels below them continue the table by the reference's own chain (walk_deep_chain); a global table down to kTabDepth
+// serves the lanes whose bracket is not confirmed.  (A 12-level LDS table, 49 KB, made a 1920x1080 / depth-14 tree march 8 %
+// shorter on its own and the frame loop 4 % slower -- fewer workgroups of the other stages fit beside it: removed in round 4.)
 constexpr int kTabDepth = 16;                   // == SVOSLAM_MAX_DEPTH: every level a pool of this library can have
 constexpr int kTabCells = 1 << kTabDepth;
 constexpr int kTabStride = kTabCells + 3;       // [-inf, -inf, S[0..2^T-2], +inf, +inf]
-// The LDS table is compiled for 11 and for 12 levels (25 / 49 KB per workgroup); the host picks 11 when the LOD
-// depth at one metre does not exceed it (640x480 at a 4 m half edge), which leaves the LDS to the kernels of the
-// other streams (+3 % frames/s), and 12 otherwise (1920x1080: 2 % faster than 11).
-constexpr int kLdsDepthMax = 12;
+constexpr int kLdsDepthMax = 11;
 constexpr int kLdsStrideMax = (1 << kLdsDepthMax) + 3;
 __host__ __device__ constexpr int lds_cells(int d) { return 1 << d; }
 __host__ __device__ constexpr int lds_stride(int d) { return (1 << d) + 3; }
-constexpr int kTraceThreads = 512;              // 11-level table: 4 workgroups x 8 waves per CU (25 KB of LDS each)
-#ifndef SVO_TRACE_THREADS12
-#define SVO_TRACE_THREADS12 512
-#endif
-constexpr int kTraceThreads12 = SVO_TRACE_THREADS12;  // 12-level table (49 KB)
+constexpr int kTraceThreads = 512;              // 4 workgroups x 8 waves per CU (25 KB of LDS each)
 
 // ---- level grid ------------------------------------------------------------
 // Dense (2^G)^3 array, G = 7 (8 for renders of a megapixel and more), indexed by the first G octant bits of each axis (z, y, x).
@@ -139,10 +133,7 @@ constexpr int kTraceThreads12 = SVO_TRACE_THREADS12;  // 12-level table (49 KB)
 // so the first G dependent loads of the reference become one.  Rebuilt from the pool at the
 // start of every render (the pool is const during it): 16.8 MB, ~9 us.  (G = 6: 2 MB / 5 us build but
 // 9 % more trace time; G = 8: 14 % less trace time but 134 MB / 30 us of build per render.)
-#ifndef SVO_GRID_LEVEL
-#define SVO_GRID_LEVEL 7
-#endif
-constexpr int kGridLevelSmall = SVO_GRID_LEVEL;   // 128^3 cells, 16.8 MB, ~9 us to rebuild
+constexpr int kGridLevelSmall = 7;                // 128^3 cells, 16.8 MB, ~9 us to rebuild
 constexpr int kGridLevelLarge = 8;                // 256^3 cells, 134 MB, ~30 us: pays off when the march itself is long (>= 1 M rays)
 __host__ __device__ constexpr int grid_entries(int g) { return 1 << (3 * g); }
 
@@ -154,10 +145,9 @@ struct TraceParams {
   int row_first, row_end;  // rows [row_first, row_end) are traced (row band of a multi-GPU tile split)
   // lookup helpers (host-computed)
   float lo[3], inv_cell, inv_cell_lds;   // guess of the table cell: (t - lo) * inv_cell
-  int lds_depth;                          // levels of the LDS table of this render (11 or 12)
+  int lds_depth;                          // levels of the LDS table (11)
   int xcd_w, xcd_h;                       // tile -> XCD mapping (see cone_trace_kernel)
   int lod_always;                         // brick march: pix_scale x [0.001, 11 + size] lies inside the fast LOD form's range
-  int xcd_rows;                           // brick march: 1 = the two XCD groups take alternate tile rows (see cone_trace_brick_kernel)
   uint32_t lod_first, lod_span, size_man;  // fast LOD: valid when bits(pix_size) - lod_first <= lod_span
   int size_exp;
 };
@@ -384,9 +374,6 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
                                                          const uint2 *__restrict__ grid, const float *__restrict__ table,
                                                          const float *__restrict__ alpha_lut_g, TraceParams P,
                                                          unsigned long long *__restrict__ counters, unsigned long long *__restrict__ slots) {
-#ifdef SVO_MARCH_PRIO
-  __builtin_amdgcn_s_setprio(SVO_MARCH_PRIO);
-#endif
   __shared__ float alpha_lut[256];
   constexpr int kLdsDepth = LDSD;
   constexpr int kGridLevel = GRID;
@@ -447,16 +434,7 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
     uint32_t oct_val = 0;
     int alpha = 0;
     bool range_exit = false;
-#ifdef SVO_PROF
-    long long pc[5] = {0, 0, 0, 0, 0};
-#define PROF_T(k) { const long long now_ = clock64(); pc[k] += now_ - t_prev; t_prev = now_; }
-#else
-#define PROF_T(k)
-#endif
     for (int step = 0; step < kMaxSteps; step++) {
-#ifdef SVO_PROF
-      long long t_prev = clock64();
-#endif
       my_steps++;
       const float tx = P.origin[0] + rx, ty = P.origin[1] + ry, tz = P.origin[2] + rz;
       const float pix_size = ray_len * P.pix_scale;
@@ -509,7 +487,6 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
         zb = axis_bits_chain(tz, P.center[2], P.size, kLdsDepth);
       }
       asm volatile("" :: "v"(xb), "v"(yb), "v"(zb));
-      PROF_T(0)
       // ---- the walk (:76-105) ----
       // (A per-lane cache of the previous sample's path -- resume at the first level that differs -- was
       // measured: it removes most loads of a lane but not the wavefront's latency, which is set by the one
@@ -531,7 +508,6 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
         if (cell != cell_s) g = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(grid) + (cell << 3));
         w1 = g.y;
         asm volatile("" :: "v"(w1));
-        PROF_T(1)
         if (!(g.x & kFlag)) {
           depth = (int)g.x;  // stopped at the first childless node
         } else if (depth > kGridLevel) {
@@ -564,7 +540,6 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
       my_levels += (uint32_t)(depth > 0 ? depth : 0);  // levels the reference visits == the depth it ends on
       oct_val = w1;
       asm volatile("" :: "v"(w1));
-      PROF_T(2)
 
       // :108 max(0, unsigned) is the (int, unsigned) overload: no clamp, alpha = A - 127 signed
       alpha = (int)((oct_val >> 24) - 127u);
@@ -592,15 +567,8 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
         ray_len = length3(rx, ry, rz);
       }
       asm volatile("" :: "v"(ray_len));
-      PROF_T(3)
       if (ray_len > kMaxRange) { range_exit = true; break; }
     }
-#ifdef SVO_PROF
-    if (counters && lane == 0) {
-      for (int k = 0; k < 4; k++) atomicAdd(&counters[2 + k], (unsigned long long)pc[k]);
-      atomicAdd(&counters[6], (unsigned long long)my_steps);
-    }
-#endif
     if (!CARRY) {  // the pixel of the retiring step, formed from an all-zero pos[index]
       const float af = alpha_lut[alpha + 127];
       vx = f2u8(af * (float)(oct_val & 0xFF));
@@ -693,9 +661,6 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
   constexpr int BL = brick_bits_level(S);                               // level of the per-octant bits
   constexpr int kFine = kCells << S;                                   // cells per axis at the bricks' cell level
   constexpr uint32_t kOrg = brick_window_origin(S);                    // first cell of the window
-#ifdef SVO_BRICK_PRIO
-  __builtin_amdgcn_s_setprio(SVO_BRICK_PRIO);
-#endif
 #ifdef SVO_BRICK_DIAG
   const long long c_entry = clock64();
 #endif
@@ -720,20 +685,14 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
   const long long c_tables = clock64();
 #endif
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  int tile_x, tile_y;  // (tile -> XCD mapping: see cone_trace_kernel)
-  if (P.xcd_w > 0) {
-    const int xcd = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);
-    const int slot_y = slot / P.xcd_w;
-    tile_x = (xcd & 3) * P.xcd_w + (slot - slot_y * P.xcd_w);
-    tile_y = P.xcd_rows ? 2 * slot_y + (xcd >> 2) : (xcd >> 2) * P.xcd_h + slot_y;
-  } else {
-    // Row-major order (the default here): the march is bound by instruction issue, not by its loads, and the long rays
-    // of a frame come in bands of rows (grazing views of the floor, a silhouette) -- with one image region per XCD the
-    // SIMDs of the other regions idle through the tail; dealing consecutive tiles to the eight XCDs spreads it
-    // (640x480, 300-frame map: 0.388 ms with regions, 0.333 with alternate rows per XCD group, 0.324 row-major).
-    tile_y = (int)blockIdx.x / P.xcd_h;
-    tile_x = (int)blockIdx.x - tile_y * P.xcd_h;
-  }
+  // Tiles in row-major order: the march is bound by instruction issue, not by its loads, and the long rays of a frame come in
+  // bands of rows (grazing views of the floor, a silhouette) -- with one image region per XCD (the tree march's mapping) the
+  // SIMDs of the other regions idle through the tail; dealing consecutive tiles to the eight XCDs spreads it (640x480,
+  // 300-frame map: 0.388 ms with regions, 0.333 with alternate rows per XCD group, 0.324 row-major).  (Round 4, measured and
+  // not kept: persistent workgroups taking tiles from a queue -- the LDS tables loaded once per workgroup instead of once per
+  // tile -- gave nothing at 1920x1080: 0.336 against 0.325 ms.)
+  const int tile_y = (int)blockIdx.x / P.xcd_h;  // (xcd_h = tiles per row)
+  const int tile_x = (int)blockIdx.x - tile_y * P.xcd_h;
   const int px = tile_x * 32 + (int)(wave & 3u) * 8 + (int)(lane & 7u);
   const int py = P.row_first + tile_y * (THREADS / 32) + (int)(wave >> 2) * 8 + (int)(lane >> 3);
   uint32_t my_steps = 0, my_levels = 0;
@@ -1084,16 +1043,11 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   P.pix_scale = tanf(fov * 3.14159f / 180.0f) / (float)height;
   P.width = width; P.height = height; P.mode = mode;
   P.row_first = row_first; P.row_end = row_first + rows;
-  P.xcd_rows = 0; P.lod_always = 0;
+  P.lod_always = 0;
   // lookup helpers: the table-cell guess and the operand range of the fast LOD form
   for (int k = 0; k < 3; k++) P.lo[k] = center[k] - size;
   P.inv_cell = (float)kTabCells / (2.0f * size);
-  {  // LDS table depth.  Levels below it continue the table by the reference's chain (walk_deep_chain), so 11 levels
-     // (24 KB) serve every render; the 12-level table (49 KB) makes a 1920x1080 / depth-14 march 8 % shorter on its own
-     // but costs the frame loop 4 % (fewer workgroups of the other stages fit beside it): SVOSLAM_MARCH_LDS_DEPTH=12
-    static const int forced = [] { const char *e = getenv("SVOSLAM_MARCH_LDS_DEPTH"); return e ? atoi(e) : 0; }();
-    P.lds_depth = forced == kLdsDepthMax ? kLdsDepthMax : 11;
-  }
+  P.lds_depth = kLdsDepthMax;
   P.inv_cell_lds = (float)lds_cells(P.lds_depth) / (2.0f * size);
   {
     uint32_t us;
@@ -1129,11 +1083,7 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   DeviceBuffer &accel = sa->buf;
   const std::shared_ptr<PoolAccel> pa_hold = pool_accel_find(d_octree);  // held until the launches below are enqueued
   PoolAccel *pa = pa_hold.get();
-#ifdef SVO_FORCE_GRID8
-  const bool large = true;
-#else
   const bool large = pa != nullptr || (long long)width * rows >= (1ll << 20);  // e.g. 1920x1080 frames
-#endif
   const int own_cells = pa ? 0 : grid_entries(large ? kGridLevelLarge : kGridLevelSmall);
   const size_t accel_bytes = (size_t)own_cells * sizeof(uint2) + (size_t)(3 * (kTabStride + kLdsStrideMax) + 256) * sizeof(float) + 64;
   const void *before = accel.ptr;
@@ -1148,8 +1098,7 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   const bool tables_match = sa->tables_valid && sa->tables_at == d_table && sa->lds_depth == P.lds_depth && sa->size == size &&
                             sa->center[0] == center[0] && sa->center[1] == center[1] && sa->center[2] == center[2];
   if (pa) {
-    // (the brick march is compiled for the 11-level LDS table: SVOSLAM_MARCH_LDS_DEPTH=12 keeps the tree march)
-    SVO_TRY(pool_accel_refresh(pa, d_octree, stream, &d_grid, (mode & 0xFF) == SVOSLAM_RENDER_REFERENCE && P.lds_depth == 11, &d_bricks, &brick_shift));
+    SVO_TRY(pool_accel_refresh(pa, d_octree, stream, &d_grid, (mode & 0xFF) == SVOSLAM_RENDER_REFERENCE, &d_bricks, &brick_shift));
     if (!tables_match) build_tables_kernel<<<(int)cdiv(3 * (kTabStride + kLdsStrideMax) + 256, 256), 256, 0, stream>>>(d_table, alpha_lut, P);
   } else {
     const int build_blocks = (int)cdiv(own_cells + 3 * (kTabStride + kLdsStrideMax) + 256, 256);
@@ -1171,14 +1120,9 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   uchar4 *out = reinterpret_cast<uchar4 *>(d_pos);
   const bool carry = (mode & 0xFF) == SVOSLAM_RENDER_CARRY;
   const bool midrange_size = size >= 9.5367431640625e-07f && size <= 1048576.0f;  // (see cone_trace_kernel: the length recurrence's short forms)
-  if (d_bricks && !carry && P.lds_depth == 11 && midrange_size) {  // a pool of this library in reference mode: the march over occupancy bricks
-    unsigned blocks = xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads / 32));
-    // SVOSLAM_MARCH_XCD: 0 = one image region per XCD, 1 = the two XCD groups take alternate tile rows, 2 (default) = row-major
-    // order (A/B measurements: see the kernel)
-    static const int xcd_mode = [] { const char *e = getenv("SVOSLAM_MARCH_XCD"); return e ? atoi(e) : 2; }();
-    P.xcd_rows = xcd_mode == 1;
-    if (xcd_mode == 2 && P.xcd_w > 0) { P.xcd_w = 0; P.xcd_h = (int)cdiv(width, 32); blocks = cdiv(width, 32) * cdiv(rows, kTraceThreads / 32); }
-    const dim3 grid(blocks);
+  if (d_bricks && !carry && midrange_size) {  // a pool of this library in reference mode: the march over occupancy bricks
+    P.xcd_w = 0; P.xcd_h = (int)cdiv(width, 32);
+    const dim3 grid((unsigned)(cdiv(width, 32) * cdiv(rows, kTraceThreads / 32)));
     auto launch = [&](auto kernel) { kernel<<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps, slots); };
     if (brick_shift == 0) {
       if (P.lod_always) launch(cone_trace_brick_kernel<kTraceThreads, true, 0>);
@@ -1187,22 +1131,14 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
       if (P.lod_always) launch(cone_trace_brick_kernel<kTraceThreads, true, 1>);
       else launch(cone_trace_brick_kernel<kTraceThreads, false, 1>);
     }
-  } else if (P.lds_depth == 11 && large) {
+  } else if (large) {
     const dim3 grid(xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads / 32)));
     if (carry) cone_trace_kernel<true, 11, kTraceThreads, kGridLevelLarge><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
     else cone_trace_kernel<false, 11, kTraceThreads, kGridLevelLarge><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
-  } else if (P.lds_depth == 11) {
+  } else {
     const dim3 grid(xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads / 32)));
     if (carry) cone_trace_kernel<true, 11, kTraceThreads, kGridLevelSmall><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
     else cone_trace_kernel<false, 11, kTraceThreads, kGridLevelSmall><<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
-  } else if (!large) {
-    const dim3 grid(xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads12 / 32)));
-    if (carry) cone_trace_kernel<true, 12, kTraceThreads12, kGridLevelSmall><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
-    else cone_trace_kernel<false, 12, kTraceThreads12, kGridLevelSmall><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
-  } else {
-    const dim3 grid(xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads12 / 32)));
-    if (carry) cone_trace_kernel<true, 12, kTraceThreads12, kGridLevelLarge><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
-    else cone_trace_kernel<false, 12, kTraceThreads12, kGridLevelLarge><<<grid, kTraceThreads12, 0, stream>>>(out, d_octree, d_grid, d_table, alpha_lut, P, d_steps, slots);
   }
   SVO_TRY(stage_end(kStageMarch, stage_token, stream));
   SVO_LAUNCH_CHECK();

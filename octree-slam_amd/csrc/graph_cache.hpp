@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "config.hpp"
 
 namespace svoslam {
 
@@ -34,7 +35,7 @@ struct GraphKey {
 // graphs (2494 against 2380 frames/s at cfg3; no difference at cfg4).  SVOSLAM_GRAPHS=1 turns the replay on -- worth
 // it where the host is the bottleneck (several ranks sharing few cores, the 38-launch chain tracker on a slow host).
 inline bool graphs_enabled() {
-  static const bool on = [] { const char *e = getenv("SVOSLAM_GRAPHS"); return e && e[0] == '1'; }();
+  const bool on = config().graphs != 0;
   return on;
 }
 

@@ -27,6 +27,7 @@
 #include <string.h>
 
 #include "graph_cache.hpp"
+#include "config.hpp"
 #include "icp.hpp"
 #include "icp_device.hpp"
 #include "image_kernels.hpp"
@@ -46,10 +47,7 @@ constexpr int kIcpThreads = 512;   // 8 wavefronts per workgroup
 constexpr int kIcpWaves = kIcpThreads / kWave;
 // workgroups of an accumulate launch (cap).  cfg4 (1080p, launch chain with work maps), frames/s on one box, means of 3:
 // 256 -> 768, 384 -> 790, 512 -> 771 (before the work maps: 256 -> 721, 512 -> 735, 1024 -> 696, 2048 -> 637)
-#ifndef SVO_ICP_BLOCKS
-#define SVO_ICP_BLOCKS 384
-#endif
-constexpr int kMaxIcpBlocks = SVO_ICP_BLOCKS;
+constexpr int kMaxIcpBlocks = 384;
 
 
 // Body of the accumulate kernel.  The 27 sums of a lane are reduced across the wavefront in registers
@@ -205,10 +203,7 @@ __global__ __launch_bounds__(kIcpThreads) void rgbd_accumulate_kernel(
 
 // column sums of partial[rows][27] into LDS totals[27] (exact integer-valued sums);
 // blockDim.x / 32 row groups x 32 columns, all loads of a thread independent (<= 8 rows each)
-#ifndef SVO_REDUCE_THREADS
-#define SVO_REDUCE_THREADS 1024
-#endif
-constexpr int kReduceThreads = SVO_REDUCE_THREADS;  // (256, a workgroup that fits wherever one march workgroup has left: cfg4 769 -> 745 frames/s)
+constexpr int kReduceThreads = 1024;  // (256, a workgroup that fits wherever one march workgroup has left: cfg4 769 -> 745 frames/s)
 __device__ inline void reduce_rows(const double *__restrict__ partial, int rows, double (*red)[27], double *totals) {
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5, ngrp = blockDim.x >> 5;
   double s = 0.0;
@@ -457,53 +452,6 @@ __global__ __launch_bounds__(kReduceThreads) void cam_reduce_solve_kernel(CamSta
   iteration_tail_wave(st, totals, slot, flags, tail_sm, pre, partial2 ? totals2 : nullptr);
 }
 
-// The launch chain's iteration in ONE launch (round 3): accumulate over work maps, and the workgroup that finishes LAST sums
-// the rows, solves and composes (what cam_reduce_solve_kernel does in a launch of its own: 14 us + a launch boundary, fifteen
-// times per 1920x1080 frame).  Hand-off as in mip_straddle2_kernel (cdna_hip_programming.md Guideline 16): rows stored
-// write-through at agent scope, every wave drains, one lane takes the ticket; the last arriver acquires and reads the rows with
-// agent-scope loads.  CamState is read by every workgroup at its start and written by the tail only after all of them have
-// taken their ticket; the next launch sees it behind the kernel boundary.  Same sums (integer-valued, order-free), same tail.
-__global__ __launch_bounds__(kIcpThreads) void icp_accumulate_work_solve_kernel(
-    const float *__restrict__ last_v, const float *__restrict__ last_n, const float *cur_v, const float *cur_n, int first, int end,
-    CamState *st, int flags, int chain_len, int chain_first, float *work_v, float *work_n, double *partial, int slot,
-    unsigned *__restrict__ ticket) {
-  SVO_HIGH_PRIO();
-  __shared__ double wsum[kIcpWaves][27];
-  __shared__ float chain_s[(kMaxChain + 1) * 16];
-  __shared__ double red[kIcpThreads / 32][27];
-  __shared__ double totals[27];
-  __shared__ float tail_sm[kTailScratch];
-  __shared__ int is_last;
-  accumulate_block<true, true>(last_v, last_n, cur_v, cur_n, first, end, st, flags, chain_len, partial, wsum, chain_s, chain_first, work_v, work_n);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // this workgroup's row (and its work-map stores) have left the CU
-  if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
-  __syncthreads();
-  if (!is_last) return;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-  }
-  __syncthreads();
-  const TailPrefetch pre = tail_prefetch(st, flags);  // written by the previous launch
-  {  // reduce_rows() with agent-scope loads
-    const int rows = (int)gridDim.x, col = threadIdx.x & 31, grp = threadIdx.x >> 5, ngrp = kIcpThreads >> 5;
-    double sacc = 0.0;
-    if (col < 27)
-      for (int r = grp; r < rows; r += ngrp) sacc += __hip_atomic_load(&partial[(size_t)r * 27 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (col < 27) red[grp][col] = sacc;
-    __syncthreads();
-    if (threadIdx.x < 27) {
-      double t = 0.0;
-      for (int g = 0; g < ngrp; g++) t += red[g][threadIdx.x];
-      totals[threadIdx.x] = t;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x >= 64) return;  // the tail runs on the first wavefront
-  iteration_tail_wave(st, totals, slot, flags, tail_sm, pre, nullptr);
-}
-
 // multi-GPU iteration tail: acc[] holds the all-reduced sums
 __global__ void cam_solve_kernel(CamState *st, double *acc, int slot, int flags) {
   SVO_HIGH_PRIO();
@@ -601,7 +549,6 @@ struct svoslam_camera {
   svoslam::TrackSync *d_sync = nullptr;
   double *d_rows = nullptr;
   unsigned *d_tickets = nullptr;
-  unsigned *d_chain_ticket = nullptr;  // arrival count of icp_accumulate_work_solve_kernel (zero between launches)
   hipStream_t cap_stream = nullptr;  // stream whose resident-workgroup capacity is cached below
   int capacity = 0;
   bool delta_fed = false;  // poses come from camera_apply_delta: there are no maps of the previous frame to track against
@@ -640,7 +587,6 @@ int camera_create(svoslam_camera **out, int w, int h, float fx, float fy) {
   SVO_HIP(hipMalloc((void **)&c->d_partial, (size_t)kMaxIcpBlocks * 27 * sizeof(double)));
   SVO_HIP(hipMalloc((void **)&c->d_sync, sizeof(TrackSync)));
   SVO_HIP(hipMalloc((void **)&c->d_tickets, track_persistent_ticket_bytes()));
-  SVO_HIP(hipMalloc((void **)&c->d_chain_ticket, 64));
   SVO_HIP(hipMalloc((void **)&c->d_rows, (size_t)(kTrkMaxWorkers + 1) * 27 * sizeof(double)));
   c->d_acc = c->d_state->acc;
   const int rc = camera_reset(c);
@@ -665,7 +611,6 @@ int camera_reset(svoslam_camera *c) {
   SVO_HIP(hipMemcpy(c->d_state, &init, sizeof(init), hipMemcpyHostToDevice));
   SVO_HIP(memset_sync(c->d_sync, 0, sizeof(TrackSync)));
   SVO_HIP(memset_sync(c->d_tickets, 0, track_persistent_ticket_bytes()));
-  SVO_HIP(memset_sync(c->d_chain_ticket, 0, 64));
   c->have_stamp = false; c->latest_stamp = 0;
   c->prepared = 0; c->tracked = 0;
   c->frame_has_icp = false;
@@ -696,7 +641,6 @@ int camera_destroy(svoslam_camera *c) {
   if (c->d_partial2) (void)hipFree(c->d_partial2);
   if (c->d_sync) (void)hipFree(c->d_sync);
   if (c->d_tickets) (void)hipFree(c->d_tickets);
-  if (c->d_chain_ticket) (void)hipFree(c->d_chain_ticket);
   if (c->d_rows) (void)hipFree(c->d_rows);
   if (c->work_v) (void)hipFree(c->work_v);
   if (c->work_n) (void)hipFree(c->work_n);
@@ -821,39 +765,19 @@ int camera_end(svoslam_camera *c, hipStream_t s) {
   return SVOSLAM_OK;
 }
 
-// Pose of the oldest prepared frame.  Default: ONE launch for the 19 iterations (track_persistent.hip).
-// SVOSLAM_TRACK_CHAIN=1 selects the launch chain instead -- two launches per ICP iteration (accumulate; reduce +
-// solve + compose), recorded once per map set and replayed as one graph; same bits, ~2x the time.  (Measured and
-// dropped in round 1 for the chain: the last-arriving workgroup solving behind an agent-scope release/acquire, and
-// every workgroup finishing the previous iteration redundantly.)
-static bool track_chain_forced() {
-  static const bool on = [] { const char *e = getenv("SVOSLAM_TRACK_CHAIN"); return e && e[0] == '1'; }();
-  return on;
-}
-
-static bool track_one_launch_forced() {
-  static const bool on = [] { const char *e = getenv("SVOSLAM_TRACK_ONE_LAUNCH"); return e && e[0] == '1'; }();
-  return on;
-}
-
-// > 0: the image is too large for the register-resident form (1920x1080: 16 pixels per lane at the finest level, which
-// would be re-read from HBM every iteration inside the one launch: measured 525 frames/s against 718 with the chain)
-// SVOSLAM_TRACK_HYBRID=0|1|2: coarse pyramid levels a LARGE image (whose finest level does not fit the registers) still
-// runs in the one launch before the launch chain takes over (track_persistent_plan_coarse)
-static int track_hybrid_levels() {
-  static const int v = [] { const char *e = getenv("SVOSLAM_TRACK_HYBRID"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
-  return v;
-}
-
-// Large images (1920x1080: the finest level does not fit the registers) run all 19 iterations in the STREAMING one-launch form
-// (track_persistent.hip: coarsest level in registers, the finer ones through the work maps) -- the default since round 4: with
-// the march over bricks the frame no longer loses what this form's residency takes (cfg4 811 -> 893 frames/s; round 3, beside
-// the tree march: 810 -> 690).  SVOSLAM_TRACK_STREAM=0: the hybrid of round 3 (coarsest level in the one launch, then the
-// launch chain).
-static bool track_stream_enabled() {
-  static const bool on = [] { const char *e = getenv("SVOSLAM_TRACK_STREAM"); return !(e && e[0] == '0'); }();
-  return on;
-}
+// Pose of the oldest prepared frame.  Default: ONE launch for the 19 iterations (track_persistent.hip): the register-resident
+// form up to 640x480-class images, the STREAMING form (coarsest level in registers, the finer ones through the work maps) for
+// large ones -- the default since round 4: with the march over bricks the frame no longer loses what this form's residency
+// takes (cfg4 811 -> 893 frames/s; round 3, beside the tree march: 810 -> 690).  svoslam_config.track_mode = 1 selects the
+// launch chain -- two launches per ICP iteration (accumulate over work maps; reduce + solve + compose); same bits, ~2x the
+// time at 640x480 -- for several processes sharing one device; track_stream = 0: large images run their coarsest level in the
+// one launch and the finer ones by the chain (round 3's hybrid).  (Built, bit-exact, measured and removed: accumulate + reduce
+// + solve of a chain iteration in one launch by its last-arriving workgroup -- cfg4 815-819 against 809-811 frames/s, the
+// tracker alone 0.666 against 0.620 ms; the two coarsest levels in the one launch, 1.29-1.36 against 1.16 ms; the chain
+// replaying the whole transform chain from the raw maps instead of work maps, 714 against 768 frames/s.)
+static bool track_chain_forced() { return config().track_mode == 1; }
+static bool track_one_launch_forced() { return config().track_mode == 2; }
+static bool track_stream_enabled() { return config().track_stream != 0; }
 
 // returns 0: the whole frame was enqueued; 1: nothing was (caller: launch chain from level 2); 2 + l: levels 2 .. l + 1 were
 // enqueued in the one launch, the launch chain continues at level l
@@ -890,11 +814,9 @@ static int track_one_launch(svoslam_camera *c, hipStream_t s) {
     }
   }
   if (A.slots[0] > kTrkSlots && !track_one_launch_forced()) {
-    const int hybrid = track_hybrid_levels();
-    if (hybrid == 0) return 1;  // caller: the launch chain for every level
-    SVO_TRY(track_persistent_plan_coarse(A, c->capacity, hybrid));
+    SVO_TRY(track_persistent_plan_coarse(A, c->capacity, 1));
     SVO_TRY(track_persistent_launch(c->d_state, c->d_sync, c->d_tickets, c->d_rows, A, s));
-    return 2 + (2 - hybrid);     // the chain continues at level 2 - hybrid
+    return 2 + 1;                // the chain continues at level 1
   }
   return track_persistent_launch(c->d_state, c->d_sync, c->d_tickets, c->d_rows, A, s);
 }
@@ -917,18 +839,14 @@ int camera_track(svoslam_camera *c, hipStream_t s) {
     }
     if (rc >= 2) top_level = rc - 2;  // hybrid: the coarser levels are already enqueued
   }
-  // Work maps (default; SVOSLAM_TRACK_WORKMAPS=0 replays the chain from the raw maps in every iteration): allocated on
-  // the first chain-tracked frame (cameras served by the one-launch tracker never pay for them), before any capture
-  static const bool work_maps = [] { const char *e = getenv("SVOSLAM_TRACK_WORKMAPS"); return !(e && e[0] == '0'); }();
-  if (has_icp && work_maps && !c->work_v) {
+  // Work maps: allocated on the first chain-tracked frame (cameras served by the one-launch tracker never pay for them),
+  // before any capture
+  const bool work_maps = true;
+  if (has_icp && !c->work_v) {
     const size_t n = (size_t)c->width * (size_t)c->height;
     SVO_HIP(hipMalloc((void **)&c->work_v, n * 12));
     SVO_HIP(hipMalloc((void **)&c->work_n, n * 12));
   }
-  // SVOSLAM_TRACK_FUSED_TAIL=1: accumulate + reduce + solve in ONE launch per iteration (icp_accumulate_work_solve_kernel).  Built,
-  // bit-exact, and no better: cfg4 815-819 frames/s against 809-811 in the loop, and the tracker ALONE 0.666 ms against 0.620 --
-  // the last arriver's acquire + agent-scope row loads cost what the launch boundary did.  Opt-in.
-  static const bool fused_tail = [] { const char *e = getenv("SVOSLAM_TRACK_FUSED_TAIL"); return e && e[0] == '1'; }();
   GraphKey key;
   key.add((unsigned long long)(c->tracked % 3u)).add((unsigned long long)has_icp)
      .add((unsigned long long)c->band_first).add((unsigned long long)c->band_rows).add((unsigned long long)c->rgbd)
@@ -949,12 +867,6 @@ int camera_track(svoslam_camera *c, hipStream_t s) {
             // iteration it > 0 reads what iteration it - 1 stored (level start and chain[0 .. it - 1) applied) and applies
             // chain[it - 1]; the last iteration of a level stores nothing
             const bool store = it + 1 < kPyramidIters[level];
-            if (fused_tail && !c->rgbd) {  // accumulate + reduce + solve in one launch
-              icp_accumulate_work_solve_kernel<<<blocks, kIcpThreads, 0, s>>>(a.lv, a.ln, it ? c->work_v : a.cv, it ? c->work_n : a.cn, a.first, end,
-                                                                              c->d_state, flags, it, it, store ? c->work_v : nullptr,
-                                                                              store ? c->work_n : nullptr, c->d_partial, it, c->d_chain_ticket);
-              continue;
-            }
             icp_accumulate_work_kernel<<<blocks, kIcpThreads, 0, s>>>(a.lv, a.ln, it ? c->work_v : a.cv, it ? c->work_n : a.cn, a.first, end,
                                                                       c->d_state, flags, it, it, store ? c->work_v : nullptr,
                                                                       store ? c->work_n : nullptr, c->d_partial);

@@ -4,6 +4,7 @@
 #include <memory>
 #include <mutex>
 
+#include "config.hpp"
 #include "pool_grid.hpp"
 
 namespace svoslam {
@@ -571,11 +572,8 @@ __global__ __launch_bounds__(kBrickThreads) void pool_refresh_kernel(const uint3
   brick_rebuild_listed<C, S>(nodes, grid, bricks, touched, dirty_a, dirty_b, r, bb * kWaves + wave, brick_blocks * kWaves, lane, trust_mip != 0);
 }
 
-// SVOSLAM_MARCH_BRICKS=0: no occupancy bricks (the march walks the tree below the level grid, as in round 2)
-static bool bricks_enabled() {
-  static const bool on = [] { const char *e = getenv("SVOSLAM_MARCH_BRICKS"); return !(e && e[0] == '0'); }();
-  return on;
-}
+// svoslam_config.march_bricks = 0: no occupancy bricks (the march walks the tree below the level grid, as in round 2)
+static bool bricks_enabled() { return config().march_bricks != 0; }
 
 // The field is 16 GiB of the 288 GB, allocated by the first reference-mode render of a pool.  It is only taken when it leaves
 // room: after it, at least twice its size must stay free for pool growth, shadow words and the caller's own
@@ -643,9 +641,7 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
   // the rings' marks alternate per state and refresh (kBrickMarkOffset)
   const int par_a = serve_idx[0] >= 0 ? (int)(pa->brick_served[serve_idx[0]] & 1u) : 0, par_b = serve_idx[1] >= 0 ? (int)(pa->brick_served[serve_idx[1]] & 1u) : 0;
   if (use_bricks) {
-    // SVOSLAM_BRICK_TRUST_MIP=0: the rebuild reads every tile of the bits level whatever the pool's history (A/B measurements)
-    static const bool trust_on = [] { const char *e = getenv("SVOSLAM_BRICK_TRUST_MIP"); return !(e && e[0] == '0'); }();
-    const int trust = trust_on && pa->mip_consistent ? 1 : 0;
+    const int trust = pa->mip_consistent ? 1 : 0;  // (PoolAccel::mip_consistent: rebuild 65 -> 39 us at cfg3)
     if (bricks_all) {
       if (fresh) pool_grid_build_kernel<<<(unsigned)(kCells / 256), 256, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
       else pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1]);

@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "config.hpp"
 #include "../../include/svoslam.h"
 
 namespace {
@@ -62,17 +63,15 @@ struct svoslam_runner {
   hipEvent_t ev_begin = nullptr, ev_end[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t last_caller = nullptr;
   int lead = -1;  // commits the host may run ahead of the device (see svoslam_runner_run); < 0: the schedule's default (1 deferred, 2 in place)
-  bool fused_front = false;  // back-projection + bounding box + keys in one launch (SVOSLAM_RUNNER_FUSED_FRONT=0: the four stand-alone calls)
-  bool early_split = true;  // SVOSLAM_RUNNER_EARLY_SPLIT=0: split_all_kernel inside the commit
+  bool fused_front = false;  // back-projection + bounding box + keys in one launch (keys that do not fit the packed word: the stand-alone calls)
+  bool early_split = true;  // split_all_kernel right behind the plan, beside the previous frame's march
   // one replica: the commit of frame k+1 is computed during the march of frame k (svoslam_svo_fuse_commit_deferred).  Default
   // since round 3 for images up to 640x480-class: the march over occupancy bricks is bound by instruction issue and no
   // longer by the loads the commit competes for (cfg3, 300-frame map: 1862 -> 2055 frames/s; the driver's 20 frames 1565 ->
-  // 1707; cfg4, where the launch-chain tracker bounds the frame, 815 -> 694: off there).  SVOSLAM_RUNNER_DEFERRED=0 / 1 overrides.
+  // 1707; cfg4, where the launch-chain tracker bounds the frame, 815 -> 694: off there).  svoslam_config.runner_deferred = 0 / 1 overrides.
   bool deferred = false, deferred_explicit = false;
   bool ran = false;
-  // SVOSLAM_RUNNER_TIMELINE=1: timing events at the stage boundaries of the last call (svoslam_runner_timeline)
-  bool maps_on_track_stream = false;  // SVOSLAM_RUNNER_MAPS_STREAM=0: maps of a frame right before its ICP on stream T (saves an
-                                      // event record and two waits per frame; measured equal within noise, 2360-2435 frames/s)
+  // svoslam_config.runner_timeline = 1: timing events at the stage boundaries of the last call (svoslam_runner_timeline)
   bool timeline = false;
   std::vector<hipEvent_t> tl_events;
   int tl_frames = 0;
@@ -107,25 +106,17 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
   r->cam = cam; r->pool = pool; r->w = width; r->h = height; r->depth = max_depth; r->mode = render_mode;
   for (int k = 0; k < 3; k++) r->center[k] = center[k];
   r->edge = edge_length; r->fx = fx; r->fy = fy;
-  const char *e = getenv("SVOSLAM_RUNNER_REPLICAS");
-  r->replicas = (e && e[0] == '2') ? 2 : 1;
-  const char *ms = getenv("SVOSLAM_RUNNER_MAPS_STREAM");
-  r->maps_on_track_stream = ms && ms[0] == '0';
-  const char *tl = getenv("SVOSLAM_RUNNER_TIMELINE");
-  r->timeline = tl && tl[0] == '1';
-  const char *df = getenv("SVOSLAM_RUNNER_DEFERRED");
-  r->deferred_explicit = df != nullptr;
-  r->deferred = df ? df[0] == '1' : ((long long)width * height <= 400000ll && r->replicas == 1);
+  const svoslam_config cfg = svoslam::config();  // (settings are taken when the runner is created)
+  r->replicas = cfg.runner_replicas == 2 ? 2 : 1;
+  r->timeline = cfg.runner_timeline != 0;
+  r->deferred_explicit = cfg.runner_deferred >= 0;
+  r->deferred = cfg.runner_deferred >= 0 ? cfg.runner_deferred == 1 : ((long long)width * height <= 400000ll && r->replicas == 1);
   {
     int idx_bits = 1;
     while ((1ll << idx_bits) < (long long)width * height) idx_bits++;
-    const char *ff = getenv("SVOSLAM_RUNNER_FUSED_FRONT"), *sp = getenv("SVOSLAM_SORT_PAIRS");
-    r->fused_front = 3 * max_depth + 1 + idx_bits <= 64 && !(ff && ff[0] == '0') && !(sp && sp[0] == '1');
+    r->fused_front = 3 * max_depth + 1 + idx_bits <= 64 && cfg.sort_pairs == 0;
   }
-  const char *es = getenv("SVOSLAM_RUNNER_EARLY_SPLIT");
-  r->early_split = !(es && es[0] == '0');
-  const char *ld = getenv("SVOSLAM_RUNNER_LEAD");
-  if (ld) r->lead = atoi(ld) < 0 ? 0 : atoi(ld);
+  if (cfg.runner_lead >= 0) r->lead = cfg.runner_lead;
   *out = r;
   const size_t n = (size_t)width * height;
   {
@@ -133,21 +124,15 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
     // and sort on the lowest.  Measured (means of 6 / 3 runs): cfg3 over the driver's 20 frames 2690 -> 2795 frames/s with
     // half the run-to-run spread, 100 and 300 frames and a rank of 8 unchanged, cfg4 748 -> 733 (there the launch-chain
     // tracker is level with the map stream and loses what the map stream gains).  Default: on for images up to 640x480-class
-    // (the one-launch tracker's domain); SVOSLAM_RUNNER_PRIO=0 / 1 overrides.
-    const char *pe = getenv("SVOSLAM_RUNNER_PRIO");
+    // (the one-launch tracker's domain); svoslam_config.runner_prio = 0 / 1 overrides.  (Measured and not kept: the tracker
+    // first -- cfg4 769 -> 774, within the noise --, the front-end stream raised: the slow steady state more often.)
     int least = 0, greatest = 0;
     const bool small = (long long)width * height <= 400000ll;
-    const bool want = pe ? pe[0] != '0' : small;
-    // '2' (large images, where the launch-chain tracker bounds the frame): tracker first, map stream second -- cfg4 769 -> 774
-    // frames/s (means of 3, within the noise), '1' there 761: left off
-    const bool tracker_first = pe && pe[0] == '2';
+    const bool want = cfg.runner_prio >= 0 ? cfg.runner_prio != 0 : small;
     const bool prio = want && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
     hipStream_t *ss[5] = {&r->s_maps, &r->s_track, &r->s_prep, &r->s_map[0], &r->s_map[1]};
     const int mid = (least + greatest) / 2;
-    // '3' / '4': the front end + sort + plan stream on the highest / the middle priority as well (round 3: with the brick march
-    // that stream's 15 short launches are the chain the frame period follows; A/B in DESIGN.md section 4)
-    const int prep_pr = (pe && pe[0] == '3') ? greatest : (pe && pe[0] == '4') ? mid : least;
-    const int pr[5] = {least, tracker_first ? greatest : mid, prep_pr, tracker_first ? mid : greatest, tracker_first ? mid : greatest};
+    const int pr[5] = {least, mid, least, greatest, greatest};
     for (int k = 0; k < 5; k++) {
       if (prio) SVO_HIP(hipStreamCreateWithPriority(ss[k], hipStreamNonBlocking, pr[k]));
       else SVO_HIP(hipStreamCreateWithFlags(ss[k], hipStreamNonBlocking));
@@ -250,7 +235,7 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
   hipEvent_t *ev_maps = r->events.data(), *ev_pose = ev_maps + n, *ev_bp = ev_pose + n, *ev_plan = ev_bp + n;
   hipEvent_t *ev_commit[2] = {ev_plan + n, ev_plan + 2 * (size_t)n};
   hipEvent_t *ev_ray = ev_plan + 3 * (size_t)n;
-  static const bool serial_marches = [] { const char *e = getenv("SVOSLAM_RUNNER_CONCURRENT_MARCHES"); return !(e && e[0] == '1'); }();
+  const bool serial_marches = true;  // (two replicas: their marches one after the other)
   std::vector<const float *> fusion_ptr((size_t)n, nullptr);
   r->ran = true; r->last_caller = cur;
   if (r->timeline) {
@@ -266,8 +251,7 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
   hipStream_t all[5] = {r->s_maps, r->s_track, r->s_prep, r->s_map[0], r->s_map[1]};
   for (hipStream_t s : all) SVO_HIP(hipStreamWaitEvent(s, r->ev_begin, 0));
 
-  static const bool staged = [] { const char *e = getenv("SVOSLAM_GRAPHS"); return e && e[0] == '1'; }();
-  const bool one_stream = r->maps_on_track_stream && !sharded;
+  const bool staged = svoslam::config().graphs != 0;  // graphs are keyed on pointers: frames are staged through fixed buffers
   // frame-sharded ranks that march at most one frame in three plan on the map stream (see enqueue_commit)
   bool plan_on_map = false;
   // ... or, by default, run the STRUCTURE CHAIN (svoslam_svo_fuse_plan_structure): a plan reads structure words only, so
@@ -281,14 +265,13 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
     int marched = 0;
     for (int i = 0; i < n; i++) marched += march[i] ? 1 : 0;
     plan_on_map = 3 * marched <= n;
-    static const bool chain_on = [] { const char *e = getenv("SVOSLAM_RUNNER_STRUCTURE_CHAIN"); return !(e && e[0] == '0'); }();
-    if (plan_on_map && chain_on && R == 1 && !deferred) { chain = true; plan_on_map = false; }
+    if (plan_on_map && R == 1 && !deferred) { chain = true; plan_on_map = false; }
   }
   if (chain) SVO_TRY(svoslam_pool_structure_begin(r->pool, r->s_prep));
-  hipStream_t s_maps = one_stream ? r->s_track : r->s_maps;
+  hipStream_t s_maps = r->s_maps;
   auto enqueue_maps = [&](int i) -> int {  // bilateral filter + pyramids of frame i (no dependence on earlier poses)
     if (sharded) return SVOSLAM_OK;  // tracked elsewhere: this camera only composes poses
-    if (!one_stream && i >= 2) SVO_HIP(hipStreamWaitEvent(s_maps, ev_pose[i - 2], 0));  // its map set was the "last" set of frame i-2
+    if (i >= 2) SVO_HIP(hipStreamWaitEvent(s_maps, ev_pose[i - 2], 0));  // its map set was the "last" set of frame i-2
     mark(i, 0, s_maps);
     // fixed input addresses only where the library replays recorded launch sequences (graphs are keyed on pointers);
     // the caller's frames stay valid for the whole call (its stream is joined at the end)
@@ -296,13 +279,13 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
     int32_t used = 0;
     SVO_TRY(svoslam_camera_prepare(r->cam, staged ? r->in_track : d_depths[i], d_rgbs[i], timestamps[i], &used, s_maps));
     if (!used) return SVOSLAM_ERR_INVALID_ARG;  // cannot happen after the validation above
-    if (!one_stream) SVO_HIP(hipEventRecord(ev_maps[i], s_maps));
+    SVO_HIP(hipEventRecord(ev_maps[i], s_maps));
     mark(i, 1, s_maps);
     return SVOSLAM_OK;
   };
   auto enqueue_track = [&](int i) -> int {
     if (i >= 4) SVO_HIP(hipStreamWaitEvent(r->s_track, ev_bp[i - 4], 0));  // ring slot i % 4 has been consumed
-    if (!one_stream && !sharded) SVO_HIP(hipStreamWaitEvent(r->s_track, ev_maps[i], 0));
+    if (!sharded) SVO_HIP(hipStreamWaitEvent(r->s_track, ev_maps[i], 0));
     if (sharded) { mark(i, 0, r->s_track); mark(i, 1, r->s_track); }  // (no maps here; keeps the timeline's origin)
     mark(i, 2, r->s_track);
     if (sharded) {

@@ -32,6 +32,7 @@
 
 #include "radix_sort.hpp"
 #include "image_device.hpp"
+#include "config.hpp"
 #include "pool_grid.hpp"
 #include "svo_build.hpp"
 #include "stage_timing.hpp"
@@ -239,13 +240,8 @@ __device__ inline u32 bucket_id(int p, int d) { return (u32)(p * 16 + (d - 1)); 
 // contiguous eighth of the Morton-ordered keys, i.e. a compact part of the tree and of the colour image, per XCD and L2 --
 // was built and A/B-measured (round 2): kernel durations in the sequential form within 3 % (leaf kernel 34.0 / 33.9 us,
 // plan_emit 10.8 / 11.0, plan_count 9.5 / 10.5), frames/s within run-to-run noise.  The plain order stays the default.
-#ifdef SVO_XCD_TILES  // the measured variant (build with SVOSLAM_EXTRA_HIPCC_FLAGS=-DSVO_XCD_TILES)
-__host__ __device__ inline int xcd_grid(int tiles) { return 8 * ((tiles + 7) / 8); }
-__device__ inline int xcd_tile(int tiles) { return (int)(blockIdx.x & 7u) * ((tiles + 7) / 8) + (int)(blockIdx.x >> 3); }
-#else
 __host__ __device__ inline int xcd_grid(int tiles) { return tiles; }
 __device__ inline int xcd_tile(int tiles) { (void)tiles; return (int)blockIdx.x; }
-#endif
 
 // Plan tiles are 512 sorted keys (8 wavefronts): half the [bucket][tile] counters of 256-key tiles to write,
 // scan and read back.  (1024-key tiles: same frames/s within noise, and a 16-wavefront workgroup is the hardest to place
@@ -621,17 +617,9 @@ __global__ void mip_root_kernel(u32 *__restrict__ pool, const PlanCounts *__rest
 // that handles those "straddlers" deepest level first.  Same values as the level-by-level passes.
 constexpr u32 kNoStraddler = 0xFFFFFFFFu;
 
-#ifndef SVO_FILL_THREADS
-#define SVO_FILL_THREADS 512
-#endif
-constexpr int kFillThreads = SVO_FILL_THREADS;  // leaves per workgroup.  Larger: fewer straddlers for the single-workgroup second launch;
+constexpr int kFillThreads = 512;  // leaves per workgroup.  Larger: fewer straddlers for the single-workgroup second launch;
 // smaller: more workgroups resident next to the tracker's (which pin 150 CUs).  Measured at cfg3, fill + straddle us:
 // 1024 -> 54 + 20, 512 -> 45 + 23, 256 -> 37 + 32; 2418 / 2481 / 2477 frames/s.
-#ifdef SVO_FILL_PROF
-#define FILL_STAMP(k) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[k] = wall_clock64(); }
-#else
-#define FILL_STAMP(k)
-#endif
 template <int MAXD>  // levels a lane keeps in registers: 12 for pools of depth <= 12 (57 VGPRs: four workgroups per CU), 16 otherwise (65: three)
 __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 *__restrict__ skey, const u32 *__restrict__ sidx, int n,
                                                              int depth, const unsigned char *__restrict__ leaf_t,
@@ -653,10 +641,6 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   __shared__ int next_pos, next_c;                   // first head lane after this workgroup and its common-prefix length
   __shared__ int min_c;                              // smallest common-prefix length of a head of this tile (99: no head)
   const int tid = (int)threadIdx.x;
-#ifdef SVO_FILL_PROF
-  unsigned long long stamp[8];
-  FILL_STAMP(0)
-#endif
   const int bid = xcd_tile(num_tiles);  // this workgroup's tile of the sorted keys
   if (bid >= num_tiles) return;
   const int j = bid * kFillThreads + tid;
@@ -744,7 +728,6 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
     __syncthreads();
     if (tid == 0) { strad_bc[2 * bid] = next_c; strad_bc[2 * bid + 1] = min_c; }
   }
-  FILL_STAMP(1)
   // early_links != 0: the child tiles of this commit were initialised ahead of it (svo_fuse_split_early: split_all_kernel
   // without its links, while the previous frame was still being ray-marched); the links of the pass-0 records -- the only
   // words of the split a ray march can see -- are written HERE, by the first head under each frontier node, and the walk
@@ -827,17 +810,14 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
         }
       }
     }
-    FILL_STAMP(2)
     const u32 word = blend_color256(pool[2 * (size_t)node + 1], cr, cg, cb);
     if (shadow) shadow_store(shadow, epoch, node, word);
     else pool[2 * (size_t)node + 1] = word;
     node_at[0] = node;  // (slot 0 is free: the root is not a lane's node)
   }
   if (shadow && j < n) apply_nodes[(size_t)(depth - 1) * n + j] = head ? node_at[0] : kNoStraddler;
-  FILL_STAMP(3)
   __syncthreads();
   if (brick_mine) brick_ring_store(grid_dirty, brick_base + brick_off, brick_entry);
-  FILL_STAMP(4)
 #pragma unroll
   for (int d = MAXD - 1; d >= 1; d--) {
     if (d < depth) {
@@ -862,22 +842,10 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   // the sibling ring (see above).  At the END of the kernel: a divergent returning atomic between the barriers of the set-up left
   // the wavefront's lanes apart at the ballots that follow there (test_async_fusion_long_runs_of_duplicates_and_invalid_points)
   if (brick_mine && lt != kNoSplit && (int)lt < brick_node_level(brick_shift)) brick_sibling_list(grid_dirty, brick_entry);
-#ifdef SVO_FILL_PROF
-  FILL_STAMP(5)
-  if (tid == 0 && (bid % 37) == 0)
-    printf("fillprof wg %d of %d: start %llu setup %llu descent %llu leaf %llu sync %llu mip %llu (x10 ns)\n", bid, num_tiles,
-           stamp[0] % 100000000ull, stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4]);
-#endif
 }
 
 // straddling nodes deepest level first, then the root quirk (Q6) and the device-side size
-#ifndef SVO_STRAD_THREADS
-#define SVO_STRAD_THREADS 1024
-#endif
-#ifndef SVO_STRAD_SLOTS
-#define SVO_STRAD_SLOTS 8
-#endif
-constexpr int kStradThreads = SVO_STRAD_THREADS;
+constexpr int kStradThreads = 1024;
 __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__restrict__ pool, const u32 *__restrict__ strad, int num_tiles,
                                                             int depth, const PlanCounts *__restrict__ counts,
                                                             int *__restrict__ d_size, u32 *__restrict__ grid_dirty,
@@ -893,7 +861,7 @@ __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__rest
   // a thread's list entries do not depend on the levels below, so those of the next level are fetched while
   // this level's tiles are averaged (one dependent load per level instead of two); kSlots entries per thread
   // in registers cover 8192 workgroups (2 M points: 1920x1080), longer lists fall back to the plain loop
-  constexpr int kSlots = SVO_STRAD_SLOTS;
+  constexpr int kSlots = 8;
   const uint2 *list = reinterpret_cast<const uint2 *>(strad);
   const bool fits = num_tiles <= kSlots * kStradThreads;
   uint2 cur[kSlots], nxt[kSlots];
@@ -1501,11 +1469,8 @@ static int packed_idx_bits(int n) {
   while ((1ll << b) < (long long)n) b++;
   return b;
 }
-// SVOSLAM_SORT_PAIRS=1: the (key, index) pair sort of round 1 for every fusion (A/B measurements, tests)
-static bool sort_pairs_forced() {
-  static const bool on = [] { const char *e = getenv("SVOSLAM_SORT_PAIRS"); return e && e[0] == '1'; }();
-  return on;
-}
+// svoslam_config.sort_pairs = 1: the (key, index) pair sort of round 1 for every fusion (tests)
+static bool sort_pairs_forced() { return config().sort_pairs != 0; }
 
 // buffers of the asynchronous phases (plan + commit) for a batch of n sorted keys
 static int reserve_async(svoslam_workspace *ws, int n, int depth) {
@@ -1847,12 +1812,8 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   u32 *strad = sb.as<u32>();
   int *strad_bc = reinterpret_cast<int *>(strad + strad_words);
   u32 *sstrad = strad + strad_words + bc_words;
-  // SVOSLAM_STRADDLE=1: the single-workgroup pass of round 2 (A/B measurements); deferred commits always use it
-  static const bool one_wg = [] { const char *e = getenv("SVOSLAM_STRADDLE"); return e && e[0] == '1'; }();
-  const bool two_tier = !deferred && !one_wg;
-  // SVOSLAM_FILL_RESUME=0: the leaf kernel walks every path from the root as in round 2 (A/B measurements)
-  static const bool resume = [] { const char *e = getenv("SVOSLAM_FILL_RESUME"); return !(e && e[0] == '0'); }();
-  const u32 *leaf_start = resume ? ws->leaf_start.as<u32>() : nullptr;
+  const bool two_tier = !deferred;  // (deferred commits keep the single-workgroup straddler pass: its list doubles as the apply list)
+  const u32 *leaf_start = ws->leaf_start.as<u32>();  // the leaf kernel resumes the plan's walk (round 3: -8 us)
   SVO_TRY(ensure_device_size(pool, stream));         // (creates the size tracker)
   PoolTracker *trk = tracker_of(pool);
   unsigned long long *shadow = nullptr;

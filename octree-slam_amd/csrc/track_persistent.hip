@@ -29,6 +29,7 @@
 #include <map>
 #include <mutex>
 
+#include "config.hpp"
 #include "track_persistent.hpp"
 
 namespace svoslam {
@@ -163,9 +164,7 @@ struct PixelSet {  // one lane's pixels of the current level
 // 12 floats of one pixel pair, as loaded (streaming levels: software-pipelined one pixel ahead)
 struct PixelRaw { float v1[3], n1[3], v2[3], n2[3]; };
 
-#ifndef SVO_TRK_MIN_WAVES
-#define SVO_TRK_MIN_WAVES 2
-#endif
+constexpr int kTrkMinWaves = 2;
 // SLOTS = pixels of a level a lane may keep in registers; MINW = minimum wavefronts per SIMD the register budget allows.
 // <kTrkSlots, 2, false>: images whose finest level fits the registers (up to 640x480-class: 4 pixels per lane on <= 247 workers,
 // ~220 VGPRs: one workgroup per CU).  <2, kTrkStreamMinWaves, true> (round 3): LARGE images -- only the coarsest level is register-resident, the
@@ -175,9 +174,7 @@ struct PixelRaw { float v1[3], n1[3], v2[3], n2[3]; };
 // current one is used.  <= 128 VGPRs, so its workgroups find room beside the march's instead of needing empty CUs.
 template <int SLOTS, int MINW, bool STREAM>
 __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(CamState *st, TrackSync *sy, unsigned *tickets, double *rows, TrackArgs A) {
-#ifndef SVO_TRK_NO_PRIO
   SVO_HIGH_PRIO();
-#endif
   __shared__ double wsum[16][27];          // workers: per-(wave, half) term sums; solver: row-group sums
   __shared__ __attribute__((aligned(16))) float rows_s[kTrkWaves * 64 * kRowFloats];  // one 32-byte row per pixel in flight
   __shared__ double totals[27];
@@ -455,9 +452,9 @@ __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(Cam
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------
-static int env_int(const char *name, int dflt) {
-  const char *e = getenv(name);
-  return (e && e[0]) ? atoi(e) : dflt;
+static int worker_cap(int dflt) {  // svoslam_config.track_workers: 0 = the form's own default
+  const int v = config().track_workers;
+  return v > 0 ? v : dflt;
 }
 
 int track_persistent_capacity(hipStream_t s, int *max_workgroups, int variant) {
@@ -474,7 +471,7 @@ int track_persistent_capacity(hipStream_t s, int *max_workgroups, int variant) {
     if (it == per_cu_of.end()) {
       int n = 0;
       if (variant) SVO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, track_persistent_kernel<kTrkStreamSlots, kTrkStreamMinWaves, true>, kTrkThreads, 0));
-      else SVO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, track_persistent_kernel<kTrkSlots, SVO_TRK_MIN_WAVES, false>, kTrkThreads, 0));
+      else SVO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, track_persistent_kernel<kTrkSlots, kTrkMinWaves, false>, kTrkThreads, 0));
       it = per_cu_of.emplace(dev, n).first;
     }
     per_cu = it->second;
@@ -501,10 +498,10 @@ int track_persistent_capacity(hipStream_t s, int *max_workgroups, int variant) {
 int track_persistent_plan_coarse(TrackArgs &A, int capacity, int coarse_levels) {
   if (coarse_levels < 1 || coarse_levels > 2) return SVOSLAM_ERR_INVALID_ARG;
   const int finest = 3 - coarse_levels;  // finest level handled here (2 or 1)
-  int cap = env_int("SVOSLAM_TRACK_WORKERS", kTrkMaxWorkers);
+  int cap = worker_cap(kTrkMaxWorkers);
   if (cap > capacity - 1) cap = capacity - 1;
   if (cap < 1) return SVOSLAM_ERR_INVALID_ARG;
-  const int slots_target = env_int("SVOSLAM_TRACK_SLOTS", kTrkSlots);
+  const int slots_target = kTrkSlots;
   long long W = 1;
   for (int l = 2; l >= 0; l--) {
     if (l < finest) { A.participants[l] = 0; A.slots[l] = 0; A.iters[l] = 0; continue; }
@@ -533,7 +530,7 @@ int track_persistent_plan_stream(TrackArgs &A, int capacity) {
   // 176 workers: the form is bound by bandwidth, not by CUs, and what it leaves free the march and the fusion use -- cfg4 with
   // the brick march, frames/s by worker count (one box, medians of 3): 64 -> 542, 96 -> 707, 128 -> 835, 160 -> 881, 176 -> 893,
   // 192 -> 884, 208 -> 865, 224 -> 773, 255 -> 790; the launch chain 811
-  int cap = env_int("SVOSLAM_TRACK_WORKERS", 176);
+  int cap = worker_cap(176);
   if (cap > capacity - 1) cap = capacity - 1;
   if (cap < 1) return SVOSLAM_ERR_INVALID_ARG;
   long long W = 1;
@@ -555,8 +552,8 @@ int track_persistent_plan_stream(TrackArgs &A, int capacity) {
 int track_persistent_plan(TrackArgs &A, int capacity) {
   // workers: the finest level decides (kTrkSlots pixels per lane); coarser levels use as many of them as give a lane
   // two pixels.  All workers take part in the finest (last) level.
-  const int slots_target = env_int("SVOSLAM_TRACK_SLOTS", kTrkSlots);
-  int cap = env_int("SVOSLAM_TRACK_WORKERS", kTrkMaxWorkers);
+  const int slots_target = kTrkSlots;
+  int cap = worker_cap(kTrkMaxWorkers);
   if (cap > capacity - 1) cap = capacity - 1;
   if (cap < 1) return SVOSLAM_ERR_INVALID_ARG;
   const long long n0 = A.level[0].end > A.level[0].first ? (long long)A.level[0].end - A.level[0].first : 0;
@@ -603,11 +600,8 @@ int track_persistent_launch(CamState *st, TrackSync *sy, unsigned *tickets, doub
   DevChain &dc = chain_of[dev];
   if (!dc.ev) SVO_HIP(hipEventCreateWithFlags(&dc.ev, hipEventDisableTiming));
   if (dc.used && dc.last != s) SVO_HIP(hipStreamWaitEvent(s, dc.ev, 0));  // the previous launch (any stream) has finished
-  // SVOSLAM_TRACK_STREAM_WAVES=2: the streaming form with the full register budget (no spills, but one workgroup per CU)
-  static const bool wide = [] { const char *e = getenv("SVOSLAM_TRACK_STREAM_WAVES"); return e && e[0] == '2'; }();
-  if (A.variant && wide) track_persistent_kernel<kTrkStreamSlots, 2, true><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, tickets, rows, A);
-  else if (A.variant) track_persistent_kernel<kTrkStreamSlots, kTrkStreamMinWaves, true><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, tickets, rows, A);
-  else track_persistent_kernel<kTrkSlots, SVO_TRK_MIN_WAVES, false><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, tickets, rows, A);
+  if (A.variant) track_persistent_kernel<kTrkStreamSlots, kTrkStreamMinWaves, true><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, tickets, rows, A);
+  else track_persistent_kernel<kTrkSlots, kTrkMinWaves, false><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, tickets, rows, A);
   SVO_LAUNCH_CHECK();
   SVO_HIP(hipEventRecord(dc.ev, s));
   dc.last = s; dc.used = true;

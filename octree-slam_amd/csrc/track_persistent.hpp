@@ -7,10 +7,7 @@ namespace svoslam {
 struct CamState;
 
 constexpr int kTrkThreads = 512;     // 8 wavefronts, 2 per SIMD: up to 256 VGPRs for the register-resident pixels
-#ifndef SVO_TRK_SLOTS
-#define SVO_TRK_SLOTS 4
-#endif
-constexpr int kTrkSlots = SVO_TRK_SLOTS;  // pixels of a level a lane may keep in registers (x 12 floats)
+constexpr int kTrkSlots = 4;  // pixels of a level a lane may keep in registers (x 12 floats)
 constexpr int kTrkMaxWorkers = 247;  // + the solver workgroup <= one per CU on an idle device
 
 // words shared between the workgroups of one launch; zeroed (with the arrival counters, two banks of which the solver
@@ -35,10 +32,7 @@ struct TrackArgs {
   int corrected = 0;     // the corrected tracker (icp_device.hpp icp_rot_rows)
 };
 constexpr int kTrkStreamSlots = 2;
-#ifndef SVO_TRK_STREAM_MIN_WAVES
-#define SVO_TRK_STREAM_MIN_WAVES 3
-#endif
-constexpr int kTrkStreamMinWaves = SVO_TRK_STREAM_MIN_WAVES;
+constexpr int kTrkStreamMinWaves = 3;
 
 int track_persistent_capacity(hipStream_t s, int *max_workgroups, int variant = 0);
 int track_persistent_plan_stream(TrackArgs &A, int capacity);  // large images: coarsest level in registers, finer levels streamed through work maps

@@ -321,7 +321,7 @@ class SlamPipeline:
             idx_bits = max(1, (width * height - 1).bit_length())
             # (the merge kernel takes at most 16 lists, svoslam_svo_fuse_merge_sorted; a forced pair sort has no packed word to export)
             self.band_keys = (os.environ.get("SVOSLAM_BAND_FUSION", "keys") != "points" and 3 * max_depth + 1 + idx_bits <= 64
-                              and self.dist.world <= 16 and os.environ.get("SVOSLAM_SORT_PAIRS") != "1")
+                              and self.dist.world <= 16 and pkg.get_config()["sort_pairs"] == 0)
             if self.band_keys:
                 self.ws_band = pkg.Workspace()
                 base, rem = divmod(height, self.dist.world)

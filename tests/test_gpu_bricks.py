@@ -190,5 +190,5 @@ print("RESULT" + json.dumps(out))
         assert r.returncode == 0, r.stderr[-2000:]
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0][6:])
     base = run({})
-    assert run({"SVOSLAM_MARCH_BRICKS": "0"}) == base
+    assert run({"SVOSLAM_CONFIG": "march_bricks=0"}) == base
     assert base[-1][1] > 8 and base[0][1][0] > 0

@@ -116,7 +116,7 @@ def test_corrected_pipeline_frames_match_oracle(env, oracle):
 
 
 def test_corrected_tracker_launch_chain_in_subprocess(oracle):
-    """the launch-chain form (SVOSLAM_TRACK_CHAIN=1, child process) in corrected mode against the oracle's poses"""
+    """the launch-chain form (svoslam_config.track_mode = 1, child process) in corrected mode against the oracle's poses"""
     import svoslam_pkg
     svoslam_pkg.load()
     synth = importlib.import_module("octree_slam_amd.synth")
@@ -148,7 +148,7 @@ for k in range(n):
     out.append([p.view(np.uint32).tolist(), o.view(np.uint32).tolist()])
 print("RESULT" + json.dumps(out))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SVOSLAM_TRACK_CHAIN="1"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SVOSLAM_CONFIG="track_mode=1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0]
     assert json.loads(line[6:]) == want

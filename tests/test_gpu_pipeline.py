@@ -238,8 +238,8 @@ def test_native_runner_equals_sequential(env, capacity, band):
 
 
 def test_graph_replay_and_chain_tracker_in_subprocess(env):
-    """HIP-graph replay of the launch sequences (SVOSLAM_GRAPHS=1; off by default since round 2) together with the
-    launch-chain tracker (SVOSLAM_TRACK_CHAIN=1), in a child process: same final image, pool and pose as the default
+    """HIP-graph replay of the launch sequences (svoslam_config.graphs = 1; off by default since round 2) together with the
+    launch-chain tracker (track_mode = 1), in a child process (settings through SVOSLAM_CONFIG): same final image, pool and pose as the default
     (direct launches, one-launch tracker) in this process"""
     import hashlib
     import json
@@ -265,24 +265,22 @@ sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 print("RESULT" + json.dumps([sha(P.image.cpu().numpy()), sha(P.pool.words()), sha(P.cam.pose()[1]), int(P.pool.size)]))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     def run(extra):
-        e = dict(os.environ, **extra)
+        e = dict(os.environ, **pkg.config_env(**extra))
         r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0][6:])
     base = run({})
-    assert run({"SVOSLAM_GRAPHS": "1", "SVOSLAM_TRACK_CHAIN": "1"}) == base
-    assert run({"SVOSLAM_GRAPHS": "1"}) == base
-    # launch chain by direct launches: with its work maps (default: iteration it applies one matrix to what iteration
-    # it - 1 stored) and with the replay of the whole transform chain from the raw maps
-    assert run({"SVOSLAM_TRACK_CHAIN": "1"}) == base
-    assert run({"SVOSLAM_TRACK_CHAIN": "1", "SVOSLAM_TRACK_WORKMAPS": "0"}) == base
+    assert run(dict(graphs=1, track_mode=1)) == base
+    assert run(dict(graphs=1)) == base
+    # launch chain by direct launches (work maps: iteration it applies one matrix to what iteration it - 1 stored)
+    assert run(dict(track_mode=1)) == base
     # the scheduler with deferred commits (commit of frame k+1 computed beside the march of frame k, then applied: the
     # default at this image size since round 3) and with in-place commits; with and without the occupancy bricks
-    assert run({"SVOSLAM_RUNNER_DEFERRED": "1"}) == base
-    assert run({"SVOSLAM_RUNNER_DEFERRED": "1", "SVOSLAM_RUNNER_LEAD": "0"}) == base
-    assert run({"SVOSLAM_RUNNER_DEFERRED": "0"}) == base
-    assert run({"SVOSLAM_RUNNER_DEFERRED": "0", "SVOSLAM_MARCH_BRICKS": "0"}) == base
-    assert run({"SVOSLAM_MARCH_BRICKS": "0"}) == base
+    assert run(dict(runner_deferred=1)) == base
+    assert run(dict(runner_deferred=1, runner_lead=0)) == base
+    assert run(dict(runner_deferred=0)) == base
+    assert run(dict(runner_deferred=0, march_bricks=0)) == base
+    assert run(dict(march_bricks=0)) == base
     assert base[3] > 8
 
 

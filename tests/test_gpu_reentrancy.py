@@ -124,12 +124,12 @@ def test_pool_replicas_commit_to(env, oracle):
         pkg.svo_fuse_commit_to(ws, dev[3][1], depth, A, 0, False)
 
 
-@pytest.mark.parametrize("replicas", ["2", "1"])
+@pytest.mark.parametrize("replicas", [2, 1])
 def test_runner_replicas_and_validation(env, replicas):
     """the scheduler with two map replicas (opt-in) and with one (default): final image, pool, pose, counters of the sequential
     loop; a call with bad timestamps is refused BEFORE anything is enqueued and leaves the runner usable"""
     pkg, torch, synth, pl = env
-    os.environ["SVOSLAM_RUNNER_REPLICAS"] = replicas
+    before = pkg.configure(runner_replicas=replicas)     # (taken when the runner is created)
     try:
         w, h, depth, center, edge, n = 160, 120, 8, (0.0, 1.5, 0.0), 4.096, 13
         frames = [synth.render_frame(k, w, h, device="cuda") for k in range(n)]
@@ -153,7 +153,7 @@ def test_runner_replicas_and_validation(env, replicas):
         assert np.array_equal(A.cam.pose()[0], B.cam.pose()[0]) and np.array_equal(A.cam.pose()[1], B.cam.pose()[1])
         assert A.counters.tolist() == B.counters.tolist()
     finally:
-        del os.environ["SVOSLAM_RUNNER_REPLICAS"]
+        pkg.configure(**before)
 
 
 def test_obj_loader_refuses_bad_indices(env, tmp_path):

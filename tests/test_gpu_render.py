@@ -150,35 +150,3 @@ def test_render_megapixel_uses_the_level8_grid(env, oracle):
     view = oracle.look_at((0.5, 1.0, -11.0), (0, 0, 0), (0, 1, 0))
     render_both(pkg, torch, oracle, pool, opool.words(), 960, 1100, view, center, edge, 0)
 
-
-def test_render_with_the_12_level_lds_table_in_subprocess(env, oracle):
-    """SVOSLAM_MARCH_LDS_DEPTH=12 (the 49 KB table, two chained levels at depth 14) in a child process: the same bytes
-    as the default 11-level table in this process, which is checked against the oracle"""
-    import hashlib
-    import subprocess
-    import sys
-    pkg, torch = env
-    center, edge = (0.0, 0.0, 0.0), 8.192
-    ws, pool, opool = build_pool(pkg, torch, oracle, 14, 2, n=20000, edge=edge, center=center, scale=5.0)
-    view = oracle.look_at((1.0, 0.5, 2.6), (0.5, -1.0, -1.5), (0, 1, 0))
-    got = render_both(pkg, torch, oracle, pool, opool.words(), 40, 1100, view, center, edge, 1)
-    want = hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest()
-    words_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "svoslam_lds12_words.npy")
-    np.save(words_path, np.asarray(opool.words(), np.uint32))
-    code = r'''
-import sys, hashlib, numpy as np, torch
-sys.path.insert(0, %r)
-import svoslam_pkg
-pkg = svoslam_pkg.load()
-words = torch.from_numpy(np.load(%r).view(np.int32)).cuda()
-img = torch.full((1100, 40, 4), 7, dtype=torch.uint8, device="cuda")
-pkg.cone_trace_svo(img, 45.0, np.array(%r, np.float32), words.data_ptr(), %r, %r, 1)
-torch.cuda.synchronize()
-print("RESULT" + hashlib.sha256(np.ascontiguousarray(img.cpu().numpy()).tobytes()).hexdigest())
-''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), words_path, [float(x) for x in np.asarray(view).reshape(-1)],
-       tuple(center), edge)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SVOSLAM_MARCH_LDS_DEPTH="12"), capture_output=True, text=True,
-                       timeout=600)
-    os.remove(words_path)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0][6:] == want

@@ -378,7 +378,7 @@ for k in range(n):
     out.append([p.view(np.uint32).tolist(), o.view(np.uint32).tolist()])
 print("RESULT" + json.dumps(out))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SVOSLAM_TRACK_ONE_LAUNCH="1", SVOSLAM_TRACK_WORKERS="4")
+    env = dict(os.environ, SVOSLAM_CONFIG="track_mode=2,track_workers=4")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0]

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Regenerates the measurement records of a round on an MI355X box:  bash tools/prof/profile_round.sh r03 [quick]
+# Regenerates the measurement records of a round on an MI355X box:  bash tools/prof/profile_round.sh r04 [quick]
 # Everything lands in gpurun_out/<tag>/ (scratch); the files worth judging are then copied to profiles/.
 # Counter passes use the SEQUENTIAL form of the bench (--no-overlap, launch-chain tracker): counter collection serialises
 # dispatches, which would deadlock the multi-stream pipeline; per-kernel traffic does not depend on the overlap.  Only
 # the library's kernels are counted (--kernel-include-regex svoslam: the torch kernels that generate the synthetic
 # stream made the round-2 passes run into their timeouts).  A failed pass FAILS the script (no `|| echo`).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 QUICK=${2:-}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT="$R/gpurun_out/$TAG"; mkdir -p "$OUT"
@@ -19,15 +19,15 @@ fail() { echo "FAILED: $*"; FAILED=1; }
 
 echo "== PMC FETCH_SIZE / WRITE_SIZE per kernel (separate passes)"
 PM=${P}_pmc_fetch_write_per_kernel.txt
-echo "# rocprofv3 --pmc <counter> --kernel-include-regex svoslam --kernel-trace -- python bench.py --workload W --no-overlap ... (SVOSLAM_TRACK_CHAIN=1); one counter per pass; KB per dispatch, all dispatches" > $PM
+echo "# rocprofv3 --pmc <counter> --kernel-include-regex svoslam --kernel-trace -- python bench.py --workload W --no-overlap ... (SVOSLAM_CONFIG=track_mode=1); one counter per pass; KB per dispatch, all dispatches" > $PM
 declare -A FR TI ARGS
-FR[cfg3]=300; TI[cfg3]=10; ARGS[cfg3]="--steps 10 --warmup 2 --map-frames 300"
-FR[cfg4]=20;  TI[cfg4]=10; ARGS[cfg4]="--steps 10 --warmup 10 --map-frames 0"
+FR[cfg3]=300; TI[cfg3]=10; ARGS[cfg3]="--steps 10 --warmup 2 --map-frames 300 --repeats 1"
+FR[cfg4]=20;  TI[cfg4]=10; ARGS[cfg4]="--steps 10 --warmup 10 --map-frames 0 --repeats 1"
 SPECS=""
 for W in cfg3 cfg4; do
   for c in FETCH_SIZE WRITE_SIZE; do
     D=$SCR/pm_${W}_$c; rm -rf $D; mkdir -p $D
-    SVOSLAM_TRACK_CHAIN=1 timeout 900 rocprofv3 --pmc $c --kernel-include-regex svoslam --kernel-trace --output-format csv -d $D -o p -- \
+    SVOSLAM_CONFIG=track_mode=1 timeout 900 rocprofv3 --pmc $c --kernel-include-regex svoslam --kernel-trace --output-format csv -d $D -o p -- \
       python $R/bench.py --workload $W ${ARGS[$W]} --no-overlap --no-cpu-baseline --allow-missing-traffic > $SCR/pm_${W}_$c.log 2>&1 || fail "pmc pass $W $c (tail: $(tail -2 $SCR/pm_${W}_$c.log))"
     f=$(find $D -name "*counter_collection.csv" | sort | tail -1)
     [ -n "$f" ] || fail "pmc pass $W $c left no counter_collection.csv"
@@ -44,21 +44,21 @@ for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
 PY
   done
   SPEC="$W:${FR[$W]}:${TI[$W]}:$SCR/${W}_FETCH_SIZE.csv:$SCR/${W}_WRITE_SIZE.csv"
-  if [ $W = cfg3 ]; then   # the one-launch tracker, on its own (the bench pass above runs the launch chain)
-    for c in FETCH_SIZE WRITE_SIZE; do
-      D=$SCR/pt_$c; rm -rf $D; mkdir -p $D
-      timeout 300 rocprofv3 --pmc $c --kernel-include-regex track_persistent --kernel-trace --output-format csv -d $D -o p -- \
-        python $R/tools/prof/track_only.py 12 > $SCR/pt_$c.log 2>&1 || fail "pmc pass one-launch tracker $c"
-      f=$(find $D -name "*counter_collection.csv" | sort | tail -1)
-      [ -n "$f" ] || fail "tracker pass $c left no csv"
-      cp "$f" $SCR/trk_$c.csv
-      python3 -c "
+  # the one-launch tracker (cfg4: its streaming form), on its own (the bench pass above runs the launch chain)
+  NT=12; [ $W = cfg4 ] && NT=6
+  for c in FETCH_SIZE WRITE_SIZE; do
+    D=$SCR/pt_${W}_$c; rm -rf $D; mkdir -p $D
+    timeout 300 rocprofv3 --pmc $c --kernel-include-regex track_persistent --kernel-trace --output-format csv -d $D -o p -- \
+      python $R/tools/prof/track_only.py $NT $W > $SCR/pt_${W}_$c.log 2>&1 || fail "pmc pass one-launch tracker $W $c"
+    f=$(find $D -name "*counter_collection.csv" | sort | tail -1)
+    [ -n "$f" ] || fail "tracker pass $W $c left no csv"
+    cp "$f" $SCR/trk_${W}_$c.csv
+    python3 -c "
 import csv,sys
 v=[float(r['Counter_Value']) for r in csv.DictReader(open('$f')) if r['Counter_Name']=='$c']
-print('cfg3,$c,svoslam::track_persistent_kernel (tools/prof/track_only.py 12),calls=%d,mean=%.1f,total=%.1f'%(len(v),sum(v)/max(1,len(v)),sum(v)))" >> $PM
-    done
-    SPEC="$SPEC:$SCR/trk_FETCH_SIZE.csv:$SCR/trk_WRITE_SIZE.csv:11"
-  fi
+print('$W,$c,svoslam::track_persistent_kernel (tools/prof/track_only.py $NT $W),calls=%d,mean=%.1f,total=%.1f'%(len(v),sum(v)/max(1,len(v)),sum(v)))" >> $PM
+  done
+  SPEC="$SPEC:$SCR/trk_${W}_FETCH_SIZE.csv:$SCR/trk_${W}_WRITE_SIZE.csv:$((NT-1))"
   SPECS="$SPECS $SPEC"
 done
 python3 $R/tools/prof/pmc_to_json.py "$OUT/pmc_traffic.json" $TAG $SPECS || fail "pmc_to_json"
@@ -100,7 +100,7 @@ done
 
 echo "== kernel stats (rocprofv3 --kernel-trace --stats) of the bench"
 for W in cfg3 cfg4; do
-  A="--steps 20 --warmup 5"; [ $W = cfg4 ] && A="--workload cfg4 --steps 40 --warmup 5"
+  A="--steps 20 --warmup 5 --repeats 1 --no-corrected-line"; [ $W = cfg4 ] && A="--workload cfg4 --steps 40 --warmup 5 --repeats 1 --no-corrected-line"
   D=$SCR/ks_$W; rm -rf $D; mkdir -p $D
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o k -- python $R/bench.py $A --no-cpu-baseline > $SCR/ks_$W.log 2>&1 || fail "kernel stats $W"
   f=$(find $D -name "*kernel_stats.csv" | sort | tail -1)
@@ -129,10 +129,12 @@ done
 
 if [ -z "$QUICK" ]; then
 echo "== A/B records of the round's switches (same box): occupancy bricks, deferred commits, tile order of the brick march"
-SVOSLAM_MARCH_BRICKS=0 python $R/bench.py --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_ab_bricks_off.json
-SVOSLAM_RUNNER_DEFERRED=0 python $R/bench.py --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_ab_inplace_commits.json
-SVOSLAM_MARCH_BRICKS=0 SVOSLAM_RUNNER_DEFERRED=0 python $R/bench.py --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_ab_round2_march_and_schedule.json
-SVOSLAM_MARCH_XCD=0 python $R/bench.py --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_ab_march_xcd_regions.json
+SVOSLAM_CONFIG=march_bricks=0 python $R/bench.py --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_ab_bricks_off.json
+SVOSLAM_CONFIG=runner_deferred=0 python $R/bench.py --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_ab_inplace_commits.json
+SVOSLAM_CONFIG=march_bricks=0,runner_deferred=0 python $R/bench.py --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_ab_round2_march_and_schedule.json
+SVOSLAM_CONFIG=march_bricks=0 python $R/bench.py --workload cfg4 --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg4_ab_bricks_off.json
+SVOSLAM_CONFIG=track_stream=0 python $R/bench.py --workload cfg4 --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg4_ab_chain_tracker.json
+python $R/bench.py --tracker corrected --no-cpu-baseline 2>/dev/null | line > ${P}_bench_cfg3_corrected_tracker.json
 for f in ${P}_bench_cfg3_ab_*.json; do python3 -c "import json,sys,os; d=json.load(open('$f')); print('%-60s %8.1f fps  march %.3f ms' % (os.path.basename('$f'), d['value'], d['roofline_stages'][0]['kernel_ms']))"; done
 echo "== brick march anatomy (diag variant of the library: -DSVO_BRICK_DIAG, built by tools/prof/build_diag_variant.sh)"
 if [ -f $R/octree-slam_amd/_variants/libsvoslam_hip_diag.so ]; then

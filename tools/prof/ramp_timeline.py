@@ -2,7 +2,7 @@
 HIP-event marks of those 20 (ms from the first mark), to see what the cold start of the timed region costs"""
 import sys, os, numpy as np, torch, importlib, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-os.environ["SVOSLAM_RUNNER_TIMELINE"] = "1"
+os.environ["SVOSLAM_CONFIG"] = "runner_timeline=1"
 import svoslam_pkg
 pkg = svoslam_pkg.load()
 synth = importlib.import_module("octree_slam_amd.synth")

@@ -1,7 +1,7 @@
 import sys, os, numpy as np, torch, importlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-os.environ["SVOSLAM_RUNNER_TIMELINE"] = "1"
+os.environ["SVOSLAM_CONFIG"] = "runner_timeline=1"
 import svoslam_pkg
 pkg = svoslam_pkg.load()
 synth = importlib.import_module("octree_slam_amd.synth")

@@ -7,8 +7,8 @@ OUT="$R/gpurun_out/state"; mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
 for lead in ${LEADS:-1 4}; do
   S=/tmp/st$lead; rm -rf $S; mkdir -p $S
-  SVOSLAM_RUNNER_LEAD=$lead timeout 600 rocprofv3 --kernel-trace --output-format csv -d $S -o k -- python $R/bench.py --no-cpu-baseline --no-stage-pass "$@" > $OUT/bench_lead$lead.log 2>&1
-  grep '^{"metric"' $OUT/bench_lead$lead.log | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('# SVOSLAM_RUNNER_LEAD=$lead under rocprofv3 --kernel-trace:', round(d['value'],1), 'frames/s')" | tee $OUT/rate_lead$lead.txt
+  SVOSLAM_CONFIG=runner_lead=$lead timeout 600 rocprofv3 --kernel-trace --output-format csv -d $S -o k -- python $R/bench.py --no-cpu-baseline --no-stage-pass "$@" > $OUT/bench_lead$lead.log 2>&1
+  grep '^{"metric"' $OUT/bench_lead$lead.log | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('# runner_lead=$lead under rocprofv3 --kernel-trace:', round(d['value'],1), 'frames/s')" | tee $OUT/rate_lead$lead.txt
   t=$(find $S -name "*kernel_trace.csv" | head -1)
   cp $OUT/rate_lead$lead.txt $OUT/frames_lead$lead.txt
   python3 - $t <<'PY' >> $OUT/frames_lead$lead.txt
