@@ -355,7 +355,9 @@ def main():
             import torch.distributed as tdist
             tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         st, lv = (int(x) for x in P.counters.cpu().tolist())
-        rec = {"elapsed": float(t.item()), "steps": st, "levels": lv, "march": pkg.stage_timing_read(pkg.STAGE_MARCH),
+        runner_ = getattr(P, "_runner", None)
+        rec = {"timeline": runner_.timeline() if (args.stages and runner_ is not None and not args.no_overlap) else None,
+               "elapsed": float(t.item()), "steps": st, "levels": lv, "march": pkg.stage_timing_read(pkg.STAGE_MARCH),
                "tracker": pkg.stage_timing_read(pkg.STAGE_TRACKER),
                "marches": P.marched_last_call if getattr(P, "frame_sharded", False) else total - first}
         pkg.stage_timing([])
@@ -559,9 +561,8 @@ def main():
         roofline.update({"steps_per_launch": steps / marches, "levels_per_launch": levels / marches})
     # stage durations from the scheduler's HIP-event marks (mean over the timed frames; stages overlap across streams)
     stages = None
-    runner = getattr(P, "_runner", None)
-    if runner is not None and not args.no_overlap and args.stages:
-        tl = runner.timeline()
+    if med.get("timeline") is not None:
+        tl = med["timeline"]            # (of the median window)
         if len(tl) == K and K > 8:
             a = tl[4:-2]
             stages = {"maps_ms": float((a[:, 1] - a[:, 0]).mean()), "tracker_ms": float((a[:, 3] - a[:, 2]).mean()),
