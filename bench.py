@@ -570,6 +570,28 @@ def main():
                       "commit_ms": float((a[:, 8] - a[:, 7]).mean()), "accel_build_plus_march_ms": float((a[:, 9] - a[:, 8]).mean()),
                       "frame_period_ms": float(np.diff(a[:, 9]).mean()),
                       "frame_latency_ms_maps_begin_to_march_end": float((a[:, 9] - a[:, 0]).mean())}
+    # ---- frame latency (a SLAM consumer cares): the multi-stream schedule trades latency for rate.  One more
+    # window on a pipeline whose runner records HIP-event marks at the stage boundaries (the marks cost ~6 % of the rate, which
+    # is why the timed windows above run without them); mean over its frames of first map kernel -> end of the frame's march.
+    latency = None
+    if single and not args.no_overlap and not args.stages and not args.include_h2d and K > 8:
+        try:
+            before = pkg.configure(runner_timeline=1)
+            cur["P"] = pl.SlamPipeline(width, height, max_depth, center, edge, render_mode=mode, count_steps=True, strict_reference=strict,
+                                       pool_capacity_nodes=(1 << 30) - 8)
+            pkg.configure(**before)
+            timed_window(t0w)
+            tl = cur["P"]._runner.timeline()
+            if len(tl) == K:
+                a = tl[4:-2]
+                latency = {"frame_latency_ms": float((a[:, 9] - a[:, 0]).mean()), "frame_period_ms_with_marks": float(np.diff(a[:, 9]).mean()),
+                           "what": "first map kernel of a frame to the end of its march, mean over the timed frames of one extra window with "
+                                   "stage marks on (svoslam_config.runner_timeline)"}
+        except Exception as e:
+            latency = {"frame_latency_ms": None, "error": repr(e)}
+        finally:
+            pkg.configure(runner_timeline=0)
+        cur["P"] = P
     # ---- single GPU, reference tracker: the same windows once more with the CORRECTED tracker, as a labelled second measurement
     # (with it the stream exercises alpha saturation, ray retirement through the bricks' A >= 254 bits,
     # fusion dominated by read-modify-writes of existing leaves).  Never `value`.
@@ -656,6 +678,8 @@ def main():
             out["other_partition"] = other
         if corrected_line:
             out["corrected_tracker"] = corrected_line
+        if latency:
+            out["latency"] = latency
         if not args.no_cpu_baseline:
             history(t0w)          # the map and the pose the timed frames started from
             seed_words = pool_i32().cpu().numpy().view(np.uint32) if t0w > 0 else None

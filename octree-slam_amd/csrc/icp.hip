@@ -998,13 +998,24 @@ int camera_set_model_depth(svoslam_camera *c, const uint16_t *d_depth, hipStream
   if (!c) return SVOSLAM_ERR_INVALID_ARG;
   if (!d_depth) { c->have_model = false; return SVOSLAM_OK; }  // no model: the following frames are tracked against the previous frame again
   const int W = c->width, H = c->height;
-  for (int i = 0; i < 3; i++)
-    if (!c->model_v[i]) {
+  if (!c->model_n[2]) {  // first model: the set's nine buffers, all or none (a failure frees what it got: ADVICE r03)
+    bool ok = true;
+    for (int i = 0; i < 3 && ok; i++) {
       const size_t n = (size_t)(W >> i) * (size_t)(H >> i);
-      SVO_HIP(hipMalloc((void **)&c->model_filt[i], n * 2));
-      SVO_HIP(hipMalloc((void **)&c->model_v[i], n * 12));
-      SVO_HIP(hipMalloc((void **)&c->model_n[i], n * 12));
+      ok = hipMalloc((void **)&c->model_filt[i], n * 2) == hipSuccess && hipMalloc((void **)&c->model_v[i], n * 12) == hipSuccess &&
+           hipMalloc((void **)&c->model_n[i], n * 12) == hipSuccess;
     }
+    if (!ok) {
+      (void)hipGetLastError();
+      for (int i = 0; i < 3; i++) {
+        if (c->model_filt[i]) (void)hipFree(c->model_filt[i]);
+        if (c->model_v[i]) (void)hipFree(c->model_v[i]);
+        if (c->model_n[i]) (void)hipFree(c->model_n[i]);
+        c->model_filt[i] = nullptr; c->model_v[i] = nullptr; c->model_n[i] = nullptr;
+      }
+      return SVOSLAM_ERR_OOM;
+    }
+  }
   SVO_TRY(bilateral_filter(d_depth, c->model_filt[0], W, H, s));
   for (int i = 0; i < 3; i++) {
     const int w = W >> i, h = H >> i;

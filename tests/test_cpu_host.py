@@ -2,6 +2,8 @@
 fails loudly without a GPU, and the oracle agrees with independent numpy float64 restatements."""
 import ctypes as C
 import os
+
+import pytest
 import re
 
 import numpy as np
@@ -216,3 +218,54 @@ def test_bench_line_contract():
     assert r["traffic"] is None or r["traffic"] > 0
     c = line["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+@pytest.mark.parametrize("name", ["r04_bench_cfg3.json", "r04_bench_cfg3_driver_args_20frames.json", "r04_bench_cfg4.json"])
+def test_bench_line_contract_round4(name):
+    """the round-4 lines: `value` is the median of the listed windows, the measured-copy peak stands beside the spec peak, the CPU
+    baseline ran on the timed frames, the pose error and the second, labelled measurement with the corrected tracker are there"""
+    import json
+    line = json.load(open(os.path.join(ROOT, "profiles", name)))
+    runs = sorted(line["runs"])
+    assert len(runs) >= 5 and abs(line["value"] - runs[(len(runs) - 1) // 2 if len(runs) % 2 else len(runs) // 2]) < 1e-6 * line["value"] or line["value"] in line["runs"]
+    assert line["value_min"] <= line["value"] <= line["value_max"] and len(line["runs_steady_state"]) == len(line["runs"])
+    assert line["pipeline_fill"]["pipeline_fill_ms"] > 0 and line["pipeline_fill"]["steady_frames_per_s"] >= line["value"] * 0.98
+    for r in [line["roofline"]] + line["roofline_stages"]:
+        assert r["peak"] == 8000.0 and r["peak_measured"] == 6290.0 and abs(r["achieved"] / 6290.0 - r["frac_of_measured"]) < 1e-9
+    first = line["config"]["frames_in_map_at_end"] - line["steps"]
+    assert "frames %d.." % (first + 1) in line["cpu_baseline"]["sample"]
+    assert line["config"]["pose_error_deg_end"] > 0 and "saturated_nodes_end" in line["config"] and "Q14" in line["config"]["tracker"]
+    ct = line["corrected_tracker"]
+    assert ct["value"] > 0 and ct["pose_error_deg_end"] < 15.0 and "corrected" in ct["what"]
+    assert line["metric"].startswith("SLAM frames/sec") and "CORRECTED" not in line["config"]["workload"]
+
+
+def test_config_struct_defaults_set_get_and_environment():
+    """svoslam_config (include/svoslam.h): defaults, set / get round trip, refused values, and the one environment variable the
+    library reads (SVOSLAM_CONFIG, in a child process: it is parsed once)"""
+    import json
+    import subprocess
+    import sys
+    import svoslam_pkg
+    pkg = svoslam_pkg.load()
+    c = pkg.get_config()
+    assert c["march_bricks"] == 1 and c["track_stream"] == 1 and c["runner_replicas"] == 1 and c["graphs"] == 0
+    before = pkg.configure(track_mode=1, runner_lead=3)
+    try:
+        now = pkg.get_config()
+        assert now["track_mode"] == 1 and now["runner_lead"] == 3 and now["march_bricks"] == before["march_bricks"]
+        with pytest.raises(pkg.SvoslamError):
+            pkg.configure(runner_replicas=3)
+        with pytest.raises(pkg.SvoslamError):
+            pkg.configure(track_mode=7)
+        with pytest.raises(KeyError):
+            pkg.configure(no_such_field=1)
+    finally:
+        pkg.configure(**before)
+    assert pkg.get_config() == before
+    code = "import sys, json; sys.path.insert(0, %r); import svoslam_pkg; print('CFG' + json.dumps(svoslam_pkg.load().get_config()))" % ROOT
+    env = dict(os.environ, **pkg.config_env(march_bricks=0, track_workers=17, runner_deferred=0))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    got = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("CFG")][0][3:])
+    assert got["march_bricks"] == 0 and got["track_workers"] == 17 and got["runner_deferred"] == 0 and got["track_stream"] == 1
