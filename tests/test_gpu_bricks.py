@@ -108,6 +108,38 @@ def test_bricks_deferred_commits_and_reset(env, oracle, depth):
         render_check(pkg, torch, oracle, pool, opool, w2, h2, oracle.look_at(eye, tgt, (0, 1, 0)), center, edge, ("after reset", eye))
 
 
+@pytest.mark.parametrize("depth", [12, 14])
+def test_large_render_tile_order_follows_the_previous_render(env, oracle, depth):
+    """renders of more tiles than the chip holds at once (1280 x 512: 1280 tiles of 32 x 16 pixels) take their tiles in the
+    order of the previous render's cost on that stream (cone_trace.hip tile_order_kernel): the oracle's image and counters
+    whatever the history -- none, this view, another view, another geometry in between -- and each repeat equal to the first"""
+    pkg, torch = env
+    rng = np.random.default_rng(40 + depth)
+    ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
+    center, edge = (0.0, 0.0, 0.0), 1.0
+    for f in range(3):
+        pts, col = surface_cloud(rng, 40000, jitter=0.002)
+        pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, pool, center, edge)
+        opool.insert_cloud(pts, col, depth, center, edge)
+    w, h = 1280, 512
+    va = oracle.look_at((0.1, 0.2, -1.6), (0, 0, 0), (0, 1, 0))
+    vb = oracle.look_at((0.9, 0.1, 0.9), (0.0, 0.05, 0.0), (0, 1, 0))   # grazing: long rays in other tiles
+    first = {}
+    for step, (name, view, ww, hh) in enumerate([("a", va, w, h), ("a", va, w, h), ("b", vb, w, h), ("a", va, w, h), ("small", va, 320, 96),
+                                                 ("b", vb, w, h), ("b", vb, w, h), ("tall", va, 640, 1024), ("a", va, w, h)]):
+        got = render_check(pkg, torch, oracle, pool, opool, ww, hh, view, center, edge, "render %d (%s)" % (step, name))
+        key = (name, ww, hh)
+        if key in first:
+            assert np.array_equal(got, first[key])
+        first[key] = got
+    # more points, then the same views again (the costs of the old map order the tiles of the new one)
+    pts, col = surface_cloud(rng, 40000, jitter=0.004)
+    pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, pool, center, edge)
+    opool.insert_cloud(pts, col, depth, center, edge)
+    for name, view in (("a", va), ("b", vb)):
+        render_check(pkg, torch, oracle, pool, opool, w, h, view, center, edge, "after more points (%s)" % name)
+
+
 def test_foreign_words_are_not_trusted(env, oracle):
     """the brick rebuild skips the level-12 tile of an unsaturated level-11 node only for pools this library fused from empty
     (averageChildren keeps a parent's alpha at the maximum of its children's); words uploaded by the caller may break that:
