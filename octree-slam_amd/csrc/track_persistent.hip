@@ -87,24 +87,29 @@ __device__ inline bool sweep_broadcast(TrackSync *sy, unsigned tag, float *out, 
 // them as one 32-byte row into LDS; then lane (t, half) walks the 32 rows of its half of the wavefront and adds
 // rint(fl(J_i * J_j) * 2^20) (or rint(fl(b * J_i) * 2^30)) of every pixel to its single accumulator.  Same products,
 // same exact integer-valued addends, any order (R3); what is left to combine per workgroup is 16 partials per term.
-constexpr int kRowFloats = 8;  // J0..J5, b, 0
+// LDS layout of a wavefront's rows: COLUMN-major, column c (J0..J5, b, and an all-zero column for the idle lanes) = the 64
+// pixels' values in a row of kColStride floats.  A lane reads four pixels of its column per ds_read_b128 (the row-major
+// layout needed a ds_read2_b32 per two pixels: 32 LDS instructions per operand pair and slot against 16, and the SQ counters
+// of the 1080p tracker showed 59 % of its wavefront-cycles waiting).  kColStride = 68: 16-byte aligned columns that start four
+// banks apart, so the seven columns (and the two halves, 32 banks apart) of one read never share a bank.
+constexpr int kCols = 8, kColStride = 68, kWaveRowFloats = kCols * kColStride;
 
-struct TermLane { int off_a, off_b; float scale; };  // byte offsets inside a row
+struct TermLane { int off_a, off_b; float scale; };  // byte offsets of the lane's two columns
 __device__ inline TermLane term_of_lane(int t) {
   TermLane L;
   if (t < 21) {  // (i, j), i <= j, row-major upper triangle: the order of Mat6x7's A entries in the 27 sums
     int i = 0, r = t;
     for (; i < 6; i++) { const int len = 6 - i; if (r < len) break; r -= len; }
-    L.off_a = 4 * i; L.off_b = 4 * (i + r); L.scale = 1048576.0f;
+    L.off_a = 4 * kColStride * i; L.off_b = 4 * kColStride * (i + r); L.scale = 1048576.0f;
   } else if (t < 27) {
-    L.off_a = 4 * 6; L.off_b = 4 * (t - 21); L.scale = 1073741824.0f;  // b * J[i]
+    L.off_a = 4 * kColStride * 6; L.off_b = 4 * kColStride * (t - 21); L.scale = 1073741824.0f;  // b * J[i]
   } else {
-    L.off_a = 4 * 7; L.off_b = 4 * 7; L.scale = 1.0f;  // idle lanes read the zero pad
+    L.off_a = 4 * kColStride * 7; L.off_b = 4 * kColStride * 7; L.scale = 1.0f;  // idle lanes read the zero column
   }
   return L;
 }
 
-// gates + Jacobian row of one pixel pair -> row[0..8) (zeros when a gate rejects the pair)
+// gates + Jacobian row of one pixel pair -> the lane's entry of columns 0..6 (zeros when a gate rejects the pair)
 __device__ __forceinline__ void icp_pixel_row(float v1x, float v1y, float v1z, float n1x, float n1y, float n1z, float v2x,
                                               float v2y, float v2z, float n2x, float n2y, float n2z, float *row, bool corrected) {
   bool ok = finitef_(v2x) && finitef_(v2y) && finitef_(v2z) && finitef_(v1x) && finitef_(v1y) && finitef_(v1z) &&
@@ -119,37 +124,33 @@ __device__ __forceinline__ void icp_pixel_row(float v1x, float v1y, float v1z, f
   J[4] = (0.0f * n1x + 1.0f * n1y) + 0.0f * n1z;
   J[5] = (0.0f * n1x + 0.0f * n1y) + 1.0f * n1z;
   const float bb = dot3(n1x, n1y, n1z, v1x - v2x, v1y - v2y, v1z - v2z);
-  float4 lo, hi;
-  lo.x = ok ? J[0] : 0.0f; lo.y = ok ? J[1] : 0.0f; lo.z = ok ? J[2] : 0.0f; lo.w = ok ? J[3] : 0.0f;
-  hi.x = ok ? J[4] : 0.0f; hi.y = ok ? J[5] : 0.0f; hi.z = ok ? bb : 0.0f; hi.w = 0.0f;
-  *reinterpret_cast<float4 *>(row) = lo;
-  *reinterpret_cast<float4 *>(row + 4) = hi;
+#pragma unroll
+  for (int c = 0; c < 6; c++) row[c * kColStride] = ok ? J[c] : 0.0f;  // (row = the wavefront's block + lane: consecutive banks)
+  row[6 * kColStride] = ok ? bb : 0.0f;
 }
 
-// lane (t, half): add its term of the 32 rows of its half (rows = this wavefront's 64 x 8 floats) to acc0 / acc1.
-// Four row pairs are requested before the first is used (eight ds_read2_b32 in flight), and the two rows of a pair go
-// through the packed multiplier together: 10 instructions per pair where the plain loop compiled to 12 behind a full
-// s_waitcnt each.
+// lane (t, half): add its term of the 32 pixels of its half (rows = this wavefront's columns) to acc0 / acc1: eight
+// 128-bit reads per operand, the pixels of a read through the packed multiplier two at a time.
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void accumulate_rows(const float *rows, const TermLane &T, int half, double &acc0, double &acc1) {
-  const char *base = reinterpret_cast<const char *>(rows) + half * 32 * kRowFloats * 4;
+  const char *base = reinterpret_cast<const char *>(rows) + half * 32 * 4;
   const v2f sc = {T.scale, T.scale};
 #pragma unroll
   for (int g = 0; g < 32; g += 8) {
-    v2f a[4], b[4];
+    float4 a[2], b[2];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int p = g + 2 * u;
-      a[u].x = *reinterpret_cast<const float *>(base + p * kRowFloats * 4 + T.off_a);
-      a[u].y = *reinterpret_cast<const float *>(base + (p + 1) * kRowFloats * 4 + T.off_a);
-      b[u].x = *reinterpret_cast<const float *>(base + p * kRowFloats * 4 + T.off_b);
-      b[u].y = *reinterpret_cast<const float *>(base + (p + 1) * kRowFloats * 4 + T.off_b);
+    for (int u = 0; u < 2; u++) {
+      a[u] = *reinterpret_cast<const float4 *>(base + T.off_a + (g + 4 * u) * 4);
+      b[u] = *reinterpret_cast<const float4 *>(base + T.off_b + (g + 4 * u) * 4);
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const v2f q = (a[u] * b[u]) * sc;  // fl(a * b), then the exact power-of-two scale: as the scalar form
-      acc0 += (double)rintf(q.x);
-      acc1 += (double)rintf(q.y);
+    for (int u = 0; u < 2; u++) {
+      const v2f a01 = {a[u].x, a[u].y}, a23 = {a[u].z, a[u].w}, b01 = {b[u].x, b[u].y}, b23 = {b[u].z, b[u].w};
+      const v2f q01 = (a01 * b01) * sc, q23 = (a23 * b23) * sc;  // fl(a * b), then the exact power-of-two scale
+      acc0 += (double)rintf(q01.x);
+      acc1 += (double)rintf(q01.y);
+      acc0 += (double)rintf(q23.x);
+      acc1 += (double)rintf(q23.y);
     }
   }
 }
@@ -189,7 +190,7 @@ template <int SLOTS, int MINW, bool STREAM>
 __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(CamState *st, TrackSync *sy, unsigned *tickets, double *rows, TrackArgs A) {
   SVO_HIGH_PRIO();
   __shared__ double wsum[16][27];          // workers: per-(wave, half) term sums; solver: row-group sums
-  __shared__ __attribute__((aligned(16))) float rows_s[kTrkWaves * 64 * kRowFloats];  // one 32-byte row per pixel in flight
+  __shared__ __attribute__((aligned(16))) float rows_s[kTrkWaves * kWaveRowFloats];  // per wavefront: eight columns of 64 pixels in flight
   __shared__ double totals[27];
   __shared__ float bc[32];                 // this_trans[16], update_trans[16] of the current epoch
   __shared__ int bc_flags;                 // bit 0: level lost, bit 1: this_trans valid
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(Cam
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   if (tid < 16) bc[16 + tid] = (tid % 5 == 0) ? 1.0f : 0.0f;  // update_trans = identity at the start of a frame (:100)
   if (tid == 0) { bc_flags = 0; s_fail = 0; }
+  rows_s[(tid >> 6) * kWaveRowFloats + 7 * kColStride + (tid & 63)] = 0.0f;  // the idle lanes' all-zero column
   __syncthreads();
 
   if (blockIdx.x == 0) {
@@ -339,14 +341,14 @@ __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(Cam
       TRK_STAMP(wid == 0 && tid == 0, e, 4);
       {
         double acc0 = 0.0, acc1 = 0.0;
-        float *my_rows = rows_s + wave * (64 * kRowFloats);
+        float *my_rows = rows_s + wave * kWaveRowFloats;
         if (!lost) {
           if (in_regs) {
 #pragma unroll
             for (int k = 0; k < SLOTS; k++) {
               if (k < slots) {
                 icp_pixel_row(px.v1[k][0], px.v1[k][1], px.v1[k][2], px.n1[k][0], px.n1[k][1], px.n1[k][2], px.v2[k][0],
-                              px.v2[k][1], px.v2[k][2], px.n2[k][0], px.n2[k][1], px.n2[k][2], my_rows + lane * kRowFloats, A.corrected != 0);
+                              px.v2[k][1], px.v2[k][2], px.n2[k][0], px.n2[k][1], px.n2[k][2], my_rows + lane, A.corrected != 0);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();  // the rows of this wavefront are read by its own lanes only
                 accumulate_rows(my_rows, T, half, acc0, acc1);
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(Cam
                 A.work_n[3 * q] = n2x; A.work_n[3 * q + 1] = n2y; A.work_n[3 * q + 2] = n2z;
               }
               icp_pixel_row(have_cur ? cur.v1[0] : __builtin_nanf(""), cur.v1[1], cur.v1[2], cur.n1[0], cur.n1[1], cur.n1[2], v2x, v2y, v2z, n2x, n2y,
-                            n2z, my_rows + lane * kRowFloats, A.corrected != 0);
+                            n2z, my_rows + lane, A.corrected != 0);
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
               __builtin_amdgcn_wave_barrier();
               accumulate_rows(my_rows, T, half, acc0, acc1);
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(Cam
                 mat4_mul_point(chain_s + 16 * c, n2x, n2y, n2z, 0.0f, ox, oy, oz);
                 n2x = ox; n2y = oy; n2z = oz;
               }
-              icp_pixel_row(v1x, v1y, v1z, n1x, n1y, n1z, v2x, v2y, v2z, n2x, n2y, n2z, my_rows + lane * kRowFloats, A.corrected != 0);
+              icp_pixel_row(v1x, v1y, v1z, n1x, n1y, n1z, v2x, v2y, v2z, n2x, n2y, n2z, my_rows + lane, A.corrected != 0);
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
               __builtin_amdgcn_wave_barrier();
               accumulate_rows(my_rows, T, half, acc0, acc1);
