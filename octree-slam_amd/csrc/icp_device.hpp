@@ -277,7 +277,9 @@ __device__ inline float lane_bcast(float v, int src_lane) {
 
 // must be called by all 64 lanes of a wavefront; sums = 27 doubles at a uniform address; x[6] on every lane
 // sums2 (optional): the photometric system's 27 sums; A = A1 + W_RGBD * A2, b likewise (rgbd_camera.cpp:130-141)
-__device__ inline void wave_solve_cholesky(const double *sums, const double *sums2, float *x, float &a_elem, float &b_elem) {
+// (SP: pointer to the sums -- generic, or LDS-qualified where the caller is not inlined into the kernel that owns the array)
+template <class SP>
+__device__ inline void wave_solve_cholesky(SP sums, const double *sums2, float *x, float &a_elem, float &b_elem) {
   const int lane = (int)(threadIdx.x & 63u);
   const int row = lane < 6 ? lane : 5;  // spare lanes shadow row 5
   // A is symmetric, sums hold its upper triangle row by row: index of (i <= j) = i*6 - i*(i-1)/2 + (j - i)
@@ -344,7 +346,8 @@ __device__ inline void wave_solve_cholesky(const double *sums, const double *sum
 }
 
 // element e = 4 * col + row of glm operator*(mat4, mat4) (type_mat4x4.inl:753-775): the expression of d_mat4_mul
-__device__ inline float mat4_mul_elem(const volatile float *a, const volatile float *b, int e) {
+template <class MP>
+__device__ inline float mat4_mul_elem(MP a, MP b, int e) {
   const int c = e >> 2, row = e & 3;
   return ((a[row] * b[4 * c] + a[4 + row] * b[4 * c + 1]) + a[8 + row] * b[4 * c + 2]) + a[12 + row] * b[4 * c + 3];
 }
@@ -402,7 +405,8 @@ __device__ inline TailPrefetch tail_prefetch(const CamState *st, int flags) {
   return p;
 }
 
-__device__ inline TailResult iteration_tail_wave(CamState *st, const double *sums, int slot, int flags, volatile float *sm,
+template <class SP, class MP>
+__device__ inline TailResult iteration_tail_wave(CamState *st, SP sums, int slot, int flags, MP sm,
                                                  const TailPrefetch &pre, const double *sums2 = nullptr) {
   TailResult res;
   res.tt = 0.0f; res.solved = 0;
@@ -466,7 +470,7 @@ __device__ inline TailResult iteration_tail_wave(CamState *st, const double *sum
     __builtin_amdgcn_wave_barrier();
     if (lane < 16) sm[112 + e] = ut;
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) frame_end_step(st, 1, sm + 112);
+    if (lane == 0) frame_end_step(st, 1, (const volatile float *)(sm + 112));
   }
   res.ut = ut; res.lost = lost;
   return res;

@@ -167,7 +167,10 @@ __device__ __attribute__((noinline)) TailResult solver_tail(CamState *st, const 
                                                             float pre_ut, int pre_lost, int corrected) {
   TailPrefetch pre;
   pre.ut = pre_ut; pre.lost = pre_lost; pre.corrected = corrected;
-  return iteration_tail_wave(st, totals, it, flags, tail_sm, pre);
+  // both arrays are the kernel's LDS: as generic pointers (this function is a real call) every access was a flat load / store
+  typedef __attribute__((address_space(3))) const double lds_cdouble;
+  typedef __attribute__((address_space(3))) volatile float lds_vfloat;
+  return iteration_tail_wave(st, (lds_cdouble *)totals, it, flags, (lds_vfloat *)tail_sm, pre);
 }
 
 template <int SLOTS>
