@@ -547,7 +547,6 @@ struct svoslam_camera {
   float *work_v = nullptr, *work_n = nullptr;  // launch-chain tracker: the current level's maps as transformed so far
   // one-launch tracker (track_persistent.hip)
   svoslam::TrackSync *d_sync = nullptr;
-  double *d_rows = nullptr;
   unsigned *d_tickets = nullptr;
   hipStream_t cap_stream = nullptr;  // stream whose resident-workgroup capacity is cached below
   int capacity = 0;
@@ -587,7 +586,6 @@ int camera_create(svoslam_camera **out, int w, int h, float fx, float fy) {
   SVO_HIP(hipMalloc((void **)&c->d_partial, (size_t)kMaxIcpBlocks * 27 * sizeof(double)));
   SVO_HIP(hipMalloc((void **)&c->d_sync, sizeof(TrackSync)));
   SVO_HIP(hipMalloc((void **)&c->d_tickets, track_persistent_ticket_bytes()));
-  SVO_HIP(hipMalloc((void **)&c->d_rows, (size_t)(kTrkMaxWorkers + 1) * 27 * sizeof(double)));
   c->d_acc = c->d_state->acc;
   const int rc = camera_reset(c);
   if (rc != SVOSLAM_OK) { camera_destroy(c); return rc; }
@@ -641,7 +639,6 @@ int camera_destroy(svoslam_camera *c) {
   if (c->d_partial2) (void)hipFree(c->d_partial2);
   if (c->d_sync) (void)hipFree(c->d_sync);
   if (c->d_tickets) (void)hipFree(c->d_tickets);
-  if (c->d_rows) (void)hipFree(c->d_rows);
   if (c->work_v) (void)hipFree(c->work_v);
   if (c->work_n) (void)hipFree(c->work_n);
   for (int i = 0; i < 3; i++) {
@@ -810,15 +807,15 @@ static int track_one_launch(svoslam_camera *c, hipStream_t s) {
     if (cap1 >= 2) {
       A.work_v = c->work_v; A.work_n = c->work_n;
       SVO_TRY(track_persistent_plan_stream(A, cap1));
-      return track_persistent_launch(c->d_state, c->d_sync, c->d_tickets, c->d_rows, A, s);
+      return track_persistent_launch(c->d_state, c->d_sync, c->d_tickets, A, s);
     }
   }
   if (A.slots[0] > kTrkSlots && !track_one_launch_forced()) {
     SVO_TRY(track_persistent_plan_coarse(A, c->capacity, 1));
-    SVO_TRY(track_persistent_launch(c->d_state, c->d_sync, c->d_tickets, c->d_rows, A, s));
+    SVO_TRY(track_persistent_launch(c->d_state, c->d_sync, c->d_tickets, A, s));
     return 2 + 1;                // the chain continues at level 1
   }
-  return track_persistent_launch(c->d_state, c->d_sync, c->d_tickets, c->d_rows, A, s);
+  return track_persistent_launch(c->d_state, c->d_sync, c->d_tickets, A, s);
 }
 
 int camera_track(svoslam_camera *c, hipStream_t s) {

@@ -56,9 +56,17 @@ __device__ __forceinline__ void st_agent32(unsigned *p, unsigned v) {
 
 // arrival counter of (bank, epoch, x = blockIdx & 7): 512 bytes apart so that the eight counters of an epoch live in
 // different memory channels (device-scope atomics on one address serialise at ~12 ns each)
-constexpr int kTicketStride = 128;  // unsigneds
+constexpr int kTicketStride = 64;  // 64-bit words
 __device__ __host__ inline size_t ticket_index(unsigned bank, int e, int x) { return ((size_t)(bank * 32u + (unsigned)e) * 8u + (unsigned)x) * kTicketStride; }
-__device__ inline unsigned *ticket_of(unsigned *tickets, unsigned bank, int e, int x) { return tickets + ticket_index(bank, e, x); }
+// The fan-in: accumulator (bank, epoch, x, term) is a 64-bit INTEGER that every worker with (blockIdx & 7) == x adds
+// (its term sum + kArriveBias) to with one agent-scope atomic.  The term sums are integer-valued (R3) and far below the bias,
+// so the word carries both the exact sum of the arrived workers and their NUMBER: n = (word + bias / 2) / bias, sum = word -
+// n x bias.  The data is its own flag: no row store, no drain before an arrival counter, no pass over 150 rows -- the solver
+// polls 8 x 27 words until every count is there (640x480: the tracker alone 0.213 -> 0.188 ms, 1080p 0.69 -> 0.65).  <= 31 workers per x
+// (kTrkMaxWorkers / 8) x 2^57 stays below 2^62; |sum| < 2^56 is implied by the exactness of the doubles it comes from (< 2^53).
+constexpr unsigned long long kArriveBias = 1ull << 57;
+static_assert((kTrkMaxWorkers + 7) / 8 <= 31, "arrival counts and sums share a 64-bit word");
+__device__ inline unsigned long long *acc_of(unsigned long long *acc, unsigned bank, int e, int x, int term) { return acc + ticket_index(bank, e, x) + term; }
 
 // one wavefront: wait until all kGranules tags equal `tag`; values -> LDS out[0..33).  Returns false on give-up.
 __device__ inline bool sweep_broadcast(TrackSync *sy, unsigned tag, float *out, int *out_flags) {
@@ -190,7 +198,7 @@ constexpr int kTrkMinWaves = 2;
 // them back -- a lane only ever re-reads what it wrote itself -- with the next pixel's 12 floats requested before the
 // current one is used.  <= 128 VGPRs, so its workgroups find room beside the march's instead of needing empty CUs.
 template <int SLOTS, int MINW, bool STREAM>
-__global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(CamState *st, TrackSync *sy, unsigned *tickets, double *rows, TrackArgs A) {
+__global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(CamState *st, TrackSync *sy, unsigned long long *acc, TrackArgs A) {
   SVO_HIGH_PRIO();
   __shared__ double wsum[16][27];          // workers: per-(wave, half) term sums; solver: row-group sums
   __shared__ __attribute__((aligned(16))) float rows_s[kTrkWaves * kWaveRowFloats];  // per wavefront: eight columns of 64 pixels in flight
@@ -211,49 +219,38 @@ __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(Cam
 
   if (blockIdx.x == 0) {
     // ------------------------------------------------------------------ solver
-    if (tid < 256) *ticket_of(tickets, bank ^ 1u, tid >> 3, tid & 7) = 0u;  // the next launch's counters (kernel boundary)
+    for (int i = tid; i < 32 * 8 * 32; i += kTrkThreads)  // the next launch's accumulators (kernel boundary): 27 (32) words of each (epoch, x)
+      acc[ticket_index(bank ^ 1u, i >> 8, (i >> 5) & 7) + (i & 31)] = 0ull;
     int e = 0;
     for (int level = 2; level >= 0; level--) {
       const int P = A.participants[level];
       for (int it = 0; it < A.iters[level]; it++) {
         e++;
         TRK_STAMP(tid == 0, e, 0);
-        if (wave == 0) {  // fan-in: every participant has stored its row and drained
-          // arrivals are counted per (blockIdx & 7) on eight counters in different memory channels; lane x polls counter x
-          const int x = (int)(lane & 7u);
+        {  // fan-in: thread (x, term) polls its accumulator until it holds the arrivals of every participant with that x
+          const int x = tid / 27, term = tid - 27 * x;
           const int first_wid = (x + 7) & 7;  // smallest wid with ((wid + 1) & 7) == x
-          const int expect = P > first_wid ? (P - first_wid + 7) / 8 : 0;
-          bool ok = true;
-          for (unsigned spins = 0;; spins++) {
-            if (__all((int)ld_agent32(ticket_of(tickets, bank, e, x)) >= expect)) break;
-            if ((spins & 63u) == 63u && (ld_agent32(&sy->fail) != 0u || spins > kSpinLimit)) { ok = false; break; }
-            __builtin_amdgcn_s_sleep(1);
+          const unsigned long long expect = x < 8 && P > first_wid ? (unsigned long long)((P - first_wid + 7) / 8) : 0ull;
+          long long part = 0;
+          if (expect) {
+            bool ok = true;
+            for (unsigned spins = 0;; spins++) {
+              const unsigned long long w = ld_agent64(acc_of(acc, bank, e, x, term));
+              const unsigned long long n = (w + (kArriveBias >> 1)) >> 57;
+              if (n == expect) { part = (long long)(w - n * kArriveBias); break; }
+              if ((spins & 63u) == 63u && (ld_agent32(&sy->fail) != 0u || spins > kSpinLimit)) { ok = false; break; }
+              __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok) { st_agent32(&sy->fail, 1u); s_fail = 1; }
           }
-          if (!ok && lane == 0) { st_agent32(&sy->fail, 1u); s_fail = 1; }
-        }
-        __syncthreads();
-        if (s_fail) return;
-        TRK_STAMP(tid == 0, e, 1);
-        {  // column sums of rows[P][27] (exact), 16 row groups x 32 columns; all of a thread's loads are issued before
-           // the first is used (a load-add loop costs one memory round trip per row: 2.7 us for 150 rows)
-          const int col = tid & 31, grp = tid >> 5;
-          constexpr int kRowsPerThread = (kTrkMaxWorkers + 15) / 16;
-          const unsigned long long *src = reinterpret_cast<const unsigned long long *>(rows) + col;
-          unsigned long long raw[kRowsPerThread];
-#pragma unroll
-          for (int k = 0; k < kRowsPerThread; k++) {
-            const int r = grp + 16 * k;
-            raw[k] = (col < 27 && r < P) ? ld_agent64(src + (size_t)r * 27) : 0ull;
-          }
-          double s = 0.0;
-#pragma unroll
-          for (int k = 0; k < kRowsPerThread; k++) s += __longlong_as_double((long long)raw[k]);
-          if (col < 27) wsum[grp][col] = s;
+          if (tid < 8 * 27) wsum[x][term] = (double)part;  // (exact: |part| < 2^53)
           __syncthreads();
+          if (s_fail) return;
+          TRK_STAMP(tid == 0, e, 1);
           if (tid < 27) {
             double t = 0.0;
 #pragma unroll
-            for (int g = 0; g < kTrkThreads / 32; g++) t += wsum[g][tid];
+            for (int g = 0; g < 8; g++) t += wsum[g][tid];
             totals[tid] = t;
           }
           __syncthreads();
@@ -432,10 +429,10 @@ __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(Cam
             double v = 0.0;
 #pragma unroll
             for (int w = 0; w < 2 * kTrkWaves; w++) v += wsum[w][tid];
-            st_agent64(reinterpret_cast<unsigned long long *>(rows) + (size_t)wid * 27 + tid, (unsigned long long)__double_as_longlong(v));
+            // sum and arrival in one atomic (see acc_of); v is integer-valued and |v| < 2^53
+            (void)__hip_atomic_fetch_add(acc_of(acc, bank, e, (int)(blockIdx.x & 7u), tid), (unsigned long long)(long long)v + kArriveBias,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row has left this CU before the arrival is counted
-          if (tid == 0) __hip_atomic_fetch_add(ticket_of(tickets, bank, e, (int)(blockIdx.x & 7u)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           TRK_STAMP(wid == 0 && tid == 0, e, 6);
         }
       }
@@ -597,7 +594,7 @@ int track_persistent_profile(const TrackSync *d_sync, unsigned long long *out, h
   return SVOSLAM_OK;
 }
 
-size_t track_persistent_ticket_bytes() { return ticket_index(2, 0, 0) * sizeof(unsigned); }
+size_t track_persistent_ticket_bytes() { return ticket_index(2, 0, 0) * sizeof(unsigned long long); }
 
 // The kernel's workgroups wait for each other, and its worker count assumes an otherwise idle device.  Two such launches
 // dispatched at the same time (two cameras or sessions of one process on one device, on different streams) could each
@@ -608,7 +605,8 @@ size_t track_persistent_ticket_bytes() { return ticket_index(2, 0, 0) * sizeof(u
 // single-stream case, but that stream may have been destroyed by then.)  Several PROCESSES sharing a device (a test
 // arrangement: bench.py's SVOSLAM_BENCH_ONE_DEVICE) use the launch chain (SVOSLAM_TRACK_CHAIN=1); a give-up still
 // surfaces as an error from the camera's next readback, and travels with the delta record of a frame-sharded session.
-int track_persistent_launch(CamState *st, TrackSync *sy, unsigned *tickets, double *rows, const TrackArgs &A, hipStream_t s) {
+int track_persistent_launch(CamState *st, TrackSync *sy, unsigned *tickets, const TrackArgs &A, hipStream_t s) {
+  unsigned long long *acc = reinterpret_cast<unsigned long long *>(tickets);
   struct DevChain { hipStream_t last = nullptr; hipEvent_t ev = nullptr; bool used = false; };
   static std::mutex mu;
   static std::map<int, DevChain> chain_of;
@@ -618,8 +616,8 @@ int track_persistent_launch(CamState *st, TrackSync *sy, unsigned *tickets, doub
   DevChain &dc = chain_of[dev];
   if (!dc.ev) SVO_HIP(hipEventCreateWithFlags(&dc.ev, hipEventDisableTiming));
   if (dc.used && dc.last != s) SVO_HIP(hipStreamWaitEvent(s, dc.ev, 0));  // the previous launch (any stream) has finished
-  if (A.variant) track_persistent_kernel<kTrkStreamSlots, kTrkStreamMinWaves, true><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, tickets, rows, A);
-  else track_persistent_kernel<kTrkSlots, kTrkMinWaves, false><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, tickets, rows, A);
+  if (A.variant) track_persistent_kernel<kTrkStreamSlots, kTrkStreamMinWaves, true><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, acc, A);
+  else track_persistent_kernel<kTrkSlots, kTrkMinWaves, false><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, acc, A);
   SVO_LAUNCH_CHECK();
   SVO_HIP(hipEventRecord(dc.ev, s));
   dc.last = s; dc.used = true;

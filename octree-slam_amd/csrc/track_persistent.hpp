@@ -39,7 +39,7 @@ int track_persistent_plan_stream(TrackArgs &A, int capacity);  // large images: 
 int track_persistent_plan(TrackArgs &A, int capacity);
 int track_persistent_plan_coarse(TrackArgs &A, int capacity, int coarse_levels);  // only the coarsest 1 or 2 levels; the rest: launch chain
 int track_persistent_profile(const TrackSync *d_sync, unsigned long long *out, hipStream_t s);
-size_t track_persistent_ticket_bytes();  // arrival counters: [2 banks][32 epochs][8], zeroed with TrackSync
-int track_persistent_launch(CamState *st, TrackSync *sy, unsigned *tickets, double *rows, const TrackArgs &A, hipStream_t s);
+size_t track_persistent_ticket_bytes();  // fan-in accumulators: [2 banks][32 epochs][8][27 of 64] 64-bit words, zeroed with TrackSync
+int track_persistent_launch(CamState *st, TrackSync *sy, unsigned *tickets, const TrackArgs &A, hipStream_t s);
 
 }  // namespace svoslam
