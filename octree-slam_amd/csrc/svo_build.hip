@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void split_all_kernel(const u64 *__restrict__ 
                                                         const u32 *__restrict__ bucket_base, const PlanCounts *__restrict__ counts,
                                                         u32 *__restrict__ pool, const int *__restrict__ d_size, int depth,
                                                         u32 *__restrict__ grid_dirty, u32 *__restrict__ n0_saved, int structure) {
-  if (!n0_saved) SVO_HIGH_PRIO();  // in-place commits sit between two raycasts on the map stream; deferred ones run beside one
+  SVO_HIGH_PRIO();  // also beside a march (deferred commits: apply -> plan -> commit -> apply is the cycle that can bind the frame; cfg3, 100 frames, 2209-2499 -> 2373-2511)
   const u32 total = (u32)counts->total_records;
   // structure != 0 (svo_fuse_plan_structure): the first tile index comes from the plan (*n0_saved, set by
   // plan_scan_finish_kernel from the structure-side size) and the links ARE written -- the next plan reads them
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   // (level `depth` = the leaf; kNoStraddler = none) for commit_apply_kernel.  The link from the key's frontier node
   // (the first node on its path without children, depth leaf_t[j]) to its new child tile is not in the pool yet either:
   // the tile is n0 + 8 x (rank of the pass-0 record of that prefix), found by key in the record bucket (0, leaf_t[j]).
-  if (!shadow) SVO_HIGH_PRIO();  // in-place commits sit between two raycasts on the map stream; deferred ones run beside one
+  SVO_HIGH_PRIO();
   __shared__ int last_owner[SVOSLAM_MAX_DEPTH + 1];  // per level: last lane of this workgroup owning a node there
   __shared__ int next_pos, next_c;                   // first head lane after this workgroup and its common-prefix length
   __shared__ int min_c;                              // smallest common-prefix length of a head of this tile (99: no head)
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__rest
                                                             int *__restrict__ d_size, u32 *__restrict__ grid_dirty,
                                                             int32_t *__restrict__ h_sizes, int *__restrict__ d_slot,
                                                             unsigned long long *__restrict__ shadow, u32 epoch) {
-  if (!shadow) SVO_HIGH_PRIO();  // in-place commits sit between two raycasts on the map stream; deferred ones run beside one
+  SVO_HIGH_PRIO();
   // shadow != nullptr: deferred commit (see fill_mip_local_kernel); the list entries double as the apply list
   auto average = [&](u32 child_base) { return shadow ? average_tile_deferred(pool, shadow, epoch, child_base) : average_tile(pool, child_base); };
   auto store = [&](u32 node, u32 word) {
