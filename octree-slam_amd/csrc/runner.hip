@@ -231,10 +231,14 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
     if (rc != SVOSLAM_OK) return rc;
   }
   // events of this call: maps, pose, back-projection, plan of every frame; commit of every frame on every replica
-  SVO_TRY(ensure_events(r, 7 * (size_t)n));
+  SVO_TRY(ensure_events(r, 8 * (size_t)n));
   hipEvent_t *ev_maps = r->events.data(), *ev_pose = ev_maps + n, *ev_bp = ev_pose + n, *ev_plan = ev_bp + n;
   hipEvent_t *ev_commit[2] = {ev_plan + n, ev_plan + 2 * (size_t)n};
   hipEvent_t *ev_ray = ev_plan + 3 * (size_t)n;
+  hipEvent_t *ev_sorted = ev_ray + n;
+  // Large images with in-place commits (1920x1080): back-projection + sort alone fill the S stream (0.83 of the 1.05 ms period in the
+  // scheduler's timeline, the plan the other 0.22), so the plan runs on the maps stream, which has 0.8 ms to spare: 932 -> 963 frames/s
+  const bool plan_on_maps = !sharded && !deferred && R == 1 && (long long)r->w * r->h > 400000ll;
   const bool serial_marches = true;  // (two replicas: their marches one after the other)
   std::vector<const float *> fusion_ptr((size_t)n, nullptr);
   r->ran = true; r->last_caller = cur;
@@ -350,11 +354,16 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
     }
     // the plan reads the replica that receives commit i-1 FIRST (the one frame i-1 is marched on); the march only reads
     const int src = i > 0 ? ((i - 1) & (R - 1)) : 0;
-    if (i > 0) SVO_HIP(hipStreamWaitEvent(r->s_prep, ev_commit[src][i - 1], 0));
-    mark(i, 5, r->s_prep);
+    if (plan_on_maps) {  // (see above)
+      SVO_HIP(hipEventRecord(ev_sorted[i], r->s_prep));
+      s_plan = r->s_maps;
+      SVO_HIP(hipStreamWaitEvent(s_plan, ev_sorted[i], 0));
+    }
+    if (i > 0) SVO_HIP(hipStreamWaitEvent(s_plan, ev_commit[src][i - 1], 0));
+    mark(i, 5, s_plan);
     svoslam_pool *planned = replica(r, src);
     const int32_t cap_before = planned->capacity;
-    SVO_TRY(svoslam_svo_fuse_plan(ws, npts, r->depth, planned, r->s_prep));
+    SVO_TRY(svoslam_svo_fuse_plan(ws, npts, r->depth, planned, s_plan));
     if (R == 2 && planned->capacity != cap_before) {
       // the plan had to grow its replica (it waited for the whole device to do so): the other one follows
       svoslam_pool *other = replica(r, src ^ 1);
@@ -363,9 +372,9 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
     }
     // the child tiles of this frame's splits, beyond the pool's size, while the previous frame is still being marched:
     // the commit on the map stream -- the stream that bounds the frame -- is then two launches instead of three
-    if (R == 1 && !deferred && r->early_split) SVO_TRY(svoslam_svo_fuse_split_early(ws, npts, r->depth, planned, r->s_prep));
-    SVO_HIP(hipEventRecord(ev_plan[i], r->s_prep));
-    mark(i, 6, r->s_prep);
+    if (R == 1 && !deferred && r->early_split) SVO_TRY(svoslam_svo_fuse_split_early(ws, npts, r->depth, planned, s_plan));
+    SVO_HIP(hipEventRecord(ev_plan[i], s_plan));
+    mark(i, 6, s_plan);
     return SVOSLAM_OK;
   };
   auto enqueue_commit = [&](int i, int k, bool last) -> int {
