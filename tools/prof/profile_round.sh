@@ -154,6 +154,29 @@ cd /tmp
 echo "== march anatomy, scheduler timeline"
 python $R/tools/prof/ray_anatomy.py 300 2>&1 | grep -v amdgpu.ids > ${P}_ray_anatomy_cfg3_300frames.txt; tail -3 ${P}_ray_anatomy_cfg3_300frames.txt
 python $R/tools/prof/runner_timeline.py 2>&1 | grep -v amdgpu.ids > ${P}_runner_timeline_cfg3.txt; tail -4 ${P}_runner_timeline_cfg3.txt
+TIMELINE_WORKLOAD=cfg4 TIMELINE_FRAMES=60 python $R/tools/prof/runner_timeline.py 2>&1 | grep -v amdgpu.ids > ${P}_runner_timeline_cfg4.txt; tail -4 ${P}_runner_timeline_cfg4.txt
+python $R/tools/prof/ramp_timeline.py 2>&1 | grep -v amdgpu.ids > ${P}_ramp_timeline_cfg3_driver_20frames.txt; head -1 ${P}_ramp_timeline_cfg3_driver_20frames.txt
+echo "== one-launch tracker: in-kernel stamps (-DSVO_TRK_PROF variant) and SQ counters of the 1080p streaming form"
+if [ -f $R/octree-slam_amd/_variants/libsvoslam_hip_trkprof.so ]; then
+  cp $R/octree-slam_amd/libsvoslam_hip.so /tmp/base.so
+  cp $R/octree-slam_amd/_variants/libsvoslam_hip_trkprof.so $R/octree-slam_amd/libsvoslam_hip.so
+  { echo "# tools/prof/tracker_profile.py with the -DSVO_TRK_PROF library: clock64 stamps of the solver workgroup (s.*) and of worker 0 (w.*) per epoch (19 ICP iterations), 640x480"
+    python $R/tools/prof/tracker_profile.py 2>&1 | grep -v amdgpu.ids
+    echo "# the same at 1920x1080 (streaming form)"
+    python $R/tools/prof/tracker_profile.py 1920 1080 2>&1 | grep -v amdgpu.ids; } > ${P}_tracker_stamps.txt
+  cp /tmp/base.so $R/octree-slam_amd/libsvoslam_hip.so
+fi
+{ echo "# rocprofv3 --pmc <4 SQ counters per pass> --kernel-include-regex track_persistent --kernel-trace -- python tools/prof/track_only.py 6 cfg4: the streaming one-launch tracker at 1920x1080 alone on the GPU; per launch, mean of 5; WAVE_CYCLES / WAIT_* / ACTIVE_* in quad-cycles"
+  for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES"; do
+    D=$SCR/sq_trk; rm -rf $D; mkdir -p $D
+    timeout 300 rocprofv3 --pmc $set --kernel-include-regex track_persistent --kernel-trace --output-format csv -d $D -o p -- python $R/tools/prof/track_only.py 6 cfg4 > $SCR/sq_trk.log 2>&1 || { echo "FAILED $set"; continue; }
+    f=$(find $D -name "*counter_collection.csv" | sort | tail -1)
+    python3 -c "
+import csv, sys, collections
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open('$f')): acc[r['Counter_Name']].append(float(r['Counter_Value']))
+for k, v in acc.items(): print('%-24s calls=%d mean=%.0f' % (k, len(v), sum(v) / len(v)))"
+  done; } > ${P}_tracker_sq_counters_cfg4_column_major_rows.txt
 fi
 ls -la "$OUT"
 echo "profile_round: FAILED=$FAILED"
