@@ -576,10 +576,9 @@ def main():
     latency = None
     if single and not args.no_overlap and not args.stages and not args.include_h2d and K > 8:
         try:
-            before = pkg.configure(runner_timeline=1)
+            pkg.configure(runner_timeline=1)     # (read when the pipeline's runner is created: at its first stream call, inside the window)
             cur["P"] = pl.SlamPipeline(width, height, max_depth, center, edge, render_mode=mode, count_steps=True, strict_reference=strict,
                                        pool_capacity_nodes=(1 << 30) - 8)
-            pkg.configure(**before)
             timed_window(t0w)
             tl = cur["P"]._runner.timeline()
             if len(tl) == K:

@@ -33,6 +33,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <array>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -42,6 +45,10 @@
 namespace {
 constexpr int kRing = 3;  // frames whose fusion may be in flight: workspaces, point clouds, colour staging
 }
+
+// stream sets of destroyed runners, by kind (see svoslam_runner_create)
+static std::mutex g_streams_mu;
+static std::map<int, std::vector<std::array<hipStream_t, 5>>> g_free_streams;
 
 struct svoslam_runner {
   svoslam_camera *cam = nullptr;
@@ -69,6 +76,7 @@ struct svoslam_runner {
   // since round 3 for images up to 640x480-class: the march over occupancy bricks is bound by instruction issue and no
   // longer by the loads the commit competes for (cfg3, 300-frame map: 1862 -> 2055 frames/s; the driver's 20 frames 1565 ->
   // 1707; cfg4, where the launch-chain tracker bounds the frame, 815 -> 694: off there).  svoslam_config.runner_deferred = 0 / 1 overrides.
+  int stream_kind = 0;  // device x priorities: which free list the five streams return to
   bool deferred = false, deferred_explicit = false;
   bool ran = false;
   // svoslam_config.runner_timeline = 1: timing events at the stage boundaries of the last call (svoslam_runner_timeline)
@@ -133,7 +141,24 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
     hipStream_t *ss[5] = {&r->s_maps, &r->s_track, &r->s_prep, &r->s_map[0], &r->s_map[1]};
     const int mid = (least + greatest) / 2;
     const int pr[5] = {least, mid, least, greatest, greatest};
-    for (int k = 0; k < 5; k++) {
+    // A destroyed runner's five streams are kept for the next runner of the same kind (device, priorities) instead of being
+    // destroyed: streams created after others were destroyed can come to share hardware queues -- a runner created after
+    // another one's destruction ran its sort behind its own march, 2700 -> 1300 frames/s at 640x480 (bench.py's second
+    // pipeline; scratch measurement in DESIGN.md section 6).
+    int dev = 0;
+    SVO_HIP(hipGetDevice(&dev));
+    r->stream_kind = dev * 2 + (prio ? 1 : 0);
+    bool reused = false;
+    {
+      std::lock_guard<std::mutex> lock(g_streams_mu);
+      auto &free_sets = g_free_streams[r->stream_kind];
+      if (!free_sets.empty()) {
+        for (int k = 0; k < 5; k++) *ss[k] = free_sets.back()[k];
+        free_sets.pop_back();
+        reused = true;
+      }
+    }
+    for (int k = 0; k < 5 && !reused; k++) {
       if (prio) SVO_HIP(hipStreamCreateWithPriority(ss[k], hipStreamNonBlocking, pr[k]));
       else SVO_HIP(hipStreamCreateWithFlags(ss[k], hipStreamNonBlocking));
     }
@@ -167,8 +192,21 @@ int svoslam_runner_destroy(svoslam_runner *r) {
   }
   for (int k = 0; k < 2; k++) (void)hipFree(r->scratch_image[k]);
   (void)hipFree(r->bbox); (void)hipFree(r->in_track); (void)hipFree(r->in_prep);
-  for (hipStream_t s : {r->s_maps, r->s_track, r->s_prep, r->s_map[0], r->s_map[1]})
-    if (s) { (void)svoslam_cone_trace_release(s, 0); (void)hipStreamDestroy(s); }
+  {
+    // (the streams' render tables are released; the streams themselves wait for the next runner: see svoslam_runner_create)
+    std::array<hipStream_t, 5> set = {r->s_maps, r->s_track, r->s_prep, r->s_map[0], r->s_map[1]};
+    bool whole = true;
+    for (hipStream_t s : set) {
+      if (s) (void)svoslam_cone_trace_release(s, 0);
+      else whole = false;
+    }
+    if (whole) {
+      std::lock_guard<std::mutex> lock(g_streams_mu);
+      g_free_streams[r->stream_kind].push_back(set);
+    } else {
+      for (hipStream_t s : set) if (s) (void)hipStreamDestroy(s);
+    }
+  }
   if (r->replica1.d_data) (void)svoslam_pool_free(&r->replica1);
   delete r;
   return SVOSLAM_OK;
