@@ -228,6 +228,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise SvoslamError("%s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
                            "There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime: whichever of the two is mapped first serves the whole process, and torch finds no
+    # device when this library's (/opt/rocm) came first -- e.g. __graft_entry__.build() followed by smoke() in one process.
+    # torch is the device-memory / stream provider of every caller of this binding, so it goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)
