@@ -237,6 +237,9 @@ def test_bench_line_contract_round4(name):
     assert line["config"]["pose_error_deg_end"] > 0 and "saturated_nodes_end" in line["config"] and "Q14" in line["config"]["tracker"]
     ct = line["corrected_tracker"]
     assert ct["value"] > 0 and ct["pose_error_deg_end"] < 15.0 and "corrected" in ct["what"]
+    assert ct["value"] > 0.7 * line["value"]   # (a second pipeline of the process runs at its own rate: the runner's streams are reused)
+    lat = line["latency"]                        # first map kernel of a frame to the end of its march: several frame periods
+    assert lat["frame_latency_ms"] > 1.5 * line["ms_per_step"] and lat["frame_period_ms_with_marks"] > 0
     assert line["metric"].startswith("SLAM frames/sec") and "CORRECTED" not in line["config"]["workload"]
 
 
