@@ -7,22 +7,23 @@
 // the same 4x4 product to the values it holds -- same operands, same order, same floats), and the iterations are
 // separated by one fan-in / one broadcast inside the launch instead of two kernel boundaries:
 //
-//   workgroup 0 ("solver")        polls the epoch's arrival counter, sums the workers' 27-double rows (exact:
-//                                 integer-valued, R3), runs the 6x6 Cholesky + pose composition on one wavefront
-//                                 (icp_device.hpp, unchanged) and publishes this_trans / update_trans / lost as
-//                                 33 eight-byte {tag = epoch, value} granules -- the data is its own flag;
-//   workgroups 1..W ("workers")   accumulate their pixels' terms, reduce them to one row (DPP + LDS), store it
-//                                 write-through (sc1), drain, bump the counter, then sweep the granules until every
-//                                 tag matches and apply this_trans to their registers.
+//   workgroup 0 ("solver")        polls the epoch's 8 x 27 fan-in accumulators (acc_of below: each holds the exact
+//                                 integer sum of the arrived workers' term AND their number), adds the eight parts,
+//                                 runs the 6x6 Cholesky + pose composition on one wavefront (icp_device.hpp) and
+//                                 publishes this_trans / update_trans / lost as 33 eight-byte {tag = epoch, value}
+//                                 granules -- in both directions the data is its own flag;
+//   workgroups 1..W ("workers")   accumulate their pixels' terms (transposed: a lane owns one of the 27), reduce them in
+//                                 LDS, add each term to its accumulator with one 64-bit integer atomic, then sweep
+//                                 the granules until every tag matches and apply this_trans to their registers.
 //
-// Every shared word is accessed with agent-scope (sc1) loads / stores only, so the exchange does not depend on which
-// XCD a workgroup runs on (cdna_hip_programming.md Guideline 16, forms R1 for the rows and R2 for the broadcast).
-// Nothing is zeroed per launch: tags carry a device-resident generation (replay-safe), the two banks of arrival
-// counters alternate and the solver clears the idle one.  The solver is the only writer of CamState, from one CU.
+// Every shared word is accessed with agent-scope loads / stores / atomics only, so the exchange does not depend on which
+// XCD a workgroup runs on (cdna_hip_programming.md Guideline 16, form R2 in both directions).
+// Nothing is zeroed per launch: tags carry a device-resident generation (replay-safe), the two banks of accumulators
+// alternate and the solver clears the idle one.  The solver is the only writer of CamState, from one CU.
 // All spins are bounded; a give-up code in TrackSync::fail makes every later call of the camera return an error.
 //
-// Images too large for registers (1920x1080 at level 0: 16 pixels per lane) fall back, per level, to re-reading the
-// maps and replaying the chain from LDS, still inside the one launch.
+// Images too large for registers (1920x1080 at level 0: 23 pixels per lane) stream, per level, through work maps inside the
+// one launch (the <2, 3, true> form below).
 #include <stdlib.h>
 
 #include "icp_device.hpp"
@@ -54,7 +55,7 @@ __device__ __forceinline__ void st_agent32(unsigned *p, unsigned v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// arrival counter of (bank, epoch, x = blockIdx & 7): 512 bytes apart so that the eight counters of an epoch live in
+// accumulator line of (bank, epoch, x = blockIdx & 7): 512 bytes apart so that the eight lines of an epoch live in
 // different memory channels (device-scope atomics on one address serialise at ~12 ns each)
 constexpr int kTicketStride = 64;  // 64-bit words
 __device__ __host__ inline size_t ticket_index(unsigned bank, int e, int x) { return ((size_t)(bank * 32u + (unsigned)e) * 8u + (unsigned)x) * kTicketStride; }

@@ -10,7 +10,7 @@ constexpr int kTrkThreads = 512;     // 8 wavefronts, 2 per SIMD: up to 256 VGPR
 constexpr int kTrkSlots = 4;  // pixels of a level a lane may keep in registers (x 12 floats)
 constexpr int kTrkMaxWorkers = 247;  // + the solver workgroup <= one per CU on an idle device
 
-// words shared between the workgroups of one launch; zeroed (with the arrival counters, two banks of which the solver
+// words shared between the workgroups of one launch; zeroed (with the fan-in accumulators, two banks of which the solver
 // clears the idle one) once when the camera is created / reset
 struct TrackSync {
   unsigned long long granule[64];  // {tag = generation * 32 + epoch, value}: this_trans, update_trans, flags
