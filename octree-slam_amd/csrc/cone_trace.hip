@@ -988,36 +988,12 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
   if (slots) count_steps(slots, counters, my_steps, my_levels, lane);
 }
 
-// Tiles of the previous render, costliest first (longest-processing-time-first: the in-order dispatcher then ends a render
-// with its cheapest tiles instead of whatever rows come last -- 1920x1080, 45-frame map: 0.265 -> 0.213 ms alone).  One
-// workgroup: a counting sort on 256 cost classes (any cost array gives a permutation, an all-zero one the row-major order),
-// and the costs are cleared for the render that follows.
-constexpr int kTileOrderThreads = 1024;
+// Tiles of the previous render, costliest first: tile_order_block (pool_grid.hpp), run by one extra workgroup of the refresh
+// launch that precedes the march (no launch of its own on the map stream: as one it took 15 us + a launch boundary per frame)
+// or, where no refresh is launched, by this kernel.
 constexpr int kTileOrderMinTiles = 768;  // resident workgroups of the brick kernel (three per CU): smaller renders start every tile at once
-__global__ __launch_bounds__(kTileOrderThreads) void tile_order_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, int n) {
-  __shared__ uint32_t hist[256], base[256], s_max;
-  const int tid = (int)threadIdx.x;
-  if (tid < 256) hist[tid] = 0;
-  if (tid == 0) s_max = 0;
-  __syncthreads();
-  uint32_t mx = 0;
-  for (int i = tid; i < n; i += kTileOrderThreads) mx = cost[i] > mx ? cost[i] : mx;
-  atomicMax(&s_max, mx);
-  __syncthreads();
-  const uint32_t top = s_max;
-  const uint32_t shift = top > 255u ? (uint32_t)(32 - __clz((int)top)) - 8u : 0u;  // class = cost >> shift <= 255
-  for (int i = tid; i < n; i += kTileOrderThreads) atomicAdd(&hist[255u - (cost[i] >> shift)], 1u);
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t run = 0;
-    for (int b = 0; b < 256; b++) { base[b] = run; run += hist[b]; }
-  }
-  __syncthreads();
-  for (int i = tid; i < n; i += kTileOrderThreads) {
-    const uint32_t pos = atomicAdd(&base[255u - (cost[i] >> shift)], 1u);  // (the order inside a class is free)
-    order[pos] = (uint32_t)i;
-    cost[i] = 0;
-  }
+__global__ __launch_bounds__(256) void tile_order_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, int n) {
+  tile_order_block(cost, order, n);
 }
 
 // tile -> XCD mapping of a render of tiles_x x tiles_y workgroup tiles; returns the number of workgroups to launch
@@ -1145,8 +1121,28 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   int brick_shift = -1;
   const bool tables_match = sa->tables_valid && sa->tables_at == d_table && sa->lds_depth == P.lds_depth && sa->size == size &&
                             sa->center[0] == center[0] && sa->center[1] == center[1] && sa->center[2] == center[2];
+  // large reference-mode renders: the tile order of the march (TraceParams::tile_order) is brought up to date by the refresh launch
+  const bool carry = (mode & 0xFF) == SVOSLAM_RENDER_CARRY;
+  const int n_tiles = (int)(cdiv(width, 32) * cdiv(rows, kTraceThreads / 32));
+  uint32_t *tile_cost = nullptr, *tile_order = nullptr;
+  bool order_done = false;
+  if (pa && !carry && n_tiles > kTileOrderMinTiles) {
+    const int n = n_tiles;
+    if (n != sa->tile_count || width != sa->tile_w || rows != sa->tile_rows || row_first != sa->tile_row_first) {
+      // another geometry: no history (all costs zero -> row-major order)
+      if (n > sa->tile_cap) {
+        if (sa->tiles) { SVO_HIP(hipStreamSynchronize(stream)); SVO_HIP(hipFree(sa->tiles)); sa->tiles = nullptr; }
+        SVO_HIP(hipMalloc((void **)&sa->tiles, (size_t)n * 8));
+        sa->tile_cap = n;
+      }
+      SVO_HIP(hipMemsetAsync(sa->tiles, 0, (size_t)n * 4, stream));
+      sa->tile_count = n; sa->tile_w = width; sa->tile_rows = rows; sa->tile_row_first = row_first;
+    }
+    tile_cost = sa->tiles; tile_order = sa->tiles + n;
+  }
   if (pa) {
-    SVO_TRY(pool_accel_refresh(pa, d_octree, stream, &d_grid, (mode & 0xFF) == SVOSLAM_RENDER_REFERENCE, &d_bricks, &brick_shift));
+    SVO_TRY(pool_accel_refresh(pa, d_octree, stream, &d_grid, (mode & 0xFF) == SVOSLAM_RENDER_REFERENCE, &d_bricks, &brick_shift,
+                               tile_cost, tile_order, tile_cost ? n_tiles : 0, &order_done));
     if (!tables_match) build_tables_kernel<<<(int)cdiv(3 * (kTabStride + kLdsStrideMax) + 256, 256), 256, 0, stream>>>(d_table, alpha_lut, P);
   } else {
     const int build_blocks = (int)cdiv(own_cells + 3 * (kTabStride + kLdsStrideMax) + 256, 256);
@@ -1166,25 +1162,13 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   long long stage_token = -1;
   SVO_TRY(stage_begin(kStageMarch, stream, &stage_token));
   uchar4 *out = reinterpret_cast<uchar4 *>(d_pos);
-  const bool carry = (mode & 0xFF) == SVOSLAM_RENDER_CARRY;
   const bool midrange_size = size >= 9.5367431640625e-07f && size <= 1048576.0f;  // (see cone_trace_kernel: the length recurrence's short forms)
   if (d_bricks && !carry && midrange_size) {  // a pool of this library in reference mode: the march over occupancy bricks
     P.xcd_w = 0; P.xcd_h = (int)cdiv(width, 32);
     const dim3 grid((unsigned)(cdiv(width, 32) * cdiv(rows, kTraceThreads / 32)));
-    if ((int)grid.x > kTileOrderMinTiles) {
-      const int n = (int)grid.x;
-      if (n != sa->tile_count || width != sa->tile_w || rows != sa->tile_rows || row_first != sa->tile_row_first) {
-        // another geometry: no history (all costs zero -> row-major order)
-        if (n > sa->tile_cap) {
-          if (sa->tiles) { SVO_HIP(hipStreamSynchronize(stream)); SVO_HIP(hipFree(sa->tiles)); sa->tiles = nullptr; }
-          SVO_HIP(hipMalloc((void **)&sa->tiles, (size_t)n * 8));
-          sa->tile_cap = n;
-        }
-        SVO_HIP(hipMemsetAsync(sa->tiles, 0, (size_t)n * 4, stream));
-        sa->tile_count = n; sa->tile_w = width; sa->tile_rows = rows; sa->tile_row_first = row_first;
-      }
-      tile_order_kernel<<<1, kTileOrderThreads, 0, stream>>>(sa->tiles, sa->tiles + n, n);
-      P.tile_cost = sa->tiles; P.tile_order = sa->tiles + n;
+    if (tile_cost) {
+      if (!order_done) tile_order_kernel<<<1, 256, 0, stream>>>(tile_cost, tile_order, n_tiles);  // (the refresh was a full build)
+      P.tile_cost = tile_cost; P.tile_order = tile_order;
     }
     auto launch = [&](auto kernel) { kernel<<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps, slots); };
     if (brick_shift == 0) {

@@ -539,7 +539,9 @@ constexpr int kRefreshBrickBlocks = kBrickBlocks, kRefreshGridBlocks = 1024, kRe
 template <int C, int S>
 __global__ __launch_bounds__(kBrickThreads) void pool_refresh_kernel(const uint32_t *__restrict__ octree, uint2 *grid, uint16_t *__restrict__ bricks,
                                                                       uint32_t *__restrict__ touched, uint32_t *dirty_a, uint32_t *dirty_b,
-                                                                      int trust_mip, int par_a, int par_b, unsigned brick_blocks) {
+                                                                      int trust_mip, int par_a, int par_b, unsigned brick_blocks,
+                                                                      uint32_t *__restrict__ tile_cost, uint32_t *__restrict__ tile_order, int n_tiles) {
+  if (n_tiles > 0 && blockIdx.x == gridDim.x - 1) { tile_order_block(tile_cost, tile_order, n_tiles); return; }  // (the march's tile order: pool_grid.hpp)
   const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
   // (the bricks' workgroups first: they are the long ones; 2048 nearly empty grid workgroups ahead of them cost the launch 20 us)
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -600,7 +602,8 @@ static void ensure_bricks(PoolAccel *pa, hipStream_t stream) {
 }
 
 int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stream, const uint2 **d_grid, bool want_bricks,
-                       const uint16_t **d_bricks, int *brick_shift) {
+                       const uint16_t **d_bricks, int *brick_shift, uint32_t *tile_cost, uint32_t *tile_order, int n_tiles, bool *order_done) {
+  if (order_done) *order_done = false;
   if (!pa || !d_octree || !d_grid) return SVOSLAM_ERR_INVALID_ARG;
   constexpr size_t kCells = (size_t)1 << (3 * kPoolGridLevel);
   // the whole enqueue under the lock: the grid's host-side state (valid, last_stream) and the launches that make it
@@ -652,8 +655,10 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
       // grid update and brick rebuild in ONE launch.  (Measured and not kept, round 3: the rebuild on a stream of its own beside
       // the march -- rays reach the surfaces before the rebuild does and pay tree walks: march 0.325 -> 0.395 ms; two launches;
       // 4096 workgroups x 2 bricks per wavefront -- kernel 55 -> 40 us, frame rate lower: DESIGN.md section 4.)
-      if (shift == 0) pool_refresh_kernel<kRefreshChains, 0><<<kRefreshBrickBlocks + kRefreshGridBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], trust, par_a, par_b, kRefreshBrickBlocks);
-      else pool_refresh_kernel<kRefreshChains, 1><<<kRefreshBrickBlocks + kRefreshGridBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], trust, par_a, par_b, kRefreshBrickBlocks);
+      const int extra = tile_cost && tile_order && n_tiles > 0 ? 1 : 0;  // one more workgroup: the tile order of the caller's march
+      if (shift == 0) pool_refresh_kernel<kRefreshChains, 0><<<kRefreshBrickBlocks + kRefreshGridBlocks + extra, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], trust, par_a, par_b, kRefreshBrickBlocks, tile_cost, tile_order, extra ? n_tiles : 0);
+      else pool_refresh_kernel<kRefreshChains, 1><<<kRefreshBrickBlocks + kRefreshGridBlocks + extra, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], trust, par_a, par_b, kRefreshBrickBlocks, tile_cost, tile_order, extra ? n_tiles : 0);
+      if (extra && order_done) *order_done = true;
     }
     for (int k = 0; k < 2; k++)
       if (serve_idx[k] >= 0) pa->brick_served[serve_idx[k]]++;

@@ -99,7 +99,10 @@ bool pool_shadow_pending(svoslam_pool *pool);
 // want_bricks: also bring the occupancy bricks up to date (allocating them on first use); *d_bricks = the field, or
 // nullptr when the pool has none (not wanted so far, SVOSLAM_MARCH_BRICKS=0, or no memory for them)
 int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stream, const uint2 **d_grid, bool want_bricks,
-                       const uint16_t **d_bricks, int *brick_shift);  // *brick_shift: the shape of *d_bricks (pool_grid.hpp "Shapes")
+                       const uint16_t **d_bricks, int *brick_shift, uint32_t *tile_cost = nullptr, uint32_t *tile_order = nullptr,
+                       int n_tiles = 0, bool *order_done = nullptr);
+// tile_cost / tile_order / n_tiles (optional): the caller's march takes its tiles costliest-first (cone_trace.hip TraceParams); the
+// incremental refresh launch brings the order up to date in one extra workgroup (*order_done = true), other forms leave it to the caller  // *brick_shift: the shape of *d_bricks (pool_grid.hpp "Shapes")
 
 constexpr int kPoolGridListOffset = kPoolGridDirtyWords;                     // words
 constexpr int kPoolGridCountOffset = kPoolGridDirtyWords + kPoolGridBlocks;  // words
@@ -234,6 +237,41 @@ __host__ __device__ inline unsigned long long brick_entry_index(uint32_t x, uint
                       ((z & 3u) << 4) | ((y & 3u) << 2) | (x & 3u);
   return ((unsigned long long)(z >> 5) << 27) | lo;
 }
+
+// One workgroup: order[0 .. n) = the tiles of a render, costliest first by cost[] (wavefront-steps of the previous render of that
+// geometry), and cost[] cleared for the render that follows.  Longest-processing-time-first: the in-order dispatcher then ends a
+// render with its cheapest tiles instead of whatever rows come last (1920x1080, 45-frame map: the march alone 0.336 -> 0.267 ms).
+// A counting sort on 256 cost classes: any cost array gives a permutation, an all-zero one the row-major order.
+#ifdef __HIPCC__
+__device__ inline void tile_order_block(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, int n) {
+  __shared__ uint32_t hist[256], base[256], s_max;
+  const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+  for (int b = tid; b < 256; b += nt) hist[b] = 0;
+  if (tid == 0) s_max = 0;
+  __syncthreads();
+  uint32_t mx = 0;
+  for (int i = tid; i < n; i += nt) mx = cost[i] > mx ? cost[i] : mx;
+  atomicMax(&s_max, mx);
+  __syncthreads();
+  const uint32_t top = s_max;
+  const uint32_t shift = top > 255u ? (uint32_t)(32 - __clz((int)top)) - 8u : 0u;  // class = cost >> shift <= 255
+  for (int i = tid; i < n; i += nt) atomicAdd(&hist[255u - (cost[i] >> shift)], 1u);
+  __syncthreads();
+  if (tid < 64) {  // exclusive scan of the 256 class counts by one wavefront: four per lane, then across the lanes
+    uint32_t v[4], run = 0;
+    for (int k = 0; k < 4; k++) { v[k] = run; run += hist[4 * tid + k]; }
+    uint32_t incl = run;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if (tid >= o) incl += t; }
+    for (int k = 0; k < 4; k++) base[4 * tid + k] = incl - run + v[k];
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += nt) {
+    const uint32_t pos = atomicAdd(&base[255u - (cost[i] >> shift)], 1u);  // (the order inside a class is free)
+    order[pos] = (uint32_t)i;
+    cost[i] = 0;
+  }
+}
+#endif
 
 // list entry of the brick at window-relative brick coordinates (x9, y9, z9): 9 bits each
 __host__ __device__ inline uint32_t brick_list_entry(uint32_t x9, uint32_t y9, uint32_t z9) { return (z9 << 18) | (y9 << 9) | x9; }
