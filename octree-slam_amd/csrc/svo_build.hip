@@ -632,7 +632,7 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
                                                              int *__restrict__ strad_bc, int brick_shift) {
   const bool early_links = leaf_rec0 != nullptr;
   // shadow != nullptr: deferred commit.  Every colour word goes to shadow[node] instead of the pool, children are read
-  // through average_tile_deferred, and apply_nodes[(level - 1) * n + j] names the node lane j wrote at that level
+  // through average_tile_deferred, and apply_nodes lists the nodes written, per workgroup (apply_append; the counts behind the lists),
   // (level `depth` = the leaf; kNoStraddler = none) for commit_apply_kernel.  The link from the key's frontier node
   // (the first node on its path without children, depth leaf_t[j]) to its new child tile is not in the pool yet either:
   // the tile is n0 + 8 x (rank of the pass-0 record of that prefix), found by key in the record bucket (0, leaf_t[j]).
@@ -640,9 +640,21 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   __shared__ int last_owner[SVOSLAM_MAX_DEPTH + 1];  // per level: last lane of this workgroup owning a node there
   __shared__ int next_pos, next_c;                   // first head lane after this workgroup and its common-prefix length
   __shared__ int min_c;                              // smallest common-prefix length of a head of this tile (99: no head)
+  __shared__ u32 apply_cnt;                          // deferred commit: nodes this workgroup has listed for the apply so far
   const int tid = (int)threadIdx.x;
   const int bid = xcd_tile(num_tiles);  // this workgroup's tile of the sorted keys
   if (bid >= num_tiles) return;
+  if (tid == 0) apply_cnt = 0;  // (first used behind the set-up's barriers)
+  // the workgroup's part of the apply list: `depth` entries per lane at most, written densely from its start (apply_append)
+  u32 *apply_mine = apply_nodes ? apply_nodes + (size_t)bid * kFillThreads * (size_t)depth : nullptr;
+  auto apply_append = [&](bool mine, u32 node) {  // all lanes of the wavefront call it; one LDS atomic per wavefront
+    const unsigned long long m = __ballot(mine);
+    if (!m) return;
+    u32 base = 0;
+    if ((tid & 63) == 0) base = atomicAdd(&apply_cnt, (u32)__popcll(m));
+    base = (u32)__shfl((int)base, 0);
+    if (mine) apply_mine[base + (u32)__popcll(m & lanemask_lt())] = node;
+  };
   const int j = bid * kFillThreads + tid;
   // Everything the setup needs from memory is requested at once (one round trip instead of four in sequence): this
   // lane's key pair and point index, and the key pair of the lane at the same place in the next workgroup, one of
@@ -815,7 +827,7 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
     else pool[2 * (size_t)node + 1] = word;
     node_at[0] = node;  // (slot 0 is free: the root is not a lane's node)
   }
-  if (shadow && j < n) apply_nodes[(size_t)(depth - 1) * n + j] = head ? node_at[0] : kNoStraddler;
+  if (shadow) apply_append(head, node_at[0]);
   __syncthreads();
   if (brick_mine) brick_ring_store(grid_dirty, brick_base + brick_off, brick_entry);
 #pragma unroll
@@ -835,13 +847,14 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
           strad[2 * ((size_t)d * num_tiles + bid) + 1] = child_at[d];
         }
       }
-      if (shadow && j < n) apply_nodes[(size_t)(d - 1) * n + j] = wrote;
+      if (shadow) apply_append(wrote != kNoStraddler, wrote);
       __syncthreads();
     }
   }
   // the sibling ring (see above).  At the END of the kernel: a divergent returning atomic between the barriers of the set-up left
   // the wavefront's lanes apart at the ballots that follow there (test_async_fusion_long_runs_of_duplicates_and_invalid_points)
   if (brick_mine && lt != kNoSplit && (int)lt < brick_node_level(brick_shift)) brick_sibling_list(grid_dirty, brick_entry);
+  if (shadow && tid == 0) apply_nodes[(size_t)num_tiles * kFillThreads * (size_t)depth + bid] = apply_cnt;  // (behind the last level's barrier)
 }
 
 // straddling nodes deepest level first, then the root quirk (Q6) and the device-side size
@@ -1002,20 +1015,27 @@ __global__ __launch_bounds__(kStrad2Threads) void mip_straddle2_kernel(u32 *__re
 }
 
 // Second half of a deferred commit: everything the commit computed while the previous frame was being ray-marched
-// becomes visible -- the colour words from the shadow array (apply_nodes: one slot per sorted key and level; the
+// becomes visible -- the colour words from the shadow array (apply_nodes: the leaf kernel's per-workgroup lists of the nodes
+// it wrote -- a dense [level][key] table of mostly empty slots until round 4: 116 MB written and read per 1080p frame --; the
 // straddler list; the root), and the links of the pass-0 split records to their (already initialised) child tiles.
 // Every word is written once; ~0.6 M scattered 4-byte stores at 640x480.
 __global__ __launch_bounds__(256) void commit_apply_kernel(u32 *__restrict__ pool, const unsigned long long *__restrict__ shadow,
-                                                           const u32 *__restrict__ apply_nodes, long long slots,
+                                                           const u32 *__restrict__ apply_nodes, int fill_tiles, int list_cap,
                                                            const u32 *__restrict__ strad, int strad_first, int strad_end,
                                                            const u32 *__restrict__ rec_front, const unsigned char *__restrict__ rec_pass,
                                                            const PlanCounts *__restrict__ counts, const u32 *__restrict__ n0_saved) {
   SVO_HIGH_PRIO();
-  const long long stride = (long long)gridDim.x * 256, t0 = (long long)blockIdx.x * 256 + threadIdx.x;
-  for (long long i = t0; i < slots; i += stride) {
-    const u32 node = apply_nodes[i];
-    if (node != kNoStraddler) pool[2 * (size_t)node + 1] = (u32)shadow[node];
+  // the leaf kernel's lists: one per fill tile, `count` entries from its start (counts behind the lists)
+  const u32 *list_counts = apply_nodes + (size_t)fill_tiles * list_cap;
+  for (int t = (int)blockIdx.x; t < fill_tiles; t += (int)gridDim.x) {
+    const u32 cnt = list_counts[t];
+    const u32 *list = apply_nodes + (size_t)t * list_cap;
+    for (u32 i = threadIdx.x; i < cnt; i += 256u) {
+      const u32 node = list[i];
+      pool[2 * (size_t)node + 1] = (u32)shadow[node];
+    }
   }
+  const long long stride = (long long)gridDim.x * 256, t0 = (long long)blockIdx.x * 256 + threadIdx.x;
   for (long long i = strad_first + t0; i < strad_end; i += stride) {
     const u32 node = strad[2 * i];
     if (node != kNoStraddler) pool[2 * (size_t)node + 1] = (u32)shadow[node];
@@ -1819,7 +1839,7 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   unsigned long long *shadow = nullptr;
   u32 epoch = 0, *apply_nodes = nullptr;
   if (deferred) {
-    SVO_TRY(ws->apply_nodes.reserve((size_t)n * (size_t)depth * 4));
+    SVO_TRY(ws->apply_nodes.reserve(((size_t)fill_tiles * kFillThreads * (size_t)depth + (size_t)fill_tiles) * 4));  // lists + counts
     apply_nodes = ws->apply_nodes.as<u32>();
     SVO_TRY(pool_shadow_begin(pool, stream, &shadow, &epoch));
     ws->deferred_pool = pool; ws->deferred_n = n; ws->deferred_depth = depth; ws->deferred_tiles = fill_tiles;
@@ -1897,11 +1917,10 @@ int svo_fuse_apply(svoslam_workspace *ws, svoslam_pool *pool, hipStream_t stream
   unsigned long long *shadow = nullptr;
   u32 epoch = 0;
   SVO_TRY(pool_shadow_current(pool, &shadow, &epoch));
-  const long long slots = (long long)n * depth;
-  int blocks = (int)cdiv(slots, 256 * 4);
+  int blocks = tiles;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  commit_apply_kernel<<<blocks, 256, 0, stream>>>(pool->d_data, shadow, ws->apply_nodes.as<u32>(), slots, ws->strad.as<u32>(), tiles,
+  commit_apply_kernel<<<blocks, 256, 0, stream>>>(pool->d_data, shadow, ws->apply_nodes.as<u32>(), tiles, kFillThreads * depth, ws->strad.as<u32>(), tiles,
                                                   depth * tiles, ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>(),
                                                   small_counts(ws), small_n0(ws));
   SVO_LAUNCH_CHECK();

@@ -48,7 +48,7 @@ struct svoslam_workspace {
   svoslam::DeviceBuffer path_nodes;                       // [(D-1)][n] node index per owned depth (mip lists)
   svoslam::DeviceBuffer strad;                            // [D][tiles][2] nodes whose leaf run crosses a workgroup (async commit)
   svoslam::DeviceBuffer strad_b;                          // the same for the commit of the plan to a second replica of the pool
-  svoslam::DeviceBuffer apply_nodes;                      // deferred commit: [D][n] node written by sorted key j at each level
+  svoslam::DeviceBuffer apply_nodes;                      // deferred commit: per fill tile, the nodes its workgroup wrote (dense from the tile's start; counts behind the lists)
   // deferred commit waiting for svo_fuse_apply (what the apply launch needs)
   const void *deferred_pool = nullptr;
   int deferred_n = 0, deferred_depth = 0, deferred_tiles = 0;
