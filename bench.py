@@ -116,6 +116,57 @@ def cpu_baseline(depth_frames, rgb_frames, views, first, width, height, max_dept
                       % (first + 1, first + n_done, width, height, max_depth, n_done, pool.size, flags, t_total)}
 
 
+def device_memory(P, torch):
+    """what the session holds on the device: the pool's reservation, the deferred commits' shadow array (8 B per
+    node of capacity, when deferred commits are on), the occupancy bricks' dense field (2 x 2048^3 bytes, taken only when three times
+    its size is free), the level grid (256^3 x 8 B), and what the process has allocated in total"""
+    GiB = float(1 << 30)
+    free_b, total_b = torch.cuda.mem_get_info()
+    cap = int(P.pool.capacity)
+    return {"pool_reserved": cap * 8 / GiB, "pool_used": int(P.pool.size) * 8 / GiB, "deferred_shadow_if_on": cap * 8 / GiB,
+            "brick_field_if_taken": 16.0, "level_grid": (256 ** 3) * 8 / GiB,
+            "device_in_use_all_processes": (total_b - free_b) / GiB, "device_total": total_b / GiB}
+
+
+def other_configs(args):
+    """the other BASELINE configurations, each in a child process on the same GPU; a failure is IN the record"""
+    out = {}
+
+    def child(cmd, timeout):
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                return {"error": "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}, time.perf_counter() - t0
+            return json.loads(lines[-1]), time.perf_counter() - t0
+        except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+            return {"error": repr(e)}, time.perf_counter() - t0
+
+    me = os.path.abspath(__file__)
+    d, w = child([sys.executable, me, "--workload", "cfg4", "--steps", "40", "--warmup", "5", "--repeats", "3", "--lean", "--cpu-budget", "7"]
+                 + (["--no-cpu-baseline"] if args.no_cpu_baseline else []), 300)
+    if "error" in d:
+        out["cfg4"] = d
+    else:
+        keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "runs", "value_min", "value_max", "dtype", "roofline", "roofline_stages",
+                "stages_sequential", "cpu_baseline")
+        out["cfg4"] = {k: d[k] for k in keep if k in d}
+        out["cfg4"]["workload"] = d["config"]["workload"]
+        out["cfg4"]["overlap"] = d["config"]["overlap"]
+        out["cfg4"]["pool_nodes_end"] = d["config"].get("pool_nodes_end")
+        out["cfg4"]["mrays_per_s"] = d["config"].get("mrays_per_s")
+        out["cfg4"]["what"] = ("BASELINE config 4 on ONE GPU (its 8-GPU tiling is bench.py --gpus 8 --workload cfg4): `python bench.py --workload cfg4 --steps 40 "
+                               "--warmup 5 --repeats 3 --lean` in a child process; median of 3 windows of 40 frames from an empty map")
+    out["cfg4"]["wall_s"] = w
+    mb = os.path.join(ROOT, "tools", "mesh_bench.py")
+    for cfg in ("cfg2", "cfg5"):
+        d, w = child([sys.executable, mb, "--config", cfg, "--reps", "2" if cfg == "cfg5" else "3"], 300)
+        d["wall_s"] = w
+        out[cfg] = d
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,11 +205,20 @@ def main():
     ap.add_argument("--allow-missing-traffic", action="store_true",
                     help="profiles/pmc_traffic.json incomplete for this workload: report traffic null instead of failing "
                          "(used by the profiling script that GENERATES that file)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default single-GPU cfg3 run: do not add `other_configs` (cfg4 through this script in a child process, the mesh "
+                         "configurations cfg2 / cfg5 through tools/mesh_bench.py)")
+    ap.add_argument("--lean", action="store_true",
+                    help="the line without its side measurements (latency window, pipeline fill, corrected-tracker line): what the "
+                         "`other_configs.cfg4` child process runs")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of single-thread CPU oracle work for `cpu_baseline`")
     ap.add_argument("--stages", action="store_true",
                     help="add `stages` (per-stage durations from HIP-event marks at the stage boundaries, svoslam_runner_timeline); "
                          "the ~10 extra event records per frame cost ~6 %% of the frame rate, so they are off for the headline line")
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
+    wall = {}
     import numpy as np
     import torch
     import svoslam_pkg
@@ -376,7 +436,7 @@ def main():
     # latency of the five-stream schedule.  T(K) = fill + K x period, measured with a second window over the last K / 2
     # frames of the same stream (same map at the end): period = (T(K) - T(K/2)) / (K - K/2), fill = T(K) - K x period.
     fill = None
-    if R > 1 and K >= 8 and not args.no_overlap and not args.include_h2d:
+    if R > 1 and K >= 8 and not args.no_overlap and not args.include_h2d and not args.lean:
         half = sorted(timed_window(t0w + K // 2)["elapsed"] for _ in range(3))[1]
         period = (elapsed - half) / (K // 2)
         if period > 0:
@@ -574,7 +634,7 @@ def main():
     # window on a pipeline whose runner records HIP-event marks at the stage boundaries (the marks cost ~6 % of the rate, which
     # is why the timed windows above run without them); mean over its frames of first map kernel -> end of the frame's march.
     latency = None
-    if single and not args.no_overlap and not args.stages and not args.include_h2d and K > 8:
+    if single and not args.no_overlap and not args.stages and not args.include_h2d and K > 8 and not args.lean:
         try:
             pkg.configure(runner_timeline=1)     # (read when the pipeline's runner is created: at its first stream call, inside the window)
             cur["P"] = pl.SlamPipeline(width, height, max_depth, center, edge, render_mode=mode, count_steps=True, strict_reference=strict,
@@ -595,7 +655,7 @@ def main():
     # (with it the stream exercises alpha saturation, ray retirement through the bricks' A >= 254 bits,
     # fusion dominated by read-modify-writes of existing leaves).  Never `value`.
     corrected_line = None
-    if single and strict and not args.no_overlap and not args.no_corrected_line and not args.include_h2d:
+    if single and strict and not args.no_overlap and not args.no_corrected_line and not args.include_h2d and not args.lean:
         try:
             cur["P"] = pl.SlamPipeline(width, height, max_depth, center, edge, render_mode=mode, count_steps=True, strict_reference=False,
                                        pool_capacity_nodes=(1 << 30) - 8)
@@ -663,7 +723,8 @@ def main():
                                    else "4 HIP streams: maps(k+2) | ICP(k+1) | back-project+sort+plan(k+1) | commit+raycast(k)"),
                        "frames_in_map_at_end": total, "frames_fused_untimed_before_warmup": pre, "frames_input": "pinned host memory, uploaded inside the timed region" if args.include_h2d else "resident in HBM",
                        "raycast_views": "ground-truth sensor poses (the reference renders from a free GLFW camera)",
-                       "mrays_per_s": width * rows / (kern_ms * 1e-3) / 1e6, **(end_state or {})},
+                       "mrays_per_s": width * rows / (kern_ms * 1e-3) / 1e6,
+                       "device_memory_GiB": device_memory(P, torch), **(end_state or {})},
             "roofline": roofline,
             "roofline_stages": roofs,
         }
@@ -679,10 +740,26 @@ def main():
             out["corrected_tracker"] = corrected_line
         if latency:
             out["latency"] = latency
+        wall["gpu_legs_s"] = time.perf_counter() - t_start
+        # ---- the other BASELINE configurations on the same line: cfg4 = this script in a child process
+        # (3 windows of 40 frames, per-stage rooflines, a short CPU leg), cfg2 / cfg5 = tools/mesh_bench.py (voxelize, SVO build,
+        # renders in both modes).  GPU legs, ahead of this process's CPU oracle.
+        if single and args.workload == "cfg3" and not args.no_other_configs and not args.lean and not args.no_overlap and not args.include_h2d:
+            t_o0 = time.perf_counter()
+            out["other_configs"] = other_configs(args)
+            wall["other_configs_s"] = time.perf_counter() - t_o0
         if not args.no_cpu_baseline:
             history(t0w)          # the map and the pose the timed frames started from
             seed_words = pool_i32().cpu().numpy().view(np.uint32) if t0w > 0 else None
-            out["cpu_baseline"] = cpu_baseline(depth[:total], rgb[:total], views, t0w, width, height, max_depth, center, edge, seed_words, P.cam.pose())
+            t_cpu0 = time.perf_counter()
+            out["cpu_baseline"] = cpu_baseline(depth[:total], rgb[:total], views, t0w, width, height, max_depth, center, edge, seed_words, P.cam.pose(),
+                                               budget_s=args.cpu_budget)
+            wall["cpu_baseline_s"] = time.perf_counter() - t_cpu0
+        wall["total_s"] = time.perf_counter() - t_start
+        wall["note"] = ("wall clock of this process: gpu_legs_s = import + stream generation + every GPU window of this workload; other_configs_s = "
+                        "the child processes (GPU); cpu_baseline_s = the single-thread CPU oracle (the GPU idles: a 5-second SMI sample taken "
+                        "there reads 0 % busy)")
+        out["wall"] = wall
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         import torch.distributed as tdist

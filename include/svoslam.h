@@ -298,6 +298,10 @@ int svoslam_texture_free(svoslam_texture *tex);
 int svoslam_mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const svoslam_texture *tex, int32_t log_N,
                                int32_t log_T, float **d_centers, float **d_colors, unsigned long long **d_indices,
                                int32_t *n_out, float *scale_out, void *stream);
+/* Statistics of the workspace's LAST svoslam_mesh_to_voxel_grid (measurement aid, no reference counterpart): the number of
+ * (cell, triangle) fragments the scan-line rasteriser emitted and sorted -- the unit of the voxelizer's per-stage algorithmic
+ * bytes; 0 before any call. */
+int svoslam_mesh_last_fragments(const svoslam_workspace *ws, int64_t *fragments_out);
 
 /* replaces voxelization::voxelGridToMesh (include/octree_slam/world/voxelization/voxelization.h:19,
  * src/world/voxelization/voxelization.cu:184-217, :325-379; SURVEY 8f.4, a display aid): one copy of the cube mesh
@@ -407,7 +411,10 @@ int svoslam_cone_trace_timing_read(float *h_ms_sum, int32_t *h_launches);
 #define SVOSLAM_STAGE_FUSE_PLAN 3    /* split planning (+ the early tile initialisation) */
 #define SVOSLAM_STAGE_FUSE_COMMIT 4  /* splits, leaf blend, mip levels */
 #define SVOSLAM_STAGE_MAPS 5         /* bilateral filter + vertex / normal pyramids */
-#define SVOSLAM_STAGE_COUNT 6
+#define SVOSLAM_STAGE_MESH_RASTER 6  /* meshToVoxelGrid: scan-line counts + scans + fragment emission (incl. the two count readbacks) */
+#define SVOSLAM_STAGE_MESH_SORT 7    /* meshToVoxelGrid: sort of the (cell, triangle) fragments */
+#define SVOSLAM_STAGE_MESH_EMIT 8    /* meshToVoxelGrid: last fragment per cell -> voxel centres + colours (incl. the count readback) */
+#define SVOSLAM_STAGE_COUNT 9
 int svoslam_stage_timing(uint32_t mask);
 int svoslam_stage_timing_read(int32_t stage, float *h_ms_sum, int32_t *h_pairs);
 
@@ -561,7 +568,8 @@ int svoslam_camera_set_rgbd(svoslam_camera *cam, int32_t enable);
  *     Rz(-x2) * Ry(-x1) * Rx(-x0) * translate(..) (rgbd_camera.cpp:154-158);
  *   - position = (position + t) * update_trans in the row-vector product of rgbd_camera.cpp:172 (Q17 drops t), so that
  *     main.cpp:40's orientation * (x + position) composes the frame-to-frame transforms.
- * Restated in oracle/svoslam_oracle.c (ora_camera_set_strict_reference) and a second time in tests/test_cpu_corrected.py.
+ * Restated in oracle/svoslam_oracle.c (ora_camera_set_strict_reference) and a second time in tests/test_oracle_second_opinion.py
+ * (track_second_opinion(..., corrected=True)).
  * Before the first frame only; not combined with the photometric term. */
 int svoslam_camera_set_strict_reference(svoslam_camera *cam, int32_t strict);
 /* Frame-to-model tracking (second half).  OWN SPECIFICATION: the reference tracks every frame against the

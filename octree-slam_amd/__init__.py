@@ -124,6 +124,7 @@ SIGNATURES = {
     "svoslam_texture_free": (C.c_int, [C.POINTER(TextureStruct)]),
     "svoslam_mesh_to_voxel_grid": (C.c_int, [_vp, C.POINTER(MeshStruct), C.POINTER(TextureStruct), _i32, _i32, C.POINTER(_vp),
                                              C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _fp, _vp]),
+    "svoslam_mesh_last_fragments": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "svoslam_voxel_grid_to_mesh": (C.c_int, [_vp, _vp, _vp, _i32, _f32, _fp, _i32, C.POINTER(C.c_int32), _i32, _fp, _vp, _vp, _vp, _vp, _vp]),
     "svoslam_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
     "svoslam_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
@@ -622,6 +623,13 @@ def mesh_to_voxel_grid(ws, mesh, tex, log_n, log_t=3, want_indices=True):
     return ce, co, idx, float(scale.value)
 
 
+def mesh_last_fragments(ws):
+    """(cell, triangle) fragments of the workspace's last mesh_to_voxel_grid (measurement aid)"""
+    n = C.c_int64(0)
+    check(lib().svoslam_mesh_last_fragments(ws._h, C.byref(n)))
+    return int(n.value)
+
+
 def voxel_grid_to_mesh(ws, centers, colors, scale_factor, cube_vbo, cube_ibo, cube_nbo):
     """voxelization::voxelGridToMesh: centers, colors cuda float32 [n,4]; cube arrays numpy -> cuda (vbo, ibo, nbo, cbo)."""
     import torch
@@ -884,8 +892,9 @@ def cone_trace_timing_read():
     return float(ms.value), int(n.value)
 
 
-STAGE_MARCH, STAGE_TRACKER, STAGE_FUSE_SORT, STAGE_FUSE_PLAN, STAGE_FUSE_COMMIT, STAGE_MAPS = range(6)   # SVOSLAM_STAGE_*
-STAGE_NAMES = ("march", "tracker", "fuse_sort", "fuse_plan", "fuse_commit", "maps")
+(STAGE_MARCH, STAGE_TRACKER, STAGE_FUSE_SORT, STAGE_FUSE_PLAN, STAGE_FUSE_COMMIT, STAGE_MAPS, STAGE_MESH_RASTER, STAGE_MESH_SORT,
+ STAGE_MESH_EMIT) = range(9)   # SVOSLAM_STAGE_*
+STAGE_NAMES = ("march", "tracker", "fuse_sort", "fuse_plan", "fuse_commit", "maps", "mesh_raster", "mesh_sort", "mesh_emit")
 
 
 def stage_timing(stages):

@@ -327,6 +327,12 @@ int svoslam_mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, 
   return mesh_to_voxel_grid(ws, mesh, tex, log_N, log_T, d_centers, d_colors, d_indices, n_out, scale_out, S(stream));
 }
 
+int svoslam_mesh_last_fragments(const svoslam_workspace *ws, int64_t *fragments_out) {
+  if (!ws || !fragments_out) return SVOSLAM_ERR_INVALID_ARG;
+  *fragments_out = ws->mesh_fragments;
+  return SVOSLAM_OK;
+}
+
 int svoslam_voxel_grid_to_mesh(svoslam_workspace *ws, const float *d_centers, const float *d_colors, int32_t n, float scale_factor,
                                const float *cube_vbo, int32_t cube_vbosize, const int32_t *cube_ibo, int32_t cube_ibosize,
                                const float *cube_nbo, float *d_vbo, int32_t *d_ibo, float *d_nbo, float *d_cbo, void *stream) {

@@ -32,7 +32,7 @@ struct GraphKey {
 
 // Off by default since round 2: with the tracker in one launch a frame is ~37 launches, which the host enqueues in
 // ~0.15 ms against a 0.4 ms frame, and direct launches turned out 4-5 % faster than replaying the same sequences as
-// graphs (2494 against 2380 frames/s at cfg3; no difference at cfg4).  SVOSLAM_GRAPHS=1 turns the replay on -- worth
+// graphs (2494 against 2380 frames/s at cfg3; no difference at cfg4).  svoslam_config.graphs = 1 turns the replay on -- worth
 // it where the host is the bottleneck (several ranks sharing few cores, the 38-launch chain tracker on a slow host).
 inline bool graphs_enabled() {
   const bool on = config().graphs != 0;

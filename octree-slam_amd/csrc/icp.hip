@@ -959,8 +959,10 @@ int camera_set_strict_reference(svoslam_camera *c, int strict) {
   if (!c) return SVOSLAM_ERR_INVALID_ARG;
   if (c->prepared != 0 && (strict == 0) != c->corrected) return SVOSLAM_ERR_INVALID_ARG;
   if (!strict && c->rgbd) return SVOSLAM_ERR_INVALID_ARG;  // (the photometric term shares the reference's rows: not combined)
+  if ((strict == 0) == c->corrected) return SVOSLAM_OK;   // unchanged value: nothing to do at ANY time (as camera_set_rgbd; ADVICE r04:
+  // a defensive set_strict_reference(cam, 1) after frames had been processed used to wipe pose, frame count and sync words)
   c->corrected = strict == 0;
-  return camera_reset(c);
+  return camera_reset(c);  // (prepared == 0 here: the mode flag lives in the device state the reset rewrites)
 }
 
 // RGBDCamera with the photometric term of rgbd_camera.cpp:126-141 switched on (W_RGBD = 0.1); before the first frame only

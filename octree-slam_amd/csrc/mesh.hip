@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "mesh.hpp"
+#include "stage_timing.hpp"
 #include "radix_sort.hpp"
 #include "wave_rank.hpp"
 
@@ -294,6 +295,7 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   if (d_indices) *d_indices = nullptr;
   if (scale_out) *scale_out = (mesh->bbox1[0] - mesh->bbox0[0]) / (float)(1 << log_N) / 2.0f;  // computeScale, :78-80
   const int n_tris = mesh->n_tris;
+  ws->mesh_fragments = 0;
   if (n_tris <= 0) return SVOSLAM_OK;
   const GridParams G = make_grid(mesh->bbox0, mesh->bbox1, log_N, log_T);
   // upload mesh + texture
@@ -311,6 +313,8 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   SVO_TRY(ws->leaf_f.reserve((size_t)n_tris * 4));
   u32 *tri_start = ws->leaf_f.as<u32>();
   u32 *d_total = ws->small.as<u32>();
+  long long tk_raster = -1, tk_sort = -1, tk_emit = -1;  // per-stage event brackets (svoslam_stage_timing; off by default)
+  (void)stage_begin(kStageMeshRaster, stream, &tk_raster);
   tri_scanline_count_kernel<<<cdiv(n_tris, 256), 256, 0, stream>>>(dv.as<float>(), n_tris, G, tri_start);
   SVO_TRY(exclusive_scan_u32(ws, tri_start, (u32)n_tris, d_total, stream));
   u32 total_scan = 0;
@@ -329,6 +333,7 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   if (total_frag == 0) return SVOSLAM_OK;
   if (total_frag > 0x7FFFFFFFu) return SVOSLAM_ERR_OOM;
   const int nf = (int)total_frag;
+  ws->mesh_fragments = nf;
   SVO_TRY(ws->keys_a.reserve((size_t)nf * 8));
   SVO_TRY(ws->keys_b.reserve((size_t)nf * 8));
   SVO_TRY(ws->vals_a.reserve((size_t)nf * 4));
@@ -337,11 +342,15 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   scanline_kernel<true><<<cdiv(total_scan, 256), 256, 0, stream>>>(dv.as<float>(), n_tris, tri_start, total_scan, G, nullptr,
                                                                   frag_start, ws->keys_a.as<u64>(), ws->vals_a.as<u32>());
   SVO_LAUNCH_CHECK();
+  (void)stage_end(kStageMeshRaster, tk_raster, stream);
   // order by framebuffer index (stable: equal cells keep ascending triangle id)
   u64 *skey = nullptr; u32 *stri = nullptr;
+  (void)stage_begin(kStageMeshSort, stream, &tk_sort);
   SVO_TRY(radix_sort_pairs(ws, nf, 3 * log_N, stream, &skey, &stri, false));
+  (void)stage_end(kStageMeshSort, tk_sort, stream);
   const int tiles = (int)cdiv(nf, 256);
   u32 *tile_cnt = ws->tile_hist.as<u32>();
+  (void)stage_begin(kStageMeshEmit, stream, &tk_emit);
   voxel_flag_kernel<<<tiles, 256, 0, stream>>>(skey, (u32)nf, tile_cnt);
   SVO_TRY(exclusive_scan_u32(ws, tile_cnt, (u32)tiles, d_total, stream));
   u32 n_vox = 0;
@@ -355,6 +364,7 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   voxel_emit_kernel<<<tiles, 256, 0, stream>>>(skey, stri, (u32)nf, tile_cnt, G, dx.as<float>(), tw, th, dt.as<float>(), tbosize,
                                                reinterpret_cast<float4 *>(ce), reinterpret_cast<float4 *>(co), ix);
   SVO_LAUNCH_CHECK();
+  (void)stage_end(kStageMeshEmit, tk_emit, stream);
   SVO_HIP(hipStreamSynchronize(stream));
   *d_centers = ce; *d_colors = co; *n_out = (int32_t)n_vox;
   if (d_indices) *d_indices = ix;

@@ -387,8 +387,16 @@ __device__ inline BrickRings brick_rings(uint32_t *dirty_a, uint32_t *dirty_b, i
   }
   return r;
 }
-__device__ inline bool brick_rings_lapped(const BrickRings &r) {
-  return r.count[0] - r.first[0] > (uint32_t)kBrickListCap || r.count[1] - r.first[1] > (uint32_t)kBrickListCap;
+__device__ inline bool brick_rings_lapped(const BrickRings &r, uint32_t cap = (uint32_t)kBrickListCap) {
+  return r.count[0] - r.first[0] > cap || r.count[1] - r.first[1] > cap;
+}
+// Either ring of the served states has lost entries since the last refresh.  The sibling ring counts too: with shape
+// S = 1 a childless level-9 sibling's eight bricks carry stop code 5, and only the path's brick is rebuilt through the main ring
+// when a key later enters it -- a lost sibling entry would leave seven lines saying "childless" that the march answers at level 9
+// without the tree.  Both cases take the same way out: every group zeroed ("ask the level grid"), bricks come back as commits touch them.
+__device__ inline bool brick_rings_lost(uint32_t *dirty_a, uint32_t *dirty_b, int par_a, int par_b) {
+  return brick_rings_lapped(brick_rings(dirty_a, dirty_b, par_a, par_b, false)) ||
+         brick_rings_lapped(brick_rings(dirty_a, dirty_b, par_a, par_b, false, kSibCountOffset), (uint32_t)kSibListCap);
 }
 
 // one wavefront per listed brick, C of them side by side; `part` of `parts` wavefronts
@@ -423,9 +431,8 @@ __device__ inline void brick_siblings_listed(const uint2 *__restrict__ nodes, co
                                              uint32_t part, uint32_t parts, unsigned lane) {
   for (int state = 0; state < 2; state++) {
     const uint32_t *dirty = state ? dirty_b : dirty_a;
-    uint32_t pending = r.count[state] - r.first[state];
+    const uint32_t pending = r.count[state] - r.first[state];  // (<= kSibListCap: a lapped ring does not get here, brick_rings_lost)
     const uint32_t first = r.first[state];
-    if (pending > (uint32_t)kSibListCap) pending = (uint32_t)kSibListCap;  // lapped: the newest entries (the others' siblings walk the tree)
     for (uint32_t i = part; i < pending; i += parts) {
       const uint32_t f = dirty[kSibListOffset + ((first + i) & (uint32_t)(kSibListCap - 1))] & 0x07FFFFFFu;
       brick_siblings<S>(nodes, grid, bricks, touched, f & 511u, (f >> 9) & 511u, f >> 18, lane);
@@ -551,13 +558,13 @@ __global__ __launch_bounds__(kBrickThreads) void pool_refresh_kernel(const uint3
     pool_grid_update_blocks(nodes, grid, dirty_a, dirty_b, bb - brick_blocks, kRefreshGridBlocks);
     // ... and the childless siblings of the listed bricks whose commit created them (brick_siblings_listed)
     const BrickRings rs = brick_rings(dirty_a, dirty_b, par_a, par_b, bb == brick_blocks && threadIdx.x == 0, kSibCountOffset);
-    if (!brick_rings_lapped(brick_rings(dirty_a, dirty_b, par_a, par_b, false)))  // (a lapped brick ring zeroes every group: nothing to complete)
+    if (!brick_rings_lost(dirty_a, dirty_b, par_a, par_b))  // (a lapped ring zeroes every group: nothing to complete)
       brick_siblings_listed<S>(nodes, grid, bricks, touched, dirty_a, dirty_b, rs, (bb - brick_blocks) * kWaves + wave, kRefreshGridBlocks * kWaves, lane);
     return;
   }
   const BrickRings r = brick_rings(dirty_a, dirty_b, par_a, par_b, bb == 0 && threadIdx.x == 0);
-  if (brick_rings_lapped(r)) {
-    // more than a million distinct bricks listed since the last refresh (never seen): the ring has lost entries.  Every group
+  if (brick_rings_lost(dirty_a, dirty_b, par_a, par_b)) {
+    // more than a million distinct bricks (or 65536 sibling entries) listed since the last refresh: a ring has lost entries.  Every group
     // that holds bricks is zeroed ("ask the level grid": such samples walk the tree, correctly) and every brick may be listed
     // again; the bricks come back as commits touch them.
     for (uint32_t w = bb * kBrickThreads + threadIdx.x; w < (uint32_t)kBrickBitsWords; w += brick_blocks * kBrickThreads) {

@@ -97,7 +97,7 @@ bool pool_shadow_pending(svoslam_pool *pool);
 
 // enqueue on `stream`: bring the grid of `pa` up to date with its pool (full build or dirty blocks only); returns the grid
 // want_bricks: also bring the occupancy bricks up to date (allocating them on first use); *d_bricks = the field, or
-// nullptr when the pool has none (not wanted so far, SVOSLAM_MARCH_BRICKS=0, or no memory for them)
+// nullptr when the pool has none (not wanted so far, svoslam_config.march_bricks = 0, or no memory for them)
 int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stream, const uint2 **d_grid, bool want_bricks,
                        const uint16_t **d_bricks, int *brick_shift, uint32_t *tile_cost = nullptr, uint32_t *tile_order = nullptr,
                        int n_tiles = 0, bool *order_done = nullptr);

@@ -18,7 +18,7 @@
 // commit 0.133 ms + build/march 0.272 ms = 0.405 ms; with TWO the replica streams do overlap but every kernel gets
 // slower -- march 0.27 -> 0.41 ms, commit 0.13 -> 0.22-0.29 ms, maps 0.10 -> 0.37 ms -- because the march keeps
 // ~4800 wavefronts (66 % of the VGPR file) resident for its whole duration and the tracker's 151 workgroups want
-// the other half: 0.52-0.55 ms per frame against 0.41-0.43.  The schedule is therefore OPT-IN (SVOSLAM_RUNNER_REPLICAS=2;
+// the other half: 0.52-0.55 ms per frame against 0.41-0.43.  The schedule is therefore OPT-IN (svoslam_config.runner_replicas = 2;
 // it is also the single-GPU form of pipelining the stages over several GPUs, where each replica has a GPU to itself);
 // the default is one pool.
 //
@@ -495,7 +495,7 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
       if (i + 1 < n) SVO_TRY(enqueue_track(i + 1));
       if (i + 2 < n) SVO_TRY(enqueue_maps(i + 2));  // (one stream: behind track i+1, ahead of track i+2 -- two map sets ahead at most)
       const int a = i & (R - 1);  // the replica frame i is marched on: it gets commit i first
-      // The host stays at most `lead` commits ahead of the device (default 2; SVOSLAM_RUNNER_LEAD=0: as far as the
+      // The host stays at most `lead` commits ahead of the device (default 2; svoslam_config.runner_lead = 0: as far as the
       // pool's size ring allows, 8).  Whatever has been enqueued when the host STOPS enqueuing drains at 0.6 ms per
       // frame instead of 0.32 (measured with HIP events per stage: the kernels themselves keep their durations and the
       // clock stays at 2.4 GHz, the gaps between them grow; AMD_DIRECT_DISPATCH=0 does not show it but costs 10 % in
@@ -567,7 +567,7 @@ int svoslam_runner_bbox(svoslam_runner *r, float h_bbox7[7]) {
 
 // diagnostic: milliseconds of the stage marks of the last call relative to its first mark, h_ms[frames][10] =
 // {maps begin, maps end, track begin, pose, prepare begin, plan begin, plan end, commit begin, commit end, march end}
-// (-1 where unavailable); needs SVOSLAM_RUNNER_TIMELINE=1 at creation.  Blocking.
+// (-1 where unavailable); needs svoslam_config.runner_timeline = 1 at creation.  Blocking.
 int svoslam_runner_timeline(svoslam_runner *r, float *h_ms, int32_t max_frames, int32_t *frames) {
   if (!r || !h_ms || !frames) return SVOSLAM_ERR_INVALID_ARG;
   *frames = 0;

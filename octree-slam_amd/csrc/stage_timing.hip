@@ -9,9 +9,10 @@ namespace svoslam {
 namespace {
 std::mutex g_mu;  // stages are enqueued from several host threads / on several streams
 unsigned g_mask = 0;
-unsigned g_generation = 1;  // advanced whenever a log is cleared: a bracket that began before does not end into the new log
 struct Entry { hipEvent_t start = nullptr, stop = nullptr; bool done = false; };
-struct Log { std::vector<Entry> e; size_t used = 0; };  // entries since the last read
+// gen: advanced whenever THIS stage's log is cleared, so that a bracket that began before does not end into the new log.  Per stage
+// (ADVICE r04): reading stage A while stage B's brackets are open on other streams used to drop B's open brackets as well
+struct Log { std::vector<Entry> e; size_t used = 0; unsigned gen = 1; };  // entries since the last read
 Log g_log[kStageCount];
 }  // namespace
 
@@ -23,8 +24,7 @@ unsigned stage_timing_mask() {
 int stage_timing(unsigned mask) {
   std::lock_guard<std::mutex> lock(g_mu);
   g_mask = mask;
-  g_generation++;
-  for (Log &l : g_log) l.used = 0;
+  for (Log &l : g_log) { l.used = 0; l.gen++; }
   return SVOSLAM_OK;
 }
 
@@ -45,7 +45,7 @@ int stage_timing_read(int stage, float *ms_sum, int *pairs) {
   *ms_sum = total;
   *pairs = n;
   l.used = 0;
-  g_generation++;
+  l.gen++;
   return SVOSLAM_OK;
 }
 
@@ -64,7 +64,8 @@ int stage_begin(int stage, hipStream_t stream, long long *token) {
   Entry &en = l.e[l.used];
   en.done = false;
   SVO_HIP(hipEventRecord(en.start, stream));  // (on failure the entry is not taken)
-  *token = ((long long)g_generation << 32) | (long long)l.used;
+  // generation in bits 32..62 (the token stays non-negative: -1 means "stage off"), entry index below
+  *token = (long long)((((unsigned long long)l.gen & 0x7FFFFFFFull) << 32) | (unsigned long long)l.used);
   l.used++;
   return SVOSLAM_OK;
 }
@@ -73,8 +74,8 @@ int stage_end(int stage, long long token, hipStream_t stream) {
   if (token < 0) return SVOSLAM_OK;
   if (stage < 0 || stage >= kStageCount) return SVOSLAM_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lock(g_mu);
-  if ((unsigned)(token >> 32) != g_generation) return SVOSLAM_OK;  // the log was cleared in between: the bracket is dropped
   Log &l = g_log[stage];
+  if ((unsigned)((unsigned long long)token >> 32) != (l.gen & 0x7FFFFFFFu)) return SVOSLAM_OK;  // the log was cleared in between: the bracket is dropped
   const size_t i = (size_t)(token & 0xFFFFFFFFll);
   if (i >= l.used) return SVOSLAM_OK;
   SVO_HIP(hipEventRecord(l.e[i].stop, stream));

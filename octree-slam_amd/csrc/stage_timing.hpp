@@ -17,6 +17,9 @@ enum Stage {
   kStageFusePlan = SVOSLAM_STAGE_FUSE_PLAN,   // plan_count + plan_scan_finish + plan_emit (+ early split_all)
   kStageFuseCommit = SVOSLAM_STAGE_FUSE_COMMIT,  // (split_all +) leaf blend / mip kernel + straddlers
   kStageMaps = SVOSLAM_STAGE_MAPS,            // bilateral + vertex / normal pyramids
+  kStageMeshRaster = SVOSLAM_STAGE_MESH_RASTER,  // mesh.hip: tri_scanline_count + scans + scanline_kernel<false / true>
+  kStageMeshSort = SVOSLAM_STAGE_MESH_SORT,      // mesh.hip: radix sort of the fragments
+  kStageMeshEmit = SVOSLAM_STAGE_MESH_EMIT,      // mesh.hip: voxel_flag + scan + voxel_emit
   kStageCount = SVOSLAM_STAGE_COUNT
 };
 

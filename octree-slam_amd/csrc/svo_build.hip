@@ -1409,16 +1409,20 @@ static inline unsigned *small_strad_ticket(svoslam_workspace *ws, int slot) { re
 
 // keys of the n inputs are in ws->keys_a
 static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, const void *d_colors, bool vec4,
-                      bool color_by_position, svoslam_fuse_stats *stats, hipStream_t stream) {
+                      bool color_by_position, svoslam_fuse_stats *stats, hipStream_t stream, long long sort_token) {
   pool_accel_invalidate(pool, depth, false);  // the blocking path does not track what it touches: the next render rebuilds the level grid
   SVO_TRY(pool_sync(pool, stream));
   u64 *skey = nullptr; u32 *sidx = nullptr;
+  long long tk = -1;  // stage brackets of the blocking path (bench.py's mesh configurations; off by default).  The sort's bracket
+  // was opened by the caller in front of its key kernel (sort_token)
   SVO_TRY(radix_sort_pairs(ws, n, 3 * depth + 1, stream, &skey, &sidx));
+  (void)stage_end(kStageFuseSort, sort_token, stream);
   const int tiles = (int)cdiv(n, 256);
   unsigned char *leaf_t = ws->leaf_t.as<unsigned char>();
   u32 *leaf_f = ws->leaf_f.as<u32>();
   u32 *tile_hist = ws->tile_hist.as<u32>();
   const int ptiles = (int)cdiv(n, kPlanThreads);
+  (void)stage_begin(kStageFusePlan, stream, &tk);
   plan_count_kernel<<<xcd_grid(ptiles), kPlanThreads, 0, stream>>>(skey, n, depth, pool->d_data, leaf_t, leaf_f, nullptr, tile_hist, ptiles, small_any(ws));
   plan_scan_finish_kernel<<<256, 256, 0, stream>>>(tile_hist, ptiles, small_totals(ws), small_ticket(ws), small_bucket_base(ws),
                                                    small_counts(ws), small_any(ws), nullptr, nullptr);
@@ -1432,6 +1436,7 @@ static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *poo
     stats->num_points = n; stats->num_split = total; stats->pool_size_before = size0;
     for (int p = 0; p <= SVOSLAM_MAX_DEPTH; p++) stats->pass_sizes[p] = hc.pass_start[p + 1] - hc.pass_start[p];
   }
+  if (total == 0) (void)stage_end(kStageFusePlan, tk, stream);
   if (total > 0) {
     SVO_TRY(grow_pool(pool, (int64_t)size0 + 8ll * total, stream));
     SVO_TRY(ws->rec_key.reserve((size_t)total * 8));
@@ -1439,6 +1444,8 @@ static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *poo
     u64 *rec_key = ws->rec_key.as<u64>();
     u32 *rec_front = ws->rec_front.as<u32>();
     plan_emit_kernel<<<xcd_grid(ptiles), kPlanThreads, 0, stream>>>(skey, n, depth, leaf_t, leaf_f, small_bucket_base(ws), tile_hist, ptiles, rec_key, rec_front, nullptr, nullptr);
+    (void)stage_end(kStageFusePlan, tk, stream);
+    (void)stage_begin(kStageFuseCommit, stream, &tk);
     for (int p = 0; p <= SVOSLAM_MAX_DEPTH; p++) {  // expandTreeAtKeys, svo.cu:278-289
       const int begin = hc.pass_start[p], end = hc.pass_start[p + 1];
       if (end > begin)
@@ -1446,10 +1453,12 @@ static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *poo
     }
     if (pool->d_size) pool_size_update_kernel<<<1, 64, 0, stream>>>(pool->d_size, small_counts(ws));
     SVO_LAUNCH_CHECK();
+    (void)stage_end(kStageFuseCommit, tk, stream);
     pool->size = size0 + 8 * total;
   }
   if (stats) stats->pool_size_after = pool->size;
   if (hc.any_valid) {
+    (void)stage_begin(kStageFuseCommit, stream, &tk);  // (a second entry of the stage: the reader sums them)
     u32 *path_nodes = ws->path_nodes.as<u32>();
     if (vec4)
       fill_kernel<true><<<tiles, 256, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, color_by_position, pool->d_data, path_nodes);
@@ -1459,6 +1468,7 @@ static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *poo
       mip_level_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, d, leaf_t, path_nodes, pool->d_data);
     mip_root_kernel<<<1, 64, 0, stream>>>(pool->d_data, small_counts(ws));
     SVO_LAUNCH_CHECK();
+    (void)stage_end(kStageFuseCommit, tk, stream);
   }
   return SVOSLAM_OK;
 }
@@ -1947,8 +1957,10 @@ int svo_from_point_cloud(svoslam_workspace *ws, const float *d_points, const uin
     return SVOSLAM_OK;
   }
   SVO_TRY(reserve_common(ws, n, depth));
+  long long tk = -1;
+  (void)stage_begin(kStageFuseSort, stream, &tk);
   compute_keys_kernel<3><<<cdiv(n, 256), 256, 0, stream>>>(d_points, n, depth, center[0], center[1], center[2], edge, ws->keys_a.as<u64>());
-  return svo_insert(ws, n, depth, pool, d_colors, false, false, stats, stream);
+  return svo_insert(ws, n, depth, pool, d_colors, false, false, stats, stream, tk);
 }
 
 int svo_from_voxel_grid(svoslam_workspace *ws, const float *d_centers, const float *d_colors, int n, int depth,
@@ -1962,10 +1974,12 @@ int svo_from_voxel_grid(svoslam_workspace *ws, const float *d_centers, const flo
     return SVOSLAM_OK;
   }
   SVO_TRY(reserve_common(ws, n, depth));
+  long long tk = -1;
+  (void)stage_begin(kStageFuseSort, stream, &tk);
   compute_keys_kernel<4><<<cdiv(n, 256), 256, 0, stream>>>(d_centers, n, depth, center[0], center[1], center[2], edge, ws->keys_a.as<u64>());
   // Q20 (svo.cu:601-602,629): the reference sorts the keys alone, so sorted key i
   // stays paired with colour i -> color_by_position
-  return svo_insert(ws, n, depth, pool, d_colors, true, true, stats, stream);
+  return svo_insert(ws, n, depth, pool, d_colors, true, true, stats, stream, tk);
 }
 
 // ----------------------------------------------------------------------------

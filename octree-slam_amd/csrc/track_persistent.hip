@@ -604,7 +604,7 @@ size_t track_persistent_ticket_bytes() { return ticket_index(2, 0, 0) * sizeof(u
 // tracker stream, which does not bound the frame), and a launch on a stream other than the previous one's first waits
 // for that event.  (Recording on the previous stream at the time of the NEXT launch would cost nothing in the
 // single-stream case, but that stream may have been destroyed by then.)  Several PROCESSES sharing a device (a test
-// arrangement: bench.py's SVOSLAM_BENCH_ONE_DEVICE) use the launch chain (SVOSLAM_TRACK_CHAIN=1); a give-up still
+// arrangement: bench.py's SVOSLAM_BENCH_ONE_DEVICE) use the launch chain (svoslam_config.track_mode = 1); a give-up still
 // surfaces as an error from the camera's next readback, and travels with the delta record of a frame-sharded session.
 int track_persistent_launch(CamState *st, TrackSync *sy, unsigned *tickets, const TrackArgs &A, hipStream_t s) {
   unsigned long long *acc = reinterpret_cast<unsigned long long *>(tickets);

@@ -57,6 +57,7 @@ struct svoslam_workspace {
   svoslam::DeviceBuffer scan_tmp;                         // chunk sums of exclusive_scan_u32
   svoslam::DeviceBuffer frame_bbox;                       // fused fusion front end: arrival ticket (word 0) + workgroup bounding boxes
   svoslam::PlanCounts *h_counts = nullptr;                // pinned host
+  long long mesh_fragments = 0;                           // (cell, triangle) fragments of the last mesh_to_voxel_grid (svoslam_mesh_last_fragments)
   // phased fusion (svo_fuse_sort -> plan -> commit): where the sort left its output, what has been planned
   const unsigned long long *sorted_keys = nullptr;
   const unsigned int *sorted_idx = nullptr;

@@ -108,6 +108,39 @@ def test_bricks_deferred_commits_and_reset(env, oracle, depth):
         render_check(pkg, torch, oracle, pool, opool, w2, h2, oracle.look_at(eye, tgt, (0, 1, 0)), center, edge, ("after reset", eye))
 
 
+@pytest.mark.parametrize("depth", [13, 14])
+def test_sibling_ring_lapped_between_renders(env, oracle, depth):
+    """more than 65536 sibling-ring entries between two renders: a render first (the bricks exist and are current),
+    then new territory in > 65536 distinct bricks whose keys create tiles above the brick node's level -- the refresh must not
+    trust lines whose sibling entries the ring has lost -- then a third, small fusion into some of the same level-9 nodes"""
+    pkg, torch = env
+    rng = np.random.default_rng(900 + depth)
+    ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
+    center, edge = (0.0, 0.0, 0.0), 1.0
+
+    def fuse(pts, col):
+        pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, pool, center, edge)
+        opool.insert_cloud(pts, col, depth, center, edge)
+
+    def renders(what):
+        for eye, tgt, (w, h) in VIEWS[1:3]:
+            render_check(pkg, torch, oracle, pool, opool, w, h, oracle.look_at(eye, tgt, (0, 1, 0)), center, edge, (what, eye))
+
+    pts, col = surface_cloud(rng, 4000, jitter=0.003)
+    fuse(pts, col)
+    renders("first")
+    # 150 000 scattered points inside the bricks' window (half the root edge): ~150 000 distinct level-10 nodes of empty space
+    big = (rng.random((150000, 3), dtype=np.float32) * np.float32(0.96) - np.float32(0.48)).astype(np.float32)
+    bcol = rng.integers(0, 256, (150000, 3), dtype=np.uint8)
+    fuse(big, bcol)
+    renders("lapped")
+    # keys entering level-9 nodes whose other bricks were written as "childless siblings" (or lost): next to some of the scattered points
+    near = (big[:3000] + np.float32(0.0009)).astype(np.float32)
+    fuse(near, bcol[:3000])
+    renders("after")
+    assert np.array_equal(pool.words()[:2 * pool.size], opool.words()[:2 * pool.size])
+
+
 @pytest.mark.parametrize("depth", [12, 14])
 def test_large_render_tile_order_follows_the_previous_render(env, oracle, depth):
     """renders of more tiles than the chip holds at once (1280 x 512: 1280 tiles of 32 x 16 pixels) take their tiles in the

@@ -57,6 +57,11 @@ def test_corrected_tracker_matches_oracle(env, oracle, w, h, n):
     assert np.array_equal(_bits(cam.pose()[1]), _bits(ocam2.pose()[1]))
     with pytest.raises(pkg.SvoslamError):
         cam.set_strict_reference(True)
+    # the UNCHANGED value after frames have been processed is a no-op (it used to reset pose and frame count)
+    before = [_bits(v) for v in cam.pose()]
+    cam.set_strict_reference(False)
+    assert all(np.array_equal(a, _bits(v)) for a, v in zip(before, cam.pose()))
+    assert not np.array_equal(_bits(cam.pose()[1]), _bits(pkg.Camera(w, h, f, f).pose()[1]))   # still the tracked pose, not identity
 
 
 def test_corrected_tracker_stepping_api_and_pair_delta(env, oracle):

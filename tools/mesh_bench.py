@@ -1,13 +1,24 @@
-"""Stage timings of the mesh configurations of BASELINE.json (configs 2 and 5; SURVEY.md 8d inputs 2 and 5):
+"""Stage timings and rooflines of the mesh configurations of BASELINE.json (configs 2 and 5; SURVEY.md 8d inputs 2 and 5):
 OBJ + BMP -> sparse voxelization -> SVO -> cone-traced renders, on one MI355X.
 
-    python tools/mesh_bench.py --config cfg2        # textured ellipsoid (4 9xx triangles), depth 10, 640x480, 3 views
-    python tools/mesh_bench.py --config cfg5        # procedural colonnade (sponza.obj is not in the reference checkout),
-                                                    # depth 16, 3840x2160, whole image and 8 row bands of 270 rows
+    python tools/mesh_bench.py --config cfg2   # the reference's own objs/bunny_tex.obj + textures/texture1.bmp (data fixtures under
+                                               # tests/data), depth 10, 640x480, 3 views
+    python tools/mesh_bench.py --config cfg5   # procedural colonnade (sponza.obj is NOT in the reference checkout), depth 16, 3840x2160,
+                                               # whole image and 8 row bands of 270 rows
 
-Inputs are generated by tests/meshgen.py (the reference's objs/ are not available on the GPU box).  Prints one
-JSON object; not the driver's bench (that is bench.py): these configs are parity-test cases
-(tests/test_gpu_mesh.py), timed here for DESIGN.md section 5."""
+Prints ONE JSON object; bench.py embeds it in its line as other_configs.cfg2 / .cfg5.  Stage times are HIP-event
+brackets on the launch stream (svoslam_stage_timing: mesh_raster / mesh_sort / mesh_emit inside svoslam_mesh_to_voxel_grid, fuse_sort /
+fuse_plan / fuse_commit inside svoslam_svo_from_voxel_grid, march around each trace kernel); `call_ms` is the wall clock of the C call.
+
+Algorithmic bytes (T triangles, F (cell, triangle) fragments, V voxels, K split nodes, D depth):
+  mesh_raster   36 T (vertices) + 12 F (8-byte cell key + 4-byte triangle id written)
+  mesh_sort     24 F per 8-bit pass (12 read + 12 written), ceil(3 D / 8) passes
+  mesh_emit     12 F read + 24 T (uv) + 32 V (centre + colour vec4) written
+  voxelize call 60 T + 32 V: what meshToVoxelGrid's interface takes in and hands out (the fragments are this build's intermediate)
+  svo_from_voxel_grid   SURVEY 8d's fusion formula with 32 bytes per voxel in: 32 V + 4 D V + 8 V + 72 K + 36 K
+                        (a fresh pool: every touched inner node is split once, so sum_l U_l = K = (nodes - 8) / 8, U_D = V)
+  render        4 (levels + steps) + 4 W H, levels and steps from the kernel's own counters
+"""
 import argparse
 import json
 import os
@@ -20,6 +31,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0
 
 
 def look_at(eye, target, up=(0.0, 1.0, 0.0)):
@@ -37,6 +50,11 @@ def look_at(eye, target, up=(0.0, 1.0, 0.0)):
     return m.T.reshape(16).copy()          # column-major
 
 
+def roof(alg_bytes, ms):
+    gbs = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else None
+    return {"alg_bytes": alg_bytes, "ms": ms, "achieved_GBs": gbs, "frac": (gbs / HBM_PEAK_GBS) if gbs else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg5"])
@@ -48,54 +66,96 @@ def main():
     pkg = svoslam_pkg.load()
     torch.cuda.set_device(0)
     tmp = tempfile.mkdtemp()
-    tex_path = meshgen.write_bmp(os.path.join(tmp, "t.bmp"), 256, 256)
     if args.config == "cfg2":
-        obj = meshgen.write_sphere_obj(os.path.join(tmp, "m.obj"), rings=36, segs=70, quads=False)
+        obj = os.path.join(ROOT, "tests", "data", "bunny_tex.obj")
+        tex_path = os.path.join(ROOT, "tests", "data", "texture1.bmp")
         depth, (W, H), bands = 10, (640, 480), 1
+        what = "bunny_tex.obj + texture1.bmp (the reference's own data files, tests/data), depth-10 SVO, 640x480"
     else:
+        tex_path = meshgen.write_bmp(os.path.join(tmp, "t.bmp"), 256, 256)
         obj = meshgen.write_colonnade_obj(os.path.join(tmp, "m.obj"), n_cols=16, length=40.0, col_radius=0.004, col_height=5.0,
                                           segs=16, z_off=3.0, beam=0.002)
         depth, (W, H), bands = 16, (3840, 2160), 8
+        what = ("STAND-IN for crytek-sponza (sponza.obj is not in the reference checkout): procedural colonnade (tests/meshgen.py), "
+                "2^16 cells per axis, depth-16 SVO, 3840x2160, whole image + 8 row bands")
     mesh, tex = pkg.Mesh(obj), pkg.Texture(tex_path)
     b0, b1 = mesh.bbox()
     center, size = (b1 + b0) / np.float32(2.0), float(b1[0])     # Scene::voxelizeMeshes, scene.cpp:72-78
     ws = pkg.Workspace()
-    out = {"config": args.config, "triangles": int(mesh.n_tris), "depth": depth, "render": [W, H], "stages_ms": {}}
-    best = {}
+    T = int(mesh.n_tris)
+    out = {"config": args.config, "workload": what, "triangles": T, "depth": depth, "render": [W, H]}
+    mesh_stages = (("mesh_raster", pkg.STAGE_MESH_RASTER), ("mesh_sort", pkg.STAGE_MESH_SORT), ("mesh_emit", pkg.STAGE_MESH_EMIT))
+    fuse_stages = (("fuse_sort", pkg.STAGE_FUSE_SORT), ("fuse_plan", pkg.STAGE_FUSE_PLAN), ("fuse_commit", pkg.STAGE_FUSE_COMMIT))
+    best, best_stage = {}, {}
+    pool = None
     for rep in range(args.reps):
+        if pool is not None:
+            del pool
         pool = pkg.Pool()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        torch.cuda.synchronize()
+        pkg.stage_timing([s for _, s in mesh_stages + fuse_stages])
+        t0 = time.perf_counter()
         ce, co, _, scale = pkg.mesh_to_voxel_grid(ws, mesh, tex, depth, want_indices=False)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         pkg.svo_from_voxel_grid(ws, ce, co, depth, pool, center, size)
         torch.cuda.synchronize(); t2 = time.perf_counter()
-        for k, v in (("voxelize", t1 - t0), ("svo_from_voxel_grid", t2 - t1)):
+        for nm, st in mesh_stages + fuse_stages:
+            ms, n = pkg.stage_timing_read(st)
+            if n:
+                best_stage[nm] = min(best_stage.get(nm, 1e9), ms)
+        pkg.stage_timing([])
+        for k, v in (("voxelize_call_ms", t1 - t0), ("svo_from_voxel_grid_call_ms", t2 - t1)):
             best[k] = min(best.get(k, 1e9), v * 1e3)
-        out["voxels"], out["nodes"] = int(ce.shape[0]), int(pool.size)
+        V, nodes = int(ce.shape[0]), int(pool.size)
         if rep + 1 < args.reps:
-            del pool
-    out["stages_ms"] = {k: round(v, 3) for k, v in best.items()}
+            del ce, co
+    out["voxels"], out["nodes"] = V, nodes
+    K = (nodes - 8) // 8
+    F = pkg.mesh_last_fragments(ws)
+    out["fragments"] = F
+    passes = (3 * depth + 7) // 8
+    vox_ms = sum(best_stage.get(nm, 0.0) for nm, _ in mesh_stages)
+    fus_ms = sum(best_stage.get(nm, 0.0) for nm, _ in fuse_stages)
+    st = {}
+    if F is not None:
+        st["mesh_raster"] = dict(kernel="tri_scanline_count_kernel + scanline_kernel<false> + scanline_kernel<true> + 2 scans (2 count readbacks inside)",
+                                 **roof(36.0 * T + 12.0 * F, best_stage.get("mesh_raster", 0.0)))
+        st["mesh_sort"] = dict(kernel="radix_sort_pairs: %d passes of 8 bits x (upsweep, row scan, downsweep)" % passes,
+                               **roof(24.0 * F * passes, best_stage.get("mesh_sort", 0.0)))
+        st["mesh_emit"] = dict(kernel="voxel_flag_kernel + scan + voxel_emit_kernel (1 count readback inside)",
+                               **roof(12.0 * F + 24.0 * T + 32.0 * V, best_stage.get("mesh_emit", 0.0)))
+    st["voxelize"] = dict(kernel="svoslam_mesh_to_voxel_grid (sum of the three stages above)", **roof(60.0 * T + 32.0 * V, vox_ms))
+    fuse_alg = 32.0 * V + 4.0 * depth * V + 8.0 * V + 72.0 * K + 36.0 * K
+    st["svo_from_voxel_grid"] = dict(kernel="compute_keys + radix_sort_pairs + plan (3) + split_pass per level + fill_kernel + mip_level per level",
+                                     parts_ms={nm: best_stage.get(nm) for nm, _ in fuse_stages}, **roof(fuse_alg, fus_ms))
+    out["stages"] = st
+    out["call_ms"] = {k: round(v, 3) for k, v in best.items()}
+    out["call_ms"]["note"] = ("wall clock of the Python call: includes the binding's device-to-device copy of the voxel grid into torch tensors "
+                              "(32 B per voxel) and allocation; the stage times above are HIP-event brackets inside the C call")
     # three fixed views around the mesh; the last one close enough for the cone LOD to reach the leaves
     c = center.astype(np.float64)
     views = [look_at(c + np.array(o) * size, c) for o in ((0.15, 0.3, -2.6), (2.2, 0.1, 0.4), (-0.3, 0.25, 0.45))]
     if args.config == "cfg5":   # inside the colonnade, grazing along the z = +3 row of columns
         views[2] = look_at((-19.6, 1.5, 2.9), (20.0, 1.6, 3.02))
     img = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
     renders = []
     for vi, view in enumerate(views):
         for mode, name in ((pkg.RENDER_REFERENCE, "reference"), (pkg.RENDER_CARRY, "carry")):
-            pkg.cone_trace_svo(img, 45.0, view, pool.data_ptr, center, size, mode)      # warm (accel tables)
+            cnt.zero_()
+            pkg.cone_trace_svo(img, 45.0, view, pool.data_ptr, center, size, mode, counters=cnt)      # warm (accel tables) + counters
             torch.cuda.synchronize()
+            steps, levels = (int(x) for x in cnt.cpu().tolist())
             pkg.cone_trace_timing(True)
             for _ in range(5):
                 pkg.cone_trace_svo(img, 45.0, view, pool.data_ptr, center, size, mode)
             ms, n = pkg.cone_trace_timing_read()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                pkg.cone_trace_svo(img, 45.0, view, pool.data_ptr, center, size, mode)
-            torch.cuda.synchronize(); call_ms = (time.perf_counter() - t0) / 5 * 1e3
-            rec = {"view": vi, "mode": name, "trace_kernel_ms": round(ms / n, 4), "call_ms": round(call_ms, 4),
-                   "Mrays_per_s_kernel": round(W * H / (ms / n) / 1e3, 1), "lit_pixels": int((img[..., :3].sum(-1) > 0).sum().item())}
+            kms = ms / n
+            alg = 4.0 * (levels + steps) + 4.0 * W * H
+            rec = {"view": vi, "mode": name, "trace_kernel_ms": round(kms, 4), "Mrays_per_s": round(W * H / kms / 1e3, 1),
+                   "steps": steps, "levels": levels, "alg_bytes": alg, "achieved_GBs": alg / (kms * 1e-3) / 1e9,
+                   "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "lit_pixels": int((img[..., :3].sum(-1) > 0).sum().item())}
             if bands > 1:
                 full = img.clone()
                 img.zero_()
@@ -107,8 +167,11 @@ def main():
                 rec["bands_ms_total_one_gpu"] = round((time.perf_counter() - t0) * 1e3, 4)
                 rec["bands_equal_full"] = bool(torch.equal(img, full))
             renders.append(rec)
-    out["renders"] = renders
     pkg.cone_trace_timing(False)
+    out["renders"] = renders
+    out["render_kernel"] = ("cone_trace_brick_kernel (reference mode over occupancy bricks)" if depth <= 14 else
+                            "cone_trace_kernel (tree march: no brick shape for pools deeper than 14)") + " / cone_trace_kernel<CARRY> (carry mode)"
+    out["mrays_per_s_min_max"] = [min(r["Mrays_per_s"] for r in renders), max(r["Mrays_per_s"] for r in renders)]
     print(json.dumps(out))
 
 
