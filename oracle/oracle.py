@@ -35,15 +35,28 @@ class _Pool(C.Structure):
     _fields_ = [("data", C.POINTER(C.c_uint32)), ("size", C.c_int)]
 
 
-def lib(native=False):
+VARIANTS = ("fmad", "satu8")   # sensitivity variants (oracle/Makefile `variants`): NEVER the parity oracle
+
+
+def lib(native=False, variant=None):
+    """the oracle library.  variant: one of VARIANTS -- a build under the other reading of a compiler choice the reference's
+    source leaves open (tests/test_oracle_compiler_choices.py); use it through `with using(L):` or the L= arguments"""
     global _LIB
-    if _LIB is not None and not native:
+    if _LIB is not None and not native and variant is None:
         return _LIB
-    path = os.path.join(_HERE, "libsvoslam_oracle_native.so" if native else "libsvoslam_oracle.so")
+    if variant is not None:
+        assert variant in VARIANTS and not native
+        name = "libsvoslam_oracle_%s.so" % variant
+    else:
+        name = "libsvoslam_oracle_native.so" if native else "libsvoslam_oracle.so"
+    path = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "svoslam_oracle.c")
     src2 = os.path.join(_HERE, "svoslam_oracle_mesh.c")
     if (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(src), os.path.getmtime(src2)):
-        build(native)
+        if variant is not None:
+            subprocess.check_call(["make", "-C", _HERE, "-s", name])
+        else:
+            build(native)
     L = C.CDLL(path)
     f32p, u8p, u16p, u32p, i64p = (C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint16),
                                    C.POINTER(C.c_uint32), C.POINTER(C.c_int64))
@@ -123,9 +136,24 @@ def lib(native=False):
     L.ora_mesh_to_voxel_grid.restype = C.c_int
     L.ora_mesh_to_voxel_grid.argtypes = [f32p, C.c_int, f32p, C.c_int, f32p, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_int,
                                          C.POINTER(f32p), C.POINTER(f32p), C.POINTER(i64p)]
-    if not native:
+    if not native and variant is None:
         _LIB = L
     return L
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def using(L):
+    """every oracle call inside the block goes to library L (a sensitivity variant); objects created inside keep it"""
+    global _LIB
+    lib()   # (the default library is loaded, so that leaving the block restores it)
+    old, _LIB = _LIB, L
+    try:
+        yield L
+    finally:
+        _LIB = old
 
 
 def _p(a, ct):

@@ -623,8 +623,15 @@ static int ceil_log2_pos(float q) {
  * PTX cvt.rzi.u32.f32 the CUDA compiler emits does), keep the low 8 bits. */
 static uint8_t f2u8(float f) {
   if (!(f > 0.0f)) return 0;
+#ifdef ORA_VARIANT_SAT_U8
+  /* sensitivity variant (oracle/Makefile `variants`, tests/test_oracle_compiler_choices.py): the other reading of the float ->
+   * uint8_t conversion, a saturating cvt.rzi.u8.f32 (resolution R9 takes the u32 conversion + low byte) */
+  if (f >= 255.0f) return 0xFF;
+  return (uint8_t)f;
+#else
   if (f >= 4294967296.0f) return 0xFF;
   return (uint8_t)((uint32_t)f & 0xFFu);
+#endif
 }
 
 #define ORA_MAX_RANGE 10.0f
@@ -684,7 +691,13 @@ int64_t ora_cone_trace_svo(uint8_t *pos, int w, int h, float fov, const float vi
       uint32_t oct_val = octree[2 * (size_t)node_idx + 1];
       /* :108 `max(0, (oct_val >> 24) - 127)` is an (int, unsigned) overload that
        * returns the unsigned operand: alpha = A - 127 as a signed int, unclamped. */
+#ifdef ORA_VARIANT_SAT_U8
+      /* the same variant reads `max(0, unsigned - 127)` as a signed clamp at zero (resolution R8: the unsigned operand, unclamped) */
+      int alpha = (int)(oct_val >> 24) - 127;
+      if (alpha < 0) alpha = 0;
+#else
       int alpha = (int)((oct_val >> 24) - 127u);
+#endif
       float af = (float)alpha / 127.0f;
       value[0] = (uint8_t)(value[0] + f2u8(af * (float)(oct_val & 0xFF)));
       value[1] = (uint8_t)(value[1] + f2u8(af * (float)((oct_val >> 8) & 0xFF)));
