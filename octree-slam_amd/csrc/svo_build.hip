@@ -98,6 +98,13 @@ __global__ __launch_bounds__(kKeysThreads) void keys_packed_kernel(const float *
   }
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   float cnt = 0;
+  // pixel coordinates: ONE integer division per lane, then + kKeysThreads per round (a division per pixel -- ~40 instructions
+  // on this ISA, next to the 14 levels' ~170 -- was a fifth of the kernel's issue time at 1920x1080)
+  int gx = 0, gy = 0;
+  if (FROM_DEPTH) {
+    const int g0 = fs.first + blockIdx.x * tile_elems + (int)threadIdx.x;
+    gy = g0 / fs.w; gx = g0 - gy * fs.w;
+  }
 #pragma unroll
   for (int r = 0; r < kKeysIPT; r++) {
     const int i = blockIdx.x * tile_elems + r * kKeysThreads + (int)threadIdx.x;
@@ -106,7 +113,8 @@ __global__ __launch_bounds__(kKeysThreads) void keys_packed_kernel(const float *
     if (FROM_DEPTH) {
       float vx, vy, vz;
       const int g = fs.first + i;  // pixel of the whole image (a row band starts at fs.first)
-      vertex_from_depth(fs.depth[g], g % fs.w, g / fs.w, fs.w, fs.h, fs.fx, fs.fy, fs.w, fs.h, vx, vy, vz);
+      if (r > 0) { gx += kKeysThreads; while (gx >= fs.w) { gx -= fs.w; gy++; } }
+      vertex_from_depth(fs.depth[g], gx, gy, fs.w, fs.h, fs.fx, fs.fy, fs.w, fs.h, vx, vy, vz);
       mat4_mul_point(m, vx, vy, vz, 1.0f, px, py, pz);
       if (finitef_(px) && finitef_(pz)) {  // computePointCloudBoundingBox (image_kernels.cu:60-102, Q1)
         lo[0] = fminf(px, lo[0]); lo[1] = fminf(py, lo[1]); lo[2] = fminf(pz, lo[2]);
@@ -163,9 +171,11 @@ __global__ __launch_bounds__(kKeysThreads) void keys_packed_kernel(const float *
     is_last = t == gridDim.x - 1;
   }
   __syncthreads();
-  if (!is_last || threadIdx.x >= 64) return;
+  if (!is_last) return;
+  // the fold by the WHOLE workgroup (round 5): one wavefront walking 1013 partials of a 1080p frame in 16 dependent rounds of
+  // agent-scope loads was 30 of the kernel's 50 us
   float r[7] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY, 0};
-  for (int b = threadIdx.x; b < (int)gridDim.x; b += 64) {
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += kKeysThreads) {
     float v[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) v[k] = __hip_atomic_load(&bbox_partial[b * 7 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -179,8 +189,17 @@ __global__ __launch_bounds__(kKeysThreads) void keys_packed_kernel(const float *
     for (int k = 0; k < 3; k++) { r[k] = fminf(r[k], __shfl_down(r[k], o)); r[3 + k] = fmaxf(r[3 + k], __shfl_down(r[3 + k], o)); }
     r[6] = fmaxf(r[6], __shfl_down(r[6], o));
   }
+  __syncthreads();  // (sm is reused)
+  if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < 7; k++) sm[wave][k] = r[k];
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    for (int k = 0; k < 7; k++) bbox_out[k] = r[k];
+    for (int w = 1; w < kKeysThreads / 64; w++) {
+      for (int k = 0; k < 3; k++) { sm[0][k] = fminf(sm[0][k], sm[w][k]); sm[0][3 + k] = fmaxf(sm[0][3 + k], sm[w][3 + k]); }
+      sm[0][6] = fmaxf(sm[0][6], sm[w][6]);
+    }
+    for (int k = 0; k < 7; k++) bbox_out[k] = sm[0][k];
     __hip_atomic_store(bbox_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
   }
 }
@@ -271,6 +290,10 @@ __global__ __launch_bounds__(kPlanThreads) void plan_count_kernel(const u64 *__r
       *any_valid = 1;  // benign race: every writer stores 1
     } else {
       leaf_t[j] = kNotHead;
+      // (every lane stores: whole lines leave the CU instead of the heads' scattered words, which cost a read-modify-write each --
+      // the kernel's WRITE_SIZE was 2.7 x its 9 bytes per key)
+      leaf_f[j] = 0u;
+      if (leaf_start) leaf_start[j] = 0u;
     }
   }
   __syncthreads();
