@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include "config.hpp"
 #include "mesh.hpp"
 #include "stage_timing.hpp"
 #include "radix_sort.hpp"
@@ -123,7 +124,9 @@ template <bool EMIT>
 __global__ __launch_bounds__(256) void scanline_kernel(const float *__restrict__ vbo, int n_tris,
                                                        const u32 *__restrict__ tri_start, u32 total_scanlines, GridParams G,
                                                        u32 *__restrict__ frag_count, const u32 *__restrict__ frag_start,
-                                                       u64 *__restrict__ frag_key, u32 *__restrict__ frag_tri) {
+                                                       u64 *__restrict__ frag_key, u32 *__restrict__ frag_tri, int pack_shift) {
+  // pack_shift >= 0 (round 5): ONE word per fragment, framebuffer index << pack_shift | triangle id, for the packed sort
+  // (radix_sort.hip) -- 8 bytes per fragment and pass instead of 8 + 4 in two arrays
   __shared__ ScanlineSetup setup[256];
   __shared__ u32 cell_prefix[257], slot[256], out_base[256], tmp[4];
   const u32 s = blockIdx.x * 256u + threadIdx.x;
@@ -200,8 +203,13 @@ __global__ __launch_bounds__(256) void scanline_kernel(const float *__restrict__
       const u64 tile = (u64)(xyz[0] >> G.log_T) + (u64)M * (u64)(xyz[1] >> G.log_T) + (u64)M * M * (u64)(xyz[2] >> G.log_T);
       const u64 pix = (u64)(xyz[0] & (G.T - 1)) + (u64)G.T * (u64)(xyz[1] & (G.T - 1)) + (u64)G.T * G.T * (u64)(xyz[2] & (G.T - 1));
       const u32 pos = out_base[sl] + k;
-      frag_key[pos] = tile * (u64)G.T * G.T * G.T + pix;  // fb index of voxelization.cu:141-164
-      frag_tri[pos] = (u32)Q.t;
+      const u64 fb = tile * (u64)G.T * G.T * G.T + pix;  // fb index of voxelization.cu:141-164
+      if (pack_shift >= 0) {
+        frag_key[pos] = (fb << pack_shift) | (u64)(u32)Q.t;
+      } else {
+        frag_key[pos] = fb;
+        frag_tri[pos] = (u32)Q.t;
+      }
     }
   }
   if (!EMIT) {
@@ -325,7 +333,7 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   SVO_TRY(ws->rec_front.reserve((size_t)total_scan * 4));
   u32 *frag_start = ws->rec_front.as<u32>();
   scanline_kernel<false><<<cdiv(total_scan, 256), 256, 0, stream>>>(dv.as<float>(), n_tris, tri_start, total_scan, G, frag_start,
-                                                                   nullptr, nullptr, nullptr);
+                                                                   nullptr, nullptr, nullptr, -1);
   SVO_TRY(exclusive_scan_u32(ws, frag_start, total_scan, d_total, stream));
   u32 total_frag = 0;
   SVO_HIP(hipMemcpyAsync(&total_frag, d_total, 4, hipMemcpyDeviceToHost, stream));
@@ -339,14 +347,21 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   SVO_TRY(ws->vals_a.reserve((size_t)nf * 4));
   SVO_TRY(ws->vals_b.reserve((size_t)nf * 4));
   SVO_TRY(ws->tile_hist.reserve(256 * ((size_t)cdiv(nf, 256) + 1) * 4));
+  // one packed word per fragment where the framebuffer index (3 log_N bits) and the triangle id fit 64 bits
+  int tri_bits = 1;
+  while ((1ll << tri_bits) < (long long)n_tris) tri_bits++;
+  const int pack_shift = (3 * log_N + tri_bits <= 64 && config().sort_pairs == 0) ? tri_bits : -1;
   scanline_kernel<true><<<cdiv(total_scan, 256), 256, 0, stream>>>(dv.as<float>(), n_tris, tri_start, total_scan, G, nullptr,
-                                                                  frag_start, ws->keys_a.as<u64>(), ws->vals_a.as<u32>());
+                                                                  frag_start, ws->keys_a.as<u64>(), ws->vals_a.as<u32>(), pack_shift);
   SVO_LAUNCH_CHECK();
   (void)stage_end(kStageMeshRaster, tk_raster, stream);
-  // order by framebuffer index (stable: equal cells keep ascending triangle id)
+  // order by framebuffer index (stable: equal cells keep ascending triangle id -- fragments are emitted triangle by triangle)
   u64 *skey = nullptr; u32 *stri = nullptr;
   (void)stage_begin(kStageMeshSort, stream, &tk_sort);
-  SVO_TRY(radix_sort_pairs(ws, nf, 3 * log_N, stream, &skey, &stri, false));
+  if (pack_shift >= 0)
+    SVO_TRY(radix_sort_packed_ex(ws, nf, 3 * log_N, pack_shift, radix_packed_digit_bits_for(nf), false, true, stream, &skey, &stri));
+  else
+    SVO_TRY(radix_sort_pairs(ws, nf, 3 * log_N, stream, &skey, &stri, false));
   (void)stage_end(kStageMeshSort, tk_sort, stream);
   const int tiles = (int)cdiv(nf, 256);
   u32 *tile_cnt = ws->tile_hist.as<u32>();

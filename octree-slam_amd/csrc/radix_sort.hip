@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kPkThreads) void packed_downsweep_kernel(const unsi
       const unsigned pos = dbase[dig] + cnt[wave][dig] + pre[r];
       if (LAST) {
         out_keys[pos] = k[r] >> idx_bits;
-        out_vals[pos] = (unsigned)(k[r] & imask);
+        if (out_vals) out_vals[pos] = (unsigned)(k[r] & imask);
       } else {
         out_keys[pos] = k[r];
       }
@@ -344,21 +344,34 @@ __global__ __launch_bounds__(kPkThreads) void packed_downsweep_kernel(const unsi
 // Output: keys (unpacked) in keys_a or keys_b, indices in vals_a.
 int radix_sort_packed(svoslam_workspace *ws, int n, int key_bits, int idx_bits, hipStream_t stream, unsigned long long **sorted_keys,
                       unsigned **sorted_vals) {
+  return radix_sort_packed_ex(ws, n, key_bits, idx_bits, kPackedMaxBits, true, true, stream, sorted_keys, sorted_vals);
+}
+
+// digit width by size: the [tile][digit] matrix of a pass is tiles x 2^bits words -- as large as half the keys at 11 bits, which
+// is fine while everything sits in the L2 / Infinity Cache (a frame's 0.3-2 M keys) and a third of the traffic beyond that
+int radix_packed_digit_bits_for(long long n) { return n <= (4ll << 20) ? kPackedMaxBits : (n <= (64ll << 20) ? 9 : 8); }
+
+int radix_sort_packed_ex(svoslam_workspace *ws, int n, int key_bits, int idx_bits, int max_bits, bool have_first_hist, bool want_vals,
+                         hipStream_t stream, unsigned long long **sorted_keys, unsigned **sorted_vals) {
+  if (max_bits < 1 || max_bits > kPackedMaxBits) return SVOSLAM_ERR_INVALID_ARG;
+  const int tiles = radix_packed_tiles(n);
+  const size_t row_words = (size_t)1 << max_bits;  // (rows are written with the pass's own width as their stride: <= this)
+  SVO_TRY(ws->tile_hist.reserve(((size_t)tiles + 1) * row_words * 4));
   unsigned long long *ka = ws->keys_a.as<unsigned long long>(), *kb = ws->keys_b.as<unsigned long long>();
   unsigned *tile_hist = ws->tile_hist.as<unsigned>();
-  const int tiles = radix_packed_tiles(n);
-  const int passes = radix_packed_passes(key_bits);
-  unsigned *totals = tile_hist + (size_t)tiles * kPackedMaxBins;  // behind the largest histogram matrix
+  int passes = (key_bits + max_bits - 1) / max_bits;
+  if (passes < 1) passes = 1;
+  unsigned *totals = tile_hist + (size_t)tiles * row_words;  // behind the largest histogram matrix
   int bit = 0;
   for (int p = 0; p < passes; p++) {
     const int remaining_bits = key_bits - bit, remaining_passes = passes - p;
     int width = (remaining_bits + remaining_passes - 1) / remaining_passes;
     if (width < 1) width = 1;
     const int bins = 1 << width, shift = idx_bits + bit;
-    if (p > 0) packed_upsweep_kernel<<<tiles, kPkThreads, 0, stream>>>(ka, n, shift, width, tile_hist);
+    if (p > 0 || !have_first_hist) packed_upsweep_kernel<<<tiles, kPkThreads, 0, stream>>>(ka, n, shift, width, tile_hist);
     packed_column_scan_kernel<<<(bins + 63) / 64, 1024, 0, stream>>>(tile_hist, tiles, bins, totals);
     if (p == passes - 1)
-      packed_downsweep_kernel<true><<<tiles, kPkThreads, 0, stream>>>(ka, kb, ws->vals_a.as<unsigned>(), n, shift, width, idx_bits, tile_hist, totals);
+      packed_downsweep_kernel<true><<<tiles, kPkThreads, 0, stream>>>(ka, kb, want_vals ? ws->vals_a.as<unsigned>() : nullptr, n, shift, width, idx_bits, tile_hist, totals);
     else
       packed_downsweep_kernel<false><<<tiles, kPkThreads, 0, stream>>>(ka, kb, nullptr, n, shift, width, idx_bits, tile_hist, totals);
     SVO_LAUNCH_CHECK();
@@ -366,7 +379,7 @@ int radix_sort_packed(svoslam_workspace *ws, int n, int key_bits, int idx_bits, 
     bit += width;
   }
   *sorted_keys = ka;
-  *sorted_vals = ws->vals_a.as<unsigned>();
+  *sorted_vals = want_vals ? ws->vals_a.as<unsigned>() : nullptr;
   return SVOSLAM_OK;
 }
 

@@ -26,6 +26,13 @@ int radix_packed_first_bits(int key_bits);
 inline size_t radix_packed_hist_words(int n) { return ((size_t)radix_packed_tiles(n) + 1) * kPackedMaxBins; }
 int radix_sort_packed(svoslam_workspace *ws, int n, int key_bits, int idx_bits, hipStream_t stream,
                       unsigned long long **sorted_keys, unsigned **sorted_vals);
+// The general form (round 5: the blocking insert and the mesh voxelizer's fragment sort use it too).  max_bits: digit width
+// (<= kPackedMaxBits; large inputs take narrower digits -- the [tile][digit] matrix of an 11-bit pass is n x 4 bytes, half the keys);
+// have_first_hist = false: the first pass counts its own histogram (an upsweep like the later passes'); want_vals = false: the
+// low idx_bits are not unpacked (keys-only sorts: svoFromVoxelGrid pairs sorted key i with colour i, Q20).  Reserves what it needs.
+int radix_sort_packed_ex(svoslam_workspace *ws, int n, int key_bits, int idx_bits, int max_bits, bool have_first_hist, bool want_vals,
+                         hipStream_t stream, unsigned long long **sorted_keys, unsigned **sorted_vals);
+int radix_packed_digit_bits_for(long long n);  // the digit width radix_sort_packed_ex callers use for n elements
 int radix_sort_packed_output(svoslam_workspace *ws, int key_bits, unsigned long long **sorted_keys, unsigned **sorted_vals);
 // In-place exclusive scan of each of 256 rows of num_tiles counters; row totals to totals[256].
 void row_scan_rows(unsigned *rows, int num_tiles, unsigned *totals, hipStream_t stream);

@@ -49,9 +49,10 @@ constexpr unsigned char kNoSplit = 0xFF;  // path fully exists, nothing to split
 // ----------------------------------------------------------------------------
 // keys  (svo.cu:33-66, 92-106)
 // ----------------------------------------------------------------------------
+// idx_bits >= 0: the word of the packed sort (radix_sort.hip), key << idx_bits | point index (idx_bits = 0: the key alone)
 template <int STRIDE>
 __global__ __launch_bounds__(256) void compute_keys_kernel(const float *__restrict__ pts, int n, int depth, float cx,
-                                                           float cy, float cz, float edge, u64 *__restrict__ keys) {
+                                                           float cy, float cz, float edge, u64 *__restrict__ keys, int idx_bits = -1) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float px = pts[(size_t)i * STRIDE], py = pts[(size_t)i * STRIDE + 1], pz = pts[(size_t)i * STRIDE + 2];
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void compute_keys_kernel(const float *__restri
       cz += edge * (z ? 1 : -1);
     }
   }
-  keys[i] = morton;
+  keys[i] = idx_bits > 0 ? ((morton << idx_bits) | (u64)(unsigned)i) : morton;
 }
 
 // Keys for the packed sort (radix_sort.hip): word = key << idx_bits | point index, plus the first pass's digit histogram of
@@ -315,12 +316,24 @@ __global__ __launch_bounds__(256) void plan_scan_finish_kernel(u32 *__restrict__
   __shared__ int is_last;
   u32 *row = rows + (size_t)blockIdx.x * num_tiles;
   u32 carry = 0;
-  for (int base = 0; base < num_tiles; base += 256) {
-    const int i = base + threadIdx.x;
-    const u32 v = i < num_tiles ? row[i] : 0u;
+  // eight counters per lane and round (round 5: a 1920x1080 frame has 4050 tiles -- sixteen rounds of two barriers each at one
+  // counter per lane); a round of zeros is not written back (most of the 256 (pass, depth) buckets are empty; its prefixes would be
+  // `carry`, but plan_emit reads the prefix of (bucket, tile) only where that tile counted a record in the bucket)
+  constexpr int kPer = 8;
+  for (int base = 0; base < num_tiles; base += 256 * kPer) {
+    const int i0 = base + (int)threadIdx.x * kPer;
+    u32 v[kPer], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) { v[k] = i0 + k < num_tiles ? row[i0 + k] : 0u; sum += v[k]; }
     u32 total;
-    const u32 ex = block256_exclusive_scan(v, tmp, total);
-    if (i < num_tiles) row[i] = carry + ex;
+    u32 run = carry + block256_exclusive_scan(sum, tmp, total);
+    if (total) {
+#pragma unroll
+      for (int k = 0; k < kPer; k++) {
+        if (i0 + k < num_tiles) row[i0 + k] = run;
+        run += v[k];
+      }
+    }
     carry += total;
   }
   if (threadIdx.x == 0) {
@@ -1431,14 +1444,22 @@ static inline unsigned *small_ticket(svoslam_workspace *ws) { return ws->small.a
 static inline unsigned *small_strad_ticket(svoslam_workspace *ws, int slot) { return ws->small.as<u32>() + 664 + 8 * slot; }  // mip_straddle2_kernel's (zero between launches)
 
 // keys of the n inputs are in ws->keys_a
+// The blocking insert's sort (round 5): one packed word per point where key and index fit 64 bits -- and the key ALONE on the
+// voxel-grid path, whose colours are paired by position (Q20) -- instead of (8-byte key, 4-byte index) pairs through 8-bit digits:
+// config 5's 318 M voxels moved 12 bytes x 2 x 7 passes, now 8 x 2 x 6.  -1: the pair sort (svoslam_config.sort_pairs, or no room).
+static int blocking_sort_idx_bits(int n, int depth, bool keys_only);
+
 static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, const void *d_colors, bool vec4,
-                      bool color_by_position, svoslam_fuse_stats *stats, hipStream_t stream, long long sort_token) {
+                      bool color_by_position, svoslam_fuse_stats *stats, hipStream_t stream, long long sort_token, int idx_bits) {
   pool_accel_invalidate(pool, depth, false);  // the blocking path does not track what it touches: the next render rebuilds the level grid
   SVO_TRY(pool_sync(pool, stream));
   u64 *skey = nullptr; u32 *sidx = nullptr;
   long long tk = -1;  // stage brackets of the blocking path (bench.py's mesh configurations; off by default).  The sort's bracket
   // was opened by the caller in front of its key kernel (sort_token)
-  SVO_TRY(radix_sort_pairs(ws, n, 3 * depth + 1, stream, &skey, &sidx));
+  if (idx_bits >= 0)
+    SVO_TRY(radix_sort_packed_ex(ws, n, 3 * depth + 1, idx_bits, radix_packed_digit_bits_for(n), false, !color_by_position, stream, &skey, &sidx));
+  else
+    SVO_TRY(radix_sort_pairs(ws, n, 3 * depth + 1, stream, &skey, &sidx));
   (void)stage_end(kStageFuseSort, sort_token, stream);
   const int tiles = (int)cdiv(n, 256);
   unsigned char *leaf_t = ws->leaf_t.as<unsigned char>();
@@ -1524,6 +1545,12 @@ static int packed_idx_bits(int n) {
 }
 // svoslam_config.sort_pairs = 1: the (key, index) pair sort of round 1 for every fusion (tests)
 static bool sort_pairs_forced() { return config().sort_pairs != 0; }
+static int blocking_sort_idx_bits(int n, int depth, bool keys_only) {
+  if (sort_pairs_forced()) return -1;
+  if (keys_only) return 0;
+  const int b = packed_idx_bits(n);
+  return 3 * depth + 1 + b <= 64 ? b : -1;
+}
 
 // buffers of the asynchronous phases (plan + commit) for a batch of n sorted keys
 static int reserve_async(svoslam_workspace *ws, int n, int depth) {
@@ -1982,8 +2009,9 @@ int svo_from_point_cloud(svoslam_workspace *ws, const float *d_points, const uin
   SVO_TRY(reserve_common(ws, n, depth));
   long long tk = -1;
   (void)stage_begin(kStageFuseSort, stream, &tk);
-  compute_keys_kernel<3><<<cdiv(n, 256), 256, 0, stream>>>(d_points, n, depth, center[0], center[1], center[2], edge, ws->keys_a.as<u64>());
-  return svo_insert(ws, n, depth, pool, d_colors, false, false, stats, stream, tk);
+  const int idx_bits = blocking_sort_idx_bits(n, depth, false);
+  compute_keys_kernel<3><<<cdiv(n, 256), 256, 0, stream>>>(d_points, n, depth, center[0], center[1], center[2], edge, ws->keys_a.as<u64>(), idx_bits);
+  return svo_insert(ws, n, depth, pool, d_colors, false, false, stats, stream, tk, idx_bits);
 }
 
 int svo_from_voxel_grid(svoslam_workspace *ws, const float *d_centers, const float *d_colors, int n, int depth,
@@ -1999,10 +2027,11 @@ int svo_from_voxel_grid(svoslam_workspace *ws, const float *d_centers, const flo
   SVO_TRY(reserve_common(ws, n, depth));
   long long tk = -1;
   (void)stage_begin(kStageFuseSort, stream, &tk);
-  compute_keys_kernel<4><<<cdiv(n, 256), 256, 0, stream>>>(d_centers, n, depth, center[0], center[1], center[2], edge, ws->keys_a.as<u64>());
+  const int idx_bits = blocking_sort_idx_bits(n, depth, true);
+  compute_keys_kernel<4><<<cdiv(n, 256), 256, 0, stream>>>(d_centers, n, depth, center[0], center[1], center[2], edge, ws->keys_a.as<u64>(), idx_bits);
   // Q20 (svo.cu:601-602,629): the reference sorts the keys alone, so sorted key i
   // stays paired with colour i -> color_by_position
-  return svo_insert(ws, n, depth, pool, d_colors, true, true, stats, stream, tk);
+  return svo_insert(ws, n, depth, pool, d_colors, true, true, stats, stream, tk, idx_bits);
 }
 
 // ----------------------------------------------------------------------------

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Regenerates the measurement records of a round on an MI355X box:  bash tools/prof/profile_round.sh r04 [quick]
+# Regenerates the measurement records of a round on an MI355X box:  bash tools/prof/profile_round.sh r05 [quick]
 # Everything lands in gpurun_out/<tag>/ (scratch); the files worth judging are then copied to profiles/.
 # Counter passes use the SEQUENTIAL form of the bench (--no-overlap, launch-chain tracker): counter collection serialises
 # dispatches, which would deadlock the multi-stream pipeline; per-kernel traffic does not depend on the overlap.  Only
 # the library's kernels are counted (--kernel-include-regex svoslam: the torch kernels that generate the synthetic
 # stream made the round-2 passes run into their timeouts).  A failed pass FAILS the script (no `|| echo`).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 QUICK=${2:-}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT="$R/gpurun_out/$TAG"; mkdir -p "$OUT"
@@ -97,6 +97,45 @@ except Exception as e:
 PY
 done
 [ -s ${P}_bench_cfg3.json ] || fail "default bench line empty"
+
+echo "== mesh configurations (BASELINE configs 2 and 5): stage times + rooflines, kernel statistics, PMC traffic per kernel"
+for C in cfg2 cfg5; do
+  python $R/tools/mesh_bench.py --config $C 2>/dev/null | grep '^{"config"' | tail -1 > ${P}_mesh_bench_$C.json
+  [ -s ${P}_mesh_bench_$C.json ] || fail "mesh bench $C"
+  D=$SCR/ks_mesh_$C; rm -rf $D; mkdir -p $D
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o k -- python $R/tools/mesh_bench.py --config $C --reps 2 > $SCR/ks_mesh_$C.log 2>&1 || fail "kernel stats mesh $C"
+  f=$(find $D -name "*kernel_stats.csv" | sort | tail -1)
+  { echo "# rocprofv3 --kernel-trace --stats -- python tools/mesh_bench.py --config $C --reps 2   (2 x (voxelize + svo_from_voxel_grid) + 3 views x 2 modes x 6 renders)"
+    head -1 $f
+    grep -v -E "at::native|rocclr|^\"Name" $f; } > ${P}_mesh_${C}_kernel_stats.csv
+  MP=${P}_mesh_pmc_fetch_write_per_kernel.txt
+  [ $C = cfg2 ] && echo "# rocprofv3 --pmc <counter> --kernel-include-regex svoslam --kernel-trace -- python tools/mesh_bench.py --config C --reps 1; one counter per pass; KB per dispatch" > $MP
+  for c in FETCH_SIZE WRITE_SIZE; do
+    D=$SCR/pm_mesh_${C}_$c; rm -rf $D; mkdir -p $D
+    timeout 900 rocprofv3 --pmc $c --kernel-include-regex svoslam --kernel-trace --output-format csv -d $D -o p -- python $R/tools/mesh_bench.py --config $C --reps 1 > $SCR/pm_mesh_${C}_$c.log 2>&1 || fail "pmc pass mesh $C $c"
+    f=$(find $D -name "*counter_collection.csv" | sort | tail -1)
+    [ -n "$f" ] && python3 - "$f" "$c" "$C" <<'PY' >> $MP
+import csv, sys, collections
+f, cname, w = sys.argv[1:4]
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if r["Counter_Name"] == cname:
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+    print("%s,%s,%s,calls=%d,mean=%.1f,total=%.1f" % (w, cname, k, len(v), sum(v) / len(v), sum(v)))
+PY
+  done
+done
+python3 - ${P}_mesh_bench_cfg2.json ${P}_mesh_bench_cfg5.json <<'PY'
+import json, sys
+for f in sys.argv[1:]:
+    try:
+        m = json.load(open(f))
+        print(m["config"], "voxels", m["voxels"], "fragments", m["fragments"], "Mrays/s", m["mrays_per_s_min_max"])
+        for k, v in m["stages"].items(): print("    %-22s %9.3f ms  frac %.4f" % (k, v["ms"], v["frac"] or 0))
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
 
 echo "== kernel stats (rocprofv3 --kernel-trace --stats) of the bench"
 for W in cfg3 cfg4; do
