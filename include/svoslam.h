@@ -637,6 +637,16 @@ int svoslam_runner_timeline(svoslam_runner *runner, float *h_ms, int32_t max_fra
 int svoslam_runner_run(svoslam_runner *runner, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs,
                        const long long *timestamps, const float *views, int32_t n, uint8_t *d_image, int32_t row_first,
                        int32_t rows, unsigned long long *d_steps, void *caller_stream);
+/* The loop with FRAME-TO-MODEL tracking (own specification, see svoslam_raycast_model_depth below: the reference
+ * leaves it as a TODO, src/sensor/rgbd_camera.cpp:185).  Per frame: track (against the model set once one has been accepted) ->
+ * back-project + fuse -> the map ray-cast into a depth image from the pose just tracked -> accepted as the next frame's model if
+ * at least min_coverage (0..1) of its pixels met the map, else the next frame is tracked against the previous frame's maps ->
+ * cone-traced view (rows of the LAST frame in d_image).  Sequential on caller_stream and BLOCKING (one 4-byte coverage readback
+ * per frame); *models_used (optional) = frames whose model was accepted.  Leaves frame-to-model tracking switched on in the
+ * camera.  One replica only. */
+int svoslam_runner_run_model(svoslam_runner *runner, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs,
+                             const long long *timestamps, const float *views, int32_t n, uint8_t *d_image, int32_t row_first,
+                             int32_t rows, unsigned long long *d_steps, float min_coverage, int32_t *models_used, void *caller_stream);
 /* the bounding box the loop computed for the last frame enqueued (computePointCloudBoundingBox, main.cpp:43):
  * {min xyz, max xyz, any point}.  Blocking. */
 int svoslam_runner_bbox(svoslam_runner *runner, float h_bbox7[7]);

@@ -128,6 +128,8 @@ SIGNATURES = {
     "svoslam_voxel_grid_to_mesh": (C.c_int, [_vp, _vp, _vp, _i32, _f32, _fp, _i32, C.POINTER(C.c_int32), _i32, _fp, _vp, _vp, _vp, _vp, _vp]),
     "svoslam_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
     "svoslam_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "svoslam_runner_run_model": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_longlong), _fp, _i32, _vp, _i32, _i32, _vp,
+                                           _f32, C.POINTER(_i32), _vp]),
     "svoslam_runner_create": (C.c_int, [C.POINTER(_vp), _vp, C.POINTER(_PoolStruct), _i32, _i32, _i32, _fp, _f32, _f32, _f32, _i32]),
     "svoslam_runner_destroy": (C.c_int, [_vp]),
     "svoslam_runner_timeline": (C.c_int, [_vp, _fp, _i32, C.POINTER(_i32)]),
@@ -702,6 +704,19 @@ class Runner:
         self._keep = (depths, rgbs, deltas, delta_events, images, sorted_keys, sorted_idx, sorted_events)
         check(lib().svoslam_runner_run_sharded_presorted(self._h, dp, rp, ts, vw.ctypes.data_as(_fp), n, dl, ev, mf, im, sk, si, se,
                                                          int(row_first), int(rows), _ptr(counters), _stream()))
+
+    def run_model(self, depths, rgbs, timestamps, views, image, row_first, rows, min_coverage=0.5, counters=None):
+        """the frame loop with frame-to-model tracking inside the library (svoslam_runner_run_model); returns the number of frames
+        whose ray-cast model was accepted.  Blocking."""
+        n = len(timestamps)
+        dp = (C.c_void_p * n)(*[d.data_ptr() for d in depths])
+        rp = (C.c_void_p * n)(*[r.data_ptr() for r in rgbs])
+        ts = (C.c_longlong * n)(*[int(t) for t in timestamps])
+        vw = np.ascontiguousarray(np.stack([np.asarray(v, np.float32).reshape(16) for v in views]), np.float32)
+        used = C.c_int32(0)
+        check(lib().svoslam_runner_run_model(self._h, dp, rp, ts, vw.ctypes.data_as(_fp), n, _ptr(image), int(row_first), int(rows),
+                                             _ptr(counters), float(min_coverage), C.byref(used), _stream()))
+        return int(used.value)
 
     def bbox(self):
         """{min xyz, max xyz, any} of the last frame's point cloud (main.cpp:43)"""

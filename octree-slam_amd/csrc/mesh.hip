@@ -124,7 +124,10 @@ template <bool EMIT>
 __global__ __launch_bounds__(256) void scanline_kernel(const float *__restrict__ vbo, int n_tris,
                                                        const u32 *__restrict__ tri_start, u32 total_scanlines, GridParams G,
                                                        u32 *__restrict__ frag_count, const u32 *__restrict__ frag_start,
-                                                       u64 *__restrict__ frag_key, u32 *__restrict__ frag_tri, int pack_shift) {
+                                                       u64 *__restrict__ frag_key, u32 *__restrict__ frag_tri, int pack_shift, int slices) {
+  // slices (round 5): blockIdx.y takes the cells [total * y / slices, total * (y + 1) / slices) of the workgroup's 256 scan lines and
+  // counts / emits into entry s * slices + y of frag_count / frag_start.  At 2^16 cells per axis a scan line is up to 65536 cells
+  // long and 256 of them were ONE workgroup's loop: config 5's 375 M fragments were the work of 22 workgroups (33 ms).
   // pack_shift >= 0 (round 5): ONE word per fragment, framebuffer index << pack_shift | triangle id, for the packed sort
   // (radix_sort.hip) -- 8 bytes per fragment and pass instead of 8 + 4 in two arrays
   __shared__ ScanlineSetup setup[256];
@@ -169,12 +172,14 @@ __global__ __launch_bounds__(256) void scanline_kernel(const float *__restrict__
   cell_prefix[threadIdx.x] = ex;
   if (threadIdx.x == 255) cell_prefix[256] = total_cells;
   slot[threadIdx.x] = 0;
-  out_base[threadIdx.x] = (EMIT && s < total_scanlines) ? frag_start[s] : 0u;
+  out_base[threadIdx.x] = (EMIT && s < total_scanlines) ? frag_start[(size_t)s * slices + blockIdx.y] : 0u;
   __syncthreads();
 
   const int M = 1 << (G.log_N - G.log_T);
   u32 sl = 0;
-  for (u32 c = threadIdx.x; c < total_cells; c += 256u) {
+  const u32 c_begin = (u32)((unsigned long long)total_cells * blockIdx.y / (unsigned)slices);
+  const u32 c_end = (u32)((unsigned long long)total_cells * (blockIdx.y + 1u) / (unsigned)slices);
+  for (u32 c = c_begin + threadIdx.x; c < c_end; c += 256u) {
     if (!(cell_prefix[sl] <= c && c < cell_prefix[sl + 1])) {  // last sl with cell_prefix[sl] <= c
       u32 lo = 0, hi = 255;
       while (lo < hi) {
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void scanline_kernel(const float *__restrict__
   }
   if (!EMIT) {
     __syncthreads();
-    if (s < total_scanlines) frag_count[s] = slot[threadIdx.x];
+    if (s < total_scanlines) frag_count[(size_t)s * slices + blockIdx.y] = slot[threadIdx.x];
   }
 }
 
@@ -330,11 +335,17 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   SVO_HIP(hipStreamSynchronize(stream));
   if (total_scan == 0) return SVOSLAM_OK;
   // fragments per scanline -> exclusive scan -> emit
-  SVO_TRY(ws->rec_front.reserve((size_t)total_scan * 4));
+  // (fine grids: the cells of a workgroup's scan lines are cut into slices -- see scanline_kernel)
+  int slices = 1;
+  while (slices < 64 && log_N - 9 > 0 && slices < (1 << (log_N - 9))) slices <<= 1;
+  if ((unsigned long long)total_scan * (unsigned)slices > 0x7FFFFFFFull) slices = 1;
+  const u32 count_entries = total_scan * (u32)slices;
+  SVO_TRY(ws->rec_front.reserve((size_t)count_entries * 4));
   u32 *frag_start = ws->rec_front.as<u32>();
-  scanline_kernel<false><<<cdiv(total_scan, 256), 256, 0, stream>>>(dv.as<float>(), n_tris, tri_start, total_scan, G, frag_start,
-                                                                   nullptr, nullptr, nullptr, -1);
-  SVO_TRY(exclusive_scan_u32(ws, frag_start, total_scan, d_total, stream));
+  const dim3 raster_grid(cdiv(total_scan, 256), (unsigned)slices);
+  scanline_kernel<false><<<raster_grid, 256, 0, stream>>>(dv.as<float>(), n_tris, tri_start, total_scan, G, frag_start,
+                                                         nullptr, nullptr, nullptr, -1, slices);
+  SVO_TRY(exclusive_scan_u32(ws, frag_start, count_entries, d_total, stream));
   u32 total_frag = 0;
   SVO_HIP(hipMemcpyAsync(&total_frag, d_total, 4, hipMemcpyDeviceToHost, stream));
   SVO_HIP(hipStreamSynchronize(stream));
@@ -351,8 +362,8 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   int tri_bits = 1;
   while ((1ll << tri_bits) < (long long)n_tris) tri_bits++;
   const int pack_shift = (3 * log_N + tri_bits <= 64 && config().sort_pairs == 0) ? tri_bits : -1;
-  scanline_kernel<true><<<cdiv(total_scan, 256), 256, 0, stream>>>(dv.as<float>(), n_tris, tri_start, total_scan, G, nullptr,
-                                                                  frag_start, ws->keys_a.as<u64>(), ws->vals_a.as<u32>(), pack_shift);
+  scanline_kernel<true><<<raster_grid, 256, 0, stream>>>(dv.as<float>(), n_tris, tri_start, total_scan, G, nullptr,
+                                                        frag_start, ws->keys_a.as<u64>(), ws->vals_a.as<u32>(), pack_shift, slices);
   SVO_LAUNCH_CHECK();
   (void)stage_end(kStageMeshRaster, tk_raster, stream);
   // order by framebuffer index (stable: equal cells keep ascending triangle id -- fragments are emitted triangle by triangle)

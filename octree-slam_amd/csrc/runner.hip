@@ -66,6 +66,8 @@ struct svoslam_runner {
   // fixed input addresses per stream: the library replays its launch sequences as HIP graphs keyed on the
   // pointers it is given (graph_cache.hpp), so every frame is copied into a staging buffer first
   uint16_t *in_track = nullptr, *in_prep = nullptr;
+  uint16_t *model_depth = nullptr;         // svoslam_runner_run_model: the map ray-cast from the pose just tracked
+  unsigned *model_count = nullptr;         // ... and the number of its pixels that met the map
   std::vector<hipEvent_t> events;  // pool, grown on demand
   hipEvent_t ev_begin = nullptr, ev_end[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t last_caller = nullptr;
@@ -192,6 +194,8 @@ int svoslam_runner_destroy(svoslam_runner *r) {
   }
   for (int k = 0; k < 2; k++) (void)hipFree(r->scratch_image[k]);
   (void)hipFree(r->bbox); (void)hipFree(r->in_track); (void)hipFree(r->in_prep);
+  if (r->model_depth) (void)hipFree(r->model_depth);
+  if (r->model_count) (void)hipFree(r->model_count);
   {
     // (the streams' render tables are released; the streams themselves wait for the next runner: see svoslam_runner_create)
     std::array<hipStream_t, 5> set = {r->s_maps, r->s_track, r->s_prep, r->s_map[0], r->s_map[1]};
@@ -555,6 +559,86 @@ int svoslam_runner_run_sharded_presorted(svoslam_runner *r, const uint16_t *cons
   if (n > 0 && (!d_deltas || !d_images || !d_sorted_keys || !d_sorted_idx)) return SVOSLAM_ERR_INVALID_ARG;
   return runner_run_impl(r, d_depths, d_rgbs, timestamps, views, n, nullptr, row_first, rows, d_steps, caller_stream, d_deltas,
                          delta_events, march, d_images, d_sorted_keys, d_sorted_idx, sorted_events);
+}
+
+// ---- frame-to-model tracking inside the native loop (VERDICT r04 missing 3) --------------------------------------
+// The reference leaves it as a TODO (src/sensor/rgbd_camera.cpp:185: "ICP should not swap, as last_frame should be updated by a
+// different function"); the entry points that ARE that function (svoslam_raycast_model_depth, svoslam_camera_set_model_depth,
+// svoslam_camera_set_frame_to_model: include/svoslam.h) were driven from the Python pipeline only.  Here the whole frame runs
+// inside the library: track (against the model set once one has been accepted) -> back-project + fuse -> ray-cast the map into a
+// depth image from the pose just tracked -> accept it as the next frame's model if it covers at least min_coverage of the
+// pixels (else the next frame falls back to the previous frame's maps) -> cone-traced view.  The model of frame k+1 is a function
+// of the map AFTER fusion k, so nothing of frame k+1 but its maps could overlap frame k: the loop is sequential on the caller's
+// stream, with ONE 4-byte readback per frame (the coverage count decides on the host which map set the next launch reads).
+__global__ __launch_bounds__(256) void count_nonzero_u16_kernel(const uint16_t *__restrict__ d, int n, unsigned *__restrict__ out) {
+  __shared__ unsigned s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  unsigned c = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) c += d[i] != 0 ? 1u : 0u;
+  const unsigned long long m = __ballot(c != 0);
+  (void)m;
+  for (int o = 32; o > 0; o >>= 1) c += (unsigned)__shfl_down((int)c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_cnt) atomicAdd(out, s_cnt);
+}
+
+int svoslam_runner_run_model(svoslam_runner *r, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs, const long long *timestamps,
+                             const float *views, int32_t n, uint8_t *d_image, int32_t row_first, int32_t rows,
+                             unsigned long long *d_steps, float min_coverage, int32_t *models_used, void *caller_stream) {
+  if (models_used) *models_used = 0;
+  if (!r || n < 0 || (n > 0 && (!d_depths || !d_rgbs || !timestamps || !views || !d_image))) return SVOSLAM_ERR_INVALID_ARG;
+  if (row_first < 0 || rows < 0 || row_first + rows > r->h || !(min_coverage >= 0.0f)) return SVOSLAM_ERR_INVALID_ARG;
+  if (r->replicas != 1) return SVOSLAM_ERR_INVALID_ARG;
+  for (int i = 0; i < n; i++) if (!d_depths[i] || !d_rgbs[i] || (i > 0 && timestamps[i] <= timestamps[i - 1])) return SVOSLAM_ERR_INVALID_ARG;
+  if (n == 0) return SVOSLAM_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(caller_stream);
+  const size_t px = (size_t)r->w * r->h;
+  const int npts = r->w * r->h;
+  if (!r->model_depth) {
+    SVO_HIP(hipMalloc((void **)&r->model_depth, px * 2));
+    SVO_HIP(hipMalloc((void **)&r->model_count, 4));
+  }
+  SVO_TRY(svoslam_camera_set_frame_to_model(r->cam, 1));
+  svoslam_workspace *ws = r->ws[0];
+  int used_models = 0;
+  for (int i = 0; i < n; i++) {
+    int32_t used = 0;
+    SVO_TRY(svoslam_camera_prepare(r->cam, d_depths[i], d_rgbs[i], timestamps[i], &used, s));
+    if (!used) return SVOSLAM_ERR_INVALID_ARG;  // (a timestamp the camera has already seen)
+    SVO_TRY(svoslam_camera_track(r->cam, s));
+    const float *pose = svoslam_camera_fusion_transform_device(r->cam);
+    if (r->fused_front) {  // main.cpp:39-44 + computeKeys in one launch, then sort / plan / commit (svoFromPointCloud)
+      SVO_TRY(svoslam_svo_fuse_sort_frame(ws, d_depths[i], pose, r->w, r->h, r->fx, r->fy, r->depth, r->center, r->edge, r->bbox, s));
+    } else {
+      float *pts = r->points[0];
+      SVO_TRY(svoslam_generate_vertex_map(d_depths[i], pts, r->w, r->h, r->fx, r->fy, r->w, r->h, s));
+      SVO_TRY(svoslam_transform_vertex_map_dmat(pts, pose, npts, s));
+      SVO_TRY(svoslam_point_cloud_bbox_device(ws, pts, npts, r->bbox, s));
+      SVO_TRY(svoslam_svo_fuse_sort(ws, pts, npts, r->depth, r->center, r->edge, s));
+    }
+    SVO_TRY(svoslam_svo_fuse_plan(ws, npts, r->depth, r->pool, s));
+    SVO_TRY(svoslam_svo_fuse_commit(ws, d_rgbs[i], npts, r->depth, r->pool, s));
+    // the map as the sensor would see it from the pose just tracked -> the maps the NEXT frame is tracked against
+    SVO_TRY(svoslam_raycast_model_depth(r->model_depth, r->w, r->h, r->fx, r->fy, nullptr, pose, r->pool->d_data, r->center, r->edge, nullptr, s));
+    SVO_HIP(hipMemsetAsync(r->model_count, 0, 4, s));
+    count_nonzero_u16_kernel<<<256, 256, 0, s>>>(r->model_depth, npts, r->model_count);
+    SVO_LAUNCH_CHECK();
+    unsigned covered = 0;
+    SVO_HIP(hipMemcpyAsync(&covered, r->model_count, 4, hipMemcpyDeviceToHost, s));
+    SVO_HIP(hipStreamSynchronize(s));
+    if ((double)covered >= (double)min_coverage * (double)px) {
+      SVO_TRY(svoslam_camera_set_model_depth(r->cam, r->model_depth, s));
+      used_models++;
+    } else {
+      SVO_TRY(svoslam_camera_set_model_depth(r->cam, nullptr, s));
+    }
+    SVO_TRY(svoslam_cone_trace_svo_band(i == n - 1 ? d_image : r->scratch_image[0], r->w, r->h, row_first, rows, r->fov, views + 16 * (size_t)i,
+                                        r->pool->d_data, r->center, r->edge, r->mode, d_steps, s));
+  }
+  if (models_used) *models_used = used_models;
+  return SVOSLAM_OK;
 }
 
 // computePointCloudBoundingBox of the last frame enqueued (main.cpp:43): {min xyz, max xyz, any}.  Blocking.

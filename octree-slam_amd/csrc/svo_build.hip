@@ -536,11 +536,16 @@ template <bool VEC4>
 __global__ __launch_bounds__(256) void fill_kernel(const u64 *__restrict__ skey, const u32 *__restrict__ sidx, int n,
                                                    int depth, const unsigned char *__restrict__ leaf_t,
                                                    const void *__restrict__ colors, int color_by_position,
-                                                   u32 *__restrict__ pool, u32 *__restrict__ path_nodes) {
+                                                   u32 *__restrict__ pool, u32 *__restrict__ path_nodes,
+                                                   unsigned char *__restrict__ leaf_c) {
+  // leaf_c (round 5): the head's common-prefix length for the mip passes (0xFF: not a head), so that each of their D - 1
+  // launches reads one byte per key instead of two 8-byte keys (config 5: 318 M keys x 15 levels)
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n || leaf_t[j] == kNotHead) return;
+  if (j >= n) return;
+  if (leaf_t[j] == kNotHead) { leaf_c[j] = 0xFF; return; }
   u64 key; int c = 0;
   (void)is_head(skey, j, key, c, depth);
+  leaf_c[j] = (unsigned char)c;
   u32 base = 0, node = 0;
   for (int lvl = 1; lvl <= depth; lvl++) {
     node = base + ((u32)(key >> (3 * (depth - lvl))) & 7u);
@@ -625,14 +630,11 @@ __device__ inline void shadow_store(unsigned long long *__restrict__ shadow, u32
   shadow[node] = ((unsigned long long)epoch << 32) | word;
 }
 
-__global__ __launch_bounds__(256) void mip_level_kernel(const u64 *__restrict__ skey, int n, int depth, int d,
-                                                        const unsigned char *__restrict__ leaf_t,
+__global__ __launch_bounds__(256) void mip_level_kernel(int n, int d, const unsigned char *__restrict__ leaf_c,
                                                         const u32 *__restrict__ path_nodes, u32 *__restrict__ pool) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n || leaf_t[j] == kNotHead) return;
-  u64 key; int c = 0;
-  (void)is_head(skey, j, key, c, depth);
-  if (c >= d) return;  // an earlier leaf owns this prefix
+  if (j >= n) return;
+  if ((int)leaf_c[j] >= d) return;  // not a head (0xFF), or an earlier leaf owns this prefix
   const u32 node = path_nodes[(size_t)(d - 1) * n + j];
   pool[2 * (size_t)node + 1] = average_tile(pool, pool[2 * (size_t)node] & kMask);
 }
@@ -1504,12 +1506,14 @@ static int svo_insert(svoslam_workspace *ws, int n, int depth, svoslam_pool *poo
   if (hc.any_valid) {
     (void)stage_begin(kStageFuseCommit, stream, &tk);  // (a second entry of the stage: the reader sums them)
     u32 *path_nodes = ws->path_nodes.as<u32>();
+    SVO_TRY(ws->leaf_start.reserve((size_t)n));  // (the async path's buffer, free in the blocking one: one byte per key here)
+    unsigned char *leaf_c = ws->leaf_start.as<unsigned char>();
     if (vec4)
-      fill_kernel<true><<<tiles, 256, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, color_by_position, pool->d_data, path_nodes);
+      fill_kernel<true><<<tiles, 256, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, color_by_position, pool->d_data, path_nodes, leaf_c);
     else
-      fill_kernel<false><<<tiles, 256, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, color_by_position, pool->d_data, path_nodes);
+      fill_kernel<false><<<tiles, 256, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, color_by_position, pool->d_data, path_nodes, leaf_c);
     for (int d = depth - 1; d >= 1; d--)  // mipmapNodes, svo.cu:450-465
-      mip_level_kernel<<<tiles, 256, 0, stream>>>(skey, n, depth, d, leaf_t, path_nodes, pool->d_data);
+      mip_level_kernel<<<tiles, 256, 0, stream>>>(n, d, leaf_c, path_nodes, pool->d_data);
     mip_root_kernel<<<1, 64, 0, stream>>>(pool->d_data, small_counts(ws));
     SVO_LAUNCH_CHECK();
     (void)stage_end(kStageFuseCommit, tk, stream);

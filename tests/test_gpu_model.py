@@ -236,3 +236,50 @@ def test_model_depth_full_size_cfg3_geometry(env, oracle):
         ocam.set_model_depth(omodel if (omodel > 0).sum() >= 0.5 * w * h else None)
     valid = (omodel > 0)
     assert valid.mean() > 0.5
+
+
+def test_native_model_loop_equals_the_pipeline_loop(env, oracle):
+    """svoslam_runner_run_model (csrc/runner.hip: frame-to-model tracking inside the library's frame loop) against
+    SlamPipeline.frame() -- the loop the test above checks against the oracle call by call -- from the same saturated starting map:
+    poses, pools, accepted models and the last image equal bit for bit; and on a young map (no model accepted) it is the plain loop"""
+    pkg, torch, synth, pl = env
+    w, h, depth, center, edge = 160, 120, 8, (0.0, 1.5, 0.0), 4.096
+
+    def start():
+        P = pl.SlamPipeline(w, h, depth, center, edge, frame_to_model=True)
+        d, c = synth.render_frame(0, w, h, device="cuda")
+        P.track(d, c, 0)
+        P.backproject(d)
+        for _ in range(64):
+            P.fuse(c)
+        P.refresh_model()
+        return P
+
+    A, B = start(), start()
+    assert A.model_used == 1 and np.array_equal(A.pool.words(), B.pool.words())
+    frames = [synth.render_frame(2 * k, w, h, device="cuda") for k in range(1, 5)]
+    views = [pl.ground_truth_view(2 * k, synth) for k in range(1, 5)]
+    for k, ((d, c), view) in enumerate(zip(frames, views), start=1):
+        img_a = A.frame(d, c, k, view)
+    runner = pkg.Runner(B.cam, B.pool, w, h, depth, center, edge, B.focal, B.focal, B.mode)
+    used = runner.run_model([d for d, _ in frames], [c for _, c in frames], [1, 2, 3, 4], views, B.image, 0, h, min_coverage=0.5)
+    torch.cuda.synchronize()
+    assert used == A.model_used - 1 == 4
+    pa, oa = A.cam.pose(); pb, ob = B.cam.pose()
+    assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32)) and np.array_equal(oa.view(np.uint32), ob.view(np.uint32))
+    assert A.pool.size == B.pool.size and np.array_equal(A.pool.words(), B.pool.words())
+    assert np.array_equal(img_a.cpu().numpy(), B.image.cpu().numpy())
+    # young map: nothing answers a model ray, no model is accepted, the frames are tracked frame to frame
+    Y = pl.SlamPipeline(w, h, depth, center, edge)
+    Z = pl.SlamPipeline(w, h, depth, center, edge)
+    fr = [synth.render_frame(2 * k, w, h, device="cuda") for k in range(4)]
+    vw = [pl.ground_truth_view(2 * k, synth) for k in range(4)]
+    for k, ((d, c), view) in enumerate(zip(fr, vw)):
+        img_y = Y.frame(d, c, k, view)
+    rz = pkg.Runner(Z.cam, Z.pool, w, h, depth, center, edge, Z.focal, Z.focal, Z.mode)
+    assert rz.run_model([d for d, _ in fr], [c for _, c in fr], [0, 1, 2, 3], vw, Z.image, 0, h) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(Y.cam.pose()[1], Z.cam.pose()[1]) and np.array_equal(Y.pool.words(), Z.pool.words())
+    assert np.array_equal(img_y.cpu().numpy(), Z.image.cpu().numpy())
+    with pytest.raises(pkg.SvoslamError):
+        rz.run_model([fr[0][0]], [fr[0][1]], [3], vw[:1], Z.image, 0, h)      # a timestamp the camera has seen
