@@ -194,8 +194,10 @@ __global__ __launch_bounds__(256) void scanline_kernel(const float *__restrict__
     const float uf = ((float)u + 0.5f) * pick(G.delta, U);
     const float wf = Q.pz - (Q.px * uf + Q.py * Q.vf);
     const int w = (int)(wf * pick(G.inv_delta, W));
-    int xyz[3];
-    xyz[U] = u; xyz[V] = Q.v; xyz[W] = w;
+    // (selects, not xyz[U] = u: an array indexed by a runtime axis lives in scratch memory -- a store and three loads per cell)
+    // axis 0: (U, V, W) = (1, 2, 0); axis 1: (0, 2, 1); axis 2: (0, 1, 2)
+    const int xyz[3] = {W == 0 ? w : u, W == 0 ? u : (W == 1 ? w : Q.v), W == 2 ? w : Q.v};
+    (void)V;
     // the tile holding (u, v, w) must be one of the tiles of the triangle's integer bbox ...
     const int tw = w >> G.log_T;
     if (w < 0 || tw < Q.tw_lo || tw > Q.tw_hi) continue;

@@ -208,13 +208,23 @@ __global__ __launch_bounds__(kPkThreads) void packed_upsweep_kernel(const unsign
 
 // hist[t][d] (t < tiles, d < bins) -> exclusive prefix over t, in place; totals[d] = column sum.  One workgroup of 16
 // wavefronts per 64 digits: wavefront w scans the tiles [w C, (w + 1) C) of its 64 columns (256-byte row segments).
+// MODE 0: the whole matrix by bins / 64 workgroups (a frame's keys: <= 1013 tiles).  Large inputs (round 5: config 5 sorts 375 M
+// fragments = 183 000 tiles through 8-bit digits -- FOUR workgroups walked a 187 MB matrix, 2.3 ms per pass and 30 ms of the
+// configuration's 130) cut the tiles into chunks (blockIdx.y): MODE 1 writes each chunk's column sums to chunk_mat[chunk][d],
+// MODE 0 scans that small matrix in place, MODE 2 scans every chunk again on top of its entry.
+template <int MODE>
 __global__ __launch_bounds__(1024) void packed_column_scan_kernel(unsigned *__restrict__ hist, int tiles, int bins,
-                                                                  unsigned *__restrict__ totals) {
+                                                                  unsigned *__restrict__ totals, unsigned *__restrict__ chunk_mat,
+                                                                  int chunk_tiles) {
   __shared__ unsigned csum[16][64];
   const int lane = (int)(threadIdx.x & 63u), w = (int)(threadIdx.x >> 6);
   const int d = blockIdx.x * 64 + lane;
-  const int C = (tiles + 15) / 16;
-  const int t0 = w * C, t1 = (t0 + C < tiles) ? t0 + C : tiles;
+  const int c_begin = MODE == 0 ? 0 : (int)blockIdx.y * chunk_tiles;
+  int c_end = MODE == 0 ? tiles : c_begin + chunk_tiles;
+  if (c_end > tiles) c_end = tiles;
+  const int span = c_end > c_begin ? c_end - c_begin : 0;
+  const int C = (span + 15) / 16;
+  const int t0 = c_begin + w * C, t1 = (t0 + C < c_end) ? t0 + C : c_end;
   const bool col = d < bins;
   unsigned sum = 0;
   for (int t = t0; t < t1; t += 8) {
@@ -233,6 +243,11 @@ __global__ __launch_bounds__(1024) void packed_column_scan_kernel(unsigned *__re
     if (k < w) run += c;
     total += c;
   }
+  if (MODE == 1) {
+    if (w == 0 && col) chunk_mat[(size_t)blockIdx.y * bins + d] = total;
+    return;
+  }
+  if (MODE == 2 && col) run += chunk_mat[(size_t)blockIdx.y * bins + d];
   for (int t = t0; t < t1; t += 8) {
     unsigned v[8];
 #pragma unroll
@@ -243,7 +258,23 @@ __global__ __launch_bounds__(1024) void packed_column_scan_kernel(unsigned *__re
       run += v[k];
     }
   }
-  if (w == 0 && col) totals[d] = total;
+  if (MODE == 0 && w == 0 && col) totals[d] = total;
+}
+
+// the column scan of one pass: one launch, or three for large matrices (see above); chunk_mat: >= 256 x bins words
+static void packed_column_scan(unsigned *tile_hist, int tiles, int bins, unsigned *totals, unsigned *chunk_mat, hipStream_t stream) {
+  const unsigned gx = (unsigned)(bins + 63) / 64;
+  if (tiles <= 8192 || !chunk_mat) {
+    packed_column_scan_kernel<0><<<gx, 1024, 0, stream>>>(tile_hist, tiles, bins, totals, nullptr, 0);
+    return;
+  }
+  int chunks = tiles / 1024;
+  if (chunks > 256) chunks = 256;
+  const int chunk_tiles = (tiles + chunks - 1) / chunks;
+  chunks = (tiles + chunk_tiles - 1) / chunk_tiles;
+  packed_column_scan_kernel<1><<<dim3(gx, (unsigned)chunks), 1024, 0, stream>>>(tile_hist, tiles, bins, nullptr, chunk_mat, chunk_tiles);
+  packed_column_scan_kernel<0><<<gx, 1024, 0, stream>>>(chunk_mat, chunks, bins, totals, nullptr, 0);
+  packed_column_scan_kernel<2><<<dim3(gx, (unsigned)chunks), 1024, 0, stream>>>(tile_hist, tiles, bins, nullptr, chunk_mat, chunk_tiles);
 }
 
 template <bool LAST>
@@ -362,6 +393,11 @@ int radix_sort_packed_ex(svoslam_workspace *ws, int n, int key_bits, int idx_bit
   int passes = (key_bits + max_bits - 1) / max_bits;
   if (passes < 1) passes = 1;
   unsigned *totals = tile_hist + (size_t)tiles * row_words;  // behind the largest histogram matrix
+  unsigned *chunk_mat = nullptr;  // large inputs: the chunks' column sums (packed_column_scan)
+  if (tiles > 8192) {
+    SVO_TRY(ws->scan_tmp.reserve((size_t)256 * row_words * 4));
+    chunk_mat = ws->scan_tmp.as<unsigned>();
+  }
   int bit = 0;
   for (int p = 0; p < passes; p++) {
     const int remaining_bits = key_bits - bit, remaining_passes = passes - p;
@@ -369,7 +405,7 @@ int radix_sort_packed_ex(svoslam_workspace *ws, int n, int key_bits, int idx_bit
     if (width < 1) width = 1;
     const int bins = 1 << width, shift = idx_bits + bit;
     if (p > 0 || !have_first_hist) packed_upsweep_kernel<<<tiles, kPkThreads, 0, stream>>>(ka, n, shift, width, tile_hist);
-    packed_column_scan_kernel<<<(bins + 63) / 64, 1024, 0, stream>>>(tile_hist, tiles, bins, totals);
+    packed_column_scan(tile_hist, tiles, bins, totals, chunk_mat, stream);
     if (p == passes - 1)
       packed_downsweep_kernel<true><<<tiles, kPkThreads, 0, stream>>>(ka, kb, want_vals ? ws->vals_a.as<unsigned>() : nullptr, n, shift, width, idx_bits, tile_hist, totals);
     else
