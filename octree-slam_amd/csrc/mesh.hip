@@ -338,8 +338,11 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   if (total_scan == 0) return SVOSLAM_OK;
   // fragments per scanline -> exclusive scan -> emit
   // (fine grids: the cells of a workgroup's scan lines are cut into slices -- see scanline_kernel)
-  int slices = 1;
-  while (slices < 64 && log_N - 9 > 0 && slices < (1 << (log_N - 9))) slices <<= 1;
+  // measured on config 5's stand-in (2^16 cells per axis, 375 M fragments), count + emit: 1 slice 33.7 ms, 2: 21.0, 4: 17.4, 8: 20.5,
+  // 16: 38, 64: 33.7 -- every slice repeats the workgroup's set-up (a binary search over the triangles' scan-line offsets + the
+  // triangle's raster set-up per lane), and the SQ counters show the kernel waiting, not issuing (8 % VALU, 60 % of its
+  // wavefront-cycles in s_waitcnt), at every slice count
+  int slices = log_N >= 15 ? 4 : (log_N >= 13 ? 2 : 1);
   if ((unsigned long long)total_scan * (unsigned)slices > 0x7FFFFFFFull) slices = 1;
   const u32 count_entries = total_scan * (u32)slices;
   SVO_TRY(ws->rec_front.reserve((size_t)count_entries * 4));
