@@ -11,9 +11,9 @@ brackets on the launch stream (svoslam_stage_timing: mesh_raster / mesh_sort / m
 fuse_plan / fuse_commit inside svoslam_svo_from_voxel_grid, march around each trace kernel); `call_ms` is the wall clock of the C call.
 
 Algorithmic bytes (T triangles, F (cell, triangle) fragments, V voxels, K split nodes, D depth):
-  mesh_raster   36 T (vertices) + 12 F (8-byte cell key + 4-byte triangle id written)
-  mesh_sort     24 F per 8-bit pass (12 read + 12 written), ceil(3 D / 8) passes
-  mesh_emit     12 F read + 24 T (uv) + 32 V (centre + colour vec4) written
+  mesh_raster   36 T (vertices) + 8 F (one packed word per fragment: cell index << tri_bits | triangle id)
+  mesh_sort     16 F per pass (8 read + 8 written), ceil(3 D / b) passes of b-bit digits (b = 11 / 9 / 8 by size: radix_sort.hip)
+  mesh_emit     12 F read (8-byte key + 4-byte triangle id of the unpacking pass) + 24 T (uv) + 32 V (centre + colour vec4) written
   voxelize call 60 T + 32 V: what meshToVoxelGrid's interface takes in and hands out (the fragments are this build's intermediate)
   svo_from_voxel_grid   SURVEY 8d's fusion formula with 32 bytes per voxel in: 32 V + 4 D V + 8 V + 72 K + 36 K
                         (a fresh pool: every touched inner node is split once, so sum_l U_l = K = (nodes - 8) / 8, U_D = V)
@@ -113,20 +113,21 @@ def main():
     K = (nodes - 8) // 8
     F = pkg.mesh_last_fragments(ws)
     out["fragments"] = F
-    passes = (3 * depth + 7) // 8
+    digit = 11 if F <= (4 << 20) else (9 if F <= (64 << 20) else 8)     # radix_packed_digit_bits_for
+    passes = (3 * depth + digit - 1) // digit
     vox_ms = sum(best_stage.get(nm, 0.0) for nm, _ in mesh_stages)
     fus_ms = sum(best_stage.get(nm, 0.0) for nm, _ in fuse_stages)
     st = {}
     if F is not None:
         st["mesh_raster"] = dict(kernel="tri_scanline_count_kernel + scanline_kernel<false> + scanline_kernel<true> + 2 scans (2 count readbacks inside)",
-                                 **roof(36.0 * T + 12.0 * F, best_stage.get("mesh_raster", 0.0)))
-        st["mesh_sort"] = dict(kernel="radix_sort_pairs: %d passes of 8 bits x (upsweep, row scan, downsweep)" % passes,
-                               **roof(24.0 * F * passes, best_stage.get("mesh_sort", 0.0)))
+                                 **roof(36.0 * T + 8.0 * F, best_stage.get("mesh_raster", 0.0)))
+        st["mesh_sort"] = dict(kernel="radix_sort_packed_ex: %d passes of <= %d bits x (packed_upsweep, packed_column_scan, packed_downsweep)" % (passes, digit),
+                               **roof(16.0 * F * passes, best_stage.get("mesh_sort", 0.0)))
         st["mesh_emit"] = dict(kernel="voxel_flag_kernel + scan + voxel_emit_kernel (1 count readback inside)",
                                **roof(12.0 * F + 24.0 * T + 32.0 * V, best_stage.get("mesh_emit", 0.0)))
     st["voxelize"] = dict(kernel="svoslam_mesh_to_voxel_grid (sum of the three stages above)", **roof(60.0 * T + 32.0 * V, vox_ms))
     fuse_alg = 32.0 * V + 4.0 * depth * V + 8.0 * V + 72.0 * K + 36.0 * K
-    st["svo_from_voxel_grid"] = dict(kernel="compute_keys + radix_sort_pairs + plan (3) + split_pass per level + fill_kernel + mip_level per level",
+    st["svo_from_voxel_grid"] = dict(kernel="compute_keys + packed key-only sort (radix_sort_packed_ex) + plan (3) + split_pass per level + fill_kernel + mip_level per level",
                                      parts_ms={nm: best_stage.get(nm) for nm, _ in fuse_stages}, **roof(fuse_alg, fus_ms))
     out["stages"] = st
     out["call_ms"] = {k: round(v, 3) for k, v in best.items()}
