@@ -118,16 +118,58 @@ __global__ __launch_bounds__(256) void tri_scanline_count_kernel(const float *__
 struct ScanlineSetup {
   int t, v, min_u, axis, tw_lo, tw_hi;
   float px, py, pz, vf, n[3], r1, r2;
+  u32 len;  // cells of the scan line's u range (0: none)
 };
+static_assert(sizeof(ScanlineSetup) == 64, "one 64-byte record per scan line");
+
+// The set-up of every scan line ONCE, as a 64-byte record (round 5): the count and the emit pass used to repeat it -- a binary
+// search over the triangles' scan-line offsets and the triangle's raster set-up, ~25 us of dependent loads per workgroup -- and
+// cutting a workgroup's cells into slices repeated it once more per slice, which is what kept the slices coarse.
+__global__ __launch_bounds__(256) void scanline_setup_kernel(const float *__restrict__ vbo, int n_tris, const u32 *__restrict__ tri_start,
+                                                             u32 total_scanlines, GridParams G, ScanlineSetup *__restrict__ out) {
+  const u32 s = blockIdx.x * 256u + threadIdx.x;
+  if (s >= total_scanlines) return;
+  // triangle of this scanline: last t with tri_start[t] <= s
+  int lo = 0, hi = n_tris - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tri_start[mid] <= s) lo = mid; else hi = mid - 1;
+  }
+  const int t = lo;
+  TriSetup S;
+  setup_triangle(vbo, t, G, S);
+  const int v = S.lo[S.V] + (int)(s - tri_start[t]);
+  const float b[3] = {S.a[0] + (float)v * S.ndv[0], S.a[1] + (float)v * S.ndv[1], S.a[2] + (float)v * S.ndv[2]};
+  int min_u = S.lo[S.U], max_u = S.hi[S.U];
+  bool invalid = false;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (S.ndu[k] > 0.0f) { const int c = (int)ceilf(-b[k] * S.inv_du[k]); min_u = c > min_u ? c : min_u; }
+    else if (S.ndu[k] < 0.0f) { const int c = (int)(-b[k] * S.inv_du[k]); max_u = c < max_u ? c : max_u; }
+    else if (b[k] < 0.0f) invalid = true;
+  }
+  ScanlineSetup Q;
+  Q.len = (!invalid && max_u >= min_u) ? (u32)(max_u - min_u + 1) : 0u;
+  Q.t = t; Q.v = v; Q.min_u = min_u; Q.axis = S.axis;
+  Q.tw_lo = S.lo[S.W] >> G.log_T; Q.tw_hi = S.hi[S.W] >> G.log_T;
+  Q.px = S.px; Q.py = S.py; Q.pz = S.pz;
+  Q.vf = ((float)v + 0.5f) * pick(G.delta, S.V);
+  Q.n[0] = S.n[0]; Q.n[1] = S.n[1]; Q.n[2] = S.n[2];
+  // fine.h:936-959, the two tile-independent terms of the plane/tile test
+  const float T = (float)G.T;
+  const float c0 = S.n[0] > 0 ? G.delta[0] * T : 0.0f, c1 = S.n[1] > 0 ? G.delta[1] * T : 0.0f, c2 = S.n[2] > 0 ? G.delta[2] * T : 0.0f;
+  Q.r1 = S.n[0] * (c0 - S.v0[0]) + S.n[1] * (c1 - S.v0[1]) + S.n[2] * (c2 - S.v0[2]);
+  Q.r2 = S.n[0] * (G.delta[0] * T - c0 - S.v0[0]) + S.n[1] * (G.delta[1] * T - c1 - S.v0[1]) + S.n[2] * (G.delta[2] * T - c2 - S.v0[2]);
+  out[s] = Q;
+}
 
 template <bool EMIT>
-__global__ __launch_bounds__(256) void scanline_kernel(const float *__restrict__ vbo, int n_tris,
-                                                       const u32 *__restrict__ tri_start, u32 total_scanlines, GridParams G,
+__global__ __launch_bounds__(256) void scanline_kernel(const ScanlineSetup *__restrict__ lines, u32 total_scanlines, GridParams G,
                                                        u32 *__restrict__ frag_count, const u32 *__restrict__ frag_start,
                                                        u64 *__restrict__ frag_key, u32 *__restrict__ frag_tri, int pack_shift, int slices) {
   // slices (round 5): blockIdx.y takes the cells [total * y / slices, total * (y + 1) / slices) of the workgroup's 256 scan lines and
   // counts / emits into entry s * slices + y of frag_count / frag_start.  At 2^16 cells per axis a scan line is up to 65536 cells
-  // long and 256 of them were ONE workgroup's loop: config 5's 375 M fragments were the work of 22 workgroups (33 ms).
+  // long and 256 of them were ONE workgroup's loop.
   // pack_shift >= 0 (round 5): ONE word per fragment, framebuffer index << pack_shift | triangle id, for the packed sort
   // (radix_sort.hip) -- 8 bytes per fragment and pass instead of 8 + 4 in two arrays
   __shared__ ScanlineSetup setup[256];
@@ -135,37 +177,8 @@ __global__ __launch_bounds__(256) void scanline_kernel(const float *__restrict__
   const u32 s = blockIdx.x * 256u + threadIdx.x;
   u32 len = 0;
   if (s < total_scanlines) {
-    // triangle of this scanline: last t with tri_start[t] <= s
-    int lo = 0, hi = n_tris - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (tri_start[mid] <= s) lo = mid; else hi = mid - 1;
-    }
-    const int t = lo;
-    TriSetup S;
-    setup_triangle(vbo, t, G, S);
-    const int v = S.lo[S.V] + (int)(s - tri_start[t]);
-    const float b[3] = {S.a[0] + (float)v * S.ndv[0], S.a[1] + (float)v * S.ndv[1], S.a[2] + (float)v * S.ndv[2]};
-    int min_u = S.lo[S.U], max_u = S.hi[S.U];
-    bool invalid = false;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      if (S.ndu[k] > 0.0f) { const int c = (int)ceilf(-b[k] * S.inv_du[k]); min_u = c > min_u ? c : min_u; }
-      else if (S.ndu[k] < 0.0f) { const int c = (int)(-b[k] * S.inv_du[k]); max_u = c < max_u ? c : max_u; }
-      else if (b[k] < 0.0f) invalid = true;
-    }
-    if (!invalid && max_u >= min_u) len = (u32)(max_u - min_u + 1);
-    ScanlineSetup &Q = setup[threadIdx.x];
-    Q.t = t; Q.v = v; Q.min_u = min_u; Q.axis = S.axis;
-    Q.tw_lo = S.lo[S.W] >> G.log_T; Q.tw_hi = S.hi[S.W] >> G.log_T;
-    Q.px = S.px; Q.py = S.py; Q.pz = S.pz;
-    Q.vf = ((float)v + 0.5f) * pick(G.delta, S.V);
-    Q.n[0] = S.n[0]; Q.n[1] = S.n[1]; Q.n[2] = S.n[2];
-    // fine.h:936-959, the two tile-independent terms of the plane/tile test
-    const float T = (float)G.T;
-    const float c0 = S.n[0] > 0 ? G.delta[0] * T : 0.0f, c1 = S.n[1] > 0 ? G.delta[1] * T : 0.0f, c2 = S.n[2] > 0 ? G.delta[2] * T : 0.0f;
-    Q.r1 = S.n[0] * (c0 - S.v0[0]) + S.n[1] * (c1 - S.v0[1]) + S.n[2] * (c2 - S.v0[2]);
-    Q.r2 = S.n[0] * (G.delta[0] * T - c0 - S.v0[0]) + S.n[1] * (G.delta[1] * T - c1 - S.v0[1]) + S.n[2] * (G.delta[2] * T - c2 - S.v0[2]);
+    setup[threadIdx.x] = lines[s];  // (one 64-byte record: scanline_setup_kernel)
+    len = setup[threadIdx.x].len;
   }
   u32 total_cells;
   const u32 ex = block256_exclusive_scan(len, tmp, total_cells);
@@ -200,12 +213,27 @@ __global__ __launch_bounds__(256) void scanline_kernel(const float *__restrict__
     (void)V;
     // the tile holding (u, v, w) must be one of the tiles of the triangle's integer bbox ...
     const int tw = w >> G.log_T;
-    if (w < 0 || tw < Q.tw_lo || tw > Q.tw_hi) continue;
+    bool keep = !(w < 0 || tw < Q.tw_lo || tw > Q.tw_hi);
     // ... and pass the plane test
     const int tx = (xyz[0] >> G.log_T) << G.log_T, ty = (xyz[1] >> G.log_T) << G.log_T, tz = (xyz[2] >> G.log_T) << G.log_T;
     const float np = Q.n[0] * (G.bbox0[0] + (float)tx * G.delta[0]) + Q.n[1] * (G.bbox0[1] + (float)ty * G.delta[1]) + Q.n[2] * (G.bbox0[2] + (float)tz * G.delta[2]);
-    if (!((np + Q.r1) * (np + Q.r2) <= 0.0f)) continue;
-    const u32 k = atomicAdd(&slot[sl], 1u);
+    keep = keep && ((np + Q.r1) * (np + Q.r2) <= 0.0f);
+    // The slot of the fragment inside its scan line's range.  The 64 cells of a wavefront almost always belong to ONE scan line (they
+    // are up to 65536 cells long): one LDS atomic for the wavefront and a popcount rank instead of 64 returning atomics on one
+    // address, which the LDS serialises -- at 2^16 cells per axis that was the kernel (round 5: 8 % VALU issue, 8.5 ms per pass).
+    const unsigned long long km = __ballot(keep);
+    if (!km) continue;
+    const int leader = __ffsll((long long)km) - 1;
+    const u32 sl0 = (u32)__shfl((int)sl, leader);
+    u32 k = 0;
+    if (__all(!keep || sl == sl0)) {
+      u32 base = 0;
+      if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(&slot[sl0], (u32)__popcll(km));
+      k = (u32)__shfl((int)base, leader) + (u32)__popcll(km & ((1ull << (threadIdx.x & 63u)) - 1ull));
+    } else if (keep) {
+      k = atomicAdd(&slot[sl], 1u);
+    }
+    if (!keep) continue;
     if (EMIT) {
       const u64 tile = (u64)(xyz[0] >> G.log_T) + (u64)M * (u64)(xyz[1] >> G.log_T) + (u64)M * M * (u64)(xyz[2] >> G.log_T);
       const u64 pix = (u64)(xyz[0] & (G.T - 1)) + (u64)G.T * (u64)(xyz[1] & (G.T - 1)) + (u64)G.T * G.T * (u64)(xyz[2] & (G.T - 1));
@@ -336,20 +364,22 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   SVO_HIP(hipMemcpyAsync(&total_scan, d_total, 4, hipMemcpyDeviceToHost, stream));
   SVO_HIP(hipStreamSynchronize(stream));
   if (total_scan == 0) return SVOSLAM_OK;
-  // fragments per scanline -> exclusive scan -> emit
-  // (fine grids: the cells of a workgroup's scan lines are cut into slices -- see scanline_kernel)
-  // measured on config 5's stand-in (2^16 cells per axis, 375 M fragments), count + emit: 1 slice 33.7 ms, 2: 21.0, 4: 17.4, 8: 20.5,
-  // 16: 38, 64: 33.7 -- every slice repeats the workgroup's set-up (a binary search over the triangles' scan-line offsets + the
-  // triangle's raster set-up per lane), and the SQ counters show the kernel waiting, not issuing (8 % VALU, 60 % of its
-  // wavefront-cycles in s_waitcnt), at every slice count
+  // every scan line's set-up, once (64 bytes each), then fragments per scanline -> exclusive scan -> emit
+  SVO_TRY(ws->path_nodes.reserve((size_t)total_scan * sizeof(ScanlineSetup)));
+  ScanlineSetup *lines = ws->path_nodes.as<ScanlineSetup>();
+  scanline_setup_kernel<<<cdiv(total_scan, 256), 256, 0, stream>>>(dv.as<float>(), n_tris, tri_start, total_scan, G, lines);
+  // fine grids: the cells of a workgroup's 256 scan lines are cut into slices (scanline_kernel).  Config 5's stand-in (2^16 cells
+  // per axis, 375 M fragments, 525 k scan lines of which ~11 k -- the faces whose scan lines run along the long axis -- hold most
+  // of the cells), count + emit: 1 slice 33.7 ms, 2: 21.0, 4: 16-17, 8: 20.5, 16: 38, 64 / 256: 35-36.  Neither the set-up (now
+  // done once), nor the scratch-memory indexing, nor the per-lane LDS atomics (both gone) moved these numbers; the SQ counters show
+  // a kernel that waits (8 % VALU issue).  Unexplained beyond 4 slices; 4 it is.
   int slices = log_N >= 15 ? 4 : (log_N >= 13 ? 2 : 1);
   if ((unsigned long long)total_scan * (unsigned)slices > 0x7FFFFFFFull) slices = 1;
   const u32 count_entries = total_scan * (u32)slices;
   SVO_TRY(ws->rec_front.reserve((size_t)count_entries * 4));
   u32 *frag_start = ws->rec_front.as<u32>();
   const dim3 raster_grid(cdiv(total_scan, 256), (unsigned)slices);
-  scanline_kernel<false><<<raster_grid, 256, 0, stream>>>(dv.as<float>(), n_tris, tri_start, total_scan, G, frag_start,
-                                                         nullptr, nullptr, nullptr, -1, slices);
+  scanline_kernel<false><<<raster_grid, 256, 0, stream>>>(lines, total_scan, G, frag_start, nullptr, nullptr, nullptr, -1, slices);
   SVO_TRY(exclusive_scan_u32(ws, frag_start, count_entries, d_total, stream));
   u32 total_frag = 0;
   SVO_HIP(hipMemcpyAsync(&total_frag, d_total, 4, hipMemcpyDeviceToHost, stream));
@@ -367,8 +397,8 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   int tri_bits = 1;
   while ((1ll << tri_bits) < (long long)n_tris) tri_bits++;
   const int pack_shift = (3 * log_N + tri_bits <= 64 && config().sort_pairs == 0) ? tri_bits : -1;
-  scanline_kernel<true><<<raster_grid, 256, 0, stream>>>(dv.as<float>(), n_tris, tri_start, total_scan, G, nullptr,
-                                                        frag_start, ws->keys_a.as<u64>(), ws->vals_a.as<u32>(), pack_shift, slices);
+  scanline_kernel<true><<<raster_grid, 256, 0, stream>>>(lines, total_scan, G, nullptr, frag_start, ws->keys_a.as<u64>(), ws->vals_a.as<u32>(),
+                                                        pack_shift, slices);
   SVO_LAUNCH_CHECK();
   (void)stage_end(kStageMeshRaster, tk_raster, stream);
   // order by framebuffer index (stable: equal cells keep ascending triangle id -- fragments are emitted triangle by triangle)
