@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void tri_scanline_count_kernel(const float *__
 // walked by the whole workgroup (cell c -> scanline by search in the LDS prefix of the u-range lengths), so a
 // 65536-cell scanline of a long thin triangle costs 256 iterations, not 65536.  Fragments of one scanline have
 // distinct cells, so their order inside the scanline's slot range does not matter (LDS atomic slot counter).
+constexpr unsigned kPieceCells = 32768;  // candidate cells per raster workgroup (128 rounds of its 256 lanes)
 struct ScanlineSetup {
   int t, v, min_u, axis, tw_lo, tw_hi;
   float px, py, pz, vf, n[3], r1, r2;
@@ -126,9 +128,16 @@ static_assert(sizeof(ScanlineSetup) == 64, "one 64-byte record per scan line");
 // search over the triangles' scan-line offsets and the triangle's raster set-up, ~25 us of dependent loads per workgroup -- and
 // cutting a workgroup's cells into slices repeated it once more per slice, which is what kept the slices coarse.
 __global__ __launch_bounds__(256) void scanline_setup_kernel(const float *__restrict__ vbo, int n_tris, const u32 *__restrict__ tri_start,
-                                                             u32 total_scanlines, GridParams G, ScanlineSetup *__restrict__ out) {
+                                                             u32 total_scanlines, GridParams G, ScanlineSetup *__restrict__ out,
+                                                             u32 *__restrict__ pieces) {
+  // pieces[chunk] (chunk = this workgroup's 256 scan lines): how many workgroups the raster passes give the chunk -- one per
+  // kPieceCells candidate cells.  Config 5's stand-in has 33.6 M scan lines in 131 130 chunks with a median of 512 cells, and 100
+  // chunks (the faces whose scan lines run along the long axis) of 1-7 M cells: a uniform number of slices either leaves those
+  // to a few workgroups or multiplies 131 000 nearly empty ones.
+  __shared__ u32 tmp_red[4];
   const u32 s = blockIdx.x * 256u + threadIdx.x;
-  if (s >= total_scanlines) return;
+  u32 my_len = 0;
+  if (s < total_scanlines) {
   // triangle of this scanline: last t with tri_start[t] <= s
   int lo = 0, hi = n_tris - 1;
   while (lo < hi) {
@@ -161,20 +170,42 @@ __global__ __launch_bounds__(256) void scanline_setup_kernel(const float *__rest
   Q.r1 = S.n[0] * (c0 - S.v0[0]) + S.n[1] * (c1 - S.v0[1]) + S.n[2] * (c2 - S.v0[2]);
   Q.r2 = S.n[0] * (G.delta[0] * T - c0 - S.v0[0]) + S.n[1] * (G.delta[1] * T - c1 - S.v0[1]) + S.n[2] * (G.delta[2] * T - c2 - S.v0[2]);
   out[s] = Q;
+  my_len = Q.len;
+  }
+  u32 chunk_cells;
+  (void)block256_exclusive_scan(my_len, tmp_red, chunk_cells);
+  if (threadIdx.x == 0) {
+    u32 p = (chunk_cells + kPieceCells - 1u) / kPieceCells;
+    pieces[blockIdx.x] = p < 1u ? 1u : (p > 256u ? 256u : p);
+  }
+}
+
+// piece -> chunk: chunk c owns pieces [piece_base[c], piece_base[c] + pieces)
+__global__ __launch_bounds__(256) void piece_map_kernel(const u32 *__restrict__ piece_base, u32 chunks, u32 total_pieces, u32 *__restrict__ map) {
+  const u32 c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= chunks) return;
+  const u32 b = piece_base[c], e = c + 1 < chunks ? piece_base[c + 1] : total_pieces;
+  for (u32 p = b; p < e; p++) map[p] = c;
 }
 
 template <bool EMIT>
 __global__ __launch_bounds__(256) void scanline_kernel(const ScanlineSetup *__restrict__ lines, u32 total_scanlines, GridParams G,
                                                        u32 *__restrict__ frag_count, const u32 *__restrict__ frag_start,
-                                                       u64 *__restrict__ frag_key, u32 *__restrict__ frag_tri, int pack_shift, int slices) {
-  // slices (round 5): blockIdx.y takes the cells [total * y / slices, total * (y + 1) / slices) of the workgroup's 256 scan lines and
-  // counts / emits into entry s * slices + y of frag_count / frag_start.  At 2^16 cells per axis a scan line is up to 65536 cells
-  // long and 256 of them were ONE workgroup's loop.
+                                                       u64 *__restrict__ frag_key, u32 *__restrict__ frag_tri, int pack_shift,
+                                                       const u32 *__restrict__ piece_base, const u32 *__restrict__ piece_map, u32 chunks,
+                                                       u32 total_pieces) {
+  // One workgroup per PIECE of a chunk of 256 scan lines (scanline_setup_kernel): piece y of the chunk's S pieces takes the cells
+  // [total * y / S, total * (y + 1) / S) of the chunk and counts / emits into entry 256 * piece_base[chunk] + lane * S + y of
+  // frag_count / frag_start -- scan-line-major, so that the fragments of scan line s precede those of s + 1 whatever S is.
   // pack_shift >= 0 (round 5): ONE word per fragment, framebuffer index << pack_shift | triangle id, for the packed sort
   // (radix_sort.hip) -- 8 bytes per fragment and pass instead of 8 + 4 in two arrays
   __shared__ ScanlineSetup setup[256];
   __shared__ u32 cell_prefix[257], slot[256], out_base[256], tmp[4];
-  const u32 s = blockIdx.x * 256u + threadIdx.x;
+  const u32 chunk = piece_map[blockIdx.x];
+  const u32 pb = piece_base[chunk];
+  const u32 slices = (chunk + 1 < chunks ? piece_base[chunk + 1] : total_pieces) - pb, slice = blockIdx.x - pb;
+  const size_t entry = (size_t)256 * pb + (size_t)threadIdx.x * slices + slice;
+  const u32 s = chunk * 256u + threadIdx.x;
   u32 len = 0;
   if (s < total_scanlines) {
     setup[threadIdx.x] = lines[s];  // (one 64-byte record: scanline_setup_kernel)
@@ -185,13 +216,13 @@ __global__ __launch_bounds__(256) void scanline_kernel(const ScanlineSetup *__re
   cell_prefix[threadIdx.x] = ex;
   if (threadIdx.x == 255) cell_prefix[256] = total_cells;
   slot[threadIdx.x] = 0;
-  out_base[threadIdx.x] = (EMIT && s < total_scanlines) ? frag_start[(size_t)s * slices + blockIdx.y] : 0u;
+  out_base[threadIdx.x] = (EMIT && s < total_scanlines) ? frag_start[entry] : 0u;
   __syncthreads();
 
   const int M = 1 << (G.log_N - G.log_T);
   u32 sl = 0;
-  const u32 c_begin = (u32)((unsigned long long)total_cells * blockIdx.y / (unsigned)slices);
-  const u32 c_end = (u32)((unsigned long long)total_cells * (blockIdx.y + 1u) / (unsigned)slices);
+  const u32 c_begin = (u32)((unsigned long long)total_cells * slice / (unsigned)slices);
+  const u32 c_end = (u32)((unsigned long long)total_cells * (slice + 1u) / (unsigned)slices);
   for (u32 c = c_begin + threadIdx.x; c < c_end; c += 256u) {
     if (!(cell_prefix[sl] <= c && c < cell_prefix[sl + 1])) {  // last sl with cell_prefix[sl] <= c
       u32 lo = 0, hi = 255;
@@ -249,7 +280,7 @@ __global__ __launch_bounds__(256) void scanline_kernel(const ScanlineSetup *__re
   }
   if (!EMIT) {
     __syncthreads();
-    if (s < total_scanlines) frag_count[(size_t)s * slices + blockIdx.y] = slot[threadIdx.x];
+    frag_count[entry] = s < total_scanlines ? slot[threadIdx.x] : 0u;  // (every entry of the piece is written: the scan reads them all)
   }
 }
 
@@ -364,22 +395,28 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   SVO_HIP(hipMemcpyAsync(&total_scan, d_total, 4, hipMemcpyDeviceToHost, stream));
   SVO_HIP(hipStreamSynchronize(stream));
   if (total_scan == 0) return SVOSLAM_OK;
-  // every scan line's set-up, once (64 bytes each), then fragments per scanline -> exclusive scan -> emit
+  // every scan line's set-up, once (64 bytes each) + the pieces of every chunk of 256 scan lines; then fragments per (scan line,
+  // piece) -> exclusive scan -> emit
+  const u32 chunks = cdiv(total_scan, 256);
   SVO_TRY(ws->path_nodes.reserve((size_t)total_scan * sizeof(ScanlineSetup)));
+  SVO_TRY(ws->leaf_t.reserve((size_t)(chunks + 1) * 4));
   ScanlineSetup *lines = ws->path_nodes.as<ScanlineSetup>();
-  scanline_setup_kernel<<<cdiv(total_scan, 256), 256, 0, stream>>>(dv.as<float>(), n_tris, tri_start, total_scan, G, lines);
-  // fine grids: the cells of a workgroup's 256 scan lines are cut into slices (scanline_kernel).  Config 5's stand-in (2^16 cells
-  // per axis, 375 M fragments, 525 k scan lines of which ~11 k -- the faces whose scan lines run along the long axis -- hold most
-  // of the cells), count + emit: 1 slice 33.7 ms, 2: 21.0, 4: 16-17, 8: 20.5, 16: 38, 64 / 256: 35-36.  Neither the set-up (now
-  // done once), nor the scratch-memory indexing, nor the per-lane LDS atomics (both gone) moved these numbers; the SQ counters show
-  // a kernel that waits (8 % VALU issue).  Unexplained beyond 4 slices; 4 it is.
-  int slices = log_N >= 15 ? 4 : (log_N >= 13 ? 2 : 1);
-  if ((unsigned long long)total_scan * (unsigned)slices > 0x7FFFFFFFull) slices = 1;
-  const u32 count_entries = total_scan * (u32)slices;
+  u32 *piece_base = ws->leaf_t.as<u32>();
+  scanline_setup_kernel<<<chunks, 256, 0, stream>>>(dv.as<float>(), n_tris, tri_start, total_scan, G, lines, piece_base);
+  SVO_TRY(exclusive_scan_u32(ws, piece_base, chunks, d_total, stream));
+  u32 total_pieces = 0;
+  SVO_HIP(hipMemcpyAsync(&total_pieces, d_total, 4, hipMemcpyDeviceToHost, stream));
+  SVO_HIP(hipStreamSynchronize(stream));
+  if ((unsigned long long)total_pieces * 256ull > 0x7FFFFFFFull) return SVOSLAM_ERR_OOM;
+  SVO_TRY(ws->leaf_rec0.reserve((size_t)total_pieces * 4));
+  u32 *piece_map = ws->leaf_rec0.as<u32>();
+  piece_map_kernel<<<cdiv(chunks, 256), 256, 0, stream>>>(piece_base, chunks, total_pieces, piece_map);
+  const u32 count_entries = total_pieces * 256u;
   SVO_TRY(ws->rec_front.reserve((size_t)count_entries * 4));
   u32 *frag_start = ws->rec_front.as<u32>();
-  const dim3 raster_grid(cdiv(total_scan, 256), (unsigned)slices);
-  scanline_kernel<false><<<raster_grid, 256, 0, stream>>>(lines, total_scan, G, frag_start, nullptr, nullptr, nullptr, -1, slices);
+  const unsigned raster_grid = total_pieces;
+  scanline_kernel<false><<<raster_grid, 256, 0, stream>>>(lines, total_scan, G, frag_start, nullptr, nullptr, nullptr, -1, piece_base, piece_map,
+                                                         chunks, total_pieces);
   SVO_TRY(exclusive_scan_u32(ws, frag_start, count_entries, d_total, stream));
   u32 total_frag = 0;
   SVO_HIP(hipMemcpyAsync(&total_frag, d_total, 4, hipMemcpyDeviceToHost, stream));
@@ -398,7 +435,7 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   while ((1ll << tri_bits) < (long long)n_tris) tri_bits++;
   const int pack_shift = (3 * log_N + tri_bits <= 64 && config().sort_pairs == 0) ? tri_bits : -1;
   scanline_kernel<true><<<raster_grid, 256, 0, stream>>>(lines, total_scan, G, nullptr, frag_start, ws->keys_a.as<u64>(), ws->vals_a.as<u32>(),
-                                                        pack_shift, slices);
+                                                        pack_shift, piece_base, piece_map, chunks, total_pieces);
   SVO_LAUNCH_CHECK();
   (void)stage_end(kStageMeshRaster, tk_raster, stream);
   // order by framebuffer index (stable: equal cells keep ascending triangle id -- fragments are emitted triangle by triangle)
