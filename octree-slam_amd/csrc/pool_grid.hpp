@@ -162,6 +162,9 @@ __host__ __device__ constexpr int brick_bits_level(int s) { return 12 + s; }
 // first cell of the window on every axis, in cells of level 11 + s (a multiple of 32: whole groups)
 __host__ __device__ constexpr uint32_t brick_window_origin(int s) { return ((1u << (11 + s)) - kBrickWindowCells) >> 1; }
 // the shape for a pool whose deepest fusion was `depth` levels (-1: no bricks)
+// (round 5, measured and not kept: shape 1 for depth-15 / 16 pools as well -- bit-exact, test_gpu_bricks.py passes at depth 15 / 16,
+// but config 5's 4K renders of a depth-16 SVO got SLOWER from outside the model, 0.113 -> 0.167 and 0.214 -> 0.262 ms, and 6 %
+// faster from inside it, 0.566 -> 0.535: half the colonnade lies outside the window and far samples stop above the bricks' levels)
 inline int brick_shift_for_depth(int depth) { return depth <= 12 ? 0 : (depth <= 14 ? 1 : -1); }
 constexpr size_t kBrickFieldEntries = (size_t)1 << (3 * kBrickWindowBits);
 constexpr size_t kBrickFieldBytes = 2 * kBrickFieldEntries;

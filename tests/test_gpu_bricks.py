@@ -48,7 +48,7 @@ VIEWS = (((0.1, 0.2, -2.6), (0, 0, 0), (96, 72)),            # far, coarse pixel
          ((0.12, -0.18, 0.14), (0.1, -0.2, -0.3), (24, 480)))  # centimetres outside the sphere, grazing: LOD 13+ (below the bricks)
 
 
-@pytest.mark.parametrize("depth", [10, 12, 13, 14])
+@pytest.mark.parametrize("depth", [10, 12, 13, 14, 16])
 def test_bricks_follow_incremental_fusion_through_saturation(env, oracle, depth):
     """the same surface observed 131 times with a few new points each time (asynchronous fusion: the commit lists the
     stale bricks, the render rebuilds them): leaves pass A = 254 at observation 127 and rays begin to retire on them"""
@@ -78,7 +78,7 @@ def test_bricks_follow_incremental_fusion_through_saturation(env, oracle, depth)
     assert retired_seen or depth > 12
 
 
-@pytest.mark.parametrize("depth", [11, 14])
+@pytest.mark.parametrize("depth", [11, 14, 15])
 def test_bricks_deferred_commits_and_reset(env, oracle, depth):
     """deferred commit + apply (marks go to the other dirty state), a render between the two halves (old map), a reset
     followed by a different cloud (every brick of the old map must be gone)"""
