@@ -69,9 +69,7 @@ typedef struct svoslam_config {
   int32_t runner_timeline;  /* 1: HIP-event marks at the stage boundaries (svoslam_runner_timeline); costs ~6 % */
   int32_t sort_pairs;       /* 1: force the (key, index) pair sort instead of the packed one-word sort */
   int32_t graphs;           /* 1: launch sequences recorded and replayed as HIP graphs (0: direct launches, the default) */
-  int32_t track_recompute;  /* streaming one-launch tracker: 1 = the last frame's vertex (and 2 = also its normal) recomputed from the
-                               filtered depth pyramid inside the kernel instead of read from the maps (an A/B switch: DESIGN.md section 6) */
-  int32_t reserved[4];
+  int32_t reserved[5];
 } svoslam_config;
 int svoslam_config_get(svoslam_config *out);
 int svoslam_config_set(const svoslam_config *in);

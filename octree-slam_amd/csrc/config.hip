@@ -19,7 +19,7 @@ const Field kFields[] = {
     {"runner_deferred", &svoslam_config::runner_deferred}, {"runner_lead", &svoslam_config::runner_lead},
     {"runner_prio", &svoslam_config::runner_prio}, {"runner_replicas", &svoslam_config::runner_replicas},
     {"runner_timeline", &svoslam_config::runner_timeline}, {"sort_pairs", &svoslam_config::sort_pairs},
-    {"graphs", &svoslam_config::graphs}, {"track_recompute", &svoslam_config::track_recompute},
+    {"graphs", &svoslam_config::graphs},
 };
 
 bool config_valid(const svoslam_config &c) {

@@ -525,7 +525,6 @@ struct svoslam_camera {
   long long latest_stamp = 0;
   int band_first = 0, band_rows = 0;
   uint16_t *filt[3] = {nullptr, nullptr, nullptr};
-  uint16_t *filt_set[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // per map set: a copy of its filtered depth pyramid (track_recompute)
   // pyramid maps of frame f live in set f % 3: the tracker reads sets f and f-1 while the maps of frame f+1
   // can already be generated on another stream (rgbd_camera.cpp:181-189 swaps two sets)
   float *vert[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
@@ -623,7 +622,6 @@ int camera_destroy(svoslam_camera *c) {
   if (!c) return SVOSLAM_OK;
   for (int i = 0; i < 3; i++) {
     if (c->filt[i]) (void)hipFree(c->filt[i]);
-    for (int k = 0; k < 3; k++) if (c->filt_set[k][i]) (void)hipFree(c->filt_set[k][i]);
     for (int s = 0; s < 3; s++) {
       if (c->vert[s][i]) (void)hipFree(c->vert[s][i]);
       if (c->norm[s][i]) (void)hipFree(c->norm[s][i]);
@@ -669,10 +667,6 @@ static int enqueue_preprocess(const svoslam_camera *c, const uint16_t *d_depth, 
     const int w = W >> i, h = H >> i;
     SVO_TRY(generate_vertex_normal_maps(c->filt[i], c->vert[set][i], c->norm[set][i], w, h, c->fx, c->fy, W, H, s));
     if (i != 2) SVO_TRY(subsample_depth_u16_to(c->filt[i], c->filt[i + 1], w, h, s));
-    if (config().track_recompute != 0 && set >= 0 && set < 3) {  // (experiment: the set keeps its filtered depth)
-      if (!c->filt_set[set][i]) SVO_HIP(hipMalloc((void **)&c->filt_set[set][i], (size_t)w * h * 2));
-      SVO_HIP(hipMemcpyAsync(c->filt_set[set][i], c->filt[i], (size_t)w * h * 2, hipMemcpyDeviceToDevice, s));
-    }
   }
   return SVOSLAM_OK;
 }
@@ -726,13 +720,13 @@ static int iter_flags(int level, int iter) {
   return f;
 }
 
-struct LevelArgs { const float *lv, *ln, *cv, *cn; int w, h, first, num; int last_set; };
+struct LevelArgs { const float *lv, *ln, *cv, *cn; int w, h, first, num; };
 static LevelArgs level_args(const svoslam_camera *c, int level) {
   LevelArgs a;
   a.w = c->width >> level; a.h = c->height >> level;
   const int r0 = c->band_first >> level, r1 = (c->band_first + c->band_rows) >> level;
   const int cur = (int)(c->tracked % 3u), last = (int)((c->tracked + 2u) % 3u);  // frames f and f-1
-  a.lv = c->vert[last][level]; a.ln = c->norm[last][level]; a.last_set = last;
+  a.lv = c->vert[last][level]; a.ln = c->norm[last][level];
   if (c->to_model && c->have_model) { a.lv = c->model_v[level]; a.ln = c->model_n[level]; }
   a.cv = c->vert[cur][level]; a.cn = c->norm[cur][level];
   a.first = r0 * a.w; a.num = (r1 - r0) * a.w;
@@ -792,12 +786,9 @@ static int track_one_launch(svoslam_camera *c, hipStream_t s) {
     (void)accumulate_range(a.w, a.h, a.first, a.num, end);
     A.level[level].lv = a.lv; A.level[level].ln = a.ln; A.level[level].cv = a.cv; A.level[level].cn = a.cn;
     A.level[level].first = a.first; A.level[level].end = end > a.first ? end : a.first;
-    A.level[level].w = a.w; A.level[level].h = a.h;
-    A.level[level].ld = (config().track_recompute != 0 && !(c->to_model && c->have_model)) ? c->filt_set[a.last_set][level] : nullptr;
     A.iters[level] = kPyramidIters[level];
   }
   A.corrected = c->corrected ? 1 : 0;
-  A.recompute = config().track_recompute; A.fx = c->fx; A.fy = c->fy; A.img_w = c->width; A.img_h = c->height;
   if (c->capacity == 0 || c->cap_stream != s) {
     SVO_TRY(track_persistent_capacity(s, &c->capacity));
     c->cap_stream = s;

@@ -23,6 +23,16 @@ __global__ __launch_bounds__(256) void vertex_map_kernel(const uint16_t *__restr
   vmap[3 * (size_t)idx] = vx; vmap[3 * (size_t)idx + 1] = vy; vmap[3 * (size_t)idx + 2] = vz;
 }
 
+// normalize(-cross(v1, v2)), glm operation order (func_geometric.inl)
+__device__ inline void normal_from_vertices(float cx, float cy, float cz, float ax, float ay, float az, float bx, float by,
+                                            float bz, float &nx, float &ny, float &nz) {
+  const float v1x = ax - cx, v1y = ay - cy, v1z = az - cz;
+  const float v2x = bx - cx, v2y = by - cy, v2z = bz - cz;
+  const float crx = -(v1y * v2z - v2y * v1z), cry = -(v1z * v2x - v2z * v1x), crz = -(v1x * v2y - v2x * v1y);
+  const float inv = 1.0f / sqrtf((crx * crx + cry * cry) + crz * crz);
+  nx = crx * inv; ny = cry * inv; nz = crz * inv;
+}
+
 __global__ __launch_bounds__(256) void normal_map_kernel(const float *__restrict__ vmap, float *__restrict__ nmap, int width,
                                                          int height) {
   const int idx = blockIdx.x * 256 + threadIdx.x;

@@ -27,7 +27,6 @@
 #include <stdlib.h>
 
 #include "icp_device.hpp"
-#include "image_device.hpp"
 #include <map>
 #include <mutex>
 
@@ -199,7 +198,7 @@ constexpr int kTrkMinWaves = 2;
 // what the reference rewrites in place, rgbd_camera.cpp:163-167), applies the one new this_trans, uses them and stores
 // them back -- a lane only ever re-reads what it wrote itself -- with the next pixel's 12 floats requested before the
 // current one is used.  <= 128 VGPRs, so its workgroups find room beside the march's instead of needing empty CUs.
-template <int SLOTS, int MINW, bool STREAM, int RECOMP = 0>  // RECOMP: svoslam_config.track_recompute (an A/B experiment, streaming form only)
+template <int SLOTS, int MINW, bool STREAM>
 __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(CamState *st, TrackSync *sy, unsigned long long *acc, TrackArgs A) {
   SVO_HIGH_PRIO();
   __shared__ double wsum[16][27];          // workers: per-(wave, half) term sums; solver: row-group sums
@@ -368,29 +367,7 @@ __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(Cam
               const size_t q = have ? (size_t)p : (size_t)L.first;
               const float *cv = raw ? L.cv : A.work_v, *cn = raw ? L.cn : A.work_n;
 #pragma unroll
-              for (int c = 0; c < 3; c++) { r.v2[c] = cv[3 * q + c]; r.n2[c] = cn[3 * q + c]; }
-              if (RECOMP > 0 && L.ld) {
-                // experiment (svoslam_config.track_recompute): the last frame's vertex (and normal) from 2 (6) bytes of its filtered
-                // depth with the expressions of vertex_normal_kernel -- the same floats -- instead of 12 (24) bytes of its maps
-                const int x = (int)(q % (size_t)L.w), y = (int)(q / (size_t)L.w);
-                vertex_from_depth(L.ld[q], x, y, L.w, L.h, A.fx, A.fy, A.img_w, A.img_h, r.v1[0], r.v1[1], r.v1[2]);
-                if (RECOMP >= 2) {
-                  if (x == L.w - 1 || y == L.h - 1) {
-                    r.n1[0] = r.n1[1] = r.n1[2] = INFINITY;
-                  } else {
-                    float ax, ay, az, bx, by, bz;
-                    vertex_from_depth(L.ld[q + 1], x + 1, y, L.w, L.h, A.fx, A.fy, A.img_w, A.img_h, ax, ay, az);
-                    vertex_from_depth(L.ld[q + (size_t)L.w], x, y + 1, L.w, L.h, A.fx, A.fy, A.img_w, A.img_h, bx, by, bz);
-                    normal_from_vertices(r.v1[0], r.v1[1], r.v1[2], ax, ay, az, bx, by, bz, r.n1[0], r.n1[1], r.n1[2]);
-                  }
-                } else {
-#pragma unroll
-                  for (int c = 0; c < 3; c++) r.n1[c] = L.ln[3 * q + c];
-                }
-              } else {
-#pragma unroll
-                for (int c = 0; c < 3; c++) { r.v1[c] = L.lv[3 * q + c]; r.n1[c] = L.ln[3 * q + c]; }
-              }
+              for (int c = 0; c < 3; c++) { r.v2[c] = cv[3 * q + c]; r.n2[c] = cn[3 * q + c]; r.v1[c] = L.lv[3 * q + c]; r.n1[c] = L.ln[3 * q + c]; }
             };
             PixelRaw cur, nxt;
             bool have_cur, have_nxt = false;
@@ -640,9 +617,7 @@ int track_persistent_launch(CamState *st, TrackSync *sy, unsigned *tickets, cons
   DevChain &dc = chain_of[dev];
   if (!dc.ev) SVO_HIP(hipEventCreateWithFlags(&dc.ev, hipEventDisableTiming));
   if (dc.used && dc.last != s) SVO_HIP(hipStreamWaitEvent(s, dc.ev, 0));  // the previous launch (any stream) has finished
-  if (A.variant && A.recompute == 1) track_persistent_kernel<kTrkStreamSlots, kTrkStreamMinWaves, true, 1><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, acc, A);
-  else if (A.variant && A.recompute >= 2) track_persistent_kernel<kTrkStreamSlots, kTrkStreamMinWaves, true, 2><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, acc, A);
-  else if (A.variant) track_persistent_kernel<kTrkStreamSlots, kTrkStreamMinWaves, true><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, acc, A);
+  if (A.variant) track_persistent_kernel<kTrkStreamSlots, kTrkStreamMinWaves, true><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, acc, A);
   else track_persistent_kernel<kTrkSlots, kTrkMinWaves, false><<<A.workers + 1, kTrkThreads, 0, s>>>(st, sy, acc, A);
   SVO_LAUNCH_CHECK();
   SVO_HIP(hipEventRecord(dc.ev, s));

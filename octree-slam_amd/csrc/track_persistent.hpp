@@ -20,7 +20,7 @@ struct TrackSync {
   unsigned long long prof[32][8];  // SVO_TRK_PROF builds: s_memtime stamps per epoch (solver 0..3, worker 0 4..7)
 };
 
-struct TrackLevel { const float *lv, *ln, *cv, *cn; int first, end; const uint16_t *ld = nullptr; int w = 0, h = 0; };  // ld: the last frame's filtered depth of this level (track_recompute)
+struct TrackLevel { const float *lv, *ln, *cv, *cn; int first, end; };
 struct TrackArgs {
   TrackLevel level[3];
   int iters[3];
@@ -30,8 +30,6 @@ struct TrackArgs {
   float *work_v = nullptr, *work_n = nullptr;  // streaming levels: the current frame's maps as transformed so far (finest-level size)
   int variant = 0;       // 0: register-resident form <kTrkSlots, 2>; 1: streaming form for large images
   int corrected = 0;     // the corrected tracker (icp_device.hpp icp_rot_rows)
-  int recompute = 0;     // svoslam_config.track_recompute (streaming levels): 1 = v1 from level.ld, 2 = v1 and n1
-  float fx = 0, fy = 0; int img_w = 0, img_h = 0;  // generateVertexMap's arguments for that
 };
 constexpr int kTrkStreamSlots = 2;
 constexpr int kTrkStreamMinWaves = 3;
