@@ -28,6 +28,10 @@ through the same four-stream path, so that the W warm-up and K timed frames are 
 config (a young map has short rays and flatters the number: VERDICT r02); `config.frames_in_map_at_end` = 300.
 --map-frames overrides (0 = K + W, the young map).
 
+The default single-GPU cfg3 line also carries `other_configs` (round 5): cfg4 through a child run of this script (`--workload cfg4 --lean`),
+cfg2 and the cfg5 stand-in through tools/mesh_bench.py (stage times from HIP events inside the C calls, algorithmic bytes, fractions, renders),
+and `wall` (seconds in this process's GPU legs, in the children, in the CPU oracle -- which runs LAST).
+
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel = whichever of the march kernel and the tracker
 kernel EXECUTES longer (each alone on the GPU in the sequential pass after the timed region: the order of the rocprofv3
 kernel statistics; an event interval on a busy device also contains the launch's wait for its turn, which is most of
