@@ -199,6 +199,47 @@ def test_large_cloud_invariants(env):
     assert st3.num_split == 0 and st2.num_split < st1.num_split  # only the one-off Q4 splits in pass 2
 
 
+_BIG_CHILD = r"""
+import hashlib, sys
+import numpy as np, torch
+import svoslam_pkg
+pkg = svoslam_pkg.load()
+n, depth, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+g = torch.Generator(device="cuda"); g.manual_seed(4242)
+pts = torch.rand((n, 3), generator=g, device="cuda", dtype=torch.float32) * 1.9 - 0.95
+pts[::1001] = float("nan")
+col = torch.randint(0, 256, (n, 3), generator=g, device="cuda", dtype=torch.uint8)
+ws, pool = pkg.Workspace(), pkg.Pool()
+if mode == "grid":     # svoFromVoxelGrid: keys alone are sorted, colour i stays with sorted key i (Q20)
+    ce = torch.cat([torch.nan_to_num(pts, nan=0.0), torch.ones((n, 1), device="cuda")], 1).contiguous()
+    co = torch.cat([col.float() / 255.0, torch.ones((n, 1), device="cuda")], 1).contiguous()
+    pkg.svo_from_voxel_grid(ws, ce, co, depth, pool, (0, 0, 0), 1.0)
+else:
+    pkg.svo_from_point_cloud(ws, pts, col, depth, pool, (0, 0, 0), 1.0)
+torch.cuda.synchronize()
+print("DIGEST", pool.size, hashlib.sha256(pool.words().tobytes()).hexdigest())
+"""
+
+
+@pytest.mark.parametrize("n,depth,mode", [(20_000_000, 7, "cloud"), (70_000_000, 7, "cloud"), (70_000_000, 8, "grid")])
+def test_large_inputs_packed_sort_equals_pair_sort(env, n, depth, mode):
+    """the blocking insert's packed sort at sizes no oracle run reaches -- 9-bit digits and the column scan in chunks (20 M points:
+    9766 tiles), 8-bit digits (70 M), keys alone on the voxel-grid path -- against the independent (key, index) PAIR sort of round 1
+    (svoslam_config.sort_pairs = 1) in a child process: the pools (node indices, colours of ten-fold duplicated leaves: the
+    lowest point index wins) must be identical"""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    digests = []
+    for cfg in ("", "sort_pairs=1"):
+        e = dict(os.environ, SVOSLAM_CONFIG=cfg, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", _BIG_CHILD, str(n), str(depth), mode], env=e, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-800:]
+        digests.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1], digests
+    assert int(digests[0].split()[1]) > 100000
+
+
 @pytest.mark.parametrize("depth,n,frames", [(2, 500, 3), (6, 20000, 4), (10, 40000, 4), (12, 60000, 3), (16, 20000, 2)])
 def test_async_fusion_matches_oracle(env, oracle, depth, n, frames):
     """the asynchronous entry point (no readback, all splits in one launch) builds the same pool"""
