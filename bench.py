@@ -128,7 +128,7 @@ def device_memory(P, torch):
     free_b, total_b = torch.cuda.mem_get_info()
     cap = int(P.pool.capacity)
     return {"pool_reserved": cap * 8 / GiB, "pool_used": int(P.pool.size) * 8 / GiB, "deferred_shadow_if_on": cap * 8 / GiB,
-            "brick_field_if_taken": 16.0, "level_grid": (256 ** 3) * 8 / GiB,
+            "brick_field_if_taken": 16.0, "level_grid": (256 ** 3) * 8 / GiB, "march_accel": P.pool.march_accel(),
             "device_in_use_all_processes": (total_b - free_b) / GiB, "device_total": total_b / GiB}
 
 

@@ -121,6 +121,12 @@ int svoslam_pool_save(svoslam_pool *pool, const char *path, const float center[3
  * derived data it keeps per pool -- the level grid of the ray march -- is rebuilt at the next render.  Pools must
  * otherwise be modified through the library only.  Host state only, no device access. */
 int svoslam_pool_touch(svoslam_pool *pool);
+/* What the ray march of this pool currently runs on (host state only; round 5: the fallback to the tree march when the 16 GiB
+ * occupancy-brick field does not fit beside other pools / ranks of the device used to be silent): *has_grid = the level-8 grid
+ * exists, *brick_state = 1 bricks in use, 0 not built (no reference-mode render yet, svoslam_config.march_bricks = 0, or a pool
+ * deeper than any shape), -1 the field could not be allocated -- the pool is marched through the tree (correct, slower);
+ * *brick_shift = the shape (0: depth <= 12, 1: depth 13 / 14, -1: none).  Any of the pointers may be NULL. */
+int svoslam_pool_march_accel(const svoslam_pool *pool, int32_t *has_grid, int32_t *brick_state, int32_t *brick_shift);
 /* Replaces the pool's contents by num_nodes host nodes (2 words each, reference format; child pointers validated) and
  * resets all size bookkeeping incl. the device-resident size the asynchronous fusion allocates from.  Blocking. */
 int svoslam_pool_set_nodes(svoslam_pool *pool, const uint32_t *h_words, int32_t num_nodes, void *stream);

@@ -81,6 +81,7 @@ SIGNATURES = {
     "svoslam_camera_reset": (C.c_int, [_vp]),
     "svoslam_pool_save": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _fp, _f32, _i32, _vp]),
     "svoslam_pool_touch": (C.c_int, [C.POINTER(_PoolStruct)]),
+    "svoslam_pool_march_accel": (C.c_int, [C.POINTER(_PoolStruct), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "svoslam_pool_set_nodes": (C.c_int, [C.POINTER(_PoolStruct), C.POINTER(C.c_uint32), _i32, _vp]),
     "svoslam_pool_evict_subtree": (C.c_int, [C.POINTER(_PoolStruct), C.POINTER(C.c_uint8), _i32, C.c_char_p, _vp]),
     "svoslam_pool_restore_subtree": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _vp]),
@@ -388,6 +389,13 @@ class Pool:
     def reset(self):
         """empty map (8 zeroed root children), same allocation"""
         check(lib().svoslam_pool_reset(C.byref(self._p), _stream()))
+
+    def march_accel(self):
+        """what the ray march of this pool runs on: {grid: bool, bricks: 1 in use / 0 not built / -1 allocation failed (tree march),
+        brick_shift}"""
+        g, b, sh = C.c_int32(0), C.c_int32(0), C.c_int32(-1)
+        check(lib().svoslam_pool_march_accel(C.byref(self._p), C.byref(g), C.byref(b), C.byref(sh)))
+        return {"grid": bool(g.value), "bricks": int(b.value), "brick_shift": int(sh.value)}
 
     def expand(self, center, edge_length, toward):
         """doubles the root cube towards `toward` (re-rooting); returns the new (center, edge_length)"""

@@ -117,6 +117,14 @@ int svoslam_pool_touch(svoslam_pool *pool) {
   pool_accel_invalidate(pool);
   return SVOSLAM_OK;
 }
+int svoslam_pool_march_accel(const svoslam_pool *pool, int32_t *has_grid, int32_t *brick_state, int32_t *brick_shift) {
+  if (!pool) return SVOSLAM_ERR_INVALID_ARG;
+  const std::shared_ptr<PoolAccel> pa = pool_accel_find(pool->d_data);
+  if (has_grid) *has_grid = pa && pa->grid.ptr ? 1 : 0;
+  if (brick_state) *brick_state = !pa ? 0 : (pa->bricks_failed ? -1 : (pa->bricks ? 1 : 0));
+  if (brick_shift) *brick_shift = pa && pa->bricks ? pa->brick_shift : -1;
+  return SVOSLAM_OK;
+}
 int svoslam_pool_sync(svoslam_pool *pool, void *stream) {
   NEED_DEVICE();
   return pool_sync(pool, S(stream));

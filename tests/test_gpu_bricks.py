@@ -71,6 +71,12 @@ def test_bricks_follow_incremental_fusion_through_saturation(env, oracle, depth)
                 retired_seen |= bool((got[..., :3] != 0).any())
                 steps_at[(it, eye)] = render_check.last_steps
     assert np.array_equal(pool.words()[:2 * pool.size], opool.words()[:2 * pool.size])
+    acc = pool.march_accel()       # (svoslam_pool_march_accel: the fallback to the tree march is visible)
+    assert acc["grid"], acc
+    if depth <= 14:   # (-1: the 16 GiB field did not fit beside whatever else holds the device: the renders above went through the tree)
+        assert acc["bricks"] in (1, -1) and (acc["bricks"] == -1 or acc["brick_shift"] == (0 if depth <= 12 else 1)), acc
+    else:
+        assert acc["bricks"] == 0 and acc["brick_shift"] == -1, acc
     # saturated leaves were reached: rays retire on them (fewer march steps than through the young map), and up to depth 12 some
     # pixel carries a colour (deeper trees dilute the mip colour of a lone leaf to zero at the LOD's level: averageChildren
     # divides by 8 per level, Q5)
