@@ -124,9 +124,8 @@ struct ScanlineSetup {
 };
 static_assert(sizeof(ScanlineSetup) == 64, "one 64-byte record per scan line");
 
-// The set-up of every scan line ONCE, as a 64-byte record (round 5): the count and the emit pass used to repeat it -- a binary
-// search over the triangles' scan-line offsets and the triangle's raster set-up, ~25 us of dependent loads per workgroup -- and
-// cutting a workgroup's cells into slices repeated it once more per slice, which is what kept the slices coarse.
+// The set-up of every scan line ONCE, as a 64-byte record (round 5): the count and the emit pass used to repeat it (a binary
+// search over the triangles' scan-line offsets and the triangle's raster set-up per lane), and so would every piece of a chunk.
 __global__ __launch_bounds__(256) void scanline_setup_kernel(const float *__restrict__ vbo, int n_tris, const u32 *__restrict__ tri_start,
                                                              u32 total_scanlines, GridParams G, ScanlineSetup *__restrict__ out,
                                                              u32 *__restrict__ pieces) {
