@@ -1,4 +1,5 @@
 #!/bin/bash
+# RECORD of a round-5 A/B call: the svoslam_config switch it sets existed only at the commit of the experiment (git log); the library now ignores it
 # one-sweep sort: parity tests of the paths that sort, then A/B of the bench lines (sequential stage pass included)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r05b; mkdir -p $O

@@ -1,4 +1,5 @@
 #!/bin/bash
+# RECORD of a round-5 A/B call: the svoslam_config switch it sets existed only at the commit of the experiment (git log); the library now ignores it
 # streaming tracker: the last frame's vertex (1) / vertex + normal (2) recomputed from its filtered depth instead of read from the maps
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r05k; mkdir -p $O
