@@ -190,7 +190,8 @@ struct PixelSet {  // one lane's pixels of the current level
 // 12 floats of one pixel pair, as loaded (streaming levels: software-pipelined one pixel ahead)
 struct PixelRaw { float v1[3], n1[3], v2[3], n2[3]; };
 
-constexpr int kTrkMinWaves = 2;
+constexpr int kTrkMinWaves = 2;  // (round 5, measured: 3 -- 168 VGPRs with 32 spilled, so that a march workgroup fits beside a tracker workgroup on its
+// CU instead of finding 150 CUs taken -- cfg3 2416 / 2285 against 2449 / 2424 frames/s over 100 frames, 2055 / 2060 against 2020 / 2130 over 20)
 // SLOTS = pixels of a level a lane may keep in registers; MINW = minimum wavefronts per SIMD the register budget allows.
 // <kTrkSlots, 2, false>: images whose finest level fits the registers (up to 640x480-class: 4 pixels per lane on <= 247 workers,
 // ~220 VGPRs: one workgroup per CU).  <2, kTrkStreamMinWaves, true> (round 3): LARGE images -- only the coarsest level is register-resident, the
