@@ -20,10 +20,15 @@ def f32(x):
     return np.float32(x)
 
 
-@pytest.mark.parametrize("shape,log_n", [("cube", 5), ("cube", 8), ("sphere", 7), ("sphere", 10), ("soup", 8), ("soup", 9)])
+@pytest.mark.parametrize("shape,log_n", [("cube", 5), ("cube", 8), ("sphere", 7), ("sphere", 10), ("soup", 8), ("soup", 9),
+                                         ("soup3", 11), ("soup5", 12)])
 def test_mesh_to_voxel_grid_matches_oracle(env, oracle, tmp_path, shape, log_n):
+    """(soup3 / soup5, round 5: random triangles at 2^11 / 2^12 cells per axis -- 2 M / 6.8 M voxels: scan lines of thousands of cells,
+    chunks cut into several pieces of 32 768 candidate cells, 9-bit digits in the fragment sort)"""
     pkg, torch = env
-    path = {"cube": meshgen.write_cube_obj, "sphere": meshgen.write_sphere_obj, "soup": meshgen.write_soup_obj}[shape](tmp_path / (shape + ".obj"))
+    writers = {"cube": meshgen.write_cube_obj, "sphere": meshgen.write_sphere_obj, "soup": meshgen.write_soup_obj,
+               "soup3": lambda q: meshgen.write_soup_obj(q, n=120, seed=3), "soup5": lambda q: meshgen.write_soup_obj(q, n=60, seed=5)}
+    path = writers[shape](tmp_path / (shape + ".obj"))
     tex_path = meshgen.write_bmp(tmp_path / "t.bmp") if shape == "sphere" else None
     mesh, tex = pkg.Mesh(path), (pkg.Texture(tex_path) if tex_path else None)
     omesh, otex = oracle.mesh_load_obj(str(path)), (oracle.load_bmp(str(tex_path)) if tex_path else None)
