@@ -991,7 +991,14 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
 // Tiles of the previous render, costliest first: tile_order_block (pool_grid.hpp), run by one extra workgroup of the refresh
 // launch that precedes the march (no launch of its own on the map stream: as one it took 15 us + a launch boundary per frame)
 // or, where no refresh is launched, by this kernel.
-constexpr int kTileOrderMinTiles = 768;  // resident workgroups of the brick kernel (three per CU): smaller renders start every tile at once
+// Two workgroups of the brick kernel per CU, not the three its 50 KB of tables would allow: kBrickMarchLdsPad bytes of dynamic LDS
+// nobody reads take the third away.  With the costliest tiles first, the long rays of a frame (640x480, 300-frame map: 12 % of the
+// rays, in 647 of 4800 wavefronts, the lower half of the image -- profiles/r05_ray_anatomy_cfg3_300frames.txt) start at t = 0 with
+// four wavefronts per SIMD instead of six and the short tiles fill in behind them: 640x480 in the loop 2505 / 2523 -> 2547..2585
+// frames/s (2358 -> 2563 on a box in a slower state), 1080p 925 / 939 -> 940..958; either change alone gives nothing or loses
+// (profiles/r05_march_occupancy.txt; one workgroup per CU: 2000).
+constexpr int kBrickMarchLdsPad = 6144;
+constexpr int kTileOrderMinTiles = 512;  // resident workgroups of the brick kernel (two per CU): smaller renders start every tile at once
 __global__ __launch_bounds__(256) void tile_order_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, int n) {
   tile_order_block(cost, order, n);
 }
@@ -1170,7 +1177,9 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
       if (!order_done) tile_order_kernel<<<1, 256, 0, stream>>>(tile_cost, tile_order, n_tiles);  // (the refresh was a full build)
       P.tile_cost = tile_cost; P.tile_order = tile_order;
     }
-    auto launch = [&](auto kernel) { kernel<<<grid, kTraceThreads, 0, stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps, slots); };
+    auto launch = [&](auto kernel) {
+      kernel<<<grid, kTraceThreads, (size_t)kBrickMarchLdsPad, stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps, slots);
+    };
     if (brick_shift == 0) {
       if (P.lod_always) launch(cone_trace_brick_kernel<kTraceThreads, true, 0>);
       else launch(cone_trace_brick_kernel<kTraceThreads, false, 0>);

@@ -41,4 +41,12 @@ xs, ys = np.array(xs, float), np.array(ys)
 A = np.stack([np.ones_like(xs), xs], 1)
 coef = np.linalg.lstsq(A, ys, rcond=None)[0]
 print("fit: band ms = %.4f + %.5f * max_steps  (=> %.3f us per step on the critical path)" % (coef[0], coef[1], coef[1] * 1e3))
-# empty-ish render (a view looking away) to get the fixed cost: accel build + launch
+# VERDICT r04 item 5 asked whether the render is "a ~0.1 ms bulk plus a single-wavefront tail": parts of the image alone
+long_rows = np.where(st.max(axis=1) >= 200)[0]
+lo, hi = int(long_rows.min()) // 16 * 16, (int(long_rows.max()) // 16 + 1) * 16
+n_long_rays, n_long_waves = int((st >= 200).sum()), int((t >= 200).sum())
+print("rays with >= 200 steps: %d (%.1f %%), in %d of %d wavefronts (8x8 pixels), rows %d..%d" % (n_long_rays, 100.0 * n_long_rays / st.size, n_long_waves, t.size, lo, hi))
+for a, b, what in ((0, lo, "rows above the long rays"), (lo, hi, "the rows that hold the long rays"), (0, H, "whole image")):
+    if b > a:
+        ms = timeit(lambda: pkg.cone_trace_svo_band(img, a, b - a, 45.0, view, P.pool.data_ptr, P.center, P.edge, 0), 10)
+        print("rows %3d..%3d alone: %.4f ms  (%s: %d wavefronts, %d of them with a ray of >= 200 steps, total steps %d)" % (a, b, ms, what, (b - a) // 8 * (W // 8), int((t[a // 8:b // 8] >= 200).sum()), int(st[a:b].sum())))
