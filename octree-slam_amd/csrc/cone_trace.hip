@@ -700,7 +700,10 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
   const int tile_y = tile_id / P.xcd_h;  // (xcd_h = tiles per row)
   const int tile_x = tile_id - tile_y * P.xcd_h;
   const int px = tile_x * 32 + (int)(wave & 3u) * 8 + (int)(lane & 7u);
-  const int py = P.row_first + tile_y * (THREADS / 32) + (int)(wave >> 2) * 8 + (int)(lane >> 3);
+  // xcd_w != 0 (= the number of tile rows): the tile's two 32 x 8 strips lie half the render apart -- wavefronts w and w + 4 share a
+  // SIMD, and the long rays of a frame come in bands of rows, so a wavefront of the expensive band is paired with one of the cheap band
+  const int py = P.xcd_w ? P.row_first + (tile_y + (int)(wave >> 2) * P.xcd_w) * 8 + (int)(lane >> 3)
+                         : P.row_first + tile_y * (THREADS / 32) + (int)(wave >> 2) * 8 + (int)(lane >> 3);
   uint32_t my_steps = 0, my_levels = 0;
   if (px < P.width && py < P.row_end) {
     const int idx = py * P.width + px;
@@ -998,6 +1001,7 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
 // frames/s (2358 -> 2563 on a box in a slower state), 1080p 925 / 939 -> 940..958; either change alone gives nothing or loses
 // (profiles/r05_march_occupancy.txt; one workgroup per CU: 2000).
 constexpr int kBrickMarchLdsPad = 6144;
+constexpr int kPairMaxTiles = 1024;
 constexpr int kTileOrderMinTiles = 512;  // resident workgroups of the brick kernel (two per CU): smaller renders start every tile at once
 __global__ __launch_bounds__(256) void tile_order_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, int n) {
   tile_order_block(cost, order, n);
@@ -1171,7 +1175,10 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   uchar4 *out = reinterpret_cast<uchar4 *>(d_pos);
   const bool midrange_size = size >= 9.5367431640625e-07f && size <= 1048576.0f;  // (see cone_trace_kernel: the length recurrence's short forms)
   if (d_bricks && !carry && midrange_size) {  // a pool of this library in reference mode: the march over occupancy bricks
-    P.xcd_w = 0; P.xcd_h = (int)cdiv(width, 32);
+    // renders of up to kPairMaxTiles tiles: the two 32 x 8 strips of a tile lie half the render apart (see the kernel).  640x480 in
+    // the loop 2366 -> 2498 frames/s (march alone 0.313 -> 0.297 ms); 1080p (4080 tiles, in rounds): alone 0.258 -> 0.238 but in
+    // the loop 0.50 -> 0.58 ms and 954 -> 944 frames/s, so large renders keep their strips together (profiles/r05_march_occupancy.txt)
+    P.xcd_w = n_tiles <= kPairMaxTiles ? (int)cdiv(rows, kTraceThreads / 32) : 0; P.xcd_h = (int)cdiv(width, 32);
     const dim3 grid((unsigned)(cdiv(width, 32) * cdiv(rows, kTraceThreads / 32)));
     if (tile_cost) {
       if (!order_done) tile_order_kernel<<<1, 256, 0, stream>>>(tile_cost, tile_order, n_tiles);  // (the refresh was a full build)
