@@ -151,7 +151,8 @@ def test_sibling_ring_lapped_between_renders(env, oracle, depth):
 def test_large_render_tile_order_follows_the_previous_render(env, oracle, depth):
     """renders of more tiles than the chip holds at once (1280 x 512: 1280 tiles of 32 x 16 pixels) take their tiles in the
     order of the previous render's cost on that stream (cone_trace.hip tile_order_kernel): the oracle's image and counters
-    whatever the history -- none, this view, another view, another geometry in between -- and each repeat equal to the first"""
+    whatever the history -- none, this view, another view, another geometry in between -- and each repeat equal to the first.
+    Renders of 513..1024 tiles (round 5) are ordered too and split every tile into two strips half the render apart."""
     pkg, torch = env
     rng = np.random.default_rng(40 + depth)
     ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
@@ -165,7 +166,9 @@ def test_large_render_tile_order_follows_the_previous_render(env, oracle, depth)
     vb = oracle.look_at((0.9, 0.1, 0.9), (0.0, 0.05, 0.0), (0, 1, 0))   # grazing: long rays in other tiles
     first = {}
     for step, (name, view, ww, hh) in enumerate([("a", va, w, h), ("a", va, w, h), ("b", vb, w, h), ("a", va, w, h), ("small", va, 320, 96),
-                                                 ("b", vb, w, h), ("b", vb, w, h), ("tall", va, 640, 1024), ("a", va, w, h)]):
+                                                 ("b", vb, w, h), ("b", vb, w, h), ("tall", va, 640, 1024), ("a", va, w, h),
+                                                 # 26 x 38 = 988 tiles, ragged on both edges: cost order AND the tiles' two strips half the render apart
+                                                 ("mid", vb, 808, 600), ("mid", vb, 808, 600), ("a", va, w, h), ("mid", vb, 808, 600)]):
         got = render_check(pkg, torch, oracle, pool, opool, ww, hh, view, center, edge, "render %d (%s)" % (step, name))
         key = (name, ww, hh)
         if key in first:
