@@ -1,4 +1,5 @@
 #!/bin/bash
+# RECORD of a round-5 A/B call: the SVO_EXP_* environment knobs it sets existed only at the commit of the experiment (git log); the library now ignores them
 # EXPERIMENT: the brick march with fewer resident workgroups per CU (dynamic LDS padding) and its tiles costliest-first at 640x480
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

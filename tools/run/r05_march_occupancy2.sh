@@ -1,4 +1,5 @@
 #!/bin/bash
+# RECORD of a round-5 A/B call: the SVO_EXP_* environment knobs it sets existed only at the commit of the experiment (git log); the library now ignores them
 # EXPERIMENT (second pass): two workgroups per CU + costliest-first tiles against the baseline, alternated; cfg4 and the driver's 20 frames too
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

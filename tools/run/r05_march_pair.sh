@@ -1,4 +1,5 @@
 #!/bin/bash
+# RECORD of a round-5 A/B call: the SVO_EXP_* environment knobs it sets existed only at the commit of the experiment (git log); the library now ignores them
 # EXPERIMENT: the two 32 x 8 strips of a march tile half the render apart (wavefronts w and w + 4 share a SIMD)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
