@@ -1001,6 +1001,9 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
 // frames/s (2358 -> 2563 on a box in a slower state), 1080p 925 / 939 -> 940..958; either change alone gives nothing or loses
 // (profiles/r05_march_occupancy.txt; one workgroup per CU: 2000).
 constexpr int kBrickMarchLdsPad = 6144;
+constexpr int kBrickMarchStaticLds = 1024 + 4 * (3 * lds_stride(11) + 3 * lds_cells(11));  // alpha_lut + lds_tab of cone_trace_brick_kernel
+static_assert(3 * (kBrickMarchStaticLds + kBrickMarchLdsPad) > 160 * 1024 && 2 * (kBrickMarchStaticLds + kBrickMarchLdsPad) <= 160 * 1024 &&
+              kBrickMarchStaticLds + kBrickMarchLdsPad <= 64 * 1024, "the pad must leave room for exactly two workgroups in a CU's 160 KB of LDS");
 constexpr int kPairMaxTiles = 1024;
 constexpr int kTileOrderMinTiles = 512;  // resident workgroups of the brick kernel (two per CU): smaller renders start every tile at once
 __global__ __launch_bounds__(256) void tile_order_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, int n) {
