@@ -182,6 +182,40 @@ def test_large_render_tile_order_follows_the_previous_render(env, oracle, depth)
         render_check(pkg, torch, oracle, pool, opool, w, h, view, center, edge, "after more points (%s)" % name)
 
 
+def test_random_bands_equal_the_rows_of_the_whole_render(env, oracle):
+    """row bands of arbitrary geometry -- widths that are no multiple of 32, bands that start and end anywhere, 1 .. 1100 tiles: with and
+    without the cost order, with and without the tiles' two strips half the band apart (cone_trace.hip kPairMaxTiles) -- write exactly
+    the rows of the whole render and count exactly their steps and levels; the whole render itself is the oracle's."""
+    pkg, torch = env
+    rng = np.random.default_rng(77)
+    ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
+    center, edge, depth = (0.0, 0.0, 0.0), 1.0, 12
+    for f in range(3):
+        pts, col = surface_cloud(rng, 40000, jitter=0.002)
+        pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, pool, center, edge)
+        opool.insert_cloud(pts, col, depth, center, edge)
+    view = oracle.look_at((0.9, 0.1, 0.9), (0.0, 0.05, 0.0), (0, 1, 0))
+    for w, h in ((200, 150), (808, 600), (1000, 500)):
+        whole = render_check(pkg, torch, oracle, pool, opool, w, h, view, center, edge, "whole %dx%d" % (w, h))
+        per_row = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        pkg.cone_trace_svo(per_row, 45.0, view, pool.data_ptr, center, edge, 0x100)   # (mode bit 8: the pixel = the ray's step count)
+        steps_of = per_row.cpu().numpy().view(np.uint32).reshape(h, w).astype(np.int64).sum(axis=1)
+        bands = [(0, 1), (h - 1, 1), (0, h), (3, h - 3)]
+        for _ in range(10):
+            first = int(rng.integers(0, h - 1))
+            bands.append((first, int(rng.integers(1, h - first + 1))))
+        for first, rows in bands:
+            img = torch.full((h, w, 4), 7, dtype=torch.uint8, device="cuda")
+            cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+            for _ in range(2):   # (the second render of the geometry takes the first one's tile costs as its order)
+                cnt.zero_()
+                pkg.cone_trace_svo_band(img, first, rows, 45.0, view, pool.data_ptr, center, edge, 0, counters=cnt)
+                got = img.cpu().numpy()
+                assert np.array_equal(got[first:first + rows], whole[first:first + rows]), (w, h, first, rows)
+                assert (got[:first] == 7).all() and (got[first + rows:] == 7).all(), (w, h, first, rows)
+                assert int(cnt[0]) == int(steps_of[first:first + rows].sum()), (w, h, first, rows)
+
+
 def test_foreign_words_are_not_trusted(env, oracle):
     """the brick rebuild skips the level-12 tile of an unsaturated level-11 node only for pools this library fused from empty
     (averageChildren keeps a parent's alpha at the maximum of its children's); words uploaded by the caller may break that:
