@@ -72,7 +72,134 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_MEASURED_COPY_GBS = 6290.0  # the same guide's measured copy ceiling; quoted beside the spec peak
 
 
-def cpu_baseline(depth_frames, rgb_frames, views, first, width, height, max_depth, center, edge, seed_words, seed_pose, budget_s=20.0):
+LINE_LIMIT = 6000   # bytes: the driver keeps ~8 KB of stdout; round 5's 20.9 KB line was cut and its record lost
+
+
+def _sig(x, nd=4):
+    """floats to `nd` significant digits (the full-precision numbers are in the details file)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (nd, x))
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, nd) for v in x]
+    if isinstance(x, dict):
+        return {k: _sig(v, nd) for k, v in x.items()}
+    return x
+
+
+def _cut(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_line(full, details_path=None, limit=LINE_LIMIT):
+    """The ONE stdout line of the contract, built from the full record: every contract key (metric, value, unit, n_gpus, steps, warmup,
+    ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data, config.workload, roofline, cpu_baseline) plus a few numbers per stage
+    and per other configuration; everything else lives in `details_path`.  Optional parts are dropped, last first, until the line is
+    <= `limit` bytes -- the contract keys never are.  Pure function of `full` (tests/test_bench_line.py runs it on canned records)."""
+    cfgf = full.get("config") or {}
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    mem = cfgf.get("device_memory_GiB") or {}
+    out["config"] = {k: cfgf[k] for k in ("workload", "parallelism", "frames_in_map_at_end", "frames_input", "mrays_per_s", "pool_nodes_end",
+                                          "image_coloured_pixels_end", "saturated_nodes_end") if k in cfgf}
+    out["config"]["workload"] = _cut(out["config"].get("workload"), 200)
+    out["config"]["parallelism"] = _cut(out["config"].get("parallelism"), 160)
+    if mem:
+        out["config"]["device_GiB_in_use"] = mem.get("device_in_use_all_processes")
+    rf = full.get("roofline")
+    if rf:
+        out["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "alg_bytes_per_launch")}
+        out["roofline"]["limiter"] = _cut(rf.get("limiter"), 140)
+    else:
+        out["roofline"] = None
+    cb = full.get("cpu_baseline")
+    out["cpu_baseline"] = ({k: (_cut(cb.get(k), 260) if k == "sample" else cb.get(k)) for k in ("value", "unit", "cores", "kind", "sample")}
+                           if cb else None)
+    if "runs" in full:
+        out["runs"] = full["runs"]
+
+    def stage_row(r):
+        row = {"stage": r.get("stage"), "kernel": _cut(r.get("kernel"), 48), "ms": r.get("kernel_ms"), "alg_MB": (r.get("alg_bytes_per_launch") or 0) / 1e6,
+               "frac": r.get("frac")}
+        if r.get("traffic") is not None:
+            row["traffic_MB"] = r["traffic"] / 1e6
+        if r.get("floor_bytes") is not None:
+            row["floor_MB"] = r["floor_bytes"] / 1e6
+        if r.get("launches_per_frame") is not None:
+            row["launches"] = r["launches_per_frame"]
+        return row
+
+    optional = []   # (key, value): appended in this order, dropped from the END when the line is too long
+    if full.get("roofline_stages"):
+        optional.append(("roofline_stages", [stage_row(r) for r in full["roofline_stages"]]))
+    oc = full.get("other_configs")
+    if oc:
+        c = {}
+        for name, d in oc.items():
+            if not isinstance(d, dict):
+                continue
+            if "error" in d:
+                c[name] = {"error": _cut(d["error"], 120)}
+                continue
+            e = {}
+            if "value" in d:       # a stream configuration (cfg4) through this script
+                e.update({"value": d["value"], "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step")})
+                r4 = d.get("roofline") or {}
+                e.update({"kernel": _cut(r4.get("kernel"), 40), "kernel_ms": r4.get("kernel_ms"), "frac": r4.get("frac")})
+                if d.get("cpu_baseline"):
+                    e["cpu_value"] = d["cpu_baseline"].get("value")
+                if d.get("roofline_stages"):
+                    e["stages"] = [{"stage": r.get("stage"), "ms": r.get("kernel_ms"), "frac": r.get("frac")} for r in d["roofline_stages"]]
+            else:                  # a mesh configuration (cfg2 / cfg5) through tools/mesh_bench.py
+                st = d.get("stages") or {}
+                for k in ("voxelize", "svo_from_voxel_grid"):
+                    if k in st:
+                        e[k + "_ms"] = st[k].get("ms")
+                        e[k + "_frac"] = st[k].get("frac")
+                rs = d.get("renders") or []
+                e["renders"] = [{"view": r.get("view"), "mode": (r.get("mode") or "")[:3], "ms": r.get("trace_kernel_ms"), "Mrays_s": r.get("Mrays_per_s"),
+                                 "frac": r.get("frac"), "lit": r.get("lit_pixels")} for r in rs]
+                e["kernel"] = _cut(d.get("render_kernel"), 60)
+                e["voxels"] = d.get("voxels")
+            c[name] = e
+        optional.append(("other_configs", c))
+    for k in ("stages_sequential", "corrected_tracker", "latency", "pipeline_fill", "other_partition", "wall"):
+        v = full.get(k)
+        if isinstance(v, dict):
+            optional.append((k, {a: b for a, b in v.items() if not isinstance(b, (str, dict, list)) or a in ("exchange", "error")}))
+    if details_path:
+        out["details"] = details_path
+    out = _sig(out, 5)
+    optional = [(k, _sig(v, 4)) for k, v in optional]
+    while True:
+        line = json.dumps({**out, **dict(optional)}, separators=(",", ":"))
+        if len(line.encode()) <= limit or not optional:
+            break
+        optional.pop()
+    if len(line.encode()) > limit:     # (cannot happen with the cuts above; never print a line the driver would truncate)
+        for k in ("runs",):
+            out.pop(k, None)
+        out["cpu_baseline"] = out["cpu_baseline"] and {**out["cpu_baseline"], "sample": _cut(out["cpu_baseline"].get("sample"), 80)}
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line.encode()) <= limit, len(line)
+    return line
+
+
+def write_details(full, path):
+    """the full record (every number of every leg) beside the compact line; a failure to write is reported, never fatal"""
+    try:
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f)
+            f.write("\n")
+        return path
+    except OSError as e:
+        print("bench.py: could not write %s: %r" % (path, e), file=sys.stderr)
+        return None
+
+
+def cpu_baseline(depth_frames, rgb_frames, views, first, width, height, max_depth, center, edge, seed_words, seed_pose, budget_s=20.0, min_frames=1):
     """Single-thread CPU oracle on the TIMED frames of the same stream (reported baseline only): its pool starts from the
     words of the GPU's map after frame first - 1 (bit-identical to the oracle's own, tests/test_gpu_fullsize.py), its tracker
     from the GPU's pose and the maps of frame first - 1 (built untimed), then frames first, first + 1, ... until the budget."""
@@ -112,7 +239,7 @@ def cpu_baseline(depth_frames, rgb_frames, views, first, width, height, max_dept
         ora.cone_trace(pool, width, height, 45.0, views[k], center, edge, ora.RENDER_REFERENCE, L=L)
         t_total += time.perf_counter() - t0
         n_done += 1
-        if t_total > budget_s:
+        if t_total > budget_s and n_done >= min_frames:
             break
     return {"value": n_done / t_total, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "frames %d..%d of the same %dx%d depth-%d stream = the first %d of the GPU's timed frames, from the map and pose the GPU "
@@ -148,7 +275,7 @@ def other_configs(args):
             return {"error": repr(e)}, time.perf_counter() - t0
 
     me = os.path.abspath(__file__)
-    d, w = child([sys.executable, me, "--workload", "cfg4", "--steps", "40", "--warmup", "5", "--repeats", "3", "--lean", "--cpu-budget", "7"]
+    d, w = child([sys.executable, me, "--workload", "cfg4", "--steps", "40", "--warmup", "5", "--repeats", "3", "--lean", "--full-line", "--cpu-budget", "7", "--cpu-min-frames", "5"]
                  + (["--no-cpu-baseline"] if args.no_cpu_baseline else []), 300)
     if "error" in d:
         out["cfg4"] = d
@@ -160,6 +287,7 @@ def other_configs(args):
         out["cfg4"]["overlap"] = d["config"]["overlap"]
         out["cfg4"]["pool_nodes_end"] = d["config"].get("pool_nodes_end")
         out["cfg4"]["mrays_per_s"] = d["config"].get("mrays_per_s")
+        out["cfg4"]["device_memory_GiB"] = d["config"].get("device_memory_GiB")   # incl. march_accel: a degraded child run is visible
         out["cfg4"]["what"] = ("BASELINE config 4 on ONE GPU (its 8-GPU tiling is bench.py --gpus 8 --workload cfg4): `python bench.py --workload cfg4 --steps 40 "
                                "--warmup 5 --repeats 3 --lean` in a child process; median of 3 windows of 40 frames from an empty map")
     out["cfg4"]["wall_s"] = w
@@ -215,6 +343,12 @@ def main():
     ap.add_argument("--lean", action="store_true",
                     help="the line without its side measurements (latency window, pipeline fill, corrected-tracker line): what the "
                          "`other_configs.cfg4` child process runs")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the FULL record as the stdout line (tens of KB) instead of the compact one: what the child runs and "
+                         "tools/prof/*.sh ask for (also SVOSLAM_BENCH_FULL_LINE=1); the driver's run never does")
+    ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"),
+                    help="where the full record goes beside the compact line ('' = nowhere)")
+    ap.add_argument("--cpu-min-frames", type=int, default=1, help="`cpu_baseline` runs at least this many frames, whatever --cpu-budget says")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of single-thread CPU oracle work for `cpu_baseline`")
     ap.add_argument("--stages", action="store_true",
                     help="add `stages` (per-stage durations from HIP-event marks at the stage boundaries, svoslam_runner_timeline); "
@@ -744,27 +878,41 @@ def main():
             out["corrected_tracker"] = corrected_line
         if latency:
             out["latency"] = latency
+        # the CPU leg's starting point, read while the pipeline still exists: the map and the pose the timed frames started from
+        seed_words = seed_pose = None
+        if not args.no_cpu_baseline:
+            history(t0w)
+            seed_words = pool_i32().cpu().numpy().view(np.uint32).copy() if t0w > 0 else None
+            seed_pose = P.cam.pose()
         wall["gpu_legs_s"] = time.perf_counter() - t_start
         # ---- the other BASELINE configurations on the same line: cfg4 = this script in a child process
         # (3 windows of 40 frames, per-stage rooflines, a short CPU leg), cfg2 / cfg5 = tools/mesh_bench.py (voxelize, SVO build,
-        # renders in both modes).  GPU legs, ahead of this process's CPU oracle.
+        # renders in both modes).  GPU legs, ahead of this process's CPU oracle -- and AFTER this process has given its pool
+        # reservation, shadow array and brick field back (the children measured beside 40 GiB held by an idle parent).
         if single and args.workload == "cfg3" and not args.no_other_configs and not args.lean and not args.no_overlap and not args.include_h2d:
             t_o0 = time.perf_counter()
+            cur["P"] = None
+            P.close()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
             out["other_configs"] = other_configs(args)
             wall["other_configs_s"] = time.perf_counter() - t_o0
         if not args.no_cpu_baseline:
-            history(t0w)          # the map and the pose the timed frames started from
-            seed_words = pool_i32().cpu().numpy().view(np.uint32) if t0w > 0 else None
             t_cpu0 = time.perf_counter()
-            out["cpu_baseline"] = cpu_baseline(depth[:total], rgb[:total], views, t0w, width, height, max_depth, center, edge, seed_words, P.cam.pose(),
-                                               budget_s=args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(depth[:total], rgb[:total], views, t0w, width, height, max_depth, center, edge, seed_words, seed_pose,
+                                               budget_s=args.cpu_budget, min_frames=args.cpu_min_frames)
             wall["cpu_baseline_s"] = time.perf_counter() - t_cpu0
         wall["total_s"] = time.perf_counter() - t_start
         wall["note"] = ("wall clock of this process: gpu_legs_s = import + stream generation + every GPU window of this workload; other_configs_s = "
                         "the child processes (GPU); cpu_baseline_s = the single-thread CPU oracle (the GPU idles: a 5-second SMI sample taken "
                         "there reads 0 % busy)")
         out["wall"] = wall
-        print(json.dumps(out), flush=True)
+        if args.full_line or os.environ.get("SVOSLAM_BENCH_FULL_LINE") == "1":
+            print(json.dumps(out), flush=True)
+        else:
+            # the contract's ONE line, <= LINE_LIMIT bytes; the full record goes beside it (and to stderr-free disk only)
+            dp = write_details(out, args.details) if args.details else None
+            print(compact_line(out, os.path.relpath(dp, ROOT) if dp else None), flush=True)
     if world > 1 or force_dist:
         import torch.distributed as tdist
         tdist.barrier()

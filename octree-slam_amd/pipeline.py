@@ -342,6 +342,16 @@ class SlamPipeline:
             self.model_steps = torch.zeros(1, dtype=torch.int64, device=dev) if count_steps else None
             self.cam.set_frame_to_model(True)
 
+    def close(self):
+        """give the device back: runner (streams, events) first, then the pool's reservation (+ shadow array, brick field), workspaces
+        and cameras; the object is unusable afterwards.  bench.py calls it before its child processes measure the other configurations."""
+        for name in ("_runner", "pool", "ws", "ws_sort", "ws_band", "cam", "delta_cam", "sort_cam"):
+            o = self.__dict__.pop(name, None)
+            if o is not None:
+                o.close()
+        for name in ("points", "image", "counters", "model_depth", "acc"):
+            self.__dict__.pop(name, None)
+
     def refresh_model(self):
         """the map as a depth image from the pose of the frame just tracked -> the maps the next frame is tracked against"""
         pkg.raycast_model_depth(self.model_depth, self.focal, self.focal, self.pool.data_ptr, self.center, self.edge,

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SVOSLAM_BENCH_FULL_LINE=1
 # Same-box A/B of a variant library against the built one (frames/s differ by +-2 % from box to box):
 #   octree-slam_amd/_variants/libsvoslam_hip_spec.so = the variant (built by hand with extra -D flags, git-ignored)
 # Usage (on the GPU box): bash tools/prof/ab_variant.sh [reps] [pytest-files...]

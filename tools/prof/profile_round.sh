@@ -12,6 +12,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT="$R/gpurun_out/$TAG"; mkdir -p "$OUT"
 SCR=/tmp/svoslam_prof; mkdir -p $SCR
 cd /tmp; export TMPDIR=/tmp
+export SVOSLAM_BENCH_FULL_LINE=1   # the files under profiles/ hold the FULL record (bench.py prints a <= 6000-byte line by default)
 line() { grep '^{"metric"' | tail -1; }
 P="$OUT/$TAG"
 FAILED=0
