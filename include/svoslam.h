@@ -69,7 +69,10 @@ typedef struct svoslam_config {
   int32_t runner_timeline;  /* 1: HIP-event marks at the stage boundaries (svoslam_runner_timeline); costs ~6 % */
   int32_t sort_pairs;       /* 1: force the (key, index) pair sort instead of the packed one-word sort */
   int32_t graphs;           /* 1: launch sequences recorded and replayed as HIP graphs (0: direct launches, the default) */
-  int32_t reserved[5];
+  int32_t march_ahead;      /* brick march: n >= 0: from step n + 1 on every step also advances by the previous step's level and requests
+                               the next sample's entries before waiting for its own (results identical; hides the round trip in the
+                               long rays of a render); -1: the plain march */
+  int32_t reserved[4];
 } svoslam_config;
 int svoslam_config_get(svoslam_config *out);
 int svoslam_config_set(const svoslam_config *in);

@@ -281,7 +281,7 @@ def _fa(values, n):
 class ConfigStruct(C.Structure):
     """include/svoslam.h svoslam_config"""
     _fields_ = [(n, C.c_int32) for n in ("march_bricks", "track_mode", "track_workers", "track_stream", "runner_deferred", "runner_lead",
-                                         "runner_prio", "runner_replicas", "runner_timeline", "sort_pairs", "graphs")] + [("reserved", C.c_int32 * 5)]
+                                         "runner_prio", "runner_replicas", "runner_timeline", "sort_pairs", "graphs", "march_ahead")] + [("reserved", C.c_int32 * 4)]
 
 
 def get_config():

@@ -1,5 +1,6 @@
 // abi.hip -- the extern "C" surface of libsvoslam_hip.so (include/svoslam.h).
 // Thin: argument checks, device check, dispatch into the kernel translation units.
+#include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -21,6 +22,12 @@ static thread_local char g_last_error[512] = "";
 static char g_arch[256] = "";
 static int g_device_state = 0;  // 0 = unknown, 1 = ok, -1 = none
 
+void set_last_error_text(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+}
 void set_last_error(const char *what, hipError_t e) {
   snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
 }

@@ -22,6 +22,7 @@ constexpr int kWave = 64;  // gfx950 wavefront
 
 // ---- error plumbing -------------------------------------------------------
 void set_last_error(const char *what, hipError_t e);
+void set_last_error_text(const char *fmt, ...) __attribute__((format(printf, 1, 2)));  // a limit of the library, in words
 int ensure_device();
 
 // hipMemset of device memory may return before the fill has run, and the fill runs on the NULL stream, which the library's

@@ -25,6 +25,7 @@
 #include <mutex>
 #include <vector>
 
+#include "config.hpp"
 #include "cone_trace.hpp"
 #include "pool_grid.hpp"
 #include "stage_timing.hpp"
@@ -155,6 +156,7 @@ struct TraceParams {
   // cost (wavefront-steps) to tile_cost for the next one.  nullptr: row-major, nothing recorded.
   const uint32_t *tile_order;
   uint32_t *tile_cost;
+  int spec_from;   // cone_trace_brick_ahead_kernel: steps after this one are marched one sample ahead
 };
 
 // entry e of [fine table | LDS image | alpha LUT] (see "split-plane table")
@@ -213,6 +215,25 @@ __global__ __launch_bounds__(256) void build_accel_kernel(const uint32_t *__rest
     return;
   }
   e -= grid_entries(GRID);
+  if (e < (int)pyr_entries(GRID)) {  // the pyramid of levels 1 .. GRID - 1 behind the grid (pool_grid.hpp)
+    int L = 1;
+    while (L < GRID - 1 && (uint32_t)e >= pyr_offset(L + 1)) L++;
+    const uint32_t c = (uint32_t)e - pyr_offset(L), m = (1u << L) - 1u;
+    const uint32_t xi = c & m, yi = (c >> L) & m, zi = c >> (2 * L);
+    uint32_t base = 0;
+    uint2 out = make_uint2(0u, 0u);
+    for (int l = 1; l <= L; l++) {
+      const int sh = L - l;
+      const uint32_t oct = ((xi >> sh) & 1u) | (((yi >> sh) & 1u) << 1) | (((zi >> sh) & 1u) << 2);
+      const uint2 nd = nodes[base + oct];
+      if (!(nd.x & kFlag)) { out = make_uint2((uint32_t)l, nd.y); break; }
+      base = nd.x & kMask;
+      out = make_uint2(kFlag | base, nd.y);
+    }
+    grid[grid_entries(GRID) + e] = out;
+    return;
+  }
+  e -= (int)pyr_entries(GRID);
   build_table_entry(e, table, alpha_lut, P);
 }
 
@@ -313,18 +334,18 @@ __device__ __forceinline__ void walk_deep_chain(const uint2 *__restrict__ nodes,
   }
 }
 
-// walk from the root for an LOD depth above the grid level (1 <= depth < grid level)
-template <int LDSD>
-__device__ __forceinline__ void walk_shallow(const uint2 *__restrict__ nodes, uint32_t xb, uint32_t yb, uint32_t zb, int &depth, uint32_t &w1) {
-  uint32_t child_idx = 0;
-  for (int i = 1; i <= depth; i++) {
-    const int sh = LDSD - i;
-    const uint32_t oct = ((xb >> sh) & 1u) | (((yb >> sh) & 1u) << 1) | (((zb >> sh) & 1u) << 2);
-    const uint2 nd = nodes[child_idx + oct];
-    w1 = nd.y;
-    if (!(nd.x & kFlag)) { depth = i; break; }
-    child_idx = nd.x & kMask;
-  }
+// an LOD depth above the grid level (1 <= depth < grid level): the reference's walk from the root ends on the level-`depth` node or on
+// the first childless node above it -- ONE entry of the grid's pyramid (pool_grid.hpp; until round 6: `depth` dependent loads)
+template <int LDSD, int GRID>
+__device__ __forceinline__ uint32_t pyramid_index(uint32_t xb, uint32_t yb, uint32_t zb, int depth) {
+  const int sh = LDSD - depth;
+  return (uint32_t)grid_entries(GRID) + pyr_offset_rt(depth) + (((zb >> sh) << (2 * depth)) | ((yb >> sh) << depth) | (xb >> sh));
+}
+template <int LDSD, int GRID>
+__device__ __forceinline__ void walk_shallow(const uint2 *__restrict__ grid, uint32_t xb, uint32_t yb, uint32_t zb, int &depth, uint32_t &w1) {
+  const uint2 p = grid[pyramid_index<LDSD, GRID>(xb, yb, zb, depth)];
+  w1 = p.y;
+  if (!(p.x & kFlag)) depth = (int)p.x;
 }
 
 // ---- step / level counters ---------------------------------------------------------------------------------------------
@@ -452,16 +473,18 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
       gy = gy < 0 ? 0 : (gy > lds_cells(LDSD) - 1 ? lds_cells(LDSD) - 1 : gy);
       gz = gz < 0 ? 0 : (gz > lds_cells(LDSD) - 1 ? lds_cells(LDSD) - 1 : gz);
       constexpr int kGridShift = kLdsDepth - kGridLevel;
-      const uint32_t cell_s = (((uint32_t)gz >> kGridShift) << (2 * kGridLevel)) | (((uint32_t)gy >> kGridShift) << kGridLevel) | ((uint32_t)gx >> kGridShift);
-      const uint2 g_s = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(grid) + (cell_s << 3));
-      // LOD depth (:69); fast form of step_lod when both operands are ordinary positive floats.  (After the grid request:
-      // the request needs the position only.)
+      // LOD depth (:69); fast form of step_lod when both operands are ordinary positive floats.  Ahead of the request since round 6:
+      // an LOD coarser than the grid level asks the grid's PYRAMID (pool_grid.hpp) for the cell of its own level instead.
       int depth;
       {
         const uint32_t ub = f2bits(pix_size);
         if (ub - P.lod_first <= P.lod_span) depth = (P.size_exp - (int)(ub >> 23)) + ((ub & 0x7FFFFFu) < P.size_man ? 1 : 0);
         else depth = step_lod(P.size, pix_size);
       }
+      const bool coarse = depth < kGridLevel && depth >= 1;
+      const uint32_t cell_s = coarse ? pyramid_index<kLdsDepth, kGridLevel>((uint32_t)gx, (uint32_t)gy, (uint32_t)gz, depth)
+                                     : (((uint32_t)gz >> kGridShift) << (2 * kGridLevel)) | (((uint32_t)gy >> kGridShift) << kGridLevel) | ((uint32_t)gx >> kGridShift);
+      const uint2 g_s = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(grid) + ((size_t)cell_s << 3));
       // the part of the length recurrence's division that depends on the divisor alone (div_rn_midrange: v_rcp + 2 fma)
       float inv_len = __builtin_amdgcn_rcpf(ray_len);
       inv_len = fmaf(fmaf(-ray_len, inv_len, 1.0f), inv_len, inv_len);
@@ -537,8 +560,13 @@ __global__ __launch_bounds__(THREADS) void cone_trace_kernel(uchar4 *__restrict_
           }
         }
       } else if (depth >= 1) {
-        // LOD coarser than the grid (sample farther than ~size/(32 pix_scale)): the reference's walk from the root
-        walk_shallow<LDSD>(nodes, xb, yb, zb, depth, w1);
+        // LOD coarser than the grid (sample farther than ~size/(32 pix_scale)): the reference's walk from the root ends at the LOD
+        // level or on a childless node above it -- the pyramid's entry of that cell, requested above from the guessed ranks
+        const uint32_t cell = pyramid_index<kLdsDepth, kGridLevel>(xb, yb, zb, depth);
+        uint2 g = g_s;
+        if (cell != cell_s) g = grid[cell];
+        w1 = g.y;
+        if (!(g.x & kFlag)) depth = (int)g.x;
       } else {
         w1 = octree[1];  // depth <= 0: the reference reads node 0 (:107 with node_idx = 0)
       }
@@ -633,7 +661,7 @@ __device__ __forceinline__ uint32_t walk_sample(const uint2 *__restrict__ nodes,
       }
     }
   } else if (depth >= 1) {
-    walk_shallow<LDSD>(nodes, xb, yb, zb, depth, w1);
+    walk_shallow<LDSD, GRID>(grid, xb, yb, zb, depth, w1);
   } else {
     w1 = octree[1];
   }
@@ -764,8 +792,11 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       }
       // the grid: a first childless node at level gq.x <= 8 ends every walk whose LOD reaches it; a level-8 node with
       // children (gq.x = flag | tile >= 2^30) ends the walk of LOD 8 only
-      const uint32_t depth_g = gq.x < (uint32_t)GRID ? gq.x : (uint32_t)GRID;
-      const uint32_t top_g = gq.x < kFlag ? 127u : (uint32_t)GRID;   // the LODs it answers: depth_g .. top_g
+      // (round 6: a sample whose LOD is coarser than the grid level has asked the PYRAMID for the cell of its own level lv = LOD: the
+      // same rule one level up -- a childless node at gq.x <= lv ends the walk, a level-lv node with children ends the walk of LOD lv)
+      const uint32_t lv = lod_ < GRID ? (uint32_t)lod_ : (uint32_t)GRID;
+      const uint32_t depth_g = gq.x < kFlag ? gq.x : lv;
+      const uint32_t top_g = gq.x < kFlag ? 127u : lv;   // the LODs it answers: depth_g .. top_g
       const bool by_grid = (uint32_t)lod_ - depth_g <= top_g - depth_g;
       depth = by_brick ? depth_b : (int)depth_g;
       ret = by_brick ? (e >> bit) & 1u : (uint32_t)(gq.y >= 0xFE000000u);
@@ -790,14 +821,16 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       fy_ = fy_ < 0 ? 0 : (fy_ > kFine - 1 ? kFine - 1 : fy_);
       fz_ = fz_ < 0 ? 0 : (fz_ > kFine - 1 ? kFine - 1 : fz_);
       const int gx = fx_ >> S, gy = fy_ >> S, gz = fz_ >> S;
-      // entries requested from the GUESSED cells (see cone_trace_kernel)
-      const uint2 gq = grid[(((uint32_t)gz >> (LDSD - GRID)) << (2 * GRID)) | (((uint32_t)gy >> (LDSD - GRID)) << GRID) | ((uint32_t)gx >> (LDSD - GRID))];
-      const bool with_brick = __any((prev_gx & kFlag) != 0u);  // (uniform: some ray of this wavefront is among nodes)
-      uint32_t e = 0;
-      if (with_brick) e = brick_entry((uint32_t)fx_, (uint32_t)fy_, (uint32_t)fz_);
       const uint32_t ub = f2bits(pix_size);
       lod = (P.size_exp - (int)(ub >> 23)) + ((ub & 0x7FFFFFu) < P.size_man ? 1 : 0);
       const bool lod_ok = LOD_ALWAYS || ub - P.lod_first <= P.lod_span;
+      // entries requested from the GUESSED cells (see cone_trace_kernel); an LOD coarser than the grid level asks the pyramid
+      const bool coarse = (uint32_t)(lod - 1) < (uint32_t)(GRID - 1);   // 1 <= lod < GRID
+      const uint2 gq = grid[coarse ? pyramid_index<LDSD, GRID>((uint32_t)gx, (uint32_t)gy, (uint32_t)gz, lod)
+                                   : (((uint32_t)gz >> (LDSD - GRID)) << (2 * GRID)) | (((uint32_t)gy >> (LDSD - GRID)) << GRID) | ((uint32_t)gx >> (LDSD - GRID))];
+      const bool with_brick = __any((prev_gx & kFlag) != 0u);  // (uniform: some ray of this wavefront is among nodes)
+      uint32_t e = 0;
+      if (with_brick) e = brick_entry((uint32_t)fx_, (uint32_t)fy_, (uint32_t)fz_);
       float inv_len = __builtin_amdgcn_rcpf(ray_len);
       inv_len = fmaf(fmaf(-ray_len, inv_len, 1.0f), inv_len, inv_len);
       // confirmation of the guessed ranks: S[g-1] < t <= S[g] on every axis
@@ -811,9 +844,9 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const long long c2 = clock64();
 #endif
-      prev_gx = gq.x;
+      prev_gx = coarse ? 0u : gq.x;   // (a pyramid entry's children flag is not about a level-8 node: no brick can answer that LOD)
       // the step that enters a level-8 node with children: its brick entry has not been requested yet
-      if (!with_brick && __any((gq.x & kFlag) != 0u && lod > GRID)) e = brick_entry((uint32_t)fx_, (uint32_t)fy_, (uint32_t)fz_);
+      if (!with_brick && __any((gq.x & kFlag) != 0u && lod > GRID && lod_ok)) e = brick_entry((uint32_t)fx_, (uint32_t)fy_, (uint32_t)fz_);
       // the octant at the bits level, where some lane's walk ends there: the level-11 decision's plane is the table entry at
       // the even rank (walk_deep_chain), i.e. S[g-1] for an odd rank and S[g] for an even one -- one of the two entries
       // the confirmation has read (valid for confirmed guesses; the others are redone below).  S = 1: the level-12 bit of the
@@ -863,8 +896,12 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
               yb = axis_bits_chain(ty, P.center[1], P.size, LDSD);
               zb = axis_bits_chain(tz, P.center[2], P.size, LDSD);
             }
-            g2 = grid[((zb >> (LDSD - GRID)) << (2 * GRID)) | ((yb >> (LDSD - GRID)) << GRID) | (xb >> (LDSD - GRID))];
-            prev_gx = g2.x;
+          }
+          if (!conf || !lod_ok) {  // the grid (or pyramid) entry of the confirmed ranks at the true LOD
+            const bool coarse2 = (uint32_t)(lod - 1) < (uint32_t)(GRID - 1);
+            g2 = grid[coarse2 ? pyramid_index<LDSD, GRID>(xb, yb, zb, lod)
+                              : ((zb >> (LDSD - GRID)) << (2 * GRID)) | ((yb >> (LDSD - GRID)) << GRID) | (xb >> (LDSD - GRID))];
+            prev_gx = coarse2 ? 0u : g2.x;
           }
           // the reference's centres below the table (walk_deep_chain): the level-12 octant, and for S = 1 the level-13 one
           float cx = lds_tab[(xb & ~1u) + 2u], cy = lds_tab[kLdsStride + (yb & ~1u) + 2u], cz = lds_tab[2 * kLdsStride + (zb & ~1u) + 2u];
@@ -991,6 +1028,330 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
   if (slots) count_steps(slots, counters, my_steps, my_levels, lane);
 }
 
+// ---- the same march, one sample AHEAD (round 6) ---------------------------------------------------------
+// What binds cone_trace_brick_kernel in the tail of a render is not what it issues but the round trip of a step's two entries: a
+// wavefront alone on its SIMD parks ~680 of a step's ~1100 cycles at s_waitcnt (profiles/r05_march_sq_counters_cfg3.txt), and the
+// render ends when its longest ray does (394 steps at cfg3, 768 in config 2's side view).  77 % of a long ray's steps end on the
+// same level as the step before (profiles/HISTORY_r01_r03.md).  So each step, BEFORE it waits for its own entries, advances the
+// ray by the previous step's level -- the reference's own arithmetic (:126-131), same operands, same bits -- and requests the
+// entries of the sample that advance leads to.  When the step's level turns out to be the predicted one (`hit`), the next step
+// finds its position, LOD and entries already there: its round trip has overlapped this step's; otherwise the advance is redone
+// with the right level and the entries are requested again, which is cone_trace_brick_kernel's step.  No result depends on the
+// prediction: a hit IS the advance the unpredicted code performs.  The loop is unrolled by two with the two sample records
+// swapping roles -- a copy of the prefetched entries into the "current" registers would be a use, and wait for them.
+// spec_from: steps before this one run unpredicted (the chip is full then and bound by issue, not latency).
+struct MarchSample {
+  float rx, ry, rz, len;   // the ray to this sample and its length
+  float tx, ty, tz;        // the sample
+  int fx, fy, fz;          // its guessed cell at the bricks' cell level
+  int lod;
+  uint32_t lod_ok;
+  uint2 gq;                // requested: its level-grid (or pyramid) entry
+  uint32_t e, have_e;      // ... and its brick entry (have_e = 0: not requested, the ray was not among nodes)
+};
+
+template <int THREADS, bool LOD_ALWAYS, int S>
+__global__ __launch_bounds__(THREADS, 4) void cone_trace_brick_ahead_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
+                                                                         const uint2 *__restrict__ grid, const uint16_t *__restrict__ bricks,
+                                                                         const float *__restrict__ table, const float *__restrict__ alpha_lut_g,
+                                                                         TraceParams P, unsigned long long *__restrict__ counters,
+                                                                         unsigned long long *__restrict__ slots) {
+  constexpr int LDSD = 11, GRID = kPoolGridLevel;
+  constexpr int kLdsStride = lds_stride(LDSD);
+  constexpr int kCells = lds_cells(LDSD);
+  constexpr int BL = brick_bits_level(S);
+  constexpr int kFine = kCells << S;
+  constexpr uint32_t kOrg = brick_window_origin(S);
+  __shared__ float alpha_lut[256];
+  __shared__ float lds_tab[3 * kLdsStride + 3 * kCells];
+  uint32_t *spread = reinterpret_cast<uint32_t *>(lds_tab + 3 * kLdsStride);
+  if (threadIdx.x < 256) alpha_lut[threadIdx.x] = alpha_lut_g[threadIdx.x];
+  {
+    const float *src = table + 3 * kTabStride;
+    for (int i = threadIdx.x; i < 3 * kLdsStride; i += THREADS) lds_tab[i] = src[i];
+    for (int i = threadIdx.x; i < kCells; i += THREADS) {
+      const uint32_t r = (uint32_t)i;
+      spread[i] = (uint32_t)(brick_entry_index(r, 0u, 0u) >> 1);
+      spread[kCells + i] = (uint32_t)(brick_entry_index(0u, r, 0u) >> 1);
+      spread[2 * kCells + i] = (uint32_t)(brick_entry_index(0u, 0u, r) >> 1);
+    }
+  }
+  __syncthreads();
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const int tile_id = P.tile_order ? (int)P.tile_order[blockIdx.x] : (int)blockIdx.x;
+  const int tile_y = tile_id / P.xcd_h;
+  const int tile_x = tile_id - tile_y * P.xcd_h;
+  const int px = tile_x * 32 + (int)(wave & 3u) * 8 + (int)(lane & 7u);
+  const int py = P.xcd_w ? P.row_first + (tile_y + (int)(wave >> 2) * P.xcd_w) * 8 + (int)(lane >> 3)
+                         : P.row_first + tile_y * (THREADS / 32) + (int)(wave >> 2) * 8 + (int)(lane >> 3);
+  uint32_t my_steps = 0, my_levels = 0;
+  if (px < P.width && py < P.row_end) {
+    const int idx = py * P.width + px;
+    const float res_x = (float)P.width, res_y = (float)P.height;
+    const float magx = ((float)px - res_x / 2.0f) / 532.57f;
+    const float magy = ((float)py - res_y / 2.0f) / 531.54f;
+    const float nyx = -P.y_dir[0], nyy = -P.y_dir[1], nyz = -P.y_dir[2];
+    const float fwx = P.x_dir[1] * nyz - nyy * P.x_dir[2];
+    const float fwy = P.x_dir[2] * nyx - nyz * P.x_dir[0];
+    const float fwz = P.x_dir[0] * nyy - nyx * P.x_dir[1];
+    const float dx = ((magx * P.x_dir[0]) + (magy * P.y_dir[0])) + fwx;
+    const float dy = ((magx * P.x_dir[1]) + (magy * P.y_dir[1])) + fwy;
+    const float dz = ((magx * P.x_dir[2]) + (magy * P.y_dir[2])) + fwz;
+    const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+    const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
+    const float ts11 = ldexpf(P.size, -LDSD);
+    const float ts12 = ldexpf(P.size, -LDSD - 1);
+    const float inv_cell_fine = S == 0 ? P.inv_cell_lds : P.inv_cell_lds * 2.0f;
+    // position, guessed cell and LOD of the sample at the end of q's ray
+    auto place = [&](MarchSample &q) {
+      q.tx = P.origin[0] + q.rx; q.ty = P.origin[1] + q.ry; q.tz = P.origin[2] + q.rz;
+      int fx_ = (int)((q.tx - P.lo[0]) * inv_cell_fine), fy_ = (int)((q.ty - P.lo[1]) * inv_cell_fine), fz_ = (int)((q.tz - P.lo[2]) * inv_cell_fine);
+      q.fx = fx_ < 0 ? 0 : (fx_ > kFine - 1 ? kFine - 1 : fx_);
+      q.fy = fy_ < 0 ? 0 : (fy_ > kFine - 1 ? kFine - 1 : fy_);
+      q.fz = fz_ < 0 ? 0 : (fz_ > kFine - 1 ? kFine - 1 : fz_);
+      const uint32_t ub = f2bits(q.len * P.pix_scale);
+      q.lod = (P.size_exp - (int)(ub >> 23)) + ((ub & 0x7FFFFFu) < P.size_man ? 1 : 0);
+      q.lod_ok = (LOD_ALWAYS || ub - P.lod_first <= P.lod_span) ? 1u : 0u;
+    };
+    // its two entries, from the guessed cell.  with_brick (wavefront-uniform): some ray of the wavefront is among nodes; the brick
+    // load is issued either way (from the field's first entry when not wanted) so that the number of loads in flight is static
+    auto request = [&](MarchSample &q, bool with_brick) {
+      const uint32_t gx = (uint32_t)(q.fx >> S), gy = (uint32_t)(q.fy >> S), gz = (uint32_t)(q.fz >> S);
+      const bool coarse = (uint32_t)(q.lod - 1) < (uint32_t)(GRID - 1);
+      q.gq = grid[coarse ? pyramid_index<LDSD, GRID>(gx, gy, gz, q.lod)
+                         : ((gz >> (LDSD - GRID)) << (2 * GRID)) | ((gy >> (LDSD - GRID)) << GRID) | (gx >> (LDSD - GRID))];
+      uint32_t x = (uint32_t)q.fx, y = (uint32_t)q.fy, z = (uint32_t)q.fz;
+      bool use = with_brick;
+      if (S > 0) {  // the window: cells outside it have no entry (0 = "ask the level grid")
+        x -= kOrg; y -= kOrg; z -= kOrg;
+        const bool inwin = (x | y | z) < kBrickWindowCells;
+        use = use && inwin;
+        x = inwin ? x : 0u; y = inwin ? y : 0u; z = inwin ? z : 0u;
+      }
+      const uint32_t d = spread[x] | spread[kCells + y] | spread[2 * kCells + z];
+      const size_t off = use ? (((size_t)d << 2) | ((x & 1u) << 1)) : (size_t)0;
+      const uint32_t v = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(bricks) + off);
+      q.e = use ? v : 0u;
+      q.have_e = with_brick ? 1u : 0u;
+    };
+    auto brick_entry = [&](uint32_t x, uint32_t y, uint32_t z) -> uint32_t {
+      if (S > 0) {
+        x -= kOrg; y -= kOrg; z -= kOrg;
+        if ((x | y | z) >= kBrickWindowCells) return 0u;
+      }
+      const uint32_t d = spread[x] | spread[kCells + y] | spread[2 * kCells + z];
+      return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(bricks) + (((size_t)d << 2) | ((x & 1u) << 1)));
+    };
+    // (cone_trace_brick_kernel's decode, word for word)
+    auto decode = [&](uint32_t e, uint2 gq, int lod_, uint32_t oct12, int &depth, uint32_t &ret) -> bool {
+      const int st = S == 0 ? (int)((e & 7u) | 8u) : (int)((0x009DCBA8u >> ((e & 7u) << 2)) & 15u);
+      const int depth_b = lod_ < st ? lod_ : st;
+      uint32_t bit = (uint32_t)(depth_b - 5);
+      constexpr int NLv = brick_node_level(S);
+      bool by_brick = (uint32_t)(depth_b - NLv) < 3u;
+      if (S > 0) by_brick = by_brick || (st > GRID && st < NLv && depth_b == st);
+      if (lod_ >= BL) {
+        const bool deep = depth_b == BL && (lod_ == BL || !(e & 8u));
+        by_brick = by_brick || deep;
+        bit = deep ? 8u + oct12 : bit;
+      }
+      const uint32_t lv = lod_ < GRID ? (uint32_t)lod_ : (uint32_t)GRID;
+      const uint32_t depth_g = gq.x < kFlag ? gq.x : lv;
+      const uint32_t top_g = gq.x < kFlag ? 127u : lv;
+      const bool by_grid = (uint32_t)lod_ - depth_g <= top_g - depth_g;
+      depth = by_brick ? depth_b : (int)depth_g;
+      ret = by_brick ? (e >> bit) & 1u : (uint32_t)(gq.y >= 0xFE000000u);
+      return by_brick || by_grid;
+    };
+    uint32_t retired = 0, prev_gx = 0;
+    int dprev = 1 << 20;              // the previous step's level (none yet: predicts nothing)
+    float last_tx = 0.0f, last_ty = 0.0f, last_tz = 0.0f, ray_len = 0.0f;   // the last sample and the length after its advance
+    int last_lod = 0;
+    // one step: `cur` is the sample (placed, its entries requested); `nxt` becomes the next one.  Returns true when the ray is done.
+    auto step = [&](MarchSample &cur, MarchSample &nxt) -> bool {
+      my_steps++;
+      const bool spec_on = (int)__builtin_amdgcn_readfirstlane((int)my_steps) > P.spec_from;
+      float inv_len = __builtin_amdgcn_rcpf(cur.len);
+      inv_len = fmaf(fmaf(-cur.len, inv_len, 1.0f), inv_len, inv_len);
+      const int gx = cur.fx >> S, gy = cur.fy >> S, gz = cur.fz >> S;
+      const float tx = cur.tx, ty = cur.ty, tz = cur.tz;
+      const float ax = lds_tab[gx + 1], bx = lds_tab[gx + 2];
+      const float ay = lds_tab[kLdsStride + gy + 1], by = lds_tab[kLdsStride + gy + 2];
+      const float az = lds_tab[2 * kLdsStride + gz + 1], bz = lds_tab[2 * kLdsStride + gz + 2];
+      bool conf = (((int)(ax < tx) & (int)!(bx < tx)) & ((int)(ay < ty) & (int)!(by < ty)) & ((int)(az < tz) & (int)!(bz < tz))) != 0;
+      const bool coarse = (uint32_t)(cur.lod - 1) < (uint32_t)(GRID - 1);
+      // ---- one sample ahead: the advance by the previous step's level, its sample, its entries ----
+      if (spec_on) {
+        const float nd = ldexpf(P.size, -dprev);
+        const float sp = div_rn_midrange_r(cur.len + nd, cur.len, inv_len);
+        nxt.rx = cur.rx * sp; nxt.ry = cur.ry * sp; nxt.rz = cur.rz * sp;
+        nxt.len = sqrt_rn_midrange(dot3(nxt.rx, nxt.ry, nxt.rz, nxt.rx, nxt.ry, nxt.rz));
+        place(nxt);
+        request(nxt, __any((prev_gx & kFlag) != 0u));
+      }
+      // ---- this sample's answers (the loads above stay in flight) ----
+      const int lod = cur.lod;
+      const bool lod_ok = LOD_ALWAYS || cur.lod_ok != 0u;
+      uint2 gq = cur.gq;
+      uint32_t e = cur.e;
+      prev_gx = coarse ? 0u : gq.x;
+      {  // the step that enters a level-8 node with children without a brick entry requested
+        const bool need = cur.have_e == 0u && (gq.x & kFlag) != 0u && lod > GRID && !coarse;
+        if (__any(need)) { if (need) e = brick_entry((uint32_t)cur.fx, (uint32_t)cur.fy, (uint32_t)cur.fz); }
+      }
+      uint32_t oct12 = 0;
+      if (S > 0 || __any(lod >= BL)) {
+        float cx = (gx & 1) ? ax : bx, cy = (gy & 1) ? ay : by, cz = (gz & 1) ? az : bz;
+        cx += ts11 * ((gx & 1) ? 1.0f : -1.0f);
+        cy += ts11 * ((gy & 1) ? 1.0f : -1.0f);
+        cz += ts11 * ((gz & 1) ? 1.0f : -1.0f);
+        const uint32_t hx = (uint32_t)(tx > cx), hy = (uint32_t)(ty > cy), hz = (uint32_t)(tz > cz);
+        if (S == 0) {
+          oct12 = hx | (hy << 1) | (hz << 2);
+        } else {
+          conf = conf && (((hx ^ (uint32_t)cur.fx) | (hy ^ (uint32_t)cur.fy) | (hz ^ (uint32_t)cur.fz)) & 1u) == 0u;
+          if (__any(lod >= BL)) {
+            cx += ts12 * (hx ? 1.0f : -1.0f);
+            cy += ts12 * (hy ? 1.0f : -1.0f);
+            cz += ts12 * (hz ? 1.0f : -1.0f);
+            oct12 = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
+          }
+        }
+      }
+      int depth;
+      const bool decided = decode(e, gq, lod, oct12, depth, retired);
+      float new_dist = ldexpf(P.size, -depth);
+      bool full_form = false;
+      int lod_last = lod;
+      if (__builtin_expect(__any(!(decided && conf && lod_ok)), 0)) {
+        if (!(decided && conf && lod_ok)) {
+          // the rare sample (cone_trace_brick_kernel's, word for word)
+          int lod2 = lod;
+          if (!lod_ok) lod2 = step_lod(P.size, cur.len * P.pix_scale);
+          lod_last = lod2;
+          bool ok = true;
+          uint32_t xb = (uint32_t)gx, yb = (uint32_t)gy, zb = (uint32_t)gz;
+          uint32_t e2 = e;
+          uint2 g2 = gq;
+          if (!conf) {
+            xb = axis_bits_lds<LDSD>(tx, P.lo[0], P.inv_cell_lds, lds_tab, ok);
+            yb = axis_bits_lds<LDSD>(ty, P.lo[1], P.inv_cell_lds, lds_tab + kLdsStride, ok);
+            zb = axis_bits_lds<LDSD>(tz, P.lo[2], P.inv_cell_lds, lds_tab + 2 * kLdsStride, ok);
+            if (!ok) {
+              xb = axis_bits_chain(tx, P.center[0], P.size, LDSD);
+              yb = axis_bits_chain(ty, P.center[1], P.size, LDSD);
+              zb = axis_bits_chain(tz, P.center[2], P.size, LDSD);
+            }
+          }
+          if (!conf || !lod_ok) {
+            const bool coarse2 = (uint32_t)(lod2 - 1) < (uint32_t)(GRID - 1);
+            g2 = grid[coarse2 ? pyramid_index<LDSD, GRID>(xb, yb, zb, lod2)
+                              : ((zb >> (LDSD - GRID)) << (2 * GRID)) | ((yb >> (LDSD - GRID)) << GRID) | (xb >> (LDSD - GRID))];
+            prev_gx = coarse2 ? 0u : g2.x;
+          }
+          float cx = lds_tab[(xb & ~1u) + 2u], cy = lds_tab[kLdsStride + (yb & ~1u) + 2u], cz = lds_tab[2 * kLdsStride + (zb & ~1u) + 2u];
+          cx += ts11 * ((xb & 1u) ? 1.0f : -1.0f);
+          cy += ts11 * ((yb & 1u) ? 1.0f : -1.0f);
+          cz += ts11 * ((zb & 1u) ? 1.0f : -1.0f);
+          uint32_t oct12r = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
+          if (S > 0) {
+            const uint32_t cxf = (xb << 1) | (oct12r & 1u), cyf = (yb << 1) | ((oct12r >> 1) & 1u), czf = (zb << 1) | (oct12r >> 2);
+            if (!conf) e2 = ok ? brick_entry(cxf, cyf, czf) : 0u;
+            cx += ts12 * ((oct12r & 1u) ? 1.0f : -1.0f);
+            cy += ts12 * ((oct12r & 2u) ? 1.0f : -1.0f);
+            cz += ts12 * ((oct12r & 4u) ? 1.0f : -1.0f);
+            oct12r = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
+          } else if (!conf) {
+            e2 = ok ? brick_entry(xb, yb, zb) : 0u;
+          }
+          const bool decided2 = ok && decode(e2, g2, lod2, oct12r, depth, retired);
+          if (!decided2) {
+            depth = lod2;
+            const uint32_t w = walk_sample<LDSD, GRID>(nodes, octree, grid, table, lds_tab, P, tx, ty, tz, xb, yb, zb, ok, depth);
+            retired = (w >> 24) >= 254u ? 1u : 0u;
+          }
+          new_dist = (depth >= -100 && depth <= 100) ? ldexpf(P.size, -depth) : P.size / ldexpf(1.0f, depth);
+          full_form = depth < -60;
+        }
+      }
+      my_levels += (uint32_t)(depth > 0 ? depth : 0);
+      // ---- the advance (:126-131): already there when the level is the predicted one ----
+      const bool hit = spec_on && depth == dprev && !full_form;
+      dprev = depth;
+      if (__any(!hit)) {
+        if (!hit) {
+          float s = div_rn_midrange_r(cur.len + new_dist, cur.len, inv_len);
+          if (full_form) s = (cur.len + new_dist) / cur.len;
+          nxt.rx = cur.rx * s; nxt.ry = cur.ry * s; nxt.rz = cur.rz * s;
+          nxt.len = full_form ? length3(nxt.rx, nxt.ry, nxt.rz) : sqrt_rn_midrange(dot3(nxt.rx, nxt.ry, nxt.rz, nxt.rx, nxt.ry, nxt.rz));
+        }
+      }
+      if (retired != 0u || nxt.len > kMaxRange || my_steps >= (uint32_t)kMaxSteps) {
+        last_tx = tx; last_ty = ty; last_tz = tz; last_lod = lod_last; ray_len = nxt.len;
+        return true;
+      }
+      const bool with_brick = __any((prev_gx & kFlag) != 0u);
+      if (__any(!hit)) {
+        if (!hit) {
+          place(nxt);
+          request(nxt, with_brick);
+        }
+      }
+      return false;
+    };
+    MarchSample A, B;
+    A.rx = kStartDist * (dx * inv); A.ry = kStartDist * (dy * inv); A.rz = kStartDist * (dz * inv);
+    A.len = length3(A.rx, A.ry, A.rz);
+    place(A);
+    request(A, false);
+    B = A;
+    for (;;) {
+      if (step(A, B)) break;
+      if (step(B, A)) break;
+    }
+    const bool range_exit = retired == 0u && ray_len > kMaxRange;
+    uint32_t w_last;
+    {
+      bool ok = true;
+      uint32_t xb = axis_bits_lds<LDSD>(last_tx, P.lo[0], P.inv_cell_lds, lds_tab, ok);
+      uint32_t yb = axis_bits_lds<LDSD>(last_ty, P.lo[1], P.inv_cell_lds, lds_tab + kLdsStride, ok);
+      uint32_t zb = axis_bits_lds<LDSD>(last_tz, P.lo[2], P.inv_cell_lds, lds_tab + 2 * kLdsStride, ok);
+      if (!ok) {
+        xb = axis_bits_chain(last_tx, P.center[0], P.size, LDSD);
+        yb = axis_bits_chain(last_ty, P.center[1], P.size, LDSD);
+        zb = axis_bits_chain(last_tz, P.center[2], P.size, LDSD);
+      }
+      int d2 = last_lod;
+      w_last = walk_sample<LDSD, GRID>(nodes, octree, grid, table, lds_tab, P, last_tx, last_ty, last_tz, xb, yb, zb, ok, d2);
+    }
+    const int alpha = (int)((w_last >> 24) - 127u);
+    const float af = alpha_lut[alpha + 127];
+    uint32_t vx = f2u8(af * (float)(w_last & 0xFF));
+    uint32_t vy = f2u8(af * (float)((w_last >> 8) & 0xFF));
+    uint32_t vz = f2u8(af * (float)((w_last >> 16) & 0xFF));
+    const uint32_t vw = (uint32_t)alpha & 0xFFu;
+    if (range_exit) {
+      const float sc = 127.0f / (float)vw;
+      vx = f2u8((float)vx * sc);
+      vy = f2u8((float)vy * sc);
+      vz = f2u8((float)vz * sc);
+    }
+    uint32_t out = vx | (vy << 8) | (vz << 16) | (255u << 24);
+    if (P.mode & 0x100) out = my_steps;
+    uchar4 o;
+    o.x = (unsigned char)(out & 0xFF); o.y = (unsigned char)((out >> 8) & 0xFF);
+    o.z = (unsigned char)((out >> 16) & 0xFF); o.w = (unsigned char)(out >> 24);
+    pos[idx] = o;
+  }
+  if (P.tile_cost) {
+    uint32_t mx = my_steps;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)mx, o); mx = v > mx ? v : mx; }
+    if (lane == 0) atomicAdd(&P.tile_cost[tile_id], mx);
+  }
+  if (slots) count_steps(slots, counters, my_steps, my_levels, lane);
+}
+
 // Tiles of the previous render, costliest first: tile_order_block (pool_grid.hpp), run by one extra workgroup of the refresh
 // launch that precedes the march (no launch of its own on the map stream: as one it took 15 us + a launch boundary per frame)
 // or, where no refresh is launched, by this kernel.
@@ -1072,7 +1433,7 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   float inv[16];
   mat4_inverse_host(view, inv);
   TraceParams P;
-  P.tile_order = nullptr; P.tile_cost = nullptr;
+  P.tile_order = nullptr; P.tile_cost = nullptr; P.spec_from = 0;
   mat4_mul_point(inv, 0.0f, 0.0f, 0.0f, 1.0f, P.origin[0], P.origin[1], P.origin[2]);
   mat4_mul_point(inv, -1.0f, 0.0f, 0.0f, 0.0f, P.x_dir[0], P.x_dir[1], P.x_dir[2]);
   mat4_mul_point(inv, 0.0f, -1.0f, 0.0f, 0.0f, P.y_dir[0], P.y_dir[1], P.y_dir[2]);
@@ -1123,12 +1484,13 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   PoolAccel *pa = pa_hold.get();
   const bool large = pa != nullptr || (long long)width * rows >= (1ll << 20);  // e.g. 1920x1080 frames
   const int own_cells = pa ? 0 : grid_entries(large ? kGridLevelLarge : kGridLevelSmall);
-  const size_t accel_bytes = (size_t)own_cells * sizeof(uint2) + (size_t)(3 * (kTabStride + kLdsStrideMax) + 256) * sizeof(float) + 64;
+  const int own_total = pa ? 0 : own_cells + (int)pyr_entries(large ? kGridLevelLarge : kGridLevelSmall);  // the grid, then its pyramid (pool_grid.hpp)
+  const size_t accel_bytes = (size_t)own_total * sizeof(uint2) + (size_t)(3 * (kTabStride + kLdsStrideMax) + 256) * sizeof(float) + 64;
   const void *before = accel.ptr;
   SVO_TRY(accel.reserve(accel_bytes));
   if (accel.ptr != before) sa->tables_valid = false;
   uint2 *own_grid = accel.as<uint2>();
-  float *d_table = reinterpret_cast<float *>(own_grid + own_cells);
+  float *d_table = reinterpret_cast<float *>(own_grid + own_total);
   float *alpha_lut = d_table + 3 * (kTabStride + kLdsStrideMax);
   const uint2 *d_grid = own_grid;
   const uint16_t *d_bricks = nullptr;
@@ -1159,7 +1521,7 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
                                tile_cost, tile_order, tile_cost ? n_tiles : 0, &order_done));
     if (!tables_match) build_tables_kernel<<<(int)cdiv(3 * (kTabStride + kLdsStrideMax) + 256, 256), 256, 0, stream>>>(d_table, alpha_lut, P);
   } else {
-    const int build_blocks = (int)cdiv(own_cells + 3 * (kTabStride + kLdsStrideMax) + 256, 256);
+    const int build_blocks = (int)cdiv(own_total + 3 * (kTabStride + kLdsStrideMax) + 256, 256);
     if (large) build_accel_kernel<kGridLevelLarge><<<build_blocks, 256, 0, stream>>>(d_octree, own_grid, d_table, alpha_lut, P);
     else build_accel_kernel<kGridLevelSmall><<<build_blocks, 256, 0, stream>>>(d_octree, own_grid, d_table, alpha_lut, P);
   }
@@ -1190,7 +1552,18 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
     auto launch = [&](auto kernel) {
       kernel<<<grid, kTraceThreads, (size_t)kBrickMarchLdsPad, stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps, slots);
     };
-    if (brick_shift == 0) {
+    // svoslam_config.march_ahead: < 0 = cone_trace_brick_kernel; n >= 0 = the march one sample ahead from step n + 1 on
+    const int ahead = config().march_ahead;
+    P.spec_from = ahead;
+    if (ahead >= 0) {
+      if (brick_shift == 0) {
+        if (P.lod_always) launch(cone_trace_brick_ahead_kernel<kTraceThreads, true, 0>);
+        else launch(cone_trace_brick_ahead_kernel<kTraceThreads, false, 0>);
+      } else {
+        if (P.lod_always) launch(cone_trace_brick_ahead_kernel<kTraceThreads, true, 1>);
+        else launch(cone_trace_brick_ahead_kernel<kTraceThreads, false, 1>);
+      }
+    } else if (brick_shift == 0) {
       if (P.lod_always) launch(cone_trace_brick_kernel<kTraceThreads, true, 0>);
       else launch(cone_trace_brick_kernel<kTraceThreads, false, 0>);
     } else {

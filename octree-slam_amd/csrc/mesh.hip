@@ -406,7 +406,10 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   u32 total_pieces = 0;
   SVO_HIP(hipMemcpyAsync(&total_pieces, d_total, 4, hipMemcpyDeviceToHost, stream));
   SVO_HIP(hipStreamSynchronize(stream));
-  if ((unsigned long long)total_pieces * 256ull > 0x7FFFFFFFull) return SVOSLAM_ERR_OOM;
+  if ((unsigned long long)total_pieces * 256ull > 0x7FFFFFFFull) {
+    set_last_error_text("mesh_to_voxel_grid: %u raster pieces (of 32768 candidate cells) x 256 count entries exceed 2^31 (%u scan lines)", total_pieces, total_scan);
+    return SVOSLAM_ERR_OOM;
+  }
   SVO_TRY(ws->leaf_rec0.reserve((size_t)total_pieces * 4));
   u32 *piece_map = ws->leaf_rec0.as<u32>();
   piece_map_kernel<<<cdiv(chunks, 256), 256, 0, stream>>>(piece_base, chunks, total_pieces, piece_map);
@@ -421,7 +424,10 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   SVO_HIP(hipMemcpyAsync(&total_frag, d_total, 4, hipMemcpyDeviceToHost, stream));
   SVO_HIP(hipStreamSynchronize(stream));
   if (total_frag == 0) return SVOSLAM_OK;
-  if (total_frag > 0x7FFFFFFFu) return SVOSLAM_ERR_OOM;
+  if (total_frag > 0x7FFFFFFFu) {
+    set_last_error_text("mesh_to_voxel_grid: %u (cell, triangle) fragments exceed 2^31", total_frag);
+    return SVOSLAM_ERR_OOM;
+  }
   const int nf = (int)total_frag;
   ws->mesh_fragments = nf;
   SVO_TRY(ws->keys_a.reserve((size_t)nf * 8));

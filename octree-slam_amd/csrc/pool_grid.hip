@@ -164,6 +164,29 @@ std::shared_ptr<PoolAccel> pool_accel_find(const uint32_t *d_data) {
 // outcome of the reference's walk over levels 1..G on the path of cell (xi, yi, zi) (cone_tracing_kernels.cu:76-105):
 //   all G nodes have children:  x = flag | tile index of the level-G node's children, y = its colour word
 //   first childless node at level st (1..G): x = st, y = that node's colour word
+// the same for a cell of level L <= G (xi, yi, zi: L bits each): an entry of the pyramid (pool_grid.hpp)
+__device__ inline uint2 grid_entry_level(const uint2 *__restrict__ nodes, uint32_t xi, uint32_t yi, uint32_t zi, int L) {
+  uint32_t base = 0;
+  uint2 out = make_uint2(0u, 0u);
+  for (int l = 1; l <= L; l++) {
+    const int sh = L - l;
+    const uint32_t oct = ((xi >> sh) & 1u) | (((yi >> sh) & 1u) << 1) | (((zi >> sh) & 1u) << 2);
+    const uint2 nd = nodes[base + oct];
+    if (!(nd.x & kFlag)) { out = make_uint2((uint32_t)l, nd.y); break; }
+    base = nd.x & kMask;
+    out = make_uint2(kFlag | base, nd.y);
+  }
+  return out;
+}
+// entry `e` of the pyramid (levels 1 .. G - 1, level by level)
+__device__ inline void pyramid_write(const uint2 *__restrict__ nodes, uint2 *__restrict__ grid, uint32_t e) {
+  constexpr int G = kPoolGridLevel;
+  int l = 1;
+  while (l < G - 1 && e >= pyr_offset(l + 1)) l++;
+  const uint32_t c = e - pyr_offset(l), m = (1u << l) - 1u;
+  grid[((size_t)1 << (3 * G)) + e] = grid_entry_level(nodes, c & m, (c >> l) & m, c >> (2 * l), l);
+}
+
 __device__ inline uint2 grid_entry(const uint2 *__restrict__ nodes, uint32_t xi, uint32_t yi, uint32_t zi) {
   constexpr int G = kPoolGridLevel;
   uint32_t base = 0;
@@ -185,6 +208,7 @@ __global__ __launch_bounds__(256) void pool_grid_build_kernel(const uint32_t *__
   constexpr uint32_t kAxisMask = (1u << G) - 1u;
   const uint32_t e = blockIdx.x * 256u + threadIdx.x;
   grid[e] = grid_entry(reinterpret_cast<const uint2 *>(octree), e & kAxisMask, (e >> G) & kAxisMask, e >> (2 * G));
+  if (e < pyr_entries(G)) pyramid_write(reinterpret_cast<const uint2 *>(octree), grid, e);
   // every mark made so far is served by this build (not those of a deferred commit still running: dirty_b == nullptr)
   if (e < (uint32_t)kPoolGridDirtyWords) { dirty_a[e] = 0u; if (dirty_b) dirty_b[e] = 0u; }
   if (e == 0) { dirty_a[kPoolGridCountOffset] = 0u; if (dirty_b) dirty_b[kPoolGridCountOffset] = 0u; }
@@ -523,6 +547,22 @@ __device__ inline void pool_grid_update_blocks(const uint2 *__restrict__ nodes, 
         const uint32_t xi = (bx << S) | (c & ((1u << S) - 1u)), yi = (by << S) | ((c >> S) & ((1u << S) - 1u)), zi = (bz << S) | (c >> (2 * S));
         grid[(zi << (2 * G)) | (yi << G) | xi] = grid_entry(nodes, xi, yi, zi);
       }
+      // the pyramid's cells inside the block (levels B + 1 .. G - 1), the block's own and its ancestors' (levels B .. 1)
+      for (uint32_t c = threadIdx.x; c < (uint32_t)B + pyr_offset(S); c += blockDim.x) {
+        int l; uint32_t xi, yi, zi;
+        if (c < (uint32_t)B) {  // level B - c: the block (c = 0) and its ancestors
+          l = B - (int)c;
+          xi = bx >> c; yi = by >> c; zi = bz >> c;
+        } else {                // level B + d, 1 <= d < S: cell q of the 8^d inside the block
+          const uint32_t r = c - (uint32_t)B;   // 0 .. 8 + 64 + ... - 1
+          int d = 1;
+          while (r >= pyr_offset(d + 1)) d++;
+          const uint32_t q = r - pyr_offset(d), m = (1u << d) - 1u;
+          l = B + d;
+          xi = (bx << d) | (q & m); yi = (by << d) | ((q >> d) & m); zi = (bz << d) | (q >> (2 * d));
+        }
+        grid[((size_t)1 << (3 * G)) + pyr_offset(l) + ((zi << (2 * l)) | (yi << l) | xi)] = grid_entry_level(nodes, xi, yi, zi, l);
+      }
       if (threadIdx.x == 0) atomicAnd(&dirty[b >> 5], ~(1u << (b & 31u)));
     }
   }
@@ -617,7 +657,7 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
   // true are one step for every other host thread
   std::lock_guard<std::mutex> lock(g_mu);
   if (!pa->grid.ptr) {
-    SVO_TRY(pa->grid.reserve(kCells * sizeof(uint2)));
+    SVO_TRY(pa->grid.reserve((kCells + pyr_entries(kPoolGridLevel)) * sizeof(uint2)));   // the level-8 grid, then the pyramid of levels 1 .. 7
     pa->valid = false;
   }
   if (!ensure_dirty_states(pa)) return SVOSLAM_ERR_HIP;

@@ -27,6 +27,18 @@
 namespace svoslam {
 
 constexpr int kPoolGridLevel = 8;                          // (2^8)^3 cells x 8 B = 134 MB per pool that is rendered
+// The grid PYRAMID (round 6): behind the level-G grid, the same kind of entry for the cells of levels 1 .. G - 1 (8 + 64 + ... + 8^(G-1)
+// = 2.4 M entries, 19 MB): a sample whose cone LOD is COARSER than the grid level -- a ray far from a small root cube: every view of a
+// mesh from outside (configs 2 and 5) -- ends the reference's walk at the LOD level on a node WITH children, whose alpha only the tree
+// knew: LOD dependent loads from the root per step (cfg2's side view: 1.9 us per step of its longest rays).  Now ONE load:
+//   entry of a level-l cell = (first childless node on the path at level st <= l: st, its colour word) or
+//                             (flag | children tile of the level-l node, the level-l node's colour word).
+// Kept current with the grid: every dirty level-5 block rewrites its cells of levels 6 .. G - 1, its own and its four ancestors'
+// entries (the colour word of a node with children changes with anything below it; several blocks write an ancestor the same value).
+__host__ __device__ constexpr uint32_t pyr_offset(int l) { return ((1u << (3 * l)) - 8u) / 7u; }   // entries of levels 1 .. l - 1
+__host__ __device__ constexpr uint32_t pyr_entries(int g) { return pyr_offset(g); }                  // levels 1 .. g - 1
+// the same for a run-time level 1 <= l <= 10: bits 3, 6, ..., 3 (l - 1) of 0b...001001001000
+__device__ __forceinline__ uint32_t pyr_offset_rt(int l) { return 0x09249248u & ((1u << (3 * l)) - 1u); }
 constexpr int kPoolGridBlockLevel = 5;                     // dirty tracking granularity: (2^5)^3 = 32768 blocks of 8^3 cells
 constexpr int kPoolGridBlocks = 1 << (3 * kPoolGridBlockLevel);
 constexpr int kPoolGridDirtyWords = kPoolGridBlocks / 32;  // 4 KB bitmap

@@ -150,3 +150,42 @@ def test_render_megapixel_uses_the_level8_grid(env, oracle):
     view = oracle.look_at((0.5, 1.0, -11.0), (0, 0, 0), (0, 1, 0))
     render_both(pkg, torch, oracle, pool, opool.words(), 960, 1100, view, center, edge, 0)
 
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_render_from_far_outside_a_small_root_uses_the_grid_pyramid(env, oracle, mode):
+    """the eye 3 .. 8 half-edges outside a SMALL root cube whose content reaches its faces (a mesh seen from
+    outside, configs 2 and 5): the cone LOD is coarser than the level grid for most of the way (LODs 3 .. 7), samples beyond the
+    cube clamp into boundary cells (Q11) and rays run on to MAX_RANGE = 33 half-edges.  Every such sample is answered by the grid's
+    pyramid (pool_grid.hpp) -- images and step / level counters byte-equal to the oracle, for a pool of this library (full build,
+    then block-wise updates after more fusions through the asynchronous path) and for foreign node memory (grid built per render)."""
+    pkg, torch = env
+    center, edge, depth = (0.05, -0.02, 0.01), 0.3, 10
+    rng = np.random.default_rng(11)
+    ws, pool, opool = pkg.Workspace(), pkg.Pool(), oracle.Pool()
+    c = np.asarray(center, np.float32)
+    views = [oracle.look_at(tuple(c + np.asarray(o, np.float32) * np.float32(edge)), tuple(c), (0, 1, 0))
+             for o in ((3.1, 0.2, 0.4), (-2.2, 0.1, 0.3), (4.5, 3.0, -5.5))]
+    for frame in range(3):
+        pts, col = surface_cloud(rng, 9000)
+        pts = (pts * np.float32(edge / 0.85) + c).astype(np.float32)          # reaches (and leaves: clamped, Q11) the faces
+        pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, pool, center, edge)
+        opool.insert_cloud(pts, col, depth, center, edge)
+        words = opool.words()
+        for vi, view in enumerate(views):
+            w, h = ((96, 72), (64, 48), (40, 30))[vi]
+            render_both(pkg, torch, oracle, pool, words, w, h, view, center, edge, mode)
+    # the same nodes as memory the library does not know: the per-render grid + pyramid (level 7; level 8 for a megapixel)
+    foreign = torch.from_numpy(words.view(np.int32).copy()).cuda()
+    img = torch.zeros((72, 96, 4), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+    pkg.cone_trace_svo(img, 45.0, views[0], foreign.data_ptr(), center, edge, mode, counters=cnt)
+    ref, steps, levels = oracle.cone_trace(words, 96, 72, 45.0, views[0], center, edge, mode)
+    assert np.array_equal(img.cpu().numpy(), ref) and cnt.cpu().tolist() == [steps, levels]
+    if mode == 1:
+        return
+    big = torch.zeros((1100, 960, 4), dtype=torch.uint8, device="cuda")
+    cnt.zero_()
+    pkg.cone_trace_svo(big, 45.0, views[1], foreign.data_ptr(), center, edge, mode, counters=cnt)
+    ref, steps, levels = oracle.cone_trace(words, 960, 1100, 45.0, views[1], center, edge, mode)
+    assert np.array_equal(big.cpu().numpy(), ref) and cnt.cpu().tolist() == [steps, levels]
