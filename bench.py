@@ -126,6 +126,8 @@ def compact_line(full, details_path=None, limit=LINE_LIMIT):
             row["traffic_MB"] = r["traffic"] / 1e6
         if r.get("floor_bytes") is not None:
             row["floor_MB"] = r["floor_bytes"] / 1e6
+            if r.get("traffic_over_floor"):
+                row["traffic_over_floor"] = r["traffic_over_floor"]
         if r.get("launches_per_frame") is not None:
             row["launches"] = r["launches_per_frame"]
         return row
@@ -694,7 +696,7 @@ def main():
     stage_seq = None
     if stage_pass:
         fus = {"sort": [0.0, 0], "plan": [0.0, 0], "commit": [0.0, 0], "maps": [0.0, 0], "tracker": [0.0, 0]}
-        alg_f, marches_seq = [], []
+        alg_f, marches_seq, floors_f = [], [], []
         lo = torch.tensor(center, device="cuda", dtype=torch.float32) - edge
         for k in range(total, total + extra):
             torch.cuda.synchronize()
@@ -721,6 +723,19 @@ def main():
                 cell = torch.clamp(((q - lo) / (2 * edge / (1 << l))).floor().long(), 0, (1 << l) - 1)
                 U.append(int(torch.unique((cell[:, 0] << 40) | (cell[:, 1] << 20) | cell[:, 2]).numel()))
             alg_f.append(V * 15.0 + V * 4.0 * max_depth + U[-1] * 8.0 + splits * 72.0 + 36.0 * sum(U[:-1]))
+            # ---- sector floor of THIS build's fusion: the distinct 64-byte sectors its kernels must move, from the
+            # frame's own counts.  A tile of eight sibling nodes IS one 64-byte sector (node index = 8 x tile), T_l = U_(l-1) distinct
+            # tiles hold the touched nodes of level l (U_0 = 1).  Streams are dense (n = width x height lanes of 8-byte packed keys).
+            n_px = width * height
+            tiles = [1] + U[:-1]                      # T_1 .. T_D
+            key_bits = 3 * max_depth + 1
+            digit = 11 if n_px <= (4 << 20) else 9   # radix_packed_digit_bits_for
+            passes = -(-key_bits // digit)
+            floors_f.append({
+                "front": 2.0 * n_px + 8.0 * n_px,                               # depth in, packed keys out
+                "sort": passes * 24.0 * n_px,                                    # per pass: keys read by the count, read + written by the scatter
+                "plan": 16.0 * n_px + 64.0 * sum(tiles) + 12.0 * splits,        # keys read by count and emit, one walk's tiles, the split records
+                "commit": 128.0 * splits + 11.0 * n_px + 128.0 * sum(tiles)})   # new tile + parent's sector per split; keys + colours in; every touched tile read + written once (leaf blend, mip)
         fuse_ms = sum(fus[nm][0] for nm in ("sort", "plan", "commit")) / extra
         fuse_alg = sum(alg_f) / len(alg_f)
         roofs.append(roof("fusion", "keys_packed + packed sort (12 launches) + plan (3) + split_all + fill_mip_local + mip_straddle",
@@ -728,6 +743,23 @@ def main():
                           "floors, not bandwidth"))
         roofs[-1]["timed"] = "sequential pass over %d frames after the timed region (sum of the event-bracketed launch groups)" % extra
         roofs[-1]["parts_ms"] = {nm: fus[nm][0] / extra for nm in ("sort", "plan", "commit")}
+        fl = {k: sum(f[k] for f in floors_f) / len(floors_f) for k in floors_f[0]}
+        roofs[-1]["floor_bytes"] = sum(fl.values())
+        roofs[-1]["floor_parts"] = fl
+        roofs[-1]["floor_is"] = ("distinct 64-byte sectors this build's fusion kernels must move, from the frame's own counts: front 10 n; sort passes x 24 n; "
+                                 "plan 16 n + 64 sum_l T_l + 12 K; commit 128 K + 11 n + 128 sum_l T_l (n pixels, T_l = U_(l-1) touched tiles of level l, "
+                                 "K splits); traffic_over_floor = counter traffic of the group's kernels over it")
+        try:   # counter traffic per kernel group (profiles/pmc_traffic.json), against its floor
+            with open(traffic_file) as f:
+                kern = json.load(f)[args.workload]["stages"]["fusion"]["kernels"]
+            grp = {"front": ("keys_packed",), "sort": ("packed_",), "plan": ("plan_",), "commit": ("split_", "fill_", "mip_")}
+            tr_g = {g: sum(v["calls_per_frame"] * (2.0 * v["fetch_kb"] + v["write_kb"]) * 1024.0 for k, v in kern.items() if k.startswith(pre))
+                    for g, pre in grp.items()}
+            roofs[-1]["traffic_parts"] = tr_g
+            roofs[-1]["traffic_over_floor"] = {g: tr_g[g] / fl[g] for g in fl}
+            roofs[-1]["traffic_over_floor"]["all"] = sum(tr_g.values()) / sum(fl.values())
+        except (OSError, KeyError, ValueError, TypeError, ZeroDivisionError):
+            pass
         stage_seq = {"maps_ms": fus["maps"][0] / extra, "tracker_ms": fus["tracker"][0] / extra, "fuse_sort_ms": fus["sort"][0] / extra, "fuse_plan_ms": fus["plan"][0] / extra,
                      "fuse_commit_ms": fus["commit"][0] / extra, "march_ms": sum(marches_seq) / extra,
                      "note": "stages one after the other on an otherwise idle GPU, frames %d..%d" % (total, total + extra - 1)}

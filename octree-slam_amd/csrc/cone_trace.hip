@@ -23,6 +23,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "config.hpp"
@@ -190,6 +191,7 @@ __device__ inline void build_table_entry(int e, float *__restrict__ table, float
   e -= 3 * (kTabStride + kLdsStrideMax);
   // (float)alpha / 127.0f of :110-112 for alpha = A - 127 in [-127, 128]: 256 IEEE quotients, computed once
   if (e < 256) alpha_lut[e] = (float)(e - 127) / 127.0f;
+  else if (e < 256 + 4) alpha_lut[e] = 0.0f;   // sixteen zero bytes: the "no brick" entry of cone_trace_brick_ahead_kernel
 }
 
 template <int GRID>
@@ -1028,18 +1030,25 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
   if (slots) count_steps(slots, counters, my_steps, my_levels, lane);
 }
 
-// ---- the same march, one sample AHEAD (round 6) ---------------------------------------------------------
+// ---- the same march in BURSTS of speculated samples (round 6) ------------------------------------------------
 // What binds cone_trace_brick_kernel in the tail of a render is not what it issues but the round trip of a step's two entries: a
 // wavefront alone on its SIMD parks ~680 of a step's ~1100 cycles at s_waitcnt (profiles/r05_march_sq_counters_cfg3.txt), and the
 // render ends when its longest ray does (394 steps at cfg3, 768 in config 2's side view).  77 % of a long ray's steps end on the
-// same level as the step before (profiles/HISTORY_r01_r03.md).  So each step, BEFORE it waits for its own entries, advances the
-// ray by the previous step's level -- the reference's own arithmetic (:126-131), same operands, same bits -- and requests the
-// entries of the sample that advance leads to.  When the step's level turns out to be the predicted one (`hit`), the next step
-// finds its position, LOD and entries already there: its round trip has overlapped this step's; otherwise the advance is redone
-// with the right level and the entries are requested again, which is cone_trace_brick_kernel's step.  No result depends on the
-// prediction: a hit IS the advance the unpredicted code performs.  The loop is unrolled by two with the two sample records
-// swapping roles -- a copy of the prefetched entries into the "current" registers would be a use, and wait for them.
-// spec_from: steps before this one run unpredicted (the chip is full then and bound by issue, not latency).
+// same level as the step before (profiles/HISTORY_r01_r03.md).  So, past the first `spec_from` steps, an iteration of the loop places
+// B samples at once: the current one and B - 1 further ones reached by advancing with the PREVIOUS step's level -- the reference's own
+// arithmetic (:126-131) on the same operands, hence the same bits whenever that level is the one the step then finds -- and requests
+// the entries of all of them back to back: B round trips overlap.  The samples are answered in order; a lane follows the chain as
+// long as each step ends on the predicted level (`hit`) and otherwise advances by the level it found and starts the next iteration
+// from there.  No result depends on the prediction: a hit IS the advance the unpredicted code performs; a miss discards samples
+// nobody has counted.  Lanes of a wavefront fall out of step with each other (each counts its own), which costs issue slots while
+// the chip is full -- hence bursts of one sample (the plain march) for the first spec_from steps.
+// (Round 6, built first and dropped: one sample ahead with the prefetched entries carried across the loop's back edge.  The
+// registers of in-flight loads are then free for the step's temporaries, the compiler orders every such write behind the loads it
+// still counts, and merges of paths with different numbers of loads in flight end in s_waitcnt vmcnt(0): no overlap left.  Here
+// every load is issued and consumed inside one iteration.)
+#ifndef SVO_AHEAD_WAVES
+#define SVO_AHEAD_WAVES 4
+#endif
 struct MarchSample {
   float rx, ry, rz, len;   // the ray to this sample and its length
   float tx, ty, tz;        // the sample
@@ -1047,11 +1056,11 @@ struct MarchSample {
   int lod;
   uint32_t lod_ok;
   uint2 gq;                // requested: its level-grid (or pyramid) entry
-  uint32_t e, have_e;      // ... and its brick entry (have_e = 0: not requested, the ray was not among nodes)
+  uint32_t e, have_e;      // ... and its brick entry (have_e = 0: not requested, the wavefront was not among nodes)
 };
 
-template <int THREADS, bool LOD_ALWAYS, int S>
-__global__ __launch_bounds__(THREADS, 4) void cone_trace_brick_ahead_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
+template <int THREADS, bool LOD_ALWAYS, int S, int B>
+__global__ __launch_bounds__(THREADS, SVO_AHEAD_WAVES) void cone_trace_brick_ahead_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
                                                                          const uint2 *__restrict__ grid, const uint16_t *__restrict__ bricks,
                                                                          const float *__restrict__ table, const float *__restrict__ alpha_lut_g,
                                                                          TraceParams P, unsigned long long *__restrict__ counters,
@@ -1102,6 +1111,7 @@ __global__ __launch_bounds__(THREADS, 4) void cone_trace_brick_ahead_kernel(ucha
     const float ts11 = ldexpf(P.size, -LDSD);
     const float ts12 = ldexpf(P.size, -LDSD - 1);
     const float inv_cell_fine = S == 0 ? P.inv_cell_lds : P.inv_cell_lds * 2.0f;
+    const char *zero_entry = reinterpret_cast<const char *>(alpha_lut_g + 256);
     // position, guessed cell and LOD of the sample at the end of q's ray
     auto place = [&](MarchSample &q) {
       q.tx = P.origin[0] + q.rx; q.ty = P.origin[1] + q.ry; q.tz = P.origin[2] + q.rz;
@@ -1114,7 +1124,8 @@ __global__ __launch_bounds__(THREADS, 4) void cone_trace_brick_ahead_kernel(ucha
       q.lod_ok = (LOD_ALWAYS || ub - P.lod_first <= P.lod_span) ? 1u : 0u;
     };
     // its two entries, from the guessed cell.  with_brick (wavefront-uniform): some ray of the wavefront is among nodes; the brick
-    // load is issued either way (from the field's first entry when not wanted) so that the number of loads in flight is static
+    // load is issued either way (from sixteen zero bytes behind the alpha table when not wanted: entry 0 = "no brick, ask the level
+    // grid") and its value taken as is, so that the number of loads in flight at every later wait is known to the compiler
     auto request = [&](MarchSample &q, bool with_brick) {
       const uint32_t gx = (uint32_t)(q.fx >> S), gy = (uint32_t)(q.fy >> S), gz = (uint32_t)(q.fz >> S);
       const bool coarse = (uint32_t)(q.lod - 1) < (uint32_t)(GRID - 1);
@@ -1122,16 +1133,15 @@ __global__ __launch_bounds__(THREADS, 4) void cone_trace_brick_ahead_kernel(ucha
                          : ((gz >> (LDSD - GRID)) << (2 * GRID)) | ((gy >> (LDSD - GRID)) << GRID) | (gx >> (LDSD - GRID))];
       uint32_t x = (uint32_t)q.fx, y = (uint32_t)q.fy, z = (uint32_t)q.fz;
       bool use = with_brick;
-      if (S > 0) {  // the window: cells outside it have no entry (0 = "ask the level grid")
+      if (S > 0) {  // the window: cells outside it have no entry
         x -= kOrg; y -= kOrg; z -= kOrg;
         const bool inwin = (x | y | z) < kBrickWindowCells;
         use = use && inwin;
         x = inwin ? x : 0u; y = inwin ? y : 0u; z = inwin ? z : 0u;
       }
       const uint32_t d = spread[x] | spread[kCells + y] | spread[2 * kCells + z];
-      const size_t off = use ? (((size_t)d << 2) | ((x & 1u) << 1)) : (size_t)0;
-      const uint32_t v = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(bricks) + off);
-      q.e = use ? v : 0u;
+      const char *at = use ? reinterpret_cast<const char *>(bricks) + (((size_t)d << 2) | ((x & 1u) << 1)) : zero_entry;
+      q.e = *reinterpret_cast<const uint16_t *>(at);
       q.have_e = with_brick ? 1u : 0u;
     };
     auto brick_entry = [&](uint32_t x, uint32_t y, uint32_t z) -> uint32_t {
@@ -1164,41 +1174,23 @@ __global__ __launch_bounds__(THREADS, 4) void cone_trace_brick_ahead_kernel(ucha
       return by_brick || by_grid;
     };
     uint32_t retired = 0, prev_gx = 0;
-    int dprev = 1 << 20;              // the previous step's level (none yet: predicts nothing)
-    float last_tx = 0.0f, last_ty = 0.0f, last_tz = 0.0f, ray_len = 0.0f;   // the last sample and the length after its advance
-    int last_lod = 0;
-    // one step: `cur` is the sample (placed, its entries requested); `nxt` becomes the next one.  Returns true when the ray is done.
-    auto step = [&](MarchSample &cur, MarchSample &nxt) -> bool {
-      my_steps++;
-      const bool spec_on = (int)__builtin_amdgcn_readfirstlane((int)my_steps) > P.spec_from;
-      float inv_len = __builtin_amdgcn_rcpf(cur.len);
-      inv_len = fmaf(fmaf(-cur.len, inv_len, 1.0f), inv_len, inv_len);
-      const int gx = cur.fx >> S, gy = cur.fy >> S, gz = cur.fz >> S;
-      const float tx = cur.tx, ty = cur.ty, tz = cur.tz;
+    // what one sample's entries say (cone_trace_brick_kernel's step between its request and its advance): the level the walk ends
+    // on (as the reference counts it: before the clip at 0), `retired`, the step length, and the LOD it was evaluated with
+    auto answer = [&](const MarchSample &q, float &new_dist, bool &full_form, int &lod_used) -> int {
+      const int gx = q.fx >> S, gy = q.fy >> S, gz = q.fz >> S;
+      const float tx = q.tx, ty = q.ty, tz = q.tz;
       const float ax = lds_tab[gx + 1], bx = lds_tab[gx + 2];
       const float ay = lds_tab[kLdsStride + gy + 1], by = lds_tab[kLdsStride + gy + 2];
       const float az = lds_tab[2 * kLdsStride + gz + 1], bz = lds_tab[2 * kLdsStride + gz + 2];
       bool conf = (((int)(ax < tx) & (int)!(bx < tx)) & ((int)(ay < ty) & (int)!(by < ty)) & ((int)(az < tz) & (int)!(bz < tz))) != 0;
-      const bool coarse = (uint32_t)(cur.lod - 1) < (uint32_t)(GRID - 1);
-      // ---- one sample ahead: the advance by the previous step's level, its sample, its entries ----
-      if (spec_on) {
-        const float nd = ldexpf(P.size, -dprev);
-        const float sp = div_rn_midrange_r(cur.len + nd, cur.len, inv_len);
-        nxt.rx = cur.rx * sp; nxt.ry = cur.ry * sp; nxt.rz = cur.rz * sp;
-        nxt.len = sqrt_rn_midrange(dot3(nxt.rx, nxt.ry, nxt.rz, nxt.rx, nxt.ry, nxt.rz));
-        place(nxt);
-        request(nxt, __any((prev_gx & kFlag) != 0u));
-      }
-      // ---- this sample's answers (the loads above stay in flight) ----
-      const int lod = cur.lod;
-      const bool lod_ok = LOD_ALWAYS || cur.lod_ok != 0u;
-      uint2 gq = cur.gq;
-      uint32_t e = cur.e;
+      const int lod = q.lod;
+      const bool lod_ok = LOD_ALWAYS || q.lod_ok != 0u;
+      const bool coarse = (uint32_t)(lod - 1) < (uint32_t)(GRID - 1);
+      const uint2 gq = q.gq;
+      const uint32_t e = q.e;
       prev_gx = coarse ? 0u : gq.x;
-      {  // the step that enters a level-8 node with children without a brick entry requested
-        const bool need = cur.have_e == 0u && (gq.x & kFlag) != 0u && lod > GRID && !coarse;
-        if (__any(need)) { if (need) e = brick_entry((uint32_t)cur.fx, (uint32_t)cur.fy, (uint32_t)cur.fz); }
-      }
+      // the step that enters a level-8 node with children without a brick entry requested: a second round trip, on the rare path
+      const bool need = q.have_e == 0u && (gq.x & kFlag) != 0u && lod > GRID && !coarse;
       uint32_t oct12 = 0;
       if (S > 0 || __any(lod >= BL)) {
         float cx = (gx & 1) ? ax : bx, cy = (gy & 1) ? ay : by, cz = (gz & 1) ? az : bz;
@@ -1209,7 +1201,7 @@ __global__ __launch_bounds__(THREADS, 4) void cone_trace_brick_ahead_kernel(ucha
         if (S == 0) {
           oct12 = hx | (hy << 1) | (hz << 2);
         } else {
-          conf = conf && (((hx ^ (uint32_t)cur.fx) | (hy ^ (uint32_t)cur.fy) | (hz ^ (uint32_t)cur.fz)) & 1u) == 0u;
+          conf = conf && (((hx ^ (uint32_t)q.fx) | (hy ^ (uint32_t)q.fy) | (hz ^ (uint32_t)q.fz)) & 1u) == 0u;
           if (__any(lod >= BL)) {
             cx += ts12 * (hx ? 1.0f : -1.0f);
             cy += ts12 * (hy ? 1.0f : -1.0f);
@@ -1219,20 +1211,21 @@ __global__ __launch_bounds__(THREADS, 4) void cone_trace_brick_ahead_kernel(ucha
         }
       }
       int depth;
-      const bool decided = decode(e, gq, lod, oct12, depth, retired);
-      float new_dist = ldexpf(P.size, -depth);
-      bool full_form = false;
-      int lod_last = lod;
+      const bool decided = decode(e, gq, lod, oct12, depth, retired) && !need;
+      new_dist = ldexpf(P.size, -depth);
+      full_form = false;
+      lod_used = lod;
       if (__builtin_expect(__any(!(decided && conf && lod_ok)), 0)) {
         if (!(decided && conf && lod_ok)) {
-          // the rare sample (cone_trace_brick_kernel's, word for word)
+          // the rare sample (cone_trace_brick_kernel's, word for word, plus the second trip above)
           int lod2 = lod;
-          if (!lod_ok) lod2 = step_lod(P.size, cur.len * P.pix_scale);
-          lod_last = lod2;
+          if (!lod_ok) lod2 = step_lod(P.size, q.len * P.pix_scale);
+          lod_used = lod2;
           bool ok = true;
           uint32_t xb = (uint32_t)gx, yb = (uint32_t)gy, zb = (uint32_t)gz;
           uint32_t e2 = e;
           uint2 g2 = gq;
+          if (need && conf) e2 = brick_entry((uint32_t)q.fx, (uint32_t)q.fy, (uint32_t)q.fz);
           if (!conf) {
             xb = axis_bits_lds<LDSD>(tx, P.lo[0], P.inv_cell_lds, lds_tab, ok);
             yb = axis_bits_lds<LDSD>(ty, P.lo[1], P.inv_cell_lds, lds_tab + kLdsStride, ok);
@@ -1272,43 +1265,72 @@ __global__ __launch_bounds__(THREADS, 4) void cone_trace_brick_ahead_kernel(ucha
           }
           new_dist = (depth >= -100 && depth <= 100) ? ldexpf(P.size, -depth) : P.size / ldexpf(1.0f, depth);
           full_form = depth < -60;
+          // every load of this block has landed before it is left: one whose result a path does not consume (a short-circuited
+          // decode) would stay "in flight" in the compiler's book-keeping and turn later waits into vmcnt(0)
+          __builtin_amdgcn_s_waitcnt(0x0F70);
         }
       }
-      my_levels += (uint32_t)(depth > 0 ? depth : 0);
-      // ---- the advance (:126-131): already there when the level is the predicted one ----
-      const bool hit = spec_on && depth == dprev && !full_form;
-      dprev = depth;
-      if (__any(!hit)) {
-        if (!hit) {
-          float s = div_rn_midrange_r(cur.len + new_dist, cur.len, inv_len);
-          if (full_form) s = (cur.len + new_dist) / cur.len;
-          nxt.rx = cur.rx * s; nxt.ry = cur.ry * s; nxt.rz = cur.rz * s;
-          nxt.len = full_form ? length3(nxt.rx, nxt.ry, nxt.rz) : sqrt_rn_midrange(dot3(nxt.rx, nxt.ry, nxt.rz, nxt.rx, nxt.ry, nxt.rz));
-        }
-      }
-      if (retired != 0u || nxt.len > kMaxRange || my_steps >= (uint32_t)kMaxSteps) {
-        last_tx = tx; last_ty = ty; last_tz = tz; last_lod = lod_last; ray_len = nxt.len;
-        return true;
-      }
-      const bool with_brick = __any((prev_gx & kFlag) != 0u);
-      if (__any(!hit)) {
-        if (!hit) {
-          place(nxt);
-          request(nxt, with_brick);
-        }
-      }
-      return false;
+      return depth;
     };
-    MarchSample A, B;
-    A.rx = kStartDist * (dx * inv); A.ry = kStartDist * (dy * inv); A.rz = kStartDist * (dz * inv);
-    A.len = length3(A.rx, A.ry, A.rz);
-    place(A);
-    request(A, false);
-    B = A;
-    for (;;) {
-      if (step(A, B)) break;
-      if (step(B, A)) break;
-    }
+    float rx = kStartDist * (dx * inv), ry = kStartDist * (dy * inv), rz = kStartDist * (dz * inv);
+    float ray_len = length3(rx, ry, rz);
+    int dprev = 1 << 20;              // the previous step's level (none yet: nothing to predict with)
+    float last_tx = 0.0f, last_ty = 0.0f, last_tz = 0.0f;   // the last sample, for the pixel
+    int last_lod = 0;
+    // one iteration = a burst of N samples; returns true when the ray is done (`rx.. ray_len` = the advance past its last sample)
+    auto burst = [&](auto n_tag) -> bool {
+      constexpr int N = decltype(n_tag)::value;
+      MarchSample q[N];
+      const bool with_brick = __any((prev_gx & kFlag) != 0u);
+      q[0].rx = rx; q[0].ry = ry; q[0].rz = rz; q[0].len = ray_len;
+      place(q[0]);
+      request(q[0], with_brick);
+      if (N > 1) {
+        const float nd = ldexpf(P.size, -dprev);
+#pragma unroll
+        for (int j = 1; j < N; j++) {
+          float il = __builtin_amdgcn_rcpf(q[j - 1].len);
+          il = fmaf(fmaf(-q[j - 1].len, il, 1.0f), il, il);
+          const float sp = div_rn_midrange_r(q[j - 1].len + nd, q[j - 1].len, il);
+          q[j].rx = q[j - 1].rx * sp; q[j].ry = q[j - 1].ry * sp; q[j].rz = q[j - 1].rz * sp;
+          q[j].len = sqrt_rn_midrange(dot3(q[j].rx, q[j].ry, q[j].rz, q[j].rx, q[j].ry, q[j].rz));
+          place(q[j]);
+          request(q[j], with_brick);
+        }
+      }
+      bool done = false, chain = true;
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        if (chain) {
+          my_steps++;
+          float new_dist; bool full_form; int lod_used;
+          const int depth = answer(q[j], new_dist, full_form, lod_used);
+          my_levels += (uint32_t)(depth > 0 ? depth : 0);
+          const bool hit = j + 1 < N && depth == dprev && !full_form;
+          dprev = depth;
+          if (hit) {   // the next sample of the chain IS this advance
+            rx = q[j + 1 < N ? j + 1 : j].rx; ry = q[j + 1 < N ? j + 1 : j].ry; rz = q[j + 1 < N ? j + 1 : j].rz; ray_len = q[j + 1 < N ? j + 1 : j].len;
+          } else {     // (:126-131)
+            float il = __builtin_amdgcn_rcpf(q[j].len);
+            il = fmaf(fmaf(-q[j].len, il, 1.0f), il, il);
+            float s = div_rn_midrange_r(q[j].len + new_dist, q[j].len, il);
+            if (full_form) s = (q[j].len + new_dist) / q[j].len;
+            rx = q[j].rx * s; ry = q[j].ry * s; rz = q[j].rz * s;
+            ray_len = full_form ? length3(rx, ry, rz) : sqrt_rn_midrange(dot3(rx, ry, rz, rx, ry, rz));
+          }
+          last_tx = q[j].tx; last_ty = q[j].ty; last_tz = q[j].tz; last_lod = lod_used;
+          if (retired != 0u || ray_len > kMaxRange || my_steps >= (uint32_t)kMaxSteps) { done = true; chain = false; }
+          else if (!hit) chain = false;
+        }
+      }
+      // (entries of samples nobody answered: landed before the registers are reused -- they were requested with the first ones)
+      if (N > 1) __builtin_amdgcn_s_waitcnt(0x0F70);
+      return done;
+    };
+    bool done = false;
+    // the first spec_from steps one sample at a time (every lane of the wavefront on the same step: the chip is full, issue binds)
+    while (!done && (int)my_steps < P.spec_from) done = burst(std::integral_constant<int, 1>{});
+    while (!done) done = burst(std::integral_constant<int, B>{});
     const bool range_exit = retired == 0u && ray_len > kMaxRange;
     uint32_t w_last;
     {
@@ -1361,6 +1383,10 @@ __global__ __launch_bounds__(THREADS, 4) void cone_trace_brick_ahead_kernel(ucha
 // four wavefronts per SIMD instead of six and the short tiles fill in behind them: 640x480 in the loop 2505 / 2523 -> 2547..2585
 // frames/s (2358 -> 2563 on a box in a slower state), 1080p 925 / 939 -> 940..958; either change alone gives nothing or loses
 // (profiles/r05_march_occupancy.txt; one workgroup per CU: 2000).
+#ifndef SVO_AHEAD_BURST
+#define SVO_AHEAD_BURST 2
+#endif
+constexpr int kAheadBurst = SVO_AHEAD_BURST;   // samples per iteration of cone_trace_brick_ahead_kernel past spec_from
 constexpr int kBrickMarchLdsPad = 6144;
 constexpr int kBrickMarchStaticLds = 1024 + 4 * (3 * lds_stride(11) + 3 * lds_cells(11));  // alpha_lut + lds_tab of cone_trace_brick_kernel
 static_assert(3 * (kBrickMarchStaticLds + kBrickMarchLdsPad) > 160 * 1024 && 2 * (kBrickMarchStaticLds + kBrickMarchLdsPad) <= 160 * 1024 &&
@@ -1485,7 +1511,7 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   const bool large = pa != nullptr || (long long)width * rows >= (1ll << 20);  // e.g. 1920x1080 frames
   const int own_cells = pa ? 0 : grid_entries(large ? kGridLevelLarge : kGridLevelSmall);
   const int own_total = pa ? 0 : own_cells + (int)pyr_entries(large ? kGridLevelLarge : kGridLevelSmall);  // the grid, then its pyramid (pool_grid.hpp)
-  const size_t accel_bytes = (size_t)own_total * sizeof(uint2) + (size_t)(3 * (kTabStride + kLdsStrideMax) + 256) * sizeof(float) + 64;
+  const size_t accel_bytes = (size_t)own_total * sizeof(uint2) + (size_t)(3 * (kTabStride + kLdsStrideMax) + 256 + 4) * sizeof(float) + 64;
   const void *before = accel.ptr;
   SVO_TRY(accel.reserve(accel_bytes));
   if (accel.ptr != before) sa->tables_valid = false;
@@ -1519,9 +1545,9 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   if (pa) {
     SVO_TRY(pool_accel_refresh(pa, d_octree, stream, &d_grid, (mode & 0xFF) == SVOSLAM_RENDER_REFERENCE, &d_bricks, &brick_shift,
                                tile_cost, tile_order, tile_cost ? n_tiles : 0, &order_done));
-    if (!tables_match) build_tables_kernel<<<(int)cdiv(3 * (kTabStride + kLdsStrideMax) + 256, 256), 256, 0, stream>>>(d_table, alpha_lut, P);
+    if (!tables_match) build_tables_kernel<<<(int)cdiv(3 * (kTabStride + kLdsStrideMax) + 256 + 4, 256), 256, 0, stream>>>(d_table, alpha_lut, P);
   } else {
-    const int build_blocks = (int)cdiv(own_total + 3 * (kTabStride + kLdsStrideMax) + 256, 256);
+    const int build_blocks = (int)cdiv(own_total + 3 * (kTabStride + kLdsStrideMax) + 256 + 4, 256);
     if (large) build_accel_kernel<kGridLevelLarge><<<build_blocks, 256, 0, stream>>>(d_octree, own_grid, d_table, alpha_lut, P);
     else build_accel_kernel<kGridLevelSmall><<<build_blocks, 256, 0, stream>>>(d_octree, own_grid, d_table, alpha_lut, P);
   }
@@ -1557,11 +1583,11 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
     P.spec_from = ahead;
     if (ahead >= 0) {
       if (brick_shift == 0) {
-        if (P.lod_always) launch(cone_trace_brick_ahead_kernel<kTraceThreads, true, 0>);
-        else launch(cone_trace_brick_ahead_kernel<kTraceThreads, false, 0>);
+        if (P.lod_always) launch(cone_trace_brick_ahead_kernel<kTraceThreads, true, 0, kAheadBurst>);
+        else launch(cone_trace_brick_ahead_kernel<kTraceThreads, false, 0, kAheadBurst>);
       } else {
-        if (P.lod_always) launch(cone_trace_brick_ahead_kernel<kTraceThreads, true, 1>);
-        else launch(cone_trace_brick_ahead_kernel<kTraceThreads, false, 1>);
+        if (P.lod_always) launch(cone_trace_brick_ahead_kernel<kTraceThreads, true, 1, kAheadBurst>);
+        else launch(cone_trace_brick_ahead_kernel<kTraceThreads, false, 1, kAheadBurst>);
       }
     } else if (brick_shift == 0) {
       if (P.lod_always) launch(cone_trace_brick_kernel<kTraceThreads, true, 0>);

@@ -124,7 +124,7 @@ def write_colonnade_obj(path, n_cols=8, length=40.0, col_radius=0.15, col_height
                         beam=0.2, slab=None, floor=None):
     """Stand-in for config 5's crytek-sponza (sponza.obj is not in the reference checkout): two rows of
     n_cols prismatic columns (quad sides, triangle-fan caps) along x, a lintel box on each row and
-    optionally a floor slab (x half-width, z half-width) or a floor QUAD (x0, x1, z0, z1) in the plane y = 0 (one face: the voxel
+    optionally a floor slab (x half-width, z half-width) or a floor of nx x nz QUADS (x0, x1, z0, z1[, nx, nz[, y]]) in a plane y = const (one face: the voxel
     grid is N cells along each axis of the mesh's own box, so a surface costs its share of that box's FACE times N^2 voxels, whatever
     its size in metres); textured ('v/vt' faces).  x is the longest axis,
     so the voxel grid edge is `length`."""
@@ -164,12 +164,13 @@ def write_colonnade_obj(path, n_cols=8, length=40.0, col_radius=0.15, col_height
         # tiles, each with its own texture coordinates: a triangle takes ONE colour, the texel at its first vertex (voxelization.cu:113-127)
         x0, x1, z0, z1 = floor[:4]
         nx, nz = (floor[4], floor[5]) if len(floor) > 4 else (1, 1)
+        fy = floor[6] if len(floor) > 6 else 0.0
         for i in range(nx):
             for j in range(nz):
                 xa, xb = x0 + (x1 - x0) * i / nx, x0 + (x1 - x0) * (i + 1) / nx
                 za, zb = z0 + (z1 - z0) * j / nz, z0 + (z1 - z0) * (j + 1) / nz
                 uv = (((i * 37 + j * 11) % 64) / 64.0 + 0.004, ((i * 13 + j * 29) % 64) / 64.0 + 0.004)
-                c = [add_v((x, 0.0, z), (uv[0] + 0.003 * k, uv[1] + 0.002 * k)) for k, (x, z) in enumerate(((xa, za), (xa, zb), (xb, zb), (xb, za)))]
+                c = [add_v((x, fy, z), (uv[0] + 0.003 * k, uv[1] + 0.002 * k)) for k, (x, z) in enumerate(((xa, za), (xa, zb), (xb, zb), (xb, za)))]
                 faces.append((c[0], c[1], c[2], c[3]))
     with open(path, "w") as fp:
         fp.write("# generated colonnade\n")

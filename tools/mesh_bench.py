@@ -65,7 +65,7 @@ def scene_spec(cfg, tmp, meshgen):
     # put leaf-level surfaces (cone LOD 15 / 16: within ~1.3 m of the eye at 3840x2160) over a quarter of the image.  (The voxel grid is
     # 2^16 cells along each axis of the mesh's own 40 x 5 x 6 m box: the quad is 1/20 of the box's floor = 215 M voxels of 0.6 x 0.09 mm.)
     obj = meshgen.write_colonnade_obj(os.path.join(tmp, "m.obj"), n_cols=16, length=40.0, col_radius=0.004, col_height=5.0,
-                                      segs=16, z_off=3.0, beam=0.002, floor=(-20.0, -10.0, -0.6, 0.6, 80, 10))
+                                      segs=16, z_off=3.0, beam=0.002, floor=(-20.0, -10.0, -0.6, 0.6, 80, 10, 0.37))
     return (obj, tex_path, 16, (3840, 2160), 8,
             "STAND-IN for crytek-sponza (sponza.obj is not in the reference checkout): procedural colonnade + a floor quad (tests/meshgen.py), "
             "2^16 cells per axis, depth-16 SVO, 3840x2160, whole image + 8 row bands")
@@ -78,9 +78,11 @@ def scene_views(cfg, center, size):
         return [(n, look_at(c + np.array(o) * size, c)) for n, o in (("front, outside the root cube", (0.15, 0.3, -2.6)),
                                                                       ("side, outside the root cube", (2.2, 0.1, 0.4)),
                                                                       ("close, inside", (-0.3, 0.25, 0.45)))]
-    # inside the colonnade (x along the nave, floor at y = 0 for x in [-20, -10], |z| <= 0.6; columns at z = +-3)
-    return [("nave: 0.3 m over the floor, along +x", look_at((-18.0, 0.30, 0.02), (20.0, -0.4, 0.0))),
-            ("floor from 0.5 m, diagonal", look_at((-15.0, 0.5, -0.3), (-13.6, 0.0, 0.5))),
+    # inside the colonnade (x along the nave; the floor is a platform at y = 0.37 for x in [-20, -10], |z| <= 0.6 -- NOT at y = 0: the
+    # root cube's centre is at y = 2.501, so a floor at 0 lies 1 mm under the boundary of a 2.5 m level-4 cell, every ray above it takes
+    # 1.25 m steps and jumps through it (the reference's step is half the edge of the EMPTY cell the sample is in); columns at z = +-3)
+    return [("nave: 0.3 m over the floor, along +x", look_at((-18.0, 0.67, 0.02), (20.0, -0.03, 0.0))),
+            ("floor from 0.5 m, diagonal", look_at((-15.0, 0.87, -0.3), (-13.6, 0.37, 0.5))),
             ("grazing along the z = +3 row of columns", look_at((-19.6, 1.5, 2.9), (20.0, 1.6, 3.02)))]
 
 
