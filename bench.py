@@ -676,7 +676,8 @@ def main():
 
     # which march runs: pools fused to depth <= 14 are marched over occupancy bricks in reference mode (csrc/pool_grid.hpp)
     bricks = max_depth <= 14 and args.render_mode == "reference" and cfg["march_bricks"] != 0
-    roofs = [roof("march", "cone_trace_brick_kernel" if bricks else "cone_trace_kernel", march_alg, kern_ms, 1,
+    march_kernel = ("cone_trace_brick_ahead_kernel" if cfg.get("march_ahead", -1) >= 0 else "cone_trace_brick_kernel") if bricks else "cone_trace_kernel"
+    roofs = [roof("march", march_kernel, march_alg, kern_ms, 1,
                   ("instruction issue: a step is ONE memory round trip (brick entry + level-grid entry requested together, mostly L1 / L2 "
                    "hits: counter traffic is a few percent of the algorithmic bytes) and ~160 instructions; a lone wavefront of the tail "
                    "issues them in ~0.5 us, the full chip is VALU-bound (profiles/r03_brick_march_anatomy.txt); not HBM bandwidth") if bricks else

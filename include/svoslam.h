@@ -69,9 +69,10 @@ typedef struct svoslam_config {
   int32_t runner_timeline;  /* 1: HIP-event marks at the stage boundaries (svoslam_runner_timeline); costs ~6 % */
   int32_t sort_pairs;       /* 1: force the (key, index) pair sort instead of the packed one-word sort */
   int32_t graphs;           /* 1: launch sequences recorded and replayed as HIP graphs (0: direct launches, the default) */
-  int32_t march_ahead;      /* brick march: n >= 0: from step n + 1 on every step also advances by the previous step's level and requests
-                               the next sample's entries before waiting for its own (results identical; hides the round trip in the
-                               long rays of a render); -1: the plain march */
+  int32_t march_ahead;      /* brick march: n >= 0 (default 90): past its first n steps a ray is marched in BURSTS of three samples -- the
+                               current one and two reached by advancing with the previous step's level, their entries requested
+                               together -- and follows the burst as long as each step ends on that level (results identical; overlaps
+                               the round trips of a render's long rays); -1: one sample per iteration throughout */
   int32_t reserved[4];
 } svoslam_config;
 int svoslam_config_get(svoslam_config *out);
@@ -651,8 +652,10 @@ int svoslam_runner_run(svoslam_runner *runner, const uint16_t *const *d_depths, 
  * back-project + fuse -> the map ray-cast into a depth image from the pose just tracked -> accepted as the next frame's model if
  * at least min_coverage (0..1) of its pixels met the map, else the next frame is tracked against the previous frame's maps ->
  * cone-traced view (rows of the LAST frame in d_image).  Sequential on caller_stream and BLOCKING (one 4-byte coverage readback
- * per frame); *models_used (optional) = frames whose model was accepted.  Leaves frame-to-model tracking switched on in the
- * camera.  One replica only. */
+ * per frame); *models_used (optional) = frames whose model was accepted.  Same call rules as svoslam_runner_run (one caller stream
+ * per runner, timestamps newer than the camera's latest).  Leaves frame-to-model tracking switched on in the camera and the last
+ * accepted model set, so that a second call continues the sequence as one longer call would; a later svoslam_runner_run on the
+ * same runner -- the loop without a model refresh -- clears both when it starts and tracks frame to frame.  One replica only. */
 int svoslam_runner_run_model(svoslam_runner *runner, const uint16_t *const *d_depths, const uint8_t *const *d_rgbs,
                              const long long *timestamps, const float *views, int32_t n, uint8_t *d_image, int32_t row_first,
                              int32_t rows, unsigned long long *d_steps, float min_coverage, int32_t *models_used, void *caller_stream);

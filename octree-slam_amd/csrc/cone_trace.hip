@@ -19,6 +19,8 @@
 //  (2) levels 1..7 of the walk are ONE load from a dense 128^3 grid that stores, per cell,
 //      where the reference's walk stops and the colour word it ends on ("level grid");
 //  (3) the per-step arithmetic is one division and one square root (see step_lod / loop notes).
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -148,7 +150,8 @@ struct TraceParams {
   // lookup helpers (host-computed)
   float lo[3], inv_cell, inv_cell_lds;   // guess of the table cell: (t - lo) * inv_cell
   int lds_depth;                          // levels of the LDS table (11)
-  int xcd_w, xcd_h;                       // tile -> XCD mapping (see cone_trace_kernel)
+  int xcd_w, xcd_h;                       // tile -> XCD mapping (see cone_trace_kernel); brick march: xcd_h = tiles per row
+  int pair_rows;                          // brick march: != 0 (= the number of tile rows): the two 32 x 8 strips of a tile lie half the render apart
   int lod_always;                         // brick march: pix_scale x [0.001, 11 + size] lies inside the fast LOD form's range
   uint32_t lod_first, lod_span, size_man;  // fast LOD: valid when bits(pix_size) - lod_first <= lod_span
   int size_exp;
@@ -730,9 +733,9 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
   const int tile_y = tile_id / P.xcd_h;  // (xcd_h = tiles per row)
   const int tile_x = tile_id - tile_y * P.xcd_h;
   const int px = tile_x * 32 + (int)(wave & 3u) * 8 + (int)(lane & 7u);
-  // xcd_w != 0 (= the number of tile rows): the tile's two 32 x 8 strips lie half the render apart -- wavefronts w and w + 4 share a
+  // pair_rows != 0 (= the number of tile rows): the tile's two 32 x 8 strips lie half the render apart -- wavefronts w and w + 4 share a
   // SIMD, and the long rays of a frame come in bands of rows, so a wavefront of the expensive band is paired with one of the cheap band
-  const int py = P.xcd_w ? P.row_first + (tile_y + (int)(wave >> 2) * P.xcd_w) * 8 + (int)(lane >> 3)
+  const int py = P.pair_rows ? P.row_first + (tile_y + (int)(wave >> 2) * P.pair_rows) * 8 + (int)(lane >> 3)
                          : P.row_first + tile_y * (THREADS / 32) + (int)(wave >> 2) * 8 + (int)(lane >> 3);
   uint32_t my_steps = 0, my_levels = 0;
   if (px < P.width && py < P.row_end) {
@@ -1046,8 +1049,13 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
 // registers of in-flight loads are then free for the step's temporaries, the compiler orders every such write behind the loads it
 // still counts, and merges of paths with different numbers of loads in flight end in s_waitcnt vmcnt(0): no overlap left.  Here
 // every load is issued and consumed inside one iteration.)
+// Measured (profiles/r06_march_ahead_ab.txt; same-box A/B of library variants, cfg3 300-frame map): bursts of 2 at 128 VGPRs: the
+// march 0.317 -> 0.279 ms in the loop but the FRAME slower (2410 -> 2200 frames/s: 107 VGPRs x 4 wavefronts leave a SIMD no room for
+// the tracker's); at 80 VGPRs (SVO_AHEAD_WAVES = 6: 18-30 spilled) bursts of 2 / 3 from step 90: the march 0.319 -> 0.291 ms, the
+// frame +2.2 % over 100 frames (2401 -> 2453) and +3.5 % over the driver's 20 (2073 -> 2145), three alternations; bursts from step 0
+// lose in the loop (2254) and on short renders.  Default: bursts of 3 from step 91 (svoslam_config.march_ahead = 90).
 #ifndef SVO_AHEAD_WAVES
-#define SVO_AHEAD_WAVES 4
+#define SVO_AHEAD_WAVES 6
 #endif
 struct MarchSample {
   float rx, ry, rz, len;   // the ray to this sample and its length
@@ -1091,8 +1099,8 @@ __global__ __launch_bounds__(THREADS, SVO_AHEAD_WAVES) void cone_trace_brick_ahe
   const int tile_y = tile_id / P.xcd_h;
   const int tile_x = tile_id - tile_y * P.xcd_h;
   const int px = tile_x * 32 + (int)(wave & 3u) * 8 + (int)(lane & 7u);
-  const int py = P.xcd_w ? P.row_first + (tile_y + (int)(wave >> 2) * P.xcd_w) * 8 + (int)(lane >> 3)
-                         : P.row_first + tile_y * (THREADS / 32) + (int)(wave >> 2) * 8 + (int)(lane >> 3);
+  const int py = P.pair_rows ? P.row_first + (tile_y + (int)(wave >> 2) * P.pair_rows) * 8 + (int)(lane >> 3)
+                             : P.row_first + tile_y * (THREADS / 32) + (int)(wave >> 2) * 8 + (int)(lane >> 3);
   uint32_t my_steps = 0, my_levels = 0;
   if (px < P.width && py < P.row_end) {
     const int idx = py * P.width + px;
@@ -1377,20 +1385,37 @@ __global__ __launch_bounds__(THREADS, SVO_AHEAD_WAVES) void cone_trace_brick_ahe
 // Tiles of the previous render, costliest first: tile_order_block (pool_grid.hpp), run by one extra workgroup of the refresh
 // launch that precedes the march (no launch of its own on the map stream: as one it took 15 us + a launch boundary per frame)
 // or, where no refresh is launched, by this kernel.
-// Two workgroups of the brick kernel per CU, not the three its 50 KB of tables would allow: kBrickMarchLdsPad bytes of dynamic LDS
+// Two workgroups of the brick kernel per CU, not the three its 50 KB of tables would allow: brick_march_lds_pad() bytes of dynamic LDS
 // nobody reads take the third away.  With the costliest tiles first, the long rays of a frame (640x480, 300-frame map: 12 % of the
 // rays, in 647 of 4800 wavefronts, the lower half of the image -- profiles/r05_ray_anatomy_cfg3_300frames.txt) start at t = 0 with
 // four wavefronts per SIMD instead of six and the short tiles fill in behind them: 640x480 in the loop 2505 / 2523 -> 2547..2585
 // frames/s (2358 -> 2563 on a box in a slower state), 1080p 925 / 939 -> 940..958; either change alone gives nothing or loses
 // (profiles/r05_march_occupancy.txt; one workgroup per CU: 2000).
 #ifndef SVO_AHEAD_BURST
-#define SVO_AHEAD_BURST 2
+#define SVO_AHEAD_BURST 3
 #endif
 constexpr int kAheadBurst = SVO_AHEAD_BURST;   // samples per iteration of cone_trace_brick_ahead_kernel past spec_from
-constexpr int kBrickMarchLdsPad = 6144;
 constexpr int kBrickMarchStaticLds = 1024 + 4 * (3 * lds_stride(11) + 3 * lds_cells(11));  // alpha_lut + lds_tab of cone_trace_brick_kernel
-static_assert(3 * (kBrickMarchStaticLds + kBrickMarchLdsPad) > 160 * 1024 && 2 * (kBrickMarchStaticLds + kBrickMarchLdsPad) <= 160 * 1024 &&
-              kBrickMarchStaticLds + kBrickMarchLdsPad <= 64 * 1024, "the pad must leave room for exactly two workgroups in a CU's 160 KB of LDS");
+// the pad, from the device's own LDS size (6144 bytes on gfx950's 160 KB per CU; a part with another size gets the pad
+// that leaves exactly two workgroups there, or none where two do not fit anyway)
+static int brick_march_lds_pad() {
+  static int pad = -1;
+  if (pad >= 0) return pad;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  size_t lds = 160 * 1024;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.maxSharedMemoryPerMultiProcessor > 0)
+    lds = (size_t)prop.maxSharedMemoryPerMultiProcessor;
+  else
+    (void)hipGetLastError();
+  long long p = (long long)(lds / 3) + 1 - kBrickMarchStaticLds;   // three workgroups no longer fit
+  p = p < 0 ? 0 : ((p + 255) / 256) * 256;
+  if (p > 0 && p < 6144 && 2 * (kBrickMarchStaticLds + 6144) <= (long long)lds) p = 6144;   // (the value the round-5 measurements were taken with)
+  if (2 * (kBrickMarchStaticLds + p) > (long long)lds || kBrickMarchStaticLds + p > 64 * 1024) p = 0;
+  if (getenv("SVOSLAM_DEBUG_LDS")) fprintf(stderr, "svoslam: LDS per CU %zu bytes, brick march pad %lld\n", lds, p);
+  pad = (int)p;
+  return pad;
+}
 constexpr int kPairMaxTiles = 1024;
 constexpr int kTileOrderMinTiles = 512;  // resident workgroups of the brick kernel (two per CU): smaller renders start every tile at once
 __global__ __launch_bounds__(256) void tile_order_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, int n) {
@@ -1459,7 +1484,7 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   float inv[16];
   mat4_inverse_host(view, inv);
   TraceParams P;
-  P.tile_order = nullptr; P.tile_cost = nullptr; P.spec_from = 0;
+  P.tile_order = nullptr; P.tile_cost = nullptr; P.spec_from = 0; P.pair_rows = 0;
   mat4_mul_point(inv, 0.0f, 0.0f, 0.0f, 1.0f, P.origin[0], P.origin[1], P.origin[2]);
   mat4_mul_point(inv, -1.0f, 0.0f, 0.0f, 0.0f, P.x_dir[0], P.x_dir[1], P.x_dir[2]);
   mat4_mul_point(inv, 0.0f, -1.0f, 0.0f, 0.0f, P.y_dir[0], P.y_dir[1], P.y_dir[2]);
@@ -1569,14 +1594,14 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
     // renders of up to kPairMaxTiles tiles: the two 32 x 8 strips of a tile lie half the render apart (see the kernel).  640x480 in
     // the loop 2366 -> 2498 frames/s (march alone 0.313 -> 0.297 ms); 1080p (4080 tiles, in rounds): alone 0.258 -> 0.238 but in
     // the loop 0.50 -> 0.58 ms and 954 -> 944 frames/s, so large renders keep their strips together (profiles/r05_march_occupancy.txt)
-    P.xcd_w = n_tiles <= kPairMaxTiles ? (int)cdiv(rows, kTraceThreads / 32) : 0; P.xcd_h = (int)cdiv(width, 32);
+    P.pair_rows = n_tiles <= kPairMaxTiles ? (int)cdiv(rows, kTraceThreads / 32) : 0; P.xcd_w = 0; P.xcd_h = (int)cdiv(width, 32);
     const dim3 grid((unsigned)(cdiv(width, 32) * cdiv(rows, kTraceThreads / 32)));
     if (tile_cost) {
       if (!order_done) tile_order_kernel<<<1, 256, 0, stream>>>(tile_cost, tile_order, n_tiles);  // (the refresh was a full build)
       P.tile_cost = tile_cost; P.tile_order = tile_order;
     }
     auto launch = [&](auto kernel) {
-      kernel<<<grid, kTraceThreads, (size_t)kBrickMarchLdsPad, stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps, slots);
+      kernel<<<grid, kTraceThreads, (size_t)brick_march_lds_pad(), stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps, slots);
     };
     // svoslam_config.march_ahead: < 0 = cone_trace_brick_kernel; n >= 0 = the march one sample ahead from step n + 1 on
     const int ahead = config().march_ahead;

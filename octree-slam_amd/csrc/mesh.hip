@@ -393,7 +393,7 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   u32 total_scan = 0;
   SVO_HIP(hipMemcpyAsync(&total_scan, d_total, 4, hipMemcpyDeviceToHost, stream));
   SVO_HIP(hipStreamSynchronize(stream));
-  if (total_scan == 0) return SVOSLAM_OK;
+  if (total_scan == 0) { (void)stage_end(kStageMeshRaster, tk_raster, stream); return SVOSLAM_OK; }
   // every scan line's set-up, once (64 bytes each) + the pieces of every chunk of 256 scan lines; then fragments per (scan line,
   // piece) -> exclusive scan -> emit
   const u32 chunks = cdiv(total_scan, 256);
@@ -402,17 +402,20 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   ScanlineSetup *lines = ws->path_nodes.as<ScanlineSetup>();
   u32 *piece_base = ws->leaf_t.as<u32>();
   scanline_setup_kernel<<<chunks, 256, 0, stream>>>(dv.as<float>(), n_tris, tri_start, total_scan, G, lines, piece_base);
+  SVO_LAUNCH_CHECK();
   SVO_TRY(exclusive_scan_u32(ws, piece_base, chunks, d_total, stream));
   u32 total_pieces = 0;
   SVO_HIP(hipMemcpyAsync(&total_pieces, d_total, 4, hipMemcpyDeviceToHost, stream));
   SVO_HIP(hipStreamSynchronize(stream));
   if ((unsigned long long)total_pieces * 256ull > 0x7FFFFFFFull) {
     set_last_error_text("mesh_to_voxel_grid: %u raster pieces (of 32768 candidate cells) x 256 count entries exceed 2^31 (%u scan lines)", total_pieces, total_scan);
+    (void)stage_end(kStageMeshRaster, tk_raster, stream);
     return SVOSLAM_ERR_OOM;
   }
   SVO_TRY(ws->leaf_rec0.reserve((size_t)total_pieces * 4));
   u32 *piece_map = ws->leaf_rec0.as<u32>();
   piece_map_kernel<<<cdiv(chunks, 256), 256, 0, stream>>>(piece_base, chunks, total_pieces, piece_map);
+  SVO_LAUNCH_CHECK();
   const u32 count_entries = total_pieces * 256u;
   SVO_TRY(ws->rec_front.reserve((size_t)count_entries * 4));
   u32 *frag_start = ws->rec_front.as<u32>();
@@ -423,9 +426,10 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   u32 total_frag = 0;
   SVO_HIP(hipMemcpyAsync(&total_frag, d_total, 4, hipMemcpyDeviceToHost, stream));
   SVO_HIP(hipStreamSynchronize(stream));
-  if (total_frag == 0) return SVOSLAM_OK;
+  if (total_frag == 0) { (void)stage_end(kStageMeshRaster, tk_raster, stream); return SVOSLAM_OK; }
   if (total_frag > 0x7FFFFFFFu) {
     set_last_error_text("mesh_to_voxel_grid: %u (cell, triangle) fragments exceed 2^31", total_frag);
+    (void)stage_end(kStageMeshRaster, tk_raster, stream);
     return SVOSLAM_ERR_OOM;
   }
   const int nf = (int)total_frag;
@@ -469,6 +473,8 @@ int mesh_to_voxel_grid(svoslam_workspace *ws, const svoslam_mesh *mesh, const sv
   SVO_LAUNCH_CHECK();
   (void)stage_end(kStageMeshEmit, tk_emit, stream);
   SVO_HIP(hipStreamSynchronize(stream));
+  // the scan lines' set-up records (64 bytes each: 2.1 GB at 2^16 cells per axis) do not stay with the workspace
+  if (ws->path_nodes.bytes > ((size_t)256 << 20)) ws->path_nodes.release();
   *d_centers = ce; *d_colors = co; *n_out = (int32_t)n_vox;
   if (d_indices) *d_indices = ix;
   return SVOSLAM_OK;

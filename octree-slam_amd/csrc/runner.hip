@@ -71,6 +71,7 @@ struct svoslam_runner {
   std::vector<hipEvent_t> events;  // pool, grown on demand
   hipEvent_t ev_begin = nullptr, ev_end[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t last_caller = nullptr;
+  bool model_pending = false;   // svoslam_runner_run_model left its model in the camera (cleared by the next svoslam_runner_run)
   int lead = -1;  // commits the host may run ahead of the device (see svoslam_runner_run); < 0: the schedule's default (1 deferred, 2 in place)
   bool fused_front = false;  // back-projection + bounding box + keys in one launch (keys that do not fit the packed word: the stand-alone calls)
   bool early_split = true;  // split_all_kernel right behind the plan, beside the previous frame's march
@@ -262,6 +263,13 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
       if (!d_depths[i] || !d_rgbs[i]) return SVOSLAM_ERR_INVALID_ARG;
       if ((i == 0 && have && timestamps[0] <= latest) || (i > 0 && timestamps[i] <= timestamps[i - 1])) return SVOSLAM_ERR_INVALID_ARG;
     }
+  }
+  if (r->model_pending) {
+    // a model left by svoslam_runner_run_model: this loop never refreshes it, and would track every frame against a map view that
+    // ages with every frame it fuses -- back to frame-to-frame tracking, as the loop is specified
+    SVO_TRY(svoslam_camera_set_model_depth(r->cam, nullptr, cur));
+    SVO_TRY(svoslam_camera_set_frame_to_model(r->cam, 0));
+    r->model_pending = false;
   }
   const size_t px = (size_t)r->w * r->h;
   const int npts = (int)px;
@@ -594,6 +602,14 @@ int svoslam_runner_run_model(svoslam_runner *r, const uint16_t *const *d_depths,
   for (int i = 0; i < n; i++) if (!d_depths[i] || !d_rgbs[i] || (i > 0 && timestamps[i] <= timestamps[i - 1])) return SVOSLAM_ERR_INVALID_ARG;
   if (n == 0) return SVOSLAM_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(caller_stream);
+  // the same call bookkeeping as svoslam_runner_run: one caller stream per runner, timestamps after the camera's latest
+  if (r->ran && s != r->last_caller) return SVOSLAM_ERR_INVALID_ARG;
+  {
+    int32_t have = 0; long long latest = 0;
+    SVO_TRY(svoslam_camera_latest_timestamp(r->cam, &have, &latest));
+    if (have && timestamps[0] <= latest) return SVOSLAM_ERR_INVALID_ARG;
+  }
+  r->ran = true; r->last_caller = s;
   const size_t px = (size_t)r->w * r->h;
   const int npts = r->w * r->h;
   if (!r->model_depth) {
@@ -638,6 +654,9 @@ int svoslam_runner_run_model(svoslam_runner *r, const uint16_t *const *d_depths,
                                         r->pool->d_data, r->center, r->edge, r->mode, d_steps, s));
   }
   if (models_used) *models_used = used_models;
+  // (the camera leaves with frame-to-model tracking ON and the last accepted model set: a second call continues the sequence exactly
+  // as one longer call would.  svoslam_runner_run -- the loop without a model refresh -- clears both when it starts: ADVICE r05)
+  r->model_pending = true;
   return SVOSLAM_OK;
 }
 

@@ -417,6 +417,9 @@ __global__ __launch_bounds__(kPlanThreads) void plan_emit_kernel(const u64 *__re
     const u32 b = bucket_id(d - t, d) & 255u;
     const unsigned long long peers = match_digit8(valid, b);
     if (valid) {
+      // INVARIANT: row_prefix[(b, tile)] is read only where THIS tile counted a record in bucket b (plan_count ran over
+      // the same keys with the same rule), so the round of 2048 tiles it lies in had a non-zero sum and plan_scan_finish wrote its
+      // prefixes; entries of all-zero rounds still hold raw zero counts, not `carry`, and nobody may read them as prefixes
       const u32 pos = bucket_base[b] + row_prefix[(size_t)b * num_tiles + tile] + cnt[wave][b] +
                       (u32)__popcll(peers & lt);
       rec_key[pos] = key >> (3 * (depth - d));  // prefix key with its leading 1

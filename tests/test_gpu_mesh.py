@@ -128,8 +128,9 @@ def test_config5_style_depth16_4k_bands(env, oracle, tmp_path):
     8.3 M rays stay within seconds; tools/mesh_bench.py times the 318 M-voxel variant."""
     pkg, torch = env
     log_n, (w, h) = 16, (3840, 2160)
+    # (round 6: with a patch of floor platform, as tools/mesh_bench.py's stand-in has it, and a pose over it)
     path = meshgen.write_colonnade_obj(tmp_path / "col.obj", n_cols=1, length=8.0, col_radius=0.0003, col_height=2.0, segs=6,
-                                       z_off=1.0, beam=0.0002)
+                                       z_off=1.0, beam=0.0002, floor=(-4.0, -3.9, -0.05, 0.05, 4, 2, 0.148))
     tex_path = meshgen.write_bmp(tmp_path / "t.bmp", 256, 256)
     scene = pkg.Scene()
     scene.load_obj(path)
@@ -145,8 +146,11 @@ def test_config5_style_depth16_4k_bands(env, oracle, tmp_path):
     assert gscale == scale and np.array_equal(gce.view(np.uint32), ece.view(np.uint32)) and np.array_equal(gco.view(np.uint32), eco.view(np.uint32))
     # close to a column foot, so that the cone LOD reaches depth 16 (voxel 0.12 mm, pixel footprint 0.36 mrad)
     target = ece[len(ece) // 3, :3].astype(np.float64)
-    view = oracle.look_at(tuple(target + np.array((0.004, 0.003, -0.012))), tuple(target), (0, 1, 0))
-    for mode in (0, 1):
+    views = [oracle.look_at(tuple(target + np.array((0.004, 0.003, -0.012))), tuple(target), (0, 1, 0)),
+             # tools/mesh_bench.py's "nave" pose at this mesh's scale: low over the floor platform, along +x, slightly down
+             oracle.look_at((-3.99, 0.148 + 0.03, 0.002), (4.0, 0.148 - 0.04, 0.0), (0, 1, 0))]
+    lit = []
+    for view, mode in ((views[0], 0), (views[0], 1), (views[1], 1)):
         img = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
         cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
         pkg.cone_trace_svo(img, 45.0, view, svo["data_ptr"], center, size, mode, counters=cnt)
@@ -158,7 +162,9 @@ def test_config5_style_depth16_4k_bands(env, oracle, tmp_path):
         for b in range(8):
             pkg.cone_trace_svo_band(band, b * 270, 270, 45.0, view, svo["data_ptr"], center, size, mode)
         assert torch.equal(band, img)
-    assert (ref[..., :3].sum(-1) > 0).sum() > 1000      # the column is in view (carry mode)
+        lit.append(int((ref[..., :3].sum(-1) > 0).sum()))
+    assert lit[1] > 1000            # the column is in view (carry mode)
+    assert lit[2] > 0.04 * w * h    # the floor platform lights a good part of the image from the pose over it (4.9 % here)
 
 
 def test_voxel_grid_to_mesh(env, oracle, tmp_path):

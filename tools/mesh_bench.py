@@ -82,7 +82,7 @@ def scene_views(cfg, center, size):
     # root cube's centre is at y = 2.501, so a floor at 0 lies 1 mm under the boundary of a 2.5 m level-4 cell, every ray above it takes
     # 1.25 m steps and jumps through it (the reference's step is half the edge of the EMPTY cell the sample is in); columns at z = +-3)
     return [("nave: 0.3 m over the floor, along +x", look_at((-18.0, 0.67, 0.02), (20.0, -0.03, 0.0))),
-            ("floor from 0.5 m, diagonal", look_at((-15.0, 0.87, -0.3), (-13.6, 0.37, 0.5))),
+            ("back along -x, 0.25 m over the floor", look_at((-12.0, 0.62, 0.3), (-20.0, 0.2, -0.3))),
             ("grazing along the z = +3 row of columns", look_at((-19.6, 1.5, 2.9), (20.0, 1.6, 3.02)))]
 
 
@@ -201,7 +201,7 @@ def main():
             renders.append(rec)
     pkg.cone_trace_timing(False)
     out["renders"] = renders
-    out["render_kernel"] = ("cone_trace_brick_kernel (reference mode over occupancy bricks)" if depth <= 14 else
+    out["render_kernel"] = ("cone_trace_brick_%skernel (reference mode over occupancy bricks)" % ("ahead_" if pkg.get_config().get("march_ahead", -1) >= 0 else "") if depth <= 14 else
                             "cone_trace_kernel (tree march: no brick shape for pools deeper than 14)") + " / cone_trace_kernel<CARRY> (carry mode)"
     out["mrays_per_s_min_max"] = [min(r["Mrays_per_s"] for r in renders), max(r["Mrays_per_s"] for r in renders)]
     print(json.dumps(out))

@@ -14,7 +14,7 @@ import json
 import sys
 
 STAGES = {
-    "march": ("cone_trace_brick_kernel", "cone_trace_kernel"),
+    "march": ("cone_trace_brick_ahead_kernel", "cone_trace_brick_kernel", "cone_trace_kernel"),
     "march_accel": ("pool_refresh_kernel", "pool_grid_update_kernel", "pool_grid_build_kernel", "build_tables_kernel", "build_accel_kernel",
                     "brick_rebuild_kernel", "brick_clear_kernel"),
     "tracker": ("track_persistent_kernel", "icp_accumulate_work_kernel", "icp_accumulate_kernel", "cam_reduce_solve_kernel", "cam_frame_end_kernel"),
