@@ -69,7 +69,7 @@ typedef struct svoslam_config {
   int32_t runner_timeline;  /* 1: HIP-event marks at the stage boundaries (svoslam_runner_timeline); costs ~6 % */
   int32_t sort_pairs;       /* 1: force the (key, index) pair sort instead of the packed one-word sort */
   int32_t graphs;           /* 1: launch sequences recorded and replayed as HIP graphs (0: direct launches, the default) */
-  int32_t march_ahead;      /* brick march: n >= 0 (default 90): past its first n steps a ray is marched in BURSTS of three samples -- the
+  int32_t march_ahead;      /* brick march: n >= 0 (default 60): past its first n steps a ray is marched in BURSTS of three samples -- the
                                current one and two reached by advancing with the previous step's level, their entries requested
                                together -- and follows the burst as long as each step ends on that level (results identical; overlaps
                                the round trips of a render's long rays); -1: one sample per iteration throughout */

@@ -160,7 +160,7 @@ struct TraceParams {
   // cost (wavefront-steps) to tile_cost for the next one.  nullptr: row-major, nothing recorded.
   const uint32_t *tile_order;
   uint32_t *tile_cost;
-  int spec_from;   // cone_trace_brick_ahead_kernel: steps after this one are marched one sample ahead
+  int spec_from;   // cone_trace_brick_kernel<.., B > 0>: steps after this one are marched in bursts of B samples
 };
 
 // entry e of [fine table | LDS image | alpha LUT] (see "split-plane table")
@@ -194,7 +194,7 @@ __device__ inline void build_table_entry(int e, float *__restrict__ table, float
   e -= 3 * (kTabStride + kLdsStrideMax);
   // (float)alpha / 127.0f of :110-112 for alpha = A - 127 in [-127, 128]: 256 IEEE quotients, computed once
   if (e < 256) alpha_lut[e] = (float)(e - 127) / 127.0f;
-  else if (e < 256 + 4) alpha_lut[e] = 0.0f;   // sixteen zero bytes: the "no brick" entry of cone_trace_brick_ahead_kernel
+  else if (e < 256 + 4) alpha_lut[e] = 0.0f;   // sixteen zero bytes: the "no brick" entry of the brick march's bursts
 }
 
 template <int GRID>
@@ -687,8 +687,47 @@ __device__ __forceinline__ uint32_t walk_sample(const uint2 *__restrict__ nodes,
 // table's ranks: it is GUESSED by the same float multiply at the finer pitch, its upper 11 bits are confirmed against the table
 // as before and its last bit against the reference's own next centre (c_11 = table entry +- size / 2^11: the level-12 decision of
 // walk_deep_chain), which the S = 0 kernel forms anyway whenever an LOD reaches 12.
-template <int THREADS, bool LOD_ALWAYS, int S>  // LOD_ALWAYS: every pixel size this render can form is in the fast LOD form's range (checked by the host)
-__global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
+// ---- the march's second phase: BURSTS of speculated samples (round 6; template parameter B of the kernel below) ----
+// What binds the kernel in the tail of a render is not what it issues but the round trip of a step's two entries: a
+// wavefront alone on its SIMD parks ~680 of a step's ~1100 cycles at s_waitcnt (profiles/r05_march_sq_counters_cfg3.txt), and the
+// render ends when its longest ray does (394 steps at cfg3, 768 in config 2's side view).  77 % of a long ray's steps end on the
+// same level as the step before (profiles/HISTORY_r01_r03.md).  So, past the first `spec_from` steps, an iteration of the loop places
+// B samples at once: the current one and B - 1 further ones reached by advancing with the PREVIOUS step's level -- the reference's own
+// arithmetic (:126-131) on the same operands, hence the same bits whenever that level is the one the step then finds -- and requests
+// the entries of all of them back to back: B round trips overlap.  The samples are answered in order; a lane follows the chain as
+// long as each step ends on the predicted level (`hit`) and otherwise advances by the level it found and starts the next iteration
+// from there.  No result depends on the prediction: a hit IS the advance the unpredicted code performs; a miss discards samples
+// nobody has counted.  Lanes of a wavefront fall out of step with each other (each counts its own), which costs issue slots while
+// the chip is full -- hence the plain loop (phase 1: every lane of a wavefront on the same step) for the first spec_from steps.
+// (Round 6, built first and dropped: one sample ahead with the prefetched entries carried across the loop's back edge.  The
+// registers of in-flight loads are then free for the step's temporaries, the compiler orders every such write behind the loads it
+// still counts, and merges of paths with different numbers of loads in flight end in s_waitcnt vmcnt(0): no overlap left.  Here
+// every load is issued and consumed inside one iteration.)
+// Measured (profiles/r06_march_ahead_ab.txt; same-box A/B of library variants, cfg3 300-frame map, three alternations each): as a kernel
+// of its own with a 128-VGPR budget, bursts of 2: the march 0.317 -> 0.279 ms in the loop but the FRAME slower (2410 -> 2200 frames/s: 107
+// VGPRs x 4 wavefronts leave a SIMD no room for the tracker's); at 80 VGPRs (spilling) bursts of 2 / 3 from step 90: the march 0.319 ->
+// 0.291 ms, the frame +2 % over 100 frames and +3 % over the driver's 20; merged into this kernel (phase 1 = the tuned loop; 41-58 VGPRs
+// spilled, in phase 2) from step 60: the march 0.313 -> 0.281 ms, frames/s 2397 -> 2474 (+3.2 %) and 2131 -> 2190 (+2.8 %); from step 90 /
+// 130: +1..3 %; bursts from step 0 lose in the loop (2254) and on short renders; 1080p: 953 -> 945 (nothing).  The SQ counters say why
+// it is not more (profiles/r06_march_sq_counters_cfg3.txt, the march alone): wavefront-cycles parked at s_waitcnt 140.6 M -> 127.7 M ->
+// 88.8 M (none / from step 90 / from step 0) of 259-273 M, instructions issued 88.9 M -> 108.6 M -> 124.4 M quad-cycles: the bursts buy
+// their overlap with the samples they discard, almost one for one (render alone 0.274 -> 0.267 -> 0.273 ms).
+// Default: bursts of 3 from step 61 (svoslam_config.march_ahead = 60).
+#ifndef SVO_AHEAD_WAVES
+#define SVO_AHEAD_WAVES 6
+#endif
+struct MarchSample {
+  float rx, ry, rz, len;   // the ray to this sample and its length
+  float tx, ty, tz;        // the sample
+  int fx, fy, fz;          // its guessed cell at the bricks' cell level
+  int lod;
+  uint32_t lod_ok;
+  uint2 gq;                // requested: its level-grid (or pyramid) entry
+  uint32_t e, have_e;      // ... and its brick entry (have_e = 0: not requested, the wavefront was not among nodes)
+};
+
+template <int THREADS, bool LOD_ALWAYS, int S, int B>  // B: samples per burst past the first P.spec_from steps (0: none); LOD_ALWAYS: every pixel size this render can form is in the fast LOD form's range (checked by the host)
+__global__ __launch_bounds__(THREADS, SVO_AHEAD_WAVES) void cone_trace_brick_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
                                                                    const uint2 *__restrict__ grid, const uint16_t *__restrict__ bricks,
                                                                    const float *__restrict__ table, const float *__restrict__ alpha_lut_g,
                                                                    TraceParams P, unsigned long long *__restrict__ counters,
@@ -764,6 +803,8 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
     int lod = 0;
     uint32_t retired = 0;  // (an integer, not a bool: a loop-carried bool is a lane mask the compiler re-blends every iteration)
     uint32_t prev_gx = 0;  // the previous sample's grid word: its children flag = "this ray is among nodes"
+    int dprev = 1 << 20;    // (B > 0) the previous step's level
+    bool ray_done = true;   // (B > 0) false: the loop below handed the ray over to the bursts
     auto brick_entry = [&](uint32_t x, uint32_t y, uint32_t z) -> uint32_t {  // cell (x, y, z) at the bricks' cell level, through the LDS spread tables
       if (S > 0) {  // the window: cells outside it have no entry (0 = "ask the level grid")
         x -= kOrg; y -= kOrg; z -= kOrg;
@@ -831,8 +872,11 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       const bool lod_ok = LOD_ALWAYS || ub - P.lod_first <= P.lod_span;
       // entries requested from the GUESSED cells (see cone_trace_kernel); an LOD coarser than the grid level asks the pyramid
       const bool coarse = (uint32_t)(lod - 1) < (uint32_t)(GRID - 1);   // 1 <= lod < GRID
-      const uint2 gq = grid[coarse ? pyramid_index<LDSD, GRID>((uint32_t)gx, (uint32_t)gy, (uint32_t)gz, lod)
-                                   : (((uint32_t)gz >> (LDSD - GRID)) << (2 * GRID)) | (((uint32_t)gy >> (LDSD - GRID)) << GRID) | ((uint32_t)gx >> (LDSD - GRID))];
+      uint32_t gcell = (((uint32_t)gz >> (LDSD - GRID)) << (2 * GRID)) | (((uint32_t)gy >> (LDSD - GRID)) << GRID) | ((uint32_t)gx >> (LDSD - GRID));
+      if (__builtin_expect(__any(coarse), 0)) {  // (uniform: no ray of a 640x480 / 1080p SLAM frame ever gets there)
+        if (coarse) gcell = pyramid_index<LDSD, GRID>((uint32_t)gx, (uint32_t)gy, (uint32_t)gz, lod);
+      }
+      const uint2 gq = grid[gcell];
       const bool with_brick = __any((prev_gx & kFlag) != 0u);  // (uniform: some ray of this wavefront is among nodes)
       uint32_t e = 0;
       if (with_brick) e = brick_entry((uint32_t)fx_, (uint32_t)fy_, (uint32_t)fz_);
@@ -879,6 +923,7 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       const bool decided = decode(e, gq, lod, oct12, depth, retired);
       float new_dist = ldexpf(P.size, -depth);  // (decided: depth in 1..12)
       bool full_form = false;
+      int depth_raw = depth;   // (the level as the reference counts it, before the clip at 0: what the bursts predict with)
 #ifdef SVO_BRICK_DIAG
       if (decided && conf && lod_ok) diag[0]++;
       if (with_brick) diag[2]++;
@@ -935,6 +980,7 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
           }
           new_dist = (depth >= -100 && depth <= 100) ? ldexpf(P.size, -depth) : P.size / ldexpf(1.0f, depth);
           full_form = depth < -60;
+          depth_raw = depth;
           if (depth < 0) depth = 0;  // (levels the reference visits: none)
 #ifdef SVO_BRICK_DIAG
           diag[1]++;
@@ -962,7 +1008,198 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
       // one exit: a retired ray, the range exit (:131), the step guard.  The advance is committed either way (the pixel is formed
       // from tx, ty, tz and the LOD of the last sample; which exit it was is read off `retired` below)
       rx = nx; ry = ny; rz = nz; ray_len = nlen;
+      if (B > 0) dprev = depth_raw;
       if (retired != 0u || nlen > kMaxRange || my_steps >= (uint32_t)kMaxSteps) break;
+      if (B > 0 && (int)my_steps >= P.spec_from) { ray_done = false; break; }   // the rest of this ray in bursts (below)
+    }
+    if (B > 0 && !ray_done) {
+      // ---- phase 2: the rest of the ray in bursts of B samples (see "the same march in BURSTS" above the kernel) ----
+      const char *zero_entry = reinterpret_cast<const char *>(alpha_lut_g + 256);
+      // position, guessed cell and LOD of the sample at the end of q's ray
+      auto place = [&](MarchSample &q) {
+        q.tx = P.origin[0] + q.rx; q.ty = P.origin[1] + q.ry; q.tz = P.origin[2] + q.rz;
+        int fx_ = (int)((q.tx - P.lo[0]) * inv_cell_fine), fy_ = (int)((q.ty - P.lo[1]) * inv_cell_fine), fz_ = (int)((q.tz - P.lo[2]) * inv_cell_fine);
+        q.fx = fx_ < 0 ? 0 : (fx_ > kFine - 1 ? kFine - 1 : fx_);
+        q.fy = fy_ < 0 ? 0 : (fy_ > kFine - 1 ? kFine - 1 : fy_);
+        q.fz = fz_ < 0 ? 0 : (fz_ > kFine - 1 ? kFine - 1 : fz_);
+        const uint32_t ub = f2bits(q.len * P.pix_scale);
+        q.lod = (P.size_exp - (int)(ub >> 23)) + ((ub & 0x7FFFFFu) < P.size_man ? 1 : 0);
+        q.lod_ok = (LOD_ALWAYS || ub - P.lod_first <= P.lod_span) ? 1u : 0u;
+      };
+      // its two entries, from the guessed cell.  with_brick (wavefront-uniform): some ray of the wavefront is among nodes; the brick
+      // load is issued either way (from sixteen zero bytes behind the alpha table when not wanted: entry 0 = "no brick, ask the level
+      // grid") and its value taken as is, so that the number of loads in flight at every later wait is known to the compiler
+      auto request = [&](MarchSample &q, bool with_brick) {
+        const uint32_t gx = (uint32_t)(q.fx >> S), gy = (uint32_t)(q.fy >> S), gz = (uint32_t)(q.fz >> S);
+        const bool coarse = (uint32_t)(q.lod - 1) < (uint32_t)(GRID - 1);
+        uint32_t gcell = ((gz >> (LDSD - GRID)) << (2 * GRID)) | ((gy >> (LDSD - GRID)) << GRID) | (gx >> (LDSD - GRID));
+        if (__builtin_expect(__any(coarse), 0)) {  // (uniform: no ray of a 640x480 / 1080p SLAM frame ever gets there)
+          if (coarse) gcell = pyramid_index<LDSD, GRID>(gx, gy, gz, q.lod);
+        }
+        q.gq = grid[gcell];
+        uint32_t x = (uint32_t)q.fx, y = (uint32_t)q.fy, z = (uint32_t)q.fz;
+        bool use = with_brick;
+        if (S > 0) {  // the window: cells outside it have no entry
+          x -= kOrg; y -= kOrg; z -= kOrg;
+          const bool inwin = (x | y | z) < kBrickWindowCells;
+          use = use && inwin;
+          x = inwin ? x : 0u; y = inwin ? y : 0u; z = inwin ? z : 0u;
+        }
+        const uint32_t d = spread[x] | spread[kCells + y] | spread[2 * kCells + z];
+        const char *at = use ? reinterpret_cast<const char *>(bricks) + (((size_t)d << 2) | ((x & 1u) << 1)) : zero_entry;
+        q.e = *reinterpret_cast<const uint16_t *>(at);
+        q.have_e = with_brick ? 1u : 0u;
+      };
+      // what one sample's entries say (cone_trace_brick_kernel's step between its request and its advance): the level the walk ends
+      // on (as the reference counts it: before the clip at 0), `retired`, the step length, and the LOD it was evaluated with
+      auto answer = [&](const MarchSample &q, float &new_dist, bool &full_form, int &lod_used) -> int {
+        const int gx = q.fx >> S, gy = q.fy >> S, gz = q.fz >> S;
+        const float tx = q.tx, ty = q.ty, tz = q.tz;
+        const float ax = lds_tab[gx + 1], bx = lds_tab[gx + 2];
+        const float ay = lds_tab[kLdsStride + gy + 1], by = lds_tab[kLdsStride + gy + 2];
+        const float az = lds_tab[2 * kLdsStride + gz + 1], bz = lds_tab[2 * kLdsStride + gz + 2];
+        bool conf = (((int)(ax < tx) & (int)!(bx < tx)) & ((int)(ay < ty) & (int)!(by < ty)) & ((int)(az < tz) & (int)!(bz < tz))) != 0;
+        const int lod = q.lod;
+        const bool lod_ok = LOD_ALWAYS || q.lod_ok != 0u;
+        const bool coarse = (uint32_t)(lod - 1) < (uint32_t)(GRID - 1);
+        const uint2 gq = q.gq;
+        const uint32_t e = q.e;
+        prev_gx = coarse ? 0u : gq.x;
+        // the step that enters a level-8 node with children without a brick entry requested: a second round trip, on the rare path
+        const bool need = q.have_e == 0u && (gq.x & kFlag) != 0u && lod > GRID && !coarse;
+        uint32_t oct12 = 0;
+        if (S > 0 || __any(lod >= BL)) {
+          float cx = (gx & 1) ? ax : bx, cy = (gy & 1) ? ay : by, cz = (gz & 1) ? az : bz;
+          cx += ts11 * ((gx & 1) ? 1.0f : -1.0f);
+          cy += ts11 * ((gy & 1) ? 1.0f : -1.0f);
+          cz += ts11 * ((gz & 1) ? 1.0f : -1.0f);
+          const uint32_t hx = (uint32_t)(tx > cx), hy = (uint32_t)(ty > cy), hz = (uint32_t)(tz > cz);
+          if (S == 0) {
+            oct12 = hx | (hy << 1) | (hz << 2);
+          } else {
+            conf = conf && (((hx ^ (uint32_t)q.fx) | (hy ^ (uint32_t)q.fy) | (hz ^ (uint32_t)q.fz)) & 1u) == 0u;
+            if (__any(lod >= BL)) {
+              cx += ts12 * (hx ? 1.0f : -1.0f);
+              cy += ts12 * (hy ? 1.0f : -1.0f);
+              cz += ts12 * (hz ? 1.0f : -1.0f);
+              oct12 = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
+            }
+          }
+        }
+        int depth;
+        const bool decided = decode(e, gq, lod, oct12, depth, retired) && !need;
+        new_dist = ldexpf(P.size, -depth);
+        full_form = false;
+        lod_used = lod;
+        if (__builtin_expect(__any(!(decided && conf && lod_ok)), 0)) {
+          if (!(decided && conf && lod_ok)) {
+            // the rare sample (cone_trace_brick_kernel's, word for word, plus the second trip above)
+            int lod2 = lod;
+            if (!lod_ok) lod2 = step_lod(P.size, q.len * P.pix_scale);
+            lod_used = lod2;
+            bool ok = true;
+            uint32_t xb = (uint32_t)gx, yb = (uint32_t)gy, zb = (uint32_t)gz;
+            uint32_t e2 = e;
+            uint2 g2 = gq;
+            if (need && conf) e2 = brick_entry((uint32_t)q.fx, (uint32_t)q.fy, (uint32_t)q.fz);
+            if (!conf) {
+              xb = axis_bits_lds<LDSD>(tx, P.lo[0], P.inv_cell_lds, lds_tab, ok);
+              yb = axis_bits_lds<LDSD>(ty, P.lo[1], P.inv_cell_lds, lds_tab + kLdsStride, ok);
+              zb = axis_bits_lds<LDSD>(tz, P.lo[2], P.inv_cell_lds, lds_tab + 2 * kLdsStride, ok);
+              if (!ok) {
+                xb = axis_bits_chain(tx, P.center[0], P.size, LDSD);
+                yb = axis_bits_chain(ty, P.center[1], P.size, LDSD);
+                zb = axis_bits_chain(tz, P.center[2], P.size, LDSD);
+              }
+            }
+            if (!conf || !lod_ok) {
+              const bool coarse2 = (uint32_t)(lod2 - 1) < (uint32_t)(GRID - 1);
+              g2 = grid[coarse2 ? pyramid_index<LDSD, GRID>(xb, yb, zb, lod2)
+                                : ((zb >> (LDSD - GRID)) << (2 * GRID)) | ((yb >> (LDSD - GRID)) << GRID) | (xb >> (LDSD - GRID))];
+              prev_gx = coarse2 ? 0u : g2.x;
+            }
+            float cx = lds_tab[(xb & ~1u) + 2u], cy = lds_tab[kLdsStride + (yb & ~1u) + 2u], cz = lds_tab[2 * kLdsStride + (zb & ~1u) + 2u];
+            cx += ts11 * ((xb & 1u) ? 1.0f : -1.0f);
+            cy += ts11 * ((yb & 1u) ? 1.0f : -1.0f);
+            cz += ts11 * ((zb & 1u) ? 1.0f : -1.0f);
+            uint32_t oct12r = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
+            if (S > 0) {
+              const uint32_t cxf = (xb << 1) | (oct12r & 1u), cyf = (yb << 1) | ((oct12r >> 1) & 1u), czf = (zb << 1) | (oct12r >> 2);
+              if (!conf) e2 = ok ? brick_entry(cxf, cyf, czf) : 0u;
+              cx += ts12 * ((oct12r & 1u) ? 1.0f : -1.0f);
+              cy += ts12 * ((oct12r & 2u) ? 1.0f : -1.0f);
+              cz += ts12 * ((oct12r & 4u) ? 1.0f : -1.0f);
+              oct12r = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
+            } else if (!conf) {
+              e2 = ok ? brick_entry(xb, yb, zb) : 0u;
+            }
+            const bool decided2 = ok && decode(e2, g2, lod2, oct12r, depth, retired);
+            if (!decided2) {
+              depth = lod2;
+              const uint32_t w = walk_sample<LDSD, GRID>(nodes, octree, grid, table, lds_tab, P, tx, ty, tz, xb, yb, zb, ok, depth);
+              retired = (w >> 24) >= 254u ? 1u : 0u;
+            }
+            new_dist = (depth >= -100 && depth <= 100) ? ldexpf(P.size, -depth) : P.size / ldexpf(1.0f, depth);
+            full_form = depth < -60;
+            // every load of this block has landed before it is left: one whose result a path does not consume (a short-circuited
+            // decode) would stay "in flight" in the compiler's book-keeping and turn later waits into vmcnt(0)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+          }
+        }
+        return depth;
+      };
+      // one iteration = a burst of N samples; returns true when the ray is done (`rx.. ray_len` = the advance past its last sample)
+      auto burst = [&](auto n_tag) -> bool {
+        constexpr int N = decltype(n_tag)::value;
+        MarchSample q[N];
+        const bool with_brick = __any((prev_gx & kFlag) != 0u);
+        q[0].rx = rx; q[0].ry = ry; q[0].rz = rz; q[0].len = ray_len;
+        place(q[0]);
+        request(q[0], with_brick);
+        if (N > 1) {
+          const float nd = ldexpf(P.size, -dprev);
+  #pragma unroll
+          for (int j = 1; j < N; j++) {
+            float il = __builtin_amdgcn_rcpf(q[j - 1].len);
+            il = fmaf(fmaf(-q[j - 1].len, il, 1.0f), il, il);
+            const float sp = div_rn_midrange_r(q[j - 1].len + nd, q[j - 1].len, il);
+            q[j].rx = q[j - 1].rx * sp; q[j].ry = q[j - 1].ry * sp; q[j].rz = q[j - 1].rz * sp;
+            q[j].len = sqrt_rn_midrange(dot3(q[j].rx, q[j].ry, q[j].rz, q[j].rx, q[j].ry, q[j].rz));
+            place(q[j]);
+            request(q[j], with_brick);
+          }
+        }
+        bool done = false, chain = true;
+  #pragma unroll
+        for (int j = 0; j < N; j++) {
+          if (chain) {
+            my_steps++;
+            float new_dist; bool full_form; int lod_used;
+            const int depth = answer(q[j], new_dist, full_form, lod_used);
+            my_levels += (uint32_t)(depth > 0 ? depth : 0);
+            const bool hit = j + 1 < N && depth == dprev && !full_form;
+            dprev = depth;
+            if (hit) {   // the next sample of the chain IS this advance
+              rx = q[j + 1 < N ? j + 1 : j].rx; ry = q[j + 1 < N ? j + 1 : j].ry; rz = q[j + 1 < N ? j + 1 : j].rz; ray_len = q[j + 1 < N ? j + 1 : j].len;
+            } else {     // (:126-131)
+              float il = __builtin_amdgcn_rcpf(q[j].len);
+              il = fmaf(fmaf(-q[j].len, il, 1.0f), il, il);
+              float s = div_rn_midrange_r(q[j].len + new_dist, q[j].len, il);
+              if (full_form) s = (q[j].len + new_dist) / q[j].len;
+              rx = q[j].rx * s; ry = q[j].ry * s; rz = q[j].rz * s;
+              ray_len = full_form ? length3(rx, ry, rz) : sqrt_rn_midrange(dot3(rx, ry, rz, rx, ry, rz));
+            }
+            tx = q[j].tx; ty = q[j].ty; tz = q[j].tz; lod = lod_used;
+            if (retired != 0u || ray_len > kMaxRange || my_steps >= (uint32_t)kMaxSteps) { done = true; chain = false; }
+            else if (!hit) chain = false;
+          }
+        }
+        // (entries of samples nobody answered: landed before the registers are reused -- they were requested with the first ones)
+        if (N > 1) __builtin_amdgcn_s_waitcnt(0x0F70);
+        return done;
+      };
+      bool done = false;
+      while (!done) done = burst(std::integral_constant<int, (B > 0 ? B : 1)>{});
     }
 #ifdef SVO_BRICK_DIAG
     if (counters) {
@@ -1033,355 +1270,6 @@ __global__ __launch_bounds__(THREADS, 6) void cone_trace_brick_kernel(uchar4 *__
   if (slots) count_steps(slots, counters, my_steps, my_levels, lane);
 }
 
-// ---- the same march in BURSTS of speculated samples (round 6) ------------------------------------------------
-// What binds cone_trace_brick_kernel in the tail of a render is not what it issues but the round trip of a step's two entries: a
-// wavefront alone on its SIMD parks ~680 of a step's ~1100 cycles at s_waitcnt (profiles/r05_march_sq_counters_cfg3.txt), and the
-// render ends when its longest ray does (394 steps at cfg3, 768 in config 2's side view).  77 % of a long ray's steps end on the
-// same level as the step before (profiles/HISTORY_r01_r03.md).  So, past the first `spec_from` steps, an iteration of the loop places
-// B samples at once: the current one and B - 1 further ones reached by advancing with the PREVIOUS step's level -- the reference's own
-// arithmetic (:126-131) on the same operands, hence the same bits whenever that level is the one the step then finds -- and requests
-// the entries of all of them back to back: B round trips overlap.  The samples are answered in order; a lane follows the chain as
-// long as each step ends on the predicted level (`hit`) and otherwise advances by the level it found and starts the next iteration
-// from there.  No result depends on the prediction: a hit IS the advance the unpredicted code performs; a miss discards samples
-// nobody has counted.  Lanes of a wavefront fall out of step with each other (each counts its own), which costs issue slots while
-// the chip is full -- hence bursts of one sample (the plain march) for the first spec_from steps.
-// (Round 6, built first and dropped: one sample ahead with the prefetched entries carried across the loop's back edge.  The
-// registers of in-flight loads are then free for the step's temporaries, the compiler orders every such write behind the loads it
-// still counts, and merges of paths with different numbers of loads in flight end in s_waitcnt vmcnt(0): no overlap left.  Here
-// every load is issued and consumed inside one iteration.)
-// Measured (profiles/r06_march_ahead_ab.txt; same-box A/B of library variants, cfg3 300-frame map): bursts of 2 at 128 VGPRs: the
-// march 0.317 -> 0.279 ms in the loop but the FRAME slower (2410 -> 2200 frames/s: 107 VGPRs x 4 wavefronts leave a SIMD no room for
-// the tracker's); at 80 VGPRs (SVO_AHEAD_WAVES = 6: 18-30 spilled) bursts of 2 / 3 from step 90: the march 0.319 -> 0.291 ms, the
-// frame +2.2 % over 100 frames (2401 -> 2453) and +3.5 % over the driver's 20 (2073 -> 2145), three alternations; bursts from step 0
-// lose in the loop (2254) and on short renders.  Default: bursts of 3 from step 91 (svoslam_config.march_ahead = 90).
-#ifndef SVO_AHEAD_WAVES
-#define SVO_AHEAD_WAVES 6
-#endif
-struct MarchSample {
-  float rx, ry, rz, len;   // the ray to this sample and its length
-  float tx, ty, tz;        // the sample
-  int fx, fy, fz;          // its guessed cell at the bricks' cell level
-  int lod;
-  uint32_t lod_ok;
-  uint2 gq;                // requested: its level-grid (or pyramid) entry
-  uint32_t e, have_e;      // ... and its brick entry (have_e = 0: not requested, the wavefront was not among nodes)
-};
-
-template <int THREADS, bool LOD_ALWAYS, int S, int B>
-__global__ __launch_bounds__(THREADS, SVO_AHEAD_WAVES) void cone_trace_brick_ahead_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
-                                                                         const uint2 *__restrict__ grid, const uint16_t *__restrict__ bricks,
-                                                                         const float *__restrict__ table, const float *__restrict__ alpha_lut_g,
-                                                                         TraceParams P, unsigned long long *__restrict__ counters,
-                                                                         unsigned long long *__restrict__ slots) {
-  constexpr int LDSD = 11, GRID = kPoolGridLevel;
-  constexpr int kLdsStride = lds_stride(LDSD);
-  constexpr int kCells = lds_cells(LDSD);
-  constexpr int BL = brick_bits_level(S);
-  constexpr int kFine = kCells << S;
-  constexpr uint32_t kOrg = brick_window_origin(S);
-  __shared__ float alpha_lut[256];
-  __shared__ float lds_tab[3 * kLdsStride + 3 * kCells];
-  uint32_t *spread = reinterpret_cast<uint32_t *>(lds_tab + 3 * kLdsStride);
-  if (threadIdx.x < 256) alpha_lut[threadIdx.x] = alpha_lut_g[threadIdx.x];
-  {
-    const float *src = table + 3 * kTabStride;
-    for (int i = threadIdx.x; i < 3 * kLdsStride; i += THREADS) lds_tab[i] = src[i];
-    for (int i = threadIdx.x; i < kCells; i += THREADS) {
-      const uint32_t r = (uint32_t)i;
-      spread[i] = (uint32_t)(brick_entry_index(r, 0u, 0u) >> 1);
-      spread[kCells + i] = (uint32_t)(brick_entry_index(0u, r, 0u) >> 1);
-      spread[2 * kCells + i] = (uint32_t)(brick_entry_index(0u, 0u, r) >> 1);
-    }
-  }
-  __syncthreads();
-  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  const int tile_id = P.tile_order ? (int)P.tile_order[blockIdx.x] : (int)blockIdx.x;
-  const int tile_y = tile_id / P.xcd_h;
-  const int tile_x = tile_id - tile_y * P.xcd_h;
-  const int px = tile_x * 32 + (int)(wave & 3u) * 8 + (int)(lane & 7u);
-  const int py = P.pair_rows ? P.row_first + (tile_y + (int)(wave >> 2) * P.pair_rows) * 8 + (int)(lane >> 3)
-                             : P.row_first + tile_y * (THREADS / 32) + (int)(wave >> 2) * 8 + (int)(lane >> 3);
-  uint32_t my_steps = 0, my_levels = 0;
-  if (px < P.width && py < P.row_end) {
-    const int idx = py * P.width + px;
-    const float res_x = (float)P.width, res_y = (float)P.height;
-    const float magx = ((float)px - res_x / 2.0f) / 532.57f;
-    const float magy = ((float)py - res_y / 2.0f) / 531.54f;
-    const float nyx = -P.y_dir[0], nyy = -P.y_dir[1], nyz = -P.y_dir[2];
-    const float fwx = P.x_dir[1] * nyz - nyy * P.x_dir[2];
-    const float fwy = P.x_dir[2] * nyx - nyz * P.x_dir[0];
-    const float fwz = P.x_dir[0] * nyy - nyx * P.x_dir[1];
-    const float dx = ((magx * P.x_dir[0]) + (magy * P.y_dir[0])) + fwx;
-    const float dy = ((magx * P.x_dir[1]) + (magy * P.y_dir[1])) + fwy;
-    const float dz = ((magx * P.x_dir[2]) + (magy * P.y_dir[2])) + fwz;
-    const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
-    const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
-    const float ts11 = ldexpf(P.size, -LDSD);
-    const float ts12 = ldexpf(P.size, -LDSD - 1);
-    const float inv_cell_fine = S == 0 ? P.inv_cell_lds : P.inv_cell_lds * 2.0f;
-    const char *zero_entry = reinterpret_cast<const char *>(alpha_lut_g + 256);
-    // position, guessed cell and LOD of the sample at the end of q's ray
-    auto place = [&](MarchSample &q) {
-      q.tx = P.origin[0] + q.rx; q.ty = P.origin[1] + q.ry; q.tz = P.origin[2] + q.rz;
-      int fx_ = (int)((q.tx - P.lo[0]) * inv_cell_fine), fy_ = (int)((q.ty - P.lo[1]) * inv_cell_fine), fz_ = (int)((q.tz - P.lo[2]) * inv_cell_fine);
-      q.fx = fx_ < 0 ? 0 : (fx_ > kFine - 1 ? kFine - 1 : fx_);
-      q.fy = fy_ < 0 ? 0 : (fy_ > kFine - 1 ? kFine - 1 : fy_);
-      q.fz = fz_ < 0 ? 0 : (fz_ > kFine - 1 ? kFine - 1 : fz_);
-      const uint32_t ub = f2bits(q.len * P.pix_scale);
-      q.lod = (P.size_exp - (int)(ub >> 23)) + ((ub & 0x7FFFFFu) < P.size_man ? 1 : 0);
-      q.lod_ok = (LOD_ALWAYS || ub - P.lod_first <= P.lod_span) ? 1u : 0u;
-    };
-    // its two entries, from the guessed cell.  with_brick (wavefront-uniform): some ray of the wavefront is among nodes; the brick
-    // load is issued either way (from sixteen zero bytes behind the alpha table when not wanted: entry 0 = "no brick, ask the level
-    // grid") and its value taken as is, so that the number of loads in flight at every later wait is known to the compiler
-    auto request = [&](MarchSample &q, bool with_brick) {
-      const uint32_t gx = (uint32_t)(q.fx >> S), gy = (uint32_t)(q.fy >> S), gz = (uint32_t)(q.fz >> S);
-      const bool coarse = (uint32_t)(q.lod - 1) < (uint32_t)(GRID - 1);
-      q.gq = grid[coarse ? pyramid_index<LDSD, GRID>(gx, gy, gz, q.lod)
-                         : ((gz >> (LDSD - GRID)) << (2 * GRID)) | ((gy >> (LDSD - GRID)) << GRID) | (gx >> (LDSD - GRID))];
-      uint32_t x = (uint32_t)q.fx, y = (uint32_t)q.fy, z = (uint32_t)q.fz;
-      bool use = with_brick;
-      if (S > 0) {  // the window: cells outside it have no entry
-        x -= kOrg; y -= kOrg; z -= kOrg;
-        const bool inwin = (x | y | z) < kBrickWindowCells;
-        use = use && inwin;
-        x = inwin ? x : 0u; y = inwin ? y : 0u; z = inwin ? z : 0u;
-      }
-      const uint32_t d = spread[x] | spread[kCells + y] | spread[2 * kCells + z];
-      const char *at = use ? reinterpret_cast<const char *>(bricks) + (((size_t)d << 2) | ((x & 1u) << 1)) : zero_entry;
-      q.e = *reinterpret_cast<const uint16_t *>(at);
-      q.have_e = with_brick ? 1u : 0u;
-    };
-    auto brick_entry = [&](uint32_t x, uint32_t y, uint32_t z) -> uint32_t {
-      if (S > 0) {
-        x -= kOrg; y -= kOrg; z -= kOrg;
-        if ((x | y | z) >= kBrickWindowCells) return 0u;
-      }
-      const uint32_t d = spread[x] | spread[kCells + y] | spread[2 * kCells + z];
-      return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(bricks) + (((size_t)d << 2) | ((x & 1u) << 1)));
-    };
-    // (cone_trace_brick_kernel's decode, word for word)
-    auto decode = [&](uint32_t e, uint2 gq, int lod_, uint32_t oct12, int &depth, uint32_t &ret) -> bool {
-      const int st = S == 0 ? (int)((e & 7u) | 8u) : (int)((0x009DCBA8u >> ((e & 7u) << 2)) & 15u);
-      const int depth_b = lod_ < st ? lod_ : st;
-      uint32_t bit = (uint32_t)(depth_b - 5);
-      constexpr int NLv = brick_node_level(S);
-      bool by_brick = (uint32_t)(depth_b - NLv) < 3u;
-      if (S > 0) by_brick = by_brick || (st > GRID && st < NLv && depth_b == st);
-      if (lod_ >= BL) {
-        const bool deep = depth_b == BL && (lod_ == BL || !(e & 8u));
-        by_brick = by_brick || deep;
-        bit = deep ? 8u + oct12 : bit;
-      }
-      const uint32_t lv = lod_ < GRID ? (uint32_t)lod_ : (uint32_t)GRID;
-      const uint32_t depth_g = gq.x < kFlag ? gq.x : lv;
-      const uint32_t top_g = gq.x < kFlag ? 127u : lv;
-      const bool by_grid = (uint32_t)lod_ - depth_g <= top_g - depth_g;
-      depth = by_brick ? depth_b : (int)depth_g;
-      ret = by_brick ? (e >> bit) & 1u : (uint32_t)(gq.y >= 0xFE000000u);
-      return by_brick || by_grid;
-    };
-    uint32_t retired = 0, prev_gx = 0;
-    // what one sample's entries say (cone_trace_brick_kernel's step between its request and its advance): the level the walk ends
-    // on (as the reference counts it: before the clip at 0), `retired`, the step length, and the LOD it was evaluated with
-    auto answer = [&](const MarchSample &q, float &new_dist, bool &full_form, int &lod_used) -> int {
-      const int gx = q.fx >> S, gy = q.fy >> S, gz = q.fz >> S;
-      const float tx = q.tx, ty = q.ty, tz = q.tz;
-      const float ax = lds_tab[gx + 1], bx = lds_tab[gx + 2];
-      const float ay = lds_tab[kLdsStride + gy + 1], by = lds_tab[kLdsStride + gy + 2];
-      const float az = lds_tab[2 * kLdsStride + gz + 1], bz = lds_tab[2 * kLdsStride + gz + 2];
-      bool conf = (((int)(ax < tx) & (int)!(bx < tx)) & ((int)(ay < ty) & (int)!(by < ty)) & ((int)(az < tz) & (int)!(bz < tz))) != 0;
-      const int lod = q.lod;
-      const bool lod_ok = LOD_ALWAYS || q.lod_ok != 0u;
-      const bool coarse = (uint32_t)(lod - 1) < (uint32_t)(GRID - 1);
-      const uint2 gq = q.gq;
-      const uint32_t e = q.e;
-      prev_gx = coarse ? 0u : gq.x;
-      // the step that enters a level-8 node with children without a brick entry requested: a second round trip, on the rare path
-      const bool need = q.have_e == 0u && (gq.x & kFlag) != 0u && lod > GRID && !coarse;
-      uint32_t oct12 = 0;
-      if (S > 0 || __any(lod >= BL)) {
-        float cx = (gx & 1) ? ax : bx, cy = (gy & 1) ? ay : by, cz = (gz & 1) ? az : bz;
-        cx += ts11 * ((gx & 1) ? 1.0f : -1.0f);
-        cy += ts11 * ((gy & 1) ? 1.0f : -1.0f);
-        cz += ts11 * ((gz & 1) ? 1.0f : -1.0f);
-        const uint32_t hx = (uint32_t)(tx > cx), hy = (uint32_t)(ty > cy), hz = (uint32_t)(tz > cz);
-        if (S == 0) {
-          oct12 = hx | (hy << 1) | (hz << 2);
-        } else {
-          conf = conf && (((hx ^ (uint32_t)q.fx) | (hy ^ (uint32_t)q.fy) | (hz ^ (uint32_t)q.fz)) & 1u) == 0u;
-          if (__any(lod >= BL)) {
-            cx += ts12 * (hx ? 1.0f : -1.0f);
-            cy += ts12 * (hy ? 1.0f : -1.0f);
-            cz += ts12 * (hz ? 1.0f : -1.0f);
-            oct12 = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
-          }
-        }
-      }
-      int depth;
-      const bool decided = decode(e, gq, lod, oct12, depth, retired) && !need;
-      new_dist = ldexpf(P.size, -depth);
-      full_form = false;
-      lod_used = lod;
-      if (__builtin_expect(__any(!(decided && conf && lod_ok)), 0)) {
-        if (!(decided && conf && lod_ok)) {
-          // the rare sample (cone_trace_brick_kernel's, word for word, plus the second trip above)
-          int lod2 = lod;
-          if (!lod_ok) lod2 = step_lod(P.size, q.len * P.pix_scale);
-          lod_used = lod2;
-          bool ok = true;
-          uint32_t xb = (uint32_t)gx, yb = (uint32_t)gy, zb = (uint32_t)gz;
-          uint32_t e2 = e;
-          uint2 g2 = gq;
-          if (need && conf) e2 = brick_entry((uint32_t)q.fx, (uint32_t)q.fy, (uint32_t)q.fz);
-          if (!conf) {
-            xb = axis_bits_lds<LDSD>(tx, P.lo[0], P.inv_cell_lds, lds_tab, ok);
-            yb = axis_bits_lds<LDSD>(ty, P.lo[1], P.inv_cell_lds, lds_tab + kLdsStride, ok);
-            zb = axis_bits_lds<LDSD>(tz, P.lo[2], P.inv_cell_lds, lds_tab + 2 * kLdsStride, ok);
-            if (!ok) {
-              xb = axis_bits_chain(tx, P.center[0], P.size, LDSD);
-              yb = axis_bits_chain(ty, P.center[1], P.size, LDSD);
-              zb = axis_bits_chain(tz, P.center[2], P.size, LDSD);
-            }
-          }
-          if (!conf || !lod_ok) {
-            const bool coarse2 = (uint32_t)(lod2 - 1) < (uint32_t)(GRID - 1);
-            g2 = grid[coarse2 ? pyramid_index<LDSD, GRID>(xb, yb, zb, lod2)
-                              : ((zb >> (LDSD - GRID)) << (2 * GRID)) | ((yb >> (LDSD - GRID)) << GRID) | (xb >> (LDSD - GRID))];
-            prev_gx = coarse2 ? 0u : g2.x;
-          }
-          float cx = lds_tab[(xb & ~1u) + 2u], cy = lds_tab[kLdsStride + (yb & ~1u) + 2u], cz = lds_tab[2 * kLdsStride + (zb & ~1u) + 2u];
-          cx += ts11 * ((xb & 1u) ? 1.0f : -1.0f);
-          cy += ts11 * ((yb & 1u) ? 1.0f : -1.0f);
-          cz += ts11 * ((zb & 1u) ? 1.0f : -1.0f);
-          uint32_t oct12r = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
-          if (S > 0) {
-            const uint32_t cxf = (xb << 1) | (oct12r & 1u), cyf = (yb << 1) | ((oct12r >> 1) & 1u), czf = (zb << 1) | (oct12r >> 2);
-            if (!conf) e2 = ok ? brick_entry(cxf, cyf, czf) : 0u;
-            cx += ts12 * ((oct12r & 1u) ? 1.0f : -1.0f);
-            cy += ts12 * ((oct12r & 2u) ? 1.0f : -1.0f);
-            cz += ts12 * ((oct12r & 4u) ? 1.0f : -1.0f);
-            oct12r = (uint32_t)(tx > cx) | ((uint32_t)(ty > cy) << 1) | ((uint32_t)(tz > cz) << 2);
-          } else if (!conf) {
-            e2 = ok ? brick_entry(xb, yb, zb) : 0u;
-          }
-          const bool decided2 = ok && decode(e2, g2, lod2, oct12r, depth, retired);
-          if (!decided2) {
-            depth = lod2;
-            const uint32_t w = walk_sample<LDSD, GRID>(nodes, octree, grid, table, lds_tab, P, tx, ty, tz, xb, yb, zb, ok, depth);
-            retired = (w >> 24) >= 254u ? 1u : 0u;
-          }
-          new_dist = (depth >= -100 && depth <= 100) ? ldexpf(P.size, -depth) : P.size / ldexpf(1.0f, depth);
-          full_form = depth < -60;
-          // every load of this block has landed before it is left: one whose result a path does not consume (a short-circuited
-          // decode) would stay "in flight" in the compiler's book-keeping and turn later waits into vmcnt(0)
-          __builtin_amdgcn_s_waitcnt(0x0F70);
-        }
-      }
-      return depth;
-    };
-    float rx = kStartDist * (dx * inv), ry = kStartDist * (dy * inv), rz = kStartDist * (dz * inv);
-    float ray_len = length3(rx, ry, rz);
-    int dprev = 1 << 20;              // the previous step's level (none yet: nothing to predict with)
-    float last_tx = 0.0f, last_ty = 0.0f, last_tz = 0.0f;   // the last sample, for the pixel
-    int last_lod = 0;
-    // one iteration = a burst of N samples; returns true when the ray is done (`rx.. ray_len` = the advance past its last sample)
-    auto burst = [&](auto n_tag) -> bool {
-      constexpr int N = decltype(n_tag)::value;
-      MarchSample q[N];
-      const bool with_brick = __any((prev_gx & kFlag) != 0u);
-      q[0].rx = rx; q[0].ry = ry; q[0].rz = rz; q[0].len = ray_len;
-      place(q[0]);
-      request(q[0], with_brick);
-      if (N > 1) {
-        const float nd = ldexpf(P.size, -dprev);
-#pragma unroll
-        for (int j = 1; j < N; j++) {
-          float il = __builtin_amdgcn_rcpf(q[j - 1].len);
-          il = fmaf(fmaf(-q[j - 1].len, il, 1.0f), il, il);
-          const float sp = div_rn_midrange_r(q[j - 1].len + nd, q[j - 1].len, il);
-          q[j].rx = q[j - 1].rx * sp; q[j].ry = q[j - 1].ry * sp; q[j].rz = q[j - 1].rz * sp;
-          q[j].len = sqrt_rn_midrange(dot3(q[j].rx, q[j].ry, q[j].rz, q[j].rx, q[j].ry, q[j].rz));
-          place(q[j]);
-          request(q[j], with_brick);
-        }
-      }
-      bool done = false, chain = true;
-#pragma unroll
-      for (int j = 0; j < N; j++) {
-        if (chain) {
-          my_steps++;
-          float new_dist; bool full_form; int lod_used;
-          const int depth = answer(q[j], new_dist, full_form, lod_used);
-          my_levels += (uint32_t)(depth > 0 ? depth : 0);
-          const bool hit = j + 1 < N && depth == dprev && !full_form;
-          dprev = depth;
-          if (hit) {   // the next sample of the chain IS this advance
-            rx = q[j + 1 < N ? j + 1 : j].rx; ry = q[j + 1 < N ? j + 1 : j].ry; rz = q[j + 1 < N ? j + 1 : j].rz; ray_len = q[j + 1 < N ? j + 1 : j].len;
-          } else {     // (:126-131)
-            float il = __builtin_amdgcn_rcpf(q[j].len);
-            il = fmaf(fmaf(-q[j].len, il, 1.0f), il, il);
-            float s = div_rn_midrange_r(q[j].len + new_dist, q[j].len, il);
-            if (full_form) s = (q[j].len + new_dist) / q[j].len;
-            rx = q[j].rx * s; ry = q[j].ry * s; rz = q[j].rz * s;
-            ray_len = full_form ? length3(rx, ry, rz) : sqrt_rn_midrange(dot3(rx, ry, rz, rx, ry, rz));
-          }
-          last_tx = q[j].tx; last_ty = q[j].ty; last_tz = q[j].tz; last_lod = lod_used;
-          if (retired != 0u || ray_len > kMaxRange || my_steps >= (uint32_t)kMaxSteps) { done = true; chain = false; }
-          else if (!hit) chain = false;
-        }
-      }
-      // (entries of samples nobody answered: landed before the registers are reused -- they were requested with the first ones)
-      if (N > 1) __builtin_amdgcn_s_waitcnt(0x0F70);
-      return done;
-    };
-    bool done = false;
-    // the first spec_from steps one sample at a time (every lane of the wavefront on the same step: the chip is full, issue binds)
-    while (!done && (int)my_steps < P.spec_from) done = burst(std::integral_constant<int, 1>{});
-    while (!done) done = burst(std::integral_constant<int, B>{});
-    const bool range_exit = retired == 0u && ray_len > kMaxRange;
-    uint32_t w_last;
-    {
-      bool ok = true;
-      uint32_t xb = axis_bits_lds<LDSD>(last_tx, P.lo[0], P.inv_cell_lds, lds_tab, ok);
-      uint32_t yb = axis_bits_lds<LDSD>(last_ty, P.lo[1], P.inv_cell_lds, lds_tab + kLdsStride, ok);
-      uint32_t zb = axis_bits_lds<LDSD>(last_tz, P.lo[2], P.inv_cell_lds, lds_tab + 2 * kLdsStride, ok);
-      if (!ok) {
-        xb = axis_bits_chain(last_tx, P.center[0], P.size, LDSD);
-        yb = axis_bits_chain(last_ty, P.center[1], P.size, LDSD);
-        zb = axis_bits_chain(last_tz, P.center[2], P.size, LDSD);
-      }
-      int d2 = last_lod;
-      w_last = walk_sample<LDSD, GRID>(nodes, octree, grid, table, lds_tab, P, last_tx, last_ty, last_tz, xb, yb, zb, ok, d2);
-    }
-    const int alpha = (int)((w_last >> 24) - 127u);
-    const float af = alpha_lut[alpha + 127];
-    uint32_t vx = f2u8(af * (float)(w_last & 0xFF));
-    uint32_t vy = f2u8(af * (float)((w_last >> 8) & 0xFF));
-    uint32_t vz = f2u8(af * (float)((w_last >> 16) & 0xFF));
-    const uint32_t vw = (uint32_t)alpha & 0xFFu;
-    if (range_exit) {
-      const float sc = 127.0f / (float)vw;
-      vx = f2u8((float)vx * sc);
-      vy = f2u8((float)vy * sc);
-      vz = f2u8((float)vz * sc);
-    }
-    uint32_t out = vx | (vy << 8) | (vz << 16) | (255u << 24);
-    if (P.mode & 0x100) out = my_steps;
-    uchar4 o;
-    o.x = (unsigned char)(out & 0xFF); o.y = (unsigned char)((out >> 8) & 0xFF);
-    o.z = (unsigned char)((out >> 16) & 0xFF); o.w = (unsigned char)(out >> 24);
-    pos[idx] = o;
-  }
-  if (P.tile_cost) {
-    uint32_t mx = my_steps;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)mx, o); mx = v > mx ? v : mx; }
-    if (lane == 0) atomicAdd(&P.tile_cost[tile_id], mx);
-  }
-  if (slots) count_steps(slots, counters, my_steps, my_levels, lane);
-}
-
 // Tiles of the previous render, costliest first: tile_order_block (pool_grid.hpp), run by one extra workgroup of the refresh
 // launch that precedes the march (no launch of its own on the map stream: as one it took 15 us + a launch boundary per frame)
 // or, where no refresh is launched, by this kernel.
@@ -1394,7 +1282,7 @@ __global__ __launch_bounds__(THREADS, SVO_AHEAD_WAVES) void cone_trace_brick_ahe
 #ifndef SVO_AHEAD_BURST
 #define SVO_AHEAD_BURST 3
 #endif
-constexpr int kAheadBurst = SVO_AHEAD_BURST;   // samples per iteration of cone_trace_brick_ahead_kernel past spec_from
+constexpr int kAheadBurst = SVO_AHEAD_BURST;   // samples per burst of cone_trace_brick_kernel past P.spec_from
 constexpr int kBrickMarchStaticLds = 1024 + 4 * (3 * lds_stride(11) + 3 * lds_cells(11));  // alpha_lut + lds_tab of cone_trace_brick_kernel
 // the pad, from the device's own LDS size (6144 bytes on gfx950's 160 KB per CU; a part with another size gets the pad
 // that leaves exactly two workgroups there, or none where two do not fit anyway)
@@ -1608,18 +1496,18 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
     P.spec_from = ahead;
     if (ahead >= 0) {
       if (brick_shift == 0) {
-        if (P.lod_always) launch(cone_trace_brick_ahead_kernel<kTraceThreads, true, 0, kAheadBurst>);
-        else launch(cone_trace_brick_ahead_kernel<kTraceThreads, false, 0, kAheadBurst>);
+        if (P.lod_always) launch(cone_trace_brick_kernel<kTraceThreads, true, 0, kAheadBurst>);
+        else launch(cone_trace_brick_kernel<kTraceThreads, false, 0, kAheadBurst>);
       } else {
-        if (P.lod_always) launch(cone_trace_brick_ahead_kernel<kTraceThreads, true, 1, kAheadBurst>);
-        else launch(cone_trace_brick_ahead_kernel<kTraceThreads, false, 1, kAheadBurst>);
+        if (P.lod_always) launch(cone_trace_brick_kernel<kTraceThreads, true, 1, kAheadBurst>);
+        else launch(cone_trace_brick_kernel<kTraceThreads, false, 1, kAheadBurst>);
       }
     } else if (brick_shift == 0) {
-      if (P.lod_always) launch(cone_trace_brick_kernel<kTraceThreads, true, 0>);
-      else launch(cone_trace_brick_kernel<kTraceThreads, false, 0>);
+      if (P.lod_always) launch(cone_trace_brick_kernel<kTraceThreads, true, 0, 0>);
+      else launch(cone_trace_brick_kernel<kTraceThreads, false, 0, 0>);
     } else {
-      if (P.lod_always) launch(cone_trace_brick_kernel<kTraceThreads, true, 1>);
-      else launch(cone_trace_brick_kernel<kTraceThreads, false, 1>);
+      if (P.lod_always) launch(cone_trace_brick_kernel<kTraceThreads, true, 1, 0>);
+      else launch(cone_trace_brick_kernel<kTraceThreads, false, 1, 0>);
     }
   } else if (large) {
     const dim3 grid(xcd_mapping(P, (int)cdiv(width, 32), (int)cdiv(rows, kTraceThreads / 32)));

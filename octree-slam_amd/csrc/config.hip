@@ -31,7 +31,7 @@ bool config_valid(const svoslam_config &c) {
 void init_locked() {
   if (g_ready) return;
   memset(&g_cfg, 0, sizeof(g_cfg));
-  g_cfg.march_bricks = 1; g_cfg.track_stream = 1; g_cfg.march_ahead = 90;
+  g_cfg.march_bricks = 1; g_cfg.track_stream = 1; g_cfg.march_ahead = 60;
   g_cfg.runner_deferred = -1; g_cfg.runner_lead = -1; g_cfg.runner_prio = -1; g_cfg.runner_replicas = 1;
   // SVOSLAM_CONFIG = "name=value,name=value": the ONE environment variable the library reads (tools, child-process tests).
   // Validated like svoslam_config_set: an unknown name or a malformed pair is reported once on stderr (a typo in an
