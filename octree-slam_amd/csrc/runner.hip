@@ -143,6 +143,8 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
     const bool prio = want && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
     hipStream_t *ss[5] = {&r->s_maps, &r->s_track, &r->s_prep, &r->s_map[0], &r->s_map[1]};
     const int mid = (least + greatest) / 2;
+    // (round 6, re-measured with the shorter march, profiles/r06_priority_experiments.txt: the sort / plan stream at the middle priority
+    // and / or s_setprio(3) in its kernels: 640x480 -1..0 %, 1080p +1..2 %: within the noise, not kept)
     const int pr[5] = {least, mid, least, greatest, greatest};
     // A destroyed runner's five streams are kept for the next runner of the same kind (device, priorities) instead of being
     // destroyed: streams created after others were destroyed can come to share hardware queues -- a runner created after
