@@ -251,13 +251,16 @@ def cpu_baseline(depth_frames, rgb_frames, views, first, width, height, max_dept
 
 def device_memory(P, torch):
     """what the session holds on the device: the pool's reservation, the deferred commits' shadow array (8 B per
-    node of capacity, when deferred commits are on), the occupancy bricks' dense field (2 x 2048^3 bytes, taken only when three times
-    its size is free), the level grid (256^3 x 8 B), and what the process has allocated in total"""
+    node of capacity, when deferred commits are on), the occupancy bricks' page pool (round 6: svoslam_config.brick_pages pages of 4 MB
+    + the zero page; `brick_pages` = pages in use / capacity / requests it could not serve), the level grid + pyramid, and what the
+    process has allocated in total"""
     GiB = float(1 << 30)
     free_b, total_b = torch.cuda.mem_get_info()
     cap = int(P.pool.capacity)
+    pages = P.pool.brick_pages()
     return {"pool_reserved": cap * 8 / GiB, "pool_used": int(P.pool.size) * 8 / GiB, "deferred_shadow_if_on": cap * 8 / GiB,
-            "brick_field_if_taken": 16.0, "level_grid": (256 ** 3) * 8 / GiB, "march_accel": P.pool.march_accel(),
+            "brick_page_pool": (pages["capacity"] + 1) * 4.0 / 1024 if pages["capacity"] else 0.0, "brick_pages": pages,
+            "level_grid_and_pyramid": ((256 ** 3) + 2396744) * 8 / GiB, "march_accel": P.pool.march_accel(),
             "device_in_use_all_processes": (total_b - free_b) / GiB, "device_total": total_b / GiB}
 
 
@@ -448,9 +451,12 @@ def main():
     views = [pl.ground_truth_view(k, synth) for k in range(total + extra)]
     mode = pkg.RENDER_REFERENCE if args.render_mode == "reference" else pkg.RENDER_CARRY
     strict = args.tracker == "reference"
+    # pool reservation: room for the map at the end of the stream plus the worst-case reservation of the frames in flight (sum_d min(8^d, n)
+    # splits per frame), so that no fusion waits for a size readback: 2^29 nodes (4 GiB; + 4 GiB of shadow words) for cfg3's 279 M-node
+    # map, the whole 30-bit index range of the node format (8 GiB + 8) for 1080p frames
+    pool_cap = (1 << 29) if width * height <= 400000 else (1 << 30) - 8
     P = pl.SlamPipeline(width, height, max_depth, center, edge, render_mode=mode, dist=dist, count_steps=True, strict_reference=strict,
-                        pool_capacity_nodes=(1 << 30) - 8)   # the whole 30-bit index range of the node format, 8.6 GB of 288 GB: room for
-    # the worst-case reservation of the frames in flight (sum_d min(8^d, n) splits per frame), so no fusion waits for a size readback
+                        pool_capacity_nodes=pool_cap)
 
     per_rank = None
     if emu is not None:   # the records the other ranks would deliver, for the whole stream
@@ -809,7 +815,7 @@ def main():
         try:
             pkg.configure(runner_timeline=1)     # (read when the pipeline's runner is created: at its first stream call, inside the window)
             cur["P"] = pl.SlamPipeline(width, height, max_depth, center, edge, render_mode=mode, count_steps=True, strict_reference=strict,
-                                       pool_capacity_nodes=(1 << 30) - 8)
+                                       pool_capacity_nodes=pool_cap)
             timed_window(t0w)
             tl = cur["P"]._runner.timeline()
             if len(tl) == K:
@@ -829,7 +835,7 @@ def main():
     if single and strict and not args.no_overlap and not args.no_corrected_line and not args.include_h2d and not args.lean:
         try:
             cur["P"] = pl.SlamPipeline(width, height, max_depth, center, edge, render_mode=mode, count_steps=True, strict_reference=False,
-                                       pool_capacity_nodes=(1 << 30) - 8)
+                                       pool_capacity_nodes=pool_cap)
             r2 = [timed_window(t0w) for _ in range(min(R, 3))]
             e2 = sorted(r["elapsed"] for r in r2)[(len(r2) - 1) // 2]
             m2 = [r for r in r2 if r["elapsed"] == e2][0]
@@ -850,7 +856,7 @@ def main():
         try:
             d2 = pl.DistContext(rank, world, force=force_dist, exchange=oex)
             cur["P"] = pl.SlamPipeline(width, height, max_depth, center, edge, render_mode=mode, dist=d2, count_steps=True,
-                                       pool_capacity_nodes=(1 << 30) - 8)
+                                       pool_capacity_nodes=pool_cap)
             r2 = [timed_window(t0w) for _ in range(min(R, 3))]
             e2 = sorted(r["elapsed"] for r in r2)[(len(r2) - 1) // 2]
             other = {"exchange": oex, "value": K / e2, "unit": "frames/s", "ms_per_step": e2 / K * 1e3, "runs": [K / r["elapsed"] for r in r2],
