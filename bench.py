@@ -251,16 +251,13 @@ def cpu_baseline(depth_frames, rgb_frames, views, first, width, height, max_dept
 
 def device_memory(P, torch):
     """what the session holds on the device: the pool's reservation, the deferred commits' shadow array (8 B per
-    node of capacity, when deferred commits are on), the occupancy bricks' page pool (round 6: svoslam_config.brick_pages pages of 4 MB
-    + the zero page; `brick_pages` = pages in use / capacity / requests it could not serve), the level grid + pyramid, and what the
-    process has allocated in total"""
+    node of capacity, when deferred commits are on), the occupancy bricks' dense field (2 x 2048^3 bytes, taken only when three times
+    its size is free), the level grid (256^3 x 8 B), and what the process has allocated in total"""
     GiB = float(1 << 30)
     free_b, total_b = torch.cuda.mem_get_info()
     cap = int(P.pool.capacity)
-    pages = P.pool.brick_pages()
     return {"pool_reserved": cap * 8 / GiB, "pool_used": int(P.pool.size) * 8 / GiB, "deferred_shadow_if_on": cap * 8 / GiB,
-            "brick_page_pool": (pages["capacity"] + 1) * 4.0 / 1024 if pages["capacity"] else 0.0, "brick_pages": pages,
-            "level_grid_and_pyramid": ((256 ** 3) + 2396744) * 8 / GiB, "march_accel": P.pool.march_accel(),
+            "brick_field_if_taken": 16.0, "level_grid": (256 ** 3) * 8 / GiB, "march_accel": P.pool.march_accel(),
             "device_in_use_all_processes": (total_b - free_b) / GiB, "device_total": total_b / GiB}
 
 

@@ -73,9 +73,7 @@ typedef struct svoslam_config {
                                current one and two reached by advancing with the previous step's level, their entries requested
                                together -- and follows the burst as long as each step ends on that level (results identical; overlaps
                                the round trips of a render's long rays); -1: one sample per iteration throughout */
-  int32_t brick_pages;      /* pages (4 MB each) of a pool's occupancy-brick pool: 0 = default (768 = 3 GiB), at most 4094 (the whole
-                               window of 16^3 pages); a page is used when the first brick inside it is written */
-  int32_t reserved[3];
+  int32_t reserved[4];
 } svoslam_config;
 int svoslam_config_get(svoslam_config *out);
 int svoslam_config_set(const svoslam_config *in);
@@ -133,10 +131,6 @@ int svoslam_pool_touch(svoslam_pool *pool);
  * deeper than any shape), -1 the field could not be allocated -- the pool is marched through the tree (correct, slower);
  * *brick_shift = the shape (0: depth <= 12, 1: depth 13 / 14, -1: none).  Any of the pointers may be NULL. */
 int svoslam_pool_march_accel(const svoslam_pool *pool, int32_t *has_grid, int32_t *brick_state, int32_t *brick_shift);
-/* The occupancy bricks' page pool (round 6): pages of 4 MB in use, pages in the pool (svoslam_config.brick_pages when it was created),
- * and page requests the pool could not serve (the space of such a page is marched through the tree: correct, slower; a larger
- * brick_pages avoids it).  Zeros for a pool without bricks.  Blocking (device synchronise + a 8-byte read). */
-int svoslam_pool_brick_pages(const svoslam_pool *pool, int32_t *used, int32_t *capacity, int32_t *unserved);
 /* Replaces the pool's contents by num_nodes host nodes (2 words each, reference format; child pointers validated) and
  * resets all size bookkeeping incl. the device-resident size the asynchronous fusion allocates from.  Blocking. */
 int svoslam_pool_set_nodes(svoslam_pool *pool, const uint32_t *h_words, int32_t num_nodes, void *stream);

@@ -82,7 +82,6 @@ SIGNATURES = {
     "svoslam_pool_save": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _fp, _f32, _i32, _vp]),
     "svoslam_pool_touch": (C.c_int, [C.POINTER(_PoolStruct)]),
     "svoslam_pool_march_accel": (C.c_int, [C.POINTER(_PoolStruct), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
-    "svoslam_pool_brick_pages": (C.c_int, [C.POINTER(_PoolStruct), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "svoslam_pool_set_nodes": (C.c_int, [C.POINTER(_PoolStruct), C.POINTER(C.c_uint32), _i32, _vp]),
     "svoslam_pool_evict_subtree": (C.c_int, [C.POINTER(_PoolStruct), C.POINTER(C.c_uint8), _i32, C.c_char_p, _vp]),
     "svoslam_pool_restore_subtree": (C.c_int, [C.POINTER(_PoolStruct), C.c_char_p, _vp]),
@@ -282,7 +281,7 @@ def _fa(values, n):
 class ConfigStruct(C.Structure):
     """include/svoslam.h svoslam_config"""
     _fields_ = [(n, C.c_int32) for n in ("march_bricks", "track_mode", "track_workers", "track_stream", "runner_deferred", "runner_lead",
-                                         "runner_prio", "runner_replicas", "runner_timeline", "sort_pairs", "graphs", "march_ahead", "brick_pages")] + [("reserved", C.c_int32 * 3)]
+                                         "runner_prio", "runner_replicas", "runner_timeline", "sort_pairs", "graphs", "march_ahead")] + [("reserved", C.c_int32 * 4)]
 
 
 def get_config():
@@ -397,12 +396,6 @@ class Pool:
         g, b, sh = C.c_int32(0), C.c_int32(0), C.c_int32(-1)
         check(lib().svoslam_pool_march_accel(C.byref(self._p), C.byref(g), C.byref(b), C.byref(sh)))
         return {"grid": bool(g.value), "bricks": int(b.value), "brick_shift": int(sh.value)}
-
-    def brick_pages(self):
-        """the occupancy bricks' page pool: {used, capacity, unserved} (svoslam_pool_brick_pages; blocking)"""
-        u, c, n = C.c_int32(0), C.c_int32(0), C.c_int32(0)
-        check(lib().svoslam_pool_brick_pages(C.byref(self._p), C.byref(u), C.byref(c), C.byref(n)))
-        return {"used": int(u.value), "capacity": int(c.value), "unserved": int(n.value)}
 
     def expand(self, center, edge_length, toward):
         """doubles the root cube towards `toward` (re-rooting); returns the new (center, edge_length)"""

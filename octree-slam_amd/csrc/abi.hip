@@ -124,10 +124,6 @@ int svoslam_pool_touch(svoslam_pool *pool) {
   pool_accel_invalidate(pool);
   return SVOSLAM_OK;
 }
-int svoslam_pool_brick_pages(const svoslam_pool *pool, int32_t *used, int32_t *capacity, int32_t *unserved) {
-  if (!pool) return SVOSLAM_ERR_INVALID_ARG;
-  return pool_accel_brick_pages(pool->d_data, used, capacity, unserved);
-}
 int svoslam_pool_march_accel(const svoslam_pool *pool, int32_t *has_grid, int32_t *brick_state, int32_t *brick_shift) {
   if (!pool) return SVOSLAM_ERR_INVALID_ARG;
   const std::shared_ptr<PoolAccel> pa = pool_accel_find(pool->d_data);

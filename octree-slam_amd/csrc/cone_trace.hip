@@ -729,7 +729,6 @@ struct MarchSample {
 template <int THREADS, bool LOD_ALWAYS, int S, int B>  // B: samples per burst past the first P.spec_from steps (0: none); LOD_ALWAYS: every pixel size this render can form is in the fast LOD form's range (checked by the host)
 __global__ __launch_bounds__(THREADS, SVO_AHEAD_WAVES) void cone_trace_brick_kernel(uchar4 *__restrict__ pos, const uint32_t *__restrict__ octree,
                                                                    const uint2 *__restrict__ grid, const uint16_t *__restrict__ bricks,
-                                                                   const uint32_t *__restrict__ pages,
                                                                    const float *__restrict__ table, const float *__restrict__ alpha_lut_g,
                                                                    TraceParams P, unsigned long long *__restrict__ counters,
                                                                    unsigned long long *__restrict__ slots) {
@@ -743,28 +742,19 @@ __global__ __launch_bounds__(THREADS, SVO_AHEAD_WAVES) void cone_trace_brick_ker
   const long long c_entry = clock64();
 #endif
   __shared__ float alpha_lut[256];
-  // split planes of the three axes; then, per axis, what a cell coordinate contributes to the address of its brick entry: bits 0..19
-  // = its share of the DWORD index inside the page (brick_page_offset() >> 1; bit 0 of x picks the half), bits 20.. = its share of
-  // the page's index in the table (4 bits per axis) -- one OR of three LDS reads gives both; then the page table: page of a window
-  // cell -> its 4 MB in the pool (0 = the all-zero page: no brick there).  Round 6: pages instead of a dense field.
+  // split planes of the three axes, then what each axis' rank contributes to the DWORD index of its brick entry
+  // (brick_entry_index() >> 1: the field has 2^33 entries; bit 0 of the x rank picks the half)
   __shared__ float lds_tab[3 * kLdsStride + 3 * kCells];
-  // (the page table in DYNAMIC shared memory, ahead of the launch's pad: with it among the static arrays the compiler sees that only two
-  // workgroups fit a CU, gives up the six-wavefront register budget and takes up to 128 VGPRs -- the neighbours' problem, lesson 17)
-  extern __shared__ uint16_t page_of[];
   uint32_t *spread = reinterpret_cast<uint32_t *>(lds_tab + 3 * kLdsStride);
   if (threadIdx.x < 256) alpha_lut[threadIdx.x] = alpha_lut_g[threadIdx.x];
   {
     const float *src = table + 3 * kTabStride;
     for (int i = threadIdx.x; i < 3 * kLdsStride; i += THREADS) lds_tab[i] = src[i];
     for (int i = threadIdx.x; i < kCells; i += THREADS) {
-      const uint32_t r = (uint32_t)i, lo = r & 127u, pg = r >> kBrickPageShift;
-      spread[i] = (brick_page_offset(lo, 0u, 0u) >> 1) | (pg << 20);
-      spread[kCells + i] = (brick_page_offset(0u, lo, 0u) >> 1) | (pg << 24);
-      spread[2 * kCells + i] = (brick_page_offset(0u, 0u, lo) >> 1) | (pg << 28);
-    }
-    for (int i = threadIdx.x; i < kBrickPageTableEntries; i += THREADS) {
-      const uint32_t v = pages[i];
-      page_of[i] = (uint16_t)(v >= kBrickPageNone ? 0u : v);
+      const uint32_t r = (uint32_t)i;
+      spread[i] = (uint32_t)(brick_entry_index(r, 0u, 0u) >> 1);
+      spread[kCells + i] = (uint32_t)(brick_entry_index(0u, r, 0u) >> 1);
+      spread[2 * kCells + i] = (uint32_t)(brick_entry_index(0u, 0u, r) >> 1);
     }
   }
   __syncthreads();
@@ -821,8 +811,7 @@ __global__ __launch_bounds__(THREADS, SVO_AHEAD_WAVES) void cone_trace_brick_ker
         if ((x | y | z) >= kBrickWindowCells) return 0u;
       }
       const uint32_t d = spread[x] | spread[kCells + y] | spread[2 * kCells + z];
-      const uint32_t dw = ((uint32_t)page_of[d >> 20] << 20) | (d & 0xFFFFFu);   // DWORD index in the pool (<= 4094 pages: 32 bits)
-      return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(bricks) + (((size_t)dw << 2) | ((x & 1u) << 1)));
+      return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(bricks) + (((size_t)d << 2) | ((x & 1u) << 1)));
     };
     // the answers of a sample's two entries: `depth` / `retired` when one of them decides (return value); oct12 = the
     // sample's level-12 octant (read only when the brick's walk ends at level 12; 0 unless some lane's LOD reaches 12).
@@ -1057,8 +1046,7 @@ __global__ __launch_bounds__(THREADS, SVO_AHEAD_WAVES) void cone_trace_brick_ker
           x = inwin ? x : 0u; y = inwin ? y : 0u; z = inwin ? z : 0u;
         }
         const uint32_t d = spread[x] | spread[kCells + y] | spread[2 * kCells + z];
-        const uint32_t dw = ((uint32_t)page_of[d >> 20] << 20) | (d & 0xFFFFFu);
-        const char *at = use ? reinterpret_cast<const char *>(bricks) + (((size_t)dw << 2) | ((x & 1u) << 1)) : zero_entry;
+        const char *at = use ? reinterpret_cast<const char *>(bricks) + (((size_t)d << 2) | ((x & 1u) << 1)) : zero_entry;
         q.e = *reinterpret_cast<const uint16_t *>(at);
         q.have_e = with_brick ? 1u : 0u;
       };
@@ -1296,9 +1284,7 @@ __global__ __launch_bounds__(THREADS, SVO_AHEAD_WAVES) void cone_trace_brick_ker
 #endif
 constexpr int kAheadBurst = SVO_AHEAD_BURST;   // samples per burst of cone_trace_brick_kernel past P.spec_from
 constexpr int kBrickMarchStaticLds = 1024 + 4 * (3 * lds_stride(11) + 3 * lds_cells(11));  // alpha_lut + lds_tab of cone_trace_brick_kernel
-constexpr int kBrickMarchPageLds = 2 * kBrickPageTableEntries;                             // + its page table (dynamic, ahead of the pad)
-// the pad, from the device's own LDS size (none on gfx950's 160 KB per CU since the page table joined: 58 KB per workgroup;
-// a part with another size gets the pad
+// the pad, from the device's own LDS size (6144 bytes on gfx950's 160 KB per CU; a part with another size gets the pad
 // that leaves exactly two workgroups there, or none where two do not fit anyway)
 static int brick_march_lds_pad() {
   static int pad = -1;
@@ -1310,12 +1296,10 @@ static int brick_march_lds_pad() {
     lds = (size_t)prop.maxSharedMemoryPerMultiProcessor;
   else
     (void)hipGetLastError();
-  constexpr long long kUsed = kBrickMarchStaticLds + kBrickMarchPageLds;
-  long long p = (long long)(lds / 3) + 1 - kUsed;   // three workgroups no longer fit
+  long long p = (long long)(lds / 3) + 1 - kBrickMarchStaticLds;   // three workgroups no longer fit
   p = p < 0 ? 0 : ((p + 255) / 256) * 256;
-  constexpr long long kTunedTotal = 56340;   // LDS per workgroup the round-5 / 6 measurements were taken with (then: 50 196 static + 6144)
-  if (p > 0 && kUsed + p < kTunedTotal && 2 * kTunedTotal <= (long long)lds) p = kTunedTotal - kUsed;
-  if (2 * (kUsed + p) > (long long)lds || kUsed + p > 64 * 1024) p = 0;
+  if (p > 0 && p < 6144 && 2 * (kBrickMarchStaticLds + 6144) <= (long long)lds) p = 6144;   // (the value the round-5 measurements were taken with)
+  if (2 * (kBrickMarchStaticLds + p) > (long long)lds || kBrickMarchStaticLds + p > 64 * 1024) p = 0;
   if (getenv("SVOSLAM_DEBUG_LDS")) fprintf(stderr, "svoslam: LDS per CU %zu bytes, brick march pad %lld\n", lds, p);
   pad = (int)p;
   return pad;
@@ -1449,7 +1433,6 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   float *alpha_lut = d_table + 3 * (kTabStride + kLdsStrideMax);
   const uint2 *d_grid = own_grid;
   const uint16_t *d_bricks = nullptr;
-  const uint32_t *d_brick_pages = nullptr;
   int brick_shift = -1;
   const bool tables_match = sa->tables_valid && sa->tables_at == d_table && sa->lds_depth == P.lds_depth && sa->size == size &&
                             sa->center[0] == center[0] && sa->center[1] == center[1] && sa->center[2] == center[2];
@@ -1474,7 +1457,7 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
   }
   if (pa) {
     SVO_TRY(pool_accel_refresh(pa, d_octree, stream, &d_grid, (mode & 0xFF) == SVOSLAM_RENDER_REFERENCE, &d_bricks, &brick_shift,
-                               tile_cost, tile_order, tile_cost ? n_tiles : 0, &order_done, &d_brick_pages));
+                               tile_cost, tile_order, tile_cost ? n_tiles : 0, &order_done));
     if (!tables_match) build_tables_kernel<<<(int)cdiv(3 * (kTabStride + kLdsStrideMax) + 256 + 4, 256), 256, 0, stream>>>(d_table, alpha_lut, P);
   } else {
     const int build_blocks = (int)cdiv(own_total + 3 * (kTabStride + kLdsStrideMax) + 256 + 4, 256);
@@ -1506,7 +1489,7 @@ int cone_trace_svo(uint8_t *d_pos, int width, int height, int row_first, int row
       P.tile_cost = tile_cost; P.tile_order = tile_order;
     }
     auto launch = [&](auto kernel) {
-      kernel<<<grid, kTraceThreads, (size_t)(kBrickMarchPageLds + brick_march_lds_pad()), stream>>>(out, d_octree, d_grid, d_bricks, d_brick_pages, d_table, alpha_lut, P, d_steps, slots);
+      kernel<<<grid, kTraceThreads, (size_t)brick_march_lds_pad(), stream>>>(out, d_octree, d_grid, d_bricks, d_table, alpha_lut, P, d_steps, slots);
     };
     // svoslam_config.march_ahead: < 0 = cone_trace_brick_kernel; n >= 0 = the march one sample ahead from step n + 1 on
     const int ahead = config().march_ahead;

@@ -20,13 +20,11 @@ const Field kFields[] = {
     {"runner_prio", &svoslam_config::runner_prio}, {"runner_replicas", &svoslam_config::runner_replicas},
     {"runner_timeline", &svoslam_config::runner_timeline}, {"sort_pairs", &svoslam_config::sort_pairs},
     {"graphs", &svoslam_config::graphs}, {"march_ahead", &svoslam_config::march_ahead},
-    {"brick_pages", &svoslam_config::brick_pages},
 };
 
 bool config_valid(const svoslam_config &c) {
   if (c.runner_replicas != 1 && c.runner_replicas != 2) return false;
   if (c.track_mode < 0 || c.track_mode > 2 || c.track_workers < 0) return false;
-  if (c.brick_pages < 0 || c.brick_pages > 4094) return false;
   return true;
 }
 

@@ -21,7 +21,7 @@ PoolAccel::~PoolAccel() {
   shadow.release();
   for (uint32_t *d : d_dirty) if (d) (void)hipFree(d);
   if (bricks) (void)hipFree(bricks);
-  if (d_brick_pages) (void)hipFree(d_brick_pages);
+  if (d_brick_touched) (void)hipFree(d_brick_touched);
   if (ev_order) (void)hipEventDestroy(ev_order);
 }
 
@@ -250,7 +250,7 @@ __device__ inline uint32_t brick_level8(const uint2 *__restrict__ nodes, uint2 g
 // seven level-9 siblings from the leaf kernel instead, a divergent loop of atomics at that kernel's end.
 template <int S>
 __device__ inline void brick_siblings(const uint2 *__restrict__ nodes, const uint2 *__restrict__ grid, uint16_t *__restrict__ bricks,
-                                            const BrickPages pg, uint32_t xr, uint32_t yr, uint32_t zr, unsigned lane) {
+                                            uint32_t *__restrict__ touched, uint32_t xr, uint32_t yr, uint32_t zr, unsigned lane) {
   constexpr int G = kPoolGridLevel, NL = brick_node_level(S);
   constexpr uint32_t kOrg = brick_window_origin(S) >> 2;
   const uint32_t xa = xr + kOrg, ya = yr + kOrg, za = zr + kOrg;
@@ -268,22 +268,22 @@ __device__ inline void brick_siblings(const uint2 *__restrict__ nodes, const uin
     const uint32_t m = ~((2u << sh) - 1u);
     const uint32_t sx = (xr & m) | ((q & 1u) << sh), sy = (yr & m) | (((q >> 1) & 1u) << sh), sz = (zr & m) | ((q >> 2) << sh);
     bool need = lane < 8u && q != oct && !(sib.x & kFlag);
-    if (need) need = *brick_entry_ptr(bricks, brick_page_lookup(pg, brick_page_index(sx << 2, sy << 2, sz << 2)), sx << 2, sy << 2, sz << 2) != (uint16_t)want;
+    if (need) need = bricks[brick_entry_index(sx << 2, sy << 2, sz << 2)] != (uint16_t)want;
     unsigned long long todo = __ballot(need);
     while (todo) {
       const int src = __ffsll((long long)todo) - 1;
       todo &= todo - 1ull;
       const uint32_t bx = (uint32_t)__shfl((int)sx, src), by = (uint32_t)__shfl((int)sy, src), bz = (uint32_t)__shfl((int)sz, src);
       const uint32_t val = (uint32_t)__shfl((int)want, src);
-      const uint32_t span = 1u << sh;  // bricks per axis under the sibling (an aligned cube of <= 2^3 bricks: inside ONE page)
-      uint32_t page = 0;
-      if (lane == 0) page = brick_page_acquire(pg, brick_page_index(bx << 2, by << 2, bz << 2));
-      page = (uint32_t)__shfl((int)page, 0);
-      if (page == 0u) continue;  // (no page left in the pool: these lines stay unwritten, the march walks the tree there)
+      const uint32_t span = 1u << sh;  // bricks per axis under the sibling
       for (uint32_t dz = 0; dz < span; dz++)
         for (uint32_t dy = 0; dy < span; dy++)
           for (uint32_t dx = 0; dx < span; dx++)
-            *brick_entry_ptr(bricks, page, ((bx + dx) << 2) | (lane & 3u), ((by + dy) << 2) | ((lane >> 2) & 3u), ((bz + dz) << 2) | (lane >> 4)) = (uint16_t)val;
+            bricks[brick_entry_index(((bx + dx) << 2) | (lane & 3u), ((by + dy) << 2) | ((lane >> 2) & 3u), ((bz + dz) << 2) | (lane >> 4))] = (uint16_t)val;
+      if (lane == 0) {
+        const uint32_t grp = ((bz >> 3) << (2 * kBrickGroupLevel)) | ((by >> 3) << kBrickGroupLevel) | (bx >> 3);
+        if (!((touched[grp >> 5] >> (grp & 31u)) & 1u)) atomicOr(&touched[grp >> 5], 1u << (grp & 31u));
+      }
     }
     // on along the path
     const uint2 w = make_uint2((uint32_t)__shfl((int)sib.x, (int)oct), (uint32_t)__shfl((int)sib.y, (int)oct));
@@ -295,7 +295,7 @@ __device__ inline void brick_siblings(const uint2 *__restrict__ nodes, const uin
 
 template <int N, int S>
 __device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint2 *__restrict__ grid, uint16_t *__restrict__ bricks,
-                                     const BrickPages pg, const uint32_t (&xr)[N], const uint32_t (&yr)[N], const uint32_t (&zr)[N],
+                                     uint32_t *__restrict__ touched, const uint32_t (&xr)[N], const uint32_t (&yr)[N], const uint32_t (&zr)[N],
                                      const bool (&live)[N], unsigned lane, bool trust_mip) {
   constexpr int G = kPoolGridLevel, NL = brick_node_level(S);
   constexpr uint32_t kOrg = brick_window_origin(S) >> 2;  // in bricks
@@ -355,7 +355,7 @@ __device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint
 #ifdef SVO_BRICK_DIAG
     {  // cell-level nodes with children, and how many of them are saturated (would their tiles have to be read?)
       const unsigned long long m12 = __ballot(on12[k]), msat = __ballot(on12[k] && (w11[k].y >> 24) >= 254u);
-      if (lane == 0) { atomicAdd(&pg.table[kBrickPageTableEntries + 5], (uint32_t)__popcll(m12)); atomicAdd(&pg.table[kBrickPageTableEntries + 6], (uint32_t)__popcll(msat)); }
+      if (lane == 0) { atomicAdd(&touched[kBrickGroupWords + 3], (uint32_t)__popcll(m12)); atomicAdd(&touched[kBrickGroupWords + 4], (uint32_t)__popcll(msat)); }
     }
 #endif
     if (on12[k]) v[k] |= 4u;
@@ -378,21 +378,18 @@ __device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint
     const uint32_t cx = (xr[k] << 2) | (((lane >> 3) & 1u) << 1) | (lane & 1u);
     const uint32_t cy = (yr[k] << 2) | (((lane >> 4) & 1u) << 1) | ((lane >> 1) & 1u);
     const uint32_t cz = (zr[k] << 2) | (((lane >> 5) & 1u) << 1) | ((lane >> 2) & 1u);
-    // the brick's page: looked up (taken from the pool on first use) by one lane
-    uint32_t page = 0;
-    if (lane == 0) page = brick_page_acquire(pg, brick_page_index(xr[k] << 2, yr[k] << 2, zr[k] << 2));
-    page = (uint32_t)__shfl((int)page, 0);
-    if (page == 0u) continue;  // (no page left in the pool: the march walks the tree through this brick)
-    uint16_t *entry = brick_entry_ptr(bricks, page, cx, cy, cz);
 #ifdef SVO_BRICK_DIAG
     {  // how many rebuilt bricks actually change (diagnostic build)
-      const bool diff = *entry != (uint16_t)v[k];
+      const bool diff = bricks[brick_entry_index(cx, cy, cz)] != (uint16_t)v[k];
       const unsigned long long dm = __ballot(diff);
-      uint32_t *ctr = pg.table + kBrickPageTableEntries + 2;
-      if (lane == 0) { atomicAdd(&ctr[0], 1u); if (dm) atomicAdd(&ctr[1], 1u); atomicAdd(&ctr[2], (uint32_t)__popcll(dm)); }
+      if (lane == 0) { atomicAdd(&touched[kBrickGroupWords], 1u); if (dm) atomicAdd(&touched[kBrickGroupWords + 1], 1u); atomicAdd(&touched[kBrickGroupWords + 2], (uint32_t)__popcll(dm)); }
     }
 #endif
-    *entry = (uint16_t)v[k];
+    bricks[brick_entry_index(cx, cy, cz)] = (uint16_t)v[k];
+    if (lane == 0) {
+      const uint32_t grp = ((zr[k] >> 3) << (2 * kBrickGroupLevel)) | ((yr[k] >> 3) << kBrickGroupLevel) | (xr[k] >> 3);
+      if (!((touched[grp >> 5] >> (grp & 31u)) & 1u)) atomicOr(&touched[grp >> 5], 1u << (grp & 31u));
+    }
   }
 }
 
@@ -429,7 +426,7 @@ __device__ inline bool brick_rings_lost(uint32_t *dirty_a, uint32_t *dirty_b, in
 // one wavefront per listed brick, C of them side by side; `part` of `parts` wavefronts
 template <int C, int S>
 __device__ inline void brick_rebuild_listed(const uint2 *__restrict__ nodes, const uint2 *__restrict__ grid, uint16_t *__restrict__ bricks,
-                                            const BrickPages pg, uint32_t *dirty_a, uint32_t *dirty_b, const BrickRings &r,
+                                            uint32_t *__restrict__ touched, uint32_t *dirty_a, uint32_t *dirty_b, const BrickRings &r,
                                             uint32_t part, uint32_t parts, unsigned lane, bool trust_mip) {
   for (int state = 0; state < 2; state++) {
     uint32_t *dirty = state ? dirty_b : dirty_a;
@@ -444,7 +441,7 @@ __device__ inline void brick_rebuild_listed(const uint2 *__restrict__ nodes, con
         xs[k] = e & 511u; ys[k] = (e >> 9) & 511u; zs[k] = e >> 18;
         if (live[k] && lane == 0) atomicAnd(&dirty[kBrickBitsOffset + (e >> 5)], ~(1u << (e & 31u)));  // served: may be listed again
       }
-      brick_rebuild<C, S>(nodes, grid, bricks, pg, xs, ys, zs, live, lane, trust_mip);
+      brick_rebuild<C, S>(nodes, grid, bricks, touched, xs, ys, zs, live, lane, trust_mip);
     }
   }
 }
@@ -454,7 +451,7 @@ __device__ inline void brick_rebuild_listed(const uint2 *__restrict__ nodes, con
 // cost the refresh 10-23 us per frame; as a flag in the bricks' ring, found by scanning it, 18 us)
 template <int S>
 __device__ inline void brick_siblings_listed(const uint2 *__restrict__ nodes, const uint2 *__restrict__ grid, uint16_t *__restrict__ bricks,
-                                             const BrickPages pg, const uint32_t *dirty_a, const uint32_t *dirty_b, const BrickRings &r,
+                                             uint32_t *__restrict__ touched, const uint32_t *dirty_a, const uint32_t *dirty_b, const BrickRings &r,
                                              uint32_t part, uint32_t parts, unsigned lane) {
   for (int state = 0; state < 2; state++) {
     const uint32_t *dirty = state ? dirty_b : dirty_a;
@@ -462,7 +459,7 @@ __device__ inline void brick_siblings_listed(const uint2 *__restrict__ nodes, co
     const uint32_t first = r.first[state];
     for (uint32_t i = part; i < pending; i += parts) {
       const uint32_t f = dirty[kSibListOffset + ((first + i) & (uint32_t)(kSibListCap - 1))] & 0x07FFFFFFu;
-      brick_siblings<S>(nodes, grid, bricks, pg, f & 511u, (f >> 9) & 511u, f >> 18, lane);
+      brick_siblings<S>(nodes, grid, bricks, touched, f & 511u, (f >> 9) & 511u, f >> 18, lane);
     }
   }
 }
@@ -472,7 +469,7 @@ __device__ inline void brick_siblings_listed(const uint2 *__restrict__ nodes, co
 // the window).  Everything listed so far in the served states is served by this pass.
 template <int S>
 __global__ __launch_bounds__(kBrickThreads) void brick_rebuild_kernel(const uint32_t *__restrict__ octree, const uint2 *__restrict__ grid,
-                                                                      uint16_t *__restrict__ bricks, const BrickPages pg,
+                                                                      uint16_t *__restrict__ bricks, uint32_t *__restrict__ touched,
                                                                       uint32_t *__restrict__ dirty_a, uint32_t *__restrict__ dirty_b,
                                                                       int trust_mip, int par_a, int par_b) {
   const uint2 *nodes = reinterpret_cast<const uint2 *>(octree);
@@ -505,23 +502,23 @@ __global__ __launch_bounds__(kBrickThreads) void brick_rebuild_kernel(const uint
           xs[o] = ((px << 1) | (o & 1u)) - kOrg; ys[o] = ((py << 1) | ((o >> 1) & 1u)) - kOrg; zs[o] = ((pz << 1) | (o >> 2)) - kOrg;
           live[o] = (xs[o] | ys[o] | zs[o]) < kSpan;
         }
-        if (live[0]) brick_rebuild<8, S>(nodes, grid, bricks, pg, xs, ys, zs, live, lane, trust_mip != 0);  // (aligned groups: all eight in or out; this pass visits the siblings itself)
+        if (live[0]) brick_rebuild<8, S>(nodes, grid, bricks, touched, xs, ys, zs, live, lane, trust_mip != 0);  // (aligned groups: all eight in or out; this pass visits the siblings itself)
       }
     }
   }
 }
 
-// zero the pages in use (before every brick is rebuilt: what they say about a pool that has been reset / reloaded / re-rooted since
-// is stale); brick_pages_reset_kernel, behind it, then hands them all back: an empty table, the counter at zero
-__global__ __launch_bounds__(256) void brick_clear_kernel(uint16_t *__restrict__ bricks, const BrickPages pg) {
-  uint32_t used = pg.table[kBrickPageTableEntries];
-  if (used > pg.cap) used = pg.cap;
-  const size_t chunks = (size_t)used * (kBrickPageBytes / 16);   // 16-byte chunks of pages 1 .. used
-  uint4 *p = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(bricks) + kBrickPageBytes);
-  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < chunks; i += (size_t)gridDim.x * 256u) p[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-__global__ __launch_bounds__(256) void brick_pages_reset_kernel(const BrickPages pg) {
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)(kBrickPageTableEntries + 2); i += gridDim.x * 256u) pg.table[i] = 0u;
+// zero the 64 KB groups that hold bricks (before every brick is rebuilt: what the field says about a pool that has been
+// reset / reloaded / re-rooted since is stale) and clear their bits
+__global__ __launch_bounds__(256) void brick_clear_kernel(uint16_t *__restrict__ bricks, uint32_t *__restrict__ touched) {
+  for (uint32_t grp = blockIdx.x; grp < (uint32_t)kBrickGroups; grp += gridDim.x) {
+    const bool set = (touched[grp >> 5] >> (grp & 31u)) & 1u;
+    __syncthreads();
+    if (!set) continue;
+    uint4 *p = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(bricks) + (size_t)grp * kBrickGroupBytes);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(kBrickGroupBytes / 16); i += 256u) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x == 0) atomicAnd(&touched[grp >> 5], ~(1u << (grp & 31u)));
+  }
 }
 
 // one WORKGROUP per listed block (the list is compacted from the bitmap at the end of every commit), one cell per lane:
@@ -588,7 +585,7 @@ __global__ __launch_bounds__(kUpdateThreads) void pool_grid_update_kernel(const 
 constexpr int kRefreshBrickBlocks = kBrickBlocks, kRefreshGridBlocks = 1024, kRefreshChains = kBrickChains;
 template <int C, int S>
 __global__ __launch_bounds__(kBrickThreads) void pool_refresh_kernel(const uint32_t *__restrict__ octree, uint2 *grid, uint16_t *__restrict__ bricks,
-                                                                      const BrickPages pg, uint32_t *dirty_a, uint32_t *dirty_b,
+                                                                      uint32_t *__restrict__ touched, uint32_t *dirty_a, uint32_t *dirty_b,
                                                                       int trust_mip, int par_a, int par_b, unsigned brick_blocks,
                                                                       uint32_t *__restrict__ tile_cost, uint32_t *__restrict__ tile_order, int n_tiles) {
   if (n_tiles > 0 && blockIdx.x == gridDim.x - 1) { tile_order_block(tile_cost, tile_order, n_tiles); return; }  // (the march's tile order: pool_grid.hpp)
@@ -602,7 +599,7 @@ __global__ __launch_bounds__(kBrickThreads) void pool_refresh_kernel(const uint3
     // ... and the childless siblings of the listed bricks whose commit created them (brick_siblings_listed)
     const BrickRings rs = brick_rings(dirty_a, dirty_b, par_a, par_b, bb == brick_blocks && threadIdx.x == 0, kSibCountOffset);
     if (!brick_rings_lost(dirty_a, dirty_b, par_a, par_b))  // (a lapped ring zeroes every group: nothing to complete)
-      brick_siblings_listed<S>(nodes, grid, bricks, pg, dirty_a, dirty_b, rs, (bb - brick_blocks) * kWaves + wave, kRefreshGridBlocks * kWaves, lane);
+      brick_siblings_listed<S>(nodes, grid, bricks, touched, dirty_a, dirty_b, rs, (bb - brick_blocks) * kWaves + wave, kRefreshGridBlocks * kWaves, lane);
     return;
   }
   const BrickRings r = brick_rings(dirty_a, dirty_b, par_a, par_b, bb == 0 && threadIdx.x == 0);
@@ -614,69 +611,45 @@ __global__ __launch_bounds__(kBrickThreads) void pool_refresh_kernel(const uint3
       if (dirty_a) dirty_a[kBrickBitsOffset + w] = 0u;
       if (dirty_b) dirty_b[kBrickBitsOffset + w] = 0u;
     }
-    {  // (the pages stay with their table entries: zero = "ask the level grid" everywhere)
-      uint32_t used = pg.table[kBrickPageTableEntries];
-      if (used > pg.cap) used = pg.cap;
-      const size_t chunks = (size_t)used * (kBrickPageBytes / 16);
-      uint4 *p = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(bricks) + kBrickPageBytes);
-      for (size_t i = (size_t)bb * kBrickThreads + threadIdx.x; i < chunks; i += (size_t)brick_blocks * kBrickThreads) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t grp = bb; grp < (uint32_t)kBrickGroups; grp += brick_blocks) {
+      if (!((touched[grp >> 5] >> (grp & 31u)) & 1u)) continue;
+      uint4 *p = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(bricks) + (size_t)grp * kBrickGroupBytes);
+      for (uint32_t i = threadIdx.x; i < (uint32_t)(kBrickGroupBytes / 16); i += kBrickThreads) p[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     return;
   }
-  brick_rebuild_listed<C, S>(nodes, grid, bricks, pg, dirty_a, dirty_b, r, bb * kWaves + wave, brick_blocks * kWaves, lane, trust_mip != 0);
+  brick_rebuild_listed<C, S>(nodes, grid, bricks, touched, dirty_a, dirty_b, r, bb * kWaves + wave, brick_blocks * kWaves, lane, trust_mip != 0);
 }
 
 // svoslam_config.march_bricks = 0: no occupancy bricks (the march walks the tree below the level grid, as in round 2)
 static bool bricks_enabled() { return config().march_bricks != 0; }
 
-// The page pool (pool_grid.hpp "PAGES"), allocated by the first reference-mode render of a pool: svoslam_config.brick_pages pages of 4 MB
-// (default 768 = 3 GiB; the 300-frame 640x480 session of BASELINE config 3 uses 92, the 1080p one 43) + the zero page.  It is only taken
-// when it leaves room: after it, at least twice its size must stay free for pool growth, shadow words and the caller's own
-// tensors; a pool that does not get it is marched through the tree (correct, slower), and so is the space of a page the pool had no
-// memory left for (svoslam_pool_brick_pages reports both).
+// The field is 16 GiB of the 288 GB, allocated by the first reference-mode render of a pool.  It is only taken when it leaves
+// room: after it, at least twice its size must stay free for pool growth, shadow words and the caller's own
+// tensors -- several live pools, or ranks / test processes sharing one device, otherwise end in an out-of-memory error far from
+// here; a pool that does not get its field is marched through the tree (correct, slower).
 static void ensure_bricks(PoolAccel *pa, hipStream_t stream) {
   if (pa->bricks || pa->bricks_failed) return;
-  int cap = config().brick_pages;
-  if (cap <= 0) cap = 768;
-  if (cap > kBrickPageMax) cap = kBrickPageMax;
-  const size_t pool_bytes = ((size_t)cap + 1) * kBrickPageBytes, table_bytes = (size_t)(kBrickPageTableEntries + kBrickPageCounters) * 4;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); pa->bricks_failed = true; return; }
-  if (free_b < 3 * pool_bytes) { pa->bricks_failed = true; return; }
-  void *field = nullptr, *table = nullptr;
-  if (hipMalloc(&field, pool_bytes) != hipSuccess || hipMalloc(&table, table_bytes) != hipSuccess ||
-      hipMemsetAsync(field, 0, pool_bytes, stream) != hipSuccess || hipMemsetAsync(table, 0, table_bytes, stream) != hipSuccess) {
-    (void)hipGetLastError();  // no room on this device: the pool is marched through the tree
+  if (free_b < 3 * kBrickFieldBytes) { pa->bricks_failed = true; return; }
+  void *field = nullptr, *touched = nullptr;
+  if (hipMalloc(&field, kBrickFieldBytes) != hipSuccess || hipMalloc(&touched, (kBrickGroupWords + 8) * 4) != hipSuccess ||
+      hipMemsetAsync(field, 0, kBrickFieldBytes, stream) != hipSuccess ||
+      hipMemsetAsync(touched, 0, (kBrickGroupWords + 8) * 4, stream) != hipSuccess) {
+    (void)hipGetLastError();  // no room for the field on this device: the pool is marched through the tree
     if (field) (void)hipFree(field);
-    if (table) (void)hipFree(table);
+    if (touched) (void)hipFree(touched);
     pa->bricks_failed = true;
     return;
   }
   pa->bricks = reinterpret_cast<uint16_t *>(field);
-  pa->d_brick_pages = reinterpret_cast<uint32_t *>(table);
-  pa->brick_page_cap = cap;
+  pa->d_brick_touched = reinterpret_cast<uint32_t *>(touched);
   pa->bricks_valid = false;
 }
 
-// pages handed out / in the pool / requests the pool could not serve (blocking: a 12-byte read behind everything enqueued)
-int pool_accel_brick_pages(const uint32_t *d_data, int32_t *used, int32_t *cap, int32_t *unserved) {
-  const std::shared_ptr<PoolAccel> pa = pool_accel_find(d_data);
-  if (used) *used = 0;
-  if (cap) *cap = 0;
-  if (unserved) *unserved = 0;
-  if (!pa || !pa->bricks) return SVOSLAM_OK;
-  uint32_t c[2] = {0u, 0u};
-  SVO_HIP(hipDeviceSynchronize());
-  SVO_HIP(hipMemcpy(c, pa->d_brick_pages + kBrickPageTableEntries, 8, hipMemcpyDeviceToHost));
-  if (used) *used = (int32_t)(c[0] < (uint32_t)pa->brick_page_cap ? c[0] : (uint32_t)pa->brick_page_cap);
-  if (cap) *cap = pa->brick_page_cap;
-  if (unserved) *unserved = (int32_t)c[1];
-  return SVOSLAM_OK;
-}
-
 int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stream, const uint2 **d_grid, bool want_bricks,
-                       const uint16_t **d_bricks, int *brick_shift, uint32_t *tile_cost, uint32_t *tile_order, int n_tiles, bool *order_done,
-                       const uint32_t **d_brick_pages) {
+                       const uint16_t **d_bricks, int *brick_shift, uint32_t *tile_cost, uint32_t *tile_order, int n_tiles, bool *order_done) {
   if (order_done) *order_done = false;
   if (!pa || !d_octree || !d_grid) return SVOSLAM_ERR_INVALID_ARG;
   constexpr size_t kCells = (size_t)1 << (3 * kPoolGridLevel);
@@ -718,22 +691,20 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
   // the rings' marks alternate per state and refresh (kBrickMarkOffset)
   const int par_a = serve_idx[0] >= 0 ? (int)(pa->brick_served[serve_idx[0]] & 1u) : 0, par_b = serve_idx[1] >= 0 ? (int)(pa->brick_served[serve_idx[1]] & 1u) : 0;
   if (use_bricks) {
-    const BrickPages pg{pa->d_brick_pages, (uint32_t)pa->brick_page_cap};
     const int trust = pa->mip_consistent ? 1 : 0;  // (PoolAccel::mip_consistent: rebuild 65 -> 39 us at cfg3)
     if (bricks_all) {
       if (fresh) pool_grid_build_kernel<<<(unsigned)(kCells / 256), 256, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
       else pool_grid_update_kernel<<<kUpdateBlocks, kUpdateThreads, 0, stream>>>(d_octree, grid, serve[0], serve[1]);
-      brick_clear_kernel<<<2048, 256, 0, stream>>>(pa->bricks, pg);
-      brick_pages_reset_kernel<<<(kBrickPageTableEntries + 2 + 255) / 256, 256, 0, stream>>>(pg);
-      if (shift == 0) brick_rebuild_kernel<0><<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pg, serve[0], serve[1], trust, par_a, par_b);
-      else brick_rebuild_kernel<1><<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pg, serve[0], serve[1], trust, par_a, par_b);
+      brick_clear_kernel<<<2048, 256, 0, stream>>>(pa->bricks, pa->d_brick_touched);
+      if (shift == 0) brick_rebuild_kernel<0><<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], trust, par_a, par_b);
+      else brick_rebuild_kernel<1><<<kBrickBlocks, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], trust, par_a, par_b);
     } else {
       // grid update and brick rebuild in ONE launch.  (Measured and not kept, round 3: the rebuild on a stream of its own beside
       // the march -- rays reach the surfaces before the rebuild does and pay tree walks: march 0.325 -> 0.395 ms; two launches;
       // 4096 workgroups x 2 bricks per wavefront -- kernel 55 -> 40 us, frame rate lower: DESIGN.md section 4.)
       const int extra = tile_cost && tile_order && n_tiles > 0 ? 1 : 0;  // one more workgroup: the tile order of the caller's march
-      if (shift == 0) pool_refresh_kernel<kRefreshChains, 0><<<kRefreshBrickBlocks + kRefreshGridBlocks + extra, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pg, serve[0], serve[1], trust, par_a, par_b, kRefreshBrickBlocks, tile_cost, tile_order, extra ? n_tiles : 0);
-      else pool_refresh_kernel<kRefreshChains, 1><<<kRefreshBrickBlocks + kRefreshGridBlocks + extra, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pg, serve[0], serve[1], trust, par_a, par_b, kRefreshBrickBlocks, tile_cost, tile_order, extra ? n_tiles : 0);
+      if (shift == 0) pool_refresh_kernel<kRefreshChains, 0><<<kRefreshBrickBlocks + kRefreshGridBlocks + extra, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], trust, par_a, par_b, kRefreshBrickBlocks, tile_cost, tile_order, extra ? n_tiles : 0);
+      else pool_refresh_kernel<kRefreshChains, 1><<<kRefreshBrickBlocks + kRefreshGridBlocks + extra, kBrickThreads, 0, stream>>>(d_octree, grid, pa->bricks, pa->d_brick_touched, serve[0], serve[1], trust, par_a, par_b, kRefreshBrickBlocks, tile_cost, tile_order, extra ? n_tiles : 0);
       if (extra && order_done) *order_done = true;
     }
     for (int k = 0; k < 2; k++)
@@ -745,10 +716,10 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
       if (++calls % 50 == 0) {
         uint32_t c[5];
         (void)hipStreamSynchronize(stream);
-        (void)hipMemcpy(c, pa->d_brick_pages + kBrickPageTableEntries + 2, 20, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(c, pa->d_brick_touched + kBrickGroupWords, 20, hipMemcpyDeviceToHost);
         fprintf(stderr, "brick diag after %d refreshes: rebuilt %u bricks, %u of them changed, %u entries changed; %u cell-level nodes with children, %u of them saturated\n",
                 calls, c[0], c[1], c[2], c[3], c[4]);
-        (void)hipMemset(pa->d_brick_pages + kBrickPageTableEntries + 2, 0, 20);
+        (void)hipMemset(pa->d_brick_touched + kBrickGroupWords, 0, 20);
       }
     }
 #endif
@@ -760,7 +731,6 @@ int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stre
   SVO_LAUNCH_CHECK();
   *d_grid = grid;
   if (d_bricks) *d_bricks = use_bricks ? pa->bricks : nullptr;
-  if (d_brick_pages) *d_brick_pages = use_bricks ? pa->d_brick_pages : nullptr;
   if (brick_shift) *brick_shift = use_bricks ? shift : -1;
   return SVOSLAM_OK;
 }

@@ -65,9 +65,8 @@ struct PoolAccel {
   hipEvent_t ev_order = nullptr;
   // occupancy bricks (below): the dense field and the bitmap of the 64 KB groups that hold anything.  Allocated by the
   // first reference-mode render of the pool; bricks_valid = false: rebuild all.
-  uint16_t *bricks = nullptr;           // the page pool: page 0 (all zero = "no brick anywhere in it") + brick_page_cap pages of 4 MB
-  uint32_t *d_brick_pages = nullptr;    // [kBrickPageTableEntries] page ids by window page, then kBrickPageCounters counters (BrickPages)
-  int brick_page_cap = 0;
+  uint16_t *bricks = nullptr;
+  uint32_t *d_brick_touched = nullptr;  // [kBrickGroupWords]
   bool bricks_valid = false;
   unsigned brick_served[2] = {0u, 0u};  // how often each dirty state's ring has been served (its parity picks the mark: kBrickMarkOffset)
   bool bricks_failed = false;           // the field could not be allocated: this pool is marched through the tree
@@ -113,9 +112,7 @@ bool pool_shadow_pending(svoslam_pool *pool);
 // nullptr when the pool has none (not wanted so far, svoslam_config.march_bricks = 0, or no memory for them)
 int pool_accel_refresh(PoolAccel *pa, const uint32_t *d_octree, hipStream_t stream, const uint2 **d_grid, bool want_bricks,
                        const uint16_t **d_bricks, int *brick_shift, uint32_t *tile_cost = nullptr, uint32_t *tile_order = nullptr,
-                       int n_tiles = 0, bool *order_done = nullptr, const uint32_t **d_brick_pages = nullptr);
-// *d_brick_pages: the page table of *d_bricks (kBrickPageTableEntries ids; the march copies it into LDS)
-int pool_accel_brick_pages(const uint32_t *d_data, int32_t *used, int32_t *cap, int32_t *unserved);  // (blocking)
+                       int n_tiles = 0, bool *order_done = nullptr);
 // tile_cost / tile_order / n_tiles (optional): the caller's march takes its tiles costliest-first (cone_trace.hip TraceParams); the
 // incremental refresh launch brings the order up to date in one extra workgroup (*order_done = true), other forms leave it to the caller  // *brick_shift: the shape of *d_bricks (pool_grid.hpp "Shapes")
 
@@ -153,11 +150,12 @@ constexpr int kPoolGridStateWords = kSibListOffset + kSibListCap;
 //   bits 4-6  A >= 254 of the path's nodes at levels 9 / 10 / 11
 //   bits 8-15 A >= 254 of the eight level-12 children (octant order)
 // so a step whose LOD lies in 9..12 costs ONE 2-byte load, whatever the depth of the tree.  Bricks are addressed, not
-// allocated one by one: brick (x9, y9, z9) lives at a fixed place of its 4 MB PAGE (see "PAGES" below; until round 5: of a dense 16 GiB
-// field), zero = "ask the level grid", so nothing is built for space the map never reaches.  Upkeep rides on the level grid's: the leaf kernel of a commit appends the level-9 prefix of every run of keys
+// allocated: brick (x9, y9, z9) lives at a fixed place of a dense 2 x 2048^3-byte field (16 GiB of the 288 GB; bricks of
+// one level-6 cube are 64 KB contiguous), zero = "ask the level grid", so nothing is built for space the map never
+// reaches.  Upkeep rides on the level grid's: the leaf kernel of a commit appends the level-9 prefix of every run of keys
 // to a list (each change of a commit lies on the path of one of its keys), the refresh of the level grid adds the eight
 // children of level-8 nodes that have just been split, and one wavefront per listed node rewrites its line before the
-// march.  Anything that invalidates the level grid clears the pages in use and rebuilds every brick.
+// march.  Anything that invalidates the level grid clears the touched 64 KB groups and rebuilds every brick.
 // Shapes (round 4): shift s = 0 is the shape above; s = 1 moves every level down by one (bricks of level-10 nodes, level-12
 // cells, bits for the level-13 children) for pools fused to depth 13 / 14, and adds what the gap between the level-8 grid
 // and the brick node needs: stop code 5 = "the level-9 node on the path is childless", and bit 7 = A >= 254 of the level-(11 + s)
@@ -166,6 +164,7 @@ constexpr int kPoolGridStateWords = kSibListOffset + kSibListCap;
 // (half its edge: 8.2 m of the 16.4 m root of BASELINE config 4); a sample outside the window has no brick entry and takes the
 // level grid / the tree walk as before.  Ring entries and the dedupe bitmap hold window-relative brick coordinates (9 bits per
 // axis) in every shape.
+constexpr int kBrickGroupLevel = 6;  // (of the window: 64 KB groups of 8^3 bricks)
 constexpr int kBrickWindowBits = 11;
 constexpr uint32_t kBrickWindowCells = 1u << kBrickWindowBits;
 constexpr int kBrickMaxShift = 1;
@@ -179,32 +178,11 @@ __host__ __device__ constexpr uint32_t brick_window_origin(int s) { return ((1u 
 // but config 5's 4K renders of a depth-16 SVO got SLOWER from outside the model, 0.113 -> 0.167 and 0.214 -> 0.262 ms, and 6 %
 // faster from inside it, 0.566 -> 0.535: half the colonnade lies outside the window and far samples stop above the bricks' levels)
 inline int brick_shift_for_depth(int depth) { return depth <= 12 ? 0 : (depth <= 14 ? 1 : -1); }
-// PAGES (round 6): the 2048^3-cell window is cut into 16^3 pages of 128^3 cells (4 MB: 64 groups of 8^3 bricks, a
-// brick still one 128-byte line); a page gets memory when the first brick inside it is written (device-side: the refresh kernels take
-// the next free page of a pool with one compare-and-swap on the page table), page 0 is all zero and stands for every page nobody
-// has written ("no brick": ask the level grid).  The table -- 4096 ids -- is what the march copies into LDS (8 KB, where the dense
-// field's three 8 KB index tables were): the address of a sample's entry stays a function of the sample alone, ONE round trip.
-// Until round 5 the field was dense: 16 GiB per pool, taken only when 48 GiB were free.
-constexpr int kBrickPageShift = 7;                                           // 128 cells per axis
-constexpr int kBrickPagesAxis = (int)(kBrickWindowCells >> kBrickPageShift);  // 16
-constexpr int kBrickPageTableEntries = kBrickPagesAxis * kBrickPagesAxis * kBrickPagesAxis;
-constexpr size_t kBrickPageEntries = (size_t)1 << (3 * kBrickPageShift);     // 2 M entries
-constexpr size_t kBrickPageBytes = 2 * kBrickPageEntries;                    // 4 MB
-constexpr uint32_t kBrickPageLock = 0xFFFFu, kBrickPageNone = 0xFFFEu;       // table values: being allocated / the pool had no page left
-constexpr int kBrickPageMax = 4094;                                          // ids 1 .. 4094 (and never more pages than the window has)
-constexpr int kBrickPageCounters = 8;  // behind the table: [0] pages handed out, [1] requests the pool could not serve, [2..] diagnostics
-struct BrickPages {
-  uint32_t *table;   // [kBrickPageTableEntries] + counters
-  uint32_t cap;
-};
-// page of window cell (x, y, z) in the table; entry of the cell inside its page: [z y x bits 6..5] group, [bits 4..2] brick, [bits 1..0] cell
-__host__ __device__ inline uint32_t brick_page_index(uint32_t x, uint32_t y, uint32_t z) {
-  return ((z >> kBrickPageShift) * (uint32_t)kBrickPagesAxis + (y >> kBrickPageShift)) * (uint32_t)kBrickPagesAxis + (x >> kBrickPageShift);
-}
-__host__ __device__ inline uint32_t brick_page_offset(uint32_t x, uint32_t y, uint32_t z) {
-  return ((((z >> 5) & 3u) << 19) | (((y >> 5) & 3u) << 17) | (((x >> 5) & 3u) << 15)) | (((z >> 2) & 7u) << 12) | (((y >> 2) & 7u) << 9) |
-         (((x >> 2) & 7u) << 6) | ((z & 3u) << 4) | ((y & 3u) << 2) | (x & 3u);
-}
+constexpr size_t kBrickFieldEntries = (size_t)1 << (3 * kBrickWindowBits);
+constexpr size_t kBrickFieldBytes = 2 * kBrickFieldEntries;
+constexpr int kBrickGroups = 1 << (3 * kBrickGroupLevel);
+constexpr int kBrickGroupWords = kBrickGroups / 32;  // "touched" bitmap: 32 KB
+constexpr size_t kBrickGroupBytes = kBrickFieldBytes / kBrickGroups;  // 64 KB
 
 #ifdef __HIPCC__
 // called by ALL threads of ONE workgroup of `threads` (a multiple of 64, <= 1024) lanes after the commit's marks are
@@ -267,36 +245,13 @@ __device__ inline void pool_grid_mark(uint32_t *dirty, unsigned long long key, i
       }
 }
 
-#ifdef __HIPCC__
-// the page that holds window page `pidx`, for a WRITER (one lane calls it): taken from the pool on first use.  0 = none (pool exhausted:
-// the bricks of that page stay unwritten, the march asks the grid / walks the tree there -- correct, slower; counted in counters[1])
-__device__ inline uint32_t brick_page_acquire(const BrickPages &pg, uint32_t pidx) {
-  uint32_t v = __hip_atomic_load(&pg.table[pidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (v == 0u) {
-    const uint32_t old = atomicCAS(&pg.table[pidx], 0u, kBrickPageLock);
-    if (old == 0u) {
-      uint32_t id = atomicAdd(&pg.table[kBrickPageTableEntries], 1u) + 1u;
-      if (id > pg.cap) { id = kBrickPageNone; atomicAdd(&pg.table[kBrickPageTableEntries + 1], 1u); }
-      __hip_atomic_store(&pg.table[pidx], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return id == kBrickPageNone ? 0u : id;
-    }
-    v = old;
-  }
-  while (v == kBrickPageLock) {
-    __builtin_amdgcn_s_sleep(2);
-    v = __hip_atomic_load(&pg.table[pidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  return v == kBrickPageNone ? 0u : v;
+// entry index of window cell (x, y, z) (11 bits each, relative to brick_window_origin) in the brick field: [z>>5 | y>>5 | x>>5] group (level 6, linear),
+// [z y x bits 4..2] brick in the group, [z y x bits 1..0] cell in the brick
+__host__ __device__ inline unsigned long long brick_entry_index(uint32_t x, uint32_t y, uint32_t z) {
+  const uint32_t lo = ((y >> 5) << 21) | ((x >> 5) << 15) | (((z >> 2) & 7u) << 12) | (((y >> 2) & 7u) << 9) | (((x >> 2) & 7u) << 6) |
+                      ((z & 3u) << 4) | ((y & 3u) << 2) | (x & 3u);
+  return ((unsigned long long)(z >> 5) << 27) | lo;
 }
-// ... for a READER: 0 (the zero page) unless the page exists
-__device__ inline uint32_t brick_page_lookup(const BrickPages &pg, uint32_t pidx) {
-  const uint32_t v = __hip_atomic_load(&pg.table[pidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return v >= kBrickPageNone ? 0u : v;
-}
-__device__ inline uint16_t *brick_entry_ptr(uint16_t *bricks, uint32_t page, uint32_t x, uint32_t y, uint32_t z) {
-  return bricks + ((size_t)page << (3 * kBrickPageShift)) + brick_page_offset(x & 127u, y & 127u, z & 127u);
-}
-#endif
 
 // One workgroup: order[0 .. n) = the tiles of a render, costliest first by cost[] (wavefront-steps of the previous render of that
 // geometry), and cost[] cleared for the render that follows.  Longest-processing-time-first: the in-order dispatcher then ends a

@@ -73,7 +73,7 @@ def test_bricks_follow_incremental_fusion_through_saturation(env, oracle, depth)
     assert np.array_equal(pool.words()[:2 * pool.size], opool.words()[:2 * pool.size])
     acc = pool.march_accel()       # (svoslam_pool_march_accel: the fallback to the tree march is visible)
     assert acc["grid"], acc
-    if depth <= 14:   # (-1: the page pool did not fit beside whatever else holds the device: the renders above went through the tree)
+    if depth <= 14:   # (-1: the 16 GiB field did not fit beside whatever else holds the device: the renders above went through the tree)
         assert acc["bricks"] in (1, -1) and (acc["bricks"] == -1 or acc["brick_shift"] == (0 if depth <= 12 else 1)), acc
     else:
         assert acc["bricks"] == 0 and acc["brick_shift"] == -1, acc
@@ -299,34 +299,4 @@ print("RESULT" + json.dumps(out))
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0][6:])
     base = run({})
     assert run({"SVOSLAM_CONFIG": "march_bricks=0"}) == base
-    # a page pool of TWO pages (round 6: the bricks live in 4 MB pages taken on first use): the map's surfaces need more, the pool
-    # serves the first two and the march walks the tree through the space of the others -- same images, counters and pool words
-    assert run({"SVOSLAM_CONFIG": "brick_pages=2"}) == base
     assert base[-1][1] > 8 and base[0][1][0] > 0
-
-
-def test_two_pools_on_one_device_keep_their_bricks_in_pages(env, oracle):
-    """the bricks' field is a pool of 4 MB pages taken on first use (until round 5: a dense 16 GiB field per
-    pool, so that a second pool on the device fell back to the tree march).  Two pools fused and rendered in turns both report
-    bricks in use, each with pages of its own, each byte-equal to the oracle; a page request beyond the pool's capacity is
-    reported, not fatal (child-process half of the test above)."""
-    pkg, torch = env
-    rng = np.random.default_rng(5)
-    center, edge, depth = (0.0, 0.0, 0.0), 1.0, 12
-    pools = [(pkg.Workspace(), pkg.Pool(), oracle.Pool()) for _ in range(2)]
-    for it in range(3):
-        for k, (ws, pool, opool) in enumerate(pools):
-            pts, col = surface_cloud(rng, 5000, jitter=0.003)
-            pts = (pts * np.float32(0.9 - 0.3 * k)).astype(np.float32)     # different surfaces in the two maps
-            pkg.svo_from_point_cloud_async(ws, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, pool, center, edge)
-            opool.insert_cloud(pts, col, depth, center, edge)
-            for eye, tgt, (w, h) in VIEWS[1:3]:
-                render_check(pkg, torch, oracle, pool, opool, w, h, oracle.look_at(eye, tgt, (0, 1, 0)), center, edge, (it, k, eye))
-    stats = []
-    for ws, pool, opool in pools:
-        acc, pages = pool.march_accel(), pool.brick_pages()
-        assert acc["bricks"] == 1 and acc["brick_shift"] == 0, acc
-        assert 0 < pages["used"] <= pages["capacity"] and pages["unserved"] == 0, pages
-        stats.append(pages["used"])
-    # a 2 m root at depth 12: cells of 1 mm, pages of 12.5 cm -- a sheet + a sphere cross a few hundred of the 4096
-    assert all(10 < u < 2000 for u in stats), stats
