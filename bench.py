@@ -679,7 +679,7 @@ def main():
 
     # which march runs: pools fused to depth <= 14 are marched over occupancy bricks in reference mode (csrc/pool_grid.hpp)
     bricks = max_depth <= 14 and args.render_mode == "reference" and cfg["march_bricks"] != 0
-    march_kernel = ("cone_trace_brick_ahead_kernel" if cfg.get("march_ahead", -1) >= 0 else "cone_trace_brick_kernel") if bricks else "cone_trace_kernel"
+    march_kernel = "cone_trace_brick_kernel" if bricks else "cone_trace_kernel"   # (its template parameter B = 3 when svoslam_config.march_ahead >= 0: bursts)
     roofs = [roof("march", march_kernel, march_alg, kern_ms, 1,
                   ("instruction issue: a step is ONE memory round trip (brick entry + level-grid entry requested together, mostly L1 / L2 "
                    "hits: counter traffic is a few percent of the algorithmic bytes) and ~160 instructions; a lone wavefront of the tail "

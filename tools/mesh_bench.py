@@ -201,7 +201,7 @@ def main():
             renders.append(rec)
     pkg.cone_trace_timing(False)
     out["renders"] = renders
-    out["render_kernel"] = ("cone_trace_brick_%skernel (reference mode over occupancy bricks)" % ("ahead_" if pkg.get_config().get("march_ahead", -1) >= 0 else "") if depth <= 14 else
+    out["render_kernel"] = ("cone_trace_brick_kernel (reference mode over occupancy bricks)" if depth <= 14 else
                             "cone_trace_kernel (tree march: no brick shape for pools deeper than 14)") + " / cone_trace_kernel<CARRY> (carry mode)"
     out["mrays_per_s_min_max"] = [min(r["Mrays_per_s"] for r in renders), max(r["Mrays_per_s"] for r in renders)]
     print(json.dumps(out))
