@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of cone_trace variants (tools/prof/build_cone_variant.sh) x march_ahead settings
+# same-box A/B of cone_trace variants (tools/prof/build_variant.sh <name> cone_trace <flags>) x march_ahead settings
 O=gpurun_out/r06e; mkdir -p $O
 export SVOSLAM_BENCH_FULL_LINE=1
 L=octree-slam_amd/libsvoslam_hip.so
