@@ -175,6 +175,21 @@ def test_render_from_far_outside_a_small_root_uses_the_grid_pyramid(env, oracle,
         for vi, view in enumerate(views):
             w, h = ((96, 72), (64, 48), (40, 30))[vi]
             render_both(pkg, torch, oracle, pool, words, w, h, view, center, edge, mode)
+    # deferred commit + apply (the frame loop's default at 640x480: the marks go to the other dirty state): a render between the two
+    # halves still sees the old map, one after the apply the new one -- pyramid entries included
+    for frame in range(2):
+        pts, col = surface_cloud(rng, 7000)
+        pts = (pts * np.float32(edge / 0.9) + c).astype(np.float32)
+        tp, tc = torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda()
+        pkg.svo_fuse_sort(ws, tp, depth, center, edge)
+        pkg.svo_fuse_plan(ws, len(pts), depth, pool)
+        pkg.svo_fuse_commit_deferred(ws, tc, depth, pool)
+        render_both(pkg, torch, oracle, pool, words, 96, 72, views[0], center, edge, mode)       # still the old map
+        pkg.svo_fuse_apply(ws, pool)
+        opool.insert_cloud(pts, col, depth, center, edge)
+        words = opool.words()
+        for vi in (0, 2):
+            render_both(pkg, torch, oracle, pool, words, (96, 40)[vi // 2], (72, 30)[vi // 2], views[vi], center, edge, mode)
     # the same nodes as memory the library does not know: the per-render grid + pyramid (level 7; level 8 for a megapixel)
     foreign = torch.from_numpy(words.view(np.int32).copy()).cuda()
     img = torch.zeros((72, 96, 4), dtype=torch.uint8, device="cuda")
