@@ -239,13 +239,6 @@ int svoslam_svo_fuse_split_early(svoslam_workspace *ws, int32_t n, int32_t max_d
  * sequence, ordered after everything earlier on the pool.  Same pool contents as plan + commit per frame. */
 int svoslam_pool_structure_begin(svoslam_pool *pool, void *stream);
 int svoslam_svo_fuse_plan_structure(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream);
-/* The structure chain UNDER a renderer.  As plan_structure, but the links from existing nodes to the new child tiles (the only words
- * of splitNodes, svo.cu:239-276, that a render of the present map could reach) are written as PENDING links: word0 bit 31 + the
- * tile index, children flag (bit 30, svo.cu:130) clear.  A render sees a childless node, the next plan follows the link: the plans
- * of later frames need only the previous plan and may run while earlier frames are still being rendered.  The commit of such a
- * plan is svoslam_svo_fuse_commit_deferred + svoslam_svo_fuse_apply (which publishes colours and links together: children flag +
- * the same index) or svoslam_svo_fuse_commit.  Bit 31 is never set in a pool at rest.  Same pool contents as plan + commit. */
-int svoslam_svo_fuse_plan_structure_pending(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream);
 /* The planned commit applied to one of several BYTE-IDENTICAL replicas of a map (a plan made against any replica in
  * the state before this commit fits all of them: same tree, same tile numbering).  Each application uses its own
  * slot (0 or 1; applications with different slots may run concurrently), all but the last pass keep_plan != 0.

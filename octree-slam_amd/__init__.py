@@ -95,7 +95,6 @@ SIGNATURES = {
     "svoslam_svo_fuse_commit": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_split_early": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_plan_structure": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
-    "svoslam_svo_fuse_plan_structure_pending": (C.c_int, [_vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_adopt_sorted": (C.c_int, [_vp, _vp, _vp, _i32, _i32]),
     "svoslam_svo_fuse_sort_frame_band": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _i32, _fp, _f32, _i32, _i32, _vp]),
     "svoslam_svo_fuse_merge_sorted": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp, _vp, _vp]),
@@ -508,11 +507,6 @@ def pool_structure_begin(pool):
 def svo_fuse_plan_structure(ws, n, max_depth, pool):
     """plan + every split with its links, independent of the previous frame's commit (colour words)"""
     check(lib().svoslam_svo_fuse_plan_structure(ws._h, int(n), int(max_depth), C.byref(pool._p), _stream()))
-
-
-def svo_fuse_plan_structure_pending(ws, n, max_depth, pool):
-    """plan + every split, its links from existing nodes PENDING (invisible to a render): before svo_fuse_commit_deferred + svo_fuse_apply"""
-    check(lib().svoslam_svo_fuse_plan_structure_pending(ws._h, int(n), int(max_depth), C.byref(pool._p), _stream()))
 
 
 def svo_fuse_split_early(ws, n, max_depth, pool):

@@ -219,10 +219,6 @@ int svoslam_svo_fuse_plan_structure(svoslam_workspace *ws, int32_t n, int32_t ma
   NEED_DEVICE();
   return svo_fuse_plan_structure(ws, n, max_depth, pool, S(stream));
 }
-int svoslam_svo_fuse_plan_structure_pending(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream) {
-  NEED_DEVICE();
-  return svo_fuse_plan_structure_pending(ws, n, max_depth, pool, S(stream));
-}
 int svoslam_svo_fuse_split_early(svoslam_workspace *ws, int32_t n, int32_t max_depth, svoslam_pool *pool, void *stream) {
   NEED_DEVICE();
   return svo_fuse_split_early(ws, n, max_depth, pool, S(stream));

@@ -18,10 +18,6 @@ typedef long long octkey;  // src/world/svo/svo.cu:22
 
 constexpr uint32_t kFlag = SVOSLAM_FLAG_CHILDREN;
 constexpr uint32_t kMask = SVOSLAM_CHILD_MASK;
-// word0 bit 31 (never set in a pool at rest; the reference's format has no use for it): a PENDING link -- the child tile of a split
-// that a deferred commit has not published yet (svo_fuse_plan_structure_pending).  Everything that renders or extracts tests kFlag
-// alone and sees a childless node; the planner follows it; svo_fuse_apply turns it into kFlag + the same tile index.
-constexpr uint32_t kPend = 0x80000000u;
 constexpr int kWave = 64;  // gfx950 wavefront
 
 // ---- error plumbing -------------------------------------------------------

@@ -393,11 +393,7 @@ __device__ inline void brick_rebuild(const uint2 *__restrict__ nodes, const uint
   }
 }
 
-#ifdef SVO_EXP_REFRESH_SHAPE
-constexpr int kBrickThreads = 256, kBrickBlocks = 4096, kBrickChains = 2;
-#else
 constexpr int kBrickThreads = 256, kBrickBlocks = 2048, kBrickChains = 4;
-#endif
 // the rings of the served states: entries [mark of the previous refresh, appended count), and this refresh's mark
 // (count_off = kBrickCountOffset: the stale bricks; kSibCountOffset: the sibling ring; the marks follow the count)
 struct BrickRings {

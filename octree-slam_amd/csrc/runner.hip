@@ -81,9 +81,6 @@ struct svoslam_runner {
   // 1707; cfg4, where the launch-chain tracker bounds the frame, 815 -> 694: off there).  svoslam_config.runner_deferred = 0 / 1 overrides.
   int stream_kind = 0;  // device x priorities: which free list the five streams return to
   bool deferred = false, deferred_explicit = false;
-  // deferred commits: the plans as a structure chain of PENDING links (svoslam_svo_fuse_plan_structure_pending), independent of apply /
-  // march: 0 = off (plan k+1 waits for apply k), 1 = behind the sort on S, 2 = ahead of the commit on C
-  int plan_ahead = 0;
   bool ran = false;
   // svoslam_config.runner_timeline = 1: timing events at the stage boundaries of the last call (svoslam_runner_timeline)
   bool timeline = false;
@@ -131,7 +128,6 @@ int svoslam_runner_create(svoslam_runner **out, svoslam_camera *cam, svoslam_poo
     r->fused_front = 3 * max_depth + 1 + idx_bits <= 64 && cfg.sort_pairs == 0;
   }
   if (cfg.runner_lead >= 0) r->lead = cfg.runner_lead;
-  if (const char *e = getenv("SVOSLAM_PLAN_AHEAD")) r->plan_ahead = atoi(e);
   *out = r;
   const size_t n = (size_t)width * height;
   {
@@ -328,15 +324,6 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
     if (plan_on_map && R == 1 && !deferred) { chain = true; plan_on_map = false; }
   }
   if (chain) SVO_TRY(svoslam_pool_structure_begin(r->pool, r->s_prep));
-  const int plan_ahead = (deferred && R == 1) ? r->plan_ahead : 0;
-  // (structure-side size := the pool's size, ahead of the first plan: S for the plans on S; C waits for it through ev_begin2)
-  if (plan_ahead) {
-    SVO_TRY(svoslam_pool_structure_begin(r->pool, r->s_prep));
-    if (plan_ahead == 2) {
-      SVO_HIP(hipEventRecord(r->ev_end[2], r->s_prep));
-      SVO_HIP(hipStreamWaitEvent(r->s_map[1], r->ev_end[2], 0));
-    }
-  }
   hipStream_t s_maps = r->s_maps;
   auto enqueue_maps = [&](int i) -> int {  // bilateral filter + pyramids of frame i (no dependence on earlier poses)
     if (sharded) return SVOSLAM_OK;  // tracked elsewhere: this camera only composes poses
@@ -417,19 +404,6 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
       mark(i, 6, s_plan);
       return SVOSLAM_OK;
     }
-    if (plan_ahead) {
-      // the plan of frame i needs the plan of frame i-1 (same stream) and nothing else: its pending links are invisible to the marches
-      // and to the grid / brick refresh, and the commit that precedes it writes colour words only
-      if (plan_ahead == 2) {  // on C, ahead of the commit (enqueue_compute)
-        SVO_HIP(hipEventRecord(ev_sorted[i], s_sort));
-        return SVOSLAM_OK;
-      }
-      mark(i, 5, s_plan);
-      SVO_TRY(svoslam_svo_fuse_plan_structure_pending(ws, npts, r->depth, r->pool, s_plan));
-      SVO_HIP(hipEventRecord(ev_plan[i], s_plan));
-      mark(i, 6, s_plan);
-      return SVOSLAM_OK;
-    }
     // the plan reads the replica that receives commit i-1 FIRST (the one frame i-1 is marched on); the march only reads
     const int src = i > 0 ? ((i - 1) & (R - 1)) : 0;
     if (plan_on_maps) {  // (see above)
@@ -478,19 +452,13 @@ static int runner_run_impl(svoslam_runner *r, const uint16_t *const *d_depths, c
   // carries apply + grid / brick refresh + march instead of commit + refresh + march.  Round 2, beside the tree march (a
   // latency chain through the same L2 / HBM as the commit): the march took 0.32 ms instead of 0.28, the commit 0.27 instead of
   // 0.11, the period barely moved.  Round 3, beside the issue-bound brick march: cfg3 1862 -> 2055 frames/s; the period is
-  // now apply(k) -> plan(k+1) -> this commit -> apply(k+1) (0.42 ms) level with the map stream (0.40).
+  // now apply(k) -> plan(k+1) -> this commit -> apply(k+1) (0.42 ms) level with the map stream (0.40).  Round 6 took the plan out of
+  // that cycle (its splits' links written as pending links no march follows, the plans a chain of their own on S or on C): same pool,
+  // same images, 2350-2500 frames/s either way -- the streams share one machine, the cycle was not what held the frame; not kept
+  // (profiles/r06_plan_ahead_pending_links_experiment.txt).
   hipStream_t s_compute = r->s_map[1];
   auto enqueue_compute = [&](int i) -> int {
-    if (plan_ahead == 2) {
-      SVO_HIP(hipStreamWaitEvent(s_compute, ev_sorted[i], 0));
-      mark(i, 5, s_compute);
-      SVO_TRY(svoslam_svo_fuse_plan_structure_pending(r->ws[i % kRing], npts, r->depth, r->pool, s_compute));
-      mark(i, 6, s_compute);
-    } else {
-      SVO_HIP(hipStreamWaitEvent(s_compute, ev_plan[i], 0));
-    }
-    // plans ahead: the commit reads the colours apply i-1 publishes (it used to follow from the plan's wait for that apply)
-    if (plan_ahead && i > 0) SVO_HIP(hipStreamWaitEvent(s_compute, ev_commit[0][i - 1], 0));
+    SVO_HIP(hipStreamWaitEvent(s_compute, ev_plan[i], 0));
     // (the plan of frame i HERE, in order ahead of its commit and behind apply(i-1) -- one hand-off between streams less in the
     // cycle -- was measured: 2000-2200 frames/s against 2030-2390, the sorts then run unthrottled beside the march: not kept)
     mark(i, 7, s_compute);

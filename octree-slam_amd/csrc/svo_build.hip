@@ -239,7 +239,7 @@ __device__ inline void walk_existing(const u32 *__restrict__ pool, u64 key, int 
     node = base + oct;
     if (lvl < depth || oct == 7u) {
       const u32 w0 = pool[2 * (size_t)node];
-      if (!(w0 & (kFlag | kPend))) { t = lvl; break; }  // (a pending link -- common.hpp -- is structure like any other to a plan)
+      if (!(w0 & kFlag)) { t = lvl; break; }
       base = w0 & kMask;
       if (lvl <= c) start = base;  // (the last assignment is the base after level min(c, t - 1))
     }
@@ -447,8 +447,7 @@ __global__ __launch_bounds__(256) void split_all_kernel(const u64 *__restrict__ 
   SVO_HIGH_PRIO();  // also beside a march (deferred commits: apply -> plan -> commit -> apply is the cycle that can bind the frame; cfg3, 100 frames, 2209-2499 -> 2373-2511)
   const u32 total = (u32)counts->total_records;
   // structure != 0 (svo_fuse_plan_structure): the first tile index comes from the plan (*n0_saved, set by
-  // plan_scan_finish_kernel from the structure-side size) and the links ARE written -- the next plan reads them --; structure == 2
-  // (svo_fuse_plan_structure_pending): as PENDING links (kPend, common.hpp), which the next plan follows and no ray march does
+  // plan_scan_finish_kernel from the structure-side size) and the links ARE written -- the next plan reads them
   const u32 n0 = structure ? *n0_saved : (u32)*d_size;
   // n0_saved != nullptr: deferred commit -- the links of the pass-0 records (the only words of this kernel a concurrent
   // ray march could see) are left to commit_apply_kernel, which needs the first tile index
@@ -460,7 +459,7 @@ __global__ __launch_bounds__(256) void split_all_kernel(const u64 *__restrict__ 
     // level grid of the ray march (pool_grid.hpp): a split above the block level re-labels the whole cube of its node
     if (grid_dirty && d < kPoolGridBlockLevel) pool_grid_mark(grid_dirty, key, d);
     const u32 child = n0 + 8u * r;
-    if (pass == 0 && (!n0_saved || structure)) pool[2 * (size_t)rec_front[r]] = (structure == 2 ? kPend : kFlag) + (child & kMask);
+    if (pass == 0 && (!n0_saved || structure)) pool[2 * (size_t)rec_front[r]] = kFlag + (child & kMask);
     u32 w0[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     if (d + 1 <= depth - 1) {  // children at depth d+1 can only be records while d+1 < D
       const u32 b = bucket_id(pass + 1, d + 1);
@@ -863,7 +862,7 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
     for (int lvl = 1; lvl <= MAXD; lvl++) {
       if (lvl <= depth && lvl > skip) {
         node = base + ((u32)(key >> (3 * (depth - lvl))) & 7u);
-        if (lvl == link_level && !shadow) pool[2 * (size_t)node] = kFlag + (frontier_child & kMask);  // (deferred: commit_apply_kernel)
+        if (lvl == link_level) pool[2 * (size_t)node] = kFlag + (frontier_child & kMask);
         if (lvl < depth) {
           base = pool[2 * (size_t)node] & kMask;
           if (lvl == frontier) base = frontier_child & kMask;
@@ -1763,14 +1762,13 @@ int pool_structure_begin(svoslam_pool *pool, hipStream_t stream) {
   return SVOSLAM_OK;
 }
 
-static int fuse_plan_impl(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, int structure, hipStream_t stream) {
+static int fuse_plan_impl(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, bool structure, hipStream_t stream) {
   if (!ws || !pool || n < 0) return SVOSLAM_ERR_INVALID_ARG;
   if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
   if (pool->size == 0) SVO_TRY(pool_init(pool, 8, stream));
   ws->planned_n = -1;
   ws->early_split_pool = nullptr;
-  ws->structure_pending = false;
-  if (structure == 1 && pool_shadow_pending(pool)) return SVOSLAM_ERR_INVALID_ARG;  // (its links are real: a deferred commit's render would see them)
+  if (structure && pool_shadow_pending(pool)) return SVOSLAM_ERR_INVALID_ARG;
   if (n == 0) { ws->planned_n = 0; return SVOSLAM_OK; }
   if (!ws->sorted_keys) return SVOSLAM_ERR_INVALID_ARG;  // svo_fuse_sort has not run on this workspace
   SVO_TRY(ensure_device_size(pool, stream));
@@ -1814,7 +1812,7 @@ static int fuse_plan_impl(svoslam_workspace *ws, int n, int depth, svoslam_pool 
     if (structure)  // tiles AND links, numbered from the plan's own size; the level-grid marks come from the commit's leaf kernel
       split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(), ws->rec_pass.as<unsigned char>(),
                                                          small_bucket_base(ws), small_counts(ws), pool->d_data, pool->d_size, depth, nullptr,
-                                                         small_n0(ws), structure);
+                                                         small_n0(ws), 1);
     SVO_LAUNCH_CHECK();
     return SVOSLAM_OK;
   };
@@ -1828,24 +1826,15 @@ static int fuse_plan_impl(svoslam_workspace *ws, int n, int depth, svoslam_pool 
   ws->planned_n = n;
   ws->planned_pool = pool;
   if (structure) { ws->early_split_pool = pool; tracker_of(pool)->planned_ahead++; ws->structure_planned = true; }  // the commit: leaf kernel (links again, same values; marks) + straddlers
-  ws->structure_pending = structure == 2;
   pool->pending_bound += 8 * rmax;  // reserved from now on
   return SVOSLAM_OK;
 }
 
 int svo_fuse_plan(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream) {
-  return fuse_plan_impl(ws, n, depth, pool, 0, stream);
+  return fuse_plan_impl(ws, n, depth, pool, false, stream);
 }
 int svo_fuse_plan_structure(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream) {
-  return fuse_plan_impl(ws, n, depth, pool, 1, stream);
-}
-// The structure chain UNDER a renderer (round 6): as svo_fuse_plan_structure, but the links from existing nodes to the new tiles are
-// written as PENDING links (kPend, common.hpp) -- structure to the next plan, a childless node to everything that renders -- so
-// the plans of frames k+1, k+2 .. may run while frame k is still being ray-marched, and need nothing but the previous plan.  The
-// commit of such a plan is svo_fuse_commit_deferred (leaf kernel + straddlers into the shadow array) and svo_fuse_apply publishes
-// colours and links together (commit_apply_kernel); svo_fuse_commit works too (its leaf kernel writes the real links).
-int svo_fuse_plan_structure_pending(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream) {
-  return fuse_plan_impl(ws, n, depth, pool, 2, stream);
+  return fuse_plan_impl(ws, n, depth, pool, true, stream);
 }
 
 // Applies the planned commit to `pool`.  slot / keep_plan serve callers that keep several byte-identical replicas of
@@ -1885,8 +1874,7 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   if (!keep_plan) ws->planned_n = -1;
   ws->deferred_pool = nullptr;
   const bool early = ws->early_split_pool != nullptr;
-  // one pool; a direct commit, or a deferred one whose plan left PENDING links (svo_fuse_plan_structure_pending)
-  if (early && (ws->early_split_pool != pool || (deferred && !ws->structure_pending) || keep_plan)) return SVOSLAM_ERR_INVALID_ARG;
+  if (early && (ws->early_split_pool != pool || deferred || keep_plan)) return SVOSLAM_ERR_INVALID_ARG;  // one pool, direct commit
   ws->early_split_pool = nullptr;
   if (ws->structure_planned) {
     ws->structure_planned = false;

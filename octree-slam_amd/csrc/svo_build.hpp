@@ -33,7 +33,6 @@ int svo_fuse_merge_sorted(const unsigned long long *const *d_keys, const uint32_
 int svo_fuse_adopt_sorted(svoslam_workspace *ws, const unsigned long long *d_keys, const uint32_t *d_idx, int n, int depth);
 int svo_fuse_export_sorted(svoslam_workspace *ws, int n, unsigned long long *d_keys_out, uint32_t *d_idx_out, hipStream_t stream);
 int svo_fuse_plan_structure(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream);
-int svo_fuse_plan_structure_pending(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream);
 int svo_fuse_split_early(svoslam_workspace *ws, int n, int depth, svoslam_pool *pool, hipStream_t stream);
 int svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, int slot, bool keep_plan,
                        hipStream_t stream);

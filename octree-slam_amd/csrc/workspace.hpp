@@ -64,7 +64,6 @@ struct svoslam_workspace {
   int planned_n = -1;
   const void *early_split_pool = nullptr;                  // svo_fuse_split_early has initialised the planned splits' tiles in this pool
   bool structure_planned = false;                          // ... by svo_fuse_plan_structure (its reservation is released by its commit)
-  bool structure_pending = false;                          // ... with pending links (svo_fuse_plan_structure_pending): a deferred commit may follow
   const void *planned_pool = nullptr;                      // the pool svo_fuse_plan read (its reservation is already booked)
   svoslam::GraphCache g_sort, g_plan, g_commit;            // recorded launch sequences of the three phases
   // `small` (4 KB of totals / bases / counters) is zeroed when it is created: the planner's any_valid word and arrival

@@ -439,62 +439,6 @@ def test_structure_chain_equals_sequential_fusion(env, oracle, depth, n):
         assert_pools_equal(pool, opool)
 
 
-@pytest.mark.parametrize("depth,n", [(2, 500), (9, 30000), (12, 60000), (16, 20000)])
-def test_pending_structure_chain_under_a_renderer(env, oracle, depth, n):
-    """svoslam_svo_fuse_plan_structure_pending: the plans + splits of three frames run AHEAD of every commit, their links from existing
-    nodes pending (word0 bit 31, children flag clear); then per frame commit_deferred -> apply.  A render at ANY point sees exactly the
-    frames applied so far (compared with a second pool fused frame by frame), and after the last apply the pool is the oracle's, no
-    bit 31 left anywhere."""
-    pkg, torch = env
-    rng = np.random.default_rng(1300 + depth)
-    center, edge = (0.02, -0.01, 0.03), 1.0
-    pool, ref, opool = pkg.Pool(1 << 23), pkg.Pool(1 << 23), oracle.Pool()
-    wss, ws_ref = [pkg.Workspace() for _ in range(3)], pkg.Workspace()
-    view = oracle.look_at((0.2, 0.3, -2.2), (0, 0, 0), (0, 1, 0))
-
-    def render(p):
-        img = torch.zeros((30, 40, 4), dtype=torch.uint8, device="cuda")
-        pkg.cone_trace_svo(img, 45.0, view, p.data_ptr, center, edge, 1)
-        return img
-
-    for rnd in range(2):
-        clouds = []
-        for f in range(3):
-            pts, col = (surface_cloud(rng, n) if f != 1 else random_cloud(rng, n, nan_every=41, dup_frac=0.15))
-            pts = pts + np.float32(0.004 * (3 * rnd + f))
-            if f == 2:
-                pts[: n // 5] = np.abs(pts[: n // 5])            # octant-7 leaves gain children (Q4): pending links AT the leaf level
-            clouds.append((torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), pts, col))
-        if rnd == 0:                                             # (something to render before the chain starts)
-            pts, col = surface_cloud(rng, n)
-            for p_, w_ in ((pool, wss[0]), (ref, ws_ref)):
-                pkg.svo_from_point_cloud_async(w_, torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, p_, center, edge)
-            opool.insert_cloud(pts, col, depth, center, edge)
-        torch.cuda.synchronize()
-        size_before = pool.size
-        before = pool.words().copy()
-        pkg.pool_structure_begin(pool)
-        for f in range(3):
-            pkg.svo_fuse_sort(wss[f], clouds[f][0], depth, center, edge)
-            pkg.svo_fuse_plan_structure_pending(wss[f], n, depth, pool)
-        torch.cuda.synchronize()
-        # three frames planned: below the old size only word0s changed, each from "no children" to a pending link
-        mid = pool.words()[: 2 * size_before]
-        diff = np.nonzero(mid != before[: 2 * size_before])[0]
-        assert (diff.size > 0 or depth < 9) and np.all(diff % 2 == 0)
-        assert np.all((mid[diff] >> 30) == 2) and np.all((before[diff] & 0x40000000) == 0)
-        assert torch.equal(render(pool), render(ref))
-        for f in range(3):
-            pkg.svo_fuse_commit_deferred(wss[f], clouds[f][1], depth, pool)
-            assert torch.equal(render(pool), render(ref))        # computed, not published
-            pkg.svo_fuse_apply(wss[f], pool)
-            pkg.svo_from_point_cloud_async(ws_ref, clouds[f][0], clouds[f][1], depth, ref, center, edge)
-            assert torch.equal(render(pool), render(ref))        # frames <= f, and nothing of the later ones
-            opool.insert_cloud(clouds[f][2], clouds[f][3], depth, center, edge)
-        assert_pools_equal(pool, opool)
-        assert not np.any(pool.words()[0::2] & 0x80000000)
-
-
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_band_sort_merge_equals_whole_frame_sort(env, oracle, world):
     """SURVEY 8e's sharded fusion on the device: every band's keys are computed and sorted on their own
