@@ -10,6 +10,12 @@ namespace svoslam {
 
 __device__ constexpr float kDistThresh = 0.1f;   // localization_kernels.cu:17
 __device__ constexpr float kNormThresh = 0.87f;  // :18
+// The distance gate without the square root (round 6): sqrtf(d2) > kDistThresh  <=>  d2 > kDistThreshSq.  sqrtf is correctly rounded
+// (IEEE 754; the build asks for it) and therefore monotonic, and kDistThreshSq = 0x3C23D70B is the largest binary32 whose root rounds to a
+// value <= 0.1f (its successor's root rounds to the next float above 0.1f); NaN makes both comparisons false, +Inf both true
+// (tests/test_icp_gate.py pins threshold and equivalence on the CPU).  The correctly rounded root was 16 instructions per pixel and iteration.
+__device__ constexpr float kDistThreshSq = 0x1.47ae16p-7f;
+__device__ __forceinline__ bool beyond_dist_thresh(float d2) { return d2 > kDistThreshSq; }
 constexpr double kScaleA = 1048576.0;            // 2^20
 constexpr double kScaleB = 1073741824.0;         // 2^30
 constexpr int kMaxChain = 10;                    // max(PYRAMID_ITERS)
@@ -92,7 +98,7 @@ __device__ __forceinline__ void icp_pixel_terms(float v1x, float v1y, float v1z,
             !(v1z < 0.1f) && !(v2z < 0.1f) && !(v1z > 10.0f) && !(v2z > 10.0f);
   ok = ok && finitef_(n2x) && finitef_(n2y) && finitef_(n2z) && finitef_(n1x) && finitef_(n1y) && finitef_(n1z);
   const float dx = v2x - v1x, dy = v2y - v1y, dz = v2z - v1z;
-  ok = ok && !(sqrtf(dot3(dx, dy, dz, dx, dy, dz)) > kDistThresh);
+  ok = ok && !beyond_dist_thresh(dot3(dx, dy, dz, dx, dy, dz));  // !(length > DIST_THRESH)
   ok = ok && !(dot3(n2x, n2y, n2z, n1x, n1y, n1z) < kNormThresh);
   float J[6];
   icp_rot_rows(v2x, v2y, v2z, n1x, n1y, n1z, corrected, J[0], J[1], J[2]);
@@ -125,7 +131,7 @@ __device__ __forceinline__ void rgbd_pixel_terms(float v1x, float v1y, float v1z
   bool ok = finitef_(v2x) && finitef_(v2y) && finitef_(v2z) && finitef_(v1x) && finitef_(v1y) && finitef_(v1z) &&
             !(v1z < 0.1f) && !(v2z < 0.1f) && !(v1z > 10.0f) && !(v2z > 10.0f);
   const float dx = v2x - v1x, dy = v2y - v1y, dz = v2z - v1z;
-  ok = ok && !(sqrtf(dot3(dx, dy, dz, dx, dy, dz)) > kDistThresh);
+  ok = ok && !beyond_dist_thresh(dot3(dx, dy, dz, dx, dy, dz));  // !(length > DIST_THRESH)
   const float iz = 1.0f / v2z;
   const float ax = (fx * iz) / sx, ay = (fy * iz) / sy;
   const float wx = gx * ax;

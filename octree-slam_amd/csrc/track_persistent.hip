@@ -103,17 +103,23 @@ __device__ inline bool sweep_broadcast(TrackSync *sy, unsigned tag, float *out, 
 // banks apart, so the seven columns (and the two halves, 32 banks apart) of one read never share a bank.
 constexpr int kCols = 8, kColStride = 68, kWaveRowFloats = kCols * kColStride;
 
-struct TermLane { int off_a, off_b; float scale; };  // byte offsets of the lane's two columns
+// The fixed-point scales live in the ROWS (round 6): column c holds J_c * 2^10, column 6 holds b * 2^20, so that a lane's product of two
+// entries IS fl(J_i * J_j) * 2^20 (or fl(b * J_i) * 2^30): scaling by a power of two commutes with the rounding of the product unless the
+// product is subnormal (|J_i * J_j| < 2^-126), where both forms round to 0 under rint; nothing here comes near overflow (|J| is metres).
+// Seven multiplies per pixel where the rows are formed instead of one per pixel and TERM where they are read.
+constexpr float kRowScaleJ = 1024.0f, kRowScaleB = 1048576.0f;
+static_assert((double)kRowScaleJ * kRowScaleJ == kScaleA && (double)kRowScaleB * kRowScaleJ == kScaleB, "row scales multiply to the terms' fixed-point scales");
+struct TermLane { int off_a, off_b; };  // byte offsets of the lane's two columns
 __device__ inline TermLane term_of_lane(int t) {
   TermLane L;
   if (t < 21) {  // (i, j), i <= j, row-major upper triangle: the order of Mat6x7's A entries in the 27 sums
     int i = 0, r = t;
     for (; i < 6; i++) { const int len = 6 - i; if (r < len) break; r -= len; }
-    L.off_a = 4 * kColStride * i; L.off_b = 4 * kColStride * (i + r); L.scale = 1048576.0f;
+    L.off_a = 4 * kColStride * i; L.off_b = 4 * kColStride * (i + r);
   } else if (t < 27) {
-    L.off_a = 4 * kColStride * 6; L.off_b = 4 * kColStride * (t - 21); L.scale = 1073741824.0f;  // b * J[i]
+    L.off_a = 4 * kColStride * 6; L.off_b = 4 * kColStride * (t - 21);  // b * J[i]
   } else {
-    L.off_a = 4 * kColStride * 7; L.off_b = 4 * kColStride * 7; L.scale = 1.0f;  // idle lanes read the zero column
+    L.off_a = 4 * kColStride * 7; L.off_b = 4 * kColStride * 7;  // idle lanes read the zero column
   }
   return L;
 }
@@ -125,7 +131,7 @@ __device__ __forceinline__ void icp_pixel_row(float v1x, float v1y, float v1z, f
             !(v1z < 0.1f) && !(v2z < 0.1f) && !(v1z > 10.0f) && !(v2z > 10.0f);
   ok = ok && finitef_(n2x) && finitef_(n2y) && finitef_(n2z) && finitef_(n1x) && finitef_(n1y) && finitef_(n1z);
   const float dx = v2x - v1x, dy = v2y - v1y, dz = v2z - v1z;
-  ok = ok && !(sqrtf(dot3(dx, dy, dz, dx, dy, dz)) > kDistThresh);
+  ok = ok && !beyond_dist_thresh(dot3(dx, dy, dz, dx, dy, dz));  // !(length > DIST_THRESH), icp_device.hpp
   ok = ok && !(dot3(n2x, n2y, n2z, n1x, n1y, n1z) < kNormThresh);
   float J[6];
   icp_rot_rows(v2x, v2y, v2z, n1x, n1y, n1z, corrected, J[0], J[1], J[2]);
@@ -134,8 +140,8 @@ __device__ __forceinline__ void icp_pixel_row(float v1x, float v1y, float v1z, f
   J[5] = (0.0f * n1x + 0.0f * n1y) + 1.0f * n1z;
   const float bb = dot3(n1x, n1y, n1z, v1x - v2x, v1y - v2y, v1z - v2z);
 #pragma unroll
-  for (int c = 0; c < 6; c++) row[c * kColStride] = ok ? J[c] : 0.0f;  // (row = the wavefront's block + lane: consecutive banks)
-  row[6 * kColStride] = ok ? bb : 0.0f;
+  for (int c = 0; c < 6; c++) row[c * kColStride] = ok ? J[c] * kRowScaleJ : 0.0f;  // (row = the wavefront's block + lane: consecutive banks)
+  row[6 * kColStride] = ok ? bb * kRowScaleB : 0.0f;
 }
 
 // lane (t, half): add its term of the 32 pixels of its half (rows = this wavefront's columns) to acc0 / acc1: eight
@@ -143,7 +149,6 @@ __device__ __forceinline__ void icp_pixel_row(float v1x, float v1y, float v1z, f
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void accumulate_rows(const float *rows, const TermLane &T, int half, double &acc0, double &acc1) {
   const char *base = reinterpret_cast<const char *>(rows) + half * 32 * 4;
-  const v2f sc = {T.scale, T.scale};
 #pragma unroll
   for (int g = 0; g < 32; g += 8) {
     float4 a[2], b[2];
@@ -155,7 +160,7 @@ __device__ __forceinline__ void accumulate_rows(const float *rows, const TermLan
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const v2f a01 = {a[u].x, a[u].y}, a23 = {a[u].z, a[u].w}, b01 = {b[u].x, b[u].y}, b23 = {b[u].z, b[u].w};
-      const v2f q01 = (a01 * b01) * sc, q23 = (a23 * b23) * sc;  // fl(a * b), then the exact power-of-two scale
+      const v2f q01 = a01 * b01, q23 = a23 * b23;  // fl(J_i * J_j) * 2^20 (the rows carry the scales)
       acc0 += (double)rintf(q01.x);
       acc1 += (double)rintf(q01.y);
       acc0 += (double)rintf(q23.x);
