@@ -133,11 +133,21 @@ __device__ __forceinline__ void icp_pixel_row(float v1x, float v1y, float v1z, f
   const float dx = v2x - v1x, dy = v2y - v1y, dz = v2z - v1z;
   ok = ok && !beyond_dist_thresh(dot3(dx, dy, dz, dx, dy, dz));  // !(length > DIST_THRESH), icp_device.hpp
   ok = ok && !(dot3(n2x, n2y, n2z, n1x, n1y, n1z) < kNormThresh);
+  // A_T = G_T * n1 (icp_device.hpp icp_rot_rows / icp_pixel_terms spell out the reference's nine products per row group, zeros and ones
+  // included).  Here the row is only USED when every gate passed, i.e. all twelve inputs are finite: then 0 * n is +-0, 1 * n is n, and
+  // adding +-0 changes at most the sign of a zero -- which no product's rint'd integer can see.  So the zero / one terms are left out
+  // (12 instructions per pixel and iteration), and the strict / corrected choice is one wavefront-uniform branch instead of six selects.
   float J[6];
-  icp_rot_rows(v2x, v2y, v2z, n1x, n1y, n1z, corrected, J[0], J[1], J[2]);
-  J[3] = (1.0f * n1x + 0.0f * n1y) + 0.0f * n1z;
-  J[4] = (0.0f * n1x + 1.0f * n1y) + 0.0f * n1z;
-  J[5] = (0.0f * n1x + 0.0f * n1y) + 1.0f * n1z;
+  if (corrected) {
+    J[0] = (-v2z) * n1y + v2y * n1z;
+    J[1] = v2z * n1x + (-v2x) * n1z;
+    J[2] = (-v2y) * n1x + v2x * n1y;
+  } else {  // Q14: the reference's rows (0,-x,-y), (-z,0,x), (y,z,0)
+    J[0] = (-v2x) * n1y + (-v2y) * n1z;
+    J[1] = (-v2z) * n1x + v2x * n1z;
+    J[2] = v2y * n1x + v2z * n1y;
+  }
+  J[3] = n1x; J[4] = n1y; J[5] = n1z;
   const float bb = dot3(n1x, n1y, n1z, v1x - v2x, v1y - v2y, v1z - v2z);
 #pragma unroll
   for (int c = 0; c < 6; c++) row[c * kColStride] = ok ? J[c] * kRowScaleJ : 0.0f;  // (row = the wavefront's block + lane: consecutive banks)
@@ -378,15 +388,31 @@ __global__ __launch_bounds__(kTrkThreads, MINW) void track_persistent_kernel(Cam
             PixelRaw cur, nxt;
             bool have_cur, have_nxt = false;
             fetch(0, cur, have_cur);
+            // the usual case -- ONE matrix not yet in the work maps, this_trans of the previous iteration -- keeps its twelve used elements in
+            // scalar registers for the whole pass (round 6) instead of reading them from LDS for every pixel (four ds_read_b96 and their wait
+            // per pixel; a lane has up to 23 pixels of a 1080p level)
+            const bool one = nchain - applied == 1;
+            float m1[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+              m1[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(chain_s[16 * (one ? applied : 0) + i])));
             for (int k = 0; k < slots; k++) {  // uniform trip count: every lane writes a row (zeros past the end)
               if (k + 1 < slots) fetch(k + 1, nxt, have_nxt);
               float v2x = cur.v2[0], v2y = cur.v2[1], v2z = cur.v2[2], n2x = cur.n2[0], n2y = cur.n2[1], n2z = cur.n2[2];
-              for (int c = applied; c < nchain; c++) {  // transformVertexMap / transformNormalMap: the matrices not yet in the work maps
+              if (one) {
                 float ox, oy, oz;
-                mat4_mul_point(chain_s + 16 * c, v2x, v2y, v2z, 1.0f, ox, oy, oz);
+                mat4_mul_point(m1, v2x, v2y, v2z, 1.0f, ox, oy, oz);
                 v2x = ox; v2y = oy; v2z = oz;
-                mat4_mul_point(chain_s + 16 * c, n2x, n2y, n2z, 0.0f, ox, oy, oz);
+                mat4_mul_point(m1, n2x, n2y, n2z, 0.0f, ox, oy, oz);
                 n2x = ox; n2y = oy; n2z = oz;
+              } else {
+                for (int c = applied; c < nchain; c++) {  // transformVertexMap / transformNormalMap: the matrices not yet in the work maps
+                  float ox, oy, oz;
+                  mat4_mul_point(chain_s + 16 * c, v2x, v2y, v2z, 1.0f, ox, oy, oz);
+                  v2x = ox; v2y = oy; v2z = oz;
+                  mat4_mul_point(chain_s + 16 * c, n2x, n2y, n2z, 0.0f, ox, oy, oz);
+                  n2x = ox; n2y = oy; n2z = oz;
+                }
               }
               if (store && have_cur) {
                 const size_t q = (size_t)((long long)L.first + ((long long)k * P + wid) * kTrkThreads + tid);
