@@ -256,6 +256,30 @@ int svoslam_svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, i
 int svoslam_svo_fuse_commit_deferred(svoslam_workspace *ws, const uint8_t *d_colors, int32_t n, int32_t max_depth,
                                      svoslam_pool *pool, void *stream);
 int svoslam_svo_fuse_apply(svoslam_workspace *ws, svoslam_pool *pool, void *stream);
+/* Key-range sharded fusion: the plan + commit of ONE frame (splitKeys .. mipmapNodes, svo.cu:179-465) cut across `world` ranks by key range
+ * instead of being replicated on every rank (the reference is single-GPU, cuda_renderer.cpp:68; protocol:
+ * tests/test_keyrange_gloo.py).  Every rank holds a byte-identical replica of the pool and the frame's sorted keys (svoslam_svo_fuse_sort* +
+ * export / merge).  Per frame and rank: keyrange_commit plans and commits the rank's slice -- the keys under a contiguous run of level-3
+ * octree cells holding about n / world keys; every rank computes the same cuts -- where no replica can see it yet and writes the rank's
+ * DELTA into d_delta (delta_bytes of room; 64 bytes per key of the slice is ample): bucket sizes, new tiles, frontier links, {node,
+ * colour word} of the existing nodes it changed, records the receivers' ray-march marks need.  The caller all-gathers the deltas
+ * (word 10 of a delta = the number of 32-bit words that carry data).  keyrange_apply (same workspace) renumbers every rank's tiles into the
+ * reference's order (pass-major, depth, key), writes all deltas -- the own one included -- to their global place, makes the marks of the
+ * level grid / occupancy bricks from all keys, recomputes the colour words above the splitter level and sets the pool's size: the replica
+ * is then byte-identical to a pool that fused the frame in one piece.  d_deltas: HOST array of `world` device pointers in rank order.
+ * Frames whose splits reach above level 3 (a node of level 1 or 2 without children: the first frames of a map) are not applied:
+ * keyrange_status (blocking) then reports SVOSLAM_KEYRANGE_YOUNG and the frame must go through the replicated commit instead.
+ * world <= 16, max_depth >= 6. */
+#define SVOSLAM_KEYRANGE_YOUNG 1
+#define SVOSLAM_KEYRANGE_OVERFLOW 2  /* a delta did not fit its buffer */
+#define SVOSLAM_KEYRANGE_MISMATCH 4  /* deltas of different frames / pool states */
+#define SVOSLAM_KEYRANGE_USED_WORD 10
+int svoslam_svo_fuse_keyrange_commit(svoslam_workspace *ws, const unsigned long long *d_sorted_keys, const uint32_t *d_sorted_idx,
+                                     const uint8_t *d_colors, int32_t n, int32_t max_depth, svoslam_pool *pool, int32_t rank, int32_t world,
+                                     uint32_t *d_delta, int64_t delta_bytes, void *stream);
+int svoslam_svo_fuse_keyrange_apply(svoslam_workspace *ws, const unsigned long long *d_sorted_keys, int32_t n, int32_t max_depth, svoslam_pool *pool,
+                                    const uint32_t *const *d_deltas, int32_t world, void *stream);
+int svoslam_svo_fuse_keyrange_status(svoslam_workspace *ws, int32_t *flags, void *stream);
 
 /* replaces svo::svoFromVoxelGrid (svo.h:14, svo.cu:584-640).  d_centers,
  * d_colors: n x vec4 (VoxelGrid, common_types.h:55-63). */

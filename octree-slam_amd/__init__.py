@@ -103,6 +103,9 @@ SIGNATURES = {
     "svoslam_svo_fuse_commit_to": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _i32, _i32, _vp]),
     "svoslam_svo_fuse_commit_deferred": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _vp]),
     "svoslam_svo_fuse_apply": (C.c_int, [_vp, C.POINTER(_PoolStruct), _vp]),
+    "svoslam_svo_fuse_keyrange_commit": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _i32, _i32, _vp, C.c_int64, _vp]),
+    "svoslam_svo_fuse_keyrange_apply": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), C.POINTER(C.c_void_p), _i32, _vp]),
+    "svoslam_svo_fuse_keyrange_status": (C.c_int, [_vp, C.POINTER(C.c_int32), _vp]),
     "svoslam_frame_reader_open": (C.c_int, [C.POINTER(_vp), C.c_char_p, _f32]),
     "svoslam_frame_reader_close": (C.c_int, [_vp]),
     "svoslam_frame_reader_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
@@ -535,6 +538,31 @@ def svo_fuse_commit_deferred(ws, colors, max_depth, pool):
 
 def svo_fuse_apply(ws, pool):
     check(lib().svoslam_svo_fuse_apply(ws._h, C.byref(pool._p), _stream()))
+
+
+KEYRANGE_YOUNG, KEYRANGE_OVERFLOW, KEYRANGE_MISMATCH, KEYRANGE_USED_WORD = 1, 2, 4, 10
+
+
+def svo_fuse_keyrange_commit(ws, sorted_keys, sorted_idx, colors, max_depth, pool, rank, world, delta):
+    """key-range sharded fusion, first half: plan + (invisible) commit of rank's slice of the frame's sorted keys, its delta into `delta`
+    (a uint32 / int32 device tensor with room: 64 bytes per key of the slice is ample)"""
+    n = int(sorted_keys.shape[0])
+    check(lib().svoslam_svo_fuse_keyrange_commit(ws._h, _ptr(sorted_keys), _ptr(sorted_idx), _ptr(colors), n, int(max_depth), C.byref(pool._p),
+                                                 int(rank), int(world), _ptr(delta), int(delta.numel() * delta.element_size()), _stream()))
+
+
+def svo_fuse_keyrange_apply(ws, sorted_keys, max_depth, pool, deltas):
+    """second half, after the all-gather: every rank's delta (rank order, the own one included) into this replica"""
+    n = int(sorted_keys.shape[0])
+    arr = (C.c_void_p * len(deltas))(*[int(d.data_ptr()) for d in deltas])
+    check(lib().svoslam_svo_fuse_keyrange_apply(ws._h, _ptr(sorted_keys), n, int(max_depth), C.byref(pool._p), arr, len(deltas), _stream()))
+
+
+def svo_fuse_keyrange_status(ws):
+    """flags of the last apply on this workspace (blocking): 0 = applied"""
+    f = C.c_int32(0)
+    check(lib().svoslam_svo_fuse_keyrange_status(ws._h, C.byref(f), _stream()))
+    return int(f.value)
 
 
 def svo_from_voxel_grid(ws, centers, colors, max_depth, pool, center, edge_length):

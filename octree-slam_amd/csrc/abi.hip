@@ -242,6 +242,24 @@ int svoslam_svo_fuse_apply(svoslam_workspace *ws, svoslam_pool *pool, void *stre
   NEED_DEVICE();
   return svo_fuse_apply(ws, pool, S(stream));
 }
+int svoslam_svo_fuse_keyrange_commit(svoslam_workspace *ws, const unsigned long long *d_sorted_keys, const uint32_t *d_sorted_idx,
+                                     const uint8_t *d_colors, int32_t n, int32_t max_depth, svoslam_pool *pool, int32_t rank, int32_t world,
+                                     uint32_t *d_delta, int64_t delta_bytes, void *stream) {
+  NEED_DEVICE();
+  return svo_fuse_keyrange_commit(ws, d_sorted_keys, d_sorted_idx, d_colors, n, max_depth, pool, rank, world, d_delta, (long long)delta_bytes, S(stream));
+}
+int svoslam_svo_fuse_keyrange_apply(svoslam_workspace *ws, const unsigned long long *d_sorted_keys, int32_t n, int32_t max_depth, svoslam_pool *pool,
+                                    const uint32_t *const *d_deltas, int32_t world, void *stream) {
+  NEED_DEVICE();
+  return svo_fuse_keyrange_apply(ws, d_sorted_keys, n, max_depth, pool, d_deltas, world, S(stream));
+}
+int svoslam_svo_fuse_keyrange_status(svoslam_workspace *ws, int32_t *flags, void *stream) {
+  NEED_DEVICE();
+  int f = 0;
+  const int rc = svo_fuse_keyrange_status(ws, &f, S(stream));
+  if (flags) *flags = f;
+  return rc;
+}
 
 int svoslam_frame_reader_open(svoslam_frame_reader **reader, const char *association_file, float depth_units_per_metre) {
   return frame_reader_open(reader, association_file, depth_units_per_metre);

@@ -678,7 +678,10 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
                                                              u32 *__restrict__ apply_nodes, const u64 *__restrict__ rec_key,
                                                              const u32 *__restrict__ bucket_base, const u32 *__restrict__ n0_saved,
                                                              const u32 *__restrict__ leaf_rec0, const u32 *__restrict__ leaf_start,
-                                                             int *__restrict__ strad_bc, int brick_shift) {
+                                                             int *__restrict__ strad_bc, int brick_shift, const int *__restrict__ n_live) {
+  // n_live (optional; key-range sharded commit): only the first *n_live of the n sorted elements are keys, the rest is padding (key 1):
+  // the workgroups past them leave their list entries empty and go, and nobody searches the padding for the next head
+  if (n_live) { const int nl = *n_live; n = nl < n ? nl : n; }
   const bool early_links = leaf_rec0 != nullptr;
   // shadow != nullptr: deferred commit.  Every colour word goes to shadow[node] instead of the pool, children are read
   // through average_tile_deferred, and apply_nodes lists the nodes written, per workgroup (apply_append; the counts behind the lists),
@@ -693,6 +696,19 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   const int tid = (int)threadIdx.x;
   const int bid = xcd_tile(num_tiles);  // this workgroup's tile of the sorted keys
   if (bid >= num_tiles) return;
+  int search_tiles = num_tiles;  // where the search for the next head (below) ends
+  if (n_live) {
+    const int live_tiles = (n + kFillThreads - 1) / kFillThreads;
+    if (bid >= live_tiles) {  // padding only
+      if (tid >= 1 && tid < depth) {
+        strad[2 * ((size_t)tid * num_tiles + bid)] = kNoStraddler;
+        strad[2 * ((size_t)tid * num_tiles + bid) + 1] = 0u;
+      }
+      if (shadow && tid == 0) apply_nodes[(size_t)num_tiles * kFillThreads * (size_t)depth + bid] = 0u;
+      return;
+    }
+    search_tiles = live_tiles;
+  }
   if (tid == 0) apply_cnt = 0;  // (first used behind the set-up's barriers)
   // the workgroup's part of the apply list: `depth` entries per lane at most, written densely from its start (apply_append)
   u32 *apply_mine = apply_nodes ? apply_nodes + (size_t)bid * kFillThreads * (size_t)depth : nullptr;
@@ -765,7 +781,7 @@ __global__ __launch_bounds__(kFillThreads) void fill_mip_local_kernel(const u64 
   __syncthreads();
   if (bricks_on && tid == 0 && brick_cnt) brick_base = brick_ring_reserve(grid_dirty, brick_cnt);
   if (next_pos == 0x7FFFFFFF) {  // no head in the next workgroup (all duplicates / invalid points): look further
-    for (int nb = bid + 2; nb < num_tiles; nb++) {
+    for (int nb = bid + 2; nb < search_tiles; nb++) {
       const int jj = nb * kFillThreads + tid;
       if (jj < n && leaf_t[jj] != kNotHead) atomicMin(&next_pos, jj);
       __syncthreads();
@@ -912,9 +928,10 @@ __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__rest
                                                             int depth, const PlanCounts *__restrict__ counts,
                                                             int *__restrict__ d_size, u32 *__restrict__ grid_dirty,
                                                             int32_t *__restrict__ h_sizes, int *__restrict__ d_slot,
-                                                            unsigned long long *__restrict__ shadow, u32 epoch) {
+                                                            unsigned long long *__restrict__ shadow, u32 epoch, int keep_size) {
   SVO_HIGH_PRIO();
   // shadow != nullptr: deferred commit (see fill_mip_local_kernel); the list entries double as the apply list
+  // keep_size != 0 (key-range sharded commit): the pool's size is set by keyrange_finish_kernel, from every rank's record count
   auto average = [&](u32 child_base) { return shadow ? average_tile_deferred(pool, shadow, epoch, child_base) : average_tile(pool, child_base); };
   auto store = [&](u32 node, u32 word) {
     if (shadow) shadow_store(shadow, epoch, node, word);
@@ -953,12 +970,14 @@ __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__rest
   }
   if (threadIdx.x == 0) {
     if (counts->any_valid) store(0u, average(0u));
-    const int size_now = *d_size + 8 * counts->total_records;
-    *d_size = size_now;
-    if (h_sizes) {  // the host learns the size from pinned memory behind the commit's event (PoolTracker)
-      const int sl = *d_slot;
-      h_sizes[sl] = size_now;
-      *d_slot = (sl + 1) % 8;
+    if (!keep_size) {
+      const int size_now = *d_size + 8 * counts->total_records;
+      *d_size = size_now;
+      if (h_sizes) {  // the host learns the size from pinned memory behind the commit's event (PoolTracker)
+        const int sl = *d_slot;
+        h_sizes[sl] = size_now;
+        *d_slot = (sl + 1) % 8;
+      }
     }
   }
   // last kernel of the commit: every mark of this commit is in the bitmap (kernel boundaries); list the marked blocks
@@ -1865,8 +1884,12 @@ int svo_fuse_split_early(svoslam_workspace *ws, int n, int depth, svoslam_pool *
   return SVOSLAM_OK;
 }
 
+// keyrange (key-range sharded commit, below): a deferred commit of this rank's slice of the frame -- the workspace's sorted arrays hold the
+// slice followed by padding, *n_live its length --, without marks for the ray march's grid / bricks (keyrange_mark_kernel makes them, from
+// ALL keys), without the pool's new size and without the size readback (svo_fuse_keyrange_apply: keyrange_finish_kernel, tracker_push)
 static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, int slot,
-                       bool keep_plan, bool deferred, hipStream_t stream) {
+                       bool keep_plan, bool deferred, hipStream_t stream, const int *n_live = nullptr) {
+  const bool keyrange = n_live != nullptr;
   if (!ws || !pool || n < 0 || (n > 0 && !d_colors) || slot < 0 || slot > 1) return SVOSLAM_ERR_INVALID_ARG;
   if (pool_shadow_pending(pool)) return SVOSLAM_ERR_INVALID_ARG;  // a deferred commit of this pool has not been applied
   if (depth < 1 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
@@ -1921,7 +1944,7 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
   }
   SVO_TRY(tracker_make_room(pool));
   int brick_shift = -1;
-  u32 *grid_dirty = pool_accel_dirty_bitmap(pool, deferred ? (int)(epoch & 1u) : 0, depth, &brick_shift);  // nullptr: not a registered pool
+  u32 *grid_dirty = keyrange ? nullptr : pool_accel_dirty_bitmap(pool, deferred ? (int)(epoch & 1u) : 0, depth, &brick_shift);  // nullptr: not a registered pool
   auto enqueue = [&]() -> int {
     if (!early)
       split_all_kernel<<<split_blocks, 256, 0, stream>>>(ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
@@ -1930,18 +1953,18 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
     if (depth <= 12) fill_mip_local_kernel<12><<<xcd_grid(fill_tiles), kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
                                                                    grid_dirty, shadow, epoch, apply_nodes, ws->rec_key.as<u64>(),
                                                                    small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr, leaf_start,
-                                                                   two_tier ? strad_bc : nullptr, brick_shift);
+                                                                   two_tier ? strad_bc : nullptr, brick_shift, n_live);
     else fill_mip_local_kernel<16><<<xcd_grid(fill_tiles), kFillThreads, 0, stream>>>(skey, sidx, n, depth, leaf_t, d_colors, pool->d_data, strad, fill_tiles,
                                                                    grid_dirty, shadow, epoch, apply_nodes, ws->rec_key.as<u64>(),
                                                                    small_bucket_base(ws), small_n0(ws), early ? ws->leaf_rec0.as<u32>() : nullptr, leaf_start,
-                                                                   two_tier ? strad_bc : nullptr, brick_shift);
+                                                                   two_tier ? strad_bc : nullptr, brick_shift, n_live);
     if (two_tier)
       mip_straddle2_kernel<<<strad_groups, kStrad2Threads, 0, stream>>>(pool->d_data, strad, strad_bc, sstrad, small_strad_ticket(ws, slot), fill_tiles,
                                                                         depth, small_counts(ws), pool->d_size, grid_dirty,
                                                                         trk ? trk->h_size : nullptr, trk ? trk->d_slot : nullptr);
     else
       mip_straddle_kernel<<<1, kStradThreads, 0, stream>>>(pool->d_data, strad, fill_tiles, depth, small_counts(ws), pool->d_size, grid_dirty,
-                                                           trk ? trk->h_size : nullptr, trk ? trk->d_slot : nullptr, shadow, epoch);
+                                                           trk ? trk->h_size : nullptr, trk ? trk->d_slot : nullptr, shadow, epoch, keyrange ? 1 : 0);
     SVO_LAUNCH_CHECK();
     return SVOSLAM_OK;
   };
@@ -1950,6 +1973,7 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
       StageScope timed(kStageFuseCommit, stream);
       SVO_TRY(enqueue());
     }
+    if (keyrange) { ws->keyrange_bound = 8 * rmax; return SVOSLAM_OK; }
     pool->pending += 1;
     return tracker_push(pool, 8 * rmax, stream);
   }
@@ -2168,6 +2192,398 @@ int extract_voxel_grid(svoslam_workspace *ws, const svoslam_pool *pool, int dept
   SVO_LAUNCH_CHECK();
   SVO_HIP(hipStreamSynchronize(stream));
   *d_centers = ce; *d_colors = co; *n_out = num;
+  return SVOSLAM_OK;
+}
+
+
+// ----------------------------------------------------------------------------
+// key-range sharded commit (protocol pinned on the CPU by tests/test_keyrange_gloo.py)
+// ----------------------------------------------------------------------------
+// The plan + commit of ONE frame cut across `world` ranks by key range instead of being replicated on every rank.  Every rank holds a
+// byte-identical replica of the pool and the frame's sorted keys (sorted by their owners and all-gathered: svo_fuse_export_sorted /
+// svo_fuse_merge_sorted).  Two calls per frame and rank, ONE all-gather between them:
+//   svo_fuse_keyrange_commit  the rank's slice of the sorted keys -- the keys under a contiguous run of level-3 prefixes holding about
+//                             n / world keys (keyrange_bounds_kernel: every rank computes the same cuts) -- is planned (svo.cu:179-237)
+//                             and committed (:239-465) by the unchanged kernels as a DEFERRED commit: new tiles beyond the pool's size
+//                             in the rank's own numbering, colour words in the shadow array, nothing a replica could not still
+//                             discard.  keyrange_pack_* then writes the rank's DELTA: its (pass, depth) bucket sizes, its new tiles
+//                             (16 words each, links still in local numbering), the frontier nodes its pass-0 records link from,
+//                             {node, colour word} of every existing node it changed, the bricks whose siblings its splits created;
+//   [all-gather of the deltas -- the caller's: RCCL, or a table of precomputed deltas for an emulated rank]
+//   svo_fuse_keyrange_apply   numbering: the reference numbers the new tiles of a pass by the rank of their key among the pass's sorted
+//                             unique keys = bucket-major, key order inside a bucket; slices are key ranges, so rank s's records of
+//                             bucket b follow those of ranks < s: global index = bucket base + sum of the lower ranks' counts + local
+//                             rank in the bucket -- one table of world x 256 offsets (keyrange_setup_kernel).  Every delta (the own one
+//                             included) is written to its global place; the marks of the ray march's grid / bricks are made from ALL the
+//                             frame's keys against this replica's own dirty state (ranks render different frames: their dirty states
+//                             differ); the colour words of the nodes above the splitter level -- shared by several ranks' paths -- are
+//                             recomputed from the merged children, level by level, then the root pass (Q6); size and size readback.
+// Frames whose splits reach ABOVE the splitter level (a node of level < 3 without children: the first frames of a map, new territory)
+// would create one tile from several ranks: keyrange_setup_kernel raises kKrYoung and the result is undefined -- such frames belong to
+// the replicated commit (the general protocol, with the shared records ranked in their union, is the CPU test's; not built here).
+constexpr int kKrLevel = 3;
+constexpr int kKrMaxWorld = 16;
+constexpr int kKrHeader = 512;       // words: scalars, then the 256 bucket sizes at [256, 512)
+constexpr int kKrSibCap = 8192;      // entries
+constexpr int kKrShallowCap = 1024;  // keys (two words each)
+constexpr int kKrTiles0 = kKrHeader + kKrSibCap + 2 * kKrShallowCap;  // first word of the tiles
+enum { kKrMagic = 0, kKrRecords = 1, kKrWords = 2, kKrLinks = 3, kKrSib = 4, kKrShallow = 5, kKrAnyValid = 6, kKrOverflow = 7, kKrSliceKeys = 8,
+       kKrN0 = 9, kKrUsed = 10, kKrCapacity = 11, kKrDepth = 12 };
+enum { kKrYoung = 1, kKrOverflowed = 2, kKrMismatch = 4 };
+__host__ __device__ inline size_t kr_bid0(u32 records) { return (size_t)kKrTiles0 + 16 * (size_t)records; }
+__host__ __device__ inline size_t kr_links0(u32 records) { return kr_bid0(records) + (records + 3u) / 4u; }
+__host__ __device__ inline size_t kr_words0(u32 records, u32 links) { return kr_links0(records) + links; }
+
+// window of rank `rank`: win[0] = first, win[1] = end, win[2] = length of its slice of the sorted keys (invalid keys -- key 1 -- sort first
+// and belong to nobody).  Cut r lies at the end of the level-L run that holds key number r x valid / world.
+__global__ void keyrange_bounds_kernel(const u64 *__restrict__ skey, int n, int depth, int rank, int world, int *__restrict__ win) {
+  const int r = (int)threadIdx.x;
+  auto first_at_least = [&](int lo, int hi, u64 bound, int shift) {  // first j in [lo, hi) with (skey[j] >> shift) >= bound
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((skey[mid] >> shift) < bound) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  const int v0 = first_at_least(0, n, 2ull, 0);
+  const long long nv = n - v0;
+  int b = v0;
+  if (r >= world) b = n;
+  else if (r > 0) {
+    const int i = v0 + (int)((long long)r * nv / world);
+    if (i > v0) { const int sh = 3 * (depth - kKrLevel); b = first_at_least(i, n, (skey[i - 1] >> sh) + 1ull, sh); }
+  }
+  if (r <= world) win[4 + r] = b;
+  __syncthreads();
+  if (r == 0) { const int lo = win[4 + rank], hi = win[4 + rank + 1]; win[0] = lo; win[1] = hi; win[2] = hi - lo; }
+}
+
+__global__ __launch_bounds__(256) void keyrange_slice_kernel(const u64 *__restrict__ skey, const u32 *__restrict__ sidx, int n,
+                                                             const int *__restrict__ win, u64 *__restrict__ out_key, u32 *__restrict__ out_idx) {
+  const int j = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (j >= n) return;
+  const int lo = win[0], len = win[2];
+  out_key[j] = j < len ? skey[lo + j] : 1ull;  // the slice at the front, padding (invalid keys) behind it
+  out_idx[j] = j < len ? sidx[lo + j] : 0u;
+}
+
+__global__ __launch_bounds__(256) void keyrange_pack_header_kernel(u32 *__restrict__ delta, long long capacity_words, const u32 *__restrict__ bucket_base,
+                                                                   const PlanCounts *__restrict__ counts, const u32 *__restrict__ n0_saved,
+                                                                   const int *__restrict__ win, int depth) {
+  const int t = (int)threadIdx.x;
+  delta[256 + t] = bucket_base[t + 1] - bucket_base[t];
+  if (t == 0) {
+    const u32 R = (u32)counts->total_records, links = (u32)(counts->pass_start[1] - counts->pass_start[0]);
+    delta[kKrMagic] = 0x4B52414Eu;
+    delta[kKrRecords] = R; delta[kKrWords] = 0u; delta[kKrLinks] = links; delta[kKrSib] = 0u; delta[kKrShallow] = 0u;
+    delta[kKrAnyValid] = (u32)counts->any_valid; delta[kKrSliceKeys] = (u32)win[2]; delta[kKrN0] = *n0_saved; delta[kKrDepth] = (u32)depth;
+    delta[kKrCapacity] = capacity_words > 0xFFFFFFFFll ? 0xFFFFFFFFu : (u32)capacity_words;
+    const bool fits = (long long)kr_words0(R, links) <= capacity_words;
+    delta[kKrOverflow] = fits ? 0u : 1u;
+    delta[kKrUsed] = (u32)kr_words0(R, links);
+  }
+}
+
+// the new tiles (one lane per node), the records' buckets, the pass-0 records' frontier nodes, and what the receivers' brick / grid marks
+// need from the records: the bricks whose node this commit created (their childless siblings get their lines: pool_grid.hip
+// brick_siblings) and the keys of splits above the grid's block level (they re-label a whole cube)
+__global__ __launch_bounds__(256) void keyrange_pack_tiles_kernel(u32 *__restrict__ delta, const u32 *__restrict__ pool,
+                                                                  const unsigned long long *__restrict__ shadow, u32 epoch,
+                                                                  const u64 *__restrict__ rec_key, const u32 *__restrict__ rec_front,
+                                                                  const unsigned char *__restrict__ rec_pass, int brick_shift) {
+  if (delta[kKrOverflow]) return;
+  const u32 R = delta[kKrRecords], links = delta[kKrLinks], n0 = delta[kKrN0];
+  unsigned char *bid = reinterpret_cast<unsigned char *>(delta + kr_bid0(R));
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < 8 * (size_t)R; i += (size_t)gridDim.x * 256u) {
+    const u32 r = (u32)(i >> 3), q = (u32)(i & 7u);
+    const u32 node = n0 + 8u * r + q;
+    const unsigned long long sh = shadow[node];
+    const u32 w0 = pool[2 * (size_t)node], w1 = (u32)(sh >> 32) == epoch ? (u32)sh : pool[2 * (size_t)node + 1];
+    reinterpret_cast<uint2 *>(delta + kKrTiles0)[i] = make_uint2(w0, w1);
+    if (q == 0u) {
+      const u64 key = rec_key[r];
+      const int d = (63 - __clzll((long long)key)) / 3, pass = rec_pass[r];
+      bid[r] = (unsigned char)bucket_id(pass, d);
+      if (r < links) delta[kr_links0(R) + r] = rec_front[r];
+      if (d < kPoolGridBlockLevel) {
+        const u32 pos = atomicAdd(&delta[kKrShallow], 1u);
+        if (pos < (u32)kKrShallowCap) reinterpret_cast<u64 *>(delta + kKrHeader + kKrSibCap)[pos] = key;
+      }
+      if (brick_shift >= 0 && d == brick_node_level(brick_shift) && pass >= 1) {
+        u32 x = 0, y = 0, z = 0;
+        for (int k = 1; k <= d; k++) {
+          const u32 oct = (u32)(key >> (3 * (d - k))) & 7u;
+          x = (x << 1) | (oct & 1u); y = (y << 1) | ((oct >> 1) & 1u); z = (z << 1) | (oct >> 2);
+        }
+        const u32 org = brick_window_origin(brick_shift) >> 2;
+        x -= org; y -= org; z -= org;
+        if ((x | y | z) < (kBrickWindowCells >> 2)) {
+          const u32 pos = atomicAdd(&delta[kKrSib], 1u);
+          if (pos < (u32)kKrSibCap) delta[kKrHeader + pos] = brick_list_entry(x, y, z);
+        }
+      }
+    }
+  }
+}
+
+// {node, colour word} of the EXISTING nodes (below the pool's size) this commit changed: the leaf kernel's per-workgroup lists, then the
+// straddler list (workgroups past the lists take 2048 entries each).  A workgroup counts, reserves with one atomic, writes.
+__global__ __launch_bounds__(256) void keyrange_pack_words_kernel(u32 *__restrict__ delta, const unsigned long long *__restrict__ shadow,
+                                                                  const u32 *__restrict__ apply_nodes, int fill_tiles, int list_cap,
+                                                                  const u32 *__restrict__ strad, int strad_first, int strad_end) {
+  if (delta[kKrOverflow]) return;
+  __shared__ u32 wave_cnt[4], base_s;
+  const u32 R = delta[kKrRecords], links = delta[kKrLinks], n0 = delta[kKrN0], cap = delta[kKrCapacity];
+  const int t = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool lists = t < fill_tiles;
+  const u32 *src; u32 cnt, stride;
+  if (lists) { src = apply_nodes + (size_t)t * list_cap; cnt = apply_nodes[(size_t)fill_tiles * list_cap + t]; stride = 1u; }
+  else {
+    const long long first = strad_first + (long long)(t - fill_tiles) * 2048;
+    src = strad + 2 * first; stride = 2u;
+    const long long left = (long long)strad_end - first;
+    cnt = left <= 0 ? 0u : (left < 2048 ? (u32)left : 2048u);
+  }
+  auto wanted = [&](u32 i) { if (i >= cnt) return false; const u32 node = src[(size_t)i * stride]; return node != kNoStraddler && node < n0; };
+  u32 mine = 0;
+  for (u32 i = (u32)tid; i < cnt; i += 256u) mine += wanted(i) ? 1u : 0u;
+  u32 incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+  if (lane == 63) wave_cnt[wave] = incl;
+  __syncthreads();
+  u32 before = 0, total = 0;
+  for (int w = 0; w < 4; w++) { if (w < wave) before += wave_cnt[w]; total += wave_cnt[w]; }
+  if (tid == 0) base_s = total ? atomicAdd(&delta[kKrWords], total) : 0u;
+  __syncthreads();
+  if (!total) return;
+  const size_t w0 = kr_words0(R, links);
+  if (w0 + 2 * ((size_t)base_s + total) > (size_t)cap) { if (tid == 0) delta[kKrOverflow] = 1u; return; }
+  u32 pos = base_s + before + incl - mine;
+  for (u32 i = (u32)tid; i < cnt; i += 256u)
+    if (wanted(i)) {
+      const u32 node = src[(size_t)i * stride];
+      delta[w0 + 2 * (size_t)pos] = node;
+      delta[w0 + 2 * (size_t)pos + 1] = (u32)shadow[node];
+      pos++;
+    }
+  if (tid == 0) atomicMax(&delta[kKrUsed], (u32)(w0 + 2 * ((size_t)base_s + total)));
+}
+
+struct KrDeltas { const u32 *d[kKrMaxWorld]; };
+
+// numbering: table[s][b] = what to add to rank s's local record rank in bucket b to get its place in the reference's order; scal[0] =
+// records of all ranks, [1] = status flags, [2] = first new tile, [3] = any valid key
+__global__ __launch_bounds__(256) void keyrange_setup_kernel(KrDeltas D, int world, int *__restrict__ table, u32 *__restrict__ scal) {
+  __shared__ unsigned tmp[4];
+  const int b = (int)threadIdx.x;
+  u32 tot = 0, flags = 0, any = 0;
+  for (int s = 0; s < world; s++) {
+    tot += D.d[s][256 + b];
+    if (D.d[s][kKrOverflow]) flags |= kKrOverflowed;
+    if (D.d[s][kKrN0] != D.d[0][kKrN0] || D.d[s][kKrMagic] != 0x4B52414Eu) flags |= kKrMismatch;
+    any |= D.d[s][kKrAnyValid];
+  }
+  const int d = (b & 15) + 1;  // bucket_id(p, d) = 16 p + d - 1
+  if (tot && d < kKrLevel) flags |= kKrYoung;
+  unsigned total;
+  const u32 gbase = block256_exclusive_scan(tot, tmp, total);
+  u32 lower = 0;
+  for (int s = 0; s < world; s++) {
+    const u32 c = D.d[s][256 + b];
+    unsigned ltot;
+    const u32 lbase = block256_exclusive_scan(c, tmp, ltot);
+    table[s * 256 + b] = (int)(gbase + lower) - (int)lbase;
+    lower += c;
+  }
+  if (flags) atomicOr(&scal[1], flags);
+  if (b == 0) { scal[0] = total; scal[2] = D.d[0][kKrN0]; scal[3] = any; }
+}
+
+// every delta to its global place (blockIdx.y = the delta's rank): tiles with their links renumbered, the pass-0 links, the colour words
+// of existing nodes, and the record-borne marks (sibling ring, cubes of shallow splits) into this replica's dirty state
+__global__ __launch_bounds__(256) void keyrange_apply_kernel(KrDeltas D, const int *__restrict__ table, const u32 *__restrict__ scal,
+                                                             u32 *__restrict__ pool, u32 *__restrict__ dirty) {
+  if (scal[1]) return;  // young / overflowed / mismatching deltas: nothing is applied (svo_fuse_keyrange_status reports it)
+  const int s = (int)blockIdx.y;
+  const u32 *delta = D.d[s];
+  const int *T = table + s * 256;
+  const u32 R = delta[kKrRecords], links = delta[kKrLinks], words = delta[kKrWords], n0 = delta[kKrN0];
+  const unsigned char *bid = reinterpret_cast<const unsigned char *>(delta + kr_bid0(R));
+  auto place = [&](u32 r) { return (u32)((int)r + T[bid[r]]); };
+  const size_t stride = (size_t)gridDim.x * 256u, t0 = (size_t)blockIdx.x * 256u + threadIdx.x;
+  for (size_t i = t0; i < 8 * (size_t)R; i += stride) {
+    const u32 r = (u32)(i >> 3), q = (u32)(i & 7u);
+    uint2 w = reinterpret_cast<const uint2 *>(delta + kKrTiles0)[i];
+    if (w.x & kFlag) w.x = kFlag | ((n0 + 8u * place(((w.x & kMask) - n0) >> 3)) & kMask);
+    reinterpret_cast<uint2 *>(pool)[(size_t)n0 + 8 * (size_t)place(r) + q] = w;
+  }
+  for (size_t r = t0; r < links; r += stride) pool[2 * (size_t)delta[kr_links0(R) + r]] = kFlag | ((n0 + 8u * place((u32)r)) & kMask);
+  const size_t w0 = kr_words0(R, links);
+  for (size_t i = t0; i < words; i += stride) pool[2 * (size_t)delta[w0 + 2 * i] + 1] = delta[w0 + 2 * i + 1];
+  if (dirty) {
+    const u32 sib = delta[kKrSib] < (u32)kKrSibCap ? delta[kKrSib] : (u32)kKrSibCap;
+    for (size_t i = t0; i < sib; i += stride) brick_sibling_list(dirty, delta[kKrHeader + i]);
+    const u32 sh = delta[kKrShallow];
+    if (sh > (u32)kKrShallowCap) {  // more shallow splits than the list holds: every block is stale
+      for (size_t i = t0; i < (size_t)kPoolGridDirtyWords; i += stride) dirty[i] = 0xFFFFFFFFu;
+    } else {
+      for (size_t i = t0; i < sh; i += stride) {
+        const u64 key = reinterpret_cast<const u64 *>(delta + kKrHeader + kKrSibCap)[i];
+        pool_grid_mark(dirty, key, (63 - __clzll((long long)key)) / 3);
+      }
+    }
+  }
+}
+
+// the marks of the ray march's level grid and occupancy bricks from ALL keys of the frame (as the leaf kernel makes them for the keys it
+// commits: pool_grid.hpp), and the level-2 prefixes that occur (top[0..1]: a 64-bit mask) for the shared nodes' colour words
+__global__ __launch_bounds__(256) void keyrange_mark_kernel(const u64 *__restrict__ skey, int n, int depth, u32 *__restrict__ dirty, int brick_shift,
+                                                            unsigned long long *__restrict__ top) {
+  __shared__ u32 brick_cnt, brick_base;
+  __shared__ unsigned long long mask_s;
+  const int tid = (int)threadIdx.x, j = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (tid == 0) { brick_cnt = 0u; mask_s = 0ull; }
+  __syncthreads();
+  u64 key = 1; int c = 0;
+  const bool head = j < n && is_head(skey, j, key, c, depth);
+  if (head && c < 2) atomicOr(&mask_s, 1ull << ((key >> (3 * (depth - 2))) & 63ull));
+  if (dirty && head && c < kPoolGridBlockLevel) pool_grid_mark(dirty, key, depth);
+  const bool bricks_on = dirty != nullptr && brick_shift >= 0 && depth >= brick_node_level(brick_shift);
+  u32 entry = 0, off = 0;
+  const bool mine = bricks_on && brick_mark_test(dirty, head && c < brick_node_level(brick_shift), key, depth, brick_shift, entry);
+  const unsigned long long bm = __ballot(mine);
+  if (bm) {
+    const int leader = __ffsll((long long)bm) - 1;
+    u32 woff = 0;
+    if ((tid & 63) == leader) woff = atomicAdd(&brick_cnt, (u32)__popcll(bm));
+    off = (u32)__shfl((int)woff, leader) + (u32)__popcll(bm & ((1ull << (tid & 63)) - 1ull));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (brick_cnt) brick_base = brick_ring_reserve(dirty, brick_cnt);
+    if (mask_s) atomicOr(top, mask_s);
+  }
+  __syncthreads();
+  if (mine) brick_ring_store(dirty, brick_base + off, entry);
+}
+
+// one workgroup, behind everything else: the colour words of the nodes above the splitter level on the frame's paths from their merged
+// children (mipmapNodes restricted to levels 2 and 1, svo.cu:450-465), the root pass (Q6), the pool's size and its readback, the list of
+// the marked grid blocks
+__global__ __launch_bounds__(256) void keyrange_finish_kernel(u32 *__restrict__ pool, u32 *__restrict__ scal, unsigned long long *__restrict__ top,
+                                                              int *__restrict__ d_size, int32_t *__restrict__ h_sizes, int *__restrict__ d_slot,
+                                                              u32 *__restrict__ dirty) {
+  const int tid = (int)threadIdx.x;
+  const bool ok = scal[1] == 0u;
+  const unsigned long long m2 = *top;
+  if (ok) {
+    if (tid < 64 && ((m2 >> tid) & 1ull)) {
+      const u32 node1 = (u32)tid >> 3, base1 = pool[2 * (size_t)node1] & kMask;
+      const u32 node2 = base1 + ((u32)tid & 7u);
+      pool[2 * (size_t)node2 + 1] = average_tile(pool, pool[2 * (size_t)node2] & kMask);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < 8 && ((m2 >> (8 * tid)) & 0xFFull)) pool[2 * (size_t)tid + 1] = average_tile(pool, pool[2 * (size_t)tid] & kMask);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (ok && scal[3]) pool[1] = average_tile(pool, 0u);  // Q6
+    const int size_now = ok ? (int)(scal[2] + 8u * scal[0]) : *d_size;
+    *d_size = size_now;
+    if (h_sizes) { const int sl = *d_slot; h_sizes[sl] = size_now; *d_slot = (sl + 1) % 8; }
+    *top = 0ull;
+  }
+  if (dirty) pool_grid_compact(dirty, 256);
+}
+
+static int kr_scratch(svoslam_workspace *ws, int n) {  // slice arrays + window / table / scalars (zeroed once)
+  SVO_TRY(ws->kr_keys.reserve((size_t)n * 8));
+  SVO_TRY(ws->kr_idx.reserve((size_t)n * 4));
+  if (ws->kr_small.bytes < 32768) {
+    SVO_TRY(ws->kr_small.reserve(32768));
+    SVO_HIP(memset_sync(ws->kr_small.ptr, 0, ws->kr_small.bytes));
+  }
+  return SVOSLAM_OK;
+}
+static inline int *kr_win(svoslam_workspace *ws) { return ws->kr_small.as<int>(); }                       // [0..3] window, [4..4+world] cuts
+static inline u32 *kr_scal(svoslam_workspace *ws) { return ws->kr_small.as<u32>() + 64; }                 // setup scalars
+static inline unsigned long long *kr_top(svoslam_workspace *ws) { return reinterpret_cast<unsigned long long *>(ws->kr_small.as<u32>() + 96); }
+static inline int *kr_table(svoslam_workspace *ws) { return ws->kr_small.as<int>() + 128; }               // [world][256]
+
+int svo_fuse_keyrange_commit(svoslam_workspace *ws, const unsigned long long *d_keys, const uint32_t *d_idx, const uint8_t *d_colors, int n,
+                             int depth, svoslam_pool *pool, int rank, int world, uint32_t *d_delta, long long delta_bytes, hipStream_t stream) {
+  if (!ws || !pool || !d_delta || n <= 0 || !d_keys || !d_idx || !d_colors) return SVOSLAM_ERR_INVALID_ARG;
+  if (world < 1 || world > kKrMaxWorld || rank < 0 || rank >= world) return SVOSLAM_ERR_INVALID_ARG;
+  if (depth < kKrLevel + 3 || depth > SVOSLAM_MAX_DEPTH) return SVOSLAM_ERR_DEPTH;
+  if (delta_bytes < (long long)(kKrTiles0 + 64) * 4) return SVOSLAM_ERR_INVALID_ARG;
+  SVO_TRY(kr_scratch(ws, n));
+  int *win = kr_win(ws);
+  keyrange_bounds_kernel<<<1, 64, 0, stream>>>(d_keys, n, depth, rank, world, win);
+  keyrange_slice_kernel<<<cdiv(n, 256), 256, 0, stream>>>(d_keys, d_idx, n, win, ws->kr_keys.as<u64>(), ws->kr_idx.as<u32>());
+  SVO_LAUNCH_CHECK();
+  SVO_TRY(svo_fuse_adopt_sorted(ws, ws->kr_keys.as<u64>(), ws->kr_idx.as<u32>(), n, depth));
+  SVO_TRY(svo_fuse_plan(ws, n, depth, pool, stream));
+  SVO_TRY(commit_impl(ws, d_colors, n, depth, pool, 0, false, true, stream, win + 2));
+  // the delta
+  unsigned long long *shadow = nullptr;
+  u32 epoch = 0;
+  SVO_TRY(pool_shadow_current(pool, &shadow, &epoch));
+  int brick_shift = -1;
+  (void)pool_accel_dirty_bitmap(pool, 0, depth, &brick_shift);  // (the shape this pool's bricks have, or will have, at this depth)
+  if (depth < brick_node_level(brick_shift < 0 ? 0 : brick_shift)) brick_shift = -1;
+  const int fill_tiles = ws->deferred_tiles;
+  const long long rmax = max_records(n, depth);
+  int tile_blocks = (int)cdiv(8 * rmax, 256);
+  if (tile_blocks > 4096) tile_blocks = 4096;
+  const int strad_first = fill_tiles, strad_end = depth * fill_tiles;
+  const int strad_blocks = (int)cdiv((long long)strad_end - strad_first, 2048);
+  keyrange_pack_header_kernel<<<1, 256, 0, stream>>>(d_delta, delta_bytes / 4, small_bucket_base(ws), small_counts(ws), small_n0(ws), win, depth);
+  keyrange_pack_tiles_kernel<<<tile_blocks, 256, 0, stream>>>(d_delta, pool->d_data, shadow, epoch, ws->rec_key.as<u64>(), ws->rec_front.as<u32>(),
+                                                              ws->rec_pass.as<unsigned char>(), brick_shift);
+  keyrange_pack_words_kernel<<<fill_tiles + strad_blocks, 256, 0, stream>>>(d_delta, shadow, ws->apply_nodes.as<u32>(), fill_tiles, kFillThreads * depth,
+                                                                            ws->strad.as<u32>(), strad_first, strad_end);
+  SVO_LAUNCH_CHECK();
+  pool_shadow_end(pool);
+  ws->deferred_pool = nullptr;
+  ws->keyrange_pool = pool;
+  return SVOSLAM_OK;
+}
+
+int svo_fuse_keyrange_apply(svoslam_workspace *ws, const unsigned long long *d_keys, int n, int depth, svoslam_pool *pool,
+                            const uint32_t *const *d_deltas, int world, hipStream_t stream) {
+  if (!ws || !pool || !d_deltas || !d_keys || n <= 0 || world < 1 || world > kKrMaxWorld) return SVOSLAM_ERR_INVALID_ARG;
+  if (ws->keyrange_pool != pool) return SVOSLAM_ERR_INVALID_ARG;  // svo_fuse_keyrange_commit of this frame has not run on this workspace
+  ws->keyrange_pool = nullptr;
+  KrDeltas D;
+  for (int s = 0; s < kKrMaxWorld; s++) D.d[s] = s < world ? d_deltas[s] : nullptr;
+  for (int s = 0; s < world; s++) if (!D.d[s]) return SVOSLAM_ERR_INVALID_ARG;
+  PoolTracker *trk = tracker_of(pool);
+  int brick_shift = -1;
+  u32 *dirty = pool_accel_dirty_bitmap(pool, 0, depth, &brick_shift);  // direct-commit state; nullptr: not a registered pool
+  const long long rmax = max_records(n, depth);
+  int blocks = (int)cdiv(8 * rmax / (world > 1 ? world : 1) + 1, 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 64) blocks = 64;
+  keyrange_setup_kernel<<<1, 256, 0, stream>>>(D, world, kr_table(ws), kr_scal(ws));
+  keyrange_apply_kernel<<<dim3((unsigned)blocks, (unsigned)world), 256, 0, stream>>>(D, kr_table(ws), kr_scal(ws), pool->d_data, dirty);
+  keyrange_mark_kernel<<<cdiv(n, 256), 256, 0, stream>>>(d_keys, n, depth, dirty, brick_shift, kr_top(ws));
+  SVO_TRY(tracker_make_room(pool));
+  keyrange_finish_kernel<<<1, 256, 0, stream>>>(pool->d_data, kr_scal(ws), kr_top(ws), pool->d_size, trk ? trk->h_size : nullptr,
+                                                trk ? trk->d_slot : nullptr, dirty);
+  SVO_LAUNCH_CHECK();
+  pool->pending += 1;
+  return tracker_push(pool, ws->keyrange_bound, stream);
+}
+
+// flags of the last svo_fuse_keyrange_apply on this workspace (blocking): 0 = applied; kKrYoung / kKrOverflowed / kKrMismatch = NOT applied.
+// used_bytes (optional, [world]): bytes of each delta that carry data (what an all-gather has to move)
+int svo_fuse_keyrange_status(svoslam_workspace *ws, int *flags, hipStream_t stream) {
+  if (!ws || !flags || ws->kr_small.bytes == 0) return SVOSLAM_ERR_INVALID_ARG;
+  u32 f = 0;
+  SVO_HIP(hipMemcpyAsync(&f, kr_scal(ws) + 1, 4, hipMemcpyDeviceToHost, stream));
+  SVO_HIP(hipStreamSynchronize(stream));
+  *flags = (int)f;
+  if (f) SVO_HIP(memset_sync(kr_scal(ws) + 1, 0, 4));
   return SVOSLAM_OK;
 }
 

@@ -39,6 +39,11 @@ int svo_fuse_commit_to(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
 int svo_fuse_commit(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, hipStream_t stream);
 int svo_fuse_commit_deferred(svoslam_workspace *ws, const uint8_t *d_colors, int n, int depth, svoslam_pool *pool, hipStream_t stream);
 int svo_fuse_apply(svoslam_workspace *ws, svoslam_pool *pool, hipStream_t stream);
+int svo_fuse_keyrange_commit(svoslam_workspace *ws, const unsigned long long *d_keys, const uint32_t *d_idx, const uint8_t *d_colors, int n,
+                             int depth, svoslam_pool *pool, int rank, int world, uint32_t *d_delta, long long delta_bytes, hipStream_t stream);
+int svo_fuse_keyrange_apply(svoslam_workspace *ws, const unsigned long long *d_keys, int n, int depth, svoslam_pool *pool,
+                            const uint32_t *const *d_deltas, int world, hipStream_t stream);
+int svo_fuse_keyrange_status(svoslam_workspace *ws, int *flags, hipStream_t stream);
 int svo_from_point_cloud(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,
                          svoslam_pool *pool, const float center[3], float edge, svoslam_fuse_stats *stats,
                          hipStream_t stream);

@@ -48,6 +48,8 @@ struct svoslam_workspace {
   svoslam::DeviceBuffer path_nodes;                       // [(D-1)][n] node index per owned depth (mip lists)
   svoslam::DeviceBuffer strad;                            // [D][tiles][2] nodes whose leaf run crosses a workgroup (async commit)
   svoslam::DeviceBuffer strad_b;                          // the same for the commit of the plan to a second replica of the pool
+  svoslam::DeviceBuffer kr_keys, kr_idx, kr_small;        // key-range sharded commit: the rank's slice of the sorted arrays; window, numbering table, scalars
+  const void *keyrange_pool = nullptr;                    // ... svo_fuse_keyrange_commit has run for this pool, svo_fuse_keyrange_apply is due
   svoslam::DeviceBuffer apply_nodes;                      // deferred commit: per fill tile, the nodes its workgroup wrote (dense from the tile's start; counts behind the lists)
   // deferred commit waiting for svo_fuse_apply (what the apply launch needs)
   const void *deferred_pool = nullptr;
@@ -64,6 +66,7 @@ struct svoslam_workspace {
   int planned_n = -1;
   const void *early_split_pool = nullptr;                  // svo_fuse_split_early has initialised the planned splits' tiles in this pool
   bool structure_planned = false;                          // ... by svo_fuse_plan_structure (its reservation is released by its commit)
+  long long keyrange_bound = 0;                            // key-range commit: the plan's reservation, released by svo_fuse_keyrange_apply's size readback
   const void *planned_pool = nullptr;                      // the pool svo_fuse_plan read (its reservation is already booked)
   svoslam::GraphCache g_sort, g_plan, g_commit;            // recorded launch sequences of the three phases
   // `small` (4 KB of totals / bases / counters) is zeroed when it is created: the planner's any_valid word and arrival

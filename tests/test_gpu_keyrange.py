@@ -1,0 +1,145 @@
+"""Key-range sharded fusion on the GPU (csrc/svo_build.hip "key-range sharded commit"; the protocol is pinned on the CPU by
+tests/test_keyrange_gloo.py): `world` replicas of one pool in ONE process stand for the ranks -- every frame each of them plans and commits
+its slice of the frame's sorted keys (svoslam_svo_fuse_keyrange_commit), the deltas are "all-gathered" (the tensors are simply shared), and
+every replica applies all of them (svoslam_svo_fuse_keyrange_apply).  After every frame every replica must equal, byte for byte, the pool
+that fused the frame in one piece (which in turn equals the CPU oracle's), and render the same image with the same step / level counters
+through the level grid and the occupancy bricks -- replica 0 renders after every frame, the last replica only at the end (ranks of a
+frame-sharded session render different frames: their dirty states differ)."""
+import numpy as np
+import pytest
+
+from util import describe_mismatch, surface_cloud
+
+pytestmark = pytest.mark.gpu
+
+VIEWS = (((0.1, 0.2, -2.6), (0, 0, 0), (96, 72)), ((0.1, 0.2, -1.2), (0, 0, 0), (24, 480)), ((0.3, 0.1, 0.62), (0.28, 0.05, 0.2), (32, 480)))
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import svoslam_pkg
+    return svoslam_pkg.load(), torch
+
+
+def render(pkg, torch, pool, view, w, h, center, edge):
+    img = torch.full((h, w, 4), 9, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+    pkg.cone_trace_svo(img, 45.0, view, pool.data_ptr, center, edge, 0, counters=cnt)
+    return img.cpu().numpy(), cnt.cpu().tolist()
+
+
+@pytest.mark.parametrize("world,depth", [(2, 12), (3, 12), (8, 12), (4, 14), (8, 9)])
+def test_keyrange_replicas_equal_the_one_piece_fusion(env, oracle, world, depth):
+    pkg, torch = env
+    rng = np.random.default_rng(40 + world + depth)
+    center, edge = (0.0, 0.0, 0.0), 1.0
+    n = 12000
+    ref, opool = pkg.Pool(1 << 22), oracle.Pool()
+    reps = [pkg.Pool(1 << 22) for _ in range(world)]
+    ws_sort, ws_ref = pkg.Workspace(), pkg.Workspace()
+    wss = [pkg.Workspace() for _ in range(world)]
+    cap_words = 10752 + 48 * n
+    deltas = [torch.zeros(cap_words, dtype=torch.int32, device="cuda") for _ in range(world)]
+    keys = torch.empty(n, dtype=torch.int64, device="cuda"); idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    base, bcol = surface_cloud(rng, n)
+    sharded_frames, young_frames, used = 0, 0, []
+    for f in range(7):
+        if f == 0:
+            pts, col = base, bcol
+        else:   # the surface again, a little displaced and with new colours; frame 4 brings points with NaNs and duplicates
+            pts = (base + rng.normal(0, 0.002, base.shape).astype(np.float32) + np.float32(0.003 * f)).astype(np.float32)
+            col = rng.integers(0, 256, bcol.shape, dtype=np.uint8)
+            if f == 4:
+                pts[::37] = np.nan
+                pts[1::50] = pts[0]
+        tp, tc = torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda()
+        pkg.svo_fuse_sort(ws_sort, tp, depth, center, edge)
+        pkg.svo_fuse_export_sorted(ws_sort, n, keys, idx)
+
+        def replicated(pool, ws):
+            pkg.svo_fuse_adopt_sorted(ws, keys, idx, depth)
+            pkg.svo_fuse_plan(ws, n, depth, pool)
+            pkg.svo_fuse_commit(ws, tc, depth, pool)
+
+        replicated(ref, ws_ref)
+        opool.insert_cloud(pts, col, depth, center, edge)
+        if f == 0:      # the first frame of a map is young by definition: replicated on every rank
+            for r in range(world):
+                replicated(reps[r], wss[r])
+        else:
+            for r in range(world):
+                pkg.svo_fuse_keyrange_commit(wss[r], keys, idx, tc, depth, reps[r], r, world, deltas[r])
+            flags = set()
+            for r in range(world):
+                pkg.svo_fuse_keyrange_apply(wss[r], keys, depth, reps[r], deltas)
+                flags.add(pkg.svo_fuse_keyrange_status(wss[r]))
+            assert len(flags) == 1, flags                      # every rank comes to the same verdict
+            fl = flags.pop()
+            assert fl in (0, pkg.KEYRANGE_YOUNG), fl
+            if fl:                                             # a split above the splitter level: nothing was applied; replicated instead
+                young_frames += 1
+                for r in range(world):
+                    replicated(reps[r], wss[r])
+            else:
+                sharded_frames += 1
+                used.append([int(d[pkg.KEYRANGE_USED_WORD].item()) * 4 for d in deltas])
+        want = ref.words()
+        assert np.array_equal(want, opool.words())
+        for r in range(world):
+            assert reps[r].size == ref.size, (f, r, reps[r].size, ref.size)
+            got = reps[r].words()
+            assert np.array_equal(got, want), (f, r, np.nonzero(got != want)[0][:10], sharded_frames)
+        for eye, tgt, (w, h) in VIEWS[: 3 if f % 2 == 0 else 1]:
+            view = oracle.look_at(eye, tgt, (0, 1, 0))
+            a, ca = render(pkg, torch, ref, view, w, h, center, edge)
+            b, cb = render(pkg, torch, reps[0], view, w, h, center, edge)
+            assert np.array_equal(a, b) and ca == cb, (f, eye, describe_mismatch(b, a), ca, cb)
+    assert sharded_frames >= 4, (sharded_frames, young_frames)
+    for eye, tgt, (w, h) in VIEWS:   # the last replica has rendered nothing so far: six frames of marks at once
+        view = oracle.look_at(eye, tgt, (0, 1, 0))
+        a, ca = render(pkg, torch, ref, view, w, h, center, edge)
+        b, cb = render(pkg, torch, reps[-1], view, w, h, center, edge)
+        assert np.array_equal(a, b) and ca == cb, (eye, describe_mismatch(b, a), ca, cb)
+        if depth <= 12:
+            words = opool.words()
+            o, steps, levels = oracle.cone_trace(words, w, h, 45.0, view, center, edge, 0)
+            assert np.array_equal(a, o) and ca == [steps, levels]
+    total = np.array(used).sum(1)
+    print("world %d depth %d: %d key-range frames (%d young), delta bytes per frame all ranks: %s; per rank of the last frame: %s"
+          % (world, depth, sharded_frames, young_frames, total.tolist(), used[-1]))
+    assert total.max() < 64 * depth * n   # 8 bytes per touched node + 64 per new tile (these jittered clouds give nearly every key its own chain of new tiles) + 43 KB fixed per rank
+
+
+def test_keyrange_young_frame_is_refused(env, oracle):
+    """a frame that splits nodes above the splitter level (here: the second frame lies in octants the first never touched) is not applied:
+    every replica stays as it was and reports KEYRANGE_YOUNG"""
+    pkg, torch = env
+    rng = np.random.default_rng(5)
+    center, edge, depth, n, world = (0.0, 0.0, 0.0), 1.0, 10, 4000, 2
+    reps, wss, ws_sort = [pkg.Pool(1 << 20) for _ in range(world)], [pkg.Workspace() for _ in range(world)], pkg.Workspace()
+    pts = (rng.random((n, 3), dtype=np.float32) * np.float32(0.2) + np.float32(0.1)).astype(np.float32)      # one corner of one octant
+    col = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+    for r in range(world):
+        pkg.svo_from_point_cloud_async(wss[r], torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, reps[r], center, edge)
+    before = reps[0].words().copy()
+    pts2 = (-pts).astype(np.float32)                                                                      # the opposite octant
+    tp, tc = torch.from_numpy(pts2).cuda(), torch.from_numpy(col).cuda()
+    keys = torch.empty(n, dtype=torch.int64, device="cuda"); idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    pkg.svo_fuse_sort(ws_sort, tp, depth, center, edge)
+    pkg.svo_fuse_export_sorted(ws_sort, n, keys, idx)
+    deltas = [torch.zeros(10752 + 48 * n, dtype=torch.int32, device="cuda") for _ in range(world)]
+    for r in range(world):
+        pkg.svo_fuse_keyrange_commit(wss[r], keys, idx, tc, depth, reps[r], r, world, deltas[r])
+    for r in range(world):
+        pkg.svo_fuse_keyrange_apply(wss[r], keys, depth, reps[r], deltas)
+        assert pkg.svo_fuse_keyrange_status(wss[r]) == pkg.KEYRANGE_YOUNG
+        assert np.array_equal(reps[r].words(), before)
+    # ... and the replicated commit of the same frame still works on the untouched replicas
+    opool = oracle.Pool()
+    opool.insert_cloud(pts, col, depth, center, edge); opool.insert_cloud(pts2, col, depth, center, edge)
+    for r in range(world):
+        pkg.svo_fuse_adopt_sorted(wss[r], keys, idx, depth)
+        pkg.svo_fuse_plan(wss[r], n, depth, reps[r])
+        pkg.svo_fuse_commit(wss[r], tc, depth, reps[r])
+        assert np.array_equal(reps[r].words(), opool.words())
