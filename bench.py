@@ -319,11 +319,12 @@ def main():
     ap.add_argument("--include-h2d", action="store_true",
                     help="frames start in pinned HOST memory and are uploaded inside the timed region (the reference's frame "
                          "includes the 1.5 MB cudaMemcpy of openni_device.cpp:122,144); default: frames resident in HBM")
-    ap.add_argument("--exchange", default=None, choices=["deltas", "none", "allreduce"],
+    ap.add_argument("--exchange", default=None, choices=["deltas", "none", "allreduce", "keyrange"],
                     help="N > 1: 'deltas' (default) = frame-parallel tracking, all-gather of update_trans records, every rank fuses "
                          "every frame and ray-marches its own; 'none' = every rank tracks and fuses whole frames, only the raycast "
                          "is split into row bands; 'allreduce' = SURVEY 8e row bands with 19 ICP all-reduces + one point all-gather "
-                         "per frame")
+                         "per frame; 'keyrange' = 'deltas' with the fusion cut by key range: every rank plans + commits its slice of every "
+                         "frame's sorted keys, one all-gather of the ranks' deltas per frame (svoslam_svo_fuse_keyrange_*)")
     ap.add_argument("--emulate-rank", default=None, metavar="R/N",
                     help="one GPU: run rank R of an N-rank 'deltas' session, the other ranks' records precomputed (untimed)")
     ap.add_argument("--map-frames", type=int, default=None,
@@ -406,15 +407,15 @@ def main():
     force_dist = os.environ.get("SVOSLAM_FORCE_DIST") == "1"   # exercise the row-band/RCCL code path on one GPU
     if args.exchange is None:
         args.exchange = "deltas" if world > 1 else "none"
-    if args.no_overlap and (args.exchange == "deltas" or args.emulate_rank):
+    if args.no_overlap and (args.exchange in ("deltas", "keyrange") or args.emulate_rank):
         raise SystemExit("--no-overlap has no frame-sharded form: use --exchange none")
     emu = None
     if args.emulate_rank:
         er, en = (int(x) for x in args.emulate_rank.split("/"))
         assert world == 1 and 0 <= er < en
-        emu = pl.EmulatedRank(er, en)
+        args.exchange = "keyrange" if args.exchange == "keyrange" else "deltas"
+        emu = pl.EmulatedRank(er, en, exchange=args.exchange)
         dist = emu
-        args.exchange = "deltas"
     elif world > 1 or force_dist:
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -477,6 +478,13 @@ def main():
                 pkg.svo_fuse_sort_frame(sws, depth[k], scam.fusion_transform_ptr(), P.focal, P.focal, max_depth, center, edge)
                 pkg.svo_fuse_export_sorted(sws, width * height, tab_k[k], tab_i[k])
             torch.cuda.synchronize()
+        kr_bytes = None
+        if args.exchange == "keyrange":   # the deltas the other ranks would all-gather, frame by frame, from a pool fused in one piece
+            assert tab_k is not None
+            kr_deltas, kr_young, kr_bytes = pl.keyrange_delta_table(tab_k, tab_i, rgb, pre, emu.rank, emu.world, max_depth, pool_cap)
+            for k in range(pre):
+                kr_young[k] = True            # the untimed history: replicated commits
+            emu.expect_keyrange(kr_deltas, kr_young)
 
     def expect(lo, hi):
         if emu is not None:
@@ -877,7 +885,10 @@ def main():
             "config": {"workload": "%s: synthetic %dx%d RGB-D stream, depth-%d SVO, half-edge %.3f m, bilateral+ICP(19 it)+fuse+raycast(%s mode)%s"
                                    % (args.workload, width, height, max_depth, edge, args.render_mode,
                                       "" if strict else " -- CORRECTED TRACKER (own specification, not the reference's): a labelled second line, not the headline"),
-                       "parallelism": ("EMULATED rank %d of %d (one GPU; the other ranks' update_trans records precomputed): frames tracked "
+                       "parallelism": ("EMULATED rank %d of %d (one GPU; the other ranks' update_trans records, sorted arrays and key-range DELTAS precomputed): "
+                                       "frames tracked, sorted and ray-marched by rank k %% N; every frame's plan + commit cut by key range, this rank's slice "
+                                       "computed here, all ranks' deltas applied here" % (emu.rank, emu.world) if emu is not None and args.exchange == "keyrange" else
+                                       "EMULATED rank %d of %d (one GPU; the other ranks' update_trans records precomputed): frames tracked "
                                        "and ray-marched by rank k %% N, every fusion applied here" % (emu.rank, emu.world) if emu is not None else
                                        "single GPU" if world == 1 and not force_dist else
                                        "frames tracked + ray-marched by rank k %% %d, all-gather of 80-byte update_trans records "
@@ -910,6 +921,18 @@ def main():
             out["pipeline_fill"] = fill
         if other:
             out["other_partition"] = other
+        if args.exchange == "keyrange" and hasattr(P, "_kr"):
+            P.keyrange_check()          # (raises if an apply was refused that the schedule did not expect)
+            kb = kr_bytes[t0w:total] if emu is not None and kr_bytes is not None else None
+            out["keyrange"] = {
+                "splitter_level": 3, "ranks": emu.world if emu is not None else world,
+                "frames_timed": K, "young_frames_timed_committed_replicated": (sum(1 for k in range(t0w, total) if emu.kr_young[k]) if emu is not None else None),
+                "delta_bytes_all_ranks_per_frame_mean": (sum(sum(b) for b in kb) / len(kb)) if kb else None,
+                "delta_bytes_all_ranks_per_frame_max": max(sum(b) for b in kb) if kb else None,
+                "delta_bytes_this_rank_per_frame_mean": (sum(b[emu.rank] for b in kb) / len(kb)) if kb else None,
+                "all_gather": "ONE per frame, between svoslam_svo_fuse_keyrange_commit and _apply; an emulated rank takes the other ranks' deltas from a "
+                              "table produced before the timed region (pipeline.keyrange_delta_table): the all-gather itself is NOT in this number",
+                "hardware": "UNMEASURED on multi-GPU hardware: one rank of N on one GPU"}
         if corrected_line:
             out["corrected_tracker"] = corrected_line
         if latency:

@@ -280,6 +280,8 @@ int svoslam_svo_fuse_keyrange_commit(svoslam_workspace *ws, const unsigned long 
 int svoslam_svo_fuse_keyrange_apply(svoslam_workspace *ws, const unsigned long long *d_sorted_keys, int32_t n, int32_t max_depth, svoslam_pool *pool,
                                     const uint32_t *const *d_deltas, int32_t world, void *stream);
 int svoslam_svo_fuse_keyrange_status(svoslam_workspace *ws, int32_t *flags, void *stream);
+/* instead of keyrange_apply: the delta was wanted, the commit is dropped (the pool stays as it was, the plan's reservation is released) */
+int svoslam_svo_fuse_keyrange_discard(svoslam_workspace *ws, svoslam_pool *pool);
 
 /* replaces svo::svoFromVoxelGrid (svo.h:14, svo.cu:584-640).  d_centers,
  * d_colors: n x vec4 (VoxelGrid, common_types.h:55-63). */

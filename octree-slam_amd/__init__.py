@@ -106,6 +106,7 @@ SIGNATURES = {
     "svoslam_svo_fuse_keyrange_commit": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), _i32, _i32, _vp, C.c_int64, _vp]),
     "svoslam_svo_fuse_keyrange_apply": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_PoolStruct), C.POINTER(C.c_void_p), _i32, _vp]),
     "svoslam_svo_fuse_keyrange_status": (C.c_int, [_vp, C.POINTER(C.c_int32), _vp]),
+    "svoslam_svo_fuse_keyrange_discard": (C.c_int, [_vp, C.POINTER(_PoolStruct)]),
     "svoslam_frame_reader_open": (C.c_int, [C.POINTER(_vp), C.c_char_p, _f32]),
     "svoslam_frame_reader_close": (C.c_int, [_vp]),
     "svoslam_frame_reader_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
@@ -556,6 +557,11 @@ def svo_fuse_keyrange_apply(ws, sorted_keys, max_depth, pool, deltas):
     n = int(sorted_keys.shape[0])
     arr = (C.c_void_p * len(deltas))(*[int(d.data_ptr()) for d in deltas])
     check(lib().svoslam_svo_fuse_keyrange_apply(ws._h, _ptr(sorted_keys), n, int(max_depth), C.byref(pool._p), arr, len(deltas), _stream()))
+
+
+def svo_fuse_keyrange_discard(ws, pool):
+    """the delta of the last keyrange_commit was all that was wanted: no apply follows on this pool"""
+    check(lib().svoslam_svo_fuse_keyrange_discard(ws._h, C.byref(pool._p)))
 
 
 def svo_fuse_keyrange_status(ws):

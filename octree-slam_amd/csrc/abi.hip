@@ -253,6 +253,10 @@ int svoslam_svo_fuse_keyrange_apply(svoslam_workspace *ws, const unsigned long l
   NEED_DEVICE();
   return svo_fuse_keyrange_apply(ws, d_sorted_keys, n, max_depth, pool, d_deltas, world, S(stream));
 }
+int svoslam_svo_fuse_keyrange_discard(svoslam_workspace *ws, svoslam_pool *pool) {
+  NEED_DEVICE();
+  return svo_fuse_keyrange_discard(ws, pool);
+}
 int svoslam_svo_fuse_keyrange_status(svoslam_workspace *ws, int32_t *flags, void *stream) {
   NEED_DEVICE();
   int f = 0;

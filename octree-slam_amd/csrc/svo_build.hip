@@ -928,8 +928,12 @@ __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__rest
                                                             int depth, const PlanCounts *__restrict__ counts,
                                                             int *__restrict__ d_size, u32 *__restrict__ grid_dirty,
                                                             int32_t *__restrict__ h_sizes, int *__restrict__ d_slot,
-                                                            unsigned long long *__restrict__ shadow, u32 epoch, int keep_size) {
+                                                            unsigned long long *__restrict__ shadow, u32 epoch, int keep_size,
+                                                            const int *__restrict__ n_live) {
   SVO_HIGH_PRIO();
+  // n_live (key-range sharded commit): the tiles past the rank's slice hold no straddler (fill_mip_local_kernel): not read
+  const int list_stride = num_tiles;
+  if (n_live) { const int live = (*n_live + kFillThreads - 1) / kFillThreads; num_tiles = live < num_tiles ? live : num_tiles; }
   // shadow != nullptr: deferred commit (see fill_mip_local_kernel); the list entries double as the apply list
   // keep_size != 0 (key-range sharded commit): the pool's size is set by keyrange_finish_kernel, from every rank's record count
   auto average = [&](u32 child_base) { return shadow ? average_tile_deferred(pool, shadow, epoch, child_base) : average_tile(pool, child_base); };
@@ -948,7 +952,7 @@ __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__rest
 #pragma unroll
     for (int q = 0; q < kSlots; q++) {
       const int t = (int)threadIdx.x + kStradThreads * q;
-      e[q] = (d >= 1 && t < num_tiles) ? list[(size_t)d * num_tiles + t] : make_uint2(kNoStraddler, 0u);
+      e[q] = (d >= 1 && t < num_tiles) ? list[(size_t)d * list_stride + t] : make_uint2(kNoStraddler, 0u);
     }
   };
   if (fits) fetch(depth - 1, cur);
@@ -962,7 +966,7 @@ __global__ __launch_bounds__(kStradThreads) void mip_straddle_kernel(u32 *__rest
       for (int q = 0; q < kSlots; q++) cur[q] = nxt[q];
     } else {
       for (int t = (int)threadIdx.x; t < num_tiles; t += kStradThreads) {
-        const uint2 e = list[(size_t)d * num_tiles + t];
+        const uint2 e = list[(size_t)d * list_stride + t];
         if (e.x != kNoStraddler) store(e.x, average(e.y));
       }
     }
@@ -1964,7 +1968,7 @@ static int commit_impl(svoslam_workspace *ws, const uint8_t *d_colors, int n, in
                                                                         trk ? trk->h_size : nullptr, trk ? trk->d_slot : nullptr);
     else
       mip_straddle_kernel<<<1, kStradThreads, 0, stream>>>(pool->d_data, strad, fill_tiles, depth, small_counts(ws), pool->d_size, grid_dirty,
-                                                           trk ? trk->h_size : nullptr, trk ? trk->d_slot : nullptr, shadow, epoch, keyrange ? 1 : 0);
+                                                           trk ? trk->h_size : nullptr, trk ? trk->d_slot : nullptr, shadow, epoch, keyrange ? 1 : 0, n_live);
     SVO_LAUNCH_CHECK();
     return SVOSLAM_OK;
   };
@@ -2573,6 +2577,16 @@ int svo_fuse_keyrange_apply(svoslam_workspace *ws, const unsigned long long *d_k
   SVO_LAUNCH_CHECK();
   pool->pending += 1;
   return tracker_push(pool, ws->keyrange_bound, stream);
+}
+
+// a svo_fuse_keyrange_commit whose delta is wanted but whose apply will not follow on this pool (the deltas of OTHER ranks, produced on one
+// device for an emulated rank: bench.py --exchange keyrange --emulate-rank): the plan's reservation is released, the pool is as it was
+int svo_fuse_keyrange_discard(svoslam_workspace *ws, svoslam_pool *pool) {
+  if (!ws || !pool || ws->keyrange_pool != pool) return SVOSLAM_ERR_INVALID_ARG;
+  ws->keyrange_pool = nullptr;
+  pool->pending_bound -= ws->keyrange_bound;
+  if (pool->pending_bound < 0) pool->pending_bound = 0;
+  return SVOSLAM_OK;
 }
 
 // flags of the last svo_fuse_keyrange_apply on this workspace (blocking): 0 = applied; kKrYoung / kKrOverflowed / kKrMismatch = NOT applied.

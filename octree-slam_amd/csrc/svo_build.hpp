@@ -44,6 +44,7 @@ int svo_fuse_keyrange_commit(svoslam_workspace *ws, const unsigned long long *d_
 int svo_fuse_keyrange_apply(svoslam_workspace *ws, const unsigned long long *d_keys, int n, int depth, svoslam_pool *pool,
                             const uint32_t *const *d_deltas, int world, hipStream_t stream);
 int svo_fuse_keyrange_status(svoslam_workspace *ws, int *flags, hipStream_t stream);
+int svo_fuse_keyrange_discard(svoslam_workspace *ws, svoslam_pool *pool);
 int svo_from_point_cloud(svoslam_workspace *ws, const float *d_points, const uint8_t *d_colors, int n, int depth,
                          svoslam_pool *pool, const float center[3], float edge, svoslam_fuse_stats *stats,
                          hipStream_t stream);

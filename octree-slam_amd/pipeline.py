@@ -76,7 +76,7 @@ class DistContext:
         """exchange = "none": every rank tracks and fuses the whole frame itself (no collective in the frame loop; only
         the raycast is split into row bands).  exchange = "allreduce": SURVEY 8e -- ICP accumulation and back-projection
         per row band, 19 all-reduces of the 27 normal-equation sums and one all-gather of the point bands per frame."""
-        assert exchange in ("none", "allreduce", "deltas")
+        assert exchange in ("none", "allreduce", "deltas", "keyrange")
         self.rank, self.world, self.group, self.force, self.exchange = rank, world, group, force, exchange
         if self.enabled:
             # create the RCCL communicator and its streams NOW (first use is lazy and was observed to
@@ -191,6 +191,18 @@ class DistContext:
             out.view(-1).copy_(mine.view(-1))
         return out
 
+    def all_gather_keyrange(self, frame, mine):
+        """key-range sharded fusion: every rank's delta buffer of global frame `frame` (rank order; `mine` at this rank's place) -- ONE
+        all-gather of the buffers' capacity (a production exchange would ship the used words, word 10 of a delta: see DESIGN.md 7)"""
+        if not self.enabled:
+            return [mine]
+        import torch.distributed as dist
+        if getattr(self, "_kr_recv", None) is None or self._kr_recv[0].shape[1] != mine.numel():
+            self._kr_recv = [torch.empty((self.world, mine.numel()), dtype=mine.dtype, device=mine.device) for _ in range(2)]
+        out = self._kr_recv[frame & 1]
+        dist.all_gather_into_tensor(out.view(-1), mine.view(-1), group=self.group)
+        return [out[s] for s in range(self.world)]
+
     def all_gather_rows(self, full, height):
         """`full` is [height, ...]; each rank has filled its own band; returns with all bands filled.
         Bands may differ by one row, so gather into per-rank views of padded size."""
@@ -217,8 +229,9 @@ class EmulatedRank:
     per frame of the next run_stream call, produced beforehand by svoslam_camera_pair_delta (what RCCL would deliver)."""
     enabled, exchange, force, group = False, "deltas", False, None
 
-    def __init__(self, rank, world):
-        self.rank, self.world = rank, world
+    def __init__(self, rank, world, exchange="deltas"):
+        self.rank, self.world, self.exchange = rank, world, exchange
+        self.kr_deltas, self.kr_young = None, None
         self.table, self.first, self.per_rank, self.calls = None, 0, 1, 0
         self.sorted, self.sorted_calls = (None, None), [0, 0]
 
@@ -233,6 +246,15 @@ class EmulatedRank:
         self.table, self.first, self.per_rank, self.calls = table, first_index, per_rank, 0
         self.sorted = (sorted_keys, sorted_idx)
         self.sorted_calls = [0, 0]
+
+    def expect_keyrange(self, deltas, young):
+        """deltas[g][s]: rank s's delta of global frame g (None at this rank's place), young[g]: frame g splits above the splitter level
+        (pipeline.keyrange_delta_table); set once for the whole stream"""
+        self.kr_deltas, self.kr_young = deltas, young
+
+    def all_gather_keyrange(self, frame, mine):
+        row = self.kr_deltas[frame]
+        return [mine if s == self.rank else row[s] for s in range(self.world)]
 
     def all_gather_sorted(self, out, mine):
         which = 0 if out.dtype == torch.int64 else 1
@@ -285,7 +307,8 @@ class SlamPipeline:
         self.bbox = torch.zeros(7, dtype=torch.float32, device=dev)
         self.image = torch.zeros((height, width, 4), dtype=torch.uint8, device=dev)
         self.counters = torch.zeros(2, dtype=torch.int64, device=dev) if count_steps else None
-        self.frame_sharded = self.dist.exchange == "deltas"   # (also without a process group: world 1, or an emulated rank)
+        self.keyrange = self.dist.exchange == "keyrange"      # frame-sharded tracking / marches + key-range sharded fusion
+        self.frame_sharded = self.dist.exchange in ("deltas", "keyrange")   # (also without a process group: world 1, or an emulated rank)
         self.shard_sort = False
         if self.frame_sharded:
             self.first, self.rows = 0, height                    # whole images of this rank's frames
@@ -302,7 +325,9 @@ class SlamPipeline:
             idx_bits = max(1, (width * height - 1).bit_length())
             want = os.environ.get("SVOSLAM_SHARD_SORT")
             want = (width * height >= (1 << 20)) if want is None else want != "0"
+            want = want or self.keyrange            # (the key-range commit takes the frame's sorted arrays: the owners sort)
             self.shard_sort = want and 3 * max_depth + 1 + idx_bits <= 64
+            assert self.shard_sort or not self.keyrange, "key-range fusion needs the packed sort (3 x depth + 1 + index bits <= 64)"
             if self.shard_sort:
                 self.sort_cam = pkg.Camera(width, height, self.focal, self.focal)   # composes the poses the owner sorts with
                 if not self.strict_reference:
@@ -345,6 +370,10 @@ class SlamPipeline:
     def close(self):
         """give the device back: runner (streams, events) first, then the pool's reservation (+ shadow array, brick field), workspaces
         and cameras; the object is unusable afterwards.  bench.py calls it before its child processes measure the other configurations."""
+        kr = self.__dict__.pop("_kr", None)
+        if kr is not None:
+            for w in kr["ws"]:
+                w.close()
         for name in ("_runner", "pool", "ws", "ws_sort", "ws_band", "cam", "delta_cam", "sort_cam"):
             o = self.__dict__.pop(name, None)
             if o is not None:
@@ -635,9 +664,10 @@ class SlamPipeline:
         world, rank = self.dist.world, self.dist.rank
         if per_rank is None:
             per_rank = max(1, 16 // world)
-        if not hasattr(self, "_runner"):
-            self._runner = pkg.Runner(self.cam, self.pool, self.w, self.h, self.depth, self.center, self.edge, self.focal,
-                                      self.focal, self.mode)
+        if not hasattr(self, "_s_delta"):
+            if not self.keyrange:
+                self._runner = pkg.Runner(self.cam, self.pool, self.w, self.h, self.depth, self.center, self.edge, self.focal,
+                                          self.focal, self.mode)
             self._s_delta = torch.cuda.Stream()
             self._s_sort = torch.cuda.Stream()
         cur = torch.cuda.current_stream()
@@ -693,7 +723,9 @@ class SlamPipeline:
                     r, row = slots[i - a]
                     skeys[i], sidx[i] = all_k[r, row], all_i[r, row]
                 sevents[a] = evs
-        if use_sort:
+        if self.keyrange:
+            self._run_keyrange(n, g0, rgbs, timestamps, views, deltas, events, march, outs, skeys, sidx, sevents)
+        elif use_sort:
             self._runner.run_sharded_presorted(depths, rgbs, timestamps, views, deltas, events, march, outs, skeys, sidx, sevents, 0, self.h,
                                                self.counters)
         else:
@@ -705,6 +737,72 @@ class SlamPipeline:
         if getattr(self.dist, "mailbox", None) is not None:
             self.dist.check_mailbox()
 
+    def _run_keyrange(self, n, g0, rgbs, timestamps, views, deltas, events, march, outs, skeys, sidx, sevents):
+        """The fusion of a frame-sharded session cut by KEY RANGE (csrc/svo_build.hip "key-range sharded commit"; include/svoslam.h
+        svoslam_svo_fuse_keyrange_*): per frame, on two streams,
+          C  keyrange_commit -- this rank's slice of the frame's sorted keys planned and committed where no replica sees it, its
+             delta packed -- then the all-gather of the ranks' deltas; frame k+1's may run beside the march of frame k;
+          M  pose of the frame (the 80-byte record), keyrange_apply -- every rank's delta into this replica --, and the ray march of
+             the frames this rank owns.
+        Driven from Python (five calls per frame): the collective sits between the two halves of every frame.  A frame that splits
+        above the splitter level is refused by the apply: an emulated rank knows such frames from its table and commits them
+        replicated; a real rank reads the 4-byte status after every apply (one host round trip per frame)."""
+        world, rank = self.dist.world, self.dist.rank
+        npix = self.w * self.h
+        if not hasattr(self, "_kr"):
+            cap_words = 10752 + 16 * npix          # 64 bytes per pixel of a whole frame: ample for any slice
+            self._kr = {"sc": torch.cuda.Stream(), "sm": torch.cuda.Stream(), "ws": [pkg.Workspace(), pkg.Workspace()],
+                        "buf": [torch.zeros(cap_words, dtype=torch.int32, device="cuda") for _ in range(2)], "young": 0, "frames": 0,
+                        "used_bytes": []}
+        kr = self._kr
+        sc, sm = kr["sc"], kr["sm"]
+        cur = torch.cuda.current_stream()
+        sc.wait_stream(cur); sm.wait_stream(cur)
+        known_young = getattr(self.dist, "kr_young", None)
+        ev_apply = None
+        for i in range(n):
+            k = i & 1
+            ws, buf = kr["ws"][k], kr["buf"][k]
+            colors = rgbs[i].view(-1, 3)
+            young = bool(known_young[g0 + i]) if known_young is not None else False
+            with torch.cuda.stream(sc):
+                if sevents[i] is not None:
+                    sc.wait_event(sevents[i])          # the chunk's sorted arrays (in-order stream: once per chunk)
+                if ev_apply is not None:
+                    sc.wait_event(ev_apply)            # the plan reads the structure apply k-1 left
+                if not young:
+                    pkg.svo_fuse_keyrange_commit(ws, skeys[i], sidx[i], colors, self.depth, self.pool, rank, world, buf)
+                    gathered = self.dist.all_gather_keyrange(g0 + i, buf)
+                evc = torch.cuda.Event(); evc.record()
+            with torch.cuda.stream(sm):
+                sm.wait_event(evc)
+                if events[i] is not None:
+                    sm.wait_event(events[i])           # the chunk's pose records
+                self.cam.apply_delta(deltas[i], timestamps[i])
+                if not young:
+                    pkg.svo_fuse_keyrange_apply(ws, skeys[i], self.depth, self.pool, gathered)
+                    if known_young is None and self.dist.enabled:
+                        young = pkg.svo_fuse_keyrange_status(ws) != 0      # (blocking: every rank reads the same verdict)
+                if young:                              # the whole frame on every rank, as in the "deltas" scheme
+                    kr["young"] += 1
+                    pkg.svo_fuse_adopt_sorted(ws, skeys[i], sidx[i], self.depth)
+                    pkg.svo_fuse_plan(ws, npix, self.depth, self.pool)
+                    pkg.svo_fuse_commit(ws, colors, self.depth, self.pool)
+                ev_apply = torch.cuda.Event(); ev_apply.record()
+                if march[i]:
+                    pkg.cone_trace_svo(outs[i], FOV, views[i], self.pool.data_ptr, self.center, self.edge, self.mode, counters=self.counters)
+            kr["frames"] += 1
+        cur.wait_stream(sc); cur.wait_stream(sm)
+
+    def keyrange_check(self):
+        """after a key-range run (blocking): raises if an apply was refused that nobody expected (an emulated rank's table says which
+        frames are young; a refused frame leaves the replica behind the others)"""
+        if hasattr(self, "_kr"):
+            for w in self._kr["ws"]:
+                f = pkg.svo_fuse_keyrange_status(w) if w is not None else 0
+                if f:
+                    raise RuntimeError("key-range apply refused a frame: flags %d (1 young, 2 overflow, 4 mismatch)" % f)
+
     def _backproject_with(self, depth, fusion_ptr):
         if not self.band_exchange:
             pkg.generate_vertex_map(depth, self.points, self.focal, self.focal, self.w, self.h)
@@ -714,6 +812,42 @@ class SlamPipeline:
             pkg.transform_vertex_map_dmat(self.points[self.first:self.first + self.rows], fusion_ptr)
             self.dist.all_gather_rows(self.points, self.h)
         pkg.point_cloud_bbox_device(self.ws, self.points, self.bbox)
+
+
+def keyrange_delta_table(keys_tab, idx_tab, rgb, first, rank, world, max_depth, pool_capacity_nodes):
+    """What the OTHER ranks of a key-range session deliver, for an emulated rank (bench.py --exchange keyrange --emulate-rank R/N): a truth
+    pool fuses the stream frame by frame in one piece (keys_tab[k] / idx_tab[k]: the frame's sorted keys and point indices, rgb[k] its
+    colours); before frame k >= first is fused, every rank s != rank plans and commits ITS slice on that pool and its delta is kept
+    (svoslam_svo_fuse_keyrange_commit + _discard: the pool is not touched).  Returns (deltas, young, bytes): deltas[k][s] (used words only;
+    None for k < first and at s == rank), young[k] = the frame splits above the splitter level (every rank would be refused: such frames
+    are committed replicated), bytes[k] = [used bytes of every rank's delta] -- what one all-gather of frame k moves (the emulated rank's
+    own share measured with the same call)."""
+    total, npix = keys_tab.shape[0], keys_tab.shape[1]
+    truth = pkg.Pool(pool_capacity_nodes)
+    ws_t, ws_s = pkg.Workspace(), pkg.Workspace()
+    buf = torch.zeros(10752 + 16 * npix, dtype=torch.int32, device="cuda")
+    deltas, young, nbytes = [None] * total, [False] * total, [None] * total
+    for k in range(total):
+        colors = rgb[k].view(-1, 3)
+        if k >= first:
+            row, used, refused = [None] * world, [0] * world, False
+            for s_ in range(world):
+                pkg.svo_fuse_keyrange_commit(ws_s, keys_tab[k], idx_tab[k], colors, max_depth, truth, s_, world, buf)
+                pkg.svo_fuse_keyrange_discard(ws_s, truth)
+                head = buf[:512].cpu().numpy().view(np.uint32)
+                used[s_] = int(head[pkg.KEYRANGE_USED_WORD]) * 4
+                assert head[7] == 0, "a delta overflowed its buffer"
+                # a record above the splitter level in ANY rank's buckets (bucket b = 16 x pass + depth - 1 at word 256 + b; level 3)
+                refused = refused or bool(head[256:512].reshape(16, 16)[:, :2].any())
+                if s_ != rank:
+                    row[s_] = buf[: used[s_] // 4].clone()
+            deltas[k], young[k], nbytes[k] = row, refused, used
+        pkg.svo_fuse_adopt_sorted(ws_t, keys_tab[k], idx_tab[k], max_depth)
+        pkg.svo_fuse_plan(ws_t, npix, max_depth, truth)
+        pkg.svo_fuse_commit(ws_t, colors, max_depth, truth)
+    torch.cuda.synchronize()
+    ws_t.close(); ws_s.close(); truth.close()
+    return deltas, young, nbytes
 
 
 def ground_truth_view(frame, synth):

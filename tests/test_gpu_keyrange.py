@@ -143,3 +143,68 @@ def test_keyrange_young_frame_is_refused(env, oracle):
         pkg.svo_fuse_plan(wss[r], n, depth, reps[r])
         pkg.svo_fuse_commit(wss[r], tc, depth, reps[r])
         assert np.array_equal(reps[r].words(), opool.words())
+
+
+@pytest.mark.parametrize("world,per_rank,w,h,depth", [(2, 2, 320, 240, 10), (4, 1, 320, 240, 10), (8, 1, 160, 120, 9)])
+def test_keyrange_session_equals_single_gpu_session(world, per_rank, w, h, depth):
+    """every rank of a frame-sharded session whose FUSION is cut by key range (pipeline "keyrange" exchange; an emulated rank takes the
+    other ranks' pose records, sorted arrays and deltas from tables): poses and map replica equal the one-GPU session's after every call,
+    the frames it ray-marches equal the one-GPU images.  The first frames of the map are young and go through the replicated commit."""
+    import importlib
+    import torch
+    import svoslam_pkg
+    pkg = svoslam_pkg.load()
+    synth = importlib.import_module("octree_slam_amd.synth")
+    pl = importlib.import_module("octree_slam_amd.pipeline")
+    from test_gpu_sharded import _cam_state, _stream
+    center, edge = (0.0, 1.5, 0.0), 4.096
+    n1, n2, first = 7, 6, 2
+    n = n1 + n2
+    dstack, cstack = _stream(synth, torch, n, w, h)
+    views = [pl.ground_truth_view(k, synth) for k in range(n)]
+    A = pl.SlamPipeline(w, h, depth, center, edge)
+    ref_img, ref_state = [], []
+    for k in range(n):
+        ref_img.append(A.frame(dstack[k], cstack[k], k, views[k]).cpu().numpy().copy())
+        if k in (n1 - 1, n - 1):
+            ref_state.append((A.pool.size, A.pool.words().copy(), _cam_state(A.cam, torch, pkg)))
+    f = synth.focal_length(w)
+    D = pkg.Camera(w, h, f, f)
+    table = torch.zeros((n, pkg.DELTA_FLOATS), dtype=torch.float32, device="cuda")
+    for k in range(1, n):
+        D.pair_delta(dstack[k - 1], cstack[k - 1], dstack[k], cstack[k], table[k])
+    tab_k = torch.empty((n, w * h), dtype=torch.int64, device="cuda")
+    tab_i = torch.empty((n, w * h), dtype=torch.int32, device="cuda")
+    scam, sws = pkg.Camera(w, h, f, f), pkg.Workspace()
+    for k in range(n):
+        scam.apply_delta(table[k], k)
+        pkg.svo_fuse_sort_frame(sws, dstack[k], scam.fusion_transform_ptr(), f, f, depth, center, edge)
+        pkg.svo_fuse_export_sorted(sws, w * h, tab_k[k], tab_i[k])
+    torch.cuda.synchronize()
+    sharded = 0
+    for rank in range(world):
+        deltas, young, nbytes = pl.keyrange_delta_table(tab_k, tab_i, cstack, first, rank, world, depth, 1 << 22)
+        for k in range(first):
+            young[k] = True
+        B = pl.SlamPipeline(w, h, depth, center, edge, dist=pl.EmulatedRank(rank, world, exchange="keyrange"), pool_capacity_nodes=1 << 22)
+        assert B.keyrange and B.shard_sort
+        B.dist.expect_keyrange(deltas, young)
+        for part, (lo, hi) in enumerate(((0, n1), (n1, n))):
+            B.dist.expect(table[lo:hi], lo, per_rank, tab_k[lo:hi], tab_i[lo:hi])
+            imgs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(lo, hi)]
+            B.run_stream_sharded(list(dstack[lo:hi]), list(cstack[lo:hi]), list(range(lo, hi)), views[lo:hi], images=imgs, per_rank=per_rank)
+            torch.cuda.synchronize()
+            B.keyrange_check()
+            size, words, state = ref_state[part]
+            assert B.pool.size == size and np.array_equal(B.pool.words(), words), (rank, part)
+            got = _cam_state(B.cam, torch, pkg)
+            assert np.array_equal(got.view(np.uint32), state.view(np.uint32)), (rank, part)
+            for k in range(lo, hi):
+                if k % world == rank:
+                    assert np.array_equal(imgs[k - lo].cpu().numpy(), ref_img[k]), (rank, k, describe_mismatch(imgs[k - lo].cpu().numpy(), ref_img[k]))
+        sharded = sum(1 for k in range(n) if not young[k])
+        if rank == 0:
+            print("world %d %dx%d: %d of %d frames cut by key range; delta bytes of all ranks per such frame: %s"
+                  % (world, w, h, sharded, n, [sum(b) for k, b in enumerate(nbytes) if b is not None and not young[k]]))
+        B.close()
+    assert sharded >= 6
