@@ -174,7 +174,7 @@ def test_sharded_path_over_rccl_one_rank(env):
             dist.destroy_process_group()
 
 
-def _two_process_worker(rank, world, port, out_dir, n, w, h, depth):
+def _two_process_worker(rank, world, port, out_dir, n, w, h, depth, exchange="deltas"):
     """one rank of a REAL two-process frame-sharded session (both processes on the one GPU there is, so the process group
     is gloo -- RCCL refuses two ranks on one device; the schedule, the collectives' order and the library calls are those
     of the RCCL path)"""
@@ -194,31 +194,38 @@ def _two_process_worker(rank, world, port, out_dir, n, w, h, depth):
     center, edge = (0.0, 1.5, 0.0), 4.096
     dstack, cstack = synth.render_stream(n, w, h, device="cuda")
     views = [pl.ground_truth_view(k, synth) for k in range(n)]
-    P = pl.SlamPipeline(w, h, depth, center, edge, dist=pl.DistContext(rank, world, exchange="deltas"))
+    P = pl.SlamPipeline(w, h, depth, center, edge, dist=pl.DistContext(rank, world, exchange=exchange), pool_capacity_nodes=1 << 21)
     imgs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(n)]
     half = n // 2 + 1
     P.run_stream_sharded(list(dstack[:half]), list(cstack[:half]), list(range(half)), views[:half], images=imgs[:half], per_rank=2)
     P.run_stream_sharded(list(dstack[half:]), list(cstack[half:]), list(range(half, n)), views[half:], images=imgs[half:], per_rank=2)
     torch.cuda.synchronize()
+    kr = getattr(P, "_kr", None)
+    if exchange == "keyrange":
+        P.keyrange_check()
     p, o = P.cam.pose()
     mb = P.dist.mailbox      # the pose records travelled through the peer-to-peer mailbox (hipIpc between the two processes)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), words=P.pool.words(), size=P.pool.size, pos=p, ori=o,
              lost=P.cam.tracking_lost_count(), images=np.stack([i.cpu().numpy() for i in imgs]),
-             mailbox=np.array([mb is not None, bool(mb.failed()) if mb is not None else False]))
+             mailbox=np.array([mb is not None, bool(mb.failed()) if mb is not None else False]),
+             keyrange=np.array([kr["frames"], kr["young"]] if kr else [0, 0]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_process_sharded_session_on_one_gpu(env, tmp_path):
+@pytest.mark.parametrize("exchange", ["deltas", "keyrange"])
+def test_two_process_sharded_session_on_one_gpu(env, tmp_path, exchange):
     """two processes, one process group, frames tracked and marched alternately: each rank's replica and poses equal the
-    one-GPU session's, rank r holds the images of the frames k % 2 == r"""
+    one-GPU session's, rank r holds the images of the frames k % 2 == r.  exchange "keyrange": the fusion is cut by key range as well --
+    a REAL all-gather of the two ranks' deltas per frame, and the 4-byte status after every apply sends the young first frames of the
+    map through the replicated commit on both ranks."""
     pkg, torch, synth, pl = env
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     n, w, h, depth = 11, 160, 120, 8
     mp.get_context("spawn")
-    mp.spawn(_two_process_worker, args=(2, port, str(tmp_path), n, w, h, depth), nprocs=2, join=True)
+    mp.spawn(_two_process_worker, args=(2, port, str(tmp_path), n, w, h, depth, exchange), nprocs=2, join=True)
     center, edge = (0.0, 1.5, 0.0), 4.096
     dstack, cstack = synth.render_stream(n, w, h, device="cuda")
     A = pl.SlamPipeline(w, h, depth, center, edge)
@@ -234,6 +241,8 @@ def test_two_process_sharded_session_on_one_gpu(env, tmp_path):
                 assert np.array_equal(z["images"][k], ref[k]), (r, k)
             else:
                 assert int(z["images"][k].max()) == 0
+        if exchange == "keyrange":
+            assert int(z["keyrange"][0]) == n and 0 < int(z["keyrange"][1]) < n, z["keyrange"]   # some frames young (replicated), the rest cut by key range
 
 
 def test_bench_multi_rank_code_path_on_one_gpu(env):
