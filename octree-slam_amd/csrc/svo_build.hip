@@ -2589,8 +2589,9 @@ int svo_fuse_keyrange_discard(svoslam_workspace *ws, svoslam_pool *pool) {
   return SVOSLAM_OK;
 }
 
-// flags of the last svo_fuse_keyrange_apply on this workspace (blocking): 0 = applied; kKrYoung / kKrOverflowed / kKrMismatch = NOT applied.
-// used_bytes (optional, [world]): bytes of each delta that carry data (what an all-gather has to move)
+// flags of the svo_fuse_keyrange_apply calls on this workspace since the last call of this function (blocking; the flags are sticky on
+// the device and cleared here): 0 = every frame applied; kKrYoung / kKrOverflowed / kKrMismatch = a frame was NOT applied (the replica
+// is then behind the others unless the caller committed that frame in one piece instead, as pipeline._run_keyrange does)
 int svo_fuse_keyrange_status(svoslam_workspace *ws, int *flags, hipStream_t stream) {
   if (!ws || !flags || ws->kr_small.bytes == 0) return SVOSLAM_ERR_INVALID_ARG;
   u32 f = 0;
