@@ -32,7 +32,8 @@ struct TrackArgs {
   int corrected = 0;     // the corrected tracker (icp_device.hpp icp_rot_rows)
 };
 constexpr int kTrkStreamSlots = 2;
-constexpr int kTrkStreamMinWaves = 3;
+constexpr int kTrkStreamMinWaves = 3;  // (round 6, beside the 80-VGPR march: 2 = 192 VGPRs without spills -- the tracker alone 0.53 ms instead of 0.60, cfg4 865-878 frames/s
+// instead of 964-971: the sort's and the commit's workgroups find no room beside it; 4 = 128 VGPRs, 56 spilled: 921-926.  profiles/r06_tracker_diet_ab.txt)
 
 int track_persistent_capacity(hipStream_t s, int *max_workgroups, int variant = 0);
 int track_persistent_plan_stream(TrackArgs &A, int capacity);  // large images: coarsest level in registers, finer levels streamed through work maps
