@@ -481,10 +481,8 @@ def main():
         kr_bytes = None
         if args.exchange == "keyrange":   # the deltas the other ranks would all-gather, frame by frame, from a pool fused in one piece
             assert tab_k is not None
-            kr_deltas, kr_young, kr_bytes = pl.keyrange_delta_table(tab_k, tab_i, rgb, pre, emu.rank, emu.world, max_depth, pool_cap)
-            for k in range(pre):
-                kr_young[k] = True            # the untimed history: replicated commits
-            emu.expect_keyrange(kr_deltas, kr_young)
+            kr_deltas, kr_shared, kr_bytes = pl.keyrange_delta_table(tab_k, tab_i, rgb, pre, emu.rank, emu.world, max_depth, pool_cap)
+            emu.expect_keyrange(kr_deltas)    # (None for the untimed history before frame `pre`: committed in one piece)
 
     def expect(lo, hi):
         if emu is not None:
@@ -926,7 +924,7 @@ def main():
             kb = kr_bytes[t0w:total] if emu is not None and kr_bytes is not None else None
             out["keyrange"] = {
                 "splitter_level": 3, "ranks": emu.world if emu is not None else world,
-                "frames_timed": K, "young_frames_timed_committed_replicated": (sum(1 for k in range(t0w, total) if emu.kr_young[k]) if emu is not None else None),
+                "frames_timed": K, "frames_timed_with_records_above_the_splitter_level": (sum(1 for k in range(t0w, total) if kr_shared[k]) if emu is not None else None),
                 "delta_bytes_all_ranks_per_frame_mean": (sum(sum(b) for b in kb) / len(kb)) if kb else None,
                 "delta_bytes_all_ranks_per_frame_max": max(sum(b) for b in kb) if kb else None,
                 "delta_bytes_this_rank_per_frame_mean": (sum(b[emu.rank] for b in kb) / len(kb)) if kb else None,

@@ -267,12 +267,11 @@ int svoslam_svo_fuse_apply(svoslam_workspace *ws, svoslam_pool *pool, void *stre
  * reference's order (pass-major, depth, key), writes all deltas -- the own one included -- to their global place, makes the marks of the
  * level grid / occupancy bricks from all keys, recomputes the colour words above the splitter level and sets the pool's size: the replica
  * is then byte-identical to a pool that fused the frame in one piece.  d_deltas: HOST array of `world` device pointers in rank order.
- * Frames whose splits reach above level 3 (a node of level 1 or 2 without children: the first frames of a map) are not applied:
- * keyrange_status (blocking) then reports SVOSLAM_KEYRANGE_YOUNG and the frame must go through the replicated commit instead
- * (svoslam_svo_fuse_plan + _commit on the same sorted keys); until keyrange_status has been read, every later apply on the workspace is
- * refused as well (a replica that silently missed a frame must not go on).
+ * Frames whose splits reach above level 3 (a node of level 1 or 2 without children: the first frames of a map) make several ranks plan the
+ * same records: the deltas list those by key and the apply ranks them in the ranks' union -- no special case for the caller.
+ * keyrange_status (blocking; optional, e.g. once per call of a frame loop): 0, or why an apply did NOT happen -- until it has been
+ * read every later apply on the workspace is refused as well (a replica that silently missed a frame must not go on).
  * world <= 16, max_depth >= 6. */
-#define SVOSLAM_KEYRANGE_YOUNG 1
 #define SVOSLAM_KEYRANGE_OVERFLOW 2  /* a delta did not fit its buffer */
 #define SVOSLAM_KEYRANGE_MISMATCH 4  /* deltas of different frames / pool states */
 #define SVOSLAM_KEYRANGE_USED_WORD 10

@@ -541,7 +541,8 @@ def svo_fuse_apply(ws, pool):
     check(lib().svoslam_svo_fuse_apply(ws._h, C.byref(pool._p), _stream()))
 
 
-KEYRANGE_YOUNG, KEYRANGE_OVERFLOW, KEYRANGE_MISMATCH, KEYRANGE_USED_WORD = 1, 2, 4, 10
+KEYRANGE_OVERFLOW, KEYRANGE_MISMATCH, KEYRANGE_USED_WORD = 2, 4, 10
+KEYRANGE_FIXED_WORDS = 11264    # header + fixed-size lists of a delta; its tiles, links and words follow
 
 
 def svo_fuse_keyrange_commit(ws, sorted_keys, sorted_idx, colors, max_depth, pool, rank, world, delta):

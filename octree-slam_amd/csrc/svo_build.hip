@@ -2222,18 +2222,23 @@ int extract_voxel_grid(svoslam_workspace *ws, const svoslam_pool *pool, int dept
 //                             frame's keys against this replica's own dirty state (ranks render different frames: their dirty states
 //                             differ); the colour words of the nodes above the splitter level -- shared by several ranks' paths -- are
 //                             recomputed from the merged children, level by level, then the root pass (Q6); size and size readback.
-// Frames whose splits reach ABOVE the splitter level (a node of level < 3 without children: the first frames of a map, new territory)
-// would create one tile from several ranks: keyrange_setup_kernel raises kKrYoung and the result is undefined -- such frames belong to
-// the replicated commit (the general protocol, with the shared records ranked in their union, is the CPU test's; not built here).
+// Frames whose splits reach ABOVE the splitter level (a node of level 1 or 2 without children: the first frames of a map, new territory)
+// make several ranks plan the SAME records (the prefix of such a record lies on paths of more than one slice) and create the same tiles:
+// every delta lists its records above the splitter level by key, keyrange_setup_kernel ranks them in the ranks' UNION (the reference's
+// order inside their buckets) and clears their tiles, and the apply writes of such a tile only the nodes a rank actually filled -- a
+// level-3 node has one owner; the shallower ones get the same link from everybody and their colour words from the recomputation.
 constexpr int kKrLevel = 3;
 constexpr int kKrMaxWorld = 16;
 constexpr int kKrHeader = 512;       // words: scalars, then the 256 bucket sizes at [256, 512)
 constexpr int kKrSibCap = 8192;      // entries
 constexpr int kKrShallowCap = 1024;  // keys (two words each)
-constexpr int kKrTiles0 = kKrHeader + kKrSibCap + 2 * kKrShallowCap;  // first word of the tiles
+constexpr int kKrTopCap = 128;       // records above the splitter level: {key (two words), local record, bucket}; a rank has at most 8 + 64
+constexpr int kKrTop0 = kKrHeader + kKrSibCap + 2 * kKrShallowCap;
+constexpr int kKrTiles0 = kKrTop0 + 4 * kKrTopCap;  // first word of the tiles
 enum { kKrMagic = 0, kKrRecords = 1, kKrWords = 2, kKrLinks = 3, kKrSib = 4, kKrShallow = 5, kKrAnyValid = 6, kKrOverflow = 7, kKrSliceKeys = 8,
-       kKrN0 = 9, kKrUsed = 10, kKrCapacity = 11, kKrDepth = 12 };
-enum { kKrYoung = 1, kKrOverflowed = 2, kKrMismatch = 4 };
+       kKrN0 = 9, kKrUsed = 10, kKrCapacity = 11, kKrDepth = 12, kKrTop = 13 };
+enum { kKrOverflowed = 2, kKrMismatch = 4 };
+constexpr u32 kKrEmpty1 = 127u << 24;  // word1 of a node splitNodes has just created (svo.cu:269-275)
 __host__ __device__ inline size_t kr_bid0(u32 records) { return (size_t)kKrTiles0 + 16 * (size_t)records; }
 __host__ __device__ inline size_t kr_links0(u32 records) { return kr_bid0(records) + (records + 3u) / 4u; }
 __host__ __device__ inline size_t kr_words0(u32 records, u32 links) { return kr_links0(records) + links; }
@@ -2276,7 +2281,7 @@ __global__ __launch_bounds__(256) void keyrange_pack_header_kernel(u32 *__restri
   if (t == 0) {
     const u32 R = (u32)counts->total_records, links = (u32)(counts->pass_start[1] - counts->pass_start[0]);
     delta[kKrMagic] = 0x4B52414Eu;
-    delta[kKrRecords] = R; delta[kKrWords] = 0u; delta[kKrLinks] = links; delta[kKrSib] = 0u; delta[kKrShallow] = 0u;
+    delta[kKrRecords] = R; delta[kKrWords] = 0u; delta[kKrLinks] = links; delta[kKrSib] = 0u; delta[kKrShallow] = 0u; delta[kKrTop] = 0u;
     delta[kKrAnyValid] = (u32)counts->any_valid; delta[kKrSliceKeys] = (u32)win[2]; delta[kKrN0] = *n0_saved; delta[kKrDepth] = (u32)depth;
     delta[kKrCapacity] = capacity_words > 0xFFFFFFFFll ? 0xFFFFFFFFu : (u32)capacity_words;
     const bool fits = (long long)kr_words0(R, links) <= capacity_words;
@@ -2306,6 +2311,13 @@ __global__ __launch_bounds__(256) void keyrange_pack_tiles_kernel(u32 *__restric
       const int d = (63 - __clzll((long long)key)) / 3, pass = rec_pass[r];
       bid[r] = (unsigned char)bucket_id(pass, d);
       if (r < links) delta[kr_links0(R) + r] = rec_front[r];
+      if (d < kKrLevel) {  // a record several ranks may hold: listed by key for the union numbering
+        const u32 pos = atomicAdd(&delta[kKrTop], 1u);
+        if (pos < (u32)kKrTopCap) {
+          u32 *e = delta + kKrTop0 + 4 * pos;
+          e[0] = (u32)key; e[1] = (u32)(key >> 32); e[2] = r; e[3] = bucket_id(pass, d);
+        }
+      }
       if (d < kPoolGridBlockLevel) {
         const u32 pos = atomicAdd(&delta[kKrShallow], 1u);
         if (pos < (u32)kKrShallowCap) reinterpret_cast<u64 *>(delta + kKrHeader + kKrSibCap)[pos] = key;
@@ -2373,22 +2385,54 @@ __global__ __launch_bounds__(256) void keyrange_pack_words_kernel(u32 *__restric
 
 struct KrDeltas { const u32 *d[kKrMaxWorld]; };
 
-// numbering: table[s][b] = what to add to rank s's local record rank in bucket b to get its place in the reference's order; scal[0] =
-// records of all ranks, [1] = status flags, [2] = first new tile, [3] = any valid key
-__global__ __launch_bounds__(256) void keyrange_setup_kernel(KrDeltas D, int world, int *__restrict__ table, u32 *__restrict__ scal) {
+// numbering: table[s][b] = what to add to rank s's local record rank in bucket b (depth >= 3) to get its place in the reference's order;
+// topmap[s] = {count, then (local record, place) pairs} for rank s's records above the splitter level, ranked in the ranks' union; the
+// union's tiles cleared; scal[0] = records of all ranks (shared ones once), [1] = status flags, [2] = first new tile, [3] = any valid key
+constexpr int kKrTopMax = kKrMaxWorld * kKrTopCap;
+__global__ __launch_bounds__(256) void keyrange_setup_kernel(KrDeltas D, int world, int *__restrict__ table, u32 *__restrict__ topmap,
+                                                             u32 *__restrict__ scal, u32 *__restrict__ pool) {
   __shared__ unsigned tmp[4];
+  __shared__ u64 top_key[kKrTopMax];
+  __shared__ unsigned short top_bs[kKrTopMax];   // bucket | rank << 8
+  __shared__ unsigned char top_first[kKrTopMax];
+  __shared__ u32 top_base[kKrMaxWorld + 1], union_cnt[256];
   const int b = (int)threadIdx.x;
   u32 tot = 0, flags = 0, any = 0;
+  union_cnt[b] = 0u;
+  if (b == 0) {
+    u32 run = 0;
+    for (int s = 0; s < world; s++) { top_base[s] = run; const u32 c = D.d[s][kKrTop]; run += c < (u32)kKrTopCap ? c : (u32)kKrTopCap; }
+    top_base[world] = run;
+  }
+  __syncthreads();
+  const int M = (int)top_base[world];
   for (int s = 0; s < world; s++) {
-    tot += D.d[s][256 + b];
-    if (D.d[s][kKrOverflow]) flags |= kKrOverflowed;
+    if (D.d[s][kKrOverflow] || D.d[s][kKrTop] > (u32)kKrTopCap) flags |= kKrOverflowed;
     if (D.d[s][kKrN0] != D.d[0][kKrN0] || D.d[s][kKrMagic] != 0x4B52414Eu) flags |= kKrMismatch;
     any |= D.d[s][kKrAnyValid];
+    const int cnt = (int)(top_base[s + 1] - top_base[s]);
+    for (int i = b; i < cnt; i += 256) {
+      const u32 *e = D.d[s] + kKrTop0 + 4 * i;
+      top_key[top_base[s] + i] = ((u64)e[1] << 32) | e[0];
+      top_bs[top_base[s] + i] = (unsigned short)(e[3] | ((u32)s << 8));
+    }
   }
+  __syncthreads();
+  // the union: an entry is its record's FIRST occurrence when no earlier entry holds the same (bucket, key)
+  for (int e = b; e < M; e += 256) {
+    bool first = true;
+    for (int f = 0; f < e && first; f++) first = !(top_key[f] == top_key[e] && (top_bs[f] & 255u) == (top_bs[e] & 255u));
+    top_first[e] = first ? 1 : 0;
+    if (first) atomicAdd(&union_cnt[top_bs[e] & 255u], 1u);
+  }
+  __syncthreads();
   const int d = (b & 15) + 1;  // bucket_id(p, d) = 16 p + d - 1
-  if (tot && d < kKrLevel) flags |= kKrYoung;
+  if (d < kKrLevel) tot = union_cnt[b];
+  else for (int s = 0; s < world; s++) tot += D.d[s][256 + b];
   unsigned total;
   const u32 gbase = block256_exclusive_scan(tot, tmp, total);
+  __shared__ u32 gbase_s[256];
+  gbase_s[b] = gbase;
   u32 lower = 0;
   for (int s = 0; s < world; s++) {
     const u32 c = D.d[s][256 + b];
@@ -2397,25 +2441,52 @@ __global__ __launch_bounds__(256) void keyrange_setup_kernel(KrDeltas D, int wor
     table[s * 256 + b] = (int)(gbase + lower) - (int)lbase;
     lower += c;
   }
+  __syncthreads();
+  const u32 n0 = D.d[0][kKrN0];
+  for (int e = b; e < M; e += 256) {
+    const u32 bk = top_bs[e] & 255u, s = top_bs[e] >> 8;
+    u32 rank = 0;  // first occurrences of the bucket with a smaller key
+    for (int f = 0; f < M; f++) rank += (top_first[f] && (top_bs[f] & 255u) == bk && top_key[f] < top_key[e]) ? 1u : 0u;
+    const u32 place = gbase_s[bk] + rank;
+    const u32 slot = (u32)e - top_base[s];
+    topmap[s * (1 + 2 * kKrTopCap) + 1 + 2 * slot] = D.d[s][kKrTop0 + 4 * slot + 2];
+    topmap[s * (1 + 2 * kKrTopCap) + 2 + 2 * slot] = place;
+    if (top_first[e] && !flags) {  // the shared tile starts as eight empty children; the ranks then write what they filled
+      uint4 *tile = reinterpret_cast<uint4 *>(pool + 2 * ((size_t)n0 + 8 * (size_t)place));
+      const uint4 init = make_uint4(0u, kKrEmpty1, 0u, kKrEmpty1);
+      tile[0] = init; tile[1] = init; tile[2] = init; tile[3] = init;
+    }
+  }
+  if (b < world) topmap[b * (1 + 2 * kKrTopCap)] = top_base[b + 1] - top_base[b];
   if (flags) atomicOr(&scal[1], flags);
-  if (b == 0) { scal[0] = total; scal[2] = D.d[0][kKrN0]; scal[3] = any; }
+  if (b == 0) { scal[0] = total; scal[2] = n0; scal[3] = any; }
 }
 
 // every delta to its global place (blockIdx.y = the delta's rank): tiles with their links renumbered, the pass-0 links, the colour words
 // of existing nodes, and the record-borne marks (sibling ring, cubes of shallow splits) into this replica's dirty state
-__global__ __launch_bounds__(256) void keyrange_apply_kernel(KrDeltas D, const int *__restrict__ table, const u32 *__restrict__ scal,
-                                                             u32 *__restrict__ pool, u32 *__restrict__ dirty) {
-  if (scal[1]) return;  // young / overflowed / mismatching deltas: nothing is applied (svo_fuse_keyrange_status reports it)
+__global__ __launch_bounds__(256) void keyrange_apply_kernel(KrDeltas D, const int *__restrict__ table, const u32 *__restrict__ topmap,
+                                                             const u32 *__restrict__ scal, u32 *__restrict__ pool, u32 *__restrict__ dirty) {
+  if (scal[1]) return;  // overflowed / mismatching deltas: nothing is applied (svo_fuse_keyrange_status reports it)
   const int s = (int)blockIdx.y;
   const u32 *delta = D.d[s];
   const int *T = table + s * 256;
+  const u32 *tm = topmap + s * (1 + 2 * kKrTopCap);
   const u32 R = delta[kKrRecords], links = delta[kKrLinks], words = delta[kKrWords], n0 = delta[kKrN0];
   const unsigned char *bid = reinterpret_cast<const unsigned char *>(delta + kr_bid0(R));
-  auto place = [&](u32 r) { return (u32)((int)r + T[bid[r]]); };
+  auto shared_record = [&](u32 r) { return (int)(bid[r] & 15u) + 1 < kKrLevel; };
+  auto place = [&](u32 r) {
+    if (shared_record(r)) {  // ranked in the ranks' union (a handful per frame, in the first frames of a map)
+      const u32 cnt = tm[0];
+      for (u32 i = 0; i < cnt; i++) if (tm[1 + 2 * i] == r) return tm[2 + 2 * i];
+      return 0u;
+    }
+    return (u32)((int)r + T[bid[r]]);
+  };
   const size_t stride = (size_t)gridDim.x * 256u, t0 = (size_t)blockIdx.x * 256u + threadIdx.x;
   for (size_t i = t0; i < 8 * (size_t)R; i += stride) {
     const u32 r = (u32)(i >> 3), q = (u32)(i & 7u);
     uint2 w = reinterpret_cast<const uint2 *>(delta + kKrTiles0)[i];
+    if (shared_record(r) && w.x == 0u && w.y == kKrEmpty1) continue;  // a node of a shared tile this rank did not fill
     if (w.x & kFlag) w.x = kFlag | ((n0 + 8u * place(((w.x & kMask) - n0) >> 3)) & kMask);
     reinterpret_cast<uint2 *>(pool)[(size_t)n0 + 8 * (size_t)place(r) + q] = w;
   }
@@ -2503,8 +2574,8 @@ __global__ __launch_bounds__(256) void keyrange_finish_kernel(u32 *__restrict__ 
 static int kr_scratch(svoslam_workspace *ws, int n) {  // slice arrays + window / table / scalars (zeroed once)
   SVO_TRY(ws->kr_keys.reserve((size_t)n * 8));
   SVO_TRY(ws->kr_idx.reserve((size_t)n * 4));
-  if (ws->kr_small.bytes < 32768) {
-    SVO_TRY(ws->kr_small.reserve(32768));
+  if (ws->kr_small.bytes < 65536) {
+    SVO_TRY(ws->kr_small.reserve(65536));
     SVO_HIP(memset_sync(ws->kr_small.ptr, 0, ws->kr_small.bytes));
   }
   return SVOSLAM_OK;
@@ -2513,6 +2584,7 @@ static inline int *kr_win(svoslam_workspace *ws) { return ws->kr_small.as<int>()
 static inline u32 *kr_scal(svoslam_workspace *ws) { return ws->kr_small.as<u32>() + 64; }                 // setup scalars
 static inline unsigned long long *kr_top(svoslam_workspace *ws) { return reinterpret_cast<unsigned long long *>(ws->kr_small.as<u32>() + 96); }
 static inline int *kr_table(svoslam_workspace *ws) { return ws->kr_small.as<int>() + 128; }               // [world][256]
+static inline u32 *kr_topmap(svoslam_workspace *ws) { return ws->kr_small.as<u32>() + 128 + kKrMaxWorld * 256; }  // [world][1 + 2 x kKrTopCap]
 
 int svo_fuse_keyrange_commit(svoslam_workspace *ws, const unsigned long long *d_keys, const uint32_t *d_idx, const uint8_t *d_colors, int n,
                              int depth, svoslam_pool *pool, int rank, int world, uint32_t *d_delta, long long delta_bytes, hipStream_t stream) {
@@ -2568,8 +2640,8 @@ int svo_fuse_keyrange_apply(svoslam_workspace *ws, const unsigned long long *d_k
   int blocks = (int)cdiv(8 * rmax / (world > 1 ? world : 1) + 1, 256);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 64) blocks = 64;
-  keyrange_setup_kernel<<<1, 256, 0, stream>>>(D, world, kr_table(ws), kr_scal(ws));
-  keyrange_apply_kernel<<<dim3((unsigned)blocks, (unsigned)world), 256, 0, stream>>>(D, kr_table(ws), kr_scal(ws), pool->d_data, dirty);
+  keyrange_setup_kernel<<<1, 256, 0, stream>>>(D, world, kr_table(ws), kr_topmap(ws), kr_scal(ws), pool->d_data);
+  keyrange_apply_kernel<<<dim3((unsigned)blocks, (unsigned)world), 256, 0, stream>>>(D, kr_table(ws), kr_topmap(ws), kr_scal(ws), pool->d_data, dirty);
   keyrange_mark_kernel<<<cdiv(n, 256), 256, 0, stream>>>(d_keys, n, depth, dirty, brick_shift, kr_top(ws));
   SVO_TRY(tracker_make_room(pool));
   keyrange_finish_kernel<<<1, 256, 0, stream>>>(pool->d_data, kr_scal(ws), kr_top(ws), pool->d_size, trk ? trk->h_size : nullptr,
@@ -2590,8 +2662,8 @@ int svo_fuse_keyrange_discard(svoslam_workspace *ws, svoslam_pool *pool) {
 }
 
 // flags of the svo_fuse_keyrange_apply calls on this workspace since the last call of this function (blocking; the flags are sticky on
-// the device and cleared here): 0 = every frame applied; kKrYoung / kKrOverflowed / kKrMismatch = a frame was NOT applied (the replica
-// is then behind the others unless the caller committed that frame in one piece instead, as pipeline._run_keyrange does)
+// the device and cleared here): 0 = every frame applied; kKrOverflowed / kKrMismatch = a frame was NOT applied (the replica
+// is then behind the others)
 int svo_fuse_keyrange_status(svoslam_workspace *ws, int *flags, hipStream_t stream) {
   if (!ws || !flags || ws->kr_small.bytes == 0) return SVOSLAM_ERR_INVALID_ARG;
   u32 f = 0;

@@ -231,7 +231,7 @@ class EmulatedRank:
 
     def __init__(self, rank, world, exchange="deltas"):
         self.rank, self.world, self.exchange = rank, world, exchange
-        self.kr_deltas, self.kr_young = None, None
+        self.kr_deltas = None
         self.table, self.first, self.per_rank, self.calls = None, 0, 1, 0
         self.sorted, self.sorted_calls = (None, None), [0, 0]
 
@@ -247,10 +247,10 @@ class EmulatedRank:
         self.sorted = (sorted_keys, sorted_idx)
         self.sorted_calls = [0, 0]
 
-    def expect_keyrange(self, deltas, young):
-        """deltas[g][s]: rank s's delta of global frame g (None at this rank's place), young[g]: frame g splits above the splitter level
-        (pipeline.keyrange_delta_table); set once for the whole stream"""
-        self.kr_deltas, self.kr_young = deltas, young
+    def expect_keyrange(self, deltas):
+        """deltas[g][s]: rank s's delta of global frame g (None at this rank's place); deltas[g] = None: no table for frame g -- it is
+        committed in one piece (the untimed history of a bench run).  pipeline.keyrange_delta_table; set once for the whole stream"""
+        self.kr_deltas = deltas
 
     def all_gather_keyrange(self, frame, mine):
         row = self.kr_deltas[frame]
@@ -744,33 +744,32 @@ class SlamPipeline:
              delta packed -- then the all-gather of the ranks' deltas; frame k+1's may run beside the march of frame k;
           M  pose of the frame (the 80-byte record), keyrange_apply -- every rank's delta into this replica --, and the ray march of
              the frames this rank owns.
-        Driven from Python (five calls per frame): the collective sits between the two halves of every frame.  A frame that splits
-        above the splitter level is refused by the apply: an emulated rank knows such frames from its table and commits them
-        replicated; a real rank reads the 4-byte status after every apply (one host round trip per frame)."""
+        Driven from Python (five calls per frame): the collective sits between the two halves of every frame.  An emulated rank commits
+        the frames its table does not cover in one piece."""
         world, rank = self.dist.world, self.dist.rank
         npix = self.w * self.h
         if not hasattr(self, "_kr"):
-            cap_words = 10752 + 16 * npix          # 64 bytes per pixel of a whole frame: ample for any slice
+            cap_words = pkg.KEYRANGE_FIXED_WORDS + 16 * npix          # 64 bytes per pixel of a whole frame: ample for any slice
             self._kr = {"sc": torch.cuda.Stream(), "sm": torch.cuda.Stream(), "ws": [pkg.Workspace(), pkg.Workspace()],
-                        "buf": [torch.zeros(cap_words, dtype=torch.int32, device="cuda") for _ in range(2)], "young": 0, "frames": 0,
+                        "buf": [torch.zeros(cap_words, dtype=torch.int32, device="cuda") for _ in range(2)], "whole": 0, "frames": 0,
                         "used_bytes": []}
         kr = self._kr
         sc, sm = kr["sc"], kr["sm"]
         cur = torch.cuda.current_stream()
         sc.wait_stream(cur); sm.wait_stream(cur)
-        known_young = getattr(self.dist, "kr_young", None)
+        table = getattr(self.dist, "kr_deltas", None)
         ev_apply = None
         for i in range(n):
             k = i & 1
             ws, buf = kr["ws"][k], kr["buf"][k]
             colors = rgbs[i].view(-1, 3)
-            young = bool(known_young[g0 + i]) if known_young is not None else False
+            whole = table is not None and table[g0 + i] is None       # (an emulated rank without the other ranks' deltas for this frame)
             with torch.cuda.stream(sc):
                 if sevents[i] is not None:
                     sc.wait_event(sevents[i])          # the chunk's sorted arrays (in-order stream: once per chunk)
                 if ev_apply is not None:
                     sc.wait_event(ev_apply)            # the plan reads the structure apply k-1 left
-                if not young:
+                if not whole:
                     pkg.svo_fuse_keyrange_commit(ws, skeys[i], sidx[i], colors, self.depth, self.pool, rank, world, buf)
                     gathered = self.dist.all_gather_keyrange(g0 + i, buf)
                 evc = torch.cuda.Event(); evc.record()
@@ -779,12 +778,10 @@ class SlamPipeline:
                 if events[i] is not None:
                     sm.wait_event(events[i])           # the chunk's pose records
                 self.cam.apply_delta(deltas[i], timestamps[i])
-                if not young:
+                if not whole:
                     pkg.svo_fuse_keyrange_apply(ws, skeys[i], self.depth, self.pool, gathered)
-                    if known_young is None and self.dist.enabled:
-                        young = pkg.svo_fuse_keyrange_status(ws) != 0      # (blocking: every rank reads the same verdict)
-                if young:                              # the whole frame on every rank, as in the "deltas" scheme
-                    kr["young"] += 1
+                else:
+                    kr["whole"] += 1
                     pkg.svo_fuse_adopt_sorted(ws, skeys[i], sidx[i], self.depth)
                     pkg.svo_fuse_plan(ws, npix, self.depth, self.pool)
                     pkg.svo_fuse_commit(ws, colors, self.depth, self.pool)
@@ -795,13 +792,13 @@ class SlamPipeline:
         cur.wait_stream(sc); cur.wait_stream(sm)
 
     def keyrange_check(self):
-        """after a key-range run (blocking): raises if an apply was refused that nobody expected (an emulated rank's table says which
-        frames are young; a refused frame leaves the replica behind the others)"""
+        """after a key-range run (blocking): raises if an apply was refused (a delta overflowed its buffer, or deltas of different frames
+        met: the replica is then behind the others)"""
         if hasattr(self, "_kr"):
             for w in self._kr["ws"]:
                 f = pkg.svo_fuse_keyrange_status(w) if w is not None else 0
                 if f:
-                    raise RuntimeError("key-range apply refused a frame: flags %d (1 young, 2 overflow, 4 mismatch)" % f)
+                    raise RuntimeError("key-range apply refused a frame: flags %d (2 overflow, 4 mismatch)" % f)
 
     def _backproject_with(self, depth, fusion_ptr):
         if not self.band_exchange:
@@ -818,36 +815,35 @@ def keyrange_delta_table(keys_tab, idx_tab, rgb, first, rank, world, max_depth, 
     """What the OTHER ranks of a key-range session deliver, for an emulated rank (bench.py --exchange keyrange --emulate-rank R/N): a truth
     pool fuses the stream frame by frame in one piece (keys_tab[k] / idx_tab[k]: the frame's sorted keys and point indices, rgb[k] its
     colours); before frame k >= first is fused, every rank s != rank plans and commits ITS slice on that pool and its delta is kept
-    (svoslam_svo_fuse_keyrange_commit + _discard: the pool is not touched).  Returns (deltas, young, bytes): deltas[k][s] (used words only;
-    None for k < first and at s == rank), young[k] = the frame splits above the splitter level (every rank would be refused: such frames
-    are committed replicated), bytes[k] = [used bytes of every rank's delta] -- what one all-gather of frame k moves (the emulated rank's
-    own share measured with the same call)."""
+    (svoslam_svo_fuse_keyrange_commit + _discard: the pool is not touched).  Returns (deltas, shared, bytes): deltas[k][s] (used words only;
+    deltas[k] = None for k < first, None at s == rank), shared[k] = records above the splitter level in frame k (planned by several ranks,
+    ranked in their union: the first frames of a map), bytes[k] = [used bytes of every rank's delta] -- what one all-gather of frame k
+    moves (the emulated rank's own share measured with the same call)."""
     total, npix = keys_tab.shape[0], keys_tab.shape[1]
     truth = pkg.Pool(pool_capacity_nodes)
     ws_t, ws_s = pkg.Workspace(), pkg.Workspace()
-    buf = torch.zeros(10752 + 16 * npix, dtype=torch.int32, device="cuda")
-    deltas, young, nbytes = [None] * total, [False] * total, [None] * total
+    buf = torch.zeros(pkg.KEYRANGE_FIXED_WORDS + 16 * npix, dtype=torch.int32, device="cuda")
+    deltas, shared, nbytes = [None] * total, [0] * total, [None] * total
     for k in range(total):
         colors = rgb[k].view(-1, 3)
         if k >= first:
-            row, used, refused = [None] * world, [0] * world, False
+            row, used, top = [None] * world, [0] * world, 0
             for s_ in range(world):
                 pkg.svo_fuse_keyrange_commit(ws_s, keys_tab[k], idx_tab[k], colors, max_depth, truth, s_, world, buf)
                 pkg.svo_fuse_keyrange_discard(ws_s, truth)
                 head = buf[:512].cpu().numpy().view(np.uint32)
                 used[s_] = int(head[pkg.KEYRANGE_USED_WORD]) * 4
                 assert head[7] == 0, "a delta overflowed its buffer"
-                # a record above the splitter level in ANY rank's buckets (bucket b = 16 x pass + depth - 1 at word 256 + b; level 3)
-                refused = refused or bool(head[256:512].reshape(16, 16)[:, :2].any())
+                top = max(top, int(head[13]))            # records above the splitter level in this rank's slice
                 if s_ != rank:
                     row[s_] = buf[: used[s_] // 4].clone()
-            deltas[k], young[k], nbytes[k] = row, refused, used
+            deltas[k], shared[k], nbytes[k] = row, top, used
         pkg.svo_fuse_adopt_sorted(ws_t, keys_tab[k], idx_tab[k], max_depth)
         pkg.svo_fuse_plan(ws_t, npix, max_depth, truth)
         pkg.svo_fuse_commit(ws_t, colors, max_depth, truth)
     torch.cuda.synchronize()
     ws_t.close(); ws_s.close(); truth.close()
-    return deltas, young, nbytes
+    return deltas, shared, nbytes
 
 
 def ground_truth_view(frame, synth):

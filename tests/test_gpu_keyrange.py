@@ -39,11 +39,11 @@ def test_keyrange_replicas_equal_the_one_piece_fusion(env, oracle, world, depth)
     reps = [pkg.Pool(1 << 22) for _ in range(world)]
     ws_sort, ws_ref = pkg.Workspace(), pkg.Workspace()
     wss = [pkg.Workspace() for _ in range(world)]
-    cap_words = 10752 + 48 * n
+    cap_words = pkg.KEYRANGE_FIXED_WORDS + 48 * n
     deltas = [torch.zeros(cap_words, dtype=torch.int32, device="cuda") for _ in range(world)]
     keys = torch.empty(n, dtype=torch.int64, device="cuda"); idx = torch.empty(n, dtype=torch.int32, device="cuda")
     base, bcol = surface_cloud(rng, n)
-    sharded_frames, young_frames, used = 0, 0, []
+    sharded_frames, shared_records, used = 0, [], []
     for f in range(7):
         if f == 0:
             pts, col = base, bcol
@@ -64,38 +64,28 @@ def test_keyrange_replicas_equal_the_one_piece_fusion(env, oracle, world, depth)
 
         replicated(ref, ws_ref)
         opool.insert_cloud(pts, col, depth, center, edge)
-        if f == 0:      # the first frame of a map is young by definition: replicated on every rank
-            for r in range(world):
-                replicated(reps[r], wss[r])
-        else:
-            for r in range(world):
-                pkg.svo_fuse_keyrange_commit(wss[r], keys, idx, tc, depth, reps[r], r, world, deltas[r])
-            flags = set()
-            for r in range(world):
-                pkg.svo_fuse_keyrange_apply(wss[r], keys, depth, reps[r], deltas)
-                flags.add(pkg.svo_fuse_keyrange_status(wss[r]))
-            assert len(flags) == 1, flags                      # every rank comes to the same verdict
-            fl = flags.pop()
-            assert fl in (0, pkg.KEYRANGE_YOUNG), fl
-            if fl:                                             # a split above the splitter level: nothing was applied; replicated instead
-                young_frames += 1
-                for r in range(world):
-                    replicated(reps[r], wss[r])
-            else:
-                sharded_frames += 1
-                used.append([int(d[pkg.KEYRANGE_USED_WORD].item()) * 4 for d in deltas])
+        # every frame cut by key range -- the first one into EMPTY replicas: all its splits start above the splitter level, every rank plans
+        # the same top records and the apply ranks them in the ranks' union
+        for r in range(world):
+            pkg.svo_fuse_keyrange_commit(wss[r], keys, idx, tc, depth, reps[r], r, world, deltas[r])
+        for r in range(world):
+            pkg.svo_fuse_keyrange_apply(wss[r], keys, depth, reps[r], deltas)
+            assert pkg.svo_fuse_keyrange_status(wss[r]) == 0
+        sharded_frames += 1
+        shared_records.append(max(int(d[13].item()) for d in deltas))
+        used.append([int(d[pkg.KEYRANGE_USED_WORD].item()) * 4 for d in deltas])
         want = ref.words()
         assert np.array_equal(want, opool.words())
         for r in range(world):
             assert reps[r].size == ref.size, (f, r, reps[r].size, ref.size)
             got = reps[r].words()
-            assert np.array_equal(got, want), (f, r, np.nonzero(got != want)[0][:10], sharded_frames)
+            assert np.array_equal(got, want), (f, r, np.nonzero(got != want)[0][:10], shared_records)
         for eye, tgt, (w, h) in VIEWS[: 3 if f % 2 == 0 else 1]:
             view = oracle.look_at(eye, tgt, (0, 1, 0))
             a, ca = render(pkg, torch, ref, view, w, h, center, edge)
             b, cb = render(pkg, torch, reps[0], view, w, h, center, edge)
             assert np.array_equal(a, b) and ca == cb, (f, eye, describe_mismatch(b, a), ca, cb)
-    assert sharded_frames >= 4, (sharded_frames, young_frames)
+    assert sharded_frames == 7 and shared_records[0] > 0, shared_records     # (the first frame had records above the splitter level)
     for eye, tgt, (w, h) in VIEWS:   # the last replica has rendered nothing so far: six frames of marks at once
         view = oracle.look_at(eye, tgt, (0, 1, 0))
         a, ca = render(pkg, torch, ref, view, w, h, center, edge)
@@ -106,50 +96,52 @@ def test_keyrange_replicas_equal_the_one_piece_fusion(env, oracle, world, depth)
             o, steps, levels = oracle.cone_trace(words, w, h, 45.0, view, center, edge, 0)
             assert np.array_equal(a, o) and ca == [steps, levels]
     total = np.array(used).sum(1)
-    print("world %d depth %d: %d key-range frames (%d young), delta bytes per frame all ranks: %s; per rank of the last frame: %s"
-          % (world, depth, sharded_frames, young_frames, total.tolist(), used[-1]))
+    print("world %d depth %d: %d key-range frames, records above the splitter level per frame (max over ranks) %s, delta bytes per frame all ranks: %s; per rank of the last frame: %s"
+          % (world, depth, sharded_frames, shared_records, total.tolist(), used[-1]))
     assert total.max() < 64 * depth * n   # 8 bytes per touched node + 64 per new tile (these jittered clouds give nearly every key its own chain of new tiles) + 43 KB fixed per rank
 
 
-def test_keyrange_young_frame_is_refused(env, oracle):
-    """a frame that splits nodes above the splitter level (here: the second frame lies in octants the first never touched) is not applied:
-    every replica stays as it was and reports KEYRANGE_YOUNG"""
+@pytest.mark.parametrize("world", [2, 5, 16])
+def test_keyrange_new_territory_above_the_splitter_level(env, oracle, world):
+    """frames that split nodes ABOVE the splitter level -- an empty pool, then points in octants the map has never touched, then a cloud
+    spread over the whole root -- are planned in part by several ranks at once (the same records, the same tiles); the union numbering
+    puts them where the one-piece fusion does"""
     pkg, torch = env
     rng = np.random.default_rng(5)
-    center, edge, depth, n, world = (0.0, 0.0, 0.0), 1.0, 10, 4000, 2
+    center, edge, depth, n = (0.0, 0.0, 0.0), 1.0, 10, 4000
     reps, wss, ws_sort = [pkg.Pool(1 << 20) for _ in range(world)], [pkg.Workspace() for _ in range(world)], pkg.Workspace()
-    pts = (rng.random((n, 3), dtype=np.float32) * np.float32(0.2) + np.float32(0.1)).astype(np.float32)      # one corner of one octant
-    col = rng.integers(0, 256, (n, 3), dtype=np.uint8)
-    for r in range(world):
-        pkg.svo_from_point_cloud_async(wss[r], torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda(), depth, reps[r], center, edge)
-    before = reps[0].words().copy()
-    pts2 = (-pts).astype(np.float32)                                                                      # the opposite octant
-    tp, tc = torch.from_numpy(pts2).cuda(), torch.from_numpy(col).cuda()
-    keys = torch.empty(n, dtype=torch.int64, device="cuda"); idx = torch.empty(n, dtype=torch.int32, device="cuda")
-    pkg.svo_fuse_sort(ws_sort, tp, depth, center, edge)
-    pkg.svo_fuse_export_sorted(ws_sort, n, keys, idx)
-    deltas = [torch.zeros(10752 + 48 * n, dtype=torch.int32, device="cuda") for _ in range(world)]
-    for r in range(world):
-        pkg.svo_fuse_keyrange_commit(wss[r], keys, idx, tc, depth, reps[r], r, world, deltas[r])
-    for r in range(world):
-        pkg.svo_fuse_keyrange_apply(wss[r], keys, depth, reps[r], deltas)
-        assert pkg.svo_fuse_keyrange_status(wss[r]) == pkg.KEYRANGE_YOUNG
-        assert np.array_equal(reps[r].words(), before)
-    # ... and the replicated commit of the same frame still works on the untouched replicas
     opool = oracle.Pool()
-    opool.insert_cloud(pts, col, depth, center, edge); opool.insert_cloud(pts2, col, depth, center, edge)
-    for r in range(world):
-        pkg.svo_fuse_adopt_sorted(wss[r], keys, idx, depth)
-        pkg.svo_fuse_plan(wss[r], n, depth, reps[r])
-        pkg.svo_fuse_commit(wss[r], tc, depth, reps[r])
-        assert np.array_equal(reps[r].words(), opool.words())
+    corner = (rng.random((n, 3), dtype=np.float32) * np.float32(0.2) + np.float32(0.1)).astype(np.float32)      # one corner of one octant
+    spread = (rng.random((n, 3), dtype=np.float32) * np.float32(1.9) - np.float32(0.95)).astype(np.float32)     # every octant of the root
+    keys = torch.empty(n, dtype=torch.int64, device="cuda"); idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    deltas = [torch.zeros(pkg.KEYRANGE_FIXED_WORDS + 48 * n, dtype=torch.int32, device="cuda") for _ in range(world)]
+    tops = []
+    for f, pts in enumerate((corner, (-corner).astype(np.float32), spread, (spread * np.float32(0.5)).astype(np.float32))):
+        col = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+        tp, tc = torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda()
+        pkg.svo_fuse_sort(ws_sort, tp, depth, center, edge)
+        pkg.svo_fuse_export_sorted(ws_sort, n, keys, idx)
+        for r in range(world):
+            pkg.svo_fuse_keyrange_commit(wss[r], keys, idx, tc, depth, reps[r], r, world, deltas[r])
+        tops.append(sorted(int(d[13].item()) for d in deltas))
+        for r in range(world):
+            pkg.svo_fuse_keyrange_apply(wss[r], keys, depth, reps[r], deltas)
+            assert pkg.svo_fuse_keyrange_status(wss[r]) == 0
+        opool.insert_cloud(pts, col, depth, center, edge)
+        want = opool.words()
+        for r in range(world):
+            assert reps[r].size == opool.size, (f, r, reps[r].size, opool.size)
+            got = reps[r].words()
+            assert np.array_equal(got, want), (f, r, np.nonzero(got != want)[0][:10])
+    print("world %d: records above the splitter level per rank and frame: %s" % (world, tops))
+    assert tops[0][-1] > 0 and tops[1][-1] > 0 and tops[2][-1] >= 8      # every one of these frames exercised the union
 
 
 @pytest.mark.parametrize("world,per_rank,w,h,depth", [(2, 2, 320, 240, 10), (4, 1, 320, 240, 10), (8, 1, 160, 120, 9)])
 def test_keyrange_session_equals_single_gpu_session(world, per_rank, w, h, depth):
     """every rank of a frame-sharded session whose FUSION is cut by key range (pipeline "keyrange" exchange; an emulated rank takes the
     other ranks' pose records, sorted arrays and deltas from tables): poses and map replica equal the one-GPU session's after every call,
-    the frames it ray-marches equal the one-GPU images.  The first frames of the map are young and go through the replicated commit."""
+    the frames it ray-marches equal the one-GPU images.  Every frame, the first of the map included, is cut by key range."""
     import importlib
     import torch
     import svoslam_pkg
@@ -158,7 +150,7 @@ def test_keyrange_session_equals_single_gpu_session(world, per_rank, w, h, depth
     pl = importlib.import_module("octree_slam_amd.pipeline")
     from test_gpu_sharded import _cam_state, _stream
     center, edge = (0.0, 1.5, 0.0), 4.096
-    n1, n2, first = 7, 6, 2
+    n1, n2, first = 7, 6, 0
     n = n1 + n2
     dstack, cstack = _stream(synth, torch, n, w, h)
     views = [pl.ground_truth_view(k, synth) for k in range(n)]
@@ -181,14 +173,11 @@ def test_keyrange_session_equals_single_gpu_session(world, per_rank, w, h, depth
         pkg.svo_fuse_sort_frame(sws, dstack[k], scam.fusion_transform_ptr(), f, f, depth, center, edge)
         pkg.svo_fuse_export_sorted(sws, w * h, tab_k[k], tab_i[k])
     torch.cuda.synchronize()
-    sharded = 0
     for rank in range(world):
-        deltas, young, nbytes = pl.keyrange_delta_table(tab_k, tab_i, cstack, first, rank, world, depth, 1 << 22)
-        for k in range(first):
-            young[k] = True
+        deltas, shared, nbytes = pl.keyrange_delta_table(tab_k, tab_i, cstack, first, rank, world, depth, 1 << 22)
         B = pl.SlamPipeline(w, h, depth, center, edge, dist=pl.EmulatedRank(rank, world, exchange="keyrange"), pool_capacity_nodes=1 << 22)
         assert B.keyrange and B.shard_sort
-        B.dist.expect_keyrange(deltas, young)
+        B.dist.expect_keyrange(deltas)
         for part, (lo, hi) in enumerate(((0, n1), (n1, n))):
             B.dist.expect(table[lo:hi], lo, per_rank, tab_k[lo:hi], tab_i[lo:hi])
             imgs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(lo, hi)]
@@ -202,9 +191,9 @@ def test_keyrange_session_equals_single_gpu_session(world, per_rank, w, h, depth
             for k in range(lo, hi):
                 if k % world == rank:
                     assert np.array_equal(imgs[k - lo].cpu().numpy(), ref_img[k]), (rank, k, describe_mismatch(imgs[k - lo].cpu().numpy(), ref_img[k]))
-        sharded = sum(1 for k in range(n) if not young[k])
+        assert B._kr["frames"] == n and B._kr["whole"] == 0
         if rank == 0:
-            print("world %d %dx%d: %d of %d frames cut by key range; delta bytes of all ranks per such frame: %s"
-                  % (world, w, h, sharded, n, [sum(b) for k, b in enumerate(nbytes) if b is not None and not young[k]]))
+            print("world %d %dx%d: %d frames cut by key range, records above the splitter level per frame %s; delta bytes of all ranks per frame: %s"
+                  % (world, w, h, n, shared, [sum(b) for b in nbytes]))
         B.close()
-    assert sharded >= 6
+    assert shared[0] > 0

@@ -208,7 +208,7 @@ def _two_process_worker(rank, world, port, out_dir, n, w, h, depth, exchange="de
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), words=P.pool.words(), size=P.pool.size, pos=p, ori=o,
              lost=P.cam.tracking_lost_count(), images=np.stack([i.cpu().numpy() for i in imgs]),
              mailbox=np.array([mb is not None, bool(mb.failed()) if mb is not None else False]),
-             keyrange=np.array([kr["frames"], kr["young"]] if kr else [0, 0]))
+             keyrange=np.array([kr["frames"], kr["whole"]] if kr else [0, 0]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -217,8 +217,7 @@ def _two_process_worker(rank, world, port, out_dir, n, w, h, depth, exchange="de
 def test_two_process_sharded_session_on_one_gpu(env, tmp_path, exchange):
     """two processes, one process group, frames tracked and marched alternately: each rank's replica and poses equal the
     one-GPU session's, rank r holds the images of the frames k % 2 == r.  exchange "keyrange": the fusion is cut by key range as well --
-    a REAL all-gather of the two ranks' deltas per frame, and the 4-byte status after every apply sends the young first frames of the
-    map through the replicated commit on both ranks."""
+    a REAL all-gather of the two ranks' deltas per frame, from the first frame of the map on."""
     pkg, torch, synth, pl = env
     import socket
     import torch.multiprocessing as mp
@@ -242,7 +241,7 @@ def test_two_process_sharded_session_on_one_gpu(env, tmp_path, exchange):
             else:
                 assert int(z["images"][k].max()) == 0
         if exchange == "keyrange":
-            assert int(z["keyrange"][0]) == n and 0 < int(z["keyrange"][1]) < n, z["keyrange"]   # some frames young (replicated), the rest cut by key range
+            assert int(z["keyrange"][0]) == n and int(z["keyrange"][1]) == 0, z["keyrange"]   # every frame cut by key range
 
 
 def test_bench_multi_rank_code_path_on_one_gpu(env):
