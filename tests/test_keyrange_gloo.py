@@ -1,6 +1,7 @@
 """Key-range sharded fusion, CPU-proven: world-2 / world-3 gloo test of the PROTOCOL by which
 a frame's plan + commit can be cut across ranks by key range instead of being replicated on every rank -- with the CPU oracle as the
-per-rank worker (the HIP side does not exist yet: this pins what it must compute and exchange).
+per-rank worker (this pins what the ranks must compute and exchange; the HIP side -- csrc/svo_build.hip "key-range sharded commit", with ONE
+all-gather per frame: the numbering comes from the bucket sizes inside the deltas -- is checked by tests/test_gpu_keyrange.py).
 
 Protocol (every rank holds a byte-identical replica of the pool and the frame's keys):
  1. splitters: the distinct level-L prefixes of the frame's keys, cut into `world` contiguous runs of about equal key count; rank r owns
